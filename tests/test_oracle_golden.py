@@ -1,0 +1,269 @@
+"""Pin the CPU oracle against vectors captured from the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import scipy.interpolate
+
+from oracle import rvs_oracle as orc
+from conftest import gold_specdata
+
+TAGS = ['c0', 'c1', 'c2', 'c3']
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+@pytest.mark.parametrize('kind', ['log', 'lin'])
+def test_spline_vs_reference_golden(cases, kind):
+    g = lambda k: cases['spline/%s/%s' % (kind, k)]
+    S = orc.Spline(g('xs'), g('ys'), log_step=(kind == 'log'))
+    for k in 'ABCDh':
+        np.testing.assert_allclose(getattr(S, k), g(k), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(S(g('evalx')), g('ret'), rtol=1e-12, atol=1e-13)
+
+
+def test_spline_vs_reference_c_source():
+    ref = orc.load_reference_spliner()
+    if ref is None:
+        pytest.skip('oracle/_ref not built (reference absent)')
+    rng = np.random.RandomState(5)
+    xs = np.exp(np.linspace(np.log(3500.), np.log(5900.), 6215))
+    ys = 1 + 0.3 * rng.standard_normal(len(xs))
+    ex = np.sort(rng.uniform(3600, 5800, size=2751))
+    a, b = orc.Spline(xs, ys), orc.Spline(xs, ys, lib=ref)
+    for k in 'ABCDh':
+        np.testing.assert_allclose(getattr(a, k), getattr(b, k), rtol=1e-11,
+                                   atol=1e-12)
+    np.testing.assert_allclose(a(ex), b(ex), rtol=1e-12, atol=1e-13)
+
+
+def test_spline_vs_scipy_natural():
+    # the reference's own pin: tests/test_spline.py:6-21
+    rng = np.random.RandomState(1)
+    x = np.linspace(1000, 2000, 1000)
+    y = 0.00001 * x**2 + rng.normal(size=len(x))
+    xn = rng.uniform(1000, 2000, size=10000)
+    xn = np.sort(xn[xn < 1999.9999])
+    yref = scipy.interpolate.CubicSpline(x, y, bc_type='natural')(xn)
+    assert np.allclose(yref, orc.Spline(x, y, log_step=False)(xn))
+    x = 10**np.linspace(3, 4, 1000)
+    y = np.sin(x / 10) + rng.normal(size=len(x))
+    xn = np.sort(rng.uniform(1000, 2000, size=10000))
+    yref = scipy.interpolate.CubicSpline(x, y, bc_type='natural')(xn)
+    assert np.allclose(yref, orc.Spline(x, y, log_step=True)(xn))
+
+
+def test_spline_error_codes():
+    xs = np.exp(np.linspace(1, 2, 50))
+    S = orc.Spline(xs, np.ones(50))
+    with pytest.raises(AssertionError):
+        S(np.array([xs[0] * 0.9, xs[3]]))
+    with pytest.raises(AssertionError):
+        S(np.array([xs[3], xs[-1]]))
+    xs2 = xs.copy()
+    xs2[2] *= 1.001
+    with pytest.raises(AssertionError):
+        orc.Spline(xs2, np.ones(50))(np.array([xs[5]]))
+
+
+@pytest.mark.parametrize('name', ['gold_b', 'gold_r'])
+def test_polylinear_and_outside(cases, gold_libs, name):
+    lib = gold_libs[name]
+    P = cases['interp/params']
+    for i, p in enumerate(P):
+        spec, info = lib.eval(p, details=True)
+        np.testing.assert_allclose(spec, cases['interp/%s/eval' % name][i],
+                                   rtol=2e-7)  # float32 dats, order of sums
+        o = lib.outside_flag(p)
+        oref = cases['interp/%s/outside' % name][i]
+        if np.isfinite(oref):
+            assert abs(o - oref) <= 1e-12 * max(1, abs(oref))
+        else:
+            assert not np.isfinite(o)
+        if info['nearest'] >= 0:
+            assert info['nearest'] == cases['interp/%s/nearest' % name][i]
+
+
+def test_vsini_kernel_and_convolution(cases, gold_libs):
+    for i, R in enumerate(cases['vsini/R']):
+        np.testing.assert_allclose(orc.compute_vsini_kernel(R),
+                                   cases['vsini/kernel_%d' % i], rtol=1e-10,
+                                   atol=1e-13)
+    lib = gold_libs['gold_b']
+    for i, v in enumerate(cases['vsini/vsinis']):
+        np.testing.assert_allclose(
+            orc.convolve_vsini(lib.lam, cases['vsini/templ'], v),
+            cases['vsini/conv_%d' % i], rtol=1e-12)
+
+
+def test_cur_templ(cases, gold_libs):
+    P = cases['interp/params']
+    rots = [None, (10., ), (300., )]
+    for name, lib in gold_libs.items():
+        for ip in (0, 3, 4):
+            for ir, rot in enumerate(rots):
+                o, sp = orc.get_cur_templ(lib, P[ip], rot)
+                k = 'curtempl/%s/p%d_r%d/' % (name, ip, ir)
+                np.testing.assert_allclose(sp, cases[k + 'spec'], rtol=3e-7)
+                assert abs(o - cases[k + 'outside']) < 1e-12
+
+
+def test_bases(cases):
+    lam = cases['basis/lam']
+    for key, n, rbf in (('rbf10', 10, True), ('rbf15', 15, True),
+                        ('rbf2', 2, True), ('cheb7', 7, False)):
+        np.testing.assert_allclose(orc.get_poly_basis(lam, n, rbf),
+                                   cases['basis/' + key], rtol=1e-13,
+                                   atol=1e-15)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+@pytest.mark.parametrize('use_c', [False, True])
+def test_get_chisq(cases, gold_libs, gold_config, tag, use_c):
+    sds = gold_specdata(cases, tag, orc.SpecData)
+    for i in range(7):
+        k = '%s/chisq/t%d/' % (tag, i)
+        vs = float(cases[k + 'vsini'])
+        rot = None if np.isnan(vs) else (vs, )
+        opt = dict(npoly=int(cases[k + 'npoly']),
+                   rbf_continuum=bool(cases[k + 'rbf']))
+        val = orc.get_chisq(sds, float(cases[k + 'vel']), cases[k + 'param'],
+                            rot, options=opt, config=gold_config,
+                            libs=gold_libs, use_c=use_c)
+        ref = float(cases[k + 'value'])
+        assert abs(val - ref) <= 1e-7 * abs(ref), (i, val, ref)
+        if i < 3:
+            full = orc.get_chisq(sds, float(cases[k + 'vel']),
+                                 cases[k + 'param'], rot, options=opt,
+                                 config=gold_config, libs=gold_libs,
+                                 full_output=True, use_c=use_c)
+            assert abs(full['chisq'] - cases[k + 'full_chisq']) <= 1e-7 * abs(ref)
+            np.testing.assert_allclose(full['chisq_array'],
+                                       cases[k + 'chisq_array'], rtol=1e-6)
+            np.testing.assert_array_equal(full['npix_array'],
+                                          cases[k + 'npix_array'])
+            for n, m, rm in zip(cases[tag + '/names'], full['models'],
+                                full['raw_models']):
+                np.testing.assert_allclose(m, cases[k + 'model_%s' % n],
+                                           rtol=1e-6)
+                np.testing.assert_allclose(rm, cases[k + 'raw_model_%s' % n],
+                                           rtol=3e-7)
+    val = orc.get_chisq(sds, float(cases[tag + '/vel']), cases[tag + '/truth'],
+                        None, options=dict(npoly=10), config=gold_config,
+                        libs=gold_libs, espec_systematic=0.05, use_c=use_c)
+    assert abs(val - cases[tag + '/chisq/sys005']) <= 1e-7 * abs(val)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_find_best(cases, gold_libs, gold_config, tag):
+    sds = gold_specdata(cases, tag, orc.SpecData)
+    vg = cases['vel_grid']
+    for g in ('g1', 'g3'):
+        k = '%s/%s/' % (tag, g)
+        vs = float(cases[k + 'vsini'])
+        rot = None if np.isnan(vs) else (vs, )
+        pl = [tuple(_) for _ in cases[k + 'params_list']]
+        r = orc.find_best(sds, vg, pl, rot, options=dict(npoly=10),
+                          config=gold_config, libs=gold_libs)
+        refgrid = cases[k + 'chisq_grid']
+        assert rel(r['chisq_grid'], refgrid) < 1e-7
+        assert abs(r['best_vel'] - cases[k + 'best_vel']) < 1e-4
+        assert abs(r['vel_err'] - cases[k + 'vel_err']) < 1e-5
+        assert abs(r['kurtosis'] - cases[k + 'kurtosis']) < 1e-5
+        assert abs(r['skewness'] - cases[k + 'skewness']) < 1e-5
+        np.testing.assert_allclose(r['best_param'], cases[k + 'best_param'])
+        np.testing.assert_allclose(r['probs'], cases[k + 'probs'], rtol=1e-5,
+                                   atol=1e-12)
+        # moments on the reference's own grid: exact restatement
+        s = orc.grid_summary(vg, refgrid)
+        assert abs(s['best_vel'] - cases[k + 'best_vel']) < 1e-10
+        assert abs(s['vel_err'] - cases[k + 'vel_err']) < 1e-10
+        if g == 'g1':
+            fast = orc.chisq_grid_fast(sds, vg, pl[0], rot, dict(npoly=10),
+                                       gold_config, gold_libs)
+            assert rel(fast, refgrid[:, 0]) < 1e-7
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_chisq_continuum(cases, tag):
+    sds = gold_specdata(cases, tag, orc.SpecData)
+    r = orc.get_chisq_continuum(sds, options=dict(npoly=10))
+    np.testing.assert_allclose(r['chisq_array'], cases[tag + '/cont/chisq_array'],
+                               rtol=1e-8)
+    np.testing.assert_allclose(r['redchisq_array'],
+                               cases[tag + '/cont/redchisq_array'], rtol=1e-8)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_ccf(cases, gold_libs, gold_config, tag):
+    sds = gold_specdata(cases, tag, orc.SpecData)
+    for sd in sds:
+        k = '%s/ccf/%s/' % (tag, sd.name)
+        ps, pi, info = orc.preprocess_data(sd.lam, sd.spec, sd.espec,
+                                           gold_libs[sd.name].ccf,
+                                           badmask=sd.badmask, details=True)
+        np.testing.assert_allclose(info['filled'], cases[k + 'cont_spec0'],
+                                   rtol=1e-13)
+        np.testing.assert_allclose(info['cespec'], cases[k + 'cont_espec0'],
+                                   rtol=1e-13)
+        np.testing.assert_allclose(info['p0'], cases[k + 'cont_p0'], rtol=1e-12)
+        # scipy.optimize.least_squares is third-party arithmetic at the
+        # boundary (scipy 1.7 in the capture interpreter, 1.15 here): the TRF
+        # iterates agree only to its own 1e-8 tolerances.
+        np.testing.assert_allclose(info['x'], cases[k + 'cont_x'], rtol=0,
+                                   atol=2e-6)
+        np.testing.assert_allclose(ps, cases[k + 'proc_spec'], rtol=1e-5,
+                                   atol=1e-7)
+        np.testing.assert_allclose(pi, cases[k + 'proc_ivar'], rtol=1e-5)
+    r = orc.ccf_fit(sds, gold_config, gold_libs)
+    np.testing.assert_allclose(r['best_par'], cases[tag + '/ccf/best_par'])
+    assert abs(r['best_vel'] - cases[tag + '/ccf/best_vel']) < 1e-3
+    np.testing.assert_allclose(r['best_ccf'], cases[tag + '/ccf/best_ccf'],
+                               rtol=1e-6)
+    np.testing.assert_allclose(r['vel_grid'], cases[tag + '/ccf/vel_grid'])
+    bv = float(cases[tag + '/ccf/best_vsini'])
+    assert r['best_vsini'] == bv
+    for sd in sds:
+        np.testing.assert_allclose(
+            r['best_model'][sd.name],
+            cases['%s/ccf/%s/best_model' % (tag, sd.name)])
+
+
+def test_ccf_lag_tables_are_integer_exact(gold_libs):
+    cc = gold_libs['gold_b'].ccf
+    step, ind, sub = orc.ccf_lag_tables(cc['logl0'], cc['logl1'], cc['npoints'],
+                                        1000)
+    assert ind.dtype.kind == 'i' and len(ind) % 2 == 1
+    assert np.all(np.diff(sub) > 0)
+    # centre lag is lag 0
+    assert ind[len(ind) // 2] == 0
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_refine(cases, gold_libs, gold_config, tag):
+    sds = gold_specdata(cases, tag, orc.SpecData)
+    bv, be, sk, ku, grids = orc.find_best_vel_iterate(
+        float(cases[tag + '/refine/start_vel']), gold_config, sds,
+        tuple(cases[tag + '/truth']), None, dict(npoly=10), gold_libs)
+    assert len(grids) == int(cases[tag + '/refine/ngrids'])
+    for i, g in enumerate(grids):
+        np.testing.assert_allclose(g, cases['%s/refine/grid_%d' % (tag, i)],
+                                   rtol=0, atol=1e-5)
+    assert abs(bv - cases[tag + '/refine/best_vel']) < 1e-4
+    assert abs(be - cases[tag + '/refine/vel_err']) < 1e-5
+    assert abs(sk - cases[tag + '/refine/skewness']) < 1e-4
+    assert abs(ku - cases[tag + '/refine/kurtosis']) < 1e-4
+
+
+def test_firstguess(cases, gold_libs, gold_config):
+    sds = gold_specdata(cases, 'c0', orc.SpecData)
+    pg = {'logg': [1, 3], 'teff': [4000, 5000, 7000], 'feh': [-2, -1],
+          'alpha': [0]}
+    fg = orc.firstguess(sds, dict(npoly=10), gold_config, gold_libs,
+                        vsinigrid=(None, 100), paramsgrid=pg)
+    keys = [str(_) for _ in cases['c0/firstguess/keys']]
+    assert sorted(fg.keys()) == keys
+    np.testing.assert_allclose([float(fg[k]) for k in keys],
+                               cases['c0/firstguess/vals'])

@@ -1,0 +1,243 @@
+/*
+ * rvsgpu.h -- C-ABI of librvsgpu.so, the MI355X (gfx950) implementation of the
+ * rvspecfit likelihood hot path.
+ *
+ * Conventions (they follow the reference's only C-ABI, py/rvspecfit/ffibuilder.py:10-17,
+ * i.e. `construct` / `evaler` of py/rvspecfit/src/spliner.c):
+ *   - extern "C", plain pointers and sizes, no torch / C++ types;
+ *   - the CALLER owns every buffer; the callee never allocates or retains memory;
+ *   - every pointer is a DEVICE pointer (HBM) unless the comment says "host";
+ *   - all floating point data is float64 (the reference computes in float64),
+ *     except the template grid `dats` and the NN weights which are float32 as in
+ *     the reference's artefacts;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     launches are asynchronous, nothing synchronises;
+ *   - return value: 0 ok; <0 argument / shape / launch error (RVS_E_*).
+ *     Per-spectrum conditions that the reference reports through Python
+ *     exceptions are returned as bit flags in an int32 `status[]` output
+ *     (RVS_ST_*); the Python layer re-raises the reference's exception types
+ *     for batch-of-1 calls.
+ *
+ * Citations below are relative to /root/reference/py/rvspecfit/.
+ */
+#ifndef RVSGPU_H
+#define RVSGPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVS_E_ARG (-1)     /* bad argument / unsupported shape */
+#define RVS_E_LAUNCH (-2)  /* hipLaunch failure (hipGetLastError != 0) */
+
+/* per-job status bits */
+#define RVS_ST_SPLINE_RANGE 0x1   /* evaler() == -1 : eval point outside knots (spliner.c:78-83)  */
+#define RVS_ST_SPLINE_GRID 0x2    /* evaler() == -2 : knots not uniform (spliner.c:87,95)          */
+#define RVS_ST_NONFINITE 0x4      /* non finite -2 log L (spec_fit.py:963-974)                     */
+#define RVS_ST_CHOL_FALLBACK 0x8  /* Cholesky failed, eigen (SVD) branch used (spec_fit.py:337-354) */
+#define RVS_ST_OUTSIDE_NAN 0x10   /* template outside grid & not finite (spec_fit.py:392-397)      */
+#define RVS_ST_CCF_FAILED 0x20    /* non finite CCF minimum (fitter_ccf.py:234-236)                 */
+#define RVS_ST_ALLMASKED 0x40     /* every pixel masked in CCF preprocessing (make_ccf.py:311-315)  */
+#define RVS_ST_QUAD_ASSERT 0x80   /* parabola vertex outside its bracket (spec_fit.py:1014 assert)  */
+
+/* library version / build probe (host). */
+int rvs_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * A3  polylinear template evaluation on a regular n-D grid
+ *     replaces spec_inter.GridInterp.__call__ (spec_inter.py:134-194),
+ *     GridOutsideCheck.__call__ (:77-92) and LogParamMapper.forward
+ *     (read_grid.py:127-145), composed as SpecInterpolator.eval/outsideFlag
+ *     (spec_inter.py:257-286) + the MAX_VAL guard of getCurTempl
+ *     (spec_fit.py:392-397).
+ *
+ * dats      float32 [ngrid, ntp]  log-flux rows (interpdat_%s.npy)
+ * idgrid    int64   [prod(lens)]  row of dats or -1 (C order)
+ * uvecs     float64 [sum(lens)]   concatenated unique mapped grid values
+ * lens      int32   [ndim] (host)
+ * vecs_s    float64 [ngrid, ndim] grid points divided by ptp (KD-tree space)
+ * inv_ptp   float64 [ndim] (host) 1/ptp per dimension
+ * log_mask  bit i set -> parameter i is mapped through log10
+ * params    float64 [B, ndim]     physical parameters
+ * templ     float64 [B, ntp]  out  exp'ed template
+ * outside   float64 [B]       out  0 inside; KD distance outside; NaN if the
+ *                                   template is non finite / > 1e100 outside
+ * cellinfo  int32   [B, 2+2^ndim] out (nullable) {mode, nearest, vertex ids}
+ *           mode 0 = polylinear, 1 = nearest neighbour, 2 = non finite params
+ * weights   float64 [B, 2^ndim]  out (nullable) polylinear weights
+ * ---------------------------------------------------------------------- */
+int rvs_template_polylinear(const float *dats, int64_t ngrid, int ntp,
+                            const int64_t *idgrid, const double *uvecs,
+                            const int32_t *lens, int ndim, const double *vecs_s,
+                            const double *inv_ptp, uint32_t log_mask,
+                            int exp_flag, const double *params, int B,
+                            double *templ, double *outside, int32_t *cellinfo,
+                            double *weights, void *stream);
+
+/* ------------------------------------------------------------------------
+ * A6  rotational broadening; replaces spec_fit.convolve_vsini /
+ *     compute_vsini_kernel (spec_fit.py:495-682).  vsini[b] <= 0, NaN or
+ *     R < 1e-9 copies the row (as does a non finite `outside[b]`, nullable,
+ *     spec_fit.py:398-404).  lnstep = log(lam[1]/lam[0]) of the log-uniform
+ *     template grid.  In place (out == templ) is NOT allowed.
+ * ---------------------------------------------------------------------- */
+int rvs_vsini_convolve(const double *templ, const double *vsini,
+                       const double *outside, double lnstep, double eps,
+                       int ntp, int B, double *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * A7  natural cubic spline through (knots, ys[b]); replaces `construct`
+ *     (src/spliner.c:7-60).  coef[b, i, 0..3] = A,B,C,D of interval i
+ *     (i < ntp-1; row ntp-1 is zero padding), h is implied by knots.
+ * ---------------------------------------------------------------------- */
+int rvs_spline_construct(const double *knots, const double *ys, int ntp, int B,
+                         double *coef, void *stream);
+
+/* A7  replaces `evaler` (src/spliner.c:71-108) for B splines sharing the
+ * knots: ret[b, i] = S_b(evalx[b, i]); pos (nullable) receives the integer
+ * interval index (int)((log x - log x0)/logstep) computed exactly as the
+ * reference does; status[b] gets RVS_ST_SPLINE_RANGE / _GRID. */
+int rvs_spline_eval(const double *knots, const double *coef, int ntp,
+                    int log_step, const double *evalx, int neval, int B,
+                    double *ret, int32_t *pos, int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------
+ * A7-eval + A10 + A11 fused: Doppler resample of a spline template onto the
+ * observed pixels and continuum-marginalised -2 log L on a velocity grid;
+ * replaces the vel loop of spec_fit.find_best over spec_fit.get_chisq
+ * (spec_fit.py:797-989, 1060-1071) for ONE spectral arm.
+ *
+ * Two calls: rvs_chisq_prepare once per (arm, batch of spectra) builds the
+ * velocity-independent per-pixel terms into `work` (rvs_chisq_work_size
+ * doubles); rvs_chisq_grid may then be called many times (first guess,
+ * refinement rounds, optimiser steps) on the same `work`.
+ *
+ * lam     [npix]        observed wavelengths of the arm (shared by the batch)
+ * polysT  [npix, npoly] continuum basis, pixel-major (get_poly_basis^T)
+ * spec, espec [S, npix]
+ * knots   [ntp], coef [Tn, ntp, 4]   from rvs_spline_construct
+ * knots_host3  HOST pointer to the first three knots: the uniformity test of
+ *          spliner.c:84-96 is done on the host; returns -3 where evaler
+ *          returns -2
+ * job_spec, job_templ int32 [J] (nullable = identity): job j fits spectrum
+ *          job_spec[j] with template job_templ[j]
+ * vels    float64, job j uses vels + j*vel_stride (vel_stride 0 = shared grid)
+ * espec_sys  systematic error added in quadrature (spec_fit.py:933-940)
+ * penalty [J] (nullable) added to every velocity of job j (outside*badchi,
+ *          spec_fit.py:895-896); a non finite penalty means "template not
+ *          usable": the arm contributes 1000*badchi (spec_fit.py:888-893).
+ * beta    out = beta*out + value  (0 first arm, 1 following arms)
+ * out     [J, Nv];   status int32 [J] OR-ed (caller zeroes it)
+ * ---------------------------------------------------------------------- */
+int64_t rvs_chisq_work_size(int npix, int S);
+int rvs_chisq_prepare(const double *lam, const double *spec,
+                      const double *espec, int npix, int S,
+                      const double *knots_host3, int log_step, double espec_sys,
+                      double *work, void *stream);
+int rvs_chisq_grid(const double *lam, const double *polysT, const double *work,
+                   int npix, int npoly, int S, const double *knots,
+                   const double *coef, int ntp, int Tn, int log_step,
+                   const int32_t *job_spec, const int32_t *job_templ, int J,
+                   const double *vels, int64_t vel_stride, int Nv,
+                   const double *penalty, double badchi, double beta,
+                   double *out, int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------
+ * get_chisq(full_output=True) for one velocity per job and one arm
+ * (spec_fit.py:941-961), and get_chisq_continuum (spec_fit.py:739-783) when
+ * unit_template != 0 (template == 1, knots/coef ignored).
+ * coeffs [J, npoly], model/raw_model [J, npix] (nullable), chisq [J] (-2logL
+ * of the arm), true_chisq [J] over pixels with badmask==0, ngood int32 [J].
+ * ---------------------------------------------------------------------- */
+int rvs_chisq_full(const double *lam, const double *polysT, const double *spec,
+                   const double *espec, const uint8_t *badmask, int npix,
+                   int npoly, int S, const double *knots, const double *coef,
+                   int ntp, int Tn, int log_step, int unit_template,
+                   const int32_t *job_spec, const int32_t *job_templ, int J,
+                   const double *vel, double espec_sys, double *chisq,
+                   double *coeffs, double *model, double *raw_model,
+                   double *true_chisq, int32_t *ngood, int32_t *status,
+                   void *stream);
+
+/* ------------------------------------------------------------------------
+ * A12  grid summary; replaces the tail of spec_fit.find_best
+ * (spec_fit.py:1072-1092) and _quadratic_interp_min (:992-1015).
+ * chisq [G, Np, Nv] (velocity fastest); vels + g*vel_stride -> [Nv];
+ * nvel (nullable int32 [G]) = number of valid velocities of group g.
+ * res [G, 8] = best_chi, best_vel, vel_err, kurtosis, skewness, i1 (vel idx),
+ *              i2 (template idx), spare;   probs [G, Nv] (nullable)
+ * ---------------------------------------------------------------------- */
+int rvs_grid_moments(const double *chisq, const double *vels,
+                     int64_t vel_stride, const int32_t *nvel, int G, int Np,
+                     int Nv, int quadratic, double *res, double *probs,
+                     int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------
+ * A15  CCF pre-processing of one arm; replaces make_ccf.preprocess_data
+ * (make_ccf.py:330-414) with interp_masker (:288-327), get_continuum
+ * (:105-152) and fit_resid (:155-164).  The k=2 interpolating continuum
+ * spline is linear in its node values, so it enters as the design matrix
+ * Lmat [npix, nnode] (host-built once per arm); the robust soft-L1 fit is a
+ * device Levenberg-Marquardt on the same objective.
+ *
+ * bin_start int32 [nnode+1]  pixel ranges of the binned-median start
+ * xind int32 [nfft], rw float64 [nfft]   rebin tables (xind<0: no coverage)
+ * outputs: proc_spec, proc_ivar [B, nfft]; sse [B] = sum proc_spec^2 proc_ivar;
+ *          cont [B, npix] (nullable), pfit [B, nnode] (nullable)
+ * ---------------------------------------------------------------------- */
+int rvs_ccf_preprocess(const double *lam, const double *spec,
+                       const double *espec, const uint8_t *badmask, int npix,
+                       int B, int continuum, const double *Lmat, int nnode,
+                       const int32_t *bin_start, const int32_t *xind,
+                       const double *rw, int nfft, double maxerr,
+                       double *proc_spec, double *proc_ivar, double *sse,
+                       double *cont, double *pfit, int32_t *status,
+                       void *stream);
+
+/* ------------------------------------------------------------------------
+ * A14  FFT cross-correlation of one arm against T templates; replaces the
+ * per-arm body of fitter_ccf.fit (fitter_ccf.py:112-161, 189-216).
+ *
+ * tfft, tfft2 complex128 [T, nfft/2+1] (ccfdat_%s.npz 'fft','fft2')
+ * twid complex128 [nfft/2]   exp(+2 pi i k / nfft)
+ * lag_pos int32 [nlag]  position of lag `subind[l]` in the bit-reversed half-size
+ *         inverse FFT output viewed as doubles: 2*bitrev(n>>1) + (n&1)
+ * lag_vel float64 [nlag] ascending lag velocities (fitter_ccf.py:136-154)
+ * ilo int32 [nvel], vgrid float64 [nvel]        linear-interp tables
+ * chisq [B, T, nvel]: out = beta*out + interp(-2 c0 + c1) (continuum) or
+ *                      interp(-c0^2/c1)
+ * work  complex128 [B, 2, nfft/2+1] scratch for conj rfft of spec*ivar, ivar
+ * ---------------------------------------------------------------------- */
+int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar, int nfft,
+                  int B, const double *tfft, const double *tfft2, int T,
+                  const double *twid, int continuum, const int32_t *lag_pos,
+                  const double *lag_vel, int nlag, const int32_t *ilo,
+                  const double *vgrid, int nvel, double beta, double *chisq,
+                  double *work, void *stream);
+
+/* argmin over (template, velocity) + 3-point parabola (fitter_ccf.py:218-236).
+ * sse [B] is added to every entry (total_sse).  res [B,4] = best_id, best_vel,
+ * best_pix, min value; best_ccf [B, nvel]. */
+int rvs_ccf_select(const double *chisq, const double *sse, int narm_sse, int B,
+                   int T, const double *vgrid, int nvel, double *res,
+                   double *best_ccf, int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------
+ * A4  NN template evaluator; replaces NNInterpolator.forward
+ * (nn/NNInterpolator.py:14-91), Mapper.forward (:159-171) and
+ * RVSInterpolator.__call__ (nn/RVSInterpolator.py:36-42): float32 MLP
+ * (Linear+SiLU)*(nlayer-1), Linear, on f32-input MFMA, float64
+ * exp(clip(.,-300,300)) epilogue.
+ * W[l] float32 [dout_l, din_l] row-major (torch Linear.weight), b[l] [dout_l]
+ * ---------------------------------------------------------------------- */
+int rvs_template_nn(const double *params, int B, int ndim, uint32_t log_mask,
+                    const double *M, const double *S, int nlayer,
+                    const float *const *W, const float *const *b,
+                    const int32_t *dims, float *act0, float *act1,
+                    double *templ, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

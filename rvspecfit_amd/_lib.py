@@ -1,0 +1,104 @@
+"""ctypes binding of librvsgpu.so (the C-ABI declared in include/rvsgpu.h).
+
+There is NO fallback: if the shared library is missing the import of any
+compute entry point raises.  Device pointers are taken from torch tensors
+(`tensor.data_ptr()`); the stream is torch's current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librvsgpu.so')
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_int64
+D = ctypes.c_double
+U = ctypes.c_uint32
+
+# name -> (restype, argtypes); mirrors include/rvsgpu.h declaration by declaration
+SIGNATURES = {
+    'rvs_abi_version': (I, []),
+    'rvs_template_polylinear': (I, [P, L, I, P, P, P, I, P, P, U, I, P, I, P, P,
+                                    P, P, P]),
+    'rvs_vsini_convolve': (I, [P, P, P, D, D, I, I, P, P]),
+    'rvs_spline_construct': (I, [P, P, I, I, P, P]),
+    'rvs_spline_eval': (I, [P, P, I, I, P, I, I, P, P, P, P]),
+    'rvs_chisq_work_size': (L, [I, I]),
+    'rvs_chisq_prepare': (I, [P, P, P, I, I, P, I, D, P, P]),
+    'rvs_chisq_grid': (I, [P, P, P, I, I, I, P, P, I, I, I, P, P, I, P, L, I, P,
+                           D, D, P, P, P]),
+    'rvs_chisq_full': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, P, P, I, P,
+                           D, P, P, P, P, P, P, P, P]),
+    'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
+    'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, I, P, P, P, I, D, P, P,
+                               P, P, P, P, P]),
+    'rvs_ccf_xcorr': (I, [P, P, I, I, P, P, I, P, I, P, P, I, P, P, I, D, P, P,
+                          P]),
+    'rvs_ccf_select': (I, [P, P, I, I, I, P, I, P, P, P, P]),
+    'rvs_template_nn': (I, [P, I, I, U, P, P, I, P, P, P, P, P, P, P]),
+}
+
+_lib = None
+
+
+class RvsGpuError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librvsgpu.so; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RvsGpuError(
+                '%s not found: build it with `make -C rvspecfit_amd/csrc` '
+                '(or python -c "import __graft_entry__ as g; g.build()"). '
+                'rvspecfit_amd has no CPU fallback.' % LIB_PATH)
+        L_ = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L_, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L_
+    return _lib
+
+
+def ptr(t):
+    """device (or host, for numpy/ctypes arrays) pointer of a tensor, or None"""
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous(), 'tensor must be contiguous'
+        return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.ctypes.data)  # numpy (host pointers)
+
+
+def stream():
+    if torch.cuda.is_available():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return None
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RvsGpuError('%s failed with code %d' % (what, rc))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RvsGpuError('rvspecfit_amd needs a ROCm GPU (MI355X); '
+                          'there is no CPU path')
+
+
+# status bits (include/rvsgpu.h)
+ST_SPLINE_RANGE = 0x1
+ST_SPLINE_GRID = 0x2
+ST_NONFINITE = 0x4
+ST_CHOL_FALLBACK = 0x8
+ST_OUTSIDE_NAN = 0x10
+ST_CCF_FAILED = 0x20
+ST_ALLMASKED = 0x40
+ST_QUAD_ASSERT = 0x80

@@ -1,0 +1,129 @@
+"""Host-side, once-per-arm tables for the CCF kernels (numpy only).
+
+Everything here depends only on the arm's wavelength grid and the CCF
+configuration -- never on a spectrum -- so it is computed once on the host in
+float64/int64 exactly as the reference computes it, and uploaded:
+
+  * the lag -> velocity tables and the sub-index of lags inside +-max_vel
+    (fitter_ccf.py:132-161) -- integer work, bit-exact by construction;
+  * the 2-point rebin tables onto the log-lambda FFT grid (make_ccf.py:394-404);
+  * the pixel ranges of the binned-median start of the continuum fit
+    (make_ccf.py:128-143, scipy.stats.binned_statistic semantics);
+  * the design matrix of the k=2 INTERPOLATING spline through the continuum
+    nodes (make_ccf.py:155-164: UnivariateSpline(nodes, p, s=0, k=2)(lam)).
+    An interpolating spline is linear in its node values p, so
+    spline(lam) = Lmat @ p.  Lmat is built from the same FITPACK knot rule
+    (fpcurf.f, s=0, even k: interior knots at the mid points of the data
+    abscissae) with B-spline collocation; extrapolation beyond the last node
+    uses the end polynomial piece (ext=0).
+"""
+import numpy as np
+
+
+def _bspl_basis(t, k, x, l):
+    """The k+1 B-splines of degree k that are non zero on [t[l], t[l+1]),
+    evaluated at x (polynomially extended outside): FITPACK fpbspl."""
+    h = np.zeros(k + 1)
+    h[0] = 1.0
+    for j in range(1, k + 1):
+        hh = h[:j].copy()
+        h[0] = 0.0
+        for i in range(j):
+            li = l + i + 1
+            lj = li - j
+            f = hh[i] / (t[li] - t[lj])
+            h[i] += f * (t[li] - x)
+            h[i + 1] = f * (x - t[lj])
+    return h
+
+
+def interp_spline_design(nodes, lam, k=2):
+    """Lmat [len(lam), len(nodes)] with UnivariateSpline(nodes, p, s=0, k=2)(lam)
+    == Lmat @ p."""
+    nodes = np.asarray(nodes, dtype=np.float64)
+    m = len(nodes)
+    assert m > k and k == 2
+    # FITPACK knots for s=0, k=2
+    interior = 0.5 * (nodes[1:m - 2] + nodes[2:m - 1])
+    t = np.concatenate([[nodes[0]] * 3, interior, [nodes[-1]] * 3])
+    n = len(t)
+    assert n == m + k + 1
+
+    def design(xs):
+        E = np.zeros((len(xs), m))
+        for r, x in enumerate(xs):
+            l = np.searchsorted(t, x, 'right') - 1
+            l = min(max(l, k), n - k - 2)
+            E[r, l - k:l + 1] = _bspl_basis(t, k, x, l)
+        return E
+
+    C = design(nodes)
+    E = design(np.asarray(lam, dtype=np.float64))
+    return E @ np.linalg.inv(C)
+
+
+def continuum_nodes(lam0, splinestep):
+    """make_ccf.py:123-131"""
+    lammin = lam0.min()
+    dl = np.log(1 + splinestep / 3e5)
+    N = int(np.ceil(np.log(lam0.max() / lammin) / dl))
+    nodes = lammin * np.exp(np.arange(N) * dl)
+    edges = lammin * np.exp((-0.5 + np.arange(N + 1)) * dl)
+    return nodes, edges
+
+
+def bin_ranges(lam, edges):
+    """Pixel ranges [start_j, start_{j+1}) of every bin of
+    scipy.stats.binned_statistic(lam, ., bins=edges) for an increasing lam:
+    bin j holds edges[j] <= lam < edges[j+1], the last bin is closed on the
+    right, pixels outside the edges belong to no bin."""
+    lam = np.asarray(lam)
+    nb = len(edges) - 1
+    start = np.searchsorted(lam, edges[:-1], 'left').astype(np.int32)
+    last_end = np.searchsorted(lam, edges[-1], 'right')
+    out = np.zeros(nb + 1, dtype=np.int32)
+    out[:nb] = start
+    out[nb] = last_end
+    # first pixel of a bin can not precede the previous bin's start
+    return out
+
+
+def rebin_tables(lam, logl0, logl1, npoints):
+    """make_ccf.py:355-357, 394-399: xind (-1 where the FFT grid point has no
+    bracketing pixel pair) and the right weight."""
+    ccf_lam = np.exp(np.linspace(logl0, logl1, npoints))
+    xind = np.searchsorted(lam, ccf_lam) - 1
+    sub = (xind >= 0) & (xind <= len(lam) - 2)
+    rw = np.zeros(npoints)
+    li = xind[sub]
+    rw[sub] = (ccf_lam[sub] - lam[li]) / (lam[li + 1] - lam[li])
+    xi = np.where(sub, xind, -1).astype(np.int32)
+    return xi, rw
+
+
+def lag_tables(logl0, logl1, npoints, maxvel):
+    """fitter_ccf.py:132-154"""
+    step = (np.exp((logl1 - logl0) / npoints) - 1) * 3e5
+    L = npoints
+    off = L // 2
+    vels = -((np.arange(L) + off) % L - off) * step
+    sel = np.abs(vels) < (maxvel + step)
+    assert sel.sum() % 2 == 1
+    ind = np.roll(np.nonzero(sel)[0], sel.sum() // 2)[::-1]
+    sub = vels[ind]
+    if not np.all(np.diff(sub) > 0):
+        raise RuntimeError('Velocity grid for CCF interpolation is invalid')
+    return step, ind.astype(np.int32), np.ascontiguousarray(sub)
+
+
+def interp_tables(sub_vels, vel_grid):
+    """interp1d(kind='linear', assume_sorted=True) bracketing indices."""
+    hi = np.clip(np.searchsorted(sub_vels, vel_grid), 1, len(sub_vels) - 1)
+    return (hi - 1).astype(np.int32)
+
+
+def ccf_vel_grid(config):
+    """fitter_ccf.py:81-87"""
+    maxvel = config.get('max_vel') or 1000
+    nvel = 2 * int(maxvel * 1. / (config.get('vel_step0') or 2)) + 1
+    return maxvel, np.linspace(-maxvel, maxvel, nvel)

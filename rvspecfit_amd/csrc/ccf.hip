@@ -1,0 +1,809 @@
+// ccf.hip -- cross-correlation first guess for gfx950.
+//
+// Reference: py/rvspecfit/make_ccf.py:105-164, 288-414 (preprocess_data,
+// interp_masker, get_continuum, fit_resid) and py/rvspecfit/fitter_ccf.py:62-253.
+//
+//  ccf_preprocess_kernel  one 256-thread block per spectrum-arm: median filter,
+//      masks, gap filling, binned-median start, robust (soft-L1) continuum fit
+//      as a Levenberg-Marquardt on the same objective, normalisation, 2-point
+//      rebin with ivar propagation onto the log-lambda FFT grid.  All medians
+//      come from in-LDS bitonic sorts.
+//  ccf_rfft_kernel        conj(rfft(spec*ivar)), conj(rfft(ivar)) per spectrum.
+//  ccf_xcorr_kernel       one block per (spectrum, template): streams the
+//      template's two complex128 spectra from HBM (coalesced 16 B / lane),
+//      forms -2 F S* + F2 V*, one half-size complex inverse FFT in LDS (fp64,
+//      fused radix-4 DIF, bit-reversed output gathered only at the ~100 lags
+//      inside +-max_vel), linear interpolation to the common velocity grid.
+//  ccf_select_kernel      argmin over (template, velocity) + parabola.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// block-wide bitonic sort of n2 (power of two) doubles in LDS, ascending.
+// Optional companion key array (int16 "bin" major key).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool key_less(int ba, double va, int bb, double vb) {
+  return (ba < bb) || (ba == bb && va < vb);
+}
+
+template <bool WITH_BIN>
+__device__ void bitonic_sort(double *v, short *bin, int n2) {
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < n2; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const double a = v[i], b = v[ixj];
+          const int ba = WITH_BIN ? bin[i] : 0, bb = WITH_BIN ? bin[ixj] : 0;
+          const bool up = ((i & k) == 0);
+          const bool sw = up ? key_less(bb, b, ba, a) : key_less(ba, a, bb, b);
+          if (sw) {
+            v[i] = b;
+            v[ixj] = a;
+            if (WITH_BIN) {
+              bin[i] = (short)bb;
+              bin[ixj] = (short)ba;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// numpy median of the first n sorted values (mean of the middle two if even)
+__device__ __forceinline__ double sorted_median(const double *s, int n) {
+  if (n <= 0) return __builtin_nan("");
+  if (n & 1) return s[n >> 1];
+  return (s[(n >> 1) - 1] + s[n >> 1]) * 0.5;
+}
+
+__device__ __forceinline__ double median11(double *a) {
+  // insertion sort of 11 values, return the 6th
+#pragma unroll
+  for (int i = 1; i < 11; i++) {
+    const double x = a[i];
+    int j = i - 1;
+    while (j >= 0 && a[j] > x) {
+      a[j + 1] = a[j];
+      j--;
+    }
+    a[j + 1] = x;
+  }
+  return a[5];
+}
+
+#define CCF_MAXNODE 32
+
+struct LMShared {
+  double p[CCF_MAXNODE], pn[CCF_MAXNODE], g[CCF_MAXNODE], dl[CCF_MAXNODE];
+  double H[CCF_MAXNODE * CCF_MAXNODE];
+  double Lc[CCF_MAXNODE * CCF_MAXNODE];
+  double red[8];
+  double cost, costn, lamd, medv, mederr, medspec;
+  int flag, ngood, firstgood, lastgood, nval, stop;
+};
+
+// model + residual statistics at parameter vector pp.  Returns block-wide
+// cost 0.5*sum rho(f^2), rho(z) = 2(sqrt(1+z)-1)  (scipy soft_l1, f_scale=1).
+// If store, also writes the Gauss-Newton weights:
+//   gw[k] = (m/e) f / sqrt(1+z)        (gradient)
+//   hw[k] = (m/e)^2 (1+z)^-1.5         (Hessian, rho' + 2 rho'' f^2 scaling)
+__device__ double lm_eval(const double *__restrict__ Lmat, int m, int npix,
+                          const double *pp, const double *cs, const double *ce,
+                          double *gw, double *hw, bool store, double *red) {
+  double c = 0;
+  for (int k = threadIdx.x; k < npix; k += 256) {
+    const double *Lr = Lmat + (int64_t)k * m;
+    double s = 0;
+    for (int i = 0; i < m; i++) s = fma(Lr[i], pp[i], s);
+    const bool clipped = (s < -100.0) || (s > 100.0);
+    s = fmin(fmax(s, -100.0), 100.0);
+    const double mod = exp(s);
+    const double e = ce[k];
+    const double f = (mod - cs[k]) / e;
+    const double z = f * f;
+    const double r = sqrt(1 + z);
+    c += 2 * (r - 1);
+    if (store) {
+      const double d = clipped ? 0.0 : mod / e;
+      gw[k] = d * f / r;
+      hw[k] = d * d / (r * r * r);
+    }
+  }
+  return 0.5 * block_sum<4>(c, red);
+}
+
+__global__ void __launch_bounds__(256)
+    ccf_preprocess_kernel(const double *__restrict__ lam,
+                          const double *__restrict__ spec,
+                          const double *__restrict__ espec,
+                          const uint8_t *__restrict__ badmask, int npix, int np2,
+                          int continuum, const double *__restrict__ Lmat,
+                          int nnode, const int32_t *__restrict__ bin_start,
+                          const int32_t *__restrict__ xind,
+                          const double *__restrict__ rw, int nfft, double maxerr,
+                          double *__restrict__ proc_spec,
+                          double *__restrict__ proc_ivar, double *__restrict__ sse,
+                          double *__restrict__ cont_out,
+                          double *__restrict__ pfit, int32_t *__restrict__ status) {
+  extern __shared__ double sm[];
+  double *cs = sm;              // [npix] current spectrum
+  double *ce = cs + npix;       // [npix] current error
+  double *sb = ce + npix;       // [np2]  sort buffer / gw
+  double *hw = sb + np2;        // [npix] hessian weights
+  short *binkey = reinterpret_cast<short *>(hw + npix);       // [np2]
+  uint8_t *msk = reinterpret_cast<uint8_t *>(binkey + np2);  // [npix]
+  __shared__ LMShared S;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double *sp0 = spec + (int64_t)b * npix;
+  const double *es0 = espec + (int64_t)b * npix;
+  const double nanv = __builtin_nan("");
+
+  for (int k = tid; k < npix; k += 256) {
+    cs[k] = sp0[k];
+    ce[k] = es0[k];
+    msk[k] = badmask ? (badmask[(int64_t)b * npix + k] != 0) : 0;
+  }
+  if (tid == 0) {
+    S.flag = 0;
+    S.nval = 0;
+  }
+  __syncthreads();
+
+  // ---- nanmedian(espec) -----------------------------------------------------
+  {
+    int cnt = 0;
+    for (int k = tid; k < np2; k += 256) {
+      double v = __builtin_inf();
+      if (k < npix) {
+        const double e = ce[k];
+        if (e == e) {
+          v = e;
+          cnt++;
+        }
+      }
+      sb[k] = v;
+    }
+    cnt = wave_sum_i(cnt);
+    if ((tid & 63) == 0) atomicAdd(&S.nval, cnt);
+    bitonic_sort<false>(sb, nullptr, np2);
+    if (tid == 0) S.mederr = sorted_median(sb, S.nval);
+    __syncthreads();
+  }
+  const double mederr = S.mederr;
+
+  // ---- medfilt(spec, 11) <= 0 and error clipping (make_ccf.py:366-370) -------
+  if (continuum) {
+    for (int k = tid; k < npix; k += 256) {
+      double w[11];
+#pragma unroll
+      for (int q = 0; q < 11; q++) {
+        const int idx = k + q - 5;
+        w[q] = (idx >= 0 && idx < npix) ? cs[idx] : 0.0;  // zero padded
+      }
+      const double med = median11(w);
+      if ((ce[k] > maxerr * mederr) || (med <= 0)) msk[k] = 1;
+    }
+  }
+  __syncthreads();
+  // ---- inflate masked errors, fill gaps (interp_masker, make_ccf.py:288-327) --
+  {
+    int ng = 0, fg = npix, lg = -1;
+    for (int k = tid; k < npix; k += 256) {
+      if (msk[k]) {
+        ce[k] = 1e9 * mederr;
+      } else {
+        ng++;
+        fg = min(fg, k);
+        lg = max(lg, k);
+      }
+    }
+    ng = wave_sum_i(ng);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      fg = min(fg, __shfl_xor(fg, o, 64));
+      lg = max(lg, __shfl_xor(lg, o, 64));
+    }
+    if (tid == 0) {
+      S.ngood = 0;
+      S.firstgood = npix;
+      S.lastgood = -1;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+      atomicAdd(&S.ngood, ng);
+      atomicMin(&S.firstgood, fg);
+      atomicMax(&S.lastgood, lg);
+    }
+    __syncthreads();
+    if (S.ngood == 0) {
+      if (tid == 0) S.flag |= RVS_ST_ALLMASKED;
+      for (int k = tid; k < npix; k += 256)
+        if (!(fabs(cs[k]) <= 1.79e308)) cs[k] = 1;
+    } else {
+      const int fgood = S.firstgood, lgood = S.lastgood;
+      for (int k = tid; k < npix; k += 256) {
+        if (!msk[k]) continue;
+        double val;
+        if (k < fgood)
+          val = sp0[fgood];
+        else if (k > lgood)
+          val = sp0[lgood];
+        else {
+          int a = k - 1, c = k + 1;
+          while (msk[a]) a--;
+          while (msk[c]) c++;
+          const double l1 = lam[a], l2 = lam[c], l0 = lam[k];
+          val = (-(l1 - l0) * sp0[c] + (l2 - l0) * sp0[a]) / (l2 - l1);
+        }
+        cs[k] = val;  // only masked pixels are written, only good ones read
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- median of the filled spectrum ----------------------------------------
+  {
+    for (int k = tid; k < np2; k += 256)
+      sb[k] = (k < npix) ? cs[k] : __builtin_inf();
+    bitonic_sort<false>(sb, nullptr, np2);
+    if (tid == 0) {
+      double md = sorted_median(sb, npix);
+      S.medv = md;
+      double ms = md;
+      if (ms <= 0) {
+        ms = fabs(ms);
+        if (ms == 0) ms = 1;
+      }
+      S.medspec = ms;
+    }
+    __syncthreads();
+  }
+  const double medv = S.medv;
+
+  if (continuum) {
+    const int m = nnode;
+    // ---- binned medians -> p0 (make_ccf.py:141-143) -------------------------
+    for (int k = tid; k < np2; k += 256) {
+      double v = __builtin_inf();
+      short bn = (short)(m + 1);
+      if (k < npix) {
+        v = cs[k];
+        bn = (short)m;  // outside every bin
+        if (k >= bin_start[0] && k < bin_start[m]) {
+          int lo = 0, hi = m;  // last j with bin_start[j] <= k
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (bin_start[mid] <= k)
+              lo = mid;
+            else
+              hi = mid;
+          }
+          bn = (short)lo;
+        }
+      }
+      sb[k] = v;
+      binkey[k] = bn;
+    }
+    bitonic_sort<true>(sb, binkey, np2);
+    if (tid < m) {
+      // pixels of bin j sit, sorted, at [bin_start[j], bin_start[j+1]) shifted by
+      // the number of pixels in front of the first bin (they sort to the end)
+      const int s0 = bin_start[tid] - bin_start[0];
+      const int cnt = bin_start[tid + 1] - bin_start[tid];
+      double stat = sorted_median(sb + s0, cnt);
+      double p0 = log(fmax(stat, 1e-3 * S.medspec));
+      if (!(stat == stat)) p0 = nanv;  // np.maximum propagates NaN
+      if (!(fabs(p0) <= 1.79e308)) p0 = log(S.medspec);
+      S.p[tid] = p0;
+    }
+    __syncthreads();
+
+    // ---- Levenberg-Marquardt on the soft-L1 objective -----------------------
+    double *gw = sb;  // reuse
+    if (tid == 0) {
+      S.lamd = 1e-3;
+      S.stop = 0;
+    }
+    double cost = lm_eval(Lmat, m, npix, S.p, cs, ce, gw, hw, true, S.red);
+    const int NE = m * (m + 1) / 2 + m;
+    for (int it = 0; it < 60; it++) {
+      __syncthreads();
+      for (int e = tid; e < NE; e += 256) {
+        if (e >= m * (m + 1) / 2) {
+          const int i = e - m * (m + 1) / 2;
+          double s = 0;
+          for (int k = 0; k < npix; k++) s = fma(Lmat[(int64_t)k * m + i], gw[k], s);
+          S.g[i] = s;
+        } else {
+          int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+          while (i * (i + 1) / 2 > e) i--;
+          while ((i + 1) * (i + 2) / 2 <= e) i++;
+          const int jj = e - i * (i + 1) / 2;
+          double s = 0;
+          for (int k = 0; k < npix; k++)
+            s = fma(Lmat[(int64_t)k * m + i] * Lmat[(int64_t)k * m + jj], hw[k], s);
+          S.H[i * m + jj] = s;
+          S.H[jj * m + i] = s;
+        }
+      }
+      __syncthreads();
+      // damped step; retry with larger damping until the cost does not grow
+      for (int tries = 0; tries < 40; tries++) {
+        if (tid == 0) {
+          const double ld = S.lamd;
+          bool ok = true;
+          for (int i = 0; i < m && ok; i++)
+            for (int jj = 0; jj <= i; jj++) {
+              double s = S.H[i * m + jj];
+              if (i == jj) s += ld * S.H[i * m + i];
+              for (int k = 0; k < jj; k++) s -= S.Lc[i * m + k] * S.Lc[jj * m + k];
+              if (i == jj) {
+                if (!(s > 0)) {
+                  ok = false;
+                  break;
+                }
+                S.Lc[i * m + i] = sqrt(s);
+              } else
+                S.Lc[i * m + jj] = s / S.Lc[jj * m + jj];
+            }
+          if (ok) {
+            double y[CCF_MAXNODE];
+            for (int i = 0; i < m; i++) {
+              double s = -S.g[i];
+              for (int k = 0; k < i; k++) s -= S.Lc[i * m + k] * y[k];
+              y[i] = s / S.Lc[i * m + i];
+            }
+            for (int i = m - 1; i >= 0; i--) {
+              double s = y[i];
+              for (int k = i + 1; k < m; k++) s -= S.Lc[k * m + i] * S.dl[k];
+              S.dl[i] = s / S.Lc[i * m + i];
+            }
+            for (int i = 0; i < m; i++) S.pn[i] = S.p[i] + S.dl[i];
+          } else {
+            for (int i = 0; i < m; i++) {
+              S.dl[i] = 0;
+              S.pn[i] = S.p[i];
+            }
+          }
+        }
+        __syncthreads();
+        const double cn = lm_eval(Lmat, m, npix, S.pn, cs, ce, gw, hw, false, S.red);
+        if (cn <= cost) {  // accept (block-uniform decision)
+          double mx = 0;
+          for (int i = 0; i < m; i++) mx = fmax(mx, fabs(S.dl[i]));
+          const double rel = (cost - cn) / fmax(cost, 1e-300);
+          __syncthreads();
+          if (tid == 0) {
+            for (int i = 0; i < m; i++) S.p[i] = S.pn[i];
+            S.lamd = fmax(S.lamd / 8, 1e-12);
+            if (mx < 1e-11 || rel < 1e-15) S.stop = 1;
+          }
+          cost = cn;
+          break;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          S.lamd *= 4;
+          if (S.lamd > 1e12) S.stop = 1;
+        }
+        __syncthreads();
+        if (S.stop) break;
+      }
+      __syncthreads();
+      if (S.stop) break;
+      cost = lm_eval(Lmat, m, npix, S.p, cs, ce, gw, hw, true, S.red);
+    }
+    __syncthreads();
+    if (pfit && tid < m) pfit[(int64_t)b * m + tid] = S.p[tid];
+  }
+
+  // ---- normalise (make_ccf.py:380-392) ----------------------------------------
+  for (int k = tid; k < npix; k += 256) {
+    double cont = 1.0;
+    if (continuum) {
+      const double *Lr = Lmat + (int64_t)k * nnode;
+      double s = 0;
+      for (int i = 0; i < nnode; i++) s = fma(Lr[i], S.p[i], s);
+      cont = exp(fmin(fmax(s, -100.0), 100.0));
+    }
+    if (medv > 0)
+      cont = fmax(1e-2 * medv, cont);
+    else
+      cont = fmax(cont, 1.0);
+    if (cont_out) cont_out[(int64_t)b * npix + k] = cont;
+    const double e = ce[k];
+    double iv = 1.0 / (e * e);
+    double c = sp0[k] / cont;
+    iv = cont * cont * iv;
+    if (msk[k]) {
+      iv = 0;
+      c = 0;
+    }
+    hw[k] = c;   // normalised spectrum
+    sb[k] = iv;  // its inverse variance
+  }
+  __syncthreads();
+  // ---- rebin to the FFT grid (make_ccf.py:394-409) -----------------------------
+  double ss = 0;
+  for (int n = tid; n < nfft; n += 256) {
+    const int xi = xind[n];
+    double r1 = 0, r2 = 0;
+    if (xi >= 0) {
+      const double rwt = rw[n], lwt = 1 - rwt;
+      r1 = lwt * hw[xi] + rwt * hw[xi + 1];
+      const double a = sb[xi], c = sb[xi + 1];
+      r2 = a * c / (lwt * lwt * c + rwt * rwt * a + ((a * c) == 0 ? 1.0 : 0.0));
+    }
+    proc_spec[(int64_t)b * nfft + n] = r1;
+    proc_ivar[(int64_t)b * nfft + n] = r2;
+    ss += r1 * r1 * r2;
+  }
+  ss = block_sum<4>(ss, S.red);
+  if (tid == 0) {
+    sse[b] = ss;
+    if (S.flag && status) atomicOr(&status[b], S.flag);
+  }
+}
+
+static inline int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
+                                  const double *espec, const uint8_t *badmask,
+                                  int npix, int B, int continuum,
+                                  const double *Lmat, int nnode,
+                                  const int32_t *bin_start, const int32_t *xind,
+                                  const double *rw, int nfft, double maxerr,
+                                  double *proc_spec, double *proc_ivar,
+                                  double *sse, double *cont, double *pfit,
+                                  int32_t *status, void *stream) {
+  if (npix < 12 || B < 1 || nfft < 2) return RVS_E_ARG;
+  if (continuum && (nnode < 3 || nnode > CCF_MAXNODE)) return RVS_E_ARG;
+  const int np2 = next_pow2(npix);
+  const size_t shm = sizeof(double) * (3 * (size_t)npix + np2) +
+                     sizeof(short) * np2 + ((npix + 15) / 16) * 16;
+  if (shm > 140 * 1024) return RVS_E_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)ccf_preprocess_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              140 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ccf_preprocess_kernel, dim3(B), dim3(256), shm,
+                     rvs_stream(stream), lam, spec, espec, badmask, npix, np2,
+                     continuum, Lmat, nnode, bin_start, xind, rw, nfft, maxerr,
+                     proc_spec, proc_ivar, sse, cont, pfit, status);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// FFT helpers.  a[] holds n2 complex128 in LDS.  tw[j] = exp(+2 pi i j / nfft),
+// j < nfft/2, nfft = 2*n2.  In-place decimation-in-frequency, two radix-2
+// stages fused per LDS round trip; natural order in, BIT-REVERSED order out.
+// SIGN = +1 : sum_k a_k e^{+2 pi i k m / n2} (un-normalised inverse)
+// SIGN = -1 : forward.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) {
+  return make_double2(a.x + b.x, a.y + b.y);
+}
+__device__ __forceinline__ double2 csub(double2 a, double2 b) {
+  return make_double2(a.x - b.x, a.y - b.y);
+}
+
+template <int SIGN>
+__device__ void fft_dif(double2 *a, int log2n, const double2 *__restrict__ tw) {
+  const int n2 = 1 << log2n;
+  int lg = log2n;  // log2 of current block size
+  while (lg >= 2) {
+    const int q = 1 << (lg - 2);           // quarter block
+    const int twmul = 1 << (log2n + 1 - lg);  // nfft / (4q)
+    __syncthreads();
+    for (int t = threadIdx.x; t < (n2 >> 2); t += 256) {
+      const int j = t & (q - 1);
+      const int base = ((t >> (lg - 2)) << lg) + j;
+      double2 w1 = tw[j * twmul];  // e^{+2 pi i j/(4q)}
+      if (SIGN < 0) w1.y = -w1.y;
+      const double2 w2 = cmul(w1, w1);  // e^{+-2 pi i j/(2q)}
+      // w1 * e^{+-i pi/2}
+      const double2 w1q = (SIGN > 0) ? make_double2(-w1.y, w1.x)
+                                     : make_double2(w1.y, -w1.x);
+      const double2 a0 = a[base], a1 = a[base + q], a2 = a[base + 2 * q],
+                    a3 = a[base + 3 * q];
+      const double2 b0 = cadd(a0, a2), b2 = cmul(csub(a0, a2), w1);
+      const double2 b1 = cadd(a1, a3), b3 = cmul(csub(a1, a3), w1q);
+      a[base] = cadd(b0, b1);
+      a[base + q] = cmul(csub(b0, b1), w2);
+      a[base + 2 * q] = cadd(b2, b3);
+      a[base + 3 * q] = cmul(csub(b2, b3), w2);
+    }
+    lg -= 2;
+  }
+  if (lg == 1) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < (n2 >> 1); t += 256) {
+      const double2 u = a[2 * t], v = a[2 * t + 1];
+      a[2 * t] = cadd(u, v);
+      a[2 * t + 1] = csub(u, v);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int brev(int x, int bits) {
+  return (int)(__brev((unsigned)x) >> (32 - bits));
+}
+
+// conj(rfft(x)) for x = proc_spec*proc_ivar (which 0) and proc_ivar (which 1)
+__global__ void __launch_bounds__(256)
+    ccf_rfft_kernel(const double *__restrict__ proc_spec,
+                    const double *__restrict__ proc_ivar, int nfft, int log2n,
+                    const double2 *__restrict__ tw, double2 *__restrict__ work) {
+  extern __shared__ double2 fa[];
+  const int b = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
+  const int n2 = nfft >> 1;
+  const double *ps = proc_spec + (int64_t)b * nfft;
+  const double *pi = proc_ivar + (int64_t)b * nfft;
+  for (int n = tid; n < n2; n += 256) {
+    double x0, x1;
+    if (which == 0) {
+      x0 = ps[2 * n] * pi[2 * n];
+      x1 = ps[2 * n + 1] * pi[2 * n + 1];
+    } else {
+      x0 = pi[2 * n];
+      x1 = pi[2 * n + 1];
+    }
+    fa[n] = make_double2(x0, x1);
+  }
+  fft_dif<-1>(fa, log2n, tw);
+  double2 *out = work + ((int64_t)b * 2 + which) * (n2 + 1);
+  for (int k = tid; k <= n2; k += 256) {
+    double2 X;
+    if (k == 0 || k == n2) {
+      const double2 z0 = fa[0];
+      X = make_double2(k == 0 ? z0.x + z0.y : z0.x - z0.y, 0.0);
+    } else {
+      const double2 zk = fa[brev(k, log2n)], zm = fa[brev(n2 - k, log2n)];
+      const double2 e = make_double2(zk.x + zm.x, zk.y - zm.y);   // zk + conj(zm)
+      const double2 d = make_double2(zk.x - zm.x, zk.y + zm.y);   // zk - conj(zm)
+      double2 w = tw[k];
+      w.y = -w.y;                                // e^{-2 pi i k/nfft}
+      const double2 q = cmul(w, d);              // w d
+      // X = e/2 - (i/2) q
+      X = make_double2(0.5 * (e.x + q.y), 0.5 * (e.y - q.x));
+    }
+    out[k] = make_double2(X.x, -X.y);  // conjugate
+  }
+}
+
+// one block per (spectrum b, template t)
+__global__ void __launch_bounds__(256)
+    ccf_xcorr_kernel(const double2 *__restrict__ work, int nfft, int log2n,
+                     const double2 *__restrict__ tfft,
+                     const double2 *__restrict__ tfft2, int T,
+                     const double2 *__restrict__ tw, int continuum,
+                     const int32_t *__restrict__ lag_pos,
+                     const double *__restrict__ lag_vel, int nlag,
+                     const int32_t *__restrict__ ilo,
+                     const double *__restrict__ vgrid, int nvel, double beta,
+                     double *__restrict__ chisq) {
+  extern __shared__ double2 fa[];
+  const int n2 = nfft >> 1;
+  double *c0 = reinterpret_cast<double *>(fa + n2);  // [nlag]
+  double *c1 = c0 + nlag;                            // [nlag]
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const double2 *Sc = work + ((int64_t)b * 2) * (n2 + 1);
+  const double2 *Vc = Sc + (n2 + 1);
+  const double2 *F = tfft + (int64_t)t * (n2 + 1);
+  const double2 *F2 = tfft2 + (int64_t)t * (n2 + 1);
+  const double inv_n = 1.0 / nfft;
+  const int npass = continuum ? 1 : 2;
+  for (int pass = 0; pass < npass; pass++) {
+    // spectrum X[k], k = 0..n2 of the real sequence to be inverted
+    //   continuum: X = -2 F S* + F2 V*;  else pass 0: F S*, pass 1: F2 V*
+    for (int k = tid; k <= (n2 >> 1); k += 256) {
+      const int m = n2 - k;
+      double2 Xk, Xm;
+      if (continuum) {
+        const double2 p1 = cmul(F[k], Sc[k]), p2 = cmul(F2[k], Vc[k]);
+        Xk = make_double2(p2.x - 2 * p1.x, p2.y - 2 * p1.y);
+        const double2 q1 = cmul(F[m], Sc[m]), q2 = cmul(F2[m], Vc[m]);
+        Xm = make_double2(q2.x - 2 * q1.x, q2.y - 2 * q1.y);
+      } else if (pass == 0) {
+        Xk = cmul(F[k], Sc[k]);
+        Xm = cmul(F[m], Sc[m]);
+      } else {
+        Xk = cmul(F2[k], Vc[k]);
+        Xm = cmul(F2[m], Vc[m]);
+      }
+      if (k == 0) {
+        // numpy irfft ignores the imaginary parts of the DC and Nyquist bins
+        fa[0] = make_double2(Xk.x + Xm.x, Xk.x - Xm.x);
+      } else {
+        const double2 e = make_double2(Xk.x + Xm.x, Xk.y - Xm.y);  // Xk + conj Xm
+        const double2 d = make_double2(Xk.x - Xm.x, Xk.y + Xm.y);  // Xk - conj Xm
+        const double2 q = cmul(tw[k], d);
+        // Z[k] = e + i q ; Z[m] = conj(e) + i conj(q)
+        fa[k] = make_double2(e.x - q.y, e.y + q.x);
+        if (m != k) fa[m] = make_double2(e.x + q.y, -e.y + q.x);
+      }
+    }
+    fft_dif<1>(fa, log2n, tw);
+    const double *fr = reinterpret_cast<const double *>(fa);
+    double *dst = (pass == 0) ? c0 : c1;
+    for (int l = tid; l < nlag; l += 256) dst[l] = fr[lag_pos[l]] * inv_n;
+    __syncthreads();
+  }
+  if (!continuum) {
+    for (int l = tid; l < nlag; l += 256) c0[l] = -c0[l] * c0[l] / c1[l];
+    __syncthreads();
+  }
+  double *out = chisq + ((int64_t)b * T + t) * nvel;
+  for (int v = tid; v < nvel; v += 256) {
+    const int lo = ilo[v];
+    const double x0 = lag_vel[lo], x1 = lag_vel[lo + 1];
+    const double sl = (c0[lo + 1] - c0[lo]) / (x1 - x0);
+    const double val = sl * (vgrid[v] - x0) + c0[lo];
+    out[v] = (beta != 0.0) ? beta * out[v] + val : val;
+  }
+}
+
+extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
+                             int nfft, int B, const double *tfft,
+                             const double *tfft2, int T, const double *twid,
+                             int continuum, const int32_t *lag_pos,
+                             const double *lag_vel, int nlag, const int32_t *ilo,
+                             const double *vgrid, int nvel, double beta,
+                             double *chisq, double *work, void *stream) {
+  int log2n = 0;
+  while ((2 << log2n) < nfft) log2n++;
+  if ((2 << log2n) != nfft || nfft < 16 || nfft > 16384) return RVS_E_ARG;
+  if (B < 1 || T < 1 || nlag < 2 || nvel < 1 || T > 65535) return RVS_E_ARG;
+  const int n2 = nfft >> 1;
+  const size_t shm1 = sizeof(double2) * (size_t)n2;
+  const size_t shm2 = shm1 + sizeof(double) * 2 * (size_t)nlag;
+  if (shm2 > 150 * 1024) return RVS_E_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)ccf_rfft_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024);
+    (void)hipFuncSetAttribute((const void *)ccf_xcorr_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024);
+    attr_set = true;
+  }
+  hipStream_t st = rvs_stream(stream);
+  hipLaunchKernelGGL(ccf_rfft_kernel, dim3(B, 2), dim3(256), shm1, st, proc_spec,
+                     proc_ivar, nfft, log2n,
+                     reinterpret_cast<const double2 *>(twid),
+                     reinterpret_cast<double2 *>(work));
+  RVS_LAUNCH_CHECK();
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
+    hipLaunchKernelGGL(
+        ccf_xcorr_kernel, dim3(T, nb), dim3(256), shm2, st,
+        reinterpret_cast<const double2 *>(work) + (int64_t)b0 * 2 * (n2 + 1),
+        nfft, log2n, reinterpret_cast<const double2 *>(tfft),
+        reinterpret_cast<const double2 *>(tfft2), T,
+        reinterpret_cast<const double2 *>(twid), continuum, lag_pos, lag_vel,
+        nlag, ilo, vgrid, nvel, beta, chisq + (int64_t)b0 * T * nvel);
+    RVS_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// argmin over (template, velocity), parabola refinement (fitter_ccf.py:218-236)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool nan_less(double a, long long ka, double b,
+                                         long long kb) {
+  // "a before b" for numpy argmin: NaN is the minimum, first occurrence wins
+  const bool an = !(a == a), bn = !(b == b);
+  if (an != bn) return an;
+  if (an) return ka < kb;
+  return (a < b) || (a == b && ka < kb);
+}
+
+__global__ void __launch_bounds__(256)
+    ccf_select_kernel(const double *__restrict__ chisq,
+                      const double *__restrict__ sse, int narm, int T,
+                      const double *__restrict__ vgrid, int nvel,
+                      double *__restrict__ res, double *__restrict__ best_ccf,
+                      int32_t *__restrict__ status) {
+  __shared__ double sv[4];
+  __shared__ long long sk[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double tot = 0;
+  for (int a = 0; a < narm; a++) tot += sse[(int64_t)a * gridDim.x + b];
+  const double *c = chisq + (int64_t)b * T * nvel;
+  // best_id = argmin_t min_v; min over a row containing NaN is NaN.  The
+  // lexicographic (value, t*nvel+v) minimum gives the first template whose row
+  // minimum is smallest AND, inside it, the first velocity of that minimum.
+  // A NaN anywhere in a row makes that row's min NaN: handled by NaN-first order
+  // with key = t*nvel (row start) so the earliest NaN row wins as in numpy.
+  double bv = __builtin_inf();
+  long long bk = (1ll << 62);
+  for (int e = tid; e < T * nvel; e += 256) {
+    const double x = c[e] + tot;
+    if (nan_less(x, e, bv, bk)) {
+      bv = x;
+      bk = e;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(bv, o, 64);
+    const long long ok = __shfl_xor(bk, o, 64);
+    if (nan_less(ov, ok, bv, bk)) {
+      bv = ov;
+      bk = ok;
+    }
+  }
+  if ((tid & 63) == 0) {
+    sv[tid >> 6] = bv;
+    sk[tid >> 6] = bk;
+  }
+  __syncthreads();
+  bv = sv[0];
+  bk = sk[0];
+  for (int w = 1; w < 4; w++)
+    if (nan_less(sv[w], sk[w], bv, bk)) {
+      bv = sv[w];
+      bk = sk[w];
+    }
+  const int best_id = (int)(bk / nvel);
+  const double *row = c + (int64_t)best_id * nvel;
+  for (int v = tid; v < nvel; v += 256)
+    best_ccf[(int64_t)b * nvel + v] = row[v] + tot;
+  if (tid == 0) {
+    // first minimum inside the winning row (np.argmin(best_ccf))
+    int bp = 0;
+    double mv = row[0] + tot;
+    for (int v = 1; v < nvel; v++) {
+      const double x = row[v] + tot;
+      if (nan_less(x, v, mv, bp)) {
+        mv = x;
+        bp = v;
+      }
+    }
+    double vel = vgrid[bp];
+    if (bp != 0 && bp != nvel - 1) {
+      const double xa = vgrid[bp - 1], xb = vgrid[bp], xc = vgrid[bp + 1];
+      const double ya = row[bp - 1] + tot, yb = row[bp] + tot, yc = row[bp + 1] + tot;
+      const double d1 = (yb - ya) / (xb - xa), d2 = (yc - yb) / (xc - xb);
+      const double a2 = (d2 - d1) / (xc - xa);
+      if (a2 > 0) vel = xb - (d1 + a2 * (xb - xa)) / (2 * a2);
+    }
+    int st = 0;
+    if (!(fabs(mv) <= 1.79e308)) st |= RVS_ST_CCF_FAILED;
+    double *r = res + (int64_t)b * 4;
+    r[0] = best_id;
+    r[1] = vel;
+    r[2] = bp;
+    r[3] = mv;
+    if (st && status) atomicOr(&status[b], st);
+  }
+}
+
+extern "C" int rvs_ccf_select(const double *chisq, const double *sse,
+                              int narm_sse, int B, int T, const double *vgrid,
+                              int nvel, double *res, double *best_ccf,
+                              int32_t *status, void *stream) {
+  if (B < 1 || T < 1 || nvel < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(ccf_select_kernel, dim3(B), dim3(256), 0,
+                     rvs_stream(stream), chisq, sse, narm_sse, T, vgrid, nvel,
+                     res, best_ccf, status);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,697 @@
+// chisq.hip -- Doppler resample + continuum-marginalised chi^2 (SURVEY rows
+// A7-eval, A10, A11, A12, A13) for gfx950.
+//
+// Reference: py/rvspecfit/spec_fit.py:203-354 (get_chisq0), :707-727 (evalRV),
+// :797-989 (get_chisq), :992-1092 (find_best), src/spliner.c:71-108 (evaler).
+//
+// Layout of the hot kernel (chisq_grid_kernel):
+//   * one LANE per velocity, one wave per 64 velocities of one (spectrum,
+//     template) job, looping over the observed pixels of the arm;
+//   * everything that does not depend on the velocity -- the continuum basis
+//     row P_i(k), 1/e_k^2, s_k/e_k^2, the pixel's knot coordinate -- is
+//     wave-uniform and is fetched through the scalar cache (s_load) and fed to
+//     v_fma_f64 as an SGPR operand: no LDS, no cross-lane traffic;
+//   * the spline coefficients of the ~dozen knots a wave touches per pixel
+//     come through the vector L1 (one 32-B record per knot);
+//   * the (p+1)(p+2)/2 - 1 normal-equation sums live in registers; because a
+//     lane owns its velocity there is NO reduction -- the p x p Cholesky is
+//     done in-lane, fully unrolled.
+// The basis products are exactly the reference's: Minv_ij = sum_k (P_i t/e)(P_j t/e),
+// v_i = sum_k (P_i t/e)(s/e); -2logL = logdet + 2 sum log e + (D.D - y.y),
+// y = L^-1 v, which equals |D - a^T ST|^2 of spec_fit.py:249/298.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// work buffer layout (doubles): [0, npix) pixel knot coordinate
+//   (log lam_k - log x0)/logstep   (or (lam_k - x0)/step for linear knots)
+// [npix, npix + 2*S*npix) {1/e^2, s/e^2} per spectrum pixel
+// then [2*S] {sum log e, sum s^2/e^2}
+// ---------------------------------------------------------------------------
+extern "C" int64_t rvs_chisq_work_size(int npix, int S) {
+  return (int64_t)npix + 2ll * S * npix + 2ll * S;
+}
+
+__global__ void __launch_bounds__(256)
+    chisq_prepare_kernel(const double *__restrict__ lam,
+                         const double *__restrict__ spec,
+                         const double *__restrict__ espec, int npix, int S,
+                         double x0, double inv_step, int log_step,
+                         double espec_sys, double *__restrict__ work) {
+  __shared__ double red[8];
+  const int s = blockIdx.x;
+  double *pixa = work;
+  double2 *W = reinterpret_cast<double2 *>(work + npix);
+  double *scal = work + npix + 2ll * S * npix;
+  if (s == S) {  // extra block: per-arm pixel coordinates
+    const double lx0 = log(x0);
+    for (int k = threadIdx.x; k < npix; k += 256)
+      pixa[k] = log_step ? (log(lam[k]) - lx0) * inv_step
+                         : (lam[k] - x0) * inv_step;
+    return;
+  }
+  double lz = 0, dd = 0;
+  const double sys2 = espec_sys * espec_sys;
+  for (int k = threadIdx.x; k < npix; k += 256) {
+    double e = espec[(int64_t)s * npix + k];
+    if (espec_sys > 0) e = sqrt(sys2 + e * e);
+    const double sp = spec[(int64_t)s * npix + k];
+    const double d = sp / e;
+    lz += log(e);
+    dd += d * d;
+    W[(int64_t)s * npix + k] = make_double2(1.0 / (e * e), sp / (e * e));
+  }
+  lz = block_sum<4>(lz, red);
+  dd = block_sum<4>(dd, red);
+  if (threadIdx.x == 0) {
+    scal[2 * s] = lz;
+    scal[2 * s + 1] = dd;
+  }
+}
+
+// packed lower-triangular index
+#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+
+template <int P>
+__global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
+    chisq_grid_kernel(const double *__restrict__ lam,
+                      const double *__restrict__ polysT,
+                      const double *__restrict__ work, int npix, int S,
+                      const double *__restrict__ knots,
+                      const double4 *__restrict__ coef, int ntp, int log_step,
+                      const int32_t *__restrict__ job_spec,
+                      const int32_t *__restrict__ job_templ,
+                      const double *__restrict__ vels, int64_t vel_stride,
+                      int Nv, const double *__restrict__ penalty, double badchi,
+                      double beta_out, double *__restrict__ out,
+                      int32_t *__restrict__ status) {
+  const int j = blockIdx.y;
+  const int wave_v0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+  if (wave_v0 >= Nv) return;  // whole wave idle
+  const int iv = blockIdx.x * 256 + threadIdx.x;
+  const bool active = iv < Nv;
+  const int s = job_spec ? job_spec[j] : j;
+  const int t = job_templ ? job_templ[j] : j;
+  double *outp = out + (int64_t)j * Nv;
+
+  const double pen = penalty ? penalty[j] : 0.0;
+  if (!(pen == pen) || isinf(pen)) {
+    // template unusable (non finite outside flag): spec_fit.py:888-893
+    if (active) {
+      const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
+      outp[iv] = base + 1000.0 * badchi;
+    }
+    return;
+  }
+
+  const double *pixa = work;
+  const double2 *W = reinterpret_cast<const double2 *>(work + npix) +
+                     (int64_t)s * npix;
+  const double *scal = work + npix + 2ll * S * npix + 2 * s;
+  const double4 *cf = coef + (int64_t)t * ntp;
+
+  const double vel = vels[(int64_t)j * vel_stride + (active ? iv : 0)];
+  const double bb = vel / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double x0 = knots[0], xlast = knots[ntp - 1];
+  double shift;  // knot-coordinate shift of this velocity
+  if (log_step) {
+    const double inv_step = 1.0 / log(knots[1] / x0);
+    shift = log(f) * inv_step;
+  } else {
+    shift = 0;  // linear knots: coordinate scales instead of shifting
+  }
+  const double lin_inv_step = log_step ? 0.0 : 1.0 / (knots[1] - x0);
+
+  int32_t st = 0;
+  {  // evaler's range test on the first and last pixel (spliner.c:78-83)
+    const double xa = lam[0] * f, xb = lam[npix - 1] * f;
+    if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast)
+      st |= RVS_ST_SPLINE_RANGE;
+  }
+
+  double acc[P * (P + 1) / 2];
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < P * (P + 1) / 2; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = 0;
+
+  for (int k = 0; k < npix; k++) {
+    const double lk = lam[k];          // wave-uniform -> scalar loads
+    const double ak = pixa[k];
+    const double2 wk = W[k];
+    const double x = lk * f;
+    int pos;
+    if (log_step)
+      pos = (int)(ak + shift);
+    else
+      pos = (int)((x - x0) * lin_inv_step);
+    pos = min(max(pos, 0), ntp - 2);
+    double xl = knots[pos], xr = knots[pos + 1];
+    // the estimate is within rounding of the true interval; repair it so that
+    // xl <= x < xr exactly as the reference's (int)((log x - log x0)/step)
+    const int adj = (x < xl && pos > 0) ? -1 : ((x >= xr && pos < ntp - 2) ? 1 : 0);
+    if (adj != 0) {
+      pos += adj;
+      xl = knots[pos];
+      xr = knots[pos + 1];
+    }
+    const double4 c = cf[pos];
+    const double dl = x - xl, dr = xr - x;
+    const double tv = c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
+    const double w = tv * tv * wk.x;   // (t/e)^2
+    const double u = tv * wk.y;        // t s / e^2
+    const double *pr = polysT + (int64_t)k * P;
+    double pw[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      av[i] = fma(pr[i], u, av[i]);
+#pragma unroll
+      for (int jj = 0; jj <= i; jj++)
+        acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
+    }
+  }
+
+  // in-lane Cholesky of the packed normal matrix (spec_fit.py:230-247)
+  bool ok = true;
+  double ldet = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+#pragma unroll
+    for (int jj = 0; jj <= i; jj++) {
+      double sum = acc[TRI(i, jj)];
+#pragma unroll
+      for (int k = 0; k < jj; k++) sum -= acc[TRI(i, k)] * acc[TRI(jj, k)];
+      if (jj == i) {
+        if (!(sum > 0)) ok = false;
+        const double d = sqrt(sum);
+        acc[TRI(i, i)] = d;
+        ldet += log(d);
+      } else {
+        acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
+      }
+    }
+  }
+  double yy = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    double sum = av[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) sum -= acc[TRI(i, k)] * av[k];
+    av[i] = sum / acc[TRI(i, i)];
+    yy = fma(av[i], av[i], yy);
+  }
+  double chi = 2.0 * ldet + 2.0 * scal[0] + (scal[1] - yy);
+  if (st & RVS_ST_SPLINE_RANGE) chi = __builtin_nan("");
+  if (!ok) st |= RVS_ST_CHOL_FALLBACK;
+  if (!ok || !(fabs(chi) <= 1.79e308)) {
+    st |= RVS_ST_NONFINITE;
+    chi = __builtin_nan("");
+  }
+  if (active) {
+    const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
+    outp[iv] = base + chi + pen;
+    if (st) atomicOr(&status[j], st);
+  }
+}
+
+template <int P>
+static int launch_grid(const double *lam, const double *polysT,
+                       const double *work, int npix, int S, const double *knots,
+                       const double *coef, int ntp, int log_step,
+                       const int32_t *job_spec, const int32_t *job_templ, int J,
+                       const double *vels, int64_t vel_stride, int Nv,
+                       const double *penalty, double badchi, double beta,
+                       double *out, int32_t *status, hipStream_t st) {
+  dim3 grid((Nv + 255) / 256, J);
+  hipLaunchKernelGGL(chisq_grid_kernel<P>, grid, dim3(256), 0, st, lam, polysT,
+                     work, npix, S, knots,
+                     reinterpret_cast<const double4 *>(coef), ntp, log_step,
+                     job_spec, job_templ, vels, vel_stride, Nv, penalty, badchi,
+                     beta, out, status);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rvs_chisq_prepare(const double *lam, const double *spec,
+                                 const double *espec, int npix, int S,
+                                 const double *knots_host3, int log_step,
+                                 double espec_sys, double *work, void *stream) {
+  // knots_host3: HOST pointer to the first three knots (uniformity test of
+  // spliner.c:84-96 is done here, on the host, once per arm)
+  if (npix < 1 || S < 1 || !work) return RVS_E_ARG;
+  const double x0 = knots_host3[0], x1 = knots_host3[1], x2 = knots_host3[2];
+  double step, step2;
+  if (log_step) {
+    step = log(x1 / x0);
+    step2 = log(x2 / x1);
+  } else {
+    step = x1 - x0;
+    step2 = x2 - x1;
+  }
+  if (fabs(step - step2) > 1e-10) return -3;  // evaler's -2
+  hipLaunchKernelGGL(chisq_prepare_kernel, dim3(S + 1), dim3(256), 0,
+                     rvs_stream(stream), lam, spec, espec, npix, S, x0,
+                     1.0 / step, log_step, espec_sys, work);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rvs_chisq_grid(const double *lam, const double *polysT,
+                              const double *work, int npix, int npoly, int S,
+                              const double *knots, const double *coef, int ntp,
+                              int Tn, int log_step, const int32_t *job_spec,
+                              const int32_t *job_templ, int J,
+                              const double *vels, int64_t vel_stride, int Nv,
+                              const double *penalty, double badchi, double beta,
+                              double *out, int32_t *status, void *stream) {
+  (void)Tn;
+  if (J < 1 || Nv < 1 || npix < 1 || ntp < 3) return RVS_E_ARG;
+  if (J > 65535) return RVS_E_ARG;  // grid.y limit; callers chunk
+  hipStream_t st = rvs_stream(stream);
+#define RVS_CASE(PP)                                                          \
+  case PP:                                                                    \
+    return launch_grid<PP>(lam, polysT, work, npix, S, knots, coef, ntp,      \
+                           log_step, job_spec, job_templ, J, vels, vel_stride, \
+                           Nv, penalty, badchi, beta, out, status, st);
+  switch (npoly) {
+    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
+    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
+    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
+    default:
+      return RVS_E_ARG;
+  }
+#undef RVS_CASE
+}
+
+// ---------------------------------------------------------------------------
+// full output for one velocity per job (spec_fit.py:941-961) and the
+// continuum-only fit (spec_fit.py:739-783).  One 256-thread block per job.
+// ---------------------------------------------------------------------------
+#define FULL_MAXP 32
+__device__ void jacobi_eig_dev(double *M, int p, double *w, double *V) {
+  for (int i = 0; i < p; i++)
+    for (int j = 0; j < p; j++) V[i * p + j] = (i == j);
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int i = 0; i < p; i++)
+      for (int j = i + 1; j < p; j++) off += M[i * p + j] * M[i * p + j];
+    if (off < 1e-300) break;
+    for (int a = 0; a < p; a++)
+      for (int b = a + 1; b < p; b++) {
+        const double apq = M[a * p + b];
+        if (apq == 0) continue;
+        const double th = (M[b * p + b] - M[a * p + a]) / (2 * apq);
+        const double tt = (th >= 0 ? 1. : -1.) / (fabs(th) + sqrt(th * th + 1));
+        const double c = 1 / sqrt(tt * tt + 1), sn = tt * c;
+        for (int k = 0; k < p; k++) {
+          const double ka = M[k * p + a], kb = M[k * p + b];
+          M[k * p + a] = c * ka - sn * kb;
+          M[k * p + b] = sn * ka + c * kb;
+        }
+        for (int k = 0; k < p; k++) {
+          const double ak = M[a * p + k], bk = M[b * p + k];
+          M[a * p + k] = c * ak - sn * bk;
+          M[b * p + k] = sn * ak + c * bk;
+        }
+        for (int k = 0; k < p; k++) {
+          const double ka = V[k * p + a], kb = V[k * p + b];
+          V[k * p + a] = c * ka - sn * kb;
+          V[k * p + b] = sn * ka + c * kb;
+        }
+      }
+  }
+  for (int i = 0; i < p; i++) w[i] = M[i * p + i];
+}
+
+__global__ void __launch_bounds__(256)
+    chisq_full_kernel(const double *__restrict__ lam,
+                      const double *__restrict__ polysT,
+                      const double *__restrict__ spec,
+                      const double *__restrict__ espec,
+                      const uint8_t *__restrict__ badmask, int npix, int P,
+                      const double *__restrict__ knots,
+                      const double4 *__restrict__ coef, int ntp, int log_step,
+                      int unit_template, const int32_t *__restrict__ job_spec,
+                      const int32_t *__restrict__ job_templ,
+                      const double *__restrict__ vel, double espec_sys,
+                      double *__restrict__ chisq, double *__restrict__ coeffs,
+                      double *__restrict__ model, double *__restrict__ raw_model,
+                      double *__restrict__ true_chisq, int32_t *__restrict__ ngood,
+                      int32_t *__restrict__ status) {
+  extern __shared__ double sm[];
+  double *tvs = sm;                 // [npix]   template / e
+  double *Ds = sm + npix;           // [npix]   spec / e
+  double *Mm = Ds + npix;           // [P*P]
+  double *vv = Mm + FULL_MAXP * FULL_MAXP;  // [P]
+  double *aa = vv + FULL_MAXP;      // [P]
+  double *red = aa + FULL_MAXP;     // [8]
+  double *scr = red + 8;            // [2*P*P + P] jacobi scratch
+  __shared__ int sh_st;
+  const int j = blockIdx.x;
+  const int s = job_spec ? job_spec[j] : j;
+  const int t = job_templ ? job_templ[j] : j;
+  const int tid = threadIdx.x;
+  if (tid == 0) sh_st = 0;
+  __syncthreads();
+  const double *sp = spec + (int64_t)s * npix;
+  const double *es = espec + (int64_t)s * npix;
+  const double sys2 = espec_sys * espec_sys;
+  double f = 1, x0 = 0, xlast = 0, inv_step = 0, lx0 = 0;
+  const double4 *cf = coef + (int64_t)t * ntp;
+  if (!unit_template) {
+    const double bb = vel[j] / RVS_C_KMS;
+    f = sqrt((1.0 - bb) / (1.0 + bb));
+    x0 = knots[0];
+    xlast = knots[ntp - 1];
+    inv_step = log_step ? 1.0 / log(knots[1] / x0) : 1.0 / (knots[1] - x0);
+    lx0 = log(x0);
+    const double xa = lam[0] * f, xb = lam[npix - 1] * f;
+    if ((xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) && tid == 0)
+      atomicOr(&sh_st, RVS_ST_SPLINE_RANGE);
+  }
+  double lz = 0;
+  for (int k = tid; k < npix; k += 256) {
+    double tv = 1.0;
+    if (!unit_template) {
+      const double x = lam[k] * f;
+      int pos = log_step ? (int)((log(x) - lx0) * inv_step)
+                         : (int)((x - x0) * inv_step);
+      pos = min(max(pos, 0), ntp - 2);
+      const double4 c = cf[pos];
+      const double dl = x - knots[pos], dr = knots[pos + 1] - x;
+      tv = c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
+    }
+    if (raw_model) raw_model[(int64_t)j * npix + k] = tv;
+    double e = es[k];
+    if (espec_sys > 0) e = sqrt(sys2 + e * e);
+    lz += log(e);
+    tvs[k] = tv / e;
+    Ds[k] = sp[k] / e;
+  }
+  lz = block_sum<4>(lz, red);
+  __syncthreads();
+  // normal equations: thread e owns one entry
+  const int NE = P * (P + 1) / 2 + P;
+  for (int e = tid; e < NE; e += 256) {
+    int i, jj;
+    bool isv = e >= P * (P + 1) / 2;
+    if (isv) {
+      i = e - P * (P + 1) / 2;
+      jj = 0;
+    } else {
+      i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while (i * (i + 1) / 2 > e) i--;
+      while ((i + 1) * (i + 2) / 2 <= e) i++;
+      jj = e - i * (i + 1) / 2;
+    }
+    double sum = 0;
+    if (isv) {
+      for (int k = 0; k < npix; k++)
+        sum += (polysT[(int64_t)k * P + i] * tvs[k]) * Ds[k];
+      vv[i] = sum;
+    } else {
+      for (int k = 0; k < npix; k++)
+        sum += (polysT[(int64_t)k * P + i] * tvs[k]) *
+               (polysT[(int64_t)k * P + jj] * tvs[k]);
+      Mm[i * P + jj] = sum;
+      Mm[jj * P + i] = sum;
+    }
+  }
+  __syncthreads();
+  __shared__ double sh_ldet;
+  if (tid == 0) {
+    // Cholesky, eigen fallback (spec_fit.py:337-354)
+    double *L = scr;  // P*P
+    bool ok = true;
+    double ldet = 0;
+    for (int i = 0; i < P && ok; i++)
+      for (int jj = 0; jj <= i; jj++) {
+        double sum = Mm[i * P + jj];
+        for (int k = 0; k < jj; k++) sum -= L[i * P + k] * L[jj * P + k];
+        if (i == jj) {
+          if (!(sum > 0)) {
+            ok = false;
+            break;
+          }
+          L[i * P + i] = sqrt(sum);
+          ldet += 2 * log(L[i * P + i]);
+        } else
+          L[i * P + jj] = sum / L[jj * P + jj];
+      }
+    if (ok) {
+      double y[FULL_MAXP];
+      for (int i = 0; i < P; i++) {
+        double sum = vv[i];
+        for (int k = 0; k < i; k++) sum -= L[i * P + k] * y[k];
+        y[i] = sum / L[i * P + i];
+      }
+      for (int i = P - 1; i >= 0; i--) {
+        double sum = y[i];
+        for (int k = i + 1; k < P; k++) sum -= L[k * P + i] * aa[k];
+        aa[i] = sum / L[i * P + i];
+      }
+      if (!(fabs(ldet) <= 1.79e308)) ok = false;
+    }
+    if (!ok) {
+      atomicOr(&sh_st, RVS_ST_CHOL_FALLBACK);
+      double *Wk = scr, *V = scr + P * P;
+      double w[FULL_MAXP];
+      for (int i = 0; i < P * P; i++) Wk[i] = Mm[i];
+      jacobi_eig_dev(Wk, P, w, V);
+      ldet = 0;
+      for (int i = 0; i < P; i++) ldet += log(fabs(w[i]));
+      for (int i = 0; i < P; i++) {
+        double sum = 0;
+        for (int q = 0; q < P; q++) {
+          double vq = 0;
+          for (int k = 0; k < P; k++) vq += V[k * P + q] * vv[k];
+          sum += V[i * P + q] * vq / w[q];
+        }
+        aa[i] = sum;
+      }
+    }
+    sh_ldet = ldet;
+  }
+  __syncthreads();
+  double res = 0, tc = 0;
+  int ng = 0;
+  for (int k = tid; k < npix; k += 256) {
+    double m = 0;
+    for (int i = 0; i < P; i++) m += aa[i] * polysT[(int64_t)k * P + i];
+    const double r = Ds[k] - m * tvs[k];
+    res += r * r;
+    // model in flux units: coeffs . (polys * templ); true chi^2 uses the
+    // ORIGINAL error vector (spec_fit.py:952)
+    double e = es[k];
+    double ee = e;
+    if (espec_sys > 0) ee = sqrt(sys2 + e * e);
+    const double mod = m * tvs[k] * ee;
+    if (model) model[(int64_t)j * npix + k] = mod;
+    const double dev = (mod - sp[k]) / e;
+    const bool good = badmask ? (badmask[(int64_t)s * npix + k] == 0) : true;
+    if (good) {
+      tc += dev * dev;
+      ng++;
+    }
+  }
+  res = block_sum<4>(res, red);
+  tc = block_sum<4>(tc, red);
+  const double ngd = block_sum<4>((double)ng, red);
+  if (tid == 0) {
+    double chi = sh_ldet + 2 * lz + res;
+    int st = sh_st;
+    if (st & RVS_ST_SPLINE_RANGE) chi = __builtin_nan("");
+    if (!(fabs(chi) <= 1.79e308)) st |= RVS_ST_NONFINITE;
+    chisq[j] = chi;
+    true_chisq[j] = tc;
+    ngood[j] = (int)ngd;
+    if (st) atomicOr(&status[j], st);
+  }
+  if (coeffs)
+    for (int i = tid; i < P; i += 256) coeffs[(int64_t)j * P + i] = aa[i];
+}
+
+extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
+                              const double *spec, const double *espec,
+                              const uint8_t *badmask, int npix, int npoly,
+                              int S, const double *knots, const double *coef,
+                              int ntp, int Tn, int log_step, int unit_template,
+                              const int32_t *job_spec, const int32_t *job_templ,
+                              int J, const double *vel, double espec_sys,
+                              double *chisq, double *coeffs, double *model,
+                              double *raw_model, double *true_chisq,
+                              int32_t *ngood, int32_t *status, void *stream) {
+  (void)S;
+  (void)Tn;
+  if (npoly < 1 || npoly > FULL_MAXP || J < 1 || npix < 1) return RVS_E_ARG;
+  const size_t shm = sizeof(double) * (2 * (size_t)npix + FULL_MAXP * FULL_MAXP +
+                                       2 * FULL_MAXP + 8 +
+                                       2 * FULL_MAXP * FULL_MAXP + FULL_MAXP);
+  if (shm > 160 * 1024) return RVS_E_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)chisq_full_kernel,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(chisq_full_kernel, dim3(J), dim3(256), shm,
+                     rvs_stream(stream), lam, polysT, spec, espec, badmask,
+                     npix, npoly, knots, reinterpret_cast<const double4 *>(coef),
+                     ntp, log_step, unit_template, job_spec, job_templ, vel,
+                     espec_sys, chisq, coeffs, model, raw_model, true_chisq,
+                     ngood, status);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// A12: find_best tail (spec_fit.py:1072-1092).  One 256-thread block / group.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    grid_moments_kernel(const double *__restrict__ chisq,
+                        const double *__restrict__ vels, int64_t vel_stride,
+                        const int32_t *__restrict__ nvel, int Np, int Nv,
+                        int quadratic, double *__restrict__ res,
+                        double *__restrict__ probs,
+                        int32_t *__restrict__ status) {
+  __shared__ double red[8];
+  __shared__ double sh_val[4];
+  __shared__ long long sh_key[4];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int nv = nvel ? nvel[g] : Nv;
+  const double *c = chisq + (int64_t)g * Np * Nv;
+  const double *v = vels + (int64_t)g * vel_stride;
+  // np.argmin over the reference's [Nv, Np] array: first occurrence in
+  // velocity-major order; NaN wins (numpy argmin returns the first NaN)
+  double bval = __builtin_inf();
+  long long bkey = (1ll << 62);
+  bool bnan = false;
+  for (int e = tid; e < Np * nv; e += 256) {
+    const int p = e / nv, i = e - p * nv;
+    const double x = c[(int64_t)p * Nv + i];
+    const long long key = (long long)i * Np + p;
+    const bool xn = !(x == x);
+    bool better;
+    if (xn != bnan)
+      better = xn;
+    else if (xn)
+      better = key < bkey;
+    else
+      better = (x < bval) || (x == bval && key < bkey);
+    if (better) {
+      bval = x;
+      bkey = key;
+      bnan = xn;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(bval, o, 64);
+    const long long ok = __shfl_xor(bkey, o, 64);
+    const bool on = !(ov == ov);
+    bool better;
+    if (on != bnan)
+      better = on;
+    else if (on)
+      better = ok < bkey;
+    else
+      better = (ov < bval) || (ov == bval && ok < bkey);
+    if (better) {
+      bval = ov;
+      bkey = ok;
+      bnan = on;
+    }
+  }
+  if ((tid & 63) == 0) {
+    sh_val[tid >> 6] = bval;
+    sh_key[tid >> 6] = bkey;
+  }
+  __syncthreads();
+  bval = sh_val[0];
+  bkey = sh_key[0];
+  bnan = !(bval == bval);
+  for (int w = 1; w < 4; w++) {
+    const double ov = sh_val[w];
+    const long long ok = sh_key[w];
+    const bool on = !(ov == ov);
+    bool better;
+    if (on != bnan)
+      better = on;
+    else if (on)
+      better = ok < bkey;
+    else
+      better = (ov < bval) || (ov == bval && ok < bkey);
+    if (better) {
+      bval = ov;
+      bkey = ok;
+      bnan = on;
+    }
+  }
+  const int i1 = (int)(bkey / Np), i2 = (int)(bkey % Np);
+  const double *col = c + (int64_t)i2 * Nv;
+  double psum = 0;
+  for (int i = tid; i < nv; i += 256) psum += exp(-0.5 * (col[i] - bval));
+  psum = block_sum<4>(psum, red);
+  double bv = v[i1];
+  int st = 0;
+  if (quadratic && i1 > 0 && i1 < nv - 1) {
+    // vertex of the parabola through 3 points (np.polyfit deg 2 is exact for
+    // 3 points); computed around the centre point to limit cancellation
+    const double xa = v[i1 - 1], xb = v[i1], xc = v[i1 + 1];
+    const double ya = col[i1 - 1], yb = col[i1], yc = col[i1 + 1];
+    const double d1 = (yb - ya) / (xb - xa), d2 = (yc - yb) / (xc - xb);
+    const double a2 = (d2 - d1) / (xc - xa);
+    const double b1 = d1 + a2 * (xb - xa);  // slope at xb
+    bv = xb - b1 / (2 * a2);
+    if (!(bv < xc && bv > xa)) st |= RVS_ST_QUAD_ASSERT;
+  }
+  double m2 = 0, m3 = 0, m4 = 0;
+  for (int i = tid; i < nv; i += 256) {
+    const double pr = exp(-0.5 * (col[i] - bval)) / psum;
+    if (probs) probs[(int64_t)g * Nv + i] = pr;
+    const double d = v[i] - bv;
+    m2 += pr * d * d;
+    m3 += pr * d * d * d;
+    m4 += pr * d * d * d * d;
+  }
+  if (probs)
+    for (int i = nv + tid; i < Nv; i += 256) probs[(int64_t)g * Nv + i] = 0;
+  m2 = block_sum<4>(m2, red);
+  m3 = block_sum<4>(m3, red);
+  m4 = block_sum<4>(m4, red);
+  if (tid == 0) {
+    const double err = sqrt(m2);
+    double kur = 0, skw = 0;
+    if (!(err < 1e-10)) {
+      kur = m4 / (err * err * err * err);
+      skw = m3 / (err * err * err);
+    }
+    double *r = res + (int64_t)g * 8;
+    r[0] = bval;
+    r[1] = bv;
+    r[2] = err;
+    r[3] = kur;
+    r[4] = skw;
+    r[5] = i1;
+    r[6] = i2;
+    r[7] = psum;
+    if (st && status) atomicOr(&status[g], st);
+  }
+}
+
+extern "C" int rvs_grid_moments(const double *chisq, const double *vels,
+                                int64_t vel_stride, const int32_t *nvel, int G,
+                                int Np, int Nv, int quadratic, double *res,
+                                double *probs, int32_t *status, void *stream) {
+  if (G < 1 || Np < 1 || Nv < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(grid_moments_kernel, dim3(G), dim3(256), 0,
+                     rvs_stream(stream), chisq, vels, vel_stride, nvel, Np, Nv,
+                     quadratic, res, probs, status);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rvs_abi_version(void) { return 1; }

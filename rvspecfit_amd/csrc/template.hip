@@ -1,0 +1,518 @@
+// template.hip -- template construction kernels for gfx950 (SURVEY rows A3, A5,
+// A6, A7): polylinear gather/lerp/exp on a regular n-D grid, rotational
+// broadening FIR, natural-cubic-spline construct and the stand-alone evaluator.
+//
+// Reference: py/rvspecfit/spec_inter.py:62-194, read_grid.py:127-145,
+// spec_fit.py:357-407 (getCurTempl), :495-682 (vsini), src/spliner.c:7-108.
+#include "common.h"
+
+#define MAXDIM 6
+
+struct GridDesc {
+  int ndim;
+  int lens[MAXDIM];
+  int uoff[MAXDIM];       // offset of dimension d in the concatenated uvecs
+  int64_t gstride[MAXDIM];  // C-order strides of idgrid
+  double inv_ptp[MAXDIM];
+  uint32_t log_mask;
+};
+
+// np.searchsorted(u, x, 'right') - 1  == np.digitize(x, u) - 1
+__device__ __forceinline__ int cell_index(const double *u, int n, double x) {
+  if (!(x == x)) return n - 1;  // NaN sorts to the end
+  int lo = 0, hi = n;           // first index with u[idx] > x
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (u[mid] <= x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo - 1;
+}
+
+// One 256-thread block per spectrum.  The 2^ndim vertex rows are contiguous
+// float32 rows of `dats`: consecutive lanes read consecutive pixels (coalesced
+// 4-B loads; rows are re-read by every spectrum sharing a cell and stay in L2 /
+// Infinity Cache).  Accumulation is float64 in vertex (itertools.product) order.
+__global__ void __launch_bounds__(256)
+    polylinear_kernel(const float *__restrict__ dats, int64_t ngrid, int ntp,
+                      const int64_t *__restrict__ idgrid,
+                      const double *__restrict__ uvecs, GridDesc G,
+                      const double *__restrict__ vecs_s, int exp_flag,
+                      const double *__restrict__ params, double *__restrict__ templ,
+                      double *__restrict__ outside, int32_t *__restrict__ cellinfo,
+                      double *__restrict__ weights) {
+  __shared__ double sh_w[1 << MAXDIM];
+  __shared__ int64_t sh_id[1 << MAXDIM];
+  __shared__ int sh_mode, sh_nearest;
+  __shared__ double sh_dist;
+  __shared__ double sh_mp[MAXDIM];
+  __shared__ double red_d[4];
+  __shared__ int red_i[4];
+  __shared__ double red_m[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nd = G.ndim, nv = 1 << nd;
+  if (tid == 0) {
+    bool finite = true, outsidebox = false;
+    int pos[MAXDIM];
+    for (int d = 0; d < nd; d++) {
+      double v = params[(int64_t)b * nd + d];
+      if (G.log_mask & (1u << d)) v = log10(v);
+      sh_mp[d] = v;
+      if (!(fabs(v) <= 1.79e308)) finite = false;
+      pos[d] = cell_index(uvecs + G.uoff[d], G.lens[d], v);
+      if (pos[d] < 0 || pos[d] >= G.lens[d] - 1) outsidebox = true;
+    }
+    int mode = 0;
+    if (outsidebox) {
+      mode = finite ? 1 : 2;
+    } else {
+      // vertices in itertools.product([0,1]^ndim) order: first dim slowest
+      for (int v = 0; v < nv; v++) {
+        int64_t off = 0;
+        for (int d = 0; d < nd; d++) {
+          const int bit = (v >> (nd - 1 - d)) & 1;
+          off += (int64_t)(pos[d] + bit) * G.gstride[d];
+        }
+        const int64_t id = idgrid[off];
+        sh_id[v] = id;
+        if (id < 0) mode = 1;
+      }
+      if (mode == 0) {
+        double x[MAXDIM];
+        for (int d = 0; d < nd; d++) {
+          const double *u = uvecs + G.uoff[d];
+          x[d] = (sh_mp[d] - u[pos[d]]) / (u[pos[d] + 1] - u[pos[d]]);
+        }
+        for (int v = 0; v < nv; v++) {
+          double w = 1;
+          for (int d = 0; d < nd; d++)
+            w *= ((v >> (nd - 1 - d)) & 1) ? x[d] : (1 - x[d]);
+          sh_w[v] = w;
+        }
+      }
+    }
+    sh_mode = mode;
+  }
+  __syncthreads();
+  const int mode = sh_mode;
+  if (mode == 1) {
+    // brute-force nearest neighbour in ptp-scaled space (== cKDTree.query,
+    // spec_inter.py:127-132); first minimum wins
+    double q[MAXDIM];
+    for (int d = 0; d < nd; d++) q[d] = sh_mp[d] * G.inv_ptp[d];
+    double bd = __builtin_inf();
+    int bi = 0x7fffffff;
+    for (int64_t g = tid; g < ngrid; g += 256) {
+      double d2 = 0;
+      for (int d = 0; d < nd; d++) {
+        const double df = vecs_s[g * nd + d] - q[d];
+        d2 += df * df;
+      }
+      if (d2 < bd) {
+        bd = d2;
+        bi = (int)g;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double od = __shfl_xor(bd, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (od < bd || (od == bd && oi < bi)) {
+        bd = od;
+        bi = oi;
+      }
+    }
+    if ((tid & 63) == 0) {
+      red_d[tid >> 6] = bd;
+      red_i[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; w++)
+        if (red_d[w] < bd || (red_d[w] == bd && red_i[w] < bi)) {
+          bd = red_d[w];
+          bi = red_i[w];
+        }
+      sh_nearest = bi;
+      sh_dist = sqrt(bd);
+    }
+    __syncthreads();
+  } else if (tid == 0) {
+    sh_nearest = (mode == 2) ? 0 : -1;
+    sh_dist = (mode == 2) ? __builtin_inf() : 0.0;
+  }
+  __syncthreads();
+  double *out = templ + (int64_t)b * ntp;
+  double mx = 0;
+  bool anynan = false;
+  if (mode == 0) {
+    for (int k = tid; k < ntp; k += 256) {
+      double acc = 0;
+      for (int v = 0; v < nv; v++)
+        acc = fma(sh_w[v], (double)dats[sh_id[v] * ntp + k], acc);
+      const double val = exp_flag ? exp(acc) : acc;
+      out[k] = val;
+    }
+  } else {
+    // FF(self.dats[ret]) on a float32 row: numpy evaluates exp in float32
+    const float *row = dats + (int64_t)sh_nearest * ntp;
+    for (int k = tid; k < ntp; k += 256) {
+      const double val = exp_flag ? (double)expf(row[k]) : (double)row[k];
+      out[k] = val;
+      if (!(val == val)) anynan = true;
+      mx = fmax(mx, fabs(val));
+    }
+  }
+  if (mode != 0) {
+    // MAX_VAL guard (spec_fit.py:392-397): only for outside > 0
+    mx = wave_max(mx);
+    double nanf = wave_sum(anynan ? 1.0 : 0.0);
+    if ((tid & 63) == 0) {
+      red_m[tid >> 6] = mx;
+      red_m[4 + (tid >> 6)] = nanf;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double m = fmax(fmax(red_m[0], red_m[1]), fmax(red_m[2], red_m[3]));
+      const double nn = red_m[4] + red_m[5] + red_m[6] + red_m[7];
+      double o = sh_dist;
+      if (o > 0 && (m > 1e100 || nn > 0 || isinf(m))) o = __builtin_nan("");
+      outside[b] = o;
+    }
+  } else if (tid == 0) {
+    outside[b] = 0.0;
+  }
+  if (cellinfo && tid == 0) {
+    int32_t *ci = cellinfo + (int64_t)b * (2 + nv);
+    ci[0] = mode;
+    ci[1] = sh_nearest;
+    for (int v = 0; v < nv; v++) ci[2 + v] = (mode == 0) ? (int32_t)sh_id[v] : -1;
+  }
+  if (weights && tid < nv)
+    weights[(int64_t)b * nv + tid] = (mode == 0) ? sh_w[tid] : 0.0;
+}
+
+extern "C" int rvs_template_polylinear(
+    const float *dats, int64_t ngrid, int ntp, const int64_t *idgrid,
+    const double *uvecs, const int32_t *lens, int ndim, const double *vecs_s,
+    const double *inv_ptp, uint32_t log_mask, int exp_flag,
+    const double *params, int B, double *templ, double *outside,
+    int32_t *cellinfo, double *weights, void *stream) {
+  if (ndim < 1 || ndim > MAXDIM || B < 1 || ntp < 1) return RVS_E_ARG;
+  GridDesc G;
+  G.ndim = ndim;
+  G.log_mask = log_mask;
+  int off = 0;
+  for (int d = 0; d < ndim; d++) {
+    G.lens[d] = lens[d];
+    G.uoff[d] = off;
+    off += lens[d];
+    G.inv_ptp[d] = inv_ptp[d];
+  }
+  int64_t st = 1;
+  for (int d = ndim - 1; d >= 0; d--) {
+    G.gstride[d] = st;
+    st *= lens[d];
+  }
+  hipLaunchKernelGGL(polylinear_kernel, dim3(B), dim3(256), 0,
+                     rvs_stream(stream), dats, ngrid, ntp, idgrid, uvecs, G,
+                     vecs_s, exp_flag, params, templ, outside, cellinfo, weights);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// A6: rotational broadening (spec_fit.py:495-682)
+// ---------------------------------------------------------------------------
+#define VSINI_MAXTAP 2048  // one-sided taps kept in LDS
+
+__device__ __forceinline__ void rot_prim(double x, double eps, double &k0,
+                                         double &k1) {
+  x = fmin(fmax(x, -1.0), 1.0);
+  const double pi = 3.141592653589793;
+  const double norm = pi * (1 - eps / 3.0);
+  const double c1 = 2 * (1 - eps) / norm;
+  const double c2 = (pi / 2.0) * eps / norm;
+  const double s = sqrt(1 - x * x);
+  k0 = c1 * (0.5 * (x * s + asin(x))) + c2 * (x - x * x * x / 3.0);
+  k1 = c1 * (-1.0 / 3.0 * (1 - x * x) * s) +
+       c2 * (x * x / 2.0 - x * x * x * x / 4.0);
+}
+
+__device__ __forceinline__ double rot_segment(double xa, double xb, double slope,
+                                              double icpt, double eps) {
+  double a0, a1, b0, b1;
+  rot_prim(xb, eps, b0, b1);
+  rot_prim(xa, eps, a0, a1);
+  return slope * (b1 - a1) + icpt * (b0 - a0);
+}
+
+__global__ void __launch_bounds__(256)
+    vsini_kernel(const double *__restrict__ templ,
+                 const double *__restrict__ vsini,
+                 const double *__restrict__ outside, double lnstep, double eps,
+                 int ntp, double *__restrict__ out,
+                 int32_t *__restrict__ status) {
+  __shared__ double wpos[VSINI_MAXTAP + 1];
+  __shared__ double red[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double *in = templ + (int64_t)b * ntp;
+  double *o = out + (int64_t)b * ntp;
+  const double vs = vsini[b];
+  const double R = (vs / RVS_C_KMS) / lnstep;
+  bool copy = !(vs > 0) || (R < 1e-9);
+  if (outside) {
+    const double ov = outside[b];
+    if (!(fabs(ov) <= 1.79e308)) copy = true;  // spec_fit.py:398-404
+  }
+  int kmax = 0;
+  if (!copy) {
+    kmax = (int)ceil(R + 1);
+    if (kmax > VSINI_MAXTAP) {
+      if (tid == 0 && status) atomicOr(&status[b], RVS_ST_NONFINITE);
+      copy = true;
+    }
+  }
+  if (copy) {
+    for (int k = tid; k < ntp; k += 256) o[k] = in[k];
+    return;
+  }
+  // taps k = 0..kmax (compute_vsini_kernel, spec_fit.py:565-625)
+  double psum = 0;
+  for (int k = tid; k <= kmax; k += 256) {
+    double w = 0;
+    double lo = fmin(fmax(k / R, -1.0), 1.0), hi = fmin(fmax((k + 1) / R, -1.0), 1.0);
+    if (hi > lo) w += rot_segment(lo, hi, -R, 1.0 + k, eps);
+    lo = fmin(fmax((k - 1) / R, -1.0), 1.0);
+    hi = fmin(fmax(k / R, -1.0), 1.0);
+    if (hi > lo) w += rot_segment(lo, hi, R, 1.0 - k, eps);
+    wpos[k] = w;
+    psum += (k == 0) ? w : 2 * w;
+  }
+  psum = block_sum<4>(psum, red);
+  __syncthreads();
+  const double inv = 1.0 / psum;
+  // 'same' convolution with zero padding (scipy.signal.convolve mode='same')
+  for (int i = tid; i < ntp; i += 256) {
+    double acc = 0;
+    // same summation order as a direct convolution: ascending input index
+    for (int m = -kmax; m <= kmax; m++) {
+      const int q = i + m;
+      if (q >= 0 && q < ntp) acc = fma(in[q], wpos[m < 0 ? -m : m] * inv, acc);
+    }
+    o[i] = acc;
+  }
+}
+
+extern "C" int rvs_vsini_convolve(const double *templ, const double *vsini,
+                                  const double *outside, double lnstep,
+                                  double eps, int ntp, int B, double *out,
+                                  void *stream) {
+  if (B < 1 || ntp < 1 || templ == out || !(lnstep > 0)) return RVS_E_ARG;
+  hipLaunchKernelGGL(vsini_kernel, dim3(B), dim3(256), 0, rvs_stream(stream),
+                     templ, vsini, outside, lnstep, eps, ntp, out,
+                     (int32_t *)nullptr);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// A7: natural cubic spline construct (src/spliner.c:7-60).
+//
+// The tridiagonal system  h[i-1] z[i-1] + 2(h[i-1]+h[i]) z[i] + h[i] z[i+1] = r[i]
+// is solved with the same Thomas elimination, parallelised over 256 threads:
+// each thread owns a contiguous chunk of rows, eliminates it assuming a zero
+// incoming carry, the 256 chunk carries are propagated serially (the chunk
+// transfer factors are products of the Thomas multipliers, |m| ~ 0.27), and
+// every thread then corrects its chunk.  The modified diagonal recurrence
+// (cc_dash) depends only on the knots and is recomputed per block in LDS.
+// Result is the Thomas solution up to floating point re-association.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    spline_construct_kernel(const double *__restrict__ knots,
+                            const double *__restrict__ ys, int ntp,
+                            double4 *__restrict__ coef) {
+  extern __shared__ double sm[];
+  const int N = ntp, m = N - 2;  // unknowns z[1..N-2] -> index 0..m-1
+  double *cp = sm;               // [m]   modified super-diagonal
+  double *dp = sm + m;           // [m]   modified rhs -> then z interior
+  double *carry = dp + m;        // [257]
+  double *mult = carry + 257;    // [257]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double *y = ys + (int64_t)b * N;
+  const int CH = (m + 255) / 256;
+  const int i0 = tid * CH, i1 = min(m, i0 + CH);
+  // ---- pass 0: cp recurrence (knots only).  cp[i] = h[i+1]/(diag_i - h[i] cp[i-1])
+  // is a contraction towards ~0.268, so a chunk can be started 48 rows early
+  // from any value and be exact to rounding when it reaches its own rows.
+  {
+    int s = max(0, i0 - 48);
+    double c = 0;
+    for (int i = s; i < i1; i++) {
+      const double h0 = knots[i + 1] - knots[i], h1 = knots[i + 2] - knots[i + 1];
+      const double diag = 2 * (h1 + h0);
+      const double den = (i == 0) ? diag : diag - h0 * c;
+      c = h1 / den;
+      if (i >= i0) cp[i] = c;
+    }
+  }
+  __syncthreads();
+  // ---- pass 1: forward elimination of the rhs inside the chunk, zero carry-in
+  {
+    double d = 0, mu = 1;
+    for (int i = i0; i < i1; i++) {
+      const double h0 = knots[i + 1] - knots[i], h1 = knots[i + 2] - knots[i + 1];
+      const double s0 = (y[i + 1] - y[i]) / h0, s1 = (y[i + 2] - y[i + 1]) / h1;
+      const double rhs = 6 * (s1 - s0);
+      const double diag = 2 * (h1 + h0);
+      const double den = (i == 0) ? diag : diag - h0 * cp[i - 1];
+      d = (i == 0) ? rhs / den : (rhs - h0 * d) / den;
+      mu = (i == 0) ? 0.0 : mu * (-h0 / den);
+      dp[i] = d;
+    }
+    carry[tid + 1] = d;  // chunk output with zero input
+    mult[tid + 1] = mu;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double c = 0;
+    carry[0] = 0;
+    for (int t = 0; t < 256; t++) {
+      if (t * CH < m) c = carry[t + 1] + mult[t + 1] * c;  // non-empty chunk
+      carry[t + 1] = c;  // true dp at the end of chunk t
+    }
+  }
+  __syncthreads();
+  if (tid > 0) {
+    const double cin = carry[tid];
+    double mu = 1;
+    for (int i = i0; i < i1; i++) {
+      const double h0 = knots[i + 1] - knots[i], h1 = knots[i + 2] - knots[i + 1];
+      const double diag = 2 * (h1 + h0);
+      const double den = diag - h0 * cp[i - 1];
+      mu *= (-h0 / den);
+      dp[i] += mu * cin;
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: back substitution z[i] = dp[i] - cp[i] z[i+1], chunked likewise
+  {
+    double z = 0, mu = 1;
+    for (int i = i1 - 1; i >= i0; i--) {
+      z = (i == m - 1) ? dp[i] : dp[i] - cp[i] * z;
+      mu = (i == m - 1) ? 0.0 : mu * (-cp[i]);
+      dp[i] = z;
+    }
+    carry[tid] = z;
+    mult[tid] = mu;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double c = 0;
+    carry[256] = 0;
+    for (int t = 255; t >= 0; t--) {
+      if (t * CH < m) c = carry[t] + mult[t] * c;  // non-empty chunk
+      carry[t] = c;  // true z at the start of chunk t
+    }
+  }
+  __syncthreads();
+  if (i1 > i0 && i1 < m) {
+    const double cin = carry[tid + 1];  // z at start of the next chunk
+    double mu = 1;
+    for (int i = i1 - 1; i >= i0; i--) {
+      mu *= (-cp[i]);
+      dp[i] += mu * cin;
+    }
+  }
+  __syncthreads();
+  // ---- coefficients (spliner.c:52-59)
+  double4 *cf = coef + (int64_t)b * N;
+  for (int i = tid; i < N; i += 256) {
+    if (i >= N - 1) {
+      cf[i] = make_double4(0, 0, 0, 0);
+      continue;
+    }
+    const double h = knots[i + 1] - knots[i], hinv = 1.0 / h;
+    const double zi = (i == 0) ? 0.0 : dp[i - 1];
+    const double zi1 = (i + 1 == N - 1) ? 0.0 : dp[i];
+    const double t1 = hinv * (1.0 / 6), t2 = h * (1.0 / 6);
+    cf[i] = make_double4(zi1 * t1, zi * t1, y[i + 1] * hinv - zi1 * t2,
+                         y[i] * hinv - zi * t2);
+  }
+}
+
+extern "C" int rvs_spline_construct(const double *knots, const double *ys,
+                                    int ntp, int B, double *coef, void *stream) {
+  if (ntp < 4 || B < 1) return RVS_E_ARG;
+  const size_t shm = sizeof(double) * (2 * (size_t)(ntp - 2) + 2 * 257);
+  if (shm > 160 * 1024) return RVS_E_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)spline_construct_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(spline_construct_kernel, dim3(B), dim3(256), shm,
+                     rvs_stream(stream), knots, ys, ntp,
+                     reinterpret_cast<double4 *>(coef));
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// A7: stand-alone evaluator, same arithmetic as src/spliner.c:71-108
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    spline_eval_kernel(const double *__restrict__ knots,
+                       const double4 *__restrict__ coef, int ntp, int log_step,
+                       const double *__restrict__ evalx, int neval,
+                       double *__restrict__ ret, int32_t *__restrict__ pos_out,
+                       int32_t *__restrict__ status) {
+  const int b = blockIdx.y;
+  const double *ex = evalx + (int64_t)b * neval;
+  const double x0 = knots[0], xl = knots[ntp - 1];
+  int st = 0;
+  if (ex[0] < x0 || ex[neval - 1] < x0) st = RVS_ST_SPLINE_RANGE;
+  if (ex[0] >= xl || ex[neval - 1] >= xl) st = RVS_ST_SPLINE_RANGE;
+  double step, off;
+  if (log_step) {
+    step = log(knots[1] / x0);
+    if (fabs(step - log(knots[2] / knots[1])) > 1e-10) st |= RVS_ST_SPLINE_GRID;
+    off = log(x0);
+  } else {
+    step = knots[1] - x0;
+    if (fabs(step - (knots[2] - knots[1])) > 1e-10) st |= RVS_ST_SPLINE_GRID;
+    off = x0;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (st) {
+    if (i == 0 && status) atomicOr(&status[b], st);
+    if (i < neval) ret[(int64_t)b * neval + i] = __builtin_nan("");
+    return;
+  }
+  if (i >= neval) return;
+  const double x = ex[i];
+  int p = (int)(((log_step ? log(x) : x) - off) / step);
+  if (pos_out) pos_out[(int64_t)b * neval + i] = p;
+  p = min(max(p, 0), ntp - 2);
+  const double4 c = coef[(int64_t)b * ntp + p];
+  const double dl = x - knots[p], dr = knots[p + 1] - x;
+  ret[(int64_t)b * neval + i] =
+      c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
+}
+
+extern "C" int rvs_spline_eval(const double *knots, const double *coef, int ntp,
+                               int log_step, const double *evalx, int neval,
+                               int B, double *ret, int32_t *pos,
+                               int32_t *status, void *stream) {
+  if (ntp < 3 || neval < 1 || B < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(spline_eval_kernel, dim3((neval + 255) / 256, B), dim3(256),
+                     0, rvs_stream(stream), knots,
+                     reinterpret_cast<const double4 *>(coef), ntp, log_step,
+                     evalx, neval, ret, pos, status);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}

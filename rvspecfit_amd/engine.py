@@ -1,0 +1,449 @@
+"""Batched device engine: packs spectra in HBM and drives the HIP kernels.
+
+Host code is Python; every numerical step is a call into librvsgpu.so
+(include/rvsgpu.h).  PyTorch is used only for device memory, streams and
+small index glue (gather of CCF parameters, reshapes).
+
+HBM layout (per arm of a batch of S spectra, all sharing the wavelength grid):
+    lam      float64 [npix]
+    spec     float64 [S, npix]      espec float64 [S, npix]   badmask uint8 [S, npix]
+    polysT   float64 [npix, npoly]  continuum basis, pixel-major (scalar-cache reads)
+    work     float64 [npix + 2*S*npix + 2*S]  velocity independent per-pixel terms
+    templ    float64 [J, ntp]   ->  coef float64 [J, ntp, 4]  spline records
+    chisq    float64 [J, Nv]
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from . import ccf_tables
+
+SPEED_OF_LIGHT = 299792.458  # km/s, spec_fit.py:23
+
+
+def get_poly_basis(lam, npoly, rbf=True):
+    """Continuum basis, spec_fit.py:148-176 (host, float64; depends only on the
+    arm's wavelength grid so it is built once per arm and uploaded)."""
+    lam = np.asarray(lam, dtype=np.float64)
+    x = (lam - lam[0]) / (lam[-1] - lam[0]) * 2 - 1
+    out = np.zeros((npoly, len(lam)))
+    if rbf:
+        nmono = 3
+        for i in range(min(nmono, npoly)):
+            out[i] = x**i
+        nrbf = npoly - nmono
+        if nrbf > 0:
+            sig = 1. / nrbf
+            cen = np.linspace(-1, 1, nrbf, True)
+            out[nmono:] = np.exp(-0.5 * (x[None, :] - cen[:, None])**2 / sig**2)
+    else:
+        eye = np.eye(npoly)
+        for i in range(npoly):
+            out[i] = np.polynomial.Chebyshev(eye[i])(x)
+    return out
+
+
+class ArmData:
+    """One spectral arm of a batch: S spectra on a common wavelength grid."""
+
+    def __init__(self, name, lam, spec, espec, badmask=None, device='cuda'):
+        _lib.require_gpu()
+        self.name = name
+        self.device = device
+        self.lam_host = np.ascontiguousarray(lam, dtype=np.float64)
+        self.npix = len(self.lam_host)
+        self.lam = torch.as_tensor(self.lam_host).to(device)
+        self.spec = self._as2d(spec, torch.float64)
+        self.espec = self._as2d(espec, torch.float64)
+        self.S = self.spec.shape[0]
+        if badmask is None:
+            self.badmask = torch.zeros((self.S, self.npix), dtype=torch.uint8,
+                                       device=device)
+        else:
+            self.badmask = self._as2d(badmask, torch.uint8)
+        assert self.spec.shape == self.espec.shape == self.badmask.shape
+        assert self.spec.shape[1] == self.npix
+        self._basis = {}
+        self._work = {}
+        self._ccf = {}
+
+    def _as2d(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=dtype)
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device,
+                                                             dtype=dtype)
+        if t.dim() == 1:
+            t = t[None, :]
+        return t.contiguous()
+
+    def basis(self, npoly, rbf):
+        key = (npoly, bool(rbf))
+        if key not in self._basis:
+            P = get_poly_basis(self.lam_host, npoly, rbf)
+            self._basis[key] = torch.as_tensor(
+                np.ascontiguousarray(P.T)).to(self.device)
+        return self._basis[key]
+
+    def work(self, lib, espec_sys=0.0):
+        """rvs_chisq_prepare output for this arm against the knots of `lib`."""
+        key = (lib.name, id(lib), float(espec_sys))
+        if key not in self._work:
+            L = _lib.lib()
+            n = L.rvs_chisq_work_size(self.npix, self.S)
+            w = torch.empty(n, dtype=torch.float64, device=self.device)
+            rc = L.rvs_chisq_prepare(_lib.ptr(self.lam), _lib.ptr(self.spec),
+                                     _lib.ptr(self.espec), self.npix, self.S,
+                                     _lib.ptr(lib.knots3), int(lib.log_step),
+                                     float(espec_sys), _lib.ptr(w),
+                                     _lib.stream())
+            if rc == -3:
+                raise AssertionError('spline knots are not uniformly spaced')
+            _lib.check(rc, 'rvs_chisq_prepare')
+            self._work[key] = w
+        return self._work[key]
+
+    def ccf_tables(self, lib, config):
+        """Per-arm CCF tables (host-built once, see ccf_tables.py)."""
+        cc = lib.ccf
+        maxvel, vgrid = ccf_tables.ccf_vel_grid(config)
+        key = (lib.name, id(lib), maxvel, len(vgrid))
+        if key in self._ccf:
+            return self._ccf[key]
+        dev = self.device
+        nfft = cc['npoints']
+        T = {}
+        T['maxvel'], T['vgrid_host'] = maxvel, vgrid
+        T['vgrid'] = torch.as_tensor(vgrid).to(dev)
+        step, ind, sub = ccf_tables.lag_tables(cc['logl0'], cc['logl1'], nfft,
+                                               maxvel)
+        T['step'] = step
+        log2n = int(np.log2(nfft)) - 1
+        m = ind.astype(np.int64) >> 1
+        rev = np.zeros_like(m)
+        for bit in range(log2n):
+            rev |= ((m >> bit) & 1) << (log2n - 1 - bit)
+        T['lag_pos'] = torch.as_tensor(
+            (2 * rev + (ind & 1)).astype(np.int32)).to(dev)
+        T['lag_vel'] = torch.as_tensor(sub).to(dev)
+        T['nlag'] = len(ind)
+        T['ilo'] = torch.as_tensor(ccf_tables.interp_tables(sub, vgrid)).to(dev)
+        xi, rw = ccf_tables.rebin_tables(self.lam_host, cc['logl0'], cc['logl1'],
+                                         nfft)
+        T['xind'] = torch.as_tensor(xi).to(dev)
+        T['rw'] = torch.as_tensor(rw).to(dev)
+        tw = np.exp(2j * np.pi * np.arange(nfft // 2) / nfft)
+        T['twid'] = torch.as_tensor(
+            np.ascontiguousarray(tw).view(np.float64)).to(dev)
+        if cc['continuum']:
+            nodes, edges = ccf_tables.continuum_nodes(self.lam_host,
+                                                      cc['splinestep'])
+            Lm = ccf_tables.interp_spline_design(nodes, self.lam_host)
+            T['Lmat'] = torch.as_tensor(np.ascontiguousarray(Lm)).to(dev)
+            T['nnode'] = len(nodes)
+            T['bin_start'] = torch.as_tensor(
+                ccf_tables.bin_ranges(self.lam_host, edges)).to(dev)
+        else:
+            T['Lmat'], T['nnode'], T['bin_start'] = None, 0, None
+        self._ccf[key] = T
+        return T
+
+
+class SpecBatch:
+    """A batch of S spectra, each observed in the same list of arms."""
+
+    def __init__(self, arms):
+        self.arms = list(arms)
+        self.S = self.arms[0].S
+        assert all(a.S == self.S for a in self.arms)
+        self.device = self.arms[0].device
+        self.names = [a.name for a in self.arms]
+        self.badchi = 10 * sum(a.npix for a in self.arms)  # spec_fit.py:863
+
+    @classmethod
+    def from_specdata(cls, specdata_lists, device='cuda'):
+        """specdata_lists: list (spectra) of lists (arms) of SpecData sharing
+        per-arm wavelength grids."""
+        first = specdata_lists[0]
+        arms = []
+        for ia, sd0 in enumerate(first):
+            for sl in specdata_lists:
+                if not np.array_equal(sl[ia].lam, sd0.lam):
+                    raise ValueError('spectra of one arm must share the '
+                                     'wavelength grid to be batched')
+            arms.append(
+                ArmData(sd0.name, sd0.lam,
+                        np.stack([sl[ia].spec for sl in specdata_lists]),
+                        np.stack([sl[ia].espec for sl in specdata_lists]),
+                        np.stack([np.asarray(sl[ia].badmask, dtype=np.uint8)
+                                  for sl in specdata_lists]), device=device))
+        return cls(arms)
+
+
+def _chunks(n, size):
+    for a in range(0, n, size):
+        yield a, min(n, a + size)
+
+
+# --------------------------------------------------------------------------
+# template construction: A3/A4 -> A6 -> A7-construct
+# --------------------------------------------------------------------------
+def build_templates(lib, params, vsini=None, return_templ=False):
+    """params [J, ndim] f64 device; vsini [J] f64 device or None.
+    Returns coef [J, ntp, 4], outside [J] (+ the broadened template)."""
+    L = _lib.lib()
+    J = params.shape[0]
+    templ, outside = lib.eval_batch(params)
+    if vsini is not None:
+        out = torch.empty_like(templ)
+        rc = L.rvs_vsini_convolve(_lib.ptr(templ), _lib.ptr(vsini.contiguous()),
+                                  _lib.ptr(outside), lib.lnstep, 0.6, lib.ntp,
+                                  J, _lib.ptr(out), _lib.stream())
+        _lib.check(rc, 'rvs_vsini_convolve')
+        templ = out
+    coef = torch.empty((J, lib.ntp, 4), dtype=torch.float64, device=lib.device)
+    rc = L.rvs_spline_construct(_lib.ptr(lib.knots), _lib.ptr(templ), lib.ntp, J,
+                                _lib.ptr(coef), _lib.stream())
+    _lib.check(rc, 'rvs_spline_construct')
+    if return_templ:
+        return coef, outside, templ
+    return coef, outside
+
+
+def convolve_vsini(lib_or_lam, templ, vsini, eps=0.6):
+    """templ [J, ntp] device, vsini [J] device"""
+    L = _lib.lib()
+    lam = lib_or_lam.lam if hasattr(lib_or_lam, 'lam') else lib_or_lam
+    ratios = lam[1:] / lam[:-1]
+    assert np.allclose(ratios, ratios[0]), "Wavelength grid must be logarithmic."
+    lnstep = float(np.log(ratios[0]))
+    out = torch.empty_like(templ)
+    rc = L.rvs_vsini_convolve(_lib.ptr(templ.contiguous()), _lib.ptr(vsini),
+                              None, lnstep, float(eps), templ.shape[1],
+                              templ.shape[0], _lib.ptr(out), _lib.stream())
+    _lib.check(rc, 'rvs_vsini_convolve')
+    return out
+
+
+# --------------------------------------------------------------------------
+# chi^2 grid over velocities: A7-eval + A10 + A11 (+ penalties of A11)
+# --------------------------------------------------------------------------
+def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
+               job_spec=None, job_templ=None, espec_sys=0.0,
+               outside_penalty=True, out=None):
+    """chi^2 of J jobs on a velocity grid, summed over the arms of `batch`.
+
+    coefs[a]    [Tn, ntp_a, 4]   spline records of arm a
+    outsides[a] [Tn]             outside flag of each template of arm a
+    vels        [Nv] (shared) or [J, Nv]
+    job_spec / job_templ int32 [J] or None (identity)
+    Returns chisq [J, Nv], status int32 [J].
+    """
+    L = _lib.lib()
+    dev = batch.device
+    if job_spec is not None:
+        J = job_spec.shape[0]
+    elif job_templ is not None:
+        J = job_templ.shape[0]
+    else:
+        J = batch.S
+    vels = vels.contiguous()
+    shared = vels.dim() == 1
+    Nv = vels.shape[-1]
+    vstride = 0 if shared else Nv
+    if out is None:
+        out = torch.empty((J, Nv), dtype=torch.float64, device=dev)
+    status = torch.zeros(J, dtype=torch.int32, device=dev)
+    for ia, arm in enumerate(batch.arms):
+        lib = libs[arm.name]
+        work = arm.work(lib, espec_sys)
+        polysT = arm.basis(npoly, rbf)
+        o = outsides[ia]
+        if job_templ is not None:
+            o = o[job_templ.long()]
+        pen = o * float(batch.badchi) if outside_penalty else torch.where(
+            torch.isfinite(o), torch.zeros_like(o), o)
+        pen = pen.contiguous()
+        coef = coefs[ia]
+        for a, b in _chunks(J, 65535):
+            rc = L.rvs_chisq_grid(
+                _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(work), arm.npix,
+                npoly, arm.S, _lib.ptr(lib.knots), _lib.ptr(coef), lib.ntp,
+                coef.shape[0], int(lib.log_step),
+                _lib.ptr(job_spec[a:b]) if job_spec is not None else
+                (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None),
+                _lib.ptr(job_templ[a:b]) if job_templ is not None else
+                (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None), b - a,
+                _lib.ptr(vels if shared else vels[a:b]), vstride, Nv,
+                _lib.ptr(pen[a:b]), float(batch.badchi),
+                0.0 if ia == 0 else 1.0, _lib.ptr(out[a:b]),
+                _lib.ptr(status[a:b]), _lib.stream())
+            _lib.check(rc, 'rvs_chisq_grid')
+    return out, status
+
+
+_ar_cache = {}
+
+
+def _arange32(a, b, dev):
+    key = (a, b, str(dev))
+    if key not in _ar_cache:
+        _ar_cache[key] = torch.arange(a, b, dtype=torch.int32, device=dev)
+    return _ar_cache[key]
+
+
+def grid_moments(chisq, vels, Np=1, nvel=None, quadratic=True):
+    """chisq [G*Np, Nv] (jobs ordered group-major) -> res [G, 8], probs [G, Nv]"""
+    L = _lib.lib()
+    dev = chisq.device
+    Nv = chisq.shape[-1]
+    G = chisq.shape[0] // Np
+    res = torch.empty((G, 8), dtype=torch.float64, device=dev)
+    probs = torch.empty((G, Nv), dtype=torch.float64, device=dev)
+    status = torch.zeros(G, dtype=torch.int32, device=dev)
+    vels = vels.contiguous()
+    vstride = 0 if vels.dim() == 1 else Nv
+    rc = L.rvs_grid_moments(_lib.ptr(chisq.contiguous()), _lib.ptr(vels),
+                            vstride, _lib.ptr(nvel), G, Np, Nv, int(quadratic),
+                            _lib.ptr(res), _lib.ptr(probs), _lib.ptr(status),
+                            _lib.stream())
+    _lib.check(rc, 'rvs_grid_moments')
+    return res, probs, status
+
+
+def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
+               job_templ=None, espec_sys=0.0, unit_template=False,
+               want_models=True):
+    """Per-arm full output (spec_fit.py:941-961) for one velocity per job."""
+    L = _lib.lib()
+    dev = batch.device
+    J = batch.S if job_spec is None else job_spec.shape[0]
+    res = []
+    for ia, arm in enumerate(batch.arms):
+        lib = None if unit_template else libs[arm.name]
+        polysT = arm.basis(npoly, rbf)
+        chisq = torch.empty(J, dtype=torch.float64, device=dev)
+        tchi = torch.empty(J, dtype=torch.float64, device=dev)
+        coeffs = torch.empty((J, npoly), dtype=torch.float64, device=dev)
+        ngood = torch.empty(J, dtype=torch.int32, device=dev)
+        status = torch.zeros(J, dtype=torch.int32, device=dev)
+        model = raw = None
+        if want_models:
+            model = torch.empty((J, arm.npix), dtype=torch.float64, device=dev)
+            raw = torch.empty((J, arm.npix), dtype=torch.float64, device=dev)
+        coef = None if unit_template else coefs[ia]
+        rc = L.rvs_chisq_full(
+            _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(arm.spec),
+            _lib.ptr(arm.espec), _lib.ptr(arm.badmask), arm.npix, npoly, arm.S,
+            _lib.ptr(lib.knots) if lib else None, _lib.ptr(coef),
+            lib.ntp if lib else 0, coef.shape[0] if coef is not None else 0,
+            int(lib.log_step) if lib else 1, int(unit_template),
+            _lib.ptr(job_spec), _lib.ptr(job_templ), J,
+            _lib.ptr(vel.contiguous()) if vel is not None else None,
+            float(espec_sys), _lib.ptr(chisq), _lib.ptr(coeffs),
+            _lib.ptr(model), _lib.ptr(raw), _lib.ptr(tchi), _lib.ptr(ngood),
+            _lib.ptr(status), _lib.stream())
+        _lib.check(rc, 'rvs_chisq_full')
+        res.append(dict(chisq=chisq, true_chisq=tchi, coeffs=coeffs,
+                        ngood=ngood, status=status, model=model, raw_model=raw))
+    return res
+
+
+# --------------------------------------------------------------------------
+# CCF: A15 + A14
+# --------------------------------------------------------------------------
+def ccf_preprocess(arm, lib, config, details=False):
+    L = _lib.lib()
+    T = arm.ccf_tables(lib, config)
+    cc = lib.ccf
+    dev = arm.device
+    nfft = cc['npoints']
+    ps = torch.empty((arm.S, nfft), dtype=torch.float64, device=dev)
+    pi = torch.empty((arm.S, nfft), dtype=torch.float64, device=dev)
+    sse = torch.empty(arm.S, dtype=torch.float64, device=dev)
+    status = torch.zeros(arm.S, dtype=torch.int32, device=dev)
+    cont = pfit = None
+    if details:
+        cont = torch.empty((arm.S, arm.npix), dtype=torch.float64, device=dev)
+        pfit = torch.zeros((arm.S, max(T['nnode'], 1)), dtype=torch.float64,
+                           device=dev)
+    rc = L.rvs_ccf_preprocess(
+        _lib.ptr(arm.lam), _lib.ptr(arm.spec), _lib.ptr(arm.espec),
+        _lib.ptr(arm.badmask), arm.npix, arm.S, int(cc['continuum']),
+        _lib.ptr(T['Lmat']), T['nnode'], _lib.ptr(T['bin_start']),
+        _lib.ptr(T['xind']), _lib.ptr(T['rw']), nfft, 10.0, _lib.ptr(ps),
+        _lib.ptr(pi), _lib.ptr(sse), _lib.ptr(cont), _lib.ptr(pfit),
+        _lib.ptr(status), _lib.stream())
+    _lib.check(rc, 'rvs_ccf_preprocess')
+    out = dict(proc_spec=ps, proc_ivar=pi, sse=sse, status=status)
+    if details:
+        out.update(cont=cont, pfit=pfit)
+    return out
+
+
+def ccf_fit(batch, libs, config, keep_all=False, max_chunk=None):
+    """fitter_ccf.fit for a batch.  Returns a dict of device tensors:
+    best_id [S] int64, best_vel [S], best_ccf [S, nvel], status [S],
+    proc_spec / proc_ivar per arm."""
+    L = _lib.lib()
+    dev = batch.device
+    S = batch.S
+    ref = libs[batch.names[0]].ccf
+    Tn = ref['T']
+    for n in batch.names[1:]:
+        cc = libs[n].ccf
+        if (cc['T'] != Tn and True) and cc['T'] != Tn:
+            raise RuntimeError('CCF template counts are inconsistent across setups')
+        if (not np.array_equal(ref['params'], cc['params'])
+                or not np.array_equal(ref['vsinis'], cc['vsinis'],
+                                      equal_nan=True)):
+            raise RuntimeError('The parameters of the CCF templates do not match')
+    tabs = [a.ccf_tables(libs[a.name], config) for a in batch.arms]
+    nvel = len(tabs[0]['vgrid_host'])
+    pre = [ccf_preprocess(a, libs[a.name], config) for a in batch.arms]
+    sse = torch.stack([p['sse'] for p in pre]).contiguous()  # [narm, S]
+    status = torch.zeros(S, dtype=torch.int32, device=dev)
+    for p in pre:
+        status |= p['status']
+    # chunk spectra so that the [chunk, T, nvel] accumulator stays modest
+    if max_chunk is None:
+        max_chunk = max(1, min(S, int(2e9 // (Tn * nvel * 8))))
+    res = torch.empty((S, 4), dtype=torch.float64, device=dev)
+    best_ccf = torch.empty((S, nvel), dtype=torch.float64, device=dev)
+    allchi = None
+    for a, b in _chunks(S, max_chunk):
+        n = b - a
+        acc = torch.empty((n, Tn, nvel), dtype=torch.float64, device=dev)
+        for ia, arm in enumerate(batch.arms):
+            cc = libs[arm.name].ccf
+            T = tabs[ia]
+            nfft = cc['npoints']
+            work = torch.empty((n, 2, nfft // 2 + 1, 2), dtype=torch.float64,
+                               device=dev)
+            rc = L.rvs_ccf_xcorr(
+                _lib.ptr(pre[ia]['proc_spec'][a:b]),
+                _lib.ptr(pre[ia]['proc_ivar'][a:b]), nfft, n,
+                _lib.ptr(cc['fft']), _lib.ptr(cc['fft2']), Tn,
+                _lib.ptr(T['twid']), int(cc['continuum']),
+                _lib.ptr(T['lag_pos']), _lib.ptr(T['lag_vel']), T['nlag'],
+                _lib.ptr(T['ilo']), _lib.ptr(T['vgrid']), nvel,
+                0.0 if ia == 0 else 1.0, _lib.ptr(acc), _lib.ptr(work),
+                _lib.stream())
+            _lib.check(rc, 'rvs_ccf_xcorr')
+        sse_c = sse[:, a:b].contiguous()
+        rc = L.rvs_ccf_select(_lib.ptr(acc), _lib.ptr(sse_c), len(batch.arms),
+                              n, Tn, _lib.ptr(tabs[0]['vgrid']), nvel,
+                              _lib.ptr(res[a:b]), _lib.ptr(best_ccf[a:b]),
+                              _lib.ptr(status[a:b]), _lib.stream())
+        _lib.check(rc, 'rvs_ccf_select')
+        if keep_all:
+            allchi = acc + sse_c.sum(dim=0)[:, None, None]
+    out = dict(best_id=res[:, 0].long(), best_vel=res[:, 1].contiguous(),
+               best_pix=res[:, 2].long(), best_ccf=best_ccf, status=status,
+               vel_grid=tabs[0]['vgrid'], vel_grid_host=tabs[0]['vgrid_host'],
+               proc_spec=[p['proc_spec'] for p in pre],
+               proc_ivar=[p['proc_ivar'] for p in pre],
+               steps=[t['step'] for t in tabs])
+    if keep_all:
+        out['all_chisqs'] = allchi
+    return out

@@ -1,0 +1,166 @@
+"""Device-resident template library of one spectral setup (arm).
+
+Holds, as PyTorch-ROCm tensors in HBM, exactly what the reference keeps in its
+process-wide caches (spec_inter.interp_cache, fitter_ccf.CCFCache):
+
+  interp_%s.h5 / interpdat_%s.npy   -> dats (float32 [ngrid, ntp], log flux),
+        idgrid, uvecs, vec (mapped grid points), lam, log_step, parnames, mapper
+  ccf_%s.h5 / ccfdat_%s.npz / ccfmod_%s.npy -> fft, fft2 (complex128
+        [T, nfft/2+1]), params, vsinis, ccfconf, model (kept on the host: it is
+        only rolled and returned, fitter_ccf.py:238-241)
+  NN checkpoint + 'generic' record  -> float32 weights, Mapper M/S, hull
+
+The on-disk form read here is a plain .npz ("converted artefact", same keys as
+tests/golden/lib_*.npz); h5py is not available next to torch in this image, so
+reference artefact directories are converted once with tools/convert_artefacts.py
+under an interpreter that has h5py.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _dev(a, dtype, device):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
+
+
+class TemplateLibrary:
+
+    def __init__(self, name, d, device='cuda'):
+        self.name = name
+        self.device = device
+        d = dict(d)
+        self.lam = np.ascontiguousarray(d['lam'], dtype=np.float64)
+        self.ntp = len(self.lam)
+        self.log_step = bool(d['log_step'])
+        self.log_ids = [int(_) for _ in np.atleast_1d(d.get('log_ids', [0]))]
+        self.parnames = tuple(str(_) for _ in d['parnames'])
+        self.ndim = len(self.parnames)
+        self.log_mask = 0
+        for i in self.log_ids:
+            self.log_mask |= (1 << i)
+        self.revision = str(d.get('revision', ''))
+        self.knots = _dev(self.lam, torch.float64, device)
+        self.knots3 = np.ascontiguousarray(self.lam[:3])
+        self.lnstep = float(np.log(self.lam[1] / self.lam[0]))
+        self.kind = 'regulargrid'
+        if 'dats' in d:
+            idgrid = np.asarray(d['idgrid'], dtype=np.int64)
+            self.lens = np.array(idgrid.shape, dtype=np.int32)
+            uvecs = [np.asarray(d['uvec%d' % i], dtype=np.float64)
+                     for i in range(self.ndim)]
+            self.uvecs_host = uvecs
+            vec = np.asarray(d['vec'], dtype=np.float64)  # [ndim, ngrid] mapped
+            ptp = np.ptp(vec, axis=1)
+            self.inv_ptp = np.ascontiguousarray(1. / ptp)
+            self.ngrid = vec.shape[1]
+            self.dats = _dev(d['dats'], torch.float32, device)
+            self.idgrid = _dev(idgrid.ravel(), torch.int64, device)
+            self.uvecs = _dev(np.concatenate(uvecs), torch.float64, device)
+            self.vecs_s = _dev((vec.T / ptp[None, :]), torch.float64, device)
+            self.exp_flag = int(bool(d.get('log_spec', True)))
+        if 'nn_dims' in d:
+            self.kind = 'nn'
+            self.nn_dims = np.asarray(d['nn_dims'], dtype=np.int32)
+            nl = len(self.nn_dims) - 1
+            self.nn_W = [_dev(d['nn_W%d' % i], torch.float32, device)
+                         for i in range(nl)]
+            self.nn_b = [_dev(d['nn_b%d' % i], torch.float32, device)
+                         for i in range(nl)]
+            self.nn_M = _dev(d['nn_M'], torch.float64, device)
+            self.nn_S = _dev(d['nn_S'], torch.float64, device)
+            self.nn_hull = None
+            if 'nn_xeqs' in d:
+                self.nn_hull = (np.asarray(d['nn_xeqs']), np.asarray(d['nn_yeqs']))
+        self.ccf = None
+        if 'ccf_fft' in d:
+            fft = np.ascontiguousarray(d['ccf_fft'], dtype=np.complex128)
+            fft2 = np.ascontiguousarray(d['ccf_fft2'], dtype=np.complex128)
+            self.ccf = dict(
+                T=fft.shape[0],
+                nfft=int(d['ccf_npoints']),
+                fft=_dev(fft.view(np.float64), torch.float64, device),
+                fft2=_dev(fft2.view(np.float64), torch.float64, device),
+                mod=np.asarray(d['ccf_mod']) if 'ccf_mod' in d else None,
+                params=np.asarray(d['ccf_params'], dtype=np.float64),
+                vsinis=np.asarray(d['ccf_vsinis'], dtype=np.float64),
+                params_dev=_dev(d['ccf_params'], torch.float64, device),
+                vsinis_dev=_dev(np.nan_to_num(np.asarray(d['ccf_vsinis'],
+                                                         dtype=np.float64),
+                                              nan=0.0), torch.float64, device),
+                logl0=float(d['ccf_logl0']), logl1=float(d['ccf_logl1']),
+                npoints=int(d['ccf_npoints']),
+                continuum=bool(d['ccf_continuum']),
+                splinestep=float(d['ccf_splinestep']) if 'ccf_splinestep' in d
+                else None,
+                maxcontpts=int(d['ccf_maxcontpts']) if 'ccf_maxcontpts' in d
+                else 20)
+
+    @classmethod
+    def from_npz(cls, name, path, device='cuda'):
+        return cls(name, np.load(path, allow_pickle=False), device=device)
+
+    # -- A3 / A4 : template evaluation for a batch of parameter vectors ------
+    def eval_batch(self, params, details=False):
+        """params float64 [J, ndim] (device) -> templ [J, ntp], outside [J]"""
+        L = _lib.lib()
+        J = params.shape[0]
+        params = params.contiguous()
+        templ = torch.empty((J, self.ntp), dtype=torch.float64,
+                            device=self.device)
+        outside = torch.empty(J, dtype=torch.float64, device=self.device)
+        if self.kind == 'nn':
+            return self._eval_nn(params, templ, outside)
+        nv = 1 << self.ndim
+        cell = wts = None
+        if details:
+            cell = torch.zeros((J, 2 + nv), dtype=torch.int32,
+                               device=self.device)
+            wts = torch.zeros((J, nv), dtype=torch.float64, device=self.device)
+        rc = L.rvs_template_polylinear(
+            _lib.ptr(self.dats), self.ngrid, self.ntp, _lib.ptr(self.idgrid),
+            _lib.ptr(self.uvecs), _lib.ptr(self.lens), self.ndim,
+            _lib.ptr(self.vecs_s), _lib.ptr(self.inv_ptp), self.log_mask,
+            self.exp_flag, _lib.ptr(params), J, _lib.ptr(templ),
+            _lib.ptr(outside), _lib.ptr(cell), _lib.ptr(wts), _lib.stream())
+        _lib.check(rc, 'rvs_template_polylinear')
+        if details:
+            return templ, outside, cell, wts
+        return templ, outside
+
+    def _eval_nn(self, params, templ, outside):
+        import ctypes
+        L = _lib.lib()
+        J = params.shape[0]
+        nl = len(self.nn_W)
+        width = int(max(self.nn_dims[:-1]))
+        a0 = torch.empty((J, width), dtype=torch.float32, device=self.device)
+        a1 = torch.empty((J, width), dtype=torch.float32, device=self.device)
+        Wp = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in self.nn_W])
+        bp = (ctypes.c_void_p * nl)(*[b.data_ptr() for b in self.nn_b])
+        rc = L.rvs_template_nn(_lib.ptr(params), J, self.ndim, self.log_mask,
+                               _lib.ptr(self.nn_M), _lib.ptr(self.nn_S), nl,
+                               ctypes.cast(Wp, ctypes.c_void_p),
+                               ctypes.cast(bp, ctypes.c_void_p),
+                               _lib.ptr(self.nn_dims), _lib.ptr(a0),
+                               _lib.ptr(a1), _lib.ptr(templ), _lib.stream())
+        _lib.check(rc, 'rvs_template_nn')
+        outside.copy_(self._nn_outside(params))
+        return templ, outside
+
+    def _nn_outside(self, params):
+        """OutsideInterpolator.__call__ (nn/RVSInterpolator.py:63-71): squared
+        positive distance to the facets of two 2-D convex hulls (host-built
+        facet equations, evaluated with torch on the device)."""
+        if self.nn_hull is None:
+            return torch.zeros(params.shape[0], dtype=torch.float64,
+                               device=self.device)
+        p = params.clone()
+        for i in self.log_ids:
+            p[:, i] = torch.log10(p[:, i])
+        xe = torch.as_tensor(self.nn_hull[0], device=self.device)
+        ye = torch.as_tensor(self.nn_hull[1], device=self.device)
+        dx = (p[:, :2] @ xe[:, :-1].T + xe[:, -1]).max(dim=1).values
+        dy = (p[:, 2:] @ ye[:, :-1].T + ye[:, -1]).max(dim=1).values
+        return torch.clamp(torch.maximum(dx, dy), min=0)**2

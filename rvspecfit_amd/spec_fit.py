@@ -1,0 +1,385 @@
+"""Likelihood core -- API mirror of py/rvspecfit/spec_fit.py on the MI355X engine.
+
+Same names, argument meaning and error behaviour as the reference for one
+spectrum (a list of `SpecData`), plus batched use: every function that takes
+`specdata` also accepts an `engine.SpecBatch` (S spectra x arms resident in
+HBM); scalars then become [S] tensors and results are device tensors stacked
+on a leading batch axis.
+"""
+import logging
+import random
+import collections
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import engine
+from . import spec_inter
+from .engine import SpecBatch, get_poly_basis, SPEED_OF_LIGHT  # noqa: F401
+
+
+class SpecData:
+    """spec_fit.SpecData (spec_fit.py:70-145): one spectroscopic dataset."""
+
+    def __init__(self, name, lam, spec, espec, badmask=None, resolution=None,
+                 dtype=np.float64):
+        if resolution is not None:
+            raise NotImplementedError(
+                'resolution matrices are outside the accelerated hot path '
+                '(SURVEY 8(f) rank 4)')
+        self.name = name
+        self.lam = np.ascontiguousarray(lam, dtype=dtype)
+        self.spec = np.ascontiguousarray(spec, dtype=dtype)
+        self.espec = np.ascontiguousarray(espec, dtype=dtype)
+        self.resolution = None
+        self.spec_error_ratio = self.spec / self.espec
+        if badmask is None:
+            badmask = np.zeros(len(self.spec), dtype=bool)
+        self.badmask = np.asarray(badmask, dtype=bool)
+        self.objid = random.getrandbits(128)
+
+    def __hash__(self):
+        return self.objid
+
+
+class LRUDict:
+
+    def __init__(self, N):
+        self.N = N
+        self.D = collections.OrderedDict()
+
+    def __contains__(self, x):
+        return x in self.D
+
+    def __setitem__(self, x, y):
+        if x not in self.D and len(self.D) == self.N:
+            del self.D[next(iter(self.D))]
+        self.D[x] = y
+        self.D.move_to_end(x)
+
+    def __getitem__(self, x):
+        self.D.move_to_end(x)
+        return self.D[x]
+
+
+_batch_cache = LRUDict(16)
+
+
+def as_batch(specdata):
+    """list of SpecData (one spectrum) -> cached single-spectrum SpecBatch."""
+    if isinstance(specdata, SpecBatch):
+        return specdata, True
+    if isinstance(specdata, SpecData):
+        specdata = [specdata]
+    key = tuple(sd.objid for sd in specdata)
+    if key not in _batch_cache:
+        _batch_cache[key] = SpecBatch.from_specdata([list(specdata)])
+    return _batch_cache[key], False
+
+
+def _params_tensor(atm_params, S, ndim, dev):
+    if isinstance(atm_params, torch.Tensor):
+        p = atm_params.to(dev, torch.float64)
+    else:
+        p = torch.as_tensor(np.asarray(atm_params, dtype=np.float64)).to(dev)
+    if p.dim() == 1:
+        p = p[None, :].expand(S, ndim)
+    return p.contiguous()
+
+
+def _vsini_tensor(rot_params, S, dev):
+    if rot_params is None:
+        return None
+    if isinstance(rot_params, torch.Tensor):
+        v = rot_params.to(dev, torch.float64)
+    else:
+        v = torch.as_tensor(np.asarray(rot_params, dtype=np.float64)).to(dev)
+    v = v.reshape(-1)
+    if v.numel() == 1:
+        v = v.expand(S)
+    return v.contiguous()
+
+
+def _overlap_check(templ_l0, templ_l1, spec_l0, spec_l1, min_vel, max_vel):
+    # spec_fit.py:786-794
+    for vel in [min_vel, max_vel]:
+        corr = np.sqrt((1 + vel / SPEED_OF_LIGHT) / (1 - vel / SPEED_OF_LIGHT))
+        if templ_l0 * corr > spec_l0 or templ_l1 * corr < spec_l1:
+            raise RuntimeError(
+                f"The template library ({templ_l0},{templ_l1})  doesn't cover"
+                f" this wavelength range ({spec_l0},{spec_l1}) with "
+                f"velocities {min_vel} {max_vel}")
+
+
+def _check_overlap_all(batch, libs, config, vmin, vmax):
+    for arm in batch.arms:
+        lib = libs[arm.name]
+        _overlap_check(lib.lam[0], lib.lam[-1], arm.lam_host[0],
+                       arm.lam_host[-1], min(config['min_vel'], vmin),
+                       max(config['max_vel'], vmax))
+
+
+def _raise_for_status(st, what):
+    """batch-of-1: turn status bits back into the reference's exceptions"""
+    if st & _lib.ST_SPLINE_GRID:
+        raise AssertionError('spline knots not uniformly spaced')  # spliner.py:51
+    if st & _lib.ST_SPLINE_RANGE:
+        raise AssertionError('spline evaluated outside its knots')
+    if st & _lib.ST_NONFINITE:
+        raise RuntimeError('The log(likelihood) value is not finite when '
+                           'processing ' + what)
+
+
+def getCurTempl(spec_setup, atm_param, rot_params, config):
+    """spec_fit.getCurTempl (spec_fit.py:357-407), numpy outputs."""
+    interp = spec_inter.getInterpolator(spec_setup, config)
+    lib = interp.lib
+    p = _params_tensor(tuple(atm_param), 1, lib.ndim, lib.device)
+    vs = _vsini_tensor(rot_params, 1, lib.device)
+    _, outside, templ = engine.build_templates(lib, p, vs, return_templ=True)
+    return (float(outside[0].item()), lib.lam, templ[0].cpu().numpy(),
+            random.getrandbits(128), lib.log_step)
+
+
+def convolve_vsini(lam_templ, templ, vsini, eps=0.6):
+    """spec_fit.convolve_vsini (spec_fit.py:628-682), numpy in / numpy out."""
+    _lib.require_gpu()
+    t = torch.as_tensor(np.ascontiguousarray(templ, dtype=np.float64)[None, :]
+                        ).to('cuda')
+    v = torch.as_tensor(np.array([vsini], dtype=np.float64)).to('cuda')
+    return engine.convolve_vsini(np.asarray(lam_templ), t, v,
+                                 eps)[0].cpu().numpy()
+
+
+class _DeviceSpline:
+    """spliner.Spline look-alike (spliner.py:8-53) on the device kernels."""
+
+    def __init__(self, xs, ys, log_step=True):
+        _lib.require_gpu()
+        assert xs.dtype == np.float64 and ys.dtype == np.float64
+        self.xs = np.ascontiguousarray(xs)
+        self.N = len(xs)
+        self.log_step = int(log_step)
+        self.knots = torch.as_tensor(self.xs).to('cuda')
+        y = torch.as_tensor(np.ascontiguousarray(ys)[None, :]).to('cuda')
+        self.coef = torch.empty((1, self.N, 4), dtype=torch.float64,
+                                device='cuda')
+        rc = _lib.lib().rvs_spline_construct(_lib.ptr(self.knots), _lib.ptr(y),
+                                             self.N, 1, _lib.ptr(self.coef),
+                                             _lib.stream())
+        _lib.check(rc, 'rvs_spline_construct')
+
+    def __call__(self, evalx, return_pos=False):
+        ex = torch.as_tensor(np.ascontiguousarray(evalx, dtype=np.float64)[None]
+                             ).to('cuda')
+        n = ex.shape[1]
+        ret = torch.empty((1, n), dtype=torch.float64, device='cuda')
+        pos = torch.empty((1, n), dtype=torch.int32, device='cuda')
+        st = torch.zeros(1, dtype=torch.int32, device='cuda')
+        rc = _lib.lib().rvs_spline_eval(_lib.ptr(self.knots),
+                                        _lib.ptr(self.coef), self.N,
+                                        self.log_step, _lib.ptr(ex), n, 1,
+                                        _lib.ptr(ret), _lib.ptr(pos),
+                                        _lib.ptr(st), _lib.stream())
+        _lib.check(rc, 'rvs_spline_eval')
+        assert int(st.item()) == 0  # spliner.py:51
+        if return_pos:
+            return ret[0].cpu().numpy(), pos[0].cpu().numpy()
+        return ret[0].cpu().numpy()
+
+
+def getRVInterpol(lam_templ, templ, log_step=True):
+    return _DeviceSpline(lam_templ, templ, log_step=log_step)
+
+
+def evalRV(interpol, vel, lams):
+    beta = vel / SPEED_OF_LIGHT
+    return interpol(lams * np.sqrt((1 - beta) / (1 + beta)))
+
+
+def param_dict_to_tuple(paramDict, setup, config):
+    interp = spec_inter.getInterpolator(setup, config)
+    return tuple([paramDict[_] for _ in interp.parnames])
+
+
+def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
+              options=None, config=None, cache=None, full_output=False,
+              fast_interp=False, espec_systematic=None, outside_penalty=True):
+    """spec_fit.get_chisq (spec_fit.py:797-989).
+
+    One spectrum: returns a float (or the full_output dict of numpy arrays).
+    SpecBatch: vel [S], atm_params [S, ndim] (or one tuple), rot_params None or
+    vsini [S]; returns a device tensor [S] (or dict of tensors) and never
+    raises for per-spectrum conditions (see 'status')."""
+    if resol_params is not None:
+        raise NotImplementedError('resolution matrices: SURVEY 8(f) rank 4')
+    if fast_interp:
+        raise NotImplementedError('fast_interp (nearest pixel) is not on the '
+                                  'accelerated path')
+    if isinstance(espec_systematic, dict):
+        raise NotImplementedError('per-setup espec_systematic dict')
+    options = options or {}
+    npoly = options.get('npoly') or 5
+    rbf = options.get('rbf_continuum', True)
+    batch, is_batch = as_batch(specdata)
+    S, dev = batch.S, batch.device
+    libs = spec_inter.get_libs(batch.names, config)
+    ndim = libs[batch.names[0]].ndim
+    params = _params_tensor(atm_params, S, ndim, dev)
+    vsini = _vsini_tensor(rot_params, S, dev)
+    if isinstance(vel, torch.Tensor):
+        velt = vel.to(dev, torch.float64).reshape(S, 1)
+    else:
+        velt = torch.as_tensor(np.asarray(vel, dtype=np.float64)).to(dev)
+        velt = velt.reshape(-1, 1).expand(S, 1).contiguous()
+    vmin, vmax = float(velt.min().item()), float(velt.max().item())
+    _check_overlap_all(batch, libs, config, vmin, vmax)
+    esys = float(espec_systematic) if espec_systematic is not None else 0.0
+    coefs, outs = [], []
+    for arm in batch.arms:
+        c, o = engine.build_templates(libs[arm.name], params, vsini)
+        coefs.append(c)
+        outs.append(o)
+    chisq, status = engine.chisq_grid(batch, libs, coefs, outs, velt,
+                                      npoly=npoly, rbf=rbf, espec_sys=esys,
+                                      outside_penalty=outside_penalty)
+    chisq = chisq[:, 0]
+    # reference: a non finite arm value of an OUTSIDE template is skipped with
+    # a warning instead of raising (spec_fit.py:963-969); we flag it in status
+    if not is_batch:
+        st = int(status[0].item())
+        anyout = any(float(o[0].item()) > 0 for o in outs)
+        if not (st & _lib.ST_NONFINITE and anyout):
+            _raise_for_status(st, f'velocity {vel}, atm parameters {atm_params}')
+    if not full_output:
+        return chisq if is_batch else float(chisq[0].item())
+    full = engine.chisq_full(batch, libs, coefs, velt[:, 0].contiguous(),
+                             npoly=npoly, rbf=rbf, espec_sys=esys)
+    ret = {}
+    ret['chisq'] = chisq if is_batch else float(chisq[0].item())
+    ret['logl'] = -0.5 * ret['chisq']
+    nanarm = [~torch.isfinite(o) for o in outs]
+    ca = [torch.where(n, torch.full_like(f['true_chisq'], float('nan')),
+                      f['true_chisq']) for f, n in zip(full, nanarm)]
+    na = [f['ngood'] for f in full]
+    if is_batch:
+        ret['chisq_array'] = torch.stack(ca, dim=1)
+        ret['npix_array'] = torch.stack(na, dim=1)
+        ret['red_chisq_array'] = ret['chisq_array'] / ret['npix_array']
+        ret['models'] = [f['model'] for f in full]
+        ret['raw_models'] = [f['raw_model'] for f in full]
+        ret['status'] = status
+    else:
+        ret['chisq_array'] = [float(c[0].item()) for c in ca]
+        ret['npix_array'] = [int(n[0].item()) for n in na]
+        ret['red_chisq_array'] = [c / n for c, n in zip(ret['chisq_array'],
+                                                        ret['npix_array'])]
+        ret['models'] = [f['model'][0].cpu().numpy() for f in full]
+        ret['raw_models'] = [f['raw_model'][0].cpu().numpy() for f in full]
+    return ret
+
+
+def chisq_grid_jobs(batch, vel_grid, params, vsini, options, config,
+                    outside_penalty=True, espec_systematic=None):
+    """chi^2 [S, Np, Nv] for params [S, Np, ndim] (device) on a shared or
+    per-spectrum velocity grid: the double loop of find_best as one launch set."""
+    options = options or {}
+    npoly = options.get('npoly') or 5
+    rbf = options.get('rbf_continuum', True)
+    S, dev = batch.S, batch.device
+    libs = spec_inter.get_libs(batch.names, config)
+    Np = params.shape[1]
+    flat = params.reshape(S * Np, -1).contiguous()
+    vs = None
+    if vsini is not None:
+        vs = vsini.reshape(S, -1).expand(S, Np).reshape(-1).contiguous()
+    coefs, outs = [], []
+    for arm in batch.arms:
+        c, o = engine.build_templates(libs[arm.name], flat, vs)
+        coefs.append(c)
+        outs.append(o)
+    job_spec = torch.arange(S, dtype=torch.int32, device=dev
+                            ).repeat_interleave(Np).contiguous()
+    vg = vel_grid
+    if vg.dim() == 2:  # per spectrum grids -> per job
+        vg = vg.repeat_interleave(Np, dim=0).contiguous()
+    esys = float(espec_systematic) if espec_systematic is not None else 0.0
+    chisq, status = engine.chisq_grid(batch, libs, coefs, outs, vg,
+                                      npoly=npoly, rbf=rbf, job_spec=job_spec,
+                                      espec_sys=esys,
+                                      outside_penalty=outside_penalty)
+    return chisq.reshape(S, Np, -1), status.reshape(S, Np), outs
+
+
+def find_best(specdata, vel_grid, params_list, rot_params=None,
+              resol_params=None, options=None, config=None, quadratic=True):
+    """spec_fit.find_best (spec_fit.py:1018-1092).
+
+    One spectrum: same dict as the reference (numpy / floats).
+    SpecBatch: params_list is [Np][ndim] (shared) or a tensor [S, Np, ndim];
+    values are device tensors with a leading S axis."""
+    if resol_params is not None:
+        raise NotImplementedError('resolution matrices: SURVEY 8(f) rank 4')
+    batch, is_batch = as_batch(specdata)
+    S, dev = batch.S, batch.device
+    if isinstance(params_list, torch.Tensor):
+        params = params_list.to(dev, torch.float64)
+    else:
+        params = torch.as_tensor(np.asarray(params_list, dtype=np.float64)).to(dev)
+    if params.dim() == 2:
+        params = params[None].expand(S, *params.shape)
+    Np = params.shape[1]
+    if isinstance(vel_grid, torch.Tensor):
+        vg = vel_grid.to(dev, torch.float64)
+    else:
+        vg = torch.as_tensor(np.asarray(vel_grid, dtype=np.float64)).to(dev)
+    libs = spec_inter.get_libs(batch.names, config)
+    _check_overlap_all(batch, libs, config, float(vg.min().item()),
+                       float(vg.max().item()))
+    vsini = _vsini_tensor(rot_params, S, dev)
+    chisq, status, outs = chisq_grid_jobs(batch, vg, params.contiguous(), vsini,
+                                          options, config)
+    res, probs, mst = engine.grid_moments(chisq.reshape(S * Np, -1), vg, Np=Np,
+                                          quadratic=quadratic)
+    i2 = res[:, 6].long()
+    best_param = params[torch.arange(S, device=dev), i2]
+    if is_batch:
+        return dict(best_chi=res[:, 0], best_vel=res[:, 1], vel_err=res[:, 2],
+                    kurtosis=res[:, 3], skewness=res[:, 4], best_param=best_param,
+                    probs=probs, chisq=chisq, status=status, i1=res[:, 5].long(),
+                    i2=i2, moment_status=mst)
+    st = 0
+    for v in status[0].tolist():
+        st |= int(v)
+    anyout = any(bool((o > 0).any().item()) for o in outs)
+    if not (st & _lib.ST_NONFINITE and anyout):
+        _raise_for_status(st, 'find_best')
+    if int(mst[0].item()) & _lib.ST_QUAD_ASSERT:
+        raise AssertionError('quadratic interpolation left its bracket')
+    r = res[0].cpu().numpy()
+    kur, skw = float(r[3]), float(r[4])
+    if r[2] < 1e-10:
+        kur, skw = 0, 0
+    pl = params_list
+    best = pl[int(r[6])] if not isinstance(pl, torch.Tensor) else \
+        best_param[0].cpu().numpy()
+    return dict(best_chi=float(r[0]), best_vel=float(r[1]), vel_err=float(r[2]),
+                best_param=best, kurtosis=kur, skewness=skw,
+                probs=probs[0].cpu().numpy())
+
+
+def get_chisq_continuum(specdata, options=None):
+    """spec_fit.get_chisq_continuum (spec_fit.py:739-783)."""
+    options = options or {}
+    npoly = options.get('npoly') or 5
+    rbf = options.get('rbf_continuum', True)
+    batch, is_batch = as_batch(specdata)
+    full = engine.chisq_full(batch, None, None, None, npoly=npoly, rbf=rbf,
+                             unit_template=True, want_models=False)
+    ca = torch.stack([f['true_chisq'] for f in full], dim=1)
+    ng = torch.stack([f['ngood'] for f in full], dim=1)
+    if is_batch:
+        return dict(chisq_array=ca, redchisq_array=ca / ng)
+    ca, ng = ca[0].cpu().numpy(), ng[0].cpu().numpy()
+    return dict(chisq_array=ca, redchisq_array=ca / ng)

@@ -1,0 +1,360 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the
+golden vectors captured from the reference.  Needs a real MI355X.
+
+Tolerances (north star): chi^2 within 1e-6 relative (we assert tighter where
+the arithmetic allows), RV within 0.01 km/s, integer / index work bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, GOLD_CONFIG, gold_specdata
+from oracle import rvs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TAGS = ['c0', 'c1', 'c2', 'c3']
+CHI_RTOL = 1e-8      # well inside the 1e-6 contract
+RV_ATOL = 1e-3       # km/s, contract is 1e-2
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    from rvspecfit_amd import _lib
+    _lib.require_gpu()
+    _lib.lib()
+    return torch.device('cuda')
+
+
+@pytest.fixture(scope='module')
+def config(gpu):
+    from rvspecfit_amd import spec_inter
+    from rvspecfit_amd.library import TemplateLibrary
+    cfg = dict(GOLD_CONFIG)
+    cfg['template_lib'] = 'golden://'
+    for n in ('gold_b', 'gold_r'):
+        lib = TemplateLibrary(n, np.load(os.path.join(GOLD, 'lib_%s.npz' % n)))
+        spec_inter.register_library(lib, 'golden://')
+    return cfg
+
+
+def test_native_library_is_loaded(gpu):
+    from rvspecfit_amd import _lib
+    assert _lib.lib().rvs_abi_version() == 1
+    maps = open('/proc/self/maps').read()
+    assert 'librvsgpu.so' in maps
+
+
+@pytest.mark.parametrize('kind', ['log', 'lin'])
+def test_spline_construct_eval(cases, gpu, kind):
+    from rvspecfit_amd import spec_fit
+    g = lambda k: cases['spline/%s/%s' % (kind, k)]
+    S = spec_fit.getRVInterpol(g('xs'), g('ys'), log_step=(kind == 'log'))
+    co = S.coef[0].cpu().numpy()
+    for i, k in enumerate('ABCD'):
+        np.testing.assert_allclose(co[:-1, i], g(k), rtol=1e-9, atol=1e-12)
+    ret, pos = S(g('evalx'), return_pos=True)
+    np.testing.assert_allclose(ret, g('ret'), rtol=1e-11, atol=1e-12)
+    O = orc.Spline(g('xs'), g('ys'), log_step=(kind == 'log'))
+    _, opos = O(g('evalx'), return_pos=True)
+    np.testing.assert_array_equal(pos, opos)   # integer work: bit exact
+
+
+def test_spline_desi_size_vs_oracle(gpu):
+    from rvspecfit_amd import spec_fit
+    rng = np.random.RandomState(5)
+    xs = np.exp(np.linspace(np.log(3500.), np.log(5900.), 6215))
+    ys = 1 + 0.3 * rng.standard_normal(len(xs))
+    ex = np.sort(rng.uniform(3600, 5800, size=2751))
+    S = spec_fit.getRVInterpol(xs, ys)
+    O = orc.Spline(xs, ys)
+    co = S.coef[0].cpu().numpy()
+    for i, k in enumerate('ABCD'):
+        np.testing.assert_allclose(co[:-1, i], getattr(O, k), rtol=1e-9,
+                                   atol=1e-11)
+    ret, pos = S(ex, return_pos=True)
+    oret, opos = O(ex, return_pos=True)
+    np.testing.assert_array_equal(pos, opos)
+    np.testing.assert_allclose(ret, oret, rtol=1e-10, atol=1e-12)
+
+
+def test_spline_error_codes(gpu):
+    from rvspecfit_amd import spec_fit
+    xs = np.exp(np.linspace(1, 2, 50))
+    S = spec_fit.getRVInterpol(xs, np.ones(50))
+    with pytest.raises(AssertionError):
+        S(np.array([xs[0] * 0.9, xs[3]]))
+    with pytest.raises(AssertionError):
+        S(np.array([xs[3], xs[-1]]))
+    xs2 = xs.copy()
+    xs2[2] *= 1.001
+    with pytest.raises(AssertionError):
+        spec_fit.getRVInterpol(xs2, np.ones(50))(np.array([xs[5]]))
+
+
+@pytest.mark.parametrize('name', ['gold_b', 'gold_r'])
+def test_polylinear(cases, gold_libs, config, name):
+    from rvspecfit_amd import spec_inter
+    it = spec_inter.getInterpolator(name, config)
+    P = cases['interp/params']
+    templ, outside, cell, wts = it.lib.eval_batch(
+        torch.as_tensor(P).to('cuda'), details=True)
+    templ, outside = templ.cpu().numpy(), outside.cpu().numpy()
+    cell, wts = cell.cpu().numpy(), wts.cpu().numpy()
+    olib = gold_libs[name]
+    for i, p in enumerate(P):
+        ospec, info = olib.eval(p, details=True)
+        if info['nearest'] < 0:   # polylinear cell: ids bit exact
+            assert cell[i, 0] == 0
+            np.testing.assert_array_equal(cell[i, 2:], info['ids'])
+            np.testing.assert_allclose(wts[i], info['weights'], rtol=1e-13,
+                                       atol=1e-16)
+            np.testing.assert_allclose(templ[i], ospec, rtol=1e-12)
+        else:
+            assert cell[i, 0] in (1, 2)
+            assert cell[i, 1] == info['nearest']
+            np.testing.assert_allclose(templ[i], ospec, rtol=3e-7)
+        np.testing.assert_allclose(templ[i], cases['interp/%s/eval' % name][i],
+                                   rtol=3e-7)
+        oref = cases['interp/%s/outside' % name][i]
+        if np.isfinite(oref):
+            assert abs(outside[i] - oref) <= 1e-12 * max(1, abs(oref))
+        else:
+            assert not np.isfinite(outside[i])
+    # API of the reference object
+    np.testing.assert_allclose(it.eval(tuple(P[0])), templ[0])
+    assert it.outsideFlag(tuple(P[4])) == outside[4]
+    with pytest.raises(ValueError):
+        it.eval(dict(teff=5000., logg=2.))
+
+
+def test_vsini(cases, config, gold_libs):
+    from rvspecfit_amd import spec_fit
+    lam = gold_libs['gold_b'].lam
+    for i, v in enumerate(cases['vsini/vsinis']):
+        out = spec_fit.convolve_vsini(lam, cases['vsini/templ'], float(v))
+        np.testing.assert_allclose(out, cases['vsini/conv_%d' % i], rtol=1e-11)
+    P = cases['interp/params']
+    rots = [None, (10., ), (300., )]
+    for name in ('gold_b', 'gold_r'):
+        for ip in (0, 3, 4):
+            for ir, rot in enumerate(rots):
+                o, lam_t, sp, tag, ls = spec_fit.getCurTempl(
+                    name, tuple(P[ip]), rot, config)
+                k = 'curtempl/%s/p%d_r%d/' % (name, ip, ir)
+                np.testing.assert_allclose(sp, cases[k + 'spec'], rtol=3e-7)
+                assert abs(o - cases[k + 'outside']) < 1e-12
+
+
+def _sds(cases, tag):
+    from rvspecfit_amd import spec_fit
+    return gold_specdata(cases, tag, spec_fit.SpecData)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_get_chisq(cases, config, tag):
+    from rvspecfit_amd import spec_fit
+    sds = _sds(cases, tag)
+    for i in range(7):
+        k = '%s/chisq/t%d/' % (tag, i)
+        vs = float(cases[k + 'vsini'])
+        rot = None if np.isnan(vs) else (vs, )
+        opt = dict(npoly=int(cases[k + 'npoly']),
+                   rbf_continuum=bool(cases[k + 'rbf']))
+        val = spec_fit.get_chisq(sds, float(cases[k + 'vel']),
+                                 tuple(cases[k + 'param']), rot, options=opt,
+                                 config=config)
+        ref = float(cases[k + 'value'])
+        assert abs(val - ref) <= 1e-7 * abs(ref), (i, val, ref)
+        if i < 3:
+            full = spec_fit.get_chisq(sds, float(cases[k + 'vel']),
+                                      tuple(cases[k + 'param']), rot,
+                                      options=opt, config=config,
+                                      full_output=True)
+            np.testing.assert_allclose(full['chisq_array'],
+                                       cases[k + 'chisq_array'], rtol=1e-6)
+            np.testing.assert_array_equal(full['npix_array'],
+                                          cases[k + 'npix_array'])
+            for n, m, rm in zip(cases[tag + '/names'], full['models'],
+                                full['raw_models']):
+                np.testing.assert_allclose(m, cases[k + 'model_%s' % n],
+                                           rtol=1e-6)
+                np.testing.assert_allclose(rm, cases[k + 'raw_model_%s' % n],
+                                           rtol=3e-7)
+    val = spec_fit.get_chisq(sds, float(cases[tag + '/vel']),
+                             tuple(cases[tag + '/truth']), None,
+                             options=dict(npoly=10), config=config,
+                             espec_systematic=0.05)
+    assert abs(val - cases[tag + '/chisq/sys005']) <= 1e-7 * abs(val)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_find_best_vs_reference_and_oracle(cases, config, gold_libs,
+                                           gold_config, tag):
+    from rvspecfit_amd import spec_fit
+    sds = _sds(cases, tag)
+    osds = gold_specdata(cases, tag, orc.SpecData)
+    vg = cases['vel_grid']
+    for g in ('g1', 'g3'):
+        k = '%s/%s/' % (tag, g)
+        vs = float(cases[k + 'vsini'])
+        rot = None if np.isnan(vs) else (vs, )
+        pl = [tuple(_) for _ in cases[k + 'params_list']]
+        r = spec_fit.find_best(sds, vg, pl, rot, options=dict(npoly=10),
+                               config=config)
+        assert abs(r['best_vel'] - cases[k + 'best_vel']) < RV_ATOL
+        assert abs(r['vel_err'] - cases[k + 'vel_err']) < 1e-4
+        assert abs(r['kurtosis'] - cases[k + 'kurtosis']) < 1e-4
+        assert abs(r['skewness'] - cases[k + 'skewness']) < 1e-4
+        np.testing.assert_allclose(r['best_param'], cases[k + 'best_param'])
+        np.testing.assert_allclose(r['probs'], cases[k + 'probs'], rtol=1e-5,
+                                   atol=1e-12)
+        assert abs(r['best_chi'] - cases[k + 'best_chi']) <= 1e-7 * abs(
+            r['best_chi'])
+        # whole grid against the reference's grid
+        b, _ = spec_fit.as_batch(sds)
+        par = torch.as_tensor(np.array(pl))[None].to('cuda')
+        vst = None if rot is None else torch.as_tensor([rot[0]],
+                                                       dtype=torch.float64
+                                                       ).to('cuda')
+        chisq, st, _ = spec_fit.chisq_grid_jobs(
+            b, torch.as_tensor(vg).to('cuda'), par, vst, dict(npoly=10), config)
+        got = chisq[0].cpu().numpy().T   # [Nv, Np]
+        assert rel(got, cases[k + 'chisq_grid']) < 1e-7
+        assert int(st.sum().item()) == 0
+        if g == 'g1':
+            # and against the C oracle (tighter: same float32 template rows)
+            fast = orc.chisq_grid_fast(osds, vg, pl[0], rot, dict(npoly=10),
+                                       gold_config, gold_libs)
+            assert rel(got[:, 0], fast) < CHI_RTOL
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_chisq_continuum(cases, config, tag):
+    from rvspecfit_amd import spec_fit
+    r = spec_fit.get_chisq_continuum(_sds(cases, tag), options=dict(npoly=10))
+    np.testing.assert_allclose(r['chisq_array'],
+                               cases[tag + '/cont/chisq_array'], rtol=1e-8)
+    np.testing.assert_allclose(r['redchisq_array'],
+                               cases[tag + '/cont/redchisq_array'], rtol=1e-8)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_ccf(cases, config, gold_libs, gold_config, tag):
+    from rvspecfit_amd import fitter_ccf, spec_fit, spec_inter, engine
+    sds = _sds(cases, tag)
+    osds = gold_specdata(cases, tag, orc.SpecData)
+    b, _ = spec_fit.as_batch(sds)
+    libs = spec_inter.get_libs(b.names, config)
+    for arm, osd in zip(b.arms, osds):
+        pre = engine.ccf_preprocess(arm, libs[arm.name], config, details=True)
+        ps, pi, info = orc.preprocess_data(osd.lam, osd.spec, osd.espec,
+                                           gold_libs[osd.name].ccf,
+                                           badmask=osd.badmask, details=True)
+        gps, gpi = pre['proc_spec'][0].cpu().numpy(), pre['proc_ivar'][0].cpu().numpy()
+        # masks are integer work: the zero pattern of ivar must be identical
+        np.testing.assert_array_equal(gpi == 0, pi == 0)
+        np.testing.assert_array_equal(gps == 0, ps == 0)
+        # continuum: LM converges to the minimum TRF stops near (its 1e-8 tols)
+        np.testing.assert_allclose(pre['cont'][0].cpu().numpy(), info['cont'],
+                                   rtol=2e-6)
+        np.testing.assert_allclose(gps, ps, rtol=5e-6, atol=1e-7)
+        np.testing.assert_allclose(gpi, pi, rtol=5e-6)
+        k = '%s/ccf/%s/' % (tag, arm.name)
+        np.testing.assert_allclose(gps, cases[k + 'proc_spec'], rtol=5e-6,
+                                   atol=1e-7)
+    r = fitter_ccf.fit(sds, config)
+    o = orc.ccf_fit(osds, gold_config, gold_libs)
+    np.testing.assert_allclose([r['best_par'][k] for k in
+                                ('teff', 'logg', 'feh', 'alpha')],
+                               cases[tag + '/ccf/best_par'])
+    assert abs(r['best_vel'] - cases[tag + '/ccf/best_vel']) < RV_ATOL
+    assert abs(r['best_vel'] - o['best_vel']) < RV_ATOL
+    np.testing.assert_allclose(r['best_ccf'], cases[tag + '/ccf/best_ccf'],
+                               rtol=2e-6)
+    np.testing.assert_allclose(r['vel_grid'], cases[tag + '/ccf/vel_grid'])
+    bv = float(cases[tag + '/ccf/best_vsini'])
+    assert r['best_vsini'] == bv
+    for sd in sds:
+        np.testing.assert_allclose(
+            r['best_model'][sd.name],
+            cases['%s/ccf/%s/best_model' % (tag, sd.name)])
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_ccf_all_templates_vs_oracle(cases, config, gold_libs, gold_config,
+                                     tag):
+    """every (template, velocity) entry of the CCF chi^2 surface, computed
+    from the SAME pre-processed spectrum as the oracle (isolates the FFT)."""
+    from rvspecfit_amd import spec_fit, spec_inter, engine
+    sds = _sds(cases, tag)
+    osds = gold_specdata(cases, tag, orc.SpecData)
+    b, _ = spec_fit.as_batch(sds)
+    libs = spec_inter.get_libs(b.names, config)
+    r = engine.ccf_fit(b, libs, config, keep_all=True)
+    o = orc.ccf_fit(osds, gold_config, gold_libs, details=True)
+    got = r['all_chisqs'][0].cpu().numpy()
+    ref = o['all_chisqs']
+    scale = np.abs(ref).max()
+    assert np.max(np.abs(got - ref)) < 2e-5 * scale
+    assert int(r['best_id'][0].item()) == o['best_id']
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_refine(cases, config, tag):
+    from rvspecfit_amd import vel_fit
+    sds = _sds(cases, tag)
+    bp = dict(params=tuple(cases[tag + '/truth']), rot_params=None)
+    bv, be, sk, ku = vel_fit._find_best_vel_iterate(
+        float(cases[tag + '/refine/start_vel']), config['min_vel'],
+        config['max_vel'], config['vel_step0'], specdata=sds, best_param=bp,
+        config=config, options=dict(npoly=10),
+        min_vel_step=config['min_vel_step'])
+    assert abs(bv - cases[tag + '/refine/best_vel']) < RV_ATOL
+    assert abs(be - cases[tag + '/refine/vel_err']) < 1e-4
+    assert abs(sk - cases[tag + '/refine/skewness']) < 1e-3
+    assert abs(ku - cases[tag + '/refine/kurtosis']) < 1e-3
+
+
+def test_firstguess(cases, config):
+    from rvspecfit_amd import vel_fit
+    sds = _sds(cases, 'c0')
+    pg = {'logg': [1, 3], 'teff': [4000, 5000, 7000], 'feh': [-2, -1],
+          'alpha': [0]}
+    fg = vel_fit.firstguess(sds, options=dict(npoly=10), config=config,
+                            vsinigrid=(None, 100), paramsgrid=pg)
+    keys = [str(_) for _ in cases['c0/firstguess/keys']]
+    assert sorted(fg.keys()) == keys
+    np.testing.assert_allclose([float(fg[k]) for k in keys],
+                               cases['c0/firstguess/vals'])
+
+
+def test_batch_equals_singles(cases, config):
+    """4 golden spectra of the 2-arm cases stacked in one batch give the same
+    records as one-by-one calls (batching is arithmetic-neutral)."""
+    from rvspecfit_amd import spec_fit, pipeline
+    from rvspecfit_amd.engine import SpecBatch
+    lists = [_sds(cases, t) for t in ('c1', 'c3')]
+    batch = SpecBatch.from_specdata(lists)
+    rec = pipeline.fit_batch(batch, config, options=dict(npoly=10)).cpu().numpy()
+    for i, sl in enumerate(lists):
+        one = pipeline.fit_batch(SpecBatch.from_specdata([sl]), config,
+                                 options=dict(npoly=10)).cpu().numpy()
+        np.testing.assert_array_equal(rec[i], one[0])
+
+
+def test_overlap_error(cases, config):
+    from rvspecfit_amd import spec_fit
+    sds = _sds(cases, 'c0')
+    bad = [spec_fit.SpecData('gold_b', sds[0].lam * 1.2, sds[0].spec,
+                             sds[0].espec)]
+    with pytest.raises(RuntimeError):
+        spec_fit.get_chisq(bad, 0., tuple(cases['c0/truth']),
+                           options=dict(npoly=10), config=config)

@@ -474,6 +474,7 @@ extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
     (void)hipFuncSetAttribute((const void *)ccf_preprocess_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               140 * 1024);
+    (void)hipGetLastError();
     attr_set = true;
   }
   hipLaunchKernelGGL(ccf_preprocess_kernel, dim3(B), dim3(256), shm,
@@ -681,6 +682,7 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
     (void)hipFuncSetAttribute((const void *)ccf_xcorr_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               150 * 1024);
+    (void)hipGetLastError();
     attr_set = true;
   }
   hipStream_t st = rvs_stream(stream);

@@ -530,11 +530,12 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
   const size_t shm = sizeof(double) * (2 * (size_t)npix + FULL_MAXP * FULL_MAXP +
                                        2 * FULL_MAXP + 8 +
                                        2 * FULL_MAXP * FULL_MAXP + FULL_MAXP);
-  if (shm > 160 * 1024) return RVS_E_ARG;
+  if (shm > 150 * 1024) return RVS_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)chisq_full_kernel,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
     attr_set = true;
   }
   hipLaunchKernelGGL(chisq_full_kernel, dim3(J), dim3(256), shm,

@@ -447,12 +447,13 @@ extern "C" int rvs_spline_construct(const double *knots, const double *ys,
                                     int ntp, int B, double *coef, void *stream) {
   if (ntp < 4 || B < 1) return RVS_E_ARG;
   const size_t shm = sizeof(double) * (2 * (size_t)(ntp - 2) + 2 * 257);
-  if (shm > 160 * 1024) return RVS_E_ARG;
+  if (shm > 159 * 1024) return RVS_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)spline_construct_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+                              159 * 1024);
+    (void)hipGetLastError();
     attr_set = true;
   }
   hipLaunchKernelGGL(spline_construct_kernel, dim3(B), dim3(256), shm,

@@ -247,7 +247,7 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
         J = job_templ.shape[0]
     else:
         J = batch.S
-    vels = vels.contiguous()
+    vels = vels.to(device=dev, dtype=torch.float64).contiguous()
     shared = vels.dim() == 1
     Nv = vels.shape[-1]
     vstride = 0 if shared else Nv
@@ -392,7 +392,7 @@ def ccf_fit(batch, libs, config, keep_all=False, max_chunk=None):
     Tn = ref['T']
     for n in batch.names[1:]:
         cc = libs[n].ccf
-        if (cc['T'] != Tn and True) and cc['T'] != Tn:
+        if cc['T'] != Tn:
             raise RuntimeError('CCF template counts are inconsistent across setups')
         if (not np.array_equal(ref['params'], cc['params'])
                 or not np.array_equal(ref['vsinis'], cc['vsinis'],

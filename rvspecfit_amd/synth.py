@@ -181,3 +181,132 @@ def write_fits_grid(prefix, wavefile, grid_kw=None, holes=(), lam_hr=None):
         k += 1
     pyfits.writeto(prefix + '/' + wavefile, lam_hr, overwrite=True)
     return vec
+
+
+# --------------------------------------------------------------------------
+# vectorised generators (bench / large parity cases).  Same model as
+# spectrum(); `xp` is numpy or torch so the observed spectra of a 10 000 spectra
+# batch can be synthesised directly in HBM.
+# --------------------------------------------------------------------------
+def spectra_batch(lam, teff, logg, feh, alpha, vel=None, wresol=0.0, xp=np,
+                  lines=None):
+    """[B, npix] spectra for parameter vectors (arrays of length B) observed at
+    radial velocities `vel` (km/s) on the common grid `lam` (numpy, host).
+    With xp=torch the parameter arrays are device tensors and so is the result."""
+    lines = _LINES if lines is None else lines
+    lam_np = np.asarray(lam, dtype=np.float64)
+    if xp is np:
+        lamx = lam_np
+        f = 1.0
+        if vel is not None:
+            beta = np.asarray(vel) / SPEED_OF_LIGHT
+            f = np.sqrt((1 - beta) / (1 + beta))[:, None]
+        clip = np.clip
+    else:
+        lamx = xp.as_tensor(lam_np, device=teff.device)
+        f = 1.0
+        if vel is not None:
+            beta = vel / SPEED_OF_LIGHT
+            f = xp.sqrt((1 - beta) / (1 + beta))[:, None]
+        clip = xp.clamp
+    lr = lamx[None, :] * f  # rest-frame wavelengths [B, npix]
+    out = (teff[:, None] / 5000.)**4 * (5000. / lr)
+    tnorm = (teff - 3000.) / 9000.
+    press = 0.03 + 0.12 * logg
+    vmax = 0.0 if vel is None else 0.0045
+    for cen, dep, kind, w0 in zip(lines['cen'], lines['depth'], lines['kind'],
+                                  lines['width']):
+        if cen < lam_np[0] * (1 - vmax) - 40 or cen > lam_np[-1] * (1 + vmax) + 40:
+            continue
+        wint = xp.sqrt(w0**2 + press**2)
+        w = xp.sqrt(wint**2 + wresol**2)
+        if kind == 0:
+            amp = dep * 10**(0.45 * feh) * (1.15 - 0.7 * tnorm)
+        elif kind == 1:
+            amp = dep * 10**(0.45 * (feh + alpha)) * (1.1 - 0.6 * tnorm)
+        else:
+            amp = dep * (0.25 + 0.9 * tnorm) * (1.2 - 0.08 * logg)
+        amp = clip(amp, 0, 0.92) * wint / w
+        wmax = float(w.max())
+        i0, i1 = np.searchsorted(lam_np, [cen * (1 - vmax) - 7 * wmax,
+                                          cen * (1 + vmax) + 7 * wmax])
+        if i1 > i0:
+            x = (lr[:, i0:i1] - cen) / w[:, None]
+            out[:, i0:i1] *= 1 - amp[:, None] * xp.exp(-0.5 * x * x)
+    return out
+
+
+def make_interp_library_fast(setup, lam_left, lam_right, step, grid_kw=None,
+                             resol=None, dtype=np.float32):
+    """Vectorised make_interp_library (no holes)."""
+    grid_kw = grid_kw or {}
+    u, vec = regular_grid(**grid_kw)
+    lam = template_lam_grid(lam_left, lam_right, step)
+    wres = 0.0 if resol is None else 0.5 * (lam_left + lam_right) / resol / 2.35
+    sp = spectra_batch(lam, vec[0], vec[1], vec[2], vec[3], wresol=wres)
+    dats = np.log(sp).astype(dtype)
+    mvec = vec.copy()
+    mvec[0] = np.log10(mvec[0])
+    uv0 = [np.unique(mvec[i], return_inverse=True) for i in range(4)]
+    uvecs = [_[0] for _ in uv0]
+    idgrid = np.zeros([len(_) for _ in uvecs], dtype=np.int64) - 1
+    idgrid[tuple(_[1] for _ in uv0)] = np.arange(vec.shape[1])
+    return dict(setup=setup, lam=lam, dats=dats, vec=mvec, uvecs=uvecs,
+                idgrid=idgrid, log_step=True, log_ids=(0, ),
+                parnames=PARNAMES, physical_vec=vec)
+
+
+def library_as_npz_dict(lib, ccf=None):
+    """Flatten to the converted-artefact key set (tests/golden/lib_*.npz) that
+    both library.TemplateLibrary and the oracle's Library read."""
+    d = dict(lam=lib['lam'], dats=lib['dats'], vec=lib['vec'],
+             idgrid=lib['idgrid'], log_step=np.array(True),
+             log_ids=np.array(lib['log_ids'], dtype=np.int64),
+             parnames=np.array(list(lib['parnames'])))
+    for i, u in enumerate(lib['uvecs']):
+        d['uvec%d' % i] = u
+    if ccf is not None:
+        d.update(ccf)
+    return d
+
+
+def make_ccf_templates(lib, lam0, lam1, step, every=64, vsinis=(0., 300.),
+                       convolve=None):
+    """CCF template set for a synthetic library in the reference's artefact
+    layout (make_ccf.py:417-493): continuum-normalised, optionally rotationally
+    broadened models rebinned on exp(linspace(log lam0, log lam1, 2^k)), their
+    rfft and the rfft of their squares.  The continuum of the synthetic model is
+    known analytically, so no robust fit is needed here (offline prep, not part
+    of the hot path).  `convolve(lam, templ[J, n], vsini[J])` is the vsini
+    broadening routine (the HIP kernel in the bench)."""
+    npoints = to_power_two(int((lam1 - lam0) / step))
+    logl = np.linspace(np.log(lam0), np.log(lam1), npoints)
+    sel = np.arange(0, lib['dats'].shape[0], every)
+    phys = lib['physical_vec'][:, sel]
+    models, params, vs_list = [], [], []
+    flux = np.exp(lib['dats'][sel].astype(np.float64))
+    cont = continuum(lib['lam'][None, :], phys[0][:, None])
+    for vs in vsinis:
+        m = flux
+        if vs and vs > 0:
+            m = convolve(lib['lam'], flux, np.full(len(sel), float(vs)))
+        for i in range(len(sel)):
+            c = np.interp(logl, np.log(lib['lam']), m[i] / cont[i], left=1.,
+                          right=1.)
+            models.append(c)
+            params.append(phys[:, i])
+            vs_list.append(vs)
+    # reference order: for model: for vsini (make_ccf.py:263-272)
+    order = np.argsort(np.tile(np.arange(len(sel)), len(vsinis)), kind='stable')
+    models = np.array(models)[order]
+    params = np.array(params)[order]
+    vs_list = np.array(vs_list, dtype=float)[order]
+    splinestep = max(1000., 3e5 * (np.exp((logl[-1] - logl[0]) / 20) - 1))
+    return dict(ccf_fft=np.fft.rfft(models, axis=1),
+                ccf_fft2=np.fft.rfft(models**2, axis=1), ccf_mod=models,
+                ccf_params=params, ccf_vsinis=vs_list,
+                ccf_parnames=np.array(list(PARNAMES)),
+                ccf_logl0=np.array(logl[0]), ccf_logl1=np.array(logl[-1]),
+                ccf_npoints=np.array(npoints), ccf_continuum=np.array(True),
+                ccf_splinestep=np.array(splinestep),
+                ccf_maxcontpts=np.array(20))

@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DESI 3-arm spectra/s for the full CCF + chi^2-grid fit.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the contract unit of work (SURVEY 8(d) D1:
+fitter_ccf.fit -> template build at the CCF parameters -> find_best over 400
+velocities -> get_chisq_continuum) over a batch of `--spectra` synthetic DESI
+b/r/z spectra that are already resident in HBM.  Workload = BASELINE.json
+configs[2] (DESI 3-arm, 10 000 spectra, polylinear interpolator, T=76 CCF
+templates); with N>1 every rank holds its own 10 000-spectra shard (weak
+scaling) and the only collective is the all_gather of the fixed-size result
+records.
+
+Rank 0 prints ONE JSON line with the contract keys plus
+  roofline     algorithmic HBM bytes of the dominant kernel / its measured time
+  cpu_baseline the oracle (CPU port of the reference) timed on host cores
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from rvspecfit_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+GRID_KW = dict(nteff=7, nlogg=7, nfeh=7, nalpha=7)
+RESOL = 3000.
+ARMS = ('b', 'r', 'z')
+CONFIG = dict(min_vel=-1000, max_vel=1000, vel_step0=5, min_vel_step=0.2,
+              min_vsini=0.1, max_vsini=500, template_lib='synthetic://desi')
+OPTIONS = dict(npoly=10)
+
+
+def arm_name(a):
+    return 'desi_' + a
+
+
+def obs_lam(a):
+    lo, hi, st = synth.DESI_ARMS[a]['obs']
+    return np.arange(lo, hi, st)
+
+
+def build_library_dicts(ccf_every, convolve):
+    """Synthetic DESI-shape template libraries (7^4 grid, 6215/5303/6449 px,
+    N_fft 8192) in the converted-artefact dict layout."""
+    out = {}
+    for a in ARMS:
+        l0, l1, st = synth.DESI_ARMS[a]['templ']
+        lib = synth.make_interp_library_fast(arm_name(a), l0, l1, st,
+                                             grid_kw=GRID_KW, resol=RESOL)
+        ccf = synth.make_ccf_templates(lib, l0, l1, st, every=ccf_every,
+                                       vsinis=(0., 300.), convolve=convolve)
+        out[arm_name(a)] = synth.library_as_npz_dict(lib, ccf)
+    return out
+
+
+def truth_params(S, seed):
+    rng = np.random.RandomState(seed)
+    return dict(teff=rng.uniform(3500, 11500, S), logg=rng.uniform(0.3, 4.7, S),
+                feh=rng.uniform(-1.9, -0.1, S), alpha=rng.uniform(0.05, 0.95, S),
+                vel=rng.normal(0, 100, S),
+                snr=10**rng.uniform(1, np.log10(300), S), seed=seed)
+
+
+def make_spectra_device(tp, device):
+    """Observed spectra synthesised directly in HBM (float64)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(tp['seed']) + 77)
+    t = {k: torch.as_tensor(np.asarray(v, dtype=np.float64)).to(device)
+         for k, v in tp.items() if k != 'seed'}
+    arms = []
+    for a in ARMS:
+        lam = obs_lam(a)
+        wres = 0.5 * sum(synth.DESI_ARMS[a]['templ'][:2]) / RESOL / 2.35
+        sp0 = synth.spectra_batch(lam, t['teff'], t['logg'], t['feh'],
+                                  t['alpha'], vel=t['vel'], wresol=wres,
+                                  xp=torch)
+        es = sp0 / t['snr'][:, None]
+        noise = torch.randn(sp0.shape, dtype=torch.float64, device=device,
+                            generator=g)
+        spec = sp0 + es * noise
+        bad = torch.rand(sp0.shape, device=device, generator=g) < 0.05
+        es = torch.where(bad, es * 1e4, es)  # masked: sigma inflated
+        arms.append((arm_name(a), lam, spec, es, bad.to(torch.uint8)))
+    return arms
+
+
+# ------------------------------------------------------------------ CPU leg
+def cpu_worker(args):
+    """Runs in a fresh process (never touches the GPU): the oracle -- the CPU
+    port of the reference -- on a bounded sample of the same workload."""
+    os.environ['OMP_NUM_THREADS'] = '1'
+    from oracle import rvs_oracle as orc
+    import multiprocessing as mp
+    d = dict(np.load(args.cpu_worker))
+    n = int(d['n'])
+    t0 = time.time()
+    dicts = build_library_dicts(args.ccf_every, orc.convolve_vsini_rows)
+    tlib = time.time() - t0
+    global _W
+    _W = dict(libs={k: orc.Library(v) for k, v in dicts.items()}, d=d)
+    ncore = max(1, min(args.cpu_cores or (os.cpu_count() or 1), n))
+    t0 = time.time()
+    if ncore > 1:
+        with mp.get_context('fork').Pool(ncore) as pool:
+            recs = pool.map(_cpu_one, range(n))
+    else:
+        recs = [_cpu_one(i) for i in range(n)]
+    wall = time.time() - t0
+    t1 = time.time()
+    _cpu_one(0)
+    one = time.time() - t1
+    print(json.dumps(dict(n=n, wall=wall, cores=ncore, one_spectrum_s=one,
+                          lib_s=tlib, recs=[list(map(float, r)) for r in recs])))
+
+
+def _cpu_one(i):
+    from oracle import rvs_oracle as orc
+    libs, d = _W['libs'], _W['d']
+    sds = [orc.SpecData(arm_name(a), obs_lam(a), d['spec_' + a][i],
+                        d['espec_' + a][i], badmask=d['bad_' + a][i] != 0)
+           for a in ARMS]
+    o = orc.ccf_fit(sds, CONFIG, libs)
+    vg = np.arange(CONFIG['min_vel'], CONFIG['max_vel'], CONFIG['vel_step0'])
+    vs = o['best_vsini']
+    rot = None if np.isnan(vs) else (vs, )
+    grid = orc.chisq_grid_fast(sds, vg, o['best_par'], rot, OPTIONS, CONFIG,
+                               libs)
+    s = orc.grid_summary(vg, grid[:, None])
+    c = orc.get_chisq_continuum(sds, options=OPTIONS)
+    return [o['best_id'], o['best_vel'], s['best_vel'], s['vel_err'],
+            s['best_chi']] + list(c['chisq_array'])
+
+
+def run_cpu_baseline(arms, n, args):
+    path = '/tmp/rvs_bench_cpu_sample_%d.npz' % os.getpid()
+    sample = dict(n=n)
+    for (name, lam, spec, es, bad), a in zip(arms, ARMS):
+        sample['spec_' + a] = spec[:n].cpu().numpy()
+        sample['espec_' + a] = es[:n].cpu().numpy()
+        sample['bad_' + a] = bad[:n].cpu().numpy()
+    np.savez(path, **sample)
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', path,
+           '--ccf-every', str(args.ccf_every), '--cpu-cores',
+           str(args.cpu_cores)]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=1500)
+    os.unlink(path)
+    if out.returncode != 0:
+        raise RuntimeError('cpu baseline failed: ' + out.stderr[-2000:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+# ------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--spectra', type=int, default=10000,
+                    help='spectra per GPU per step')
+    ap.add_argument('--ccf-every', type=int, default=64,
+                    help='grid subsampling of the CCF set: 64 -> T=76, 9 -> T=534')
+    ap.add_argument('--cpu-sample', type=int, default=64)
+    ap.add_argument('--cpu-cores', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--refine', action='store_true',
+                    help='also run the _minimum_sampler refinement (add-on)')
+    ap.add_argument('--cpu-worker', type=str, default=None)
+    args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args)
+
+    import torch
+    import torch.distributed as dist
+    from rvspecfit_amd import _lib, engine, pipeline, spec_inter
+    from rvspecfit_amd.library import TemplateLibrary
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl')
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    _lib.lib()
+    S = args.spectra
+
+    def gpu_convolve(lam, templ, vsini):
+        t = torch.as_tensor(np.ascontiguousarray(templ)).to(dev)
+        v = torch.as_tensor(np.ascontiguousarray(vsini)).to(dev)
+        return engine.convolve_vsini(lam, t, v).cpu().numpy()
+
+    t_setup = time.time()
+    dicts = build_library_dicts(args.ccf_every, gpu_convolve)
+    for name, d in dicts.items():
+        spec_inter.register_library(TemplateLibrary(name, d, device=dev),
+                                    CONFIG['template_lib'])
+    Tccf = dicts[arm_name('b')]['ccf_fft'].shape[0]
+    nfft = int(dicts[arm_name('b')]['ccf_npoints'])
+    tp = truth_params(S, seed=3 + 1000 * rank)
+    arms = make_spectra_device(tp, dev)
+    batch = engine.SpecBatch([engine.ArmData(n, lam, sp, es, bad, device=dev)
+                              for n, lam, sp, es, bad in arms])
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def step():
+        for a in batch.arms:
+            a._work.clear()  # per-spectrum preparation belongs to the step
+        rec = pipeline.fit_batch(batch, CONFIG, options=OPTIONS,
+                                 refine=args.refine)
+        if world > 1:
+            allrec = torch.empty((world * S, pipeline.NREC),
+                                 dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allrec, rec)
+            return allrec
+        return rec
+
+    for _ in range(args.warmup):
+        rec = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    engine.KTIMERS = {}
+    stage = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = engine.ktimers_summary()
+    engine.KTIMERS = None
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # one extra, untimed, instrumented step for the per-stage breakdown
+    timers = {}
+    for a in batch.arms:
+        a._work.clear()
+    pipeline.fit_batch(batch, CONFIG, options=OPTIONS, timers=timers)
+    torch.cuda.synchronize()
+    stage = {k: v[0].elapsed_time(v[1]) for k, v in timers.items()}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = world * S * args.steps / dt
+    # ---- roofline of the dominant kernel -------------------------------
+    # algorithmic bytes: the CCF template block streamed once
+    # per spectrum: sum_arm T*(nfft/2+1)*16 B*2 (+ the spectrum's own S*,V*)
+    n2 = nfft // 2 + 1
+    b_ccf_unit = len(ARMS) * Tccf * n2 * 32
+    nl, ms, units = kt.get('ccf_xcorr', (0, 0.0, 0))
+    # `units` counts spectrum-arm launches units (n spectra per arm launch)
+    ccf_bytes = units / len(ARMS) * b_ccf_unit
+    ccf_gbs = ccf_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    nl2, ms2, units2 = kt.get('chisq_grid', (0, 0.0, 0))
+    npix_tot = sum(a.npix for a in batch.arms)
+    ntp_tot = sum(len(dicts[arm_name(a)]['lam']) for a in ARMS)
+    # chi^2 grid: spectrum terms (16 B/px) + spline records (32 B/knot) + out
+    b_grid_unit = npix_tot * 16 + ntp_tot * 32 + 400 * 8
+    grid_gbs = (units2 / len(ARMS)) * b_grid_unit / (ms2 * 1e-3) / 1e9 if ms2 else 0
+    flop_grid_unit = 400 * npix_tot * (2 * 65 + 40)
+    grid_tflops = (units2 / len(ARMS)) * flop_grid_unit / (ms2 * 1e-3) / 1e12 if ms2 else 0
+    dominant = 'ccf_xcorr_kernel' if ms >= ms2 else 'chisq_grid_kernel'
+    traffic = None
+    prof = os.path.join(REPO, 'profiles', 'r01_pmc_ccf_xcorr.json')
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    roof = dict(bound='hbm', kernel='ccf_xcorr_kernel', achieved=round(ccf_gbs, 1),
+                peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ccf_gbs / HBM_PEAK_GBS, 4),
+                traffic=traffic,
+                bytes_per_spectrum=b_ccf_unit,
+                avg_launch_ms=round(ms / max(nl, 1), 3), launches=nl,
+                dominant_by_time=dominant,
+                note='algorithmic bytes = CCF template block streamed once per '
+                     'spectrum (SURVEY 8(d) D3); the block is shared by every '
+                     'spectrum so most of it is served by L2/Infinity Cache')
+    kernels = {
+        'ccf_xcorr': dict(ms_per_step=round(ms / args.steps, 2),
+                          alg_GBps=round(ccf_gbs, 1)),
+        'chisq_grid': dict(ms_per_step=round(ms2 / args.steps, 2),
+                           alg_GBps=round(grid_gbs, 2),
+                           fp64_TFLOPs=round(grid_tflops, 2)),
+    }
+    if 'ccf_preprocess' in kt:
+        kernels['ccf_preprocess'] = dict(
+            ms_per_step=round(kt['ccf_preprocess'][1] / args.steps, 2))
+
+    # ---- CPU baseline + parity on the sample ---------------------------
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline:
+        n = min(args.cpu_sample, S)
+        cb = run_cpu_baseline(arms, n, args)
+        cpu = dict(value=round(cb['n'] / cb['wall'], 3), unit='spectra/s',
+                   cores=cb['cores'], kind='port',
+                   sample='%d of the %d spectra of rank 0, oracle (numpy/scipy + C '
+                          'port of the reference) CCF + 400-velocity chi^2 grid + '
+                          'continuum chi^2, process-parallel over %d host cores, '
+                          'OMP_NUM_THREADS=1' % (cb['n'], S, cb['cores']),
+                   spectra_per_s_per_core=round(cb['n'] / cb['wall'] / cb['cores'], 4),
+                   one_spectrum_seconds_1core=round(cb['one_spectrum_s'], 3))
+        g = rec[:n].cpu().numpy() if world == 1 else rec[:n].cpu().numpy()
+        o = np.array(cb['recs'])
+        same = (g[:, 0] == o[:, 0])
+        parity = dict(n=n, best_id_equal=int(same.sum()),
+                      max_abs_dvrad_ccf=float(np.abs(g[:, 1] - o[:, 1]).max()),
+                      max_abs_drv_same_template=float(
+                          np.abs(g[same, 7] - o[same, 2]).max()) if same.any() else None,
+                      max_rel_dchi_same_template=float(
+                          (np.abs(g[same, 11] - o[same, 4]) /
+                           np.abs(o[same, 4])).max()) if same.any() else None)
+
+    line = dict(
+        metric='spectra/sec (CCF+chi2 grid) DESI 3-arm',
+        value=round(value, 1), unit='spectra/s', n_gpus=world, steps=args.steps,
+        warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 2),
+        higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
+        data='synthetic',
+        config=dict(workload='DESI b/r/z 3-arm (2751/2326/2881 px), %d spectra '
+                             'per GPU per step, polylinear 7^4 grid, T=%d CCF '
+                             'templates, N_fft=%d, 400-velocity chi2 grid, '
+                             'npoly=10 (BASELINE configs[2])' % (S, Tccf, nfft),
+                    spectra_per_gpu=S, ccf_templates=Tccf, nfft=nfft,
+                    refine=bool(args.refine), parallelism='spectra-sharded x%d'
+                    % world),
+        roofline=roof, cpu_baseline=cpu, stage_ms=stage_round(stage),
+        kernels=kernels, parity_sample=parity, setup_s=round(t_setup, 1))
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def stage_round(d):
+    return {k: round(v, 2) for k, v in d.items()}
+
+
+if __name__ == '__main__':
+    main()

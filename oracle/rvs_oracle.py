@@ -817,3 +817,8 @@ def nn_forward(weights, p, M, S, log_ids=(0, )):
         if li < len(weights) - 1:
             h = silu32(h)
     return np.exp(np.clip(h.astype(np.float64), -300, 300))
+
+
+def convolve_vsini_rows(lam, templ, vsini, eps=0.6):
+    """convolve_vsini applied to every row (bench helper)."""
+    return np.array([convolve_vsini(lam, t, v, eps) for t, v in zip(templ, vsini)])

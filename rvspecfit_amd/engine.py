@@ -20,6 +20,36 @@ from . import ccf_tables
 
 SPEED_OF_LIGHT = 299792.458  # km/s, spec_fit.py:23
 
+# optional per-kernel timing with HIP events on the launch stream (bench.py):
+# KTIMERS = {} enables it; each entry is a list of (start, end, units) tuples.
+KTIMERS = None
+
+
+class _ktime:
+
+    def __init__(self, name, units=1):
+        self.name, self.units = name, units
+
+    def __enter__(self):
+        if KTIMERS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if KTIMERS is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            KTIMERS.setdefault(self.name, []).append((self.e0, e1, self.units))
+
+
+def ktimers_summary():
+    """name -> (n_launch_groups, total_ms, total_units) after a synchronize"""
+    out = {}
+    for k, lst in (KTIMERS or {}).items():
+        ms = sum(a.elapsed_time(b) for a, b, _ in lst)
+        out[k] = (len(lst), ms, sum(u for _, _, u in lst))
+    return out
+
 
 def get_poly_basis(lam, npoly, rbf=True):
     """Continuum basis, spec_fit.py:148-176 (host, float64; depends only on the
@@ -266,6 +296,7 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
         pen = pen.contiguous()
         coef = coefs[ia]
         for a, b in _chunks(J, 65535):
+          with _ktime('chisq_grid', (b - a)):
             rc = L.rvs_chisq_grid(
                 _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(work), arm.npix,
                 npoly, arm.S, _lib.ptr(lib.knots), _lib.ptr(coef), lib.ntp,
@@ -367,7 +398,8 @@ def ccf_preprocess(arm, lib, config, details=False):
         cont = torch.empty((arm.S, arm.npix), dtype=torch.float64, device=dev)
         pfit = torch.zeros((arm.S, max(T['nnode'], 1)), dtype=torch.float64,
                            device=dev)
-    rc = L.rvs_ccf_preprocess(
+    with _ktime('ccf_preprocess', arm.S):
+      rc = L.rvs_ccf_preprocess(
         _lib.ptr(arm.lam), _lib.ptr(arm.spec), _lib.ptr(arm.espec),
         _lib.ptr(arm.badmask), arm.npix, arm.S, int(cc['continuum']),
         _lib.ptr(T['Lmat']), T['nnode'], _lib.ptr(T['bin_start']),
@@ -420,7 +452,8 @@ def ccf_fit(batch, libs, config, keep_all=False, max_chunk=None):
             nfft = cc['npoints']
             work = torch.empty((n, 2, nfft // 2 + 1, 2), dtype=torch.float64,
                                device=dev)
-            rc = L.rvs_ccf_xcorr(
+            with _ktime('ccf_xcorr', n):
+              rc = L.rvs_ccf_xcorr(
                 _lib.ptr(pre[ia]['proc_spec'][a:b]),
                 _lib.ptr(pre[ia]['proc_ivar'][a:b]), nfft, n,
                 _lib.ptr(cc['fft']), _lib.ptr(cc['fft2']), Tn,

@@ -177,10 +177,13 @@ int rvs_grid_moments(const double *chisq, const double *vels,
  * A15  CCF pre-processing of one arm; replaces make_ccf.preprocess_data
  * (make_ccf.py:330-414) with interp_masker (:288-327), get_continuum
  * (:105-152) and fit_resid (:155-164).  The k=2 interpolating continuum
- * spline is linear in its node values, so it enters as the design matrix
- * Lmat [npix, nnode] (host-built once per arm); the robust soft-L1 fit is a
- * device Levenberg-Marquardt on the same objective.
+ * spline is linear in its node values p: with C the B-spline collocation
+ * matrix at the nodes, S(lam_k) = sum_{q<3} Eb[k,q] * (C^-1 p)[El[k]+q].  The
+ * robust soft-L1 fit is a device Levenberg-Marquardt on the same objective.
  *
+ * Eb float64 [npix, 3], El int32 [npix]   B-spline basis of every pixel
+ * Cinv float64 [nnode, nnode]             inverse collocation matrix
+ * istart int32 [nnode-1]                  first pixel of every knot interval
  * bin_start int32 [nnode+1]  pixel ranges of the binned-median start
  * xind int32 [nfft], rw float64 [nfft]   rebin tables (xind<0: no coverage)
  * outputs: proc_spec, proc_ivar [B, nfft]; sse [B] = sum proc_spec^2 proc_ivar;
@@ -188,7 +191,8 @@ int rvs_grid_moments(const double *chisq, const double *vels,
  * ---------------------------------------------------------------------- */
 int rvs_ccf_preprocess(const double *lam, const double *spec,
                        const double *espec, const uint8_t *badmask, int npix,
-                       int B, int continuum, const double *Lmat, int nnode,
+                       int B, int continuum, const double *Eb, const int32_t *El,
+                       const double *Cinv, const int32_t *istart, int nnode,
                        const int32_t *bin_start, const int32_t *xind,
                        const double *rw, int nfft, double maxerr,
                        double *proc_spec, double *proc_ivar, double *sse,

@@ -37,29 +37,51 @@ def _bspl_basis(t, k, x, l):
     return h
 
 
-def interp_spline_design(nodes, lam, k=2):
-    """Lmat [len(lam), len(nodes)] with UnivariateSpline(nodes, p, s=0, k=2)(lam)
-    == Lmat @ p."""
+def interp_spline_tables(nodes, lam, k=2):
+    """B-spline form of UnivariateSpline(nodes, p, s=0, k=2)(lam):
+        S(lam_r) = sum_q Eb[r, q] * (Cinv @ p)[El[r] + q],  q = 0..2
+    Returns Eb [npix, 3], El int32 [npix] (non decreasing), Cinv [m, m] and
+    istart int32 [m-1]: first pixel of every knot interval (m-2 intervals)."""
     nodes = np.asarray(nodes, dtype=np.float64)
+    lam = np.asarray(lam, dtype=np.float64)
     m = len(nodes)
     assert m > k and k == 2
-    # FITPACK knots for s=0, k=2
+    # FITPACK knots for s=0, k=2 (fpcurf.f): interior knots at data mid points
     interior = 0.5 * (nodes[1:m - 2] + nodes[2:m - 1])
     t = np.concatenate([[nodes[0]] * 3, interior, [nodes[-1]] * 3])
     n = len(t)
     assert n == m + k + 1
 
-    def design(xs):
-        E = np.zeros((len(xs), m))
+    def basis(xs):
+        Eb = np.zeros((len(xs), k + 1))
+        El = np.zeros(len(xs), dtype=np.int32)
         for r, x in enumerate(xs):
             l = np.searchsorted(t, x, 'right') - 1
-            l = min(max(l, k), n - k - 2)
-            E[r, l - k:l + 1] = _bspl_basis(t, k, x, l)
-        return E
+            l = min(max(l, k), n - k - 2)   # ext=0: end pieces extrapolate
+            Eb[r] = _bspl_basis(t, k, x, l)
+            El[r] = l - k
+        return Eb, El
 
-    C = design(nodes)
-    E = design(np.asarray(lam, dtype=np.float64))
-    return E @ np.linalg.inv(C)
+    Cb, Cl = basis(nodes)
+    C = np.zeros((m, m))
+    for r in range(m):
+        C[r, Cl[r]:Cl[r] + 3] = Cb[r]
+    Eb, El = basis(lam)
+    assert np.all(np.diff(El) >= 0)
+    nint = m - 2
+    istart = np.searchsorted(El, np.arange(nint + 1)).astype(np.int32)
+    istart[nint] = len(lam)
+    return Eb, El, np.linalg.inv(C), istart
+
+
+def interp_spline_design(nodes, lam, k=2):
+    """Dense Lmat [len(lam), len(nodes)] with
+    UnivariateSpline(nodes, p, s=0, k=2)(lam) == Lmat @ p (tests)."""
+    Eb, El, Cinv, _ = interp_spline_tables(nodes, lam, k)
+    E = np.zeros((len(lam), len(nodes)))
+    for r in range(len(lam)):
+        E[r, El[r]:El[r] + 3] = Eb[r]
+    return E @ Cinv
 
 
 def continuum_nodes(lam0, splinestep):

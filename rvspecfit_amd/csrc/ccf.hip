@@ -17,6 +17,9 @@
 //  ccf_select_kernel      argmin over (template, velocity) + parabola.
 #include "common.h"
 
+#define PP_NT 1024   // threads per block of the pre-processing kernel
+#define PP_NW (PP_NT / 64)
+
 // ---------------------------------------------------------------------------
 // block-wide bitonic sort of n2 (power of two) doubles in LDS, ascending.
 // Optional companion key array (int16 "bin" major key).
@@ -30,20 +33,20 @@ __device__ void bitonic_sort(double *v, short *bin, int n2) {
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       __syncthreads();
-      for (int i = threadIdx.x; i < n2; i += 256) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const double a = v[i], b = v[ixj];
-          const int ba = WITH_BIN ? bin[i] : 0, bb = WITH_BIN ? bin[ixj] : 0;
-          const bool up = ((i & k) == 0);
-          const bool sw = up ? key_less(bb, b, ba, a) : key_less(ba, a, bb, b);
-          if (sw) {
-            v[i] = b;
-            v[ixj] = a;
-            if (WITH_BIN) {
-              bin[i] = (short)bb;
-              bin[ixj] = (short)ba;
-            }
+      // thread t handles the pair whose lower index has bit j clear
+      for (int t = threadIdx.x; t < (n2 >> 1); t += PP_NT) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int ixj = i | j;
+        const double a = v[i], b = v[ixj];
+        const int ba = WITH_BIN ? bin[i] : 0, bb = WITH_BIN ? bin[ixj] : 0;
+        const bool up = ((i & k) == 0);
+        const bool sw = up ? key_less(bb, b, ba, a) : key_less(ba, a, bb, b);
+        if (sw) {
+          v[i] = b;
+          v[ixj] = a;
+          if (WITH_BIN) {
+            bin[i] = (short)bb;
+            bin[ixj] = (short)ba;
           }
         }
       }
@@ -74,30 +77,53 @@ __device__ __forceinline__ double median11(double *a) {
   return a[5];
 }
 
-#define CCF_MAXNODE 32
+#define CCF_MAXNODE 24
 
 struct LMShared {
   double p[CCF_MAXNODE], pn[CCF_MAXNODE], g[CCF_MAXNODE], dl[CCF_MAXNODE];
-  double H[CCF_MAXNODE * CCF_MAXNODE];
-  double Lc[CCF_MAXNODE * CCF_MAXNODE];
-  double red[8];
-  double cost, costn, lamd, medv, mederr, medspec;
-  int flag, ngood, firstgood, lastgood, nval, stop;
+  double c[CCF_MAXNODE], bvec[CCF_MAXNODE];
+  double H[CCF_MAXNODE * CCF_MAXNODE];   // normal matrix in node space
+  double T[CCF_MAXNODE * CCF_MAXNODE];   // Bm * Cinv
+  double Bm[CCF_MAXNODE * CCF_MAXNODE];  // banded normal matrix, B-spline space
+  double Ci[CCF_MAXNODE * CCF_MAXNODE];  // inverse collocation matrix
+  double isum[CCF_MAXNODE * 9];          // per knot-interval partial sums
+  double red[PP_NW];
+  double lamd, medv, mederr, medspec;
+  int flag, ngood, firstgood, lastgood, nval, stop, ok;
 };
 
-// model + residual statistics at parameter vector pp.  Returns block-wide
-// cost 0.5*sum rho(f^2), rho(z) = 2(sqrt(1+z)-1)  (scipy soft_l1, f_scale=1).
-// If store, also writes the Gauss-Newton weights:
-//   gw[k] = (m/e) f / sqrt(1+z)        (gradient)
-//   hw[k] = (m/e)^2 (1+z)^-1.5         (Hessian, rho' + 2 rho'' f^2 scaling)
-__device__ double lm_eval(const double *__restrict__ Lmat, int m, int npix,
-                          const double *pp, const double *cs, const double *ce,
-                          double *gw, double *hw, bool store, double *red) {
-  double c = 0;
-  for (int k = threadIdx.x; k < npix; k += 256) {
-    const double *Lr = Lmat + (int64_t)k * m;
+// The continuum is exp(clip(S(lam))) with S the k=2 INTERPOLATING spline
+// through (nodes, p) (make_ccf.py:155-164).  With C the B-spline collocation
+// matrix at the nodes, c = C^-1 p are its B-spline coefficients and
+// S(lam_k) = sum_{q<3} Eb[k][q] c[El[k]+q]  (3 non-zero quadratic B-splines per
+// pixel).  So every per-pixel quantity costs 3 fma, and the Gauss-Newton
+// matrix in node space is H = C^-T (E^T W E) C^-1 with E^T W E pentadiagonal.
+
+// c = Ci * pp  (all threads call; contains a barrier)
+__device__ __forceinline__ void lm_coeffs(LMShared &S, const double *pp, int m) {
+  __syncthreads();
+  if (threadIdx.x < m) {
     double s = 0;
-    for (int i = 0; i < m; i++) s = fma(Lr[i], pp[i], s);
+    for (int j = 0; j < m; j++) s = fma(S.Ci[threadIdx.x * m + j], pp[j], s);
+    S.c[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// cost 0.5*sum rho(f^2), rho(z) = 2(sqrt(1+z)-1) (scipy soft_l1, f_scale=1) at
+// the coefficients S.c.  If store, also the Gauss-Newton weights
+//   gw[k] = (m/e) f / sqrt(1+z),  hw[k] = (m/e)^2 (1+z)^-1.5
+// (rho' f and rho' + 2 rho'' f^2, the scaling scipy applies for robust losses)
+__device__ double lm_eval(LMShared &S, const double *__restrict__ Eb,
+                          const int32_t *__restrict__ El, int npix,
+                          const double *cs, const double *ce, double *gw,
+                          double *hw, bool store) {
+  double c = 0;
+  for (int k = threadIdx.x; k < npix; k += PP_NT) {
+    const int l = El[k];
+    double s = Eb[3 * k] * S.c[l];
+    s = fma(Eb[3 * k + 1], S.c[l + 1], s);
+    s = fma(Eb[3 * k + 2], S.c[l + 2], s);
     const bool clipped = (s < -100.0) || (s > 100.0);
     s = fmin(fmax(s, -100.0), 100.0);
     const double mod = exp(s);
@@ -112,16 +138,156 @@ __device__ double lm_eval(const double *__restrict__ Lmat, int m, int npix,
       hw[k] = d * d / (r * r * r);
     }
   }
-  return 0.5 * block_sum<4>(c, red);
+  return 0.5 * block_sum<PP_NW>(c, S.red);
 }
 
-__global__ void __launch_bounds__(256)
+// Gauss-Newton system in node space: S.H (m x m), S.g (m)
+__device__ void lm_normal(LMShared &S, const double *__restrict__ Eb,
+                          const int32_t *__restrict__ istart, int m,
+                          const double *gw, const double *hw) {
+  const int nint = m - 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  for (int t = wave; t < nint; t += PP_NW) {
+    double a[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) a[q] = 0;
+    for (int k = istart[t] + lane; k < istart[t + 1]; k += 64) {
+      const double e0 = Eb[3 * k], e1 = Eb[3 * k + 1], e2 = Eb[3 * k + 2];
+      const double h = hw[k], gg = gw[k];
+      a[0] = fma(h * e0, e0, a[0]);
+      a[1] = fma(h * e0, e1, a[1]);
+      a[2] = fma(h * e0, e2, a[2]);
+      a[3] = fma(h * e1, e1, a[3]);
+      a[4] = fma(h * e1, e2, a[4]);
+      a[5] = fma(h * e2, e2, a[5]);
+      a[6] = fma(gg, e0, a[6]);
+      a[7] = fma(gg, e1, a[7]);
+      a[8] = fma(gg, e2, a[8]);
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) a[q] = wave_sum(a[q]);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 9; q++) S.isum[t * 9 + q] = a[q];
+    }
+  }
+  __syncthreads();
+  // banded assembly: Bm[a][b], |a-b| <= 2; bvec[a]
+  for (int e = threadIdx.x; e < m * 5 + m; e += PP_NT) {
+    if (e < m * 5) {
+      const int a = e / 5, b = a + (e % 5) - 2;
+      if (b < 0 || b >= m) continue;
+      const int lo = min(a, b), hi = max(a, b);
+      double s = 0;
+      for (int t = max(0, hi - 2); t <= min(lo, nint - 1); t++) {
+        const int u = lo - t, v = hi - t;  // 0<=u<=v<=2
+        const int idx = (u == 0) ? v : (u == 1 ? 2 + v : 5);
+        s += S.isum[t * 9 + idx];
+      }
+      S.Bm[a * m + b] = s;
+    } else {
+      const int a = e - m * 5;
+      double s = 0;
+      for (int t = max(0, a - 2); t <= min(a, nint - 1); t++)
+        s += S.isum[t * 9 + 6 + (a - t)];
+      S.bvec[a] = s;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < m * m; e += PP_NT) {
+    const int a = e / m, j = e - a * m;
+    double s = 0;
+    for (int b = max(0, a - 2); b <= min(m - 1, a + 2); b++)
+      s = fma(S.Bm[a * m + b], S.Ci[b * m + j], s);
+    S.T[e] = s;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < m * m + m; e += PP_NT) {
+    if (e < m * m) {
+      const int i = e / m, j = e - i * m;
+      double s = 0;
+      for (int a = 0; a < m; a++) s = fma(S.Ci[a * m + i], S.T[a * m + j], s);
+      S.H[e] = s;
+    } else {
+      const int i = e - m * m;
+      double s = 0;
+      for (int a = 0; a < m; a++) s = fma(S.Ci[a * m + i], S.bvec[a], s);
+      S.g[i] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// (H + lamd diag H) dl = -g by an in-register Cholesky on ONE wave: lane i
+// holds row i, columns are exchanged with wave shuffles.  Writes S.dl, S.ok.
+__device__ void lm_solve_wave(LMShared &S, int m) {
+  const int lane = threadIdx.x & 63;
+  double r[CCF_MAXNODE];
+  const double ld = S.lamd;
+#pragma unroll
+  for (int j = 0; j < CCF_MAXNODE; j++) {
+    double v = (lane == j) ? 1.0 : 0.0;
+    if (lane < m && j < m) {
+      v = S.H[lane * m + j];
+      if (lane == j) v += ld * v;
+    }
+    r[j] = v;
+  }
+  double rhs = (lane < m) ? -S.g[lane] : 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < CCF_MAXNODE; k++) {
+    if (k < m) {
+      const double dkk = __shfl(r[k], k, 64);
+      if (!(dkk > 0)) ok = false;
+      const double lik = r[k] / sqrt(dkk);  // lane k: sqrt(dkk); lanes>k: L[i][k]
+      r[k] = lik;
+#pragma unroll
+      for (int j = k + 1; j < CCF_MAXNODE; j++) {
+        if (j < m) {
+          const double ljk = __shfl(lik, j, 64);
+          r[j] = fma(-lik, ljk, r[j]);
+        }
+      }
+    }
+  }
+  // forward substitution L y = rhs
+#pragma unroll
+  for (int k = 0; k < CCF_MAXNODE; k++) {
+    if (k < m) {
+      const double yk = __shfl(rhs / r[k], k, 64);
+      if (lane == k) rhs = yk;
+      if (lane > k) rhs = fma(-r[k], yk, rhs);
+    }
+  }
+  // back substitution L^T x = y ; L[k][i] is register r[i] of lane k
+#pragma unroll
+  for (int k = CCF_MAXNODE - 1; k >= 0; k--) {
+    if (k < m) {
+      const double xk = __shfl(rhs / r[k], k, 64);
+      if (lane == k) rhs = xk;
+#pragma unroll
+      for (int i = 0; i < k; i++) {
+        const double lki = __shfl(r[i], k, 64);
+        if (lane == i) rhs = fma(-lki, xk, rhs);
+      }
+    }
+  }
+  if (lane < m) S.dl[lane] = ok ? rhs : 0.0;
+  if (lane == 0) S.ok = ok ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(PP_NT)
     ccf_preprocess_kernel(const double *__restrict__ lam,
                           const double *__restrict__ spec,
                           const double *__restrict__ espec,
                           const uint8_t *__restrict__ badmask, int npix, int np2,
-                          int continuum, const double *__restrict__ Lmat,
-                          int nnode, const int32_t *__restrict__ bin_start,
+                          int continuum, const double *__restrict__ Eb,
+                          const int32_t *__restrict__ El,
+                          const double *__restrict__ Cinv,
+                          const int32_t *__restrict__ istart, int nnode,
+                          const int32_t *__restrict__ bin_start,
                           const int32_t *__restrict__ xind,
                           const double *__restrict__ rw, int nfft, double maxerr,
                           double *__restrict__ proc_spec,
@@ -141,11 +307,13 @@ __global__ void __launch_bounds__(256)
   const double *es0 = espec + (int64_t)b * npix;
   const double nanv = __builtin_nan("");
 
-  for (int k = tid; k < npix; k += 256) {
+  for (int k = tid; k < npix; k += PP_NT) {
     cs[k] = sp0[k];
     ce[k] = es0[k];
     msk[k] = badmask ? (badmask[(int64_t)b * npix + k] != 0) : 0;
   }
+  if (continuum)
+    for (int e = tid; e < nnode * nnode; e += PP_NT) S.Ci[e] = Cinv[e];
   if (tid == 0) {
     S.flag = 0;
     S.nval = 0;
@@ -155,7 +323,7 @@ __global__ void __launch_bounds__(256)
   // ---- nanmedian(espec) -----------------------------------------------------
   {
     int cnt = 0;
-    for (int k = tid; k < np2; k += 256) {
+    for (int k = tid; k < np2; k += PP_NT) {
       double v = __builtin_inf();
       if (k < npix) {
         const double e = ce[k];
@@ -176,7 +344,7 @@ __global__ void __launch_bounds__(256)
 
   // ---- medfilt(spec, 11) <= 0 and error clipping (make_ccf.py:366-370) -------
   if (continuum) {
-    for (int k = tid; k < npix; k += 256) {
+    for (int k = tid; k < npix; k += PP_NT) {
       double w[11];
 #pragma unroll
       for (int q = 0; q < 11; q++) {
@@ -191,7 +359,7 @@ __global__ void __launch_bounds__(256)
   // ---- inflate masked errors, fill gaps (interp_masker, make_ccf.py:288-327) --
   {
     int ng = 0, fg = npix, lg = -1;
-    for (int k = tid; k < npix; k += 256) {
+    for (int k = tid; k < npix; k += PP_NT) {
       if (msk[k]) {
         ce[k] = 1e9 * mederr;
       } else {
@@ -220,11 +388,11 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     if (S.ngood == 0) {
       if (tid == 0) S.flag |= RVS_ST_ALLMASKED;
-      for (int k = tid; k < npix; k += 256)
+      for (int k = tid; k < npix; k += PP_NT)
         if (!(fabs(cs[k]) <= 1.79e308)) cs[k] = 1;
     } else {
       const int fgood = S.firstgood, lgood = S.lastgood;
-      for (int k = tid; k < npix; k += 256) {
+      for (int k = tid; k < npix; k += PP_NT) {
         if (!msk[k]) continue;
         double val;
         if (k < fgood)
@@ -246,7 +414,7 @@ __global__ void __launch_bounds__(256)
 
   // ---- median of the filled spectrum ----------------------------------------
   {
-    for (int k = tid; k < np2; k += 256)
+    for (int k = tid; k < np2; k += PP_NT)
       sb[k] = (k < npix) ? cs[k] : __builtin_inf();
     bitonic_sort<false>(sb, nullptr, np2);
     if (tid == 0) {
@@ -266,7 +434,7 @@ __global__ void __launch_bounds__(256)
   if (continuum) {
     const int m = nnode;
     // ---- binned medians -> p0 (make_ccf.py:141-143) -------------------------
-    for (int k = tid; k < np2; k += 256) {
+    for (int k = tid; k < np2; k += PP_NT) {
       double v = __builtin_inf();
       short bn = (short)(m + 1);
       if (k < npix) {
@@ -307,70 +475,18 @@ __global__ void __launch_bounds__(256)
       S.lamd = 1e-3;
       S.stop = 0;
     }
-    double cost = lm_eval(Lmat, m, npix, S.p, cs, ce, gw, hw, true, S.red);
-    const int NE = m * (m + 1) / 2 + m;
+    lm_coeffs(S, S.p, m);
+    double cost = lm_eval(S, Eb, El, npix, cs, ce, gw, hw, true);
     for (int it = 0; it < 60; it++) {
-      __syncthreads();
-      for (int e = tid; e < NE; e += 256) {
-        if (e >= m * (m + 1) / 2) {
-          const int i = e - m * (m + 1) / 2;
-          double s = 0;
-          for (int k = 0; k < npix; k++) s = fma(Lmat[(int64_t)k * m + i], gw[k], s);
-          S.g[i] = s;
-        } else {
-          int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-          while (i * (i + 1) / 2 > e) i--;
-          while ((i + 1) * (i + 2) / 2 <= e) i++;
-          const int jj = e - i * (i + 1) / 2;
-          double s = 0;
-          for (int k = 0; k < npix; k++)
-            s = fma(Lmat[(int64_t)k * m + i] * Lmat[(int64_t)k * m + jj], hw[k], s);
-          S.H[i * m + jj] = s;
-          S.H[jj * m + i] = s;
-        }
-      }
-      __syncthreads();
+      lm_normal(S, Eb, istart, m, gw, hw);
       // damped step; retry with larger damping until the cost does not grow
       for (int tries = 0; tries < 40; tries++) {
-        if (tid == 0) {
-          const double ld = S.lamd;
-          bool ok = true;
-          for (int i = 0; i < m && ok; i++)
-            for (int jj = 0; jj <= i; jj++) {
-              double s = S.H[i * m + jj];
-              if (i == jj) s += ld * S.H[i * m + i];
-              for (int k = 0; k < jj; k++) s -= S.Lc[i * m + k] * S.Lc[jj * m + k];
-              if (i == jj) {
-                if (!(s > 0)) {
-                  ok = false;
-                  break;
-                }
-                S.Lc[i * m + i] = sqrt(s);
-              } else
-                S.Lc[i * m + jj] = s / S.Lc[jj * m + jj];
-            }
-          if (ok) {
-            double y[CCF_MAXNODE];
-            for (int i = 0; i < m; i++) {
-              double s = -S.g[i];
-              for (int k = 0; k < i; k++) s -= S.Lc[i * m + k] * y[k];
-              y[i] = s / S.Lc[i * m + i];
-            }
-            for (int i = m - 1; i >= 0; i--) {
-              double s = y[i];
-              for (int k = i + 1; k < m; k++) s -= S.Lc[k * m + i] * S.dl[k];
-              S.dl[i] = s / S.Lc[i * m + i];
-            }
-            for (int i = 0; i < m; i++) S.pn[i] = S.p[i] + S.dl[i];
-          } else {
-            for (int i = 0; i < m; i++) {
-              S.dl[i] = 0;
-              S.pn[i] = S.p[i];
-            }
-          }
+        if (tid < 64) {
+          lm_solve_wave(S, m);
+          if (tid < m) S.pn[tid] = S.p[tid] + S.dl[tid];
         }
-        __syncthreads();
-        const double cn = lm_eval(Lmat, m, npix, S.pn, cs, ce, gw, hw, false, S.red);
+        lm_coeffs(S, S.pn, m);
+        const double cn = lm_eval(S, Eb, El, npix, cs, ce, gw, hw, false);
         if (cn <= cost) {  // accept (block-uniform decision)
           double mx = 0;
           for (int i = 0; i < m; i++) mx = fmax(mx, fabs(S.dl[i]));
@@ -394,19 +510,22 @@ __global__ void __launch_bounds__(256)
       }
       __syncthreads();
       if (S.stop) break;
-      cost = lm_eval(Lmat, m, npix, S.p, cs, ce, gw, hw, true, S.red);
+      lm_coeffs(S, S.p, m);
+      cost = lm_eval(S, Eb, El, npix, cs, ce, gw, hw, true);
     }
     __syncthreads();
+    lm_coeffs(S, S.p, m);
     if (pfit && tid < m) pfit[(int64_t)b * m + tid] = S.p[tid];
   }
 
   // ---- normalise (make_ccf.py:380-392) ----------------------------------------
-  for (int k = tid; k < npix; k += 256) {
+  for (int k = tid; k < npix; k += PP_NT) {
     double cont = 1.0;
     if (continuum) {
-      const double *Lr = Lmat + (int64_t)k * nnode;
-      double s = 0;
-      for (int i = 0; i < nnode; i++) s = fma(Lr[i], S.p[i], s);
+      const int l = El[k];
+      double s = Eb[3 * k] * S.c[l];
+      s = fma(Eb[3 * k + 1], S.c[l + 1], s);
+      s = fma(Eb[3 * k + 2], S.c[l + 2], s);
       cont = exp(fmin(fmax(s, -100.0), 100.0));
     }
     if (medv > 0)
@@ -428,7 +547,7 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   // ---- rebin to the FFT grid (make_ccf.py:394-409) -----------------------------
   double ss = 0;
-  for (int n = tid; n < nfft; n += 256) {
+  for (int n = tid; n < nfft; n += PP_NT) {
     const int xi = xind[n];
     double r1 = 0, r2 = 0;
     if (xi >= 0) {
@@ -441,7 +560,7 @@ __global__ void __launch_bounds__(256)
     proc_ivar[(int64_t)b * nfft + n] = r2;
     ss += r1 * r1 * r2;
   }
-  ss = block_sum<4>(ss, S.red);
+  ss = block_sum<PP_NW>(ss, S.red);
   if (tid == 0) {
     sse[b] = ss;
     if (S.flag && status) atomicOr(&status[b], S.flag);
@@ -457,30 +576,31 @@ static inline int next_pow2(int n) {
 extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
                                   const double *espec, const uint8_t *badmask,
                                   int npix, int B, int continuum,
-                                  const double *Lmat, int nnode,
-                                  const int32_t *bin_start, const int32_t *xind,
-                                  const double *rw, int nfft, double maxerr,
-                                  double *proc_spec, double *proc_ivar,
-                                  double *sse, double *cont, double *pfit,
-                                  int32_t *status, void *stream) {
+                                  const double *Eb, const int32_t *El,
+                                  const double *Cinv, const int32_t *istart,
+                                  int nnode, const int32_t *bin_start,
+                                  const int32_t *xind, const double *rw, int nfft,
+                                  double maxerr, double *proc_spec,
+                                  double *proc_ivar, double *sse, double *cont,
+                                  double *pfit, int32_t *status, void *stream) {
   if (npix < 12 || B < 1 || nfft < 2) return RVS_E_ARG;
   if (continuum && (nnode < 3 || nnode > CCF_MAXNODE)) return RVS_E_ARG;
   const int np2 = next_pow2(npix);
   const size_t shm = sizeof(double) * (3 * (size_t)npix + np2) +
                      sizeof(short) * np2 + ((npix + 15) / 16) * 16;
-  if (shm > 140 * 1024) return RVS_E_ARG;
+  if (shm + sizeof(LMShared) > 159 * 1024) return RVS_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)ccf_preprocess_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              140 * 1024);
+                              (int)(159 * 1024 - sizeof(LMShared)));
     (void)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL(ccf_preprocess_kernel, dim3(B), dim3(256), shm,
+  hipLaunchKernelGGL(ccf_preprocess_kernel, dim3(B), dim3(PP_NT), shm,
                      rvs_stream(stream), lam, spec, espec, badmask, npix, np2,
-                     continuum, Lmat, nnode, bin_start, xind, rw, nfft, maxerr,
-                     proc_spec, proc_ivar, sse, cont, pfit, status);
+                     continuum, Eb, El, Cinv, istart, nnode, bin_start, xind, rw,
+                     nfft, maxerr, proc_spec, proc_ivar, sse, cont, pfit, status);
   RVS_LAUNCH_CHECK();
   return 0;
 }

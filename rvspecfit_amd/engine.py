@@ -168,13 +168,18 @@ class ArmData:
         if cc['continuum']:
             nodes, edges = ccf_tables.continuum_nodes(self.lam_host,
                                                       cc['splinestep'])
-            Lm = ccf_tables.interp_spline_design(nodes, self.lam_host)
-            T['Lmat'] = torch.as_tensor(np.ascontiguousarray(Lm)).to(dev)
+            Eb, El, Cinv, istart = ccf_tables.interp_spline_tables(
+                nodes, self.lam_host)
+            T['Eb'] = torch.as_tensor(np.ascontiguousarray(Eb)).to(dev)
+            T['El'] = torch.as_tensor(El).to(dev)
+            T['Cinv'] = torch.as_tensor(np.ascontiguousarray(Cinv)).to(dev)
+            T['istart'] = torch.as_tensor(istart).to(dev)
             T['nnode'] = len(nodes)
             T['bin_start'] = torch.as_tensor(
                 ccf_tables.bin_ranges(self.lam_host, edges)).to(dev)
         else:
-            T['Lmat'], T['nnode'], T['bin_start'] = None, 0, None
+            T['Eb'] = T['El'] = T['Cinv'] = T['istart'] = None
+            T['nnode'], T['bin_start'] = 0, None
         self._ccf[key] = T
         return T
 
@@ -402,7 +407,8 @@ def ccf_preprocess(arm, lib, config, details=False):
       rc = L.rvs_ccf_preprocess(
         _lib.ptr(arm.lam), _lib.ptr(arm.spec), _lib.ptr(arm.espec),
         _lib.ptr(arm.badmask), arm.npix, arm.S, int(cc['continuum']),
-        _lib.ptr(T['Lmat']), T['nnode'], _lib.ptr(T['bin_start']),
+        _lib.ptr(T['Eb']), _lib.ptr(T['El']), _lib.ptr(T['Cinv']),
+        _lib.ptr(T['istart']), T['nnode'], _lib.ptr(T['bin_start']),
         _lib.ptr(T['xind']), _lib.ptr(T['rw']), nfft, 10.0, _lib.ptr(ps),
         _lib.ptr(pi), _lib.ptr(sse), _lib.ptr(cont), _lib.ptr(pfit),
         _lib.ptr(status), _lib.stream())

@@ -29,7 +29,7 @@ SIGNATURES = {
     'rvs_chisq_work_size': (L, [I, I]),
     'rvs_chisq_prepare': (I, [P, P, P, I, I, P, I, D, P, P]),
     'rvs_chisq_grid': (I, [P, P, P, I, I, I, P, P, I, I, I, P, P, I, P, L, I, P,
-                           D, D, P, P, P]),
+                           D, D, I, P, P, P]),
     'rvs_chisq_full': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, P, P, I, P,
                            D, P, P, P, P, P, P, P, P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),

@@ -217,6 +217,241 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-DMA variant (the default): the four waves of a block fit 256 velocities
+// of ONE job, so they share the template.  The observed pixels are walked in
+// chunks of `chunk` pixels; for every chunk the window of spline records
+// [p_lo, p_lo + WMAX) that ANY of the block's velocities can touch is copied
+// HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip, 1 KiB per wave
+// instruction, asynchronous), double buffered: the copy of chunk c+1 is in
+// flight while chunk c is computed.  Inside the pixel loop there is then no
+// vector-memory instruction at all: uniform data comes through the scalar cache,
+// spline records through ds_read.
+// ---------------------------------------------------------------------------
+#define CG_WMAX 512                       // knots per LDS window
+#define CG_COEF_BYTES (CG_WMAX * 32)      // double4 records
+#define CG_KNOT_BYTES ((CG_WMAX + 2) * 8 + 1008)  // rounded to 1 KiB pieces + pad
+#define CG_BUF_BYTES (CG_COEF_BYTES + 5 * 1024)
+
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void *)g,
+      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int P>
+__global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
+    chisq_grid_lds_kernel(const double *__restrict__ lam,
+                          const double *__restrict__ polysT,
+                          const double *__restrict__ work, int npix, int S,
+                          const double *__restrict__ knots,
+                          const double4 *__restrict__ coef, int ntp,
+                          int log_step, int chunk,
+                          const int32_t *__restrict__ job_spec,
+                          const int32_t *__restrict__ job_templ,
+                          const double *__restrict__ vels, int64_t vel_stride,
+                          int Nv, const double *__restrict__ penalty,
+                          double badchi, double beta_out,
+                          double *__restrict__ out,
+                          int32_t *__restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  __shared__ double sh_minmax[8];
+  const int j = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int iv = blockIdx.x * 256 + tid;
+  const bool active = iv < Nv;
+  const int s = job_spec ? job_spec[j] : j;
+  const int t = job_templ ? job_templ[j] : j;
+  double *outp = out + (int64_t)j * Nv;
+
+  const double pen = penalty ? penalty[j] : 0.0;
+  if (!(pen == pen) || isinf(pen)) {  // spec_fit.py:888-893 (block-uniform)
+    if (active) {
+      const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
+      outp[iv] = base + 1000.0 * badchi;
+    }
+    return;
+  }
+  const double *pixa = work;
+  const double2 *W = reinterpret_cast<const double2 *>(work + npix) +
+                     (int64_t)s * npix;
+  const double *scal = work + npix + 2ll * S * npix + 2 * s;
+  const double4 *cf = coef + (int64_t)t * ntp;
+
+  // inactive lanes copy the block's first velocity so that min/max are unaffected
+  const double vel = vels[(int64_t)j * vel_stride + (active ? iv : blockIdx.x * 256)];
+  const double bb = vel / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double x0 = knots[0], xlast = knots[ntp - 1];
+  const double inv_step = log_step ? 1.0 / log(knots[1] / x0) : 1.0 / (knots[1] - x0);
+  const double shift = log_step ? log(f) * inv_step : 0.0;
+
+  // block-wide extremes of the Doppler factor (window placement)
+  {
+    double fmn = f, fmx = f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      fmn = fmin(fmn, __shfl_xor(fmn, o, 64));
+      fmx = fmax(fmx, __shfl_xor(fmx, o, 64));
+    }
+    if (lane == 0) {
+      sh_minmax[wave] = fmn;
+      sh_minmax[4 + wave] = fmx;
+    }
+    __syncthreads();
+  }
+  const double fmin_b = fmin(fmin(sh_minmax[0], sh_minmax[1]), fmin(sh_minmax[2], sh_minmax[3]));
+  const double fmax_b = fmax(fmax(sh_minmax[4], sh_minmax[5]), fmax(sh_minmax[6], sh_minmax[7]));
+  const double smin_b = log_step ? log(fmin_b) * inv_step : 0.0;
+  const double smax_b = log_step ? log(fmax_b) * inv_step : 0.0;
+
+  int32_t st = 0;
+  {
+    const double xa = lam[0] * f, xb = lam[npix - 1] * f;
+    if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) st |= RVS_ST_SPLINE_RANGE;
+  }
+
+  double acc[P * (P + 1) / 2];
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < P * (P + 1) / 2; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = 0;
+
+  // window start of a chunk: knot coordinate of its first pixel at the block's
+  // smallest Doppler factor, minus a margin, even (16-B aligned knots copy)
+  auto window_lo = [&](int k0) -> int {
+    double c;
+    if (log_step)
+      c = pixa[k0] + smin_b;
+    else
+      c = (lam[k0] * fmin_b - x0) * inv_step;
+    int p = (int)floor(c) - 2;
+    p = min(p, ntp - CG_WMAX - 2);
+    p = max(p, 0);
+    return p & ~1;
+  };
+  auto stage = [&](int k0, int buf) {
+    const int plo = window_lo(k0);
+    char *base = lds + buf * CG_BUF_BYTES;
+    const char *gsrc = reinterpret_cast<const char *>(cf + plo);
+    const int64_t cmax = (int64_t)(ntp - plo) * 32 - 16;  // last valid 16-B piece
+#pragma unroll
+    for (int q = 0; q < CG_COEF_BYTES / 4096; q++) {
+      const int seg = q * 4 + wave;  // 1 KiB pieces, 4 waves
+      int64_t off = (int64_t)seg * 1024 + lane * 16;
+      off = (off < cmax) ? off : cmax;
+      glds16(gsrc + off, base + seg * 1024);
+    }
+    // knots: (CG_WMAX+2) doubles = 5 pieces of 1 KiB (the last partly used)
+    const char *ksrc = reinterpret_cast<const char *>(knots + plo);
+    const int64_t kmax = (int64_t)(ntp - plo) * 8 - 16;
+    for (int seg = wave; seg < 5; seg += 4) {
+      int64_t off = (int64_t)seg * 1024 + lane * 16;
+      off = (off < kmax) ? off : kmax;
+      glds16(ksrc + off, base + CG_COEF_BYTES + seg * 1024);
+    }
+  };
+
+  const int nchunk = (npix + chunk - 1) / chunk;
+  stage(0, 0);
+  __syncthreads();  // waits vmcnt(0): window 0 has landed
+  for (int c = 0; c < nchunk; c++) {
+    const int k0 = c * chunk, k1 = min(npix, k0 + chunk);
+    if (c + 1 < nchunk) stage(k1, (c + 1) & 1);  // async, lands during compute
+    const int plo = window_lo(k0);
+    const char *base = lds + (c & 1) * CG_BUF_BYTES;
+    const double4 *cw = reinterpret_cast<const double4 *>(base);
+    const double *kw = reinterpret_cast<const double *>(base + CG_COEF_BYTES);
+    {  // does the window cover the chunk for this block's velocities?
+      double chi;
+      if (log_step)
+        chi = pixa[k1 - 1] + smax_b;
+      else
+        chi = (lam[k1 - 1] * fmax_b - x0) * inv_step;
+      if ((int)chi + 2 >= plo + CG_WMAX && (int)chi + 2 < ntp) st |= 0x100;
+    }
+    for (int k = k0; k < k1; k++) {
+      const double lk = lam[k];
+      const double ak = pixa[k];
+      const double2 wk = W[k];
+      const double x = lk * f;
+      int pos;
+      if (log_step)
+        pos = (int)(ak + shift);
+      else
+        pos = (int)((x - x0) * inv_step);
+      pos = min(max(pos, 0), ntp - 2);
+      int pl = min(max(pos - plo, 0), CG_WMAX - 1);
+      double xl = kw[pl], xr = kw[pl + 1];
+      const int adj = (x < xl && pl > 0) ? -1 : ((x >= xr && pl < CG_WMAX - 1 && pos < ntp - 2) ? 1 : 0);
+      if (adj != 0) {
+        pl += adj;
+        xl = kw[pl];
+        xr = kw[pl + 1];
+      }
+      const double4 cc = cw[pl];
+      const double dl = x - xl, dr = xr - x;
+      const double tv = cc.x * dl * dl * dl + cc.y * dr * dr * dr + cc.z * dl + cc.w * dr;
+      const double w = tv * tv * wk.x;
+      const double u = tv * wk.y;
+      const double *pr = polysT + (int64_t)k * P;
+      double pw[P];
+#pragma unroll
+      for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
+#pragma unroll
+      for (int i = 0; i < P; i++) {
+        av[i] = fma(pr[i], u, av[i]);
+#pragma unroll
+        for (int jj = 0; jj <= i; jj++)
+          acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
+      }
+    }
+    __syncthreads();  // next window landed (vmcnt) and this one is free again
+  }
+
+  bool ok = true;
+  double ldet = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+#pragma unroll
+    for (int jj = 0; jj <= i; jj++) {
+      double sum = acc[TRI(i, jj)];
+#pragma unroll
+      for (int k = 0; k < jj; k++) sum -= acc[TRI(i, k)] * acc[TRI(jj, k)];
+      if (jj == i) {
+        if (!(sum > 0)) ok = false;
+        const double d = sqrt(sum);
+        acc[TRI(i, i)] = d;
+        ldet += log(d);
+      } else {
+        acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
+      }
+    }
+  }
+  double yy = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    double sum = av[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) sum -= acc[TRI(i, k)] * av[k];
+    av[i] = sum / acc[TRI(i, i)];
+    yy = fma(av[i], av[i], yy);
+  }
+  double chi = 2.0 * ldet + 2.0 * scal[0] + (scal[1] - yy);
+  if (st & (RVS_ST_SPLINE_RANGE | 0x100)) chi = __builtin_nan("");
+  if (!ok) st |= RVS_ST_CHOL_FALLBACK;
+  if (!ok || !(fabs(chi) <= 1.79e308)) {
+    st |= RVS_ST_NONFINITE;
+    chi = __builtin_nan("");
+  }
+  if (active) {
+    const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
+    outp[iv] = base + chi + pen;
+    if (st) atomicOr(&status[j], st);
+  }
+}
+
 template <int P>
 static int launch_grid(const double *lam, const double *polysT,
                        const double *work, int npix, int S, const double *knots,
@@ -224,8 +459,25 @@ static int launch_grid(const double *lam, const double *polysT,
                        const int32_t *job_spec, const int32_t *job_templ, int J,
                        const double *vels, int64_t vel_stride, int Nv,
                        const double *penalty, double badchi, double beta,
-                       double *out, int32_t *status, hipStream_t st) {
+                       double *out, int32_t *status, int chunk, hipStream_t st) {
   dim3 grid((Nv + 255) / 256, J);
+  if (chunk > 0 && ntp >= CG_WMAX + 2) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)chisq_grid_lds_kernel<P>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * CG_BUF_BYTES);
+      (void)hipGetLastError();
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(chisq_grid_lds_kernel<P>, grid, dim3(256),
+                       2 * CG_BUF_BYTES, st, lam, polysT, work, npix, S, knots,
+                       reinterpret_cast<const double4 *>(coef), ntp, log_step,
+                       chunk, job_spec, job_templ, vels, vel_stride, Nv, penalty,
+                       badchi, beta, out, status);
+    RVS_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(chisq_grid_kernel<P>, grid, dim3(256), 0, st, lam, polysT,
                      work, npix, S, knots,
                      reinterpret_cast<const double4 *>(coef), ntp, log_step,
@@ -266,16 +518,17 @@ extern "C" int rvs_chisq_grid(const double *lam, const double *polysT,
                               const int32_t *job_templ, int J,
                               const double *vels, int64_t vel_stride, int Nv,
                               const double *penalty, double badchi, double beta,
-                              double *out, int32_t *status, void *stream) {
+                              int chunk, double *out, int32_t *status,
+                              void *stream) {
   (void)Tn;
-  if (J < 1 || Nv < 1 || npix < 1 || ntp < 3) return RVS_E_ARG;
+  if (J < 1 || Nv < 1 || npix < 1 || ntp < 3 || chunk < 0) return RVS_E_ARG;
   if (J > 65535) return RVS_E_ARG;  // grid.y limit; callers chunk
   hipStream_t st = rvs_stream(stream);
 #define RVS_CASE(PP)                                                          \
   case PP:                                                                    \
     return launch_grid<PP>(lam, polysT, work, npix, S, knots, coef, ntp,      \
                            log_step, job_spec, job_templ, J, vels, vel_stride, \
-                           Nv, penalty, badchi, beta, out, status, st);
+                           Nv, penalty, badchi, beta, out, status, chunk, st);
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
     RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)

@@ -263,9 +263,42 @@ def convolve_vsini(lib_or_lam, templ, vsini, eps=0.6):
 # --------------------------------------------------------------------------
 # chi^2 grid over velocities: A7-eval + A10 + A11 (+ penalties of A11)
 # --------------------------------------------------------------------------
+CG_WMAX = 512          # knots per LDS window of chisq_grid_lds_kernel
+USE_LDS_WINDOW = False  # True: LDS-DMA staged variant (measured 25 % slower at 2 waves/SIMD)
+
+
+def lds_chunk(arm, lib, vmin, vmax):
+    """Largest pixel chunk whose spline window (incl. the Doppler range
+    [vmin, vmax]) fits the 512-knot LDS window of the staged chi^2 kernel, or 0
+    when the L1-gather variant has to be used."""
+    if not USE_LDS_WINDOW or lib.ntp < CG_WMAX + 2:
+        return 0
+    key = ('chunk', lib.name, id(lib), float(vmin), float(vmax))
+    if key in arm._ccf:
+        return arm._ccf[key]
+    beta = np.array([vmin, vmax], dtype=np.float64) / SPEED_OF_LIGHT
+    f = np.sqrt((1 - beta) / (1 + beta))  # f[0] >= f[1]
+    lam = arm.lam_host
+    if lib.log_step:
+        a = (np.log(lam) - np.log(lib.lam[0])) / lib.lnstep
+        lo, hi = a + np.log(f[1]) / lib.lnstep, a + np.log(f[0]) / lib.lnstep
+    else:
+        st = lib.lam[1] - lib.lam[0]
+        lo, hi = (lam * f[1] - lib.lam[0]) / st, (lam * f[0] - lib.lam[0]) / st
+    best = 0
+    for ch in (256, 224, 192, 160, 128, 96, 64, 48, 32, 16):
+        k0 = np.arange(0, len(lam), ch)
+        k1 = np.minimum(k0 + ch, len(lam)) - 1
+        if np.all(hi[k1] - lo[k0] + 8 <= CG_WMAX - 2):
+            best = ch
+            break
+    arm._ccf[key] = best
+    return best
+
+
 def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
                job_spec=None, job_templ=None, espec_sys=0.0,
-               outside_penalty=True, out=None):
+               outside_penalty=True, out=None, vel_bounds=None):
     """chi^2 of J jobs on a velocity grid, summed over the arms of `batch`.
 
     coefs[a]    [Tn, ntp_a, 4]   spline records of arm a
@@ -289,9 +322,12 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
     if out is None:
         out = torch.empty((J, Nv), dtype=torch.float64, device=dev)
     status = torch.zeros(J, dtype=torch.int32, device=dev)
+    if vel_bounds is None:
+        vel_bounds = (float(vels.min().item()), float(vels.max().item()))
     for ia, arm in enumerate(batch.arms):
         lib = libs[arm.name]
         work = arm.work(lib, espec_sys)
+        chunk = lds_chunk(arm, lib, vel_bounds[0], vel_bounds[1])
         polysT = arm.basis(npoly, rbf)
         o = outsides[ia]
         if job_templ is not None:
@@ -312,7 +348,7 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
                 (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None), b - a,
                 _lib.ptr(vels if shared else vels[a:b]), vstride, Nv,
                 _lib.ptr(pen[a:b]), float(batch.badchi),
-                0.0 if ia == 0 else 1.0, _lib.ptr(out[a:b]),
+                0.0 if ia == 0 else 1.0, chunk, _lib.ptr(out[a:b]),
                 _lib.ptr(status[a:b]), _lib.stream())
             _lib.check(rc, 'rvs_chisq_grid')
     return out, status

@@ -52,8 +52,9 @@ def fit_batch(batch, config, options=None, refine=False, timers=None):
     vg = torch.as_tensor(
         np.arange(config['min_vel'], config['max_vel'],
                   config['vel_step0']).astype(np.float64)).to(dev)
-    chisq, status = engine.chisq_grid(batch, libs, coefs, outs, vg, npoly=npoly,
-                                      rbf=rbf)
+    chisq, status = engine.chisq_grid(
+        batch, libs, coefs, outs, vg, npoly=npoly, rbf=rbf,
+        vel_bounds=(float(config['min_vel']), float(config['max_vel'])))
     res, _, mst = engine.grid_moments(chisq, vg, Np=1)
     ev.stop('chisq_grid')
 

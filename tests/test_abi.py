@@ -48,7 +48,7 @@ def test_argument_validation_without_gpu(lib):
     # shape errors are detected on the host before any launch
     assert lib.rvs_spline_construct(None, None, 2, 1, None, None) == -1
     assert lib.rvs_chisq_grid(None, None, None, 10, 99, 1, None, None, 10, 1, 1,
-                              None, None, 1, None, 0, 4, None, 0., 0., None,
+                              None, None, 1, None, 0, 4, None, 0., 0., 0, None,
                               None, None) == -1
     assert lib.rvs_ccf_xcorr(None, None, 1000, 1, None, None, 1, None, 1, None,
                              None, 5, None, None, 5, 0., None, None,

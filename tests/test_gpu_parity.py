@@ -362,3 +362,29 @@ def test_overlap_error(cases, config):
     with pytest.raises(RuntimeError):
         spec_fit.get_chisq(bad, 0., tuple(cases['c0/truth']),
                            options=dict(npoly=10), config=config)
+
+
+def test_lds_window_and_l1_gather_variants_agree(cases, config):
+    """the LDS-DMA staged chi^2 kernel and the L1-gather variant are the same
+    arithmetic: results must be bit identical"""
+    from rvspecfit_amd import spec_fit, engine
+    sds = _sds(cases, 'c1')
+    vg = cases['vel_grid'].astype(np.float64)
+    pl = [tuple(_) for _ in cases['c1/g3/params_list']]
+    out = []
+    for flag in (True, False):
+        engine.USE_LDS_WINDOW = flag
+        try:
+            b, _ = spec_fit.as_batch(sds)
+            for a in b.arms:
+                a._ccf = {k: v for k, v in a._ccf.items()
+                          if not (isinstance(k, tuple) and k[0] == 'chunk')}
+            par = torch.as_tensor(np.array(pl))[None].to('cuda')
+            chisq, st, _ = spec_fit.chisq_grid_jobs(
+                b, torch.as_tensor(vg).to('cuda'), par, None, dict(npoly=10),
+                config)
+            out.append(chisq.cpu().numpy())
+            assert int(st.sum().item()) == 0
+        finally:
+            engine.USE_LDS_WINDOW = False
+    np.testing.assert_array_equal(out[0], out[1])

@@ -184,16 +184,15 @@ def main():
     import torch
     import torch.distributed as dist
     from rvspecfit_amd import _lib, engine, pipeline, spec_inter
+    from rvspecfit_amd import dist as rdist
     from rvspecfit_amd.library import TemplateLibrary
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl')
     _lib.require_gpu()
     torch.cuda.set_device(local)
+    rdist.init_from_env(backend='nccl')
     dev = torch.device('cuda', local)
     _lib.lib()
     S = args.spectra
@@ -222,12 +221,8 @@ def main():
             a._work.clear()  # per-spectrum preparation belongs to the step
         rec = pipeline.fit_batch(batch, CONFIG, options=OPTIONS,
                                  refine=args.refine)
-        if world > 1:
-            allrec = torch.empty((world * S, pipeline.NREC),
-                                 dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(allrec, rec)
-            return allrec
-        return rec
+        # the only collective of the path: gather of the result records
+        return rdist.gather_records(rec, world * S, rank, world)
 
     for _ in range(args.warmup):
         rec = step()

@@ -1,0 +1,75 @@
+"""Multi-GPU: spectra are independent units, so the path shards by spectrum
+index with NO data-path collective; the only exchange is one gather of the
+fixed-size per-spectrum result records.
+
+One process per GPU (torchrun / torch.distributed.run); backend "nccl" is RCCL
+over xGMI on ROCm.  The reference's counterpart is its process pool over
+spectra (desi/desi_fit.py:1215-1218, 1475-1479).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(S, rank, world):
+    """Contiguous index block [lo, hi) of rank `rank`: ceil(S/world) spectra per
+    rank, the last ranks may be short or empty."""
+    per = -(-S // world)
+    lo = min(S, rank * per)
+    hi = min(S, lo + per)
+    return lo, hi
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (as set by
+    torch.distributed.run).  Returns (rank, world, local_rank)."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        dist.init_process_group(backend)
+    return rank, world, local
+
+
+def gather_records(rec, S_total, rank=None, world=None):
+    """All-gather per-shard record tensors [n_r, NREC] into [S_total, NREC] on
+    every rank (shards follow shard_range; short shards are zero padded for
+    the fixed-size collective and trimmed afterwards)."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return rec
+    per = -(-S_total // world)
+    nrec = rec.shape[1]
+    pad = torch.zeros((per, nrec), dtype=rec.dtype, device=rec.device)
+    pad[:rec.shape[0]] = rec
+    full = torch.empty((world * per, nrec), dtype=rec.dtype, device=rec.device)
+    if rec.is_cuda:
+        dist.all_gather_into_tensor(full, pad)
+    else:  # gloo (CPU tests)
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        full = torch.cat(parts, dim=0)
+    return full[:S_total]
+
+
+def fit_sharded(make_batch, S_total, config, options=None, refine=False):
+    """Every rank fits its index block and all ranks receive the full table.
+
+    make_batch(lo, hi) -> engine.SpecBatch holding spectra lo..hi-1 on this
+    rank's GPU (the template libraries are replicated per rank)."""
+    from . import pipeline
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = shard_range(S_total, rank, world)
+    if hi > lo:
+        rec = pipeline.fit_batch(make_batch(lo, hi), config, options=options,
+                                 refine=refine)
+    else:
+        dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+        rec = torch.zeros((0, pipeline.NREC), dtype=torch.float64, device=dev)
+    return gather_records(rec, S_total, rank, world)

@@ -71,8 +71,13 @@ class TemplateLibrary:
             self.nn_M = _dev(d['nn_M'], torch.float64, device)
             self.nn_S = _dev(d['nn_S'], torch.float64, device)
             self.nn_hull = None
-            if 'nn_xeqs' in d:
-                self.nn_hull = (np.asarray(d['nn_xeqs']), np.asarray(d['nn_yeqs']))
+            if 'nn_pts' in d:
+                # OutsideInterpolator.__init__ (nn/RVSInterpolator.py:47-61):
+                # facet equations of the two 2-D convex hulls (host, once)
+                import scipy.spatial
+                pts = np.asarray(d['nn_pts'], dtype=np.float64)
+                self.nn_hull = (scipy.spatial.ConvexHull(pts[:, :2]).equations,
+                                scipy.spatial.ConvexHull(pts[:, 2:]).equations)
         self.ccf = None
         if 'ccf_fft' in d:
             fft = np.ascontiguousarray(d['ccf_fft'], dtype=np.complex128)
@@ -150,15 +155,18 @@ class TemplateLibrary:
         return templ, outside
 
     def _nn_outside(self, params):
-        """OutsideInterpolator.__call__ (nn/RVSInterpolator.py:63-71): squared
-        positive distance to the facets of two 2-D convex hulls (host-built
-        facet equations, evaluated with torch on the device)."""
+        """OutsideInterpolator.__call__ (nn/RVSInterpolator.py:63-71) on the
+        Mapper-transformed point, as SpecInterpolator.outsideFlag does
+        (spec_inter.py:257-272): squared positive distance to the facets of two
+        2-D convex hulls (facet equations built once on the host; evaluated
+        with torch on the device -- a [J,2]x[2,F] product, not a hot kernel)."""
         if self.nn_hull is None:
             return torch.zeros(params.shape[0], dtype=torch.float64,
                                device=self.device)
-        p = params.clone()
+        y = params.to(torch.float32).clone()   # Mapper.forward: float32 input
         for i in self.log_ids:
-            p[:, i] = torch.log10(p[:, i])
+            y[:, i] = torch.log10(y[:, i])
+        p = (y.double() - self.nn_M) / self.nn_S
         xe = torch.as_tensor(self.nn_hull[0], device=self.device)
         ye = torch.as_tensor(self.nn_hull[1], device=self.device)
         dx = (p[:, :2] @ xe[:, :-1].T + xe[:, -1]).max(dim=1).values

@@ -388,3 +388,49 @@ def test_lds_window_and_l1_gather_variants_agree(cases, config):
         finally:
             engine.USE_LDS_WINDOW = False
     np.testing.assert_array_equal(out[0], out[1])
+
+
+def _nn_lib(d, lam):
+    from rvspecfit_amd.library import TemplateLibrary
+    dd = dict(lam=lam, log_step=np.array(True), log_ids=np.array([0]),
+              parnames=np.array(['teff', 'logg', 'feh', 'alpha']),
+              nn_dims=d['dims'], nn_M=d['M'], nn_S=d['S'])
+    if 'pts' in d:
+        dd['nn_pts'] = d['pts']
+    for i in range(len(d['dims']) - 1):
+        dd['nn_W%d' % i] = d['W%d' % i]
+        dd['nn_b%d' % i] = d['b%d' % i]
+    return TemplateLibrary('nn_test', dd)
+
+
+def test_nn_template_vs_reference_golden(gpu):
+    d = dict(np.load(os.path.join(GOLD, 'nn_case.npz')))
+    lam = np.exp(np.linspace(np.log(4000.), np.log(4100.), int(d['dims'][-1])))
+    lib = _nn_lib(d, lam)
+    templ, outside = lib.eval_batch(torch.as_tensor(d['params']).to('cuda'))
+    # float32 MLP: the MFMA k-order differs from torch-CPU's; see DESIGN.md
+    np.testing.assert_allclose(templ.cpu().numpy(), d['out'], rtol=3e-6)
+    np.testing.assert_allclose(outside.cpu().numpy(), d['outside'], rtol=1e-5,
+                               atol=1e-9)
+
+
+def test_nn_template_desi_size_vs_oracle(gpu):
+    """the production shape 4 -> 256 -> 256 -> 256 -> 200 -> 6215 on the f32
+    MFMA path against the numpy float32 oracle, 300 parameter vectors (covers
+    partial tiles in every dimension)"""
+    rng = np.random.RandomState(12)
+    dims = np.array([4, 256, 256, 256, 200, 6215], dtype=np.int32)
+    d = dict(dims=dims, M=np.array([3.7, 2.5, -1., 0.5]),
+             S=np.array([0.15, 1.4, 0.6, 0.3]))
+    for i in range(5):
+        k, n = dims[i], dims[i + 1]
+        d['W%d' % i] = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+        d['b%d' % i] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    lam = np.exp(np.linspace(np.log(3500.), np.log(5900.), 6215))
+    lib = _nn_lib(d, lam)
+    P = np.array([rng.uniform(3500, 9000, 300), rng.uniform(0, 5, 300),
+                  rng.uniform(-2, 0, 300), rng.uniform(0, 1, 300)]).T
+    templ, _ = lib.eval_batch(torch.as_tensor(P).to('cuda'))
+    W = [(d['W%d' % i], d['b%d' % i]) for i in range(5)]
+    ref = orc.nn_forward(W, P, d['M'], d['S'])
+    np.testing.assert_allclose(templ.cpu().numpy(), ref, rtol=5e-6)

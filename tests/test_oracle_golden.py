@@ -267,3 +267,12 @@ def test_firstguess(cases, gold_libs, gold_config):
     assert sorted(fg.keys()) == keys
     np.testing.assert_allclose([float(fg[k]) for k in keys],
                                cases['c0/firstguess/vals'])
+
+
+def test_nn_forward_vs_reference_golden():
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'nn_case.npz'))
+    W = [(d['W%d' % i], d['b%d' % i]) for i in range(5)]
+    out = orc.nn_forward(W, d['params'], d['M'], d['S'])
+    # float32 network: summation order of the matmuls differs (BLAS vs torch)
+    np.testing.assert_allclose(out, d['out'], rtol=2e-6)

@@ -1,0 +1,86 @@
+"""Host-side pieces (no GPU): CCF tables, the artefact converter, synth."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.interpolate
+
+from rvspecfit_amd import ccf_tables as ct
+from rvspecfit_amd import synth
+from oracle import rvs_oracle as orc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_interp_spline_tables_match_scipy():
+    rng = np.random.RandomState(3)
+    lam = np.arange(3600., 5800.1, 0.8)
+    nodes, edges = ct.continuum_nodes(lam, 7934.)
+    Eb, El, Cinv, istart = ct.interp_spline_tables(nodes, lam)
+    p = rng.standard_normal(len(nodes))
+    c = Cinv @ p
+    mine = np.array([Eb[k] @ c[El[k]:El[k] + 3] for k in range(len(lam))])
+    ref = scipy.interpolate.UnivariateSpline(nodes, p, s=0, k=2)(lam)
+    np.testing.assert_allclose(mine, ref, rtol=1e-12, atol=1e-13)
+    assert istart[0] == 0 and istart[-1] == len(lam)
+    assert np.all(np.diff(istart) >= 0)
+    np.testing.assert_allclose(ct.interp_spline_design(nodes, lam) @ p, ref,
+                               rtol=1e-12, atol=1e-13)
+
+
+def test_bin_ranges_match_binned_statistic():
+    import scipy.stats
+    lam = np.arange(4400., 4720.1, 0.8)
+    nodes, edges = ct.continuum_nodes(lam, 1055.)
+    rng = np.random.RandomState(4)
+    y = rng.standard_normal(len(lam))
+    bs = scipy.stats.binned_statistic(lam, y, 'median', bins=edges).statistic
+    br = ct.bin_ranges(lam, edges)
+    for j in range(len(edges) - 1):
+        seg = y[br[j]:br[j + 1]]
+        if len(seg):
+            assert np.median(seg) == bs[j]
+        else:
+            assert np.isnan(bs[j])
+
+
+def test_lag_and_rebin_tables_match_oracle(gold_libs):
+    cc = gold_libs['gold_b'].ccf
+    s1, i1, v1 = ct.lag_tables(cc['logl0'], cc['logl1'], cc['npoints'], 1000)
+    s2, i2, v2 = orc.ccf_lag_tables(cc['logl0'], cc['logl1'], cc['npoints'], 1000)
+    assert s1 == s2
+    np.testing.assert_array_equal(i1, i2)
+    np.testing.assert_array_equal(v1, v2)
+
+
+def test_synth_batch_equals_scalar():
+    lam = np.arange(4400, 4720.1, 0.8)
+    a = synth.spectrum(lam, 5100., 2.2, -0.7, 0.15, wresol=0.3)
+    b = synth.spectra_batch(lam, np.array([5100.]), np.array([2.2]),
+                            np.array([-0.7]), np.array([0.15]), wresol=0.3)[0]
+    np.testing.assert_allclose(a, b, rtol=1e-14)
+
+
+@pytest.mark.skipif(not (os.path.exists('/opt/conda/bin/python3.9')
+                         and os.path.exists('/tmp/golden_work/templ/interp_gold_b.h5')),
+                    reason='needs the build container (h5py interpreter + the '
+                           'reference artefacts made by make_golden.py)')
+def test_convert_artefacts_reproduces_reference_loader(tmp_path):
+    src = '/tmp/golden_work/templ'
+    for f in os.listdir(src):
+        if 'gold_b' in f and not f.startswith('rvsgpu_'):
+            shutil.copy(os.path.join(src, f), tmp_path)
+    subprocess.check_call(['/opt/conda/bin/python3.9', '-W', 'ignore',
+                           os.path.join(REPO, 'tools', 'convert_artefacts.py'),
+                           str(tmp_path), 'gold_b'], stdout=subprocess.DEVNULL)
+    a = np.load(os.path.join(tmp_path, 'rvsgpu_gold_b.npz'))
+    b = np.load(os.path.join(REPO, 'tests', 'golden', 'lib_gold_b.npz'))
+    for k in b.files:
+        x, y = a[k], b[k]
+        assert x.shape == y.shape, k
+        if x.dtype.kind in 'USib':
+            assert np.array_equal(x, y), k
+        else:
+            np.testing.assert_array_equal(x, y, err_msg=k)

@@ -136,32 +136,55 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = 0;
 
-  for (int k = 0; k < npix; k++) {
-    const double lk = lam[k];          // wave-uniform -> scalar loads
-    const double ak = pixa[k];
-    const double2 wk = W[k];
-    const double x = lk * f;
-    int pos;
+  // Software pipeline (one pixel deep): the spline record and knot pair of
+  // pixel k+1 are requested -- at the ESTIMATED knot index -- and the scalar
+  // loads of its basis row / weights are issued before the ~75 fp64 operations
+  // of pixel k, so their latency hides behind arithmetic instead of s_waitcnt.
+  auto fetch = [&](int k, double &x, int &pos, double &xl, double &xr,
+                   double4 &c) {
+    x = lam[k] * f;
     if (log_step)
-      pos = (int)(ak + shift);
+      pos = (int)(pixa[k] + shift);
     else
       pos = (int)((x - x0) * lin_inv_step);
     pos = min(max(pos, 0), ntp - 2);
-    double xl = knots[pos], xr = knots[pos + 1];
-    // the estimate is within rounding of the true interval; repair it so that
-    // xl <= x < xr exactly as the reference's (int)((log x - log x0)/step)
-    const int adj = (x < xl && pos > 0) ? -1 : ((x >= xr && pos < ntp - 2) ? 1 : 0);
-    if (adj != 0) {
-      pos += adj;
-      xl = knots[pos];
-      xr = knots[pos + 1];
+    xl = knots[pos];
+    xr = knots[pos + 1];
+    c = cf[pos];
+  };
+  double xn, xln, xrn;
+  double4 cn;
+  int posn;
+  fetch(0, xn, posn, xln, xrn, cn);
+  double prn[P];
+#pragma unroll
+  for (int i = 0; i < P; i++) prn[i] = polysT[i];
+  double2 wn = W[0];
+  for (int k = 0; k < npix; k++) {
+    const double x = xn;
+    const double xl = xln, xr = xrn;
+    const double4 c = cn;
+    double pr[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) pr[i] = prn[i];
+    const double2 wk = wn;
+    {
+      const int kn = min(k + 1, npix - 1);
+      fetch(kn, xn, posn, xln, xrn, cn);
+      const double *pp = polysT + (int64_t)kn * P;
+#pragma unroll
+      for (int i = 0; i < P; i++) prn[i] = pp[i];
+      wn = W[kn];
     }
-    const double4 c = cf[pos];
+    // pos is (int)((log x - log x0)/step) evaluated as pixel coordinate +
+    // velocity shift; it can differ from the reference's value only when x is
+    // within rounding (~1e-11 knot spacings) of a knot, where the two adjacent
+    // cubics agree to O(dx^3) ~ 1e-33 -- exactly the ambiguity the reference's
+    // own libm log has.  (rvs_spline_eval keeps the reference formula verbatim.)
     const double dl = x - xl, dr = xr - x;
     const double tv = c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
     const double w = tv * tv * wk.x;   // (t/e)^2
     const double u = tv * wk.y;        // t s / e^2
-    const double *pr = polysT + (int64_t)k * P;
     double pw[P];
 #pragma unroll
     for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
@@ -382,14 +405,8 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
       else
         pos = (int)((x - x0) * inv_step);
       pos = min(max(pos, 0), ntp - 2);
-      int pl = min(max(pos - plo, 0), CG_WMAX - 1);
-      double xl = kw[pl], xr = kw[pl + 1];
-      const int adj = (x < xl && pl > 0) ? -1 : ((x >= xr && pl < CG_WMAX - 1 && pos < ntp - 2) ? 1 : 0);
-      if (adj != 0) {
-        pl += adj;
-        xl = kw[pl];
-        xr = kw[pl + 1];
-      }
+      const int pl = min(max(pos - plo, 0), CG_WMAX - 1);
+      const double xl = kw[pl], xr = kw[pl + 1];
       const double4 cc = cw[pl];
       const double dl = x - xl, dr = xr - x;
       const double tv = cc.x * dl * dl * dl + cc.y * dr * dr * dr + cc.z * dl + cc.w * dr;

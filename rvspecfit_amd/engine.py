@@ -111,8 +111,11 @@ class ArmData:
         key = (npoly, bool(rbf))
         if key not in self._basis:
             P = get_poly_basis(self.lam_host, npoly, rbf)
-            self._basis[key] = torch.as_tensor(
-                np.ascontiguousarray(P.T)).to(self.device)
+            # one zero row of padding: the pipelined kernel reads basis rows in
+            # 16-byte pairs, which over-reads 8 bytes for odd npoly
+            PT = np.zeros((self.npix + 1, npoly))
+            PT[:self.npix] = P.T
+            self._basis[key] = torch.as_tensor(PT).to(self.device)
         return self._basis[key]
 
     def work(self, lib, espec_sys=0.0):
@@ -264,14 +267,18 @@ def convolve_vsini(lib_or_lam, templ, vsini, eps=0.6):
 # chi^2 grid over velocities: A7-eval + A10 + A11 (+ penalties of A11)
 # --------------------------------------------------------------------------
 CG_WMAX = 512          # knots per LDS window of chisq_grid_lds_kernel
-USE_LDS_WINDOW = False  # True: LDS-DMA staged variant (measured 25 % slower at 2 waves/SIMD)
+import os as _os
+# chi^2-grid kernel variant: 'plain' (default) gathers the spline records
+# through the vector L1; 'lds' stages spline windows HBM->LDS with LDS-DMA
+# (bit-compatible, measured slower: DESIGN.md section 4.2)
+CHISQ_VARIANT = _os.environ.get('RVS_CHISQ_VARIANT', 'plain')
 
 
 def lds_chunk(arm, lib, vmin, vmax):
     """Largest pixel chunk whose spline window (incl. the Doppler range
     [vmin, vmax]) fits the 512-knot LDS window of the staged chi^2 kernel, or 0
     when the L1-gather variant has to be used."""
-    if not USE_LDS_WINDOW or lib.ntp < CG_WMAX + 2:
+    if CHISQ_VARIANT != 'lds' or lib.ntp < CG_WMAX + 2:
         return 0
     key = ('chunk', lib.name, id(lib), float(vmin), float(vmax))
     if key in arm._ccf:

@@ -364,30 +364,36 @@ def test_overlap_error(cases, config):
                            options=dict(npoly=10), config=config)
 
 
-def test_lds_window_and_l1_gather_variants_agree(cases, config):
-    """the LDS-DMA staged chi^2 kernel and the L1-gather variant are the same
-    arithmetic: results must be bit identical"""
+def test_chisq_kernel_variants_agree(cases, config):
+    """the two chi^2-grid kernel variants are the same arithmetic (differences:
+    fma contraction only)"""
     from rvspecfit_amd import spec_fit, engine
     sds = _sds(cases, 'c1')
     vg = cases['vel_grid'].astype(np.float64)
     pl = [tuple(_) for _ in cases['c1/g3/params_list']]
-    out = []
-    for flag in (True, False):
-        engine.USE_LDS_WINDOW = flag
+    out = {}
+    keep = engine.CHISQ_VARIANT
+    for var in ('plain', 'lds'):
+        engine.CHISQ_VARIANT = var
         try:
             b, _ = spec_fit.as_batch(sds)
             for a in b.arms:
                 a._ccf = {k: v for k, v in a._ccf.items()
                           if not (isinstance(k, tuple) and k[0] == 'chunk')}
             par = torch.as_tensor(np.array(pl))[None].to('cuda')
-            chisq, st, _ = spec_fit.chisq_grid_jobs(
-                b, torch.as_tensor(vg).to('cuda'), par, None, dict(npoly=10),
-                config)
-            out.append(chisq.cpu().numpy())
-            assert int(st.sum().item()) == 0
+            for npoly in (10, 7, 15):
+                chisq, st, _ = spec_fit.chisq_grid_jobs(
+                    b, torch.as_tensor(vg).to('cuda'), par, None,
+                    dict(npoly=npoly), config)
+                out[(var, npoly)] = chisq.cpu().numpy()
+                assert int(st.sum().item()) == 0
         finally:
-            engine.USE_LDS_WINDOW = False
-    np.testing.assert_array_equal(out[0], out[1])
+            engine.CHISQ_VARIANT = keep
+    for npoly in (10, 7, 15):
+        ref = out[('plain', npoly)]
+        for var in ('lds', ):
+            # chi^2 crosses zero on the grid: compare on the scale of the grid
+            assert np.max(np.abs(out[(var, npoly)] - ref)) < 1e-11 * np.abs(ref).max()
 
 
 def _nn_lib(d, lam):

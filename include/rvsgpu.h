@@ -211,14 +211,17 @@ int rvs_ccf_preprocess(const double *lam, const double *spec,
  *
  * tfft, tfft2 complex128 [T, nfft/2+1] (ccfdat_%s.npz 'fft','fft2')
  * twid complex128 [nfft/2]   exp(+2 pi i k / nfft)
- * lag_pos int32 [nlag]  position of lag `subind[l]` in the bit-reversed half-size
- *         inverse FFT output viewed as doubles: 2*bitrev(n>>1) + (n&1)
+ * lag_pos int32 [nlag]  position of lag n = subind[l] in the LDS image of the
+ *         half-size inverse FFT viewed as doubles: with p = rvs_ccf_fft_pos(nfft,
+ *         n>>1) (digit-reversed output order of the radix-8 DIF passes) and the
+ *         9/8 padding, lag_pos = 2*(p + (p>>3)) + (n&1)
  * lag_vel float64 [nlag] ascending lag velocities (fitter_ccf.py:136-154)
  * ilo int32 [nvel], vgrid float64 [nvel]        linear-interp tables
  * chisq [B, T, nvel]: out = beta*out + interp(-2 c0 + c1) (continuum) or
  *                      interp(-c0^2/c1)
  * work  complex128 [B, 2, nfft/2+1] scratch for conj rfft of spec*ivar, ivar
  * ---------------------------------------------------------------------- */
+int rvs_ccf_fft_pos(int nfft, int f);  /* host helper, see lag_pos */
 int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar, int nfft,
                   int B, const double *tfft, const double *tfft2, int T,
                   const double *twid, int continuum, const int32_t *lag_pos,

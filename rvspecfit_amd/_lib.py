@@ -35,6 +35,7 @@ SIGNATURES = {
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),
+    'rvs_ccf_fft_pos': (I, [I, I]),
     'rvs_ccf_xcorr': (I, [P, P, I, I, P, P, I, P, I, P, P, I, P, P, I, D, P, P,
                           P]),
     'rvs_ccf_select': (I, [P, P, I, I, I, P, I, P, P, P, P]),

@@ -8,12 +8,7 @@
 //      as a Levenberg-Marquardt on the same objective, normalisation, 2-point
 //      rebin with ivar propagation onto the log-lambda FFT grid.  All medians
 //      come from in-LDS bitonic sorts.
-//  ccf_rfft_kernel        conj(rfft(spec*ivar)), conj(rfft(ivar)) per spectrum.
-//  ccf_xcorr_kernel       one block per (spectrum, template): streams the
-//      template's two complex128 spectra from HBM (coalesced 16 B / lane),
-//      forms -2 F S* + F2 V*, one half-size complex inverse FFT in LDS (fp64,
-//      fused radix-4 DIF, bit-reversed output gathered only at the ~100 lags
-//      inside +-max_vel), linear interpolation to the common velocity grid.
+//  (the FFT cross-correlation itself lives in ccf_fft.hip)
 //  ccf_select_kernel      argmin over (template, velocity) + parabola.
 #include "common.h"
 
@@ -602,226 +597,6 @@ extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
                      continuum, Eb, El, Cinv, istart, nnode, bin_start, xind, rw,
                      nfft, maxerr, proc_spec, proc_ivar, sse, cont, pfit, status);
   RVS_LAUNCH_CHECK();
-  return 0;
-}
-
-// ---------------------------------------------------------------------------
-// FFT helpers.  a[] holds n2 complex128 in LDS.  tw[j] = exp(+2 pi i j / nfft),
-// j < nfft/2, nfft = 2*n2.  In-place decimation-in-frequency, two radix-2
-// stages fused per LDS round trip; natural order in, BIT-REVERSED order out.
-// SIGN = +1 : sum_k a_k e^{+2 pi i k m / n2} (un-normalised inverse)
-// SIGN = -1 : forward.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
-  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) {
-  return make_double2(a.x + b.x, a.y + b.y);
-}
-__device__ __forceinline__ double2 csub(double2 a, double2 b) {
-  return make_double2(a.x - b.x, a.y - b.y);
-}
-
-template <int SIGN>
-__device__ void fft_dif(double2 *a, int log2n, const double2 *__restrict__ tw) {
-  const int n2 = 1 << log2n;
-  int lg = log2n;  // log2 of current block size
-  while (lg >= 2) {
-    const int q = 1 << (lg - 2);           // quarter block
-    const int twmul = 1 << (log2n + 1 - lg);  // nfft / (4q)
-    __syncthreads();
-    for (int t = threadIdx.x; t < (n2 >> 2); t += 256) {
-      const int j = t & (q - 1);
-      const int base = ((t >> (lg - 2)) << lg) + j;
-      double2 w1 = tw[j * twmul];  // e^{+2 pi i j/(4q)}
-      if (SIGN < 0) w1.y = -w1.y;
-      const double2 w2 = cmul(w1, w1);  // e^{+-2 pi i j/(2q)}
-      // w1 * e^{+-i pi/2}
-      const double2 w1q = (SIGN > 0) ? make_double2(-w1.y, w1.x)
-                                     : make_double2(w1.y, -w1.x);
-      const double2 a0 = a[base], a1 = a[base + q], a2 = a[base + 2 * q],
-                    a3 = a[base + 3 * q];
-      const double2 b0 = cadd(a0, a2), b2 = cmul(csub(a0, a2), w1);
-      const double2 b1 = cadd(a1, a3), b3 = cmul(csub(a1, a3), w1q);
-      a[base] = cadd(b0, b1);
-      a[base + q] = cmul(csub(b0, b1), w2);
-      a[base + 2 * q] = cadd(b2, b3);
-      a[base + 3 * q] = cmul(csub(b2, b3), w2);
-    }
-    lg -= 2;
-  }
-  if (lg == 1) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < (n2 >> 1); t += 256) {
-      const double2 u = a[2 * t], v = a[2 * t + 1];
-      a[2 * t] = cadd(u, v);
-      a[2 * t + 1] = csub(u, v);
-    }
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ int brev(int x, int bits) {
-  return (int)(__brev((unsigned)x) >> (32 - bits));
-}
-
-// conj(rfft(x)) for x = proc_spec*proc_ivar (which 0) and proc_ivar (which 1)
-__global__ void __launch_bounds__(256)
-    ccf_rfft_kernel(const double *__restrict__ proc_spec,
-                    const double *__restrict__ proc_ivar, int nfft, int log2n,
-                    const double2 *__restrict__ tw, double2 *__restrict__ work) {
-  extern __shared__ double2 fa[];
-  const int b = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
-  const int n2 = nfft >> 1;
-  const double *ps = proc_spec + (int64_t)b * nfft;
-  const double *pi = proc_ivar + (int64_t)b * nfft;
-  for (int n = tid; n < n2; n += 256) {
-    double x0, x1;
-    if (which == 0) {
-      x0 = ps[2 * n] * pi[2 * n];
-      x1 = ps[2 * n + 1] * pi[2 * n + 1];
-    } else {
-      x0 = pi[2 * n];
-      x1 = pi[2 * n + 1];
-    }
-    fa[n] = make_double2(x0, x1);
-  }
-  fft_dif<-1>(fa, log2n, tw);
-  double2 *out = work + ((int64_t)b * 2 + which) * (n2 + 1);
-  for (int k = tid; k <= n2; k += 256) {
-    double2 X;
-    if (k == 0 || k == n2) {
-      const double2 z0 = fa[0];
-      X = make_double2(k == 0 ? z0.x + z0.y : z0.x - z0.y, 0.0);
-    } else {
-      const double2 zk = fa[brev(k, log2n)], zm = fa[brev(n2 - k, log2n)];
-      const double2 e = make_double2(zk.x + zm.x, zk.y - zm.y);   // zk + conj(zm)
-      const double2 d = make_double2(zk.x - zm.x, zk.y + zm.y);   // zk - conj(zm)
-      double2 w = tw[k];
-      w.y = -w.y;                                // e^{-2 pi i k/nfft}
-      const double2 q = cmul(w, d);              // w d
-      // X = e/2 - (i/2) q
-      X = make_double2(0.5 * (e.x + q.y), 0.5 * (e.y - q.x));
-    }
-    out[k] = make_double2(X.x, -X.y);  // conjugate
-  }
-}
-
-// one block per (spectrum b, template t)
-__global__ void __launch_bounds__(256)
-    ccf_xcorr_kernel(const double2 *__restrict__ work, int nfft, int log2n,
-                     const double2 *__restrict__ tfft,
-                     const double2 *__restrict__ tfft2, int T,
-                     const double2 *__restrict__ tw, int continuum,
-                     const int32_t *__restrict__ lag_pos,
-                     const double *__restrict__ lag_vel, int nlag,
-                     const int32_t *__restrict__ ilo,
-                     const double *__restrict__ vgrid, int nvel, double beta,
-                     double *__restrict__ chisq) {
-  extern __shared__ double2 fa[];
-  const int n2 = nfft >> 1;
-  double *c0 = reinterpret_cast<double *>(fa + n2);  // [nlag]
-  double *c1 = c0 + nlag;                            // [nlag]
-  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const double2 *Sc = work + ((int64_t)b * 2) * (n2 + 1);
-  const double2 *Vc = Sc + (n2 + 1);
-  const double2 *F = tfft + (int64_t)t * (n2 + 1);
-  const double2 *F2 = tfft2 + (int64_t)t * (n2 + 1);
-  const double inv_n = 1.0 / nfft;
-  const int npass = continuum ? 1 : 2;
-  for (int pass = 0; pass < npass; pass++) {
-    // spectrum X[k], k = 0..n2 of the real sequence to be inverted
-    //   continuum: X = -2 F S* + F2 V*;  else pass 0: F S*, pass 1: F2 V*
-    for (int k = tid; k <= (n2 >> 1); k += 256) {
-      const int m = n2 - k;
-      double2 Xk, Xm;
-      if (continuum) {
-        const double2 p1 = cmul(F[k], Sc[k]), p2 = cmul(F2[k], Vc[k]);
-        Xk = make_double2(p2.x - 2 * p1.x, p2.y - 2 * p1.y);
-        const double2 q1 = cmul(F[m], Sc[m]), q2 = cmul(F2[m], Vc[m]);
-        Xm = make_double2(q2.x - 2 * q1.x, q2.y - 2 * q1.y);
-      } else if (pass == 0) {
-        Xk = cmul(F[k], Sc[k]);
-        Xm = cmul(F[m], Sc[m]);
-      } else {
-        Xk = cmul(F2[k], Vc[k]);
-        Xm = cmul(F2[m], Vc[m]);
-      }
-      if (k == 0) {
-        // numpy irfft ignores the imaginary parts of the DC and Nyquist bins
-        fa[0] = make_double2(Xk.x + Xm.x, Xk.x - Xm.x);
-      } else {
-        const double2 e = make_double2(Xk.x + Xm.x, Xk.y - Xm.y);  // Xk + conj Xm
-        const double2 d = make_double2(Xk.x - Xm.x, Xk.y + Xm.y);  // Xk - conj Xm
-        const double2 q = cmul(tw[k], d);
-        // Z[k] = e + i q ; Z[m] = conj(e) + i conj(q)
-        fa[k] = make_double2(e.x - q.y, e.y + q.x);
-        if (m != k) fa[m] = make_double2(e.x + q.y, -e.y + q.x);
-      }
-    }
-    fft_dif<1>(fa, log2n, tw);
-    const double *fr = reinterpret_cast<const double *>(fa);
-    double *dst = (pass == 0) ? c0 : c1;
-    for (int l = tid; l < nlag; l += 256) dst[l] = fr[lag_pos[l]] * inv_n;
-    __syncthreads();
-  }
-  if (!continuum) {
-    for (int l = tid; l < nlag; l += 256) c0[l] = -c0[l] * c0[l] / c1[l];
-    __syncthreads();
-  }
-  double *out = chisq + ((int64_t)b * T + t) * nvel;
-  for (int v = tid; v < nvel; v += 256) {
-    const int lo = ilo[v];
-    const double x0 = lag_vel[lo], x1 = lag_vel[lo + 1];
-    const double sl = (c0[lo + 1] - c0[lo]) / (x1 - x0);
-    const double val = sl * (vgrid[v] - x0) + c0[lo];
-    out[v] = (beta != 0.0) ? beta * out[v] + val : val;
-  }
-}
-
-extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
-                             int nfft, int B, const double *tfft,
-                             const double *tfft2, int T, const double *twid,
-                             int continuum, const int32_t *lag_pos,
-                             const double *lag_vel, int nlag, const int32_t *ilo,
-                             const double *vgrid, int nvel, double beta,
-                             double *chisq, double *work, void *stream) {
-  int log2n = 0;
-  while ((2 << log2n) < nfft) log2n++;
-  if ((2 << log2n) != nfft || nfft < 16 || nfft > 16384) return RVS_E_ARG;
-  if (B < 1 || T < 1 || nlag < 2 || nvel < 1 || T > 65535) return RVS_E_ARG;
-  const int n2 = nfft >> 1;
-  const size_t shm1 = sizeof(double2) * (size_t)n2;
-  const size_t shm2 = shm1 + sizeof(double) * 2 * (size_t)nlag;
-  if (shm2 > 150 * 1024) return RVS_E_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)ccf_rfft_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              150 * 1024);
-    (void)hipFuncSetAttribute((const void *)ccf_xcorr_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              150 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
-  hipStream_t st = rvs_stream(stream);
-  hipLaunchKernelGGL(ccf_rfft_kernel, dim3(B, 2), dim3(256), shm1, st, proc_spec,
-                     proc_ivar, nfft, log2n,
-                     reinterpret_cast<const double2 *>(twid),
-                     reinterpret_cast<double2 *>(work));
-  RVS_LAUNCH_CHECK();
-  for (int b0 = 0; b0 < B; b0 += 65535) {
-    const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
-    hipLaunchKernelGGL(
-        ccf_xcorr_kernel, dim3(T, nb), dim3(256), shm2, st,
-        reinterpret_cast<const double2 *>(work) + (int64_t)b0 * 2 * (n2 + 1),
-        nfft, log2n, reinterpret_cast<const double2 *>(tfft),
-        reinterpret_cast<const double2 *>(tfft2), T,
-        reinterpret_cast<const double2 *>(twid), continuum, lag_pos, lag_vel,
-        nlag, ilo, vgrid, nvel, beta, chisq + (int64_t)b0 * T * nvel);
-    RVS_LAUNCH_CHECK();
-  }
   return 0;
 }
 

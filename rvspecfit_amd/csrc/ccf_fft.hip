@@ -1,0 +1,357 @@
+// ccf_fft.hip -- FFT cross-correlation for gfx950.
+//
+// Reference: py/rvspecfit/fitter_ccf.py:126-161 (rfft of spec*ivar and ivar,
+// lag tables) and :189-216 (irfft(F_t S*), irfft(F2_t V*), chi^2 = -2 c0 + c1 or
+// -c0^2/c1, linear interpolation to the common velocity grid, sum over arms).
+//
+//  ccf_rfft_kernel   conj(rfft(spec*ivar)), conj(rfft(ivar)) per spectrum.
+//  ccf_xcorr_kernel  one 512-thread block per (spectrum, template): the
+//      template's two complex128 spectra and the spectrum's S*, V* are streamed
+//      from HBM/L2 (coalesced 16 B per lane; bin pairs k, N/2-k handled together
+//      so every element is read once), the Hermitian pre-processing of the
+//      half-size inverse transform is done on the fly, then one N/2-point complex
+//      FFT in LDS: radix-8 decimation-in-frequency passes, one butterfly per
+//      thread per pass, 9/8-padded LDS image (conflict free for the stride-8 and
+//      stride-1 passes).  In continuum mode the reference's two
+//      inverse transforms collapse into ONE by linearity:
+//      -2 c0 + c1 = irfft(-2 F S* + F2 V*).  Only the ~100 lags inside +-max_vel
+//      are gathered (digit-reversed positions come from the host through
+//      rvs_ccf_fft_pos), interpolated (scipy interp1d formula) and accumulated:
+//      out = beta*out + value, so arms add up without atomics.
+#include "common.h"
+
+#define XC_NT 512
+#define XC_PAD(i) ((i) + ((i) >> 3))
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) {
+  return make_double2(a.x + b.x, a.y + b.y);
+}
+__device__ __forceinline__ double2 csub(double2 a, double2 b) {
+  return make_double2(a.x - b.x, a.y - b.y);
+}
+// multiply by +i (SIGN>0) or -i (SIGN<0)
+template <int SIGN>
+__device__ __forceinline__ double2 cmuli(double2 a) {
+  return (SIGN > 0) ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+
+// radix plan of an n2 = 2^log2n point transform: 8,8,...,(4|2)
+__host__ __device__ inline int xc_plan(int log2n, int *rad) {
+  int n = 0, l = log2n;
+  while (l >= 3) {
+    rad[n++] = 8;
+    l -= 3;
+  }
+  if (l == 2) rad[n++] = 4;
+  if (l == 1) rad[n++] = 2;
+  return n;
+}
+
+// position (un-padded) of output frequency f after the in-place DIF passes
+extern "C" int rvs_ccf_fft_pos(int nfft, int f) {
+  int log2n = 0;
+  while ((2 << log2n) < nfft) log2n++;
+  int rad[8];
+  const int np = xc_plan(log2n, rad);
+  int n2 = nfft >> 1, pos = 0, m = n2;
+  for (int p = 0; p < np; p++) {
+    const int q = f % rad[p];
+    f /= rad[p];
+    m /= rad[p];
+    pos += q * m;
+  }
+  return pos;
+}
+
+// y_q = sum_j a_j e^{SIGN 2 pi i j q / R}, natural order in and out
+template <int SIGN>
+__device__ __forceinline__ void dft4(double2 &a0, double2 &a1, double2 &a2,
+                                     double2 &a3) {
+  const double2 t0 = cadd(a0, a2), t1 = csub(a0, a2);
+  const double2 t2 = cadd(a1, a3), t3 = cmuli<SIGN>(csub(a1, a3));
+  a0 = cadd(t0, t2);
+  a2 = csub(t0, t2);
+  a1 = cadd(t1, t3);
+  a3 = csub(t1, t3);
+}
+
+template <int SIGN>
+__device__ __forceinline__ void dft8(double2 *a) {
+  // even / odd split, then twiddles W8^k = e^{SIGN i pi k/4}
+  double2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+  double2 o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
+  dft4<SIGN>(e0, e1, e2, e3);
+  dft4<SIGN>(o0, o1, o2, o3);
+  const double h = 0.70710678118654752440;
+  // W8^1 = (1 + SIGN i) h ; W8^2 = SIGN i ; W8^3 = (-1 + SIGN i) h
+  const double2 w1o = (SIGN > 0) ? make_double2(h * (o1.x - o1.y), h * (o1.x + o1.y))
+                                 : make_double2(h * (o1.x + o1.y), h * (o1.y - o1.x));
+  const double2 w2o = cmuli<SIGN>(o2);
+  const double2 w3o = (SIGN > 0) ? make_double2(-h * (o3.x + o3.y), h * (o3.x - o3.y))
+                                 : make_double2(h * (o3.y - o3.x), -h * (o3.x + o3.y));
+  a[0] = cadd(e0, o0);
+  a[4] = csub(e0, o0);
+  a[1] = cadd(e1, w1o);
+  a[5] = csub(e1, w1o);
+  a[2] = cadd(e2, w2o);
+  a[6] = csub(e2, w2o);
+  a[3] = cadd(e3, w3o);
+  a[7] = csub(e3, w3o);
+}
+
+// tw[j] = exp(+2 pi i j/nfft), j < nfft/2; returns exp(SIGN 2 pi i e / nfft)
+template <int SIGN>
+__device__ __forceinline__ double2 twid(const double2 *__restrict__ tw, int e,
+                                        int nfft) {
+  const int half = nfft >> 1;
+  double2 w = (e < half) ? tw[e] : tw[e - half];
+  if (e >= half) {
+    w.x = -w.x;
+    w.y = -w.y;
+  }
+  if (SIGN < 0) w.y = -w.y;
+  return w;
+}
+
+// in-place DIF transform of the padded LDS image a[] (n2 points)
+template <int SIGN, int NT>
+__device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw) {
+  const int n2 = 1 << log2n, nfft = n2 << 1;
+  int rad[8];
+  const int np = xc_plan(log2n, rad);
+  int M = n2;
+  for (int p = 0; p < np; p++) {
+    const int R = rad[p], Mp = M / R;
+    __syncthreads();
+    for (int u = threadIdx.x; u < n2 / R; u += NT) {
+      const int blk = u / Mp, r = u - blk * Mp;
+      const int base = blk * M + r;
+      if (R == 8) {
+        double2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = a[XC_PAD(base + Mp * j)];
+        dft8<SIGN>(v);
+        if (Mp > 1) {
+          // powers of w1 generated and consumed one at a time (short live
+          // ranges: 3 complex instead of 7); every power is a product of at most
+          // two squarings/multiplications of table values
+          const double2 w1 = twid<SIGN>(tw, r * (nfft / M), nfft);
+          v[1] = cmul(v[1], w1);
+          const double2 w2 = cmul(w1, w1);
+          v[2] = cmul(v[2], w2);
+          double2 wc = cmul(w2, w1);  // w3
+          v[3] = cmul(v[3], wc);
+          const double2 w4 = cmul(w2, w2);
+          v[4] = cmul(v[4], w4);
+          v[7] = cmul(v[7], cmul(w4, wc));  // w7 = w4 w3
+          wc = cmul(w4, w1);                // w5
+          v[5] = cmul(v[5], wc);
+          v[6] = cmul(v[6], cmul(w4, w2));  // w6
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[XC_PAD(base + Mp * q)] = v[q];
+      } else if (R == 4) {
+        double2 v0 = a[XC_PAD(base)], v1 = a[XC_PAD(base + Mp)],
+                v2 = a[XC_PAD(base + 2 * Mp)], v3 = a[XC_PAD(base + 3 * Mp)];
+        dft4<SIGN>(v0, v1, v2, v3);
+        if (Mp > 1) {
+          const double2 w1 = twid<SIGN>(tw, r * (nfft / M), nfft);
+          const double2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+          v1 = cmul(v1, w1);
+          v2 = cmul(v2, w2);
+          v3 = cmul(v3, w3);
+        }
+        a[XC_PAD(base)] = v0;
+        a[XC_PAD(base + Mp)] = v1;
+        a[XC_PAD(base + 2 * Mp)] = v2;
+        a[XC_PAD(base + 3 * Mp)] = v3;
+      } else {
+        const double2 v0 = a[XC_PAD(base)], v1 = a[XC_PAD(base + Mp)];
+        double2 d = csub(v0, v1);
+        if (Mp > 1) d = cmul(d, twid<SIGN>(tw, r * (nfft / M), nfft));
+        a[XC_PAD(base)] = cadd(v0, v1);
+        a[XC_PAD(base + Mp)] = d;
+      }
+    }
+    M = Mp;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int fft_pos(int f, int log2n) {
+  int rad[8];
+  const int np = xc_plan(log2n, rad);
+  int pos = 0, m = 1 << log2n;
+  for (int p = 0; p < np; p++) {
+    const int q = f % rad[p];
+    f /= rad[p];
+    m /= rad[p];
+    pos += q * m;
+  }
+  return pos;
+}
+
+// conj(rfft(x)) for x = proc_spec*proc_ivar (which 0) and proc_ivar (which 1)
+__global__ void __launch_bounds__(XC_NT)
+    ccf_rfft_kernel(const double *__restrict__ proc_spec,
+                    const double *__restrict__ proc_ivar, int nfft, int log2n,
+                    const double2 *__restrict__ tw, double2 *__restrict__ work) {
+  extern __shared__ double2 fa[];
+  const int b = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
+  const int n2 = nfft >> 1;
+  const double *ps = proc_spec + (int64_t)b * nfft;
+  const double *pi = proc_ivar + (int64_t)b * nfft;
+  for (int n = tid; n < n2; n += XC_NT) {
+    double x0, x1;
+    if (which == 0) {
+      x0 = ps[2 * n] * pi[2 * n];
+      x1 = ps[2 * n + 1] * pi[2 * n + 1];
+    } else {
+      x0 = pi[2 * n];
+      x1 = pi[2 * n + 1];
+    }
+    fa[XC_PAD(n)] = make_double2(x0, x1);
+  }
+  fft_lds<-1, XC_NT>(fa, log2n, tw);
+  double2 *out = work + ((int64_t)b * 2 + which) * (n2 + 1);
+  for (int k = tid; k <= n2; k += XC_NT) {
+    double2 X;
+    if (k == 0 || k == n2) {
+      const double2 z0 = fa[0];
+      X = make_double2(k == 0 ? z0.x + z0.y : z0.x - z0.y, 0.0);
+    } else {
+      const double2 zk = fa[XC_PAD(fft_pos(k, log2n))];
+      const double2 zm = fa[XC_PAD(fft_pos(n2 - k, log2n))];
+      const double2 e = make_double2(zk.x + zm.x, zk.y - zm.y);   // zk + conj(zm)
+      const double2 d = make_double2(zk.x - zm.x, zk.y + zm.y);   // zk - conj(zm)
+      const double2 q = cmul(twid<-1>(tw, k, nfft), d);
+      X = make_double2(0.5 * (e.x + q.y), 0.5 * (e.y - q.x));     // e/2 - (i/2) q
+    }
+    out[k] = make_double2(X.x, -X.y);  // conjugate
+  }
+}
+
+#define XB_NT 512  // threads per block
+
+// One block per (spectrum b, template t); two blocks are resident per CU (LDS
+// 74 kB each, < 128 VGPRs) so that the load phase of one overlaps the LDS / FFT
+// phase of the other.  Measured alternatives: 256-thread
+// blocks 17.8 ms, 512-thread blocks 14.4 ms per 2000 DESI spectra; keeping the
+// spectrum's S*, V* in registers across a chunk of templates halves the L2->CU
+// traffic but needs > 180 VGPRs (one block per CU or spills): 25-38 ms.
+__global__ void __launch_bounds__(XB_NT)
+    ccf_xcorr_kernel(const double2 *__restrict__ work, int nfft, int log2n,
+                     const double2 *__restrict__ tfft,
+                     const double2 *__restrict__ tfft2, int T,
+                     const double2 *__restrict__ tw, int continuum,
+                     const int32_t *__restrict__ lag_pos,
+                     const double *__restrict__ lag_vel, int nlag,
+                     const int32_t *__restrict__ ilo,
+                     const double *__restrict__ vgrid, int nvel, double beta,
+                     double *__restrict__ chisq) {
+  extern __shared__ double2 fa[];
+  const int n2 = nfft >> 1, npair = n2 >> 1;
+  double *c0 = reinterpret_cast<double *>(fa + XC_PAD(n2) + 1);  // [nlag]
+  double *c1 = c0 + nlag;                                        // [nlag]
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const double2 *Sc = work + ((int64_t)b * 2) * (n2 + 1);
+  const double2 *Vc = Sc + (n2 + 1);
+  const double2 *F = tfft + (int64_t)t * (n2 + 1);
+  const double2 *F2 = tfft2 + (int64_t)t * (n2 + 1);
+  const double inv_n = 1.0 / nfft;
+  const int npass = continuum ? 1 : 2;
+  for (int pass = 0; pass < npass; pass++) {
+    for (int k = tid; k <= npair; k += XB_NT) {
+      const int m = n2 - k;
+      double2 Xk, Xm;
+      if (continuum) {
+        const double2 p1 = cmul(F[k], Sc[k]), p2 = cmul(F2[k], Vc[k]);
+        Xk = make_double2(p2.x - 2 * p1.x, p2.y - 2 * p1.y);
+        const double2 q1 = cmul(F[m], Sc[m]), q2 = cmul(F2[m], Vc[m]);
+        Xm = make_double2(q2.x - 2 * q1.x, q2.y - 2 * q1.y);
+      } else if (pass == 0) {
+        Xk = cmul(F[k], Sc[k]);
+        Xm = cmul(F[m], Sc[m]);
+      } else {
+        Xk = cmul(F2[k], Vc[k]);
+        Xm = cmul(F2[m], Vc[m]);
+      }
+      if (k == 0) {
+        // numpy irfft ignores the imaginary parts of the DC and Nyquist bins
+        fa[0] = make_double2(Xk.x + Xm.x, Xk.x - Xm.x);
+      } else {
+        const double2 e = make_double2(Xk.x + Xm.x, Xk.y - Xm.y);  // Xk + conj Xm
+        const double2 d = make_double2(Xk.x - Xm.x, Xk.y + Xm.y);  // Xk - conj Xm
+        const double2 q = cmul(tw[k], d);
+        // Z[k] = e + i q ; Z[m] = conj(e) + i conj(q)  (m == k: both the same)
+        fa[XC_PAD(k)] = make_double2(e.x - q.y, e.y + q.x);
+        if (m != k) fa[XC_PAD(m)] = make_double2(e.x + q.y, -e.y + q.x);
+      }
+    }
+    fft_lds<1, XB_NT>(fa, log2n, tw);
+    const double *fr = reinterpret_cast<const double *>(fa);
+    double *dst = (pass == 0) ? c0 : c1;
+    for (int l = tid; l < nlag; l += XB_NT) dst[l] = fr[lag_pos[l]] * inv_n;
+    __syncthreads();
+  }
+  if (!continuum) {
+    for (int l = tid; l < nlag; l += XB_NT) c0[l] = -c0[l] * c0[l] / c1[l];
+    __syncthreads();
+  }
+  double *out = chisq + ((int64_t)b * T + t) * nvel;
+  for (int v = tid; v < nvel; v += XB_NT) {
+    const int lo = ilo[v];
+    const double x0 = lag_vel[lo], x1 = lag_vel[lo + 1];
+    const double sl = (c0[lo + 1] - c0[lo]) / (x1 - x0);
+    const double val = sl * (vgrid[v] - x0) + c0[lo];
+    out[v] = (beta != 0.0) ? beta * out[v] + val : val;
+  }
+}
+
+extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
+                             int nfft, int B, const double *tfft,
+                             const double *tfft2, int T, const double *twid_,
+                             int continuum, const int32_t *lag_pos,
+                             const double *lag_vel, int nlag, const int32_t *ilo,
+                             const double *vgrid, int nvel, double beta,
+                             double *chisq, double *work, void *stream) {
+  int log2n = 0;
+  while ((2 << log2n) < nfft) log2n++;
+  if ((2 << log2n) != nfft || nfft < 64 || nfft > 16384) return RVS_E_ARG;
+  if (B < 1 || T < 1 || T > 65535 || nlag < 2 || nvel < 1) return RVS_E_ARG;
+  const int n2 = nfft >> 1;
+  const size_t shm1 = sizeof(double2) * (size_t)(XC_PAD(n2) + 1);
+  const size_t shm2 = shm1 + sizeof(double) * 2 * (size_t)nlag;
+  if (shm2 > 159 * 1024) return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  const double2 *tw = reinterpret_cast<const double2 *>(twid_);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)ccf_rfft_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              159 * 1024);
+    (void)hipFuncSetAttribute((const void *)ccf_xcorr_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              159 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ccf_rfft_kernel, dim3(B, 2), dim3(XC_NT), shm1, st,
+                     proc_spec, proc_ivar, nfft, log2n, tw,
+                     reinterpret_cast<double2 *>(work));
+  RVS_LAUNCH_CHECK();
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
+    hipLaunchKernelGGL(
+        ccf_xcorr_kernel, dim3(T, nb), dim3(XB_NT), shm2, st,
+        reinterpret_cast<const double2 *>(work) + (int64_t)b0 * 2 * (n2 + 1),
+        nfft, log2n, reinterpret_cast<const double2 *>(tfft),
+        reinterpret_cast<const double2 *>(tfft2), T, tw, continuum, lag_pos,
+        lag_vel, nlag, ilo, vgrid, nvel, beta, chisq + (int64_t)b0 * T * nvel);
+    RVS_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -151,13 +151,11 @@ class ArmData:
         step, ind, sub = ccf_tables.lag_tables(cc['logl0'], cc['logl1'], nfft,
                                                maxvel)
         T['step'] = step
-        log2n = int(np.log2(nfft)) - 1
-        m = ind.astype(np.int64) >> 1
-        rev = np.zeros_like(m)
-        for bit in range(log2n):
-            rev |= ((m >> bit) & 1) << (log2n - 1 - bit)
+        L = _lib.lib()
+        pos = np.array([L.rvs_ccf_fft_pos(nfft, int(n) >> 1) for n in ind],
+                       dtype=np.int64)
         T['lag_pos'] = torch.as_tensor(
-            (2 * rev + (ind & 1)).astype(np.int32)).to(dev)
+            (2 * (pos + (pos >> 3)) + (ind & 1)).astype(np.int32)).to(dev)
         T['lag_vel'] = torch.as_tensor(sub).to(dev)
         T['nlag'] = len(ind)
         T['ilo'] = torch.as_tensor(ccf_tables.interp_tables(sub, vgrid)).to(dev)

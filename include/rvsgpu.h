@@ -89,11 +89,14 @@ int rvs_vsini_convolve(const double *templ, const double *vsini,
 
 /* ------------------------------------------------------------------------
  * A7  natural cubic spline through (knots, ys[b]); replaces `construct`
- *     (src/spliner.c:7-60).  coef[b, i, 0..3] = A,B,C,D of interval i
- *     (i < ntp-1; row ntp-1 is zero padding), h is implied by knots.
+ *     (src/spliner.c:7-60).  form 0: coef[b, i, 0..3] = A,B,C,D of interval i
+ *     exactly as the reference (i < ntp-1; row ntp-1 is zero padding; h is
+ *     implied by knots).  form 1: the SAME cubic in powers of dl = x - x_i,
+ *     {y_i, b, c, d} with S = y + dl (b + dl (c + dl d)) -- 3 fma per evaluation,
+ *     the form the fused chi^2 kernels consume.
  * ---------------------------------------------------------------------- */
 int rvs_spline_construct(const double *knots, const double *ys, int ntp, int B,
-                         double *coef, void *stream);
+                         int form, double *coef, void *stream);
 
 /* A7  replaces `evaler` (src/spliner.c:71-108) for B splines sharing the
  * knots: ret[b, i] = S_b(evalx[b, i]); pos (nullable) receives the integer
@@ -117,7 +120,7 @@ int rvs_spline_eval(const double *knots, const double *coef, int ntp,
  * lam     [npix]        observed wavelengths of the arm (shared by the batch)
  * polysT  [npix, npoly] continuum basis, pixel-major (get_poly_basis^T)
  * spec, espec [S, npix]
- * knots   [ntp], coef [Tn, ntp, 4]   from rvs_spline_construct
+ * knots   [ntp], coef [Tn, ntp, 4]   from rvs_spline_construct(form = 1)
  * knots_host3  HOST pointer to the first three knots: the uniformity test of
  *          spliner.c:84-96 is done on the host; returns -3 where evaler
  *          returns -2
@@ -152,14 +155,15 @@ int rvs_chisq_grid(const double *lam, const double *polysT, const double *work,
 /* ------------------------------------------------------------------------
  * get_chisq(full_output=True) for one velocity per job and one arm
  * (spec_fit.py:941-961), and get_chisq_continuum (spec_fit.py:739-783) when
- * unit_template != 0 (template == 1, knots/coef ignored).
+ * unit_template != 0 (template == 1, knots/coef ignored).  cform = the form of
+ * the spline records (see rvs_spline_construct).
  * coeffs [J, npoly], model/raw_model [J, npix] (nullable), chisq [J] (-2logL
  * of the arm), true_chisq [J] over pixels with badmask==0, ngood int32 [J].
  * ---------------------------------------------------------------------- */
 int rvs_chisq_full(const double *lam, const double *polysT, const double *spec,
                    const double *espec, const uint8_t *badmask, int npix,
                    int npoly, int S, const double *knots, const double *coef,
-                   int ntp, int Tn, int log_step, int unit_template,
+                   int ntp, int Tn, int log_step, int cform, int unit_template,
                    const int32_t *job_spec, const int32_t *job_templ, int J,
                    const double *vel, double espec_sys, double *chisq,
                    double *coeffs, double *model, double *raw_model,

@@ -24,14 +24,14 @@ SIGNATURES = {
     'rvs_template_polylinear': (I, [P, L, I, P, P, P, I, P, P, U, I, P, I, P, P,
                                     P, P, P]),
     'rvs_vsini_convolve': (I, [P, P, P, D, D, I, I, P, P]),
-    'rvs_spline_construct': (I, [P, P, I, I, P, P]),
+    'rvs_spline_construct': (I, [P, P, I, I, I, P, P]),
     'rvs_spline_eval': (I, [P, P, I, I, P, I, I, P, P, P, P]),
     'rvs_chisq_work_size': (L, [I, I]),
     'rvs_chisq_prepare': (I, [P, P, P, I, I, P, I, D, P, P]),
     'rvs_chisq_grid': (I, [P, P, P, I, I, I, P, P, I, I, I, P, P, I, P, L, I, P,
                            D, D, I, P, P, P]),
-    'rvs_chisq_full': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, P, P, I, P,
-                           D, P, P, P, P, P, P, P, P]),
+    'rvs_chisq_full': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, P, P, I,
+                           P, D, P, P, P, P, P, P, P, P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),

@@ -140,51 +140,27 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   // pixel k+1 are requested -- at the ESTIMATED knot index -- and the scalar
   // loads of its basis row / weights are issued before the ~75 fp64 operations
   // of pixel k, so their latency hides behind arithmetic instead of s_waitcnt.
-  auto fetch = [&](int k, double &x, int &pos, double &xl, double &xr,
-                   double4 &c) {
-    x = lam[k] * f;
+  // pos = (int)((log x - log x0)/step) evaluated as pixel coordinate + velocity
+  // shift; it can differ from the reference's value only when x is within
+  // rounding (~1e-11 knot spacings) of a knot, where the two adjacent cubics agree
+  // to O(dx^3) ~ 1e-33 -- exactly the ambiguity the reference's own libm log
+  // has (rvs_spline_eval keeps the reference formula verbatim).  The cubic is
+  // evaluated in powers of dl = x - x_i (records built with form 1): 3 fma.
+  for (int k = 0; k < npix; k++) {
+    const double x = lam[k] * f;
+    int pos;
     if (log_step)
       pos = (int)(pixa[k] + shift);
     else
       pos = (int)((x - x0) * lin_inv_step);
     pos = min(max(pos, 0), ntp - 2);
-    xl = knots[pos];
-    xr = knots[pos + 1];
-    c = cf[pos];
-  };
-  double xn, xln, xrn;
-  double4 cn;
-  int posn;
-  fetch(0, xn, posn, xln, xrn, cn);
-  double prn[P];
-#pragma unroll
-  for (int i = 0; i < P; i++) prn[i] = polysT[i];
-  double2 wn = W[0];
-  for (int k = 0; k < npix; k++) {
-    const double x = xn;
-    const double xl = xln, xr = xrn;
-    const double4 c = cn;
-    double pr[P];
-#pragma unroll
-    for (int i = 0; i < P; i++) pr[i] = prn[i];
-    const double2 wk = wn;
-    {
-      const int kn = min(k + 1, npix - 1);
-      fetch(kn, xn, posn, xln, xrn, cn);
-      const double *pp = polysT + (int64_t)kn * P;
-#pragma unroll
-      for (int i = 0; i < P; i++) prn[i] = pp[i];
-      wn = W[kn];
-    }
-    // pos is (int)((log x - log x0)/step) evaluated as pixel coordinate +
-    // velocity shift; it can differ from the reference's value only when x is
-    // within rounding (~1e-11 knot spacings) of a knot, where the two adjacent
-    // cubics agree to O(dx^3) ~ 1e-33 -- exactly the ambiguity the reference's
-    // own libm log has.  (rvs_spline_eval keeps the reference formula verbatim.)
-    const double dl = x - xl, dr = xr - x;
-    const double tv = c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
+    const double dl = x - knots[pos];
+    const double4 c = cf[pos];
+    const double2 wk = W[k];
+    const double tv = fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
     const double w = tv * tv * wk.x;   // (t/e)^2
     const double u = tv * wk.y;        // t s / e^2
+    const double *pr = polysT + (int64_t)k * P;
     double pw[P];
 #pragma unroll
     for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
@@ -406,10 +382,9 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
         pos = (int)((x - x0) * inv_step);
       pos = min(max(pos, 0), ntp - 2);
       const int pl = min(max(pos - plo, 0), CG_WMAX - 1);
-      const double xl = kw[pl], xr = kw[pl + 1];
+      const double dl = x - kw[pl];
       const double4 cc = cw[pl];
-      const double dl = x - xl, dr = xr - x;
-      const double tv = cc.x * dl * dl * dl + cc.y * dr * dr * dr + cc.z * dl + cc.w * dr;
+      const double tv = fma(fma(fma(cc.w, dl, cc.z), dl, cc.y), dl, cc.x);
       const double w = tv * tv * wk.x;
       const double u = tv * wk.y;
       const double *pr = polysT + (int64_t)k * P;
@@ -604,7 +579,8 @@ __global__ void __launch_bounds__(256)
                       const uint8_t *__restrict__ badmask, int npix, int P,
                       const double *__restrict__ knots,
                       const double4 *__restrict__ coef, int ntp, int log_step,
-                      int unit_template, const int32_t *__restrict__ job_spec,
+                      int cform, int unit_template,
+                      const int32_t *__restrict__ job_spec,
                       const int32_t *__restrict__ job_templ,
                       const double *__restrict__ vel, double espec_sys,
                       double *__restrict__ chisq, double *__restrict__ coeffs,
@@ -652,7 +628,8 @@ __global__ void __launch_bounds__(256)
       pos = min(max(pos, 0), ntp - 2);
       const double4 c = cf[pos];
       const double dl = x - knots[pos], dr = knots[pos + 1] - x;
-      tv = c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
+      tv = cform ? fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x)
+                 : c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
     }
     if (raw_model) raw_model[(int64_t)j * npix + k] = tv;
     double e = es[k];
@@ -788,9 +765,10 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
                               const double *spec, const double *espec,
                               const uint8_t *badmask, int npix, int npoly,
                               int S, const double *knots, const double *coef,
-                              int ntp, int Tn, int log_step, int unit_template,
-                              const int32_t *job_spec, const int32_t *job_templ,
-                              int J, const double *vel, double espec_sys,
+                              int ntp, int Tn, int log_step, int cform,
+                              int unit_template, const int32_t *job_spec,
+                              const int32_t *job_templ, int J, const double *vel,
+                              double espec_sys,
                               double *chisq, double *coeffs, double *model,
                               double *raw_model, double *true_chisq,
                               int32_t *ngood, int32_t *status, void *stream) {
@@ -811,8 +789,8 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
   hipLaunchKernelGGL(chisq_full_kernel, dim3(J), dim3(256), shm,
                      rvs_stream(stream), lam, polysT, spec, espec, badmask,
                      npix, npoly, knots, reinterpret_cast<const double4 *>(coef),
-                     ntp, log_step, unit_template, job_spec, job_templ, vel,
-                     espec_sys, chisq, coeffs, model, raw_model, true_chisq,
+                     ntp, log_step, cform, unit_template, job_spec, job_templ,
+                     vel, espec_sys, chisq, coeffs, model, raw_model, true_chisq,
                      ngood, status);
   RVS_LAUNCH_CHECK();
   return 0;

@@ -332,7 +332,7 @@ extern "C" int rvs_vsini_convolve(const double *templ, const double *vsini,
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
     spline_construct_kernel(const double *__restrict__ knots,
-                            const double *__restrict__ ys, int ntp,
+                            const double *__restrict__ ys, int ntp, int form,
                             double4 *__restrict__ coef) {
   extern __shared__ double sm[];
   const int N = ntp, m = N - 2;  // unknowns z[1..N-2] -> index 0..m-1
@@ -438,14 +438,19 @@ __global__ void __launch_bounds__(256)
     const double zi = (i == 0) ? 0.0 : dp[i - 1];
     const double zi1 = (i + 1 == N - 1) ? 0.0 : dp[i];
     const double t1 = hinv * (1.0 / 6), t2 = h * (1.0 / 6);
-    cf[i] = make_double4(zi1 * t1, zi * t1, y[i + 1] * hinv - zi1 * t2,
-                         y[i] * hinv - zi * t2);
+    if (form == 0)  // A, B, C, D of spliner.c:52-59
+      cf[i] = make_double4(zi1 * t1, zi * t1, y[i + 1] * hinv - zi1 * t2,
+                           y[i] * hinv - zi * t2);
+    else  // the same cubic in powers of dl = x - x_i: y + dl (b + dl (c + dl d))
+      cf[i] = make_double4(y[i], (y[i + 1] - y[i]) * hinv - t2 * (2 * zi + zi1),
+                           0.5 * zi, (zi1 - zi) * t1);
   }
 }
 
 extern "C" int rvs_spline_construct(const double *knots, const double *ys,
-                                    int ntp, int B, double *coef, void *stream) {
-  if (ntp < 4 || B < 1) return RVS_E_ARG;
+                                    int ntp, int B, int form, double *coef,
+                                    void *stream) {
+  if (ntp < 4 || B < 1 || form < 0 || form > 1) return RVS_E_ARG;
   const size_t shm = sizeof(double) * (2 * (size_t)(ntp - 2) + 2 * 257);
   if (shm > 159 * 1024) return RVS_E_ARG;
   static bool attr_set = false;
@@ -457,7 +462,7 @@ extern "C" int rvs_spline_construct(const double *knots, const double *ys,
     attr_set = true;
   }
   hipLaunchKernelGGL(spline_construct_kernel, dim3(B), dim3(256), shm,
-                     rvs_stream(stream), knots, ys, ntp,
+                     rvs_stream(stream), knots, ys, ntp, form,
                      reinterpret_cast<double4 *>(coef));
   RVS_LAUNCH_CHECK();
   return 0;

@@ -238,8 +238,9 @@ def build_templates(lib, params, vsini=None, return_templ=False):
         _lib.check(rc, 'rvs_vsini_convolve')
         templ = out
     coef = torch.empty((J, lib.ntp, 4), dtype=torch.float64, device=lib.device)
+    # form 1: power-form records {y, b, c, d} consumed by the chi^2 kernels
     rc = L.rvs_spline_construct(_lib.ptr(lib.knots), _lib.ptr(templ), lib.ntp, J,
-                                _lib.ptr(coef), _lib.stream())
+                                1, _lib.ptr(coef), _lib.stream())
     _lib.check(rc, 'rvs_spline_construct')
     if return_templ:
         return coef, outside, templ
@@ -414,7 +415,7 @@ def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
             _lib.ptr(arm.espec), _lib.ptr(arm.badmask), arm.npix, npoly, arm.S,
             _lib.ptr(lib.knots) if lib else None, _lib.ptr(coef),
             lib.ntp if lib else 0, coef.shape[0] if coef is not None else 0,
-            int(lib.log_step) if lib else 1, int(unit_template),
+            int(lib.log_step) if lib else 1, 1, int(unit_template),
             _lib.ptr(job_spec), _lib.ptr(job_templ), J,
             _lib.ptr(vel.contiguous()) if vel is not None else None,
             float(espec_sys), _lib.ptr(chisq), _lib.ptr(coeffs),

@@ -165,8 +165,9 @@ class _DeviceSpline:
         y = torch.as_tensor(np.ascontiguousarray(ys)[None, :]).to('cuda')
         self.coef = torch.empty((1, self.N, 4), dtype=torch.float64,
                                 device='cuda')
+        # form 0: the reference's A, B, C, D (spliner.c:52-59)
         rc = _lib.lib().rvs_spline_construct(_lib.ptr(self.knots), _lib.ptr(y),
-                                             self.N, 1, _lib.ptr(self.coef),
+                                             self.N, 1, 0, _lib.ptr(self.coef),
                                              _lib.stream())
         _lib.check(rc, 'rvs_spline_construct')
 

@@ -35,18 +35,44 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 GRID_KW = dict(nteff=7, nlogg=7, nfeh=7, nalpha=7)
 RESOL = 3000.
 ARMS = ('b', 'r', 'z')
+# BASELINE configs[1] ("Cfg2"): 1 arm 4000-5000 A, 2001 px, template 3950-5050 A
+# step 0.5 (2272 px), N_fft 4096
+CFG2_ARM = dict(obs=(4000., 5000.01, 0.5), templ=(3950., 5050., 0.5))
 CONFIG = dict(min_vel=-1000, max_vel=1000, vel_step0=5, min_vel_step=0.2,
               min_vsini=0.1, max_vsini=500, template_lib='synthetic://desi')
 OPTIONS = dict(npoly=10)
+EVALUATOR = 'polylinear'
 
 
 def arm_name(a):
     return 'desi_' + a
 
 
+def arm_def(a):
+    return CFG2_ARM if a == 'c' else synth.DESI_ARMS[a]
+
+
 def obs_lam(a):
-    lo, hi, st = synth.DESI_ARMS[a]['obs']
+    lo, hi, st = arm_def(a)['obs']
     return np.arange(lo, hi, st)
+
+
+def nn_weights(ntp, seed):
+    """Seeded float32 MLP 4 -> 256 -> 256 -> 256 -> 200 -> ntp (the reference's
+    default architecture, nn/train_interpolator.py:105-114).  There is no network
+    to fetch trained checkpoints and training is out of scope, so the weights
+    are random: the workload shape (GEMM sizes, bytes) is exact, the templates
+    are not physical."""
+    rng = np.random.RandomState(seed)
+    dims = np.array([4, 256, 256, 256, 200, ntp], dtype=np.int32)
+    d = dict(nn_dims=dims, nn_M=np.array([3.8, 2.5, -1., 0.5]),
+             nn_S=np.array([0.17, 1.4, 0.6, 0.3]))
+    for i in range(5):
+        k, n = dims[i], dims[i + 1]
+        d['nn_W%d' % i] = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+        d['nn_b%d' % i] = (0.05 * rng.standard_normal(n)).astype(np.float32)
+    d['nn_W4'] *= 0.1  # keep exp(output) of order one
+    return d
 
 
 def build_library_dicts(ccf_every, convolve):
@@ -54,12 +80,18 @@ def build_library_dicts(ccf_every, convolve):
     N_fft 8192) in the converted-artefact dict layout."""
     out = {}
     for a in ARMS:
-        l0, l1, st = synth.DESI_ARMS[a]['templ']
+        l0, l1, st = arm_def(a)['templ']
         lib = synth.make_interp_library_fast(arm_name(a), l0, l1, st,
                                              grid_kw=GRID_KW, resol=RESOL)
         ccf = synth.make_ccf_templates(lib, l0, l1, st, every=ccf_every,
                                        vsinis=(0., 300.), convolve=convolve)
         out[arm_name(a)] = synth.library_as_npz_dict(lib, ccf)
+        if EVALUATOR == 'nn':
+            # the NN replaces the polylinear evaluator of the template build
+            d = out[arm_name(a)]
+            for k in ('dats', 'idgrid', 'vec', 'uvec0', 'uvec1', 'uvec2', 'uvec3'):
+                d.pop(k)
+            d.update(nn_weights(len(lib['lam']), seed=11 + ord(a)))
     return out
 
 
@@ -81,7 +113,7 @@ def make_spectra_device(tp, device):
     arms = []
     for a in ARMS:
         lam = obs_lam(a)
-        wres = 0.5 * sum(synth.DESI_ARMS[a]['templ'][:2]) / RESOL / 2.35
+        wres = 0.5 * sum(arm_def(a)['templ'][:2]) / RESOL / 2.35
         sp0 = synth.spectra_batch(lam, t['teff'], t['logg'], t['feh'],
                                   t['alpha'], vel=t['vel'], wresol=wres,
                                   xp=torch)
@@ -152,7 +184,7 @@ def run_cpu_baseline(arms, n, args):
     np.savez(path, **sample)
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', path,
            '--ccf-every', str(args.ccf_every), '--cpu-cores',
-           str(args.cpu_cores)]
+           str(args.cpu_cores), '--workload', args.workload]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=1500)
     os.unlink(path)
@@ -177,7 +209,17 @@ def main():
     ap.add_argument('--refine', action='store_true',
                     help='also run the _minimum_sampler refinement (add-on)')
     ap.add_argument('--cpu-worker', type=str, default=None)
+    ap.add_argument('--workload', choices=['desi', 'cfg2'], default='desi',
+                    help='desi: BASELINE configs[2] (3 arms); cfg2: configs[1] '
+                         '(1 arm, 2001 px, N_fft 4096)')
+    ap.add_argument('--evaluator', choices=['polylinear', 'nn'],
+                    default='polylinear',
+                    help='nn: BASELINE configs[3], MLP template evaluator on MFMA')
     args = ap.parse_args()
+    global ARMS, EVALUATOR
+    if args.workload == 'cfg2':
+        ARMS = ('c', )
+    EVALUATOR = args.evaluator
     if args.cpu_worker:
         return cpu_worker(args)
 
@@ -207,8 +249,8 @@ def main():
     for name, d in dicts.items():
         spec_inter.register_library(TemplateLibrary(name, d, device=dev),
                                     CONFIG['template_lib'])
-    Tccf = dicts[arm_name('b')]['ccf_fft'].shape[0]
-    nfft = int(dicts[arm_name('b')]['ccf_npoints'])
+    Tccf = dicts[arm_name(ARMS[0])]['ccf_fft'].shape[0]
+    nfft = int(dicts[arm_name(ARMS[0])]['ccf_npoints'])
     tp = truth_params(S, seed=3 + 1000 * rank)
     arms = make_spectra_device(tp, dev)
     batch = engine.SpecBatch([engine.ArmData(n, lam, sp, es, bad, device=dev)
@@ -305,11 +347,22 @@ def main():
     if 'ccf_preprocess' in kt:
         kernels['ccf_preprocess'] = dict(
             ms_per_step=round(kt['ccf_preprocess'][1] / args.steps, 2))
+    if 'template_nn' in kt:
+        # f32 MLP on v_mfma_f32_32x32x2_f32: 2*sum(K*N) flop per spectrum-arm
+        nl3, ms3, units3 = kt['template_nn']
+        fl = 0.0
+        for a in ARMS:
+            dims = dicts[arm_name(a)]['nn_dims']
+            fl += 2.0 * sum(int(dims[i]) * int(dims[i + 1]) for i in range(5))
+        tf = (units3 / len(ARMS)) * fl / (ms3 * 1e-3) / 1e12 if ms3 else 0
+        kernels['template_nn'] = dict(
+            ms_per_step=round(ms3 / args.steps, 2), f32_mfma_TFLOPs=round(tf, 2),
+            mfma_peak_TFLOPs=157.3, mfma_frac=round(tf / 157.3, 4))
 
     # ---- CPU baseline + parity on the sample ---------------------------
     cpu = None
     parity = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and EVALUATOR == 'polylinear':
         n = min(args.cpu_sample, S)
         cb = run_cpu_baseline(arms, n, args)
         cpu = dict(value=round(cb['n'] / cb['wall'], 3), unit='spectra/s',
@@ -327,9 +380,17 @@ def main():
                       max_abs_dvrad_ccf=float(np.abs(g[:, 1] - o[:, 1]).max()),
                       max_abs_drv_same_template=float(
                           np.abs(g[same, 7] - o[same, 2]).max()) if same.any() else None,
+                      # -2 log L = log det + 2 sum log e + residual can pass
+                      # through zero, so the difference is scaled by
+                      # max(|chi|, total number of pixels) (the residual term is
+                      # of the order of the pixel count)
                       max_rel_dchi_same_template=float(
                           (np.abs(g[same, 11] - o[same, 4]) /
-                           np.abs(o[same, 4])).max()) if same.any() else None)
+                           np.maximum(np.abs(o[same, 4]), npix_tot)).max())
+                      if same.any() else None,
+                      max_abs_dchi_same_template=float(
+                          np.abs(g[same, 11] - o[same, 4]).max())
+                      if same.any() else None)
 
     line = dict(
         metric='spectra/sec (CCF+chi2 grid) DESI 3-arm',
@@ -337,10 +398,14 @@ def main():
         warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 2),
         higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
         data='synthetic',
-        config=dict(workload='DESI b/r/z 3-arm (2751/2326/2881 px), %d spectra '
-                             'per GPU per step, polylinear 7^4 grid, T=%d CCF '
-                             'templates, N_fft=%d, 400-velocity chi2 grid, '
-                             'npoly=10 (BASELINE configs[2])' % (S, Tccf, nfft),
+        config=dict(workload='%s, %d spectra per GPU per step, %s evaluator, 7^4 '
+                             'grid, T=%d CCF templates, N_fft=%d, 400-velocity '
+                             'chi2 grid, npoly=10' % (
+                                 'DESI b/r/z 3-arm (2751/2326/2881 px) (BASELINE '
+                                 'configs[%d])' % (3 if EVALUATOR == 'nn' else 2)
+                                 if args.workload == 'desi' else
+                                 '1 arm 4000-5000 A 2001 px (BASELINE configs[1])',
+                                 S, EVALUATOR, Tccf, nfft),
                     spectra_per_gpu=S, ccf_templates=Tccf, nfft=nfft,
                     refine=bool(args.refine), parallelism='spectra-sharded x%d'
                     % world),

@@ -192,7 +192,7 @@ int rvs_grid_moments(const double *chisq, const double *vels,
  * robust soft-L1 fit is a device Levenberg-Marquardt on the same objective.
  *
  * Eb float64 [npix, 3], El int32 [npix]   B-spline basis of every pixel
- * Cinv float64 [nnode, nnode]             inverse collocation matrix
+ * Cinv float64 [2, nnode, nnode]          inverse collocation matrix C^-1, then C
  * istart int32 [nnode-1]                  first pixel of every knot interval
  * bin_start int32 [nnode+1]  pixel ranges of the binned-median start
  * xind int32 [nfft], rw float64 [nfft]   rebin tables (xind<0: no coverage)

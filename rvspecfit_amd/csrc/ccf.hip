@@ -75,13 +75,12 @@ __device__ __forceinline__ double median11(double *a) {
 #define CCF_MAXNODE 24
 
 struct LMShared {
-  double p[CCF_MAXNODE], pn[CCF_MAXNODE], g[CCF_MAXNODE], dl[CCF_MAXNODE];
-  double c[CCF_MAXNODE], bvec[CCF_MAXNODE];
-  double H[CCF_MAXNODE * CCF_MAXNODE];   // normal matrix in node space
-  double T[CCF_MAXNODE * CCF_MAXNODE];   // Bm * Cinv
-  double Bm[CCF_MAXNODE * CCF_MAXNODE];  // banded normal matrix, B-spline space
-  double Ci[CCF_MAXNODE * CCF_MAXNODE];  // inverse collocation matrix
-  double isum[CCF_MAXNODE * 9];          // per knot-interval partial sums
+  double p[CCF_MAXNODE];                  // node values (start / result)
+  double c[CCF_MAXNODE], cn[CCF_MAXNODE], dl[CCF_MAXNODE];  // B-spline coeffs
+  double bvec[CCF_MAXNODE];               // gradient, B-spline space
+  double Bd[CCF_MAXNODE * 3];             // banded normal matrix: diag, sub1, sub2
+  double Lb[CCF_MAXNODE * 3];             // its LDL^T factor: d, l1, l2
+  double isum[CCF_MAXNODE * 9];           // per knot-interval partial sums
   double red[PP_NW];
   double lamd, medv, mederr, medspec;
   int flag, ngood, firstgood, lastgood, nval, stop, ok;
@@ -94,31 +93,22 @@ struct LMShared {
 // pixel).  So every per-pixel quantity costs 3 fma, and the Gauss-Newton
 // matrix in node space is H = C^-T (E^T W E) C^-1 with E^T W E pentadiagonal.
 
-// c = Ci * pp  (all threads call; contains a barrier)
-__device__ __forceinline__ void lm_coeffs(LMShared &S, const double *pp, int m) {
-  __syncthreads();
-  if (threadIdx.x < m) {
-    double s = 0;
-    for (int j = 0; j < m; j++) s = fma(S.Ci[threadIdx.x * m + j], pp[j], s);
-    S.c[threadIdx.x] = s;
-  }
-  __syncthreads();
-}
-
 // cost 0.5*sum rho(f^2), rho(z) = 2(sqrt(1+z)-1) (scipy soft_l1, f_scale=1) at
-// the coefficients S.c.  If store, also the Gauss-Newton weights
+// the B-spline coefficients cc.  If store, also the Gauss-Newton weights
 //   gw[k] = (m/e) f / sqrt(1+z),  hw[k] = (m/e)^2 (1+z)^-1.5
 // (rho' f and rho' + 2 rho'' f^2, the scaling scipy applies for robust losses)
-__device__ double lm_eval(LMShared &S, const double *__restrict__ Eb,
+__device__ double lm_eval(LMShared &S, const double *cc,
+                          const double *__restrict__ Eb,
                           const int32_t *__restrict__ El, int npix,
                           const double *cs, const double *ce, double *gw,
                           double *hw, bool store) {
+  __syncthreads();  // cc (LDS) was just written
   double c = 0;
   for (int k = threadIdx.x; k < npix; k += PP_NT) {
     const int l = El[k];
-    double s = Eb[3 * k] * S.c[l];
-    s = fma(Eb[3 * k + 1], S.c[l + 1], s);
-    s = fma(Eb[3 * k + 2], S.c[l + 2], s);
+    double s = Eb[3 * k] * cc[l];
+    s = fma(Eb[3 * k + 1], cc[l + 1], s);
+    s = fma(Eb[3 * k + 2], cc[l + 2], s);
     const bool clipped = (s < -100.0) || (s > 100.0);
     s = fmin(fmax(s, -100.0), 100.0);
     const double mod = exp(s);
@@ -136,7 +126,8 @@ __device__ double lm_eval(LMShared &S, const double *__restrict__ Eb,
   return 0.5 * block_sum<PP_NW>(c, S.red);
 }
 
-// Gauss-Newton system in node space: S.H (m x m), S.g (m)
+// Gauss-Newton system in B-SPLINE space: the pentadiagonal E^T W E (S.Bd: diag,
+// first and second sub-diagonal) and the gradient E^T gw (S.bvec).
 __device__ void lm_normal(LMShared &S, const double *__restrict__ Eb,
                           const int32_t *__restrict__ istart, int m,
                           const double *gw, const double *hw) {
@@ -168,109 +159,66 @@ __device__ void lm_normal(LMShared &S, const double *__restrict__ Eb,
     }
   }
   __syncthreads();
-  // banded assembly: Bm[a][b], |a-b| <= 2; bvec[a]
-  for (int e = threadIdx.x; e < m * 5 + m; e += PP_NT) {
-    if (e < m * 5) {
-      const int a = e / 5, b = a + (e % 5) - 2;
-      if (b < 0 || b >= m) continue;
-      const int lo = min(a, b), hi = max(a, b);
-      double s = 0;
-      for (int t = max(0, hi - 2); t <= min(lo, nint - 1); t++) {
-        const int u = lo - t, v = hi - t;  // 0<=u<=v<=2
-        const int idx = (u == 0) ? v : (u == 1 ? 2 + v : 5);
-        s += S.isum[t * 9 + idx];
-      }
-      S.Bm[a * m + b] = s;
-    } else {
-      const int a = e - m * 5;
+  // banded assembly: entry (a, a-d), d = 0,1,2 ; interval t covers coefficients
+  // t..t+2 and holds {00,01,02,11,12,22 | g0,g1,g2}
+  for (int e = threadIdx.x; e < 4 * m; e += PP_NT) {
+    const int a = e >> 2, d = e & 3;
+    if (d == 3) {
       double s = 0;
       for (int t = max(0, a - 2); t <= min(a, nint - 1); t++)
         s += S.isum[t * 9 + 6 + (a - t)];
       S.bvec[a] = s;
-    }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < m * m; e += PP_NT) {
-    const int a = e / m, j = e - a * m;
-    double s = 0;
-    for (int b = max(0, a - 2); b <= min(m - 1, a + 2); b++)
-      s = fma(S.Bm[a * m + b], S.Ci[b * m + j], s);
-    S.T[e] = s;
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < m * m + m; e += PP_NT) {
-    if (e < m * m) {
-      const int i = e / m, j = e - i * m;
-      double s = 0;
-      for (int a = 0; a < m; a++) s = fma(S.Ci[a * m + i], S.T[a * m + j], s);
-      S.H[e] = s;
     } else {
-      const int i = e - m * m;
+      const int lo = a - d;
       double s = 0;
-      for (int a = 0; a < m; a++) s = fma(S.Ci[a * m + i], S.bvec[a], s);
-      S.g[i] = s;
+      if (lo >= 0) {
+        for (int t = max(0, a - 2); t <= min(lo, nint - 1); t++) {
+          const int u = lo - t, v = a - t;  // 0<=u<=v<=2
+          const int idx = (u == 0) ? v : (u == 1 ? 2 + v : 5);
+          s += S.isum[t * 9 + idx];
+        }
+      }
+      S.Bd[a * 3 + d] = s;
     }
   }
   __syncthreads();
 }
 
-// (H + lamd diag H) dl = -g by an in-register Cholesky on ONE wave: lane i
-// holds row i, columns are exchanged with wave shuffles.  Writes S.dl, S.ok.
-__device__ void lm_solve_wave(LMShared &S, int m) {
-  const int lane = threadIdx.x & 63;
-  double r[CCF_MAXNODE];
-  const double ld = S.lamd;
-#pragma unroll
-  for (int j = 0; j < CCF_MAXNODE; j++) {
-    double v = (lane == j) ? 1.0 : 0.0;
-    if (lane < m && j < m) {
-      v = S.H[lane * m + j];
-      if (lane == j) v += ld * v;
-    }
-    r[j] = v;
-  }
-  double rhs = (lane < m) ? -S.g[lane] : 0.0;
+// (B + lamd diag B) dl = -bvec with B pentadiagonal SPD: LDL^T with a sliding
+// window, ONE thread, O(m).  Levenberg-Marquardt damping in B-spline space.
+__device__ void lm_band_solve(LMShared &S, int m) {
+  const double ld = 1.0 + S.lamd;
+  double d1 = 0, d2 = 0, l1p = 0;       // d_{i-1}, d_{i-2}, l1_{i-1}
+  double z1 = 0, z2 = 0;                // z_{i-1}, z_{i-2}
   bool ok = true;
-#pragma unroll
-  for (int k = 0; k < CCF_MAXNODE; k++) {
-    if (k < m) {
-      const double dkk = __shfl(r[k], k, 64);
-      if (!(dkk > 0)) ok = false;
-      const double lik = r[k] / sqrt(dkk);  // lane k: sqrt(dkk); lanes>k: L[i][k]
-      r[k] = lik;
-#pragma unroll
-      for (int j = k + 1; j < CCF_MAXNODE; j++) {
-        if (j < m) {
-          const double ljk = __shfl(lik, j, 64);
-          r[j] = fma(-lik, ljk, r[j]);
-        }
-      }
-    }
+  for (int i = 0; i < m; i++) {
+    const double a0 = S.Bd[i * 3] * ld, a1 = S.Bd[i * 3 + 1], a2 = S.Bd[i * 3 + 2];
+    const double l2 = (i >= 2) ? a2 / d2 : 0.0;
+    const double l1 = (i >= 1) ? (a1 - l2 * l1p * d2) / d1 : 0.0;
+    const double d = a0 - l1 * l1 * d1 - l2 * l2 * d2;
+    if (!(d > 0)) ok = false;
+    const double z = -S.bvec[i] - l1 * z1 - l2 * z2;
+    S.Lb[i * 3] = d;
+    S.Lb[i * 3 + 1] = l1;
+    S.Lb[i * 3 + 2] = l2;
+    S.dl[i] = z / d;   // w_i = z_i / d_i
+    d2 = d1;
+    d1 = d;
+    l1p = l1;
+    z2 = z1;
+    z1 = z;
   }
-  // forward substitution L y = rhs
-#pragma unroll
-  for (int k = 0; k < CCF_MAXNODE; k++) {
-    if (k < m) {
-      const double yk = __shfl(rhs / r[k], k, 64);
-      if (lane == k) rhs = yk;
-      if (lane > k) rhs = fma(-r[k], yk, rhs);
-    }
+  double x1 = 0, x2 = 0;  // x_{i+1}, x_{i+2}
+  for (int i = m - 1; i >= 0; i--) {
+    const double l1n = (i + 1 < m) ? S.Lb[(i + 1) * 3 + 1] : 0.0;
+    const double l2n = (i + 2 < m) ? S.Lb[(i + 2) * 3 + 2] : 0.0;
+    const double x = S.dl[i] - l1n * x1 - l2n * x2;
+    S.dl[i] = ok ? x : 0.0;
+    x2 = x1;
+    x1 = x;
   }
-  // back substitution L^T x = y ; L[k][i] is register r[i] of lane k
-#pragma unroll
-  for (int k = CCF_MAXNODE - 1; k >= 0; k--) {
-    if (k < m) {
-      const double xk = __shfl(rhs / r[k], k, 64);
-      if (lane == k) rhs = xk;
-#pragma unroll
-      for (int i = 0; i < k; i++) {
-        const double lki = __shfl(r[i], k, 64);
-        if (lane == i) rhs = fma(-lki, xk, rhs);
-      }
-    }
-  }
-  if (lane < m) S.dl[lane] = ok ? rhs : 0.0;
-  if (lane == 0) S.ok = ok ? 1 : 0;
+  for (int i = 0; i < m; i++) S.cn[i] = S.c[i] + S.dl[i];
+  S.ok = ok ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(PP_NT)
@@ -307,8 +255,6 @@ __global__ void __launch_bounds__(PP_NT)
     ce[k] = es0[k];
     msk[k] = badmask ? (badmask[(int64_t)b * npix + k] != 0) : 0;
   }
-  if (continuum)
-    for (int e = tid; e < nnode * nnode; e += PP_NT) S.Ci[e] = Cinv[e];
   if (tid == 0) {
     S.flag = 0;
     S.nval = 0;
@@ -465,30 +411,32 @@ __global__ void __launch_bounds__(PP_NT)
     __syncthreads();
 
     // ---- Levenberg-Marquardt on the soft-L1 objective -----------------------
+    // unknowns: the B-spline coefficients c = C^-1 p of the interpolating spline
+    // (a linear bijection of the reference's node values p, same minimum)
     double *gw = sb;  // reuse
+    if (tid < m) {
+      double s = 0;
+      for (int jj = 0; jj < m; jj++) s = fma(Cinv[tid * m + jj], S.p[jj], s);
+      S.c[tid] = s;
+    }
     if (tid == 0) {
       S.lamd = 1e-3;
       S.stop = 0;
     }
-    lm_coeffs(S, S.p, m);
-    double cost = lm_eval(S, Eb, El, npix, cs, ce, gw, hw, true);
+    double cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true);
     for (int it = 0; it < 60; it++) {
       lm_normal(S, Eb, istart, m, gw, hw);
       // damped step; retry with larger damping until the cost does not grow
       for (int tries = 0; tries < 40; tries++) {
-        if (tid < 64) {
-          lm_solve_wave(S, m);
-          if (tid < m) S.pn[tid] = S.p[tid] + S.dl[tid];
-        }
-        lm_coeffs(S, S.pn, m);
-        const double cn = lm_eval(S, Eb, El, npix, cs, ce, gw, hw, false);
+        if (tid == 0) lm_band_solve(S, m);
+        const double cn = lm_eval(S, S.cn, Eb, El, npix, cs, ce, gw, hw, false);
         if (cn <= cost) {  // accept (block-uniform decision)
           double mx = 0;
           for (int i = 0; i < m; i++) mx = fmax(mx, fabs(S.dl[i]));
           const double rel = (cost - cn) / fmax(cost, 1e-300);
           __syncthreads();
           if (tid == 0) {
-            for (int i = 0; i < m; i++) S.p[i] = S.pn[i];
+            for (int i = 0; i < m; i++) S.c[i] = S.cn[i];
             S.lamd = fmax(S.lamd / 8, 1e-12);
             if (mx < 1e-11 || rel < 1e-15) S.stop = 1;
           }
@@ -505,12 +453,16 @@ __global__ void __launch_bounds__(PP_NT)
       }
       __syncthreads();
       if (S.stop) break;
-      lm_coeffs(S, S.p, m);
-      cost = lm_eval(S, Eb, El, npix, cs, ce, gw, hw, true);
+      cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true);
     }
     __syncthreads();
-    lm_coeffs(S, S.p, m);
-    if (pfit && tid < m) pfit[(int64_t)b * m + tid] = S.p[tid];
+    if (pfit && tid < m) {
+      // node values p = C c (C follows C^-1 in the Cinv buffer)
+      const double *Cm = Cinv + m * m;
+      double s = 0;
+      for (int jj = 0; jj < m; jj++) s = fma(Cm[tid * m + jj], S.c[jj], s);
+      pfit[(int64_t)b * m + tid] = s;
+    }
   }
 
   // ---- normalise (make_ccf.py:380-392) ----------------------------------------

@@ -173,7 +173,8 @@ class ArmData:
                 nodes, self.lam_host)
             T['Eb'] = torch.as_tensor(np.ascontiguousarray(Eb)).to(dev)
             T['El'] = torch.as_tensor(El).to(dev)
-            T['Cinv'] = torch.as_tensor(np.ascontiguousarray(Cinv)).to(dev)
+            T['Cinv'] = torch.as_tensor(np.ascontiguousarray(
+                np.stack([Cinv, np.linalg.inv(Cinv)]))).to(dev)
             T['istart'] = torch.as_tensor(istart).to(dev)
             T['nnode'] = len(nodes)
             T['bin_start'] = torch.as_tensor(

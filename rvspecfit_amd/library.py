@@ -144,12 +144,14 @@ class TemplateLibrary:
         a1 = torch.empty((J, width), dtype=torch.float32, device=self.device)
         Wp = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in self.nn_W])
         bp = (ctypes.c_void_p * nl)(*[b.data_ptr() for b in self.nn_b])
-        rc = L.rvs_template_nn(_lib.ptr(params), J, self.ndim, self.log_mask,
-                               _lib.ptr(self.nn_M), _lib.ptr(self.nn_S), nl,
-                               ctypes.cast(Wp, ctypes.c_void_p),
-                               ctypes.cast(bp, ctypes.c_void_p),
-                               _lib.ptr(self.nn_dims), _lib.ptr(a0),
-                               _lib.ptr(a1), _lib.ptr(templ), _lib.stream())
+        from . import engine
+        with engine._ktime('template_nn', J):
+            rc = L.rvs_template_nn(_lib.ptr(params), J, self.ndim, self.log_mask,
+                                   _lib.ptr(self.nn_M), _lib.ptr(self.nn_S), nl,
+                                   ctypes.cast(Wp, ctypes.c_void_p),
+                                   ctypes.cast(bp, ctypes.c_void_p),
+                                   _lib.ptr(self.nn_dims), _lib.ptr(a0),
+                                   _lib.ptr(a1), _lib.ptr(templ), _lib.stream())
         _lib.check(rc, 'rvs_template_nn')
         outside.copy_(self._nn_outside(params))
         return templ, outside

@@ -171,6 +171,23 @@ int rvs_chisq_full(const double *lam, const double *polysT, const double *spec,
                    void *stream);
 
 /* ------------------------------------------------------------------------
+ * A13  get_chisq_continuum (spec_fit.py:739-783) for a whole batch of one arm:
+ * continuum-only fit (template == 1), true chi^2 over pixels with badmask == 0
+ * and their count.  One lane per spectrum, one wave per pixel slice; a Cholesky failure (numerically
+ * singular basis) is flagged and gives NaN -- rvs_chisq_full(unit_template=1)
+ * is the slower entry point with the eigen (SVD) fallback.
+ * polysT [npix, npoly]; spec, espec [S, npix]; badmask uint8 [S, npix] (nullable)
+ * work: scratch of rvs_chisq_continuum_work_size(npoly, S) bytes
+ * chisq [S] (-2 log L, nullable), true_chisq [S], ngood int32 [S]
+ * ---------------------------------------------------------------------- */
+int64_t rvs_chisq_continuum_work_size(int npoly, int S);
+int rvs_chisq_continuum(const double *polysT, const double *spec,
+                        const double *espec, const uint8_t *badmask, int npix,
+                        int npoly, int S, void *work, double *chisq,
+                        double *true_chisq, int32_t *ngood, int32_t *status,
+                        void *stream);
+
+/* ------------------------------------------------------------------------
  * A12  grid summary; replaces the tail of spec_fit.find_best
  * (spec_fit.py:1072-1092) and _quadratic_interp_min (:992-1015).
  * chisq [G, Np, Nv] (velocity fastest); vels + g*vel_stride -> [Nv];

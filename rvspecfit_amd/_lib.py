@@ -32,6 +32,8 @@ SIGNATURES = {
                            D, D, I, P, P, P]),
     'rvs_chisq_full': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, P, P, I,
                            P, D, P, P, P, P, P, P, P, P]),
+    'rvs_chisq_continuum_work_size': (L, [I, I]),
+    'rvs_chisq_continuum': (I, [P, P, P, P, I, I, I, P, P, P, P, P, P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),

@@ -797,6 +797,227 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
 }
 
 // ---------------------------------------------------------------------------
+// A13: get_chisq_continuum for a whole batch (spec_fit.py:739-783): template == 1.
+// One LANE per spectrum (the basis row is wave-uniform -> scalar cache, exactly
+// as in chisq_grid_kernel) and one WAVE per (64 spectra, pixel slice): pass 1
+// writes per-slice normal-equation partials, pass 2 sums them in slice order
+// (deterministic), factors in-lane and accumulates the model residuals of its
+// slice over the unmasked pixels, pass 3 folds the slices.
+// work layout: part[slice][value][S] doubles, value < NV = P(P+1)/2 + P + 2,
+// then res[slice][2][S] (true chi^2 partial, good-pixel count).
+// ---------------------------------------------------------------------------
+__host__ __device__ static inline int cont_nslice(int S) {
+  int groups = (S + 63) / 64;
+  int n = 2048 / groups;
+  return n < 1 ? 1 : (n > 32 ? 32 : n);
+}
+
+template <int P>
+__global__ void __launch_bounds__(64)
+    continuum_normal_kernel(const double *__restrict__ polysT,
+                            const double *__restrict__ spec,
+                            const double *__restrict__ espec, int npix, int S,
+                            int nsl, double *__restrict__ part) {
+  constexpr int NT = P * (P + 1) / 2;
+  const int s0 = blockIdx.x * 64 + threadIdx.x;
+  const bool active = s0 < S;
+  const int s = active ? s0 : S - 1;
+  const int sl = blockIdx.y;
+  const int k0 = (int)((int64_t)npix * sl / nsl);
+  const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
+  const double *sp = spec + (int64_t)s * npix;
+  const double *es = espec + (int64_t)s * npix;
+  double acc[NT];
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = 0;
+  double lz = 0, dd = 0;
+  for (int k = k0; k < k1; k++) {
+    const double e = es[k], x = sp[k];
+    const double ie = 1.0 / e;
+    const double w = ie * ie, u = x * w;
+    lz += log(e);
+    dd = fma(x * ie, x * ie, dd);
+    const double *pr = polysT + (int64_t)k * P;
+    double pw[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      av[i] = fma(pr[i], u, av[i]);
+#pragma unroll
+      for (int jj = 0; jj <= i; jj++)
+        acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
+    }
+  }
+  if (!active) return;
+  double *o = part + (int64_t)sl * (NT + P + 2) * S + s;
+#pragma unroll
+  for (int i = 0; i < NT; i++) o[(int64_t)i * S] = acc[i];
+#pragma unroll
+  for (int i = 0; i < P; i++) o[(int64_t)(NT + i) * S] = av[i];
+  o[(int64_t)(NT + P) * S] = lz;
+  o[(int64_t)(NT + P + 1) * S] = dd;
+}
+
+template <int P>
+__global__ void __launch_bounds__(64)
+    continuum_resid_kernel(const double *__restrict__ polysT,
+                           const double *__restrict__ spec,
+                           const double *__restrict__ espec,
+                           const uint8_t *__restrict__ badmask, int npix, int S,
+                           int nsl, const double *__restrict__ part,
+                           double *__restrict__ res, double *__restrict__ chisq,
+                           int32_t *__restrict__ status) {
+  constexpr int NT = P * (P + 1) / 2;
+  constexpr int NV = NT + P + 2;
+  const int s0 = blockIdx.x * 64 + threadIdx.x;
+  const bool active = s0 < S;
+  const int s = active ? s0 : S - 1;
+  const int sl = blockIdx.y;
+  double acc[NT];
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = 0;
+  double lz = 0, dd = 0;
+  for (int q = 0; q < nsl; q++) {
+    const double *o = part + (int64_t)q * NV * S + s;
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[i] += o[(int64_t)i * S];
+#pragma unroll
+    for (int i = 0; i < P; i++) av[i] += o[(int64_t)(NT + i) * S];
+    lz += o[(int64_t)(NT + P) * S];
+    dd += o[(int64_t)(NT + P + 1) * S];
+  }
+  bool ok = true;
+  double ldet = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+#pragma unroll
+    for (int jj = 0; jj <= i; jj++) {
+      double sum = acc[TRI(i, jj)];
+#pragma unroll
+      for (int q = 0; q < jj; q++) sum -= acc[TRI(i, q)] * acc[TRI(jj, q)];
+      if (jj == i) {
+        if (!(sum > 0)) ok = false;
+        const double d = sqrt(sum);
+        acc[TRI(i, i)] = d;
+        ldet += log(d);
+      } else {
+        acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
+      }
+    }
+  }
+  // L y = v ; L^T a = y
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    double sum = av[i];
+#pragma unroll
+    for (int q = 0; q < i; q++) sum -= acc[TRI(i, q)] * av[q];
+    av[i] = sum / acc[TRI(i, i)];
+  }
+  double yy = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) yy = fma(av[i], av[i], yy);
+#pragma unroll
+  for (int i = P - 1; i >= 0; i--) {
+    double sum = av[i];
+#pragma unroll
+    for (int q = i + 1; q < P; q++) sum -= acc[TRI(q, i)] * av[q];
+    av[i] = sum / acc[TRI(i, i)];
+  }
+  const int k0 = (int)((int64_t)npix * sl / nsl);
+  const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
+  const double *sp = spec + (int64_t)s * npix;
+  const double *es = espec + (int64_t)s * npix;
+  const uint8_t *bm = badmask ? badmask + (int64_t)s * npix : nullptr;
+  double tc = 0;
+  int ng = 0;
+  for (int k = k0; k < k1; k++) {
+    const double *pr = polysT + (int64_t)k * P;
+    double m = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) m = fma(av[i], pr[i], m);
+    const double dev = (m - sp[k]) / es[k];
+    const bool good = bm ? (bm[k] == 0) : true;
+    if (good) {
+      tc = fma(dev, dev, tc);
+      ng++;
+    }
+  }
+  if (!active) return;
+  res[((int64_t)sl * 2 + 0) * S + s] = ok ? tc : __builtin_nan("");
+  res[((int64_t)sl * 2 + 1) * S + s] = (double)ng;
+  if (sl == 0) {
+    int st = 0;
+    const double chi = 2.0 * ldet + 2.0 * lz + (dd - yy);
+    if (!ok) st |= RVS_ST_CHOL_FALLBACK;
+    if (!ok || !(fabs(chi) <= 1.79e308)) st |= RVS_ST_NONFINITE;
+    if (chisq) chisq[s] = chi;
+    if (st && status) atomicOr(&status[s], st);
+  }
+}
+
+__global__ void continuum_fold_kernel(const double *__restrict__ res, int S,
+                                      int nsl, double *__restrict__ true_chisq,
+                                      int32_t *__restrict__ ngood) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  double tc = 0, ng = 0;
+  for (int q = 0; q < nsl; q++) {
+    tc += res[((int64_t)q * 2 + 0) * S + s];
+    ng += res[((int64_t)q * 2 + 1) * S + s];
+  }
+  true_chisq[s] = tc;
+  ngood[s] = (int32_t)ng;
+}
+
+extern "C" int64_t rvs_chisq_continuum_work_size(int npoly, int S) {
+  if (npoly < 1 || S < 1) return 0;
+  const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly + 2;
+  return (int64_t)cont_nslice(S) * (nv + 2) * S * (int64_t)sizeof(double);
+}
+
+extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
+                                   const double *espec, const uint8_t *badmask,
+                                   int npix, int npoly, int S, void *work,
+                                   double *chisq, double *true_chisq,
+                                   int32_t *ngood, int32_t *status,
+                                   void *stream) {
+  if (S < 1 || npix < 1 || !work) return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  const int nsl = cont_nslice(S);
+  const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly + 2;
+  double *part = (double *)work;
+  double *res = part + (int64_t)nsl * nv * S;
+  dim3 grid((S + 63) / 64, nsl);
+#define RVS_CASE(PP)                                                           \
+  case PP:                                                                     \
+    hipLaunchKernelGGL(continuum_normal_kernel<PP>, grid, dim3(64), 0, st,     \
+                       polysT, spec, espec, npix, S, nsl, part);               \
+    hipLaunchKernelGGL(continuum_resid_kernel<PP>, grid, dim3(64), 0, st,      \
+                       polysT, spec, espec, badmask, npix, S, nsl, part, res,  \
+                       chisq, status);                                         \
+    break;
+  switch (npoly) {
+    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
+    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
+    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
+    default:
+      return RVS_E_ARG;
+  }
+#undef RVS_CASE
+  hipLaunchKernelGGL(continuum_fold_kernel, dim3((S + 255) / 256), dim3(256), 0,
+                     st, res, S, nsl, true_chisq, ngood);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // A12: find_best tail (spec_fit.py:1072-1092).  One 256-thread block / group.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

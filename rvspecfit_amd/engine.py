@@ -448,6 +448,53 @@ def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
     return res
 
 
+def chisq_continuum(batch, npoly=5, rbf=True):
+    """get_chisq_continuum for a batch: per arm dict(true_chisq [S], ngood [S],
+    status [S]) (rvs_chisq_continuum, one lane per spectrum).  Spectra whose
+    normal matrix is numerically singular are redone by rvs_chisq_full, which
+    carries the eigen (SVD) fallback of spec_fit.py:337-354."""
+    L = _lib.lib()
+    dev = batch.device
+    res = []
+    for arm in batch.arms:
+        polysT = arm.basis(npoly, rbf)
+        S = arm.S
+        tchi = torch.empty(S, dtype=torch.float64, device=dev)
+        ngood = torch.empty(S, dtype=torch.int32, device=dev)
+        status = torch.zeros(S, dtype=torch.int32, device=dev)
+        if npoly <= 16:
+            nb = L.rvs_chisq_continuum_work_size(npoly, S)
+            work = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+            rc = L.rvs_chisq_continuum(_lib.ptr(polysT), _lib.ptr(arm.spec),
+                                       _lib.ptr(arm.espec), _lib.ptr(arm.badmask),
+                                       arm.npix, npoly, S, _lib.ptr(work), None,
+                                       _lib.ptr(tchi),
+                                       _lib.ptr(ngood), _lib.ptr(status),
+                                       _lib.stream())
+            _lib.check(rc, 'rvs_chisq_continuum')
+        else:
+            status.fill_(_lib.ST_CHOL_FALLBACK)
+        res.append(dict(true_chisq=tchi, ngood=ngood, status=status))
+    return res
+
+
+def chisq_continuum_fix(batch, res, npoly=5, rbf=True):
+    """host-synchronising tail of chisq_continuum: redo flagged spectra with the
+    two-tier kernel.  Returns res (updated in place)."""
+    for ia, arm in enumerate(batch.arms):
+        bad = torch.nonzero(res[ia]['status'] & _lib.ST_CHOL_FALLBACK).reshape(-1)
+        if bad.numel() == 0:
+            continue
+        sub = SpecBatch([ArmData(arm.name, arm.lam_host, arm.spec[bad],
+                                 arm.espec[bad], arm.badmask[bad],
+                                 device=batch.device)])
+        full = chisq_full(sub, None, None, None, npoly=npoly, rbf=rbf,
+                          unit_template=True, want_models=False)[0]
+        res[ia]['true_chisq'][bad] = full['true_chisq']
+        res[ia]['ngood'][bad] = full['ngood']
+    return res
+
+
 # --------------------------------------------------------------------------
 # CCF: A15 + A14
 # --------------------------------------------------------------------------
@@ -509,6 +556,8 @@ def ccf_fit(batch, libs, config, keep_all=False, max_chunk=None):
     # chunk spectra so that the [chunk, T, nvel] accumulator stays modest
     if max_chunk is None:
         max_chunk = max(1, min(S, int(2e9 // (Tn * nvel * 8))))
+        nchunk = -(-S // max_chunk)
+        max_chunk = -(-S // nchunk)  # equal-sized chunks
     res = torch.empty((S, 4), dtype=torch.float64, device=dev)
     best_ccf = torch.empty((S, nvel), dtype=torch.float64, device=dev)
     allchi = None

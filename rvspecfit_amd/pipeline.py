@@ -59,8 +59,7 @@ def fit_batch(batch, config, options=None, refine=False, timers=None):
     ev.stop('chisq_grid')
 
     ev.start('continuum')
-    cont = engine.chisq_full(batch, None, None, None, npoly=npoly, rbf=rbf,
-                             unit_template=True, want_models=False)
+    cont = engine.chisq_continuum(batch, npoly=npoly, rbf=rbf)
     ev.stop('continuum')
 
     rec = torch.zeros((S, NREC), dtype=torch.float64, device=dev)
@@ -76,7 +75,10 @@ def fit_batch(batch, config, options=None, refine=False, timers=None):
     rec[:, 11] = res[:, 0]
     for ia in range(min(3, len(batch.arms))):
         rec[:, 12 + ia] = cont[ia]['true_chisq']
-    rec[:, 15] = (status | mst | ccf['status']).double()
+    cst = cont[0]['status']
+    for c in cont[1:]:
+        cst = cst | c['status']
+    rec[:, 15] = (status | mst | ccf['status'] | cst).double()
 
     if refine:
         ev.start('refine')

@@ -376,8 +376,9 @@ def get_chisq_continuum(specdata, options=None):
     npoly = options.get('npoly') or 5
     rbf = options.get('rbf_continuum', True)
     batch, is_batch = as_batch(specdata)
-    full = engine.chisq_full(batch, None, None, None, npoly=npoly, rbf=rbf,
-                             unit_template=True, want_models=False)
+    full = engine.chisq_continuum_fix(
+        batch, engine.chisq_continuum(batch, npoly=npoly, rbf=rbf), npoly=npoly,
+        rbf=rbf)
     ca = torch.stack([f['true_chisq'] for f in full], dim=1)
     ng = torch.stack([f['ngood'] for f in full], dim=1)
     if is_batch:

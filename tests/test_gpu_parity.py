@@ -354,6 +354,29 @@ def test_batch_equals_singles(cases, config):
         np.testing.assert_array_equal(rec[i], one[0])
 
 
+@pytest.mark.parametrize('S,npoly', [(131, 5), (64, 10), (3, 16)])
+def test_chisq_continuum_batched(S, npoly):
+    """rvs_chisq_continuum (lane per spectrum, pixel slices) against the oracle's
+    get_chisq_continuum on ragged batch sizes with masked pixels"""
+    from rvspecfit_amd import engine, synth
+    from rvspecfit_amd.engine import ArmData, SpecBatch
+    rng = np.random.RandomState(5 + S)
+    npix = 777
+    lam = np.linspace(4000., 5000., npix)
+    spec = 1 + 0.3 * rng.normal(size=(S, npix)) + np.linspace(0, 1, npix)
+    espec = rng.uniform(0.1, 0.5, size=(S, npix))
+    bad = rng.uniform(size=(S, npix)) < 0.1
+    batch = SpecBatch([ArmData('x', lam, spec, espec, bad, device='cuda')])
+    res = engine.chisq_continuum_fix(
+        batch, engine.chisq_continuum(batch, npoly=npoly), npoly=npoly)[0]
+    for i in range(S):
+        sd = [orc.SpecData('x', lam, spec[i], espec[i], badmask=bad[i])]
+        ref = orc.get_chisq_continuum(sd, options=dict(npoly=npoly))
+        np.testing.assert_allclose(res['true_chisq'][i].item(),
+                                   ref['chisq_array'][0], rtol=1e-8)
+        assert res['ngood'][i].item() == int((~bad[i]).sum())
+
+
 def test_overlap_error(cases, config):
     from rvspecfit_amd import spec_fit
     sds = _sds(cases, 'c0')

@@ -188,6 +188,27 @@ int rvs_chisq_continuum(const double *polysT, const double *spec,
                         void *stream);
 
 /* ------------------------------------------------------------------------
+ * A11 at one velocity per job: the objective of the optimiser stage,
+ * chisq_func0 (vel_fit.py:205-226) = get_chisq (spec_fit.py:797-989) for J
+ * (spectrum, template, velocity) triples.  One lane per job, one wave per pixel
+ * slice; the residual norm ||D - a.ST||^2 is formed explicitly (spec_fit.py:249)
+ * so the value can be finite-differenced (Hessian, vel_fit.py:699-725).
+ * polysT is the plain get_basis matrix; coef is form-1 (power form);
+ * work is the rvs_chisq_prepare buffer of this (arm, template grid);
+ * scratch: rvs_chisq_point_work_size(npoly, J) bytes;
+ * out[j] = beta*out[j] + chisq + penalty[j] (NaN penalty -> + 1000*badchi).
+ * ---------------------------------------------------------------------- */
+int64_t rvs_chisq_point_work_size(int npoly, int J);
+int rvs_chisq_point(const double *lam, const double *polysT, const double *spec,
+                    const double *espec, const double *work, int npix,
+                    int npoly, int S, const double *knots, const double *coef,
+                    int ntp, int Tn, int log_step, const int32_t *job_spec,
+                    const int32_t *job_templ, int J, const double *vel,
+                    const double *penalty, double badchi, double espec_sys,
+                    void *scratch, double beta, double *out, int32_t *status,
+                    void *stream);
+
+/* ------------------------------------------------------------------------
  * A12  grid summary; replaces the tail of spec_fit.find_best
  * (spec_fit.py:1072-1092) and _quadratic_interp_min (:992-1015).
  * chisq [G, Np, Nv] (velocity fastest); vels + g*vel_stride -> [Nv];

@@ -822,3 +822,177 @@ def nn_forward(weights, p, M, S, log_ids=(0, )):
 def convolve_vsini_rows(lam, templ, vsini, eps=0.6):
     """convolve_vsini applied to every row (bench helper)."""
     return np.array([convolve_vsini(lam, t, v, eps) for t, v in zip(templ, vsini)])
+
+
+# --------------------------------------------------------------------------
+# SURVEY 8(f) rank 1: vel_fit.process (vel_fit.py:95-312, 442-737)
+# --------------------------------------------------------------------------
+def _vsini_to_vsini(x, max_vsini):  # VSiniMapper.to_vsini, vel_fit.py:108-116
+    vsini = np.clip(x, 0, max_vsini)
+    pen = int(x < 0) * (vsini - x)**2 + int(x > max_vsini) * (vsini - x)**2
+    return vsini, pen
+
+
+def _pm_forward(p0, names, pd0, fix, fit_vsini, max_vsini):
+    """ParamMapper.forward, vel_fit.py:156-194"""
+    rev = list(p0)[::-1]
+    ret = dict(vel=rev.pop())
+    pen = 0
+    if fit_vsini:
+        ret['vsini'], pen = _vsini_to_vsini(rev.pop(), max_vsini)
+    else:
+        ret['vsini'] = pd0['vsini'] if 'vsini' in fix else None
+    ret['rot_params'] = None if ret['vsini'] is None else (ret['vsini'], )
+    ret['params'] = [pd0[x] if x in fix else rev.pop() for x in names]
+    assert len(rev) == 0
+    ret['penalty'] = pen
+    return ret
+
+
+def hessian_central(f, x, h):
+    """the stand-in for numdifftools.Hessian used by the golden harness
+    (tests/golden/make_golden_process.py): central second differences, one step"""
+    x = np.asarray(x, dtype=float)
+    n = len(x)
+    fx = f(x)
+    ee = np.diag(h)
+    H = np.zeros((n, n))
+    for i in range(n):
+        H[i, i] = (f(x + 2 * ee[i]) - 2 * fx + f(x - 2 * ee[i])) / \
+            (4. * h[i] * h[i])
+        for j in range(i + 1, n):
+            H[i, j] = (f(x + ee[i] + ee[j]) - f(x + ee[i] - ee[j]) -
+                       f(x - ee[i] + ee[j]) + f(x - ee[i] - ee[j])) / \
+                (4. * h[i] * h[j])
+            H[j, i] = H[i, j]
+    return H
+
+
+def uncertainties_from_hessian(hessian):  # vel_fit.py:464-502
+    import scipy.linalg
+    dh = np.diag(hessian)
+    with np.errstate(all='ignore'):
+        inv_d = 1. / (dh + (dh == 0))
+    inv_d[dh == 0] = np.inf
+    bad = False
+    try:
+        hinv = scipy.linalg.inv(hessian)
+    except (np.linalg.LinAlgError, ValueError):
+        bad = True
+        hinv = np.diag(inv_d)
+    e0 = np.array(np.diag(hinv))
+    e1 = inv_d
+    b0, b1 = e0 < 0, e1 < 0
+    if b0.any():
+        bad = True
+    s1, s2 = b0 & ~b1, b0 & b1
+    e0[s1] = e1[s1]
+    e0[s2] = 0
+    with np.errstate(all='ignore'):
+        err = np.sqrt(e0)
+    err[s2] = np.nan
+    if (~np.isfinite(err)).sum() != 0:
+        bad = True
+    return err, hinv, bad
+
+
+def process(specdata, paramDict0, fixParam, options, config, libs,
+            priors=None):
+    """vel_fit.process (vel_fit.py:505-737) without the optional BFGS polish;
+    Nelder-Mead is scipy's own (as in the reference); the Hessian is the
+    stand-in rule above (numdifftools is absent)."""
+    import scipy.optimize
+    names = list(libs[specdata[0].name].parnames)
+    fix = list(fixParam or [])
+    min_vel, max_vel = config['min_vel'], config['max_vel']
+    max_vsini = config['max_vsini']
+    curparam = tuple(paramDict0[_] for _ in names)
+    if 'vsini' not in paramDict0:
+        rot, fit_vsini = None, False
+    else:
+        rot = (paramDict0['vsini'], )
+        fit_vsini = 'vsini' not in fix
+    vg = np.arange(min_vel, max_vel, config['vel_step0'])
+    res = find_best(specdata, vg, [curparam], rot_params=rot, options=options,
+                    config=config, libs=libs)
+    # _get_simplex_start, vel_fit.py:272-312
+    start, std = [res['best_vel']], [5]
+    if fit_vsini:
+        start.append(np.clip(paramDict0['vsini'], 0, max_vsini))
+        std.append(3)
+    for x in names:
+        if x not in fix:
+            start.append(paramDict0[x])
+            std.append({'logg': 0.5, 'teff': 300, 'feh': 0.5,
+                        'alpha': 0.25}.get(x) or 0.5)
+    curval = np.array(start, dtype=float)
+    nd = len(curval)
+    R = np.random.RandomState(43434)
+    simplex = np.zeros((nd + 1, nd))
+    simplex[0] = curval
+    simplex[1:] = curval[None, :] + np.array(std)[None, :] * R.normal(
+        size=(nd, nd))
+    cache = {}
+
+    def chisq0(pd):  # chisq_func0, vel_fit.py:205-226
+        c = 0
+        if priors is not None:
+            for i, k in enumerate(names):
+                if k in priors:
+                    c += ((priors[k][0] - pd['params'][i]) / priors[k][1])**2
+        cache.clear()
+        return c + get_chisq(specdata, pd['vel'], tuple(pd['params']),
+                             pd['rot_params'], options=options, config=config,
+                             libs=libs, use_c=True)
+
+    def chisq_func(p):  # vel_fit.py:229-254
+        pd = _pm_forward(p, names, paramDict0, fix, fit_vsini, max_vsini)
+        if (pd['vel'] > max_vel or pd['vel'] < min_vel
+                or (~np.isfinite(pd['params'])).any()):
+            return 1e30
+        return chisq0(pd) + pd['penalty']
+
+    nits, nfevs = [], []
+    success = True
+    for it in range(2):
+        r0 = scipy.optimize.minimize(
+            chisq_func, curval, method='Nelder-Mead',
+            options=dict(fatol=1e-3, xatol=1e-2, initial_simplex=simplex,
+                         maxiter=10000, maxfev=np.inf))
+        curval, simplex = r0['x'], r0['final_simplex'][0]
+        nits.append(r0['nit'])
+        nfevs.append(r0['nfev'])
+        if r0['success']:
+            break
+        if it == 1:
+            success = False
+    best = _pm_forward(r0['x'], names, paramDict0, fix, fit_vsini, max_vsini)
+    bv, be, sk, ku, _ = find_best_vel_iterate(
+        best['vel'], config, specdata, tuple(best['params']),
+        best['rot_params'], options, libs)
+    outp = get_chisq(specdata, bv, tuple(best['params']), best['rot_params'],
+                     options=options, config=config, libs=libs,
+                     full_output=True, use_c=True)
+    base = np.array([{'vsini': 1 / 100, 'logg': 0.1 / 100, 'feh': 0.1 / 100,
+                      'alpha': .01 / 100, 'teff': 1 / 100,
+                      'vrad': 1 / 100}[_] for _ in names])
+    tmp = dict(best)
+
+    def hess_func(p):  # vel_fit.py:257-269
+        tmp['params'] = list(p)
+        return 0.5 * chisq0(tmp)
+
+    x = np.array(best['params'], dtype=float)
+    for scale in (1.0, 8.0):
+        h = scale * base * np.maximum(np.log1p(np.abs(x)), 1.0)
+        H = hessian_central(hess_func, x, h)
+        err, covar, bad = uncertainties_from_hessian(H)
+        if not bad:
+            break
+    return dict(param=dict(zip(names, best['params'])), vsini=best['vsini'],
+                vel=bv, vel_err=be, vel_skewness=sk, vel_kurtosis=ku,
+                nm_x=r0['x'], nm_fun=r0['fun'], nm_nit=nits, nm_nfev=nfevs,
+                param_err=dict(zip(names, err)), param_covar=covar,
+                minimize_success=success, bad_hessian=bad,
+                chisq=outp['chisq'], chisq_array=outp['chisq_array'],
+                npix_array=outp['npix_array'], yfit=outp['models'])

@@ -34,6 +34,9 @@ SIGNATURES = {
                            P, D, P, P, P, P, P, P, P, P]),
     'rvs_chisq_continuum_work_size': (L, [I, I]),
     'rvs_chisq_continuum': (I, [P, P, P, P, I, I, I, P, P, P, P, P, P]),
+    'rvs_chisq_point_work_size': (L, [I, I]),
+    'rvs_chisq_point': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, P, P, I, P, P,
+                             D, D, P, D, P, P, P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),

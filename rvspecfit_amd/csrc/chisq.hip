@@ -1018,6 +1018,282 @@ extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
 }
 
 // ---------------------------------------------------------------------------
+// A11 at ONE velocity per job (the optimiser's objective, vel_fit.py:205-254):
+// one LANE per job (spectrum idx, own template, own velocity), one WAVE per
+// (64 jobs, pixel slice) -- the velocity-grid kernel would run one lane of 64
+// here.  Same three-pass structure as the continuum kernels above; the residual
+// norm is formed explicitly, ||D - a.ST||^2 (spec_fit.py:249), so the value has
+// no D.D - y.y cancellation and can be finite-differenced at any S/N.
+// scratch: part[slice][NV][J], NV = P(P+1)/2 + P, then res[slice][J],
+// then aux[2][J] = {log det, ok}.
+// ---------------------------------------------------------------------------
+struct PointTempl {
+  const double *lam, *knots;
+  const double4 *coef;
+  const double *pixa;  // pixel knot coordinates (rvs_chisq_prepare)
+  int ntp, log_step;
+};
+
+__device__ __forceinline__ double point_tv(const PointTempl &T,
+                                           const double4 *cf, int k, double f,
+                                           double shift, double x0,
+                                           double lin_inv_step) {
+  const double x = T.lam[k] * f;
+  int pos = T.log_step ? (int)(T.pixa[k] + shift)
+                       : (int)((x - x0) * lin_inv_step);
+  pos = min(max(pos, 0), T.ntp - 2);
+  const double dl = x - T.knots[pos];
+  const double4 c = cf[pos];
+  return fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
+}
+
+template <int P>
+__global__ void __launch_bounds__(64)
+    point_normal_kernel(PointTempl T, const double *__restrict__ polysT,
+                        const double *__restrict__ spec,
+                        const double *__restrict__ espec, int npix,
+                        const int32_t *__restrict__ job_spec,
+                        const int32_t *__restrict__ job_templ, int J,
+                        const double *__restrict__ vel, double espec_sys,
+                        int nsl, double *__restrict__ part) {
+  constexpr int NT = P * (P + 1) / 2;
+  const int j0 = blockIdx.x * 64 + threadIdx.x;
+  const bool active = j0 < J;
+  const int j = active ? j0 : J - 1;
+  const int s = job_spec ? job_spec[j] : j;
+  const int t = job_templ ? job_templ[j] : j;
+  const int sl = blockIdx.y;
+  const int k0 = (int)((int64_t)npix * sl / nsl);
+  const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
+  const double *sp = spec + (int64_t)s * npix;
+  const double *es = espec + (int64_t)s * npix;
+  const double4 *cf = T.coef + (int64_t)t * T.ntp;
+  const double bb = vel[j] / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double x0 = T.knots[0];
+  const double shift = T.log_step ? log(f) / log(T.knots[1] / x0) : 0.0;
+  const double lin_inv_step = T.log_step ? 0.0 : 1.0 / (T.knots[1] - x0);
+  const double sys2 = espec_sys * espec_sys;
+  double acc[NT];
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = 0;
+  for (int k = k0; k < k1; k++) {
+    const double tv = point_tv(T, cf, k, f, shift, x0, lin_inv_step);
+    double e = es[k];
+    if (espec_sys > 0) e = sqrt(sys2 + e * e);
+    const double ie = 1.0 / e;
+    const double te = tv * ie;
+    const double w = te * te, u = te * (sp[k] * ie);
+    const double *pr = polysT + (int64_t)k * P;
+    double pw[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      av[i] = fma(pr[i], u, av[i]);
+#pragma unroll
+      for (int jj = 0; jj <= i; jj++)
+        acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
+    }
+  }
+  if (!active) return;
+  double *o = part + (int64_t)sl * (NT + P) * J + j;
+#pragma unroll
+  for (int i = 0; i < NT; i++) o[(int64_t)i * J] = acc[i];
+#pragma unroll
+  for (int i = 0; i < P; i++) o[(int64_t)(NT + i) * J] = av[i];
+}
+
+template <int P>
+__global__ void __launch_bounds__(64)
+    point_resid_kernel(PointTempl T, const double *__restrict__ polysT,
+                       const double *__restrict__ spec,
+                       const double *__restrict__ espec, int npix,
+                       const int32_t *__restrict__ job_spec,
+                       const int32_t *__restrict__ job_templ, int J,
+                       const double *__restrict__ vel, double espec_sys,
+                       int nsl, const double *__restrict__ part,
+                       double *__restrict__ res, double *__restrict__ aux) {
+  constexpr int NT = P * (P + 1) / 2;
+  const int j0 = blockIdx.x * 64 + threadIdx.x;
+  const bool active = j0 < J;
+  const int j = active ? j0 : J - 1;
+  const int s = job_spec ? job_spec[j] : j;
+  const int t = job_templ ? job_templ[j] : j;
+  const int sl = blockIdx.y;
+  double acc[NT];
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = 0;
+  for (int q = 0; q < nsl; q++) {
+    const double *o = part + (int64_t)q * (NT + P) * J + j;
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[i] += o[(int64_t)i * J];
+#pragma unroll
+    for (int i = 0; i < P; i++) av[i] += o[(int64_t)(NT + i) * J];
+  }
+  bool ok = true;
+  double ldet = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+#pragma unroll
+    for (int jj = 0; jj <= i; jj++) {
+      double sum = acc[TRI(i, jj)];
+#pragma unroll
+      for (int q = 0; q < jj; q++) sum -= acc[TRI(i, q)] * acc[TRI(jj, q)];
+      if (jj == i) {
+        if (!(sum > 0)) ok = false;
+        const double d = sqrt(sum);
+        acc[TRI(i, i)] = d;
+        ldet += log(d);
+      } else {
+        acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    double sum = av[i];
+#pragma unroll
+    for (int q = 0; q < i; q++) sum -= acc[TRI(i, q)] * av[q];
+    av[i] = sum / acc[TRI(i, i)];
+  }
+#pragma unroll
+  for (int i = P - 1; i >= 0; i--) {
+    double sum = av[i];
+#pragma unroll
+    for (int q = i + 1; q < P; q++) sum -= acc[TRI(q, i)] * av[q];
+    av[i] = sum / acc[TRI(i, i)];
+  }
+  const int k0 = (int)((int64_t)npix * sl / nsl);
+  const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
+  const double *sp = spec + (int64_t)s * npix;
+  const double *es = espec + (int64_t)s * npix;
+  const double4 *cf = T.coef + (int64_t)t * T.ntp;
+  const double bb = vel[j] / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double x0 = T.knots[0];
+  const double shift = T.log_step ? log(f) / log(T.knots[1] / x0) : 0.0;
+  const double lin_inv_step = T.log_step ? 0.0 : 1.0 / (T.knots[1] - x0);
+  const double sys2 = espec_sys * espec_sys;
+  double rr = 0;
+  for (int k = k0; k < k1; k++) {
+    const double tv = point_tv(T, cf, k, f, shift, x0, lin_inv_step);
+    double e = es[k];
+    if (espec_sys > 0) e = sqrt(sys2 + e * e);
+    const double ie = 1.0 / e;
+    const double *pr = polysT + (int64_t)k * P;
+    double m = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) m = fma(av[i], pr[i], m);
+    const double r = sp[k] * ie - m * (tv * ie);
+    rr = fma(r, r, rr);
+  }
+  if (!active) return;
+  res[(int64_t)sl * J + j] = rr;
+  if (sl == 0) {
+    aux[j] = ldet;
+    aux[J + j] = ok ? 1.0 : 0.0;
+  }
+}
+
+__global__ void point_fold_kernel(PointTempl T, const double *__restrict__ work,
+                                  int npix, int S,
+                                  const int32_t *__restrict__ job_spec, int J,
+                                  const double *__restrict__ vel,
+                                  const double *__restrict__ penalty,
+                                  double badchi, int nsl,
+                                  const double *__restrict__ res,
+                                  const double *__restrict__ aux, double beta,
+                                  double *__restrict__ out,
+                                  int32_t *__restrict__ status) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= J) return;
+  const int s = job_spec ? job_spec[j] : j;
+  const double base = (beta != 0.0) ? beta * out[j] : 0.0;
+  const double pen = penalty ? penalty[j] : 0.0;
+  if (!(pen == pen) || isinf(pen)) {  // spec_fit.py:888-893
+    out[j] = base + 1000.0 * badchi;
+    return;
+  }
+  double rr = 0;
+  for (int q = 0; q < nsl; q++) rr += res[(int64_t)q * J + j];
+  const double lz = work[npix + 2ll * S * npix + 2 * s];
+  double chi = 2.0 * aux[j] + 2.0 * lz + rr;
+  int st = 0;
+  const double bb = vel[j] / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double xa = T.lam[0] * f, xb = T.lam[npix - 1] * f;
+  const double x0 = T.knots[0], xlast = T.knots[T.ntp - 1];
+  if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) {
+    st |= RVS_ST_SPLINE_RANGE;
+    chi = __builtin_nan("");
+  }
+  if (aux[J + j] == 0.0) st |= RVS_ST_CHOL_FALLBACK;
+  if (aux[J + j] == 0.0 || !(fabs(chi) <= 1.79e308)) {
+    st |= RVS_ST_NONFINITE;
+    chi = __builtin_nan("");
+  }
+  out[j] = base + chi + pen;
+  if (st) atomicOr(&status[j], st);
+}
+
+extern "C" int64_t rvs_chisq_point_work_size(int npoly, int J) {
+  if (npoly < 1 || J < 1) return 0;
+  const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly;
+  return ((int64_t)cont_nslice(J) * (nv + 1) + 2) * J * (int64_t)sizeof(double);
+}
+
+extern "C" int rvs_chisq_point(const double *lam, const double *polysT,
+                               const double *spec, const double *espec,
+                               const double *work, int npix, int npoly, int S,
+                               const double *knots, const double *coef, int ntp,
+                               int Tn, int log_step, const int32_t *job_spec,
+                               const int32_t *job_templ, int J,
+                               const double *vel, const double *penalty,
+                               double badchi, double espec_sys, void *scratch,
+                               double beta, double *out, int32_t *status,
+                               void *stream) {
+  if (J < 1 || npix < 1 || ntp < 3 || Tn < 1 || !scratch) return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  const int nsl = cont_nslice(J);
+  const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly;
+  double *part = (double *)scratch;
+  double *res = part + (int64_t)nsl * nv * J;
+  double *aux = res + (int64_t)nsl * J;
+  PointTempl T{lam, knots, reinterpret_cast<const double4 *>(coef), work, ntp,
+               log_step};
+  dim3 grid((J + 63) / 64, nsl);
+#define RVS_CASE(PP)                                                           \
+  case PP:                                                                     \
+    hipLaunchKernelGGL(point_normal_kernel<PP>, grid, dim3(64), 0, st, T,      \
+                       polysT, spec, espec, npix, job_spec, job_templ, J, vel, \
+                       espec_sys, nsl, part);                                  \
+    hipLaunchKernelGGL(point_resid_kernel<PP>, grid, dim3(64), 0, st, T,       \
+                       polysT, spec, espec, npix, job_spec, job_templ, J, vel, \
+                       espec_sys, nsl, part, res, aux);                        \
+    break;
+  switch (npoly) {
+    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
+    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
+    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
+    default:
+      return RVS_E_ARG;
+  }
+#undef RVS_CASE
+  hipLaunchKernelGGL(point_fold_kernel, dim3((J + 255) / 256), dim3(256), 0, st,
+                     T, work, npix, S, job_spec, J, vel, penalty, badchi, nsl,
+                     res, aux, beta, out, status);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // A12: find_best tail (spec_fit.py:1072-1092).  One 256-thread block / group.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

@@ -251,7 +251,8 @@ def build_templates(lib, params, vsini=None, return_templ=False):
     templ, outside = lib.eval_batch(params)
     if vsini is not None:
         out = torch.empty_like(templ)
-        rc = L.rvs_vsini_convolve(_lib.ptr(templ), _lib.ptr(vsini.contiguous()),
+        vsini = vsini.to(torch.float64).contiguous()
+        rc = L.rvs_vsini_convolve(_lib.ptr(templ), _lib.ptr(vsini),
                                   _lib.ptr(outside), lib.lnstep, 0.6, lib.ntp,
                                   J, _lib.ptr(out), _lib.stream())
         _lib.check(rc, 'rvs_vsini_convolve')
@@ -381,6 +382,44 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
     return out, status
 
 
+def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
+                job_spec=None, job_templ=None, espec_sys=0.0,
+                outside_penalty=True):
+    """get_chisq for J (spectrum, template, velocity) triples, summed over the
+    arms (rvs_chisq_point: lane per job, explicit residual norm).
+    vel [J]; returns chisq [J], status int32 [J]."""
+    L = _lib.lib()
+    dev = batch.device
+    vel = vel.to(device=dev, dtype=torch.float64).contiguous()
+    J = vel.shape[0]
+    out = torch.empty(J, dtype=torch.float64, device=dev)
+    status = torch.zeros(J, dtype=torch.int32, device=dev)
+    nb = L.rvs_chisq_point_work_size(npoly, J)
+    scratch = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+    for ia, arm in enumerate(batch.arms):
+        lib = libs[arm.name]
+        work = arm.work(lib, espec_sys)
+        polysT = arm.basis(npoly, rbf)
+        o = outsides[ia]
+        if job_templ is not None:
+            o = o[job_templ.long()]
+        pen = o * float(batch.badchi) if outside_penalty else torch.where(
+            torch.isfinite(o), torch.zeros_like(o), o)
+        pen = pen.contiguous()
+        coef = coefs[ia]
+        with _ktime('chisq_point', J):
+            rc = L.rvs_chisq_point(
+                _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(arm.spec),
+                _lib.ptr(arm.espec), _lib.ptr(work), arm.npix, npoly, arm.S,
+                _lib.ptr(lib.knots), _lib.ptr(coef), lib.ntp, coef.shape[0],
+                int(lib.log_step), _lib.ptr(job_spec), _lib.ptr(job_templ), J,
+                _lib.ptr(vel), _lib.ptr(pen), float(batch.badchi),
+                float(espec_sys), _lib.ptr(scratch), 0.0 if ia == 0 else 1.0,
+                _lib.ptr(out), _lib.ptr(status), _lib.stream())
+            _lib.check(rc, 'rvs_chisq_point')
+    return out, status
+
+
 _ar_cache = {}
 
 
@@ -400,7 +439,7 @@ def grid_moments(chisq, vels, Np=1, nvel=None, quadratic=True):
     res = torch.empty((G, 8), dtype=torch.float64, device=dev)
     probs = torch.empty((G, Nv), dtype=torch.float64, device=dev)
     status = torch.zeros(G, dtype=torch.int32, device=dev)
-    vels = vels.contiguous()
+    vels = vels.to(torch.float64).contiguous()
     vstride = 0 if vels.dim() == 1 else Nv
     rc = L.rvs_grid_moments(_lib.ptr(chisq.contiguous()), _lib.ptr(vels),
                             vstride, _lib.ptr(nvel), G, Np, Nv, int(quadratic),

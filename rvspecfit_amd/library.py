@@ -111,7 +111,7 @@ class TemplateLibrary:
         """params float64 [J, ndim] (device) -> templ [J, ntp], outside [J]"""
         L = _lib.lib()
         J = params.shape[0]
-        params = params.contiguous()
+        params = params.to(torch.float64).contiguous()
         templ = torch.empty((J, self.ntp), dtype=torch.float64,
                             device=self.device)
         outside = torch.empty(J, dtype=torch.float64, device=self.device)

@@ -281,6 +281,28 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
     return ret
 
 
+def chisq_jobs(batch, idx, vel, params, vsini, options, config,
+               outside_penalty=True, espec_systematic=None):
+    """get_chisq for J jobs: job j is spectrum idx[j] against its own template
+    (params[j], vsini[j]) at velocity vel[j] (rvs_chisq_point: one lane per
+    job, residual norm formed explicitly as in spec_fit.py:249).
+    Returns chisq [J], status [J]."""
+    options = options or {}
+    npoly = options.get('npoly') or 5
+    rbf = options.get('rbf_continuum', True)
+    libs = spec_inter.get_libs(batch.names, config)
+    params = params.contiguous()
+    coefs, outs = [], []
+    for arm in batch.arms:
+        c, o = engine.build_templates(libs[arm.name], params, vsini)
+        coefs.append(c)
+        outs.append(o)
+    esys = float(espec_systematic) if espec_systematic is not None else 0.0
+    return engine.chisq_point(batch, libs, coefs, outs, vel, npoly=npoly,
+                              rbf=rbf, job_spec=idx.to(torch.int32).contiguous(),
+                              espec_sys=esys, outside_penalty=outside_penalty)
+
+
 def chisq_grid_jobs(batch, vel_grid, params, vsini, options, config,
                     outside_penalty=True, espec_systematic=None):
     """chi^2 [S, Np, Nv] for params [S, Np, ndim] (device) on a shared or

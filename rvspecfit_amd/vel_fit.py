@@ -2,12 +2,14 @@
 py/rvspecfit/vel_fit.py: firstguess (:13-94), _minimum_sampler (:358-439),
 _find_best_vel_iterate (:315-355) and the first step of process (:571-602).
 
-The optimiser / Hessian stage of `process` (Nelder-Mead -> BFGS ->
-numdifftools) is outside the accelerated hot path.
+`process` (vel_fit.py:505-737) runs its Nelder-Mead stage as S lock-step
+simplices (neldermead.py) over batched objective evaluations (SURVEY 8(f)
+rank 1); see its docstring for what differs from the reference.
 """
 import itertools
 import logging
 import math
+import time
 
 import numpy as np
 import torch
@@ -173,39 +175,406 @@ def _find_best_vel_iterate(best_vel, min_vel, max_vel, vel_step0, specdata=None,
             float(r['skewness'][0]), float(r['kurtosis'][0]))
 
 
+class VSiniMapper:
+    """vel_fit.VSiniMapper (vel_fit.py:95-116) on tensors"""
+
+    def __init__(self, max_vsini):
+        self.max_vsini = max_vsini
+
+    def to_internal(self, vsini):
+        return torch.clamp(vsini, 0, self.max_vsini)
+
+    def to_vsini(self, x):
+        vsini = torch.clamp(x, 0, self.max_vsini)
+        out = (x < 0) | (x > self.max_vsini)
+        penalty = torch.where(out, (vsini - x)**2, torch.zeros_like(x))
+        return vsini, penalty
+
+
+class ParamMapper:
+    """vel_fit.ParamMapper (vel_fit.py:119-202) for a batch: parameter vectors
+    [J, n] ordered (vel, [vsini], free stellar parameters in specParams order)
+    <-> vel [J], vsini [J] | None, params [J, ndim], penalty [J].
+    paramDict0 values are [S] tensors; `idx` selects the spectra of the J rows."""
+
+    def __init__(self, specParams, paramDict0, fixParam, vsiniMapper,
+                 fitVsini=True):
+        self.specParams = specParams
+        self.paramDict0 = paramDict0
+        self.fixParam = fixParam
+        self.vsiniMapper = vsiniMapper
+        self.fitVsini = fitVsini
+
+    def forward(self, p0, idx):
+        ret = {}
+        k = 0
+        ret['vel'] = p0[:, k]
+        k += 1
+        penalty = torch.zeros_like(ret['vel'])
+        if self.fitVsini:
+            vsini, pen = self.vsiniMapper.to_vsini(p0[:, k])
+            k += 1
+            penalty = penalty + pen
+            ret['vsini'] = vsini
+        elif 'vsini' in self.fixParam:
+            ret['vsini'] = self.paramDict0['vsini'][idx]
+        else:
+            ret['vsini'] = None
+        cols = []
+        for x in self.specParams:
+            if x in self.fixParam:
+                cols.append(self.paramDict0[x][idx])
+            else:
+                cols.append(p0[:, k])
+                k += 1
+        assert k == p0.shape[1]
+        ret['params'] = torch.stack(cols, dim=1)
+        ret['penalty'] = penalty
+        return ret
+
+    def get_fitted_params(self):
+        ret = ['vel']
+        if self.fitVsini:
+            ret.append('vsini')
+        for x in self.specParams:
+            if x not in self.fixParam:
+                ret.append(x)
+        return ret
+
+
+def get_hess_inv(param_names):
+    """vel_fit.get_hess_inv (vel_fit.py:442-461)"""
+    diag = np.zeros(len(param_names)) + 0.1**2
+    names = np.asarray(param_names)
+    diag[np.nonzero(names == 'teff')[0][0]] = 50**2
+    vi = np.nonzero(names == 'vsini')[0]
+    if len(vi) == 1:
+        diag[vi] = 5**2
+    diag[0] = 1**2
+    return np.diag(diag)
+
+
+def _uncertainties_from_hessian(hessian):
+    """vel_fit._uncertainties_from_hessian (vel_fit.py:464-502), one matrix"""
+    diag_hessian = np.diag(hessian)
+    with np.errstate(all='ignore'):
+        inv_diag_hessian = 1. / (diag_hessian + (diag_hessian == 0))
+    inv_diag_hessian[diag_hessian == 0] = np.inf
+    bad_hessian = False
+    try:
+        if not np.isfinite(hessian).all():
+            raise ValueError('non finite Hessian')  # scipy.linalg.inv check_finite
+        hessian_inv = np.linalg.inv(hessian)
+    except (np.linalg.LinAlgError, ValueError):
+        bad_hessian = True
+        hessian_inv = np.diag(inv_diag_hessian)
+    diag_err0 = np.array(np.diag(hessian_inv))
+    diag_err1 = inv_diag_hessian
+    bad_err0 = diag_err0 < 0
+    bad_err1 = diag_err1 < 0
+    if bad_err0.any():
+        bad_hessian = True
+    sub1 = bad_err0 & (~bad_err1)
+    sub2 = bad_err0 & bad_err1
+    diag_err0[sub1] = diag_err1[sub1]
+    diag_err0[sub2] = 0
+    with np.errstate(all='ignore'):
+        diag_err = np.sqrt(diag_err0)
+    diag_err[sub2] = np.nan
+    if (~np.isfinite(diag_err)).sum() != 0:
+        bad_hessian = True
+    return diag_err, hessian_inv, bad_hessian
+
+
+_SIMPLEX_STD = {'logg': 0.5, 'teff': 300, 'feh': 0.5, 'alpha': 0.25}
+HESS_BASE_STEP = {'vsini': 1 / 100, 'logg': 0.1 / 100, 'feh': 0.1 / 100,
+                  'alpha': .01 / 100, 'teff': 1 / 100, 'vrad': 1 / 100}
+
+
+def _get_simplex_start(best_vel, fixParam, specParamNames, paramDict0,
+                       vsiniMapper, fitVsini):
+    """vel_fit._get_simplex_start (vel_fit.py:272-312) for [S] starting points:
+    the same deterministic RandomState(43434) displacement pattern for every
+    spectrum."""
+    cols = [best_vel]
+    std_vec = [5]
+    if fitVsini:
+        cols.append(vsiniMapper.to_internal(paramDict0['vsini']))
+        std_vec.append(3)
+    for x in specParamNames:
+        if x not in fixParam:
+            cols.append(paramDict0[x])
+            std_vec.append(_SIMPLEX_STD.get(x) or 0.5)
+    curval = torch.stack(cols, dim=1)
+    ndim = curval.shape[1]
+    R = np.random.RandomState(43434)
+    disp = np.array(std_vec)[None, :] * R.normal(size=(ndim, ndim))
+    simp = curval[:, None, :].repeat(1, ndim + 1, 1)
+    simp[:, 1:, :] = curval[:, None, :] + torch.as_tensor(disp).to(curval.device)
+    return curval, simp
+
+
+class _Objective:
+    """chisq_func / chisq_func0 (vel_fit.py:205-254) for J jobs at a time."""
+
+    def __init__(self, batch, mapper, config, options, priors):
+        self.batch, self.mapper = batch, mapper
+        self.config, self.options, self.priors = config, options, priors
+        self.min_vel, self.max_vel = config['min_vel'], config['max_vel']
+        self.status = torch.zeros(batch.S, dtype=torch.int32,
+                                  device=batch.device)
+        self.nfev = 0
+
+    def chisq0(self, idx, vel, params, vsini):
+        chisq = torch.zeros_like(vel)
+        if self.priors is not None:
+            for i, k in enumerate(self.mapper.specParams):
+                if k in self.priors:
+                    m, sg = self.priors[k]
+                    m = m[idx] if isinstance(m, torch.Tensor) else m
+                    sg = sg[idx] if isinstance(sg, torch.Tensor) else sg
+                    chisq = chisq + ((m - params[:, i]) / sg)**2
+        c, st = spec_fit.chisq_jobs(self.batch, idx, vel, params, vsini,
+                                    self.options, self.config)
+        self.status[idx] |= st
+        self.nfev += idx.numel()
+        return chisq + c
+
+    def __call__(self, idx, p):
+        pd = self.mapper.forward(p, idx)
+        vel, params = pd['vel'], pd['params']
+        bad = (vel > self.max_vel) | (vel < self.min_vel) | \
+            (~torch.isfinite(params)).any(dim=1)
+        # rows that the reference answers with 1e30 without evaluating are
+        # evaluated at a harmless point and overwritten
+        velc = torch.where(bad, torch.zeros_like(vel), vel)
+        parc = torch.where(bad[:, None], self.safe_params[idx], params)
+        ret = self.chisq0(idx, velc, parc, pd['vsini']) + pd['penalty']
+        return torch.where(bad, torch.full_like(ret, 1e30), ret)
+
+
+def _hessian_central(func, x, h):
+    """Central second differences of func at x [S, n] with steps h [S, n]
+    (numdifftools' 'central' Hessian rule, eq. 9 of its documentation:
+    H_ii = (f(x+2h_i) - 2f(x) + f(x-2h_i)) / (4 h_i^2),
+    H_ij = (f(++) - f(+-) - f(-+) + f(--)) / (4 h_i h_j)); one step size."""
+    S, n = x.shape
+    dev = x.device
+    idx = torch.arange(S, device=dev)
+    fx = func(idx, x)
+    H = torch.empty((S, n, n), dtype=torch.float64, device=dev)
+    for i in range(n):
+        ei = torch.zeros_like(x)
+        ei[:, i] = h[:, i]
+        H[:, i, i] = (func(idx, x + 2 * ei) - 2 * fx + func(idx, x - 2 * ei)) / \
+            (4. * h[:, i] * h[:, i])
+        for j in range(i + 1, n):
+            ej = torch.zeros_like(x)
+            ej[:, j] = h[:, j]
+            v = (func(idx, x + ei + ej) - func(idx, x + ei - ej) -
+                 func(idx, x - ei + ej) + func(idx, x - ei - ej)) / \
+                (4. * h[:, i] * h[:, j])
+            H[:, i, j] = v
+            H[:, j, i] = v
+    return H
+
+
+def _as_param_tensors(paramDict0, S, dev):
+    out = {}
+    for k, v in paramDict0.items():
+        if isinstance(v, torch.Tensor):
+            t = v.to(dev, torch.float64).reshape(-1)
+        else:
+            t = torch.as_tensor(np.asarray(v, dtype=np.float64)).to(dev
+                                                                     ).reshape(-1)
+        out[k] = t.expand(S).contiguous() if t.numel() == 1 else t.contiguous()
+        assert out[k].shape[0] == S
+    return out
+
+
 def process(specdata, paramDict0, fixParam=None, options=None, config=None,
-            resolParams=None, priors=None):
-    """Only the grid-driven first stage of vel_fit.process is accelerated
-    (vel_fit.py:571-602: find_best over arange(min_vel, max_vel, vel_step0) at
-    the starting parameters) followed by the velocity refinement
-    (vel_fit.py:672) and the full-output evaluation (:689).  The Nelder-Mead /
-    BFGS / Hessian stage is SURVEY 8(f) rank 1 and is NOT run: parameters are
-    returned as given."""
+            resolParams=None, priors=None, timers=None):
+    """vel_fit.process (vel_fit.py:505-737): velocity grid at the starting
+    parameters -> Nelder-Mead (deterministic start simplex, fatol 1e-3, xatol
+    1e-2, up to two runs) -> [BFGS] -> velocity refinement -> full output ->
+    finite-difference Hessian -> parameter uncertainties.
+
+    One spectrum (list of SpecData) returns the reference's dict.  A SpecBatch
+    (paramDict0 values scalars or [S] arrays) returns [S]-leading device
+    tensors; the S optimisers advance in lock-step (neldermead.minimize), every
+    objective evaluation is one batched template build + chi^2 launch set.
+
+    Deviations, all flagged in the result:
+    * `second_minimizer` (BFGS on a forward-difference gradient whose step,
+      1.5e-8, is below the rounding noise of chi^2) is not run:
+      ret['second_minimizer_run'] = False;
+    * numdifftools is replaced by its central-difference rule at ONE step,
+      base_step * max(log1p|x|, 1) (numdifftools is absent from the build
+      image: parity of param_err is unpinned)."""
+    from . import neldermead
     if config is None:
         raise RuntimeError('Config must be provided')
+    if resolParams is not None:
+        raise NotImplementedError('resolution matrices: SURVEY 8(f) rank 4')
     options = options or {}
     batch, is_batch = as_batch(specdata)
-    if is_batch:
-        raise NotImplementedError('use pipeline.fit_batch for batches')
+    S, dev = batch.S, batch.device
+    min_vel, max_vel = config['min_vel'], config['max_vel']
+    vel_step0 = config['vel_step0']
+    max_vsini = config['max_vsini']
+    min_vel_step = config['min_vel_step']
+    fixParam = list(fixParam) if fixParam is not None else []
     names = spec_inter.getSpecParams(batch.names[0], config)
-    curparam = tuple(paramDict0[_] for _ in names)
-    rot = (paramDict0['vsini'], ) if 'vsini' in paramDict0 else None
-    vg = np.arange(config['min_vel'], config['max_vel'], config['vel_step0'])
-    res = spec_fit.find_best(specdata, vg, [curparam], rot_params=rot,
-                             config=config, options=options)
-    bv, be, sk, ku = _find_best_vel_iterate(
-        res['best_vel'], config['min_vel'], config['max_vel'],
-        config['vel_step0'], specdata=specdata,
-        best_param=dict(params=curparam, rot_params=rot), config=config,
-        options=options, min_vel_step=config['min_vel_step'])
-    outp = spec_fit.get_chisq(specdata, bv, curparam, rot, options=options,
-                              config=config, full_output=True)
-    ret = dict(param=dict(zip(names, curparam)), vel=bv, vel_err=be,
-               vel_skewness=sk, vel_kurtosis=ku, yfit=outp['models'],
-               raw_models=outp['raw_models'], chisq=outp['chisq'],
-               logl=outp['logl'], chisq_array=outp['chisq_array'],
-               npix_array=outp['npix_array'], minimize_success=False,
-               optimizer_run=False)
-    if rot is not None:
-        ret['vsini'] = rot[0]
+    pd0 = _as_param_tensors(paramDict0, S, dev)
+    curparam = torch.stack([pd0[_] for _ in names], dim=1)
+    vsiniMapper = None
+    if 'vsini' not in pd0:
+        vsini0, fitVsini = None, False
+    else:
+        vsini0 = pd0['vsini']
+        fitVsini = 'vsini' not in fixParam
+        if fitVsini:
+            vsiniMapper = VSiniMapper(max_vsini)
+    tm = timers if timers is not None else {}
+
+    def _tick(k, t0):
+        if str(dev).startswith('cuda'):
+            torch.cuda.synchronize()
+        tm[k] = tm.get(k, 0.) + time.time() - t0
+
+    # vel_fit.py:596-602
+    t0 = time.time()
+    vg = torch.as_tensor(np.arange(min_vel, max_vel, vel_step0,
+                                   dtype=np.float64)).to(dev)
+    chisq, st0, _ = spec_fit.chisq_grid_jobs(batch, vg, curparam[:, None, :],
+                                             vsini0, options, config)
+    res, _, mst = engine.grid_moments(chisq.reshape(S, -1), vg, Np=1)
+    best_vel = res[:, 1].contiguous()
+    _tick('grid0', t0)
+
+    t0 = time.time()
+    curval, simplex = _get_simplex_start(best_vel, fixParam, names, pd0,
+                                         vsiniMapper, fitVsini)
+    mapper = ParamMapper(names, pd0, fixParam, vsiniMapper, fitVsini=fitVsini)
+    obj = _Objective(batch, mapper, config, options, priors)
+    obj.safe_params = curparam
+    stats = {}
+    # vel_fit.py:624-649: a second run restarts from the final simplex
+    nm = neldermead.minimize(obj, simplex, fatol=1e-3, xatol=1e-2,
+                             maxiter=10000, stats=stats)
+    success = nm['success']
+    x, nit, nfev = nm['x'], nm['nit'], nm['nfev']
+    redo = torch.nonzero(~success).reshape(-1)
+    if redo.numel():
+        nm2 = neldermead.minimize(lambda i, p: obj(redo[i], p),
+                                  nm['final_simplex'][0][redo], fatol=1e-3,
+                                  xatol=1e-2, maxiter=10000, stats=stats)
+        x[redo] = nm2['x']
+        success[redo] = nm2['success']
+        nit[redo] += nm2['nit']
+        nfev[redo] += nm2['nfev']
+    _tick('neldermead', t0)
+
+    allidx = torch.arange(S, device=dev)
+    best = mapper.forward(x, allidx)
+    nm_vel = best['vel'].contiguous()
+    bparams = best['params'].contiguous()
+    bvsini = best['vsini']
+
+    # vel_fit.py:672-682
+    t0 = time.time()
+    vel_in = nm_vel.cpu().numpy()
+    r = _minimum_sampler_batch(batch, vel_in, bparams, bvsini, config, options)
+    best_vel = torch.as_tensor(r['best_vel']).to(dev)
+    _tick('vel_refine', t0)
+
+    # vel_fit.py:689-696
+    t0 = time.time()
+    outp = spec_fit.get_chisq(batch, best_vel, bparams,
+                              None if bvsini is None else bvsini,
+                              options=options, config=config, full_output=True)
+    _tick('full_output', t0)
+
+    # vel_fit.py:699-725: Hessian of 0.5*chisq_func0 in ALL stellar parameters
+    # at the optimiser's velocity (best_param is not updated by the refinement)
+    t0 = time.time()
+
+    def hess_func(idx, p):
+        return 0.5 * obj.chisq0(idx, nm_vel[idx], p.contiguous(),
+                                None if bvsini is None else bvsini[idx])
+
+    base = torch.as_tensor([HESS_BASE_STEP[_] for _ in names],
+                           dtype=torch.float64, device=dev)
+    bad_hessian = np.zeros(S, dtype=bool)
+    diag_err = np.zeros((S, len(names)))
+    covar = np.zeros((S, len(names), len(names)))
+    todo = np.arange(S)
+    for attempt in range(2):
+        if len(todo) == 0:
+            break
+        tt = torch.as_tensor(todo).to(dev)
+        xx = bparams[tt]
+        scale = 1.0 if attempt == 0 else 8.0
+        h = scale * base[None, :] * torch.clamp(torch.log1p(xx.abs()), min=1.0)
+        H = _hessian_central(lambda i, p: hess_func(tt[i], p), xx, h
+                             ).cpu().numpy()
+        for k, i in enumerate(todo):
+            diag_err[i], covar[i], bad_hessian[i] = \
+                _uncertainties_from_hessian(H[k])
+        todo = todo[bad_hessian[todo]]
+    _tick('hessian', t0)
+
+    ret = {}
+    if is_batch:
+        ret['param'] = {k: bparams[:, i] for i, k in enumerate(names)}
+        if fitVsini:
+            ret['vsini'] = bvsini
+        ret['vel'] = best_vel
+        ret['vel_err'] = torch.as_tensor(r['vel_err']).to(dev)
+        ret['vel_skewness'] = torch.as_tensor(r['skewness']).to(dev)
+        ret['vel_kurtosis'] = torch.as_tensor(r['kurtosis']).to(dev)
+        ret['param_err'] = {k: diag_err[:, i] for i, k in enumerate(names)}
+        ret['param_covar'] = covar
+        ret['minimize_success'] = success
+        ret['bad_hessian'] = bad_hessian
+        ret['yfit'] = outp['models']
+        ret['raw_models'] = outp['raw_models']
+        ret['chisq'] = outp['chisq']
+        ret['logl'] = outp['logl']
+        ret['chisq_array'] = outp['chisq_array']
+        ret['npix_array'] = outp['npix_array']
+        ret['status'] = obj.status | outp['status'] | st0.reshape(S, -1)[:, 0]
+    else:
+        if int(obj.status[0].item()) & _lib_nonfinite():
+            raise RuntimeError('non-finite likelihood during the optimisation')
+        bp = bparams[0].cpu().numpy()
+        ret['param'] = dict(zip(names, [float(_) for _ in bp]))
+        if fitVsini:
+            ret['vsini'] = float(bvsini[0].item())
+        ret['vel'] = float(r['best_vel'][0])
+        ret['vel_err'] = float(r['vel_err'][0])
+        ret['vel_skewness'] = float(r['skewness'][0])
+        ret['vel_kurtosis'] = float(r['kurtosis'][0])
+        ret['param_err'] = dict(zip(names, diag_err[0]))
+        ret['param_covar'] = covar[0]
+        ret['minimize_success'] = bool(success[0].item())
+        ret['bad_hessian'] = bool(bad_hessian[0])
+        ret['yfit'] = [m[0].cpu().numpy() for m in outp['models']]
+        ret['raw_models'] = [m[0].cpu().numpy() for m in outp['raw_models']]
+        ret['chisq'] = float(outp['chisq'][0].item())
+        ret['logl'] = -0.5 * ret['chisq']
+        ret['chisq_array'] = [float(_) for _ in outp['chisq_array'][0]]
+        ret['npix_array'] = [int(_) for _ in outp['npix_array'][0]]
+    ret['nm_vel'] = nm_vel if is_batch else float(nm_vel[0].item())
+    ret['nm_nit'] = nit if is_batch else int(nit[0].item())
+    ret['nm_nfev'] = nfev if is_batch else int(nfev[0].item())
+    ret['nm_rounds'] = stats.get('rounds', 0)
+    ret['objective_evals'] = obj.nfev
+    ret['second_minimizer_run'] = False
+    ret['optimizer_run'] = True
     return ret
+
+
+def _lib_nonfinite():
+    from . import _lib
+    return _lib.ST_NONFINITE

@@ -463,3 +463,135 @@ def test_nn_template_desi_size_vs_oracle(gpu):
     W = [(d['W%d' % i], d['b%d' % i]) for i in range(5)]
     ref = orc.nn_forward(W, P, d['M'], d['S'])
     np.testing.assert_allclose(templ.cpu().numpy(), ref, rtol=5e-6)
+
+
+# --------------------------------------------------------------------------
+# vel_fit.process (Nelder-Mead in lock-step + Hessian)
+# --------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def pcases():
+    return dict(np.load(os.path.join(GOLD, 'process_cases.npz')))
+
+
+def _process_args(g, t):
+    pd0 = dict(zip([str(_) for _ in g[t + '/start_keys']],
+                   [float(_) for _ in g[t + '/start_vals']]))
+    fix = [str(_) for _ in g[t + '/fix']]
+    pri = None
+    if t + '/prior_keys' in g:
+        pri = {str(k): tuple(v) for k, v in zip(g[t + '/prior_keys'],
+                                                g[t + '/prior_vals'])}
+    return pd0, fix, pri
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_chisq_point_golden(cases, config, tag):
+    """rvs_chisq_point (the optimiser's objective, one lane per job) against the
+    reference's get_chisq values, all trials of a case in ONE call"""
+    from rvspecfit_amd import spec_fit
+    sds = _sds(cases, tag)
+    b, _ = spec_fit.as_batch(sds)
+    for npoly, rbf in ((10, True), (15, True), (5, True), (7, False)):
+        sel = [i for i in range(7)
+               if int(cases['%s/chisq/t%d/npoly' % (tag, i)]) == npoly and
+               bool(cases['%s/chisq/t%d/rbf' % (tag, i)]) == rbf]
+        for with_rot in (False, True):
+            ii = [i for i in sel if np.isfinite(
+                cases['%s/chisq/t%d/vsini' % (tag, i)]) == with_rot]
+            if not ii:
+                continue
+            vel = torch.as_tensor([float(cases['%s/chisq/t%d/vel' % (tag, i)])
+                                   for i in ii], dtype=torch.float64).to('cuda')
+            par = torch.as_tensor(np.array(
+                [cases['%s/chisq/t%d/param' % (tag, i)] for i in ii])).to('cuda')
+            vs = None
+            if with_rot:
+                vs = torch.as_tensor([float(
+                    cases['%s/chisq/t%d/vsini' % (tag, i)]) for i in ii],
+                    dtype=torch.float64).to('cuda')
+            idx = torch.zeros(len(ii), dtype=torch.long, device='cuda')
+            with np.errstate(all='ignore'):
+                c, st = spec_fit.chisq_jobs(
+                    b, idx, vel, par, vs, dict(npoly=npoly, rbf_continuum=rbf),
+                    config)
+            for k, i in enumerate(ii):
+                want = float(cases['%s/chisq/t%d/value' % (tag, i)])
+                assert abs(c[k].item() / want - 1) < 1e-6, (i, c[k].item(), want)
+
+
+@pytest.mark.parametrize('t', ['p0', 'p1', 'p2', 'p3'])
+def test_process_golden(cases, pcases, config, t):
+    """vel_fit.process against the reference's own run (scipy Nelder-Mead on the
+    reference's chisq_func).  Nelder-Mead amplifies rounding differences of the
+    objective into different (equally valid) paths, so the end points are
+    compared at the optimiser's own tolerances (xatol 1e-2, fatol 1e-3), the
+    velocity and chi^2 at the contract's (0.01 km/s, 1e-6)."""
+    from rvspecfit_amd import vel_fit
+    g = pcases
+    sds = _sds(cases, str(g[t + '/case']))
+    pd0, fix, pri = _process_args(g, t)
+    cfg = dict(config)
+    cfg['second_minimizer'] = False
+    r = vel_fit.process(sds, pd0, fixParam=fix, options=dict(npoly=10),
+                        config=cfg, priors=pri)
+    assert r['minimize_success'] == bool(g[t + '/minimize_success'])
+    assert abs(r['vel'] - g[t + '/vel']) < 0.01
+    assert abs(r['vel_err'] / g[t + '/vel_err'] - 1) < 1e-2
+    assert abs(r['chisq'] - g[t + '/chisq']) < 2e-3   # fatol-level
+    assert abs(r['chisq'] / g[t + '/chisq'] - 1) < 1e-6
+    names = ['teff', 'logg', 'feh', 'alpha']
+    got = np.array([r['param'][_] for _ in names])
+    err = g[t + '/param_err']
+    ok = np.isfinite(err) & (err > 0)
+    # well inside the 1-sigma uncertainty of every parameter
+    assert np.all(np.abs(got - g[t + '/param'])[ok] < 0.02 * err[ok] + 1e-9)
+    if np.isfinite(g[t + '/vsini']):
+        assert abs(r['vsini'] - g[t + '/vsini']) < 0.05
+    assert r['npix_array'] == [int(_) for _ in g[t + '/npix_array']]
+    np.testing.assert_allclose(r['chisq_array'], g[t + '/chisq_array'],
+                               rtol=1e-5)
+    # Hessian rule: same stand-in as the golden harness (parity unpinned wrt
+    # numdifftools); finite differences of a 1e-9-noisy function: 2 %
+    assert r['bad_hessian'] == bool(g[t + '/bad_hessian'])
+    gerr = np.array([r['param_err'][_] for _ in names])
+    np.testing.assert_allclose(gerr[ok], err[ok], rtol=2e-2)
+
+
+def test_process_nm_path_vs_oracle(cases, pcases, config, gold_libs,
+                                   gold_config):
+    """with the same (Cholesky) arithmetic as the C oracle the lock-step
+    simplex follows scipy's path iteration for iteration on a 2-arm case"""
+    from rvspecfit_amd import vel_fit
+    g = pcases
+    sds = _sds(cases, 'c1')
+    pd0, fix, pri = _process_args(g, 'p1')
+    cfg = dict(config)
+    r = vel_fit.process(sds, pd0, fixParam=fix, options=dict(npoly=10),
+                        config=cfg, priors=pri)
+    o = orc.process(gold_specdata(cases, 'c1', orc.SpecData), pd0, fix,
+                    dict(npoly=10), gold_config, gold_libs, priors=pri)
+    assert abs(r['nm_nit'] - o['nm_nit'][0]) <= 0.2 * o['nm_nit'][0]
+    assert abs(r['vel'] - o['vel']) < 1e-3
+    assert abs(r['chisq'] - o['chisq']) < 2e-3
+
+
+def test_process_batch_equals_singles(cases, pcases, config):
+    from rvspecfit_amd import vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    lists = [_sds(cases, t) for t in ('c1', 'c3')]
+    starts = [dict(teff=6000., logg=2., feh=-0.5, alpha=0.2, vsini=5.),
+              dict(teff=6500., logg=2.5, feh=-0.4, alpha=0.1, vsini=20.)]
+    cfg = dict(config)
+    pd0 = {k: np.array([s[k] for s in starts]) for k in starts[0]}
+    rb = vel_fit.process(SpecBatch.from_specdata(lists), pd0,
+                         options=dict(npoly=10), config=cfg)
+    for i, (sl, st) in enumerate(zip(lists, starts)):
+        r1 = vel_fit.process(sl, st, options=dict(npoly=10), config=cfg)
+        assert r1['nm_nit'] == int(rb['nm_nit'][i])
+        assert r1['vel'] == float(rb['vel'][i])
+        assert r1['chisq'] == float(rb['chisq'][i])
+        assert r1['param']['teff'] == float(rb['param']['teff'][i])
+        assert r1['vsini'] == float(rb['vsini'][i])
+        np.testing.assert_array_equal(
+            [r1['param_err'][k] for k in ('teff', 'logg', 'feh', 'alpha')],
+            [rb['param_err'][k][i] for k in ('teff', 'logg', 'feh', 'alpha')])

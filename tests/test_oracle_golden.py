@@ -276,3 +276,38 @@ def test_nn_forward_vs_reference_golden():
     out = orc.nn_forward(W, d['params'], d['M'], d['S'])
     # float32 network: summation order of the matmuls differs (BLAS vs torch)
     np.testing.assert_allclose(out, d['out'], rtol=2e-6)
+
+
+# --------------------------------------------------------------------------
+# vel_fit.process
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('t', ['p0', 'p1', 'p2', 'p3'])
+def test_process_oracle_vs_reference(cases, gold_libs, gold_config, t):
+    """the oracle's process (scipy Nelder-Mead on the oracle's get_chisq) lands
+    where the reference's own run did; param_err uses the same stand-in Hessian
+    rule as the golden harness (numdifftools absent: unpinned)"""
+    import os
+    from conftest import GOLD
+    g = np.load(os.path.join(GOLD, 'process_cases.npz'))
+    sds = gold_specdata(cases, str(g[t + '/case']), orc.SpecData)
+    pd0 = dict(zip([str(_) for _ in g[t + '/start_keys']],
+                   [float(_) for _ in g[t + '/start_vals']]))
+    fix = [str(_) for _ in g[t + '/fix']]
+    pri = None
+    if t + '/prior_keys' in g:
+        pri = {str(k): tuple(v) for k, v in zip(g[t + '/prior_keys'],
+                                                g[t + '/prior_vals'])}
+    r = orc.process(sds, pd0, fix, dict(npoly=10), gold_config, gold_libs,
+                    priors=pri)
+    assert abs(r['nm_nit'][-1] - int(g[t + '/nm_nit'][-1])) <= 5
+    assert abs(r['vel'] - g[t + '/vel']) < 1e-4
+    assert abs(r['chisq'] - g[t + '/chisq']) < 1e-6
+    assert abs(r['vel_err'] / g[t + '/vel_err'] - 1) < 1e-5
+    err = g[t + '/param_err']
+    ok = np.isfinite(err) & (err > 0)
+    got = np.array(list(r['param'].values()))
+    assert np.all(np.abs(got - g[t + '/param'])[ok] < 1e-3 * err[ok] + 1e-9)
+    gerr = np.array(list(r['param_err'].values()))
+    np.testing.assert_allclose(gerr[ok], err[ok], rtol=1e-3)
+    assert r['bad_hessian'] == bool(g[t + '/bad_hessian'])
+    assert r['minimize_success'] == bool(g[t + '/minimize_success'])

@@ -84,3 +84,39 @@ def test_convert_artefacts_reproduces_reference_loader(tmp_path):
             assert np.array_equal(x, y), k
         else:
             np.testing.assert_array_equal(x, y, err_msg=k)
+
+
+def test_lockstep_neldermead_equals_scipy():
+    """rvspecfit_amd.neldermead follows scipy's Nelder-Mead (the optimiser of
+    vel_fit.py:627-637) iteration for iteration: same nit, nfev, final simplex"""
+    import scipy.optimize as so
+    import torch
+    from rvspecfit_amd import neldermead as nm
+    rng = np.random.RandomState(1)
+    S, N = 24, 6
+    A = rng.normal(size=(S, N, N))
+    A = np.einsum('sij,skj->sik', A, A) + np.eye(N)
+    c = rng.normal(size=(S, N))
+
+    def f1(i, x):
+        d = x - c[i]
+        return d @ A[i] @ d + 0.3 * np.sum(np.abs(d)**1.5) + \
+            (1e30 if x[0] > 5 else 0)
+
+    def fb(idx, X):
+        return torch.as_tensor(np.array(
+            [f1(int(i), x) for i, x in zip(idx.numpy(), X.numpy())]))
+
+    simp = rng.normal(size=(S, N + 1, N)) * 2
+    for maxiter in (10000, 30):
+        r = nm.minimize(fb, torch.as_tensor(simp), maxiter=maxiter)
+        for i in range(S):
+            q = so.minimize(lambda x: f1(i, x), simp[i, 0], method='Nelder-Mead',
+                            options=dict(fatol=1e-3, xatol=1e-2,
+                                         initial_simplex=simp[i],
+                                         maxiter=maxiter, maxfev=np.inf))
+            assert q.nit == int(r['nit'][i]) and q.nfev == int(r['nfev'][i])
+            assert q.success == bool(r['success'][i])
+            np.testing.assert_array_equal(q.final_simplex[0],
+                                          r['final_simplex'][0][i].numpy())
+            np.testing.assert_array_equal(q.x, r['x'][i].numpy())

@@ -93,7 +93,11 @@ int rvs_vsini_convolve(const double *templ, const double *vsini,
  *     exactly as the reference (i < ntp-1; row ntp-1 is zero padding; h is
  *     implied by knots).  form 1: the SAME cubic in powers of dl = x - x_i,
  *     {y_i, b, c, d} with S = y + dl (b + dl (c + dl d)) -- 3 fma per evaluation,
- *     the form the fused chi^2 kernels consume.
+ *     the form the fused chi^2 kernels consume.  form | 2: the caller asserts
+ *     that neighbouring knot spacings agree to ~1 % (uniform or log-uniform
+ *     grids, what `evaler` requires anyway): both Thomas recurrences then
+ *     contract by ~0.27 per row and are evaluated in independent 40-row-overlap
+ *     windows (error < 1e-22 relative) instead of by exact chunk carries.
  * ---------------------------------------------------------------------- */
 int rvs_spline_construct(const double *knots, const double *ys, int ntp, int B,
                          int form, double *coef, void *stream);
@@ -190,23 +194,28 @@ int rvs_chisq_continuum(const double *polysT, const double *spec,
 /* ------------------------------------------------------------------------
  * A11 at one velocity per job: the objective of the optimiser stage,
  * chisq_func0 (vel_fit.py:205-226) = get_chisq (spec_fit.py:797-989) for J
- * (spectrum, template, velocity) triples.  One lane per job, one wave per pixel
- * slice; the residual norm ||D - a.ST||^2 is formed explicitly (spec_fit.py:249)
- * so the value can be finite-differenced (Hessian, vel_fit.py:699-725).
- * polysT is the plain get_basis matrix; coef is form-1 (power form);
- * work is the rvs_chisq_prepare buffer of this (arm, template grid);
- * scratch: rvs_chisq_point_work_size(npoly, J) bytes;
- * out[j] = beta*out[j] + chisq + penalty[j] (NaN penalty -> + 1000*badchi).
+ * (spectrum, template, velocity) triples, ALL arms of the spectrum in one
+ * launch set.  One lane per job, one wave per (pixel slice, arm); the residual
+ * norm ||D - a.ST||^2 is formed explicitly (spec_fit.py:249) so the value can
+ * be finite-differenced (Hessian, vel_fit.py:699-725).
+ * Per arm (plain struct of device pointers, passed by value from the host):
+ *   lam [npix], polysT [npix, npoly] (plain get_basis, NOT orthonormalised),
+ *   spec, espec [S, npix], work = the rvs_chisq_prepare buffer of the arm,
+ *   knots [ntp], coef [Tn, ntp, 4] form-1 records, penalty [J] (nullable;
+ *   a NaN/inf entry means "template unusable": + 1000*badchi, arm skipped).
+ * scratch: rvs_chisq_point_work_size(npoly, J, narm) bytes.
+ * out[j] = sum over arms of (chisq + penalty).
  * ---------------------------------------------------------------------- */
-int64_t rvs_chisq_point_work_size(int npoly, int J);
-int rvs_chisq_point(const double *lam, const double *polysT, const double *spec,
-                    const double *espec, const double *work, int npix,
-                    int npoly, int S, const double *knots, const double *coef,
-                    int ntp, int Tn, int log_step, const int32_t *job_spec,
-                    const int32_t *job_templ, int J, const double *vel,
-                    const double *penalty, double badchi, double espec_sys,
-                    void *scratch, double beta, double *out, int32_t *status,
-                    void *stream);
+#define RVS_MAX_ARMS 4
+typedef struct rvs_point_arm {
+  const double *lam, *polysT, *spec, *espec, *work, *knots, *coef, *penalty;
+  int32_t npix, S, ntp, log_step;
+} rvs_point_arm;
+int64_t rvs_chisq_point_work_size(int npoly, int J, int narm);
+int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
+                    const int32_t *job_spec, const int32_t *job_templ, int J,
+                    const double *vel, double badchi, double espec_sys,
+                    void *scratch, double *out, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------
  * A12  grid summary; replaces the tail of spec_fit.find_best

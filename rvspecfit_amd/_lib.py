@@ -34,9 +34,8 @@ SIGNATURES = {
                            P, D, P, P, P, P, P, P, P, P]),
     'rvs_chisq_continuum_work_size': (L, [I, I]),
     'rvs_chisq_continuum': (I, [P, P, P, P, I, I, I, P, P, P, P, P, P]),
-    'rvs_chisq_point_work_size': (L, [I, I]),
-    'rvs_chisq_point': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, P, P, I, P, P,
-                             D, D, P, D, P, P, P]),
+    'rvs_chisq_point_work_size': (L, [I, I, I]),
+    'rvs_chisq_point': (I, [P, I, I, P, P, I, P, D, D, P, P, P, P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),
@@ -70,6 +69,14 @@ def lib():
             fn.argtypes = args
         _lib = L_
     return _lib
+
+
+class PointArm(ctypes.Structure):
+    """rvs_point_arm of include/rvsgpu.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ('lam', 'polysT', 'spec', 'espec', 'work', 'knots', 'coef',
+                 'penalty')] + [(k, ctypes.c_int32) for k in
+                                ('npix', 'S', 'ntp', 'log_step')]
 
 
 def ptr(t):

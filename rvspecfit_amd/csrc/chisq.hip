@@ -1020,26 +1020,27 @@ extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
 // ---------------------------------------------------------------------------
 // A11 at ONE velocity per job (the optimiser's objective, vel_fit.py:205-254):
 // one LANE per job (spectrum idx, own template, own velocity), one WAVE per
-// (64 jobs, pixel slice) -- the velocity-grid kernel would run one lane of 64
-// here.  Same three-pass structure as the continuum kernels above; the residual
-// norm is formed explicitly, ||D - a.ST||^2 (spec_fit.py:249), so the value has
-// no D.D - y.y cancellation and can be finite-differenced at any S/N.
-// scratch: part[slice][NV][J], NV = P(P+1)/2 + P, then res[slice][J],
-// then aux[2][J] = {log det, ok}.
+// (64 jobs, pixel slice, arm) -- the velocity-grid kernel would run one lane of
+// 64 here.  All arms of the spectrum go in ONE launch set (grid.z = arm):
+//   normal : per-slice partial normal equations      part[arm][slice][NV][J]
+//   solve  : fold the slices in order, Cholesky, coefficients a[arm][P][J]
+//   resid  : per-slice ||D - a.ST||^2 (formed explicitly, spec_fit.py:249, so
+//            the value has no D.D - y.y cancellation and can be
+//            finite-differenced at any S/N)          res[arm][slice][J]
+//   fold   : slices and arms summed in order, penalties, status.
+// scratch per arm: nsl*NV*J + (P+2)*J + nsl*J doubles, NV = P(P+1)/2 + P.
 // ---------------------------------------------------------------------------
-struct PointTempl {
-  const double *lam, *knots;
-  const double4 *coef;
-  const double *pixa;  // pixel knot coordinates (rvs_chisq_prepare)
-  int ntp, log_step;
+struct PointArms {
+  rvs_point_arm a[RVS_MAX_ARMS];
+  int n;
 };
 
-__device__ __forceinline__ double point_tv(const PointTempl &T,
+__device__ __forceinline__ double point_tv(const rvs_point_arm &T,
                                            const double4 *cf, int k, double f,
                                            double shift, double x0,
                                            double lin_inv_step) {
   const double x = T.lam[k] * f;
-  int pos = T.log_step ? (int)(T.pixa[k] + shift)
+  int pos = T.log_step ? (int)(T.work[k] + shift)
                        : (int)((x - x0) * lin_inv_step);
   pos = min(max(pos, 0), T.ntp - 2);
   const double dl = x - T.knots[pos];
@@ -1047,16 +1048,21 @@ __device__ __forceinline__ double point_tv(const PointTempl &T,
   return fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
 }
 
+__host__ __device__ static inline int64_t point_arm_doubles(int P, int J,
+                                                            int nsl) {
+  const int64_t nv = (int64_t)P * (P + 1) / 2 + P;
+  return (int64_t)nsl * nv * J + (int64_t)(P + 2) * J + (int64_t)nsl * J;
+}
+
 template <int P>
 __global__ void __launch_bounds__(64)
-    point_normal_kernel(PointTempl T, const double *__restrict__ polysT,
-                        const double *__restrict__ spec,
-                        const double *__restrict__ espec, int npix,
-                        const int32_t *__restrict__ job_spec,
+    point_normal_kernel(PointArms A, const int32_t *__restrict__ job_spec,
                         const int32_t *__restrict__ job_templ, int J,
                         const double *__restrict__ vel, double espec_sys,
-                        int nsl, double *__restrict__ part) {
+                        int nsl, double *__restrict__ scratch) {
   constexpr int NT = P * (P + 1) / 2;
+  const rvs_point_arm &T = A.a[blockIdx.z];
+  const int npix = T.npix;
   const int j0 = blockIdx.x * 64 + threadIdx.x;
   const bool active = j0 < J;
   const int j = active ? j0 : J - 1;
@@ -1065,9 +1071,10 @@ __global__ void __launch_bounds__(64)
   const int sl = blockIdx.y;
   const int k0 = (int)((int64_t)npix * sl / nsl);
   const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
-  const double *sp = spec + (int64_t)s * npix;
-  const double *es = espec + (int64_t)s * npix;
-  const double4 *cf = T.coef + (int64_t)t * T.ntp;
+  const double *sp = T.spec + (int64_t)s * npix;
+  const double *es = T.espec + (int64_t)s * npix;
+  const double4 *cf = reinterpret_cast<const double4 *>(T.coef) +
+                      (int64_t)t * T.ntp;
   const double bb = vel[j] / RVS_C_KMS;
   const double f = sqrt((1.0 - bb) / (1.0 + bb));
   const double x0 = T.knots[0];
@@ -1087,7 +1094,7 @@ __global__ void __launch_bounds__(64)
     const double ie = 1.0 / e;
     const double te = tv * ie;
     const double w = te * te, u = te * (sp[k] * ie);
-    const double *pr = polysT + (int64_t)k * P;
+    const double *pr = T.polysT + (int64_t)k * P;
     double pw[P];
 #pragma unroll
     for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
@@ -1100,6 +1107,7 @@ __global__ void __launch_bounds__(64)
     }
   }
   if (!active) return;
+  double *part = scratch + (int64_t)blockIdx.z * point_arm_doubles(P, J, nsl);
   double *o = part + (int64_t)sl * (NT + P) * J + j;
 #pragma unroll
   for (int i = 0; i < NT; i++) o[(int64_t)i * J] = acc[i];
@@ -1107,36 +1115,36 @@ __global__ void __launch_bounds__(64)
   for (int i = 0; i < P; i++) o[(int64_t)(NT + i) * J] = av[i];
 }
 
+// fold + factor + solve: 256 threads = 4 waves per 64 jobs; each wave folds a
+// quarter of the NV values over the slices (in slice order), hands them over
+// through LDS, wave 0 does the in-lane Cholesky and the two triangular solves
 template <int P>
-__global__ void __launch_bounds__(64)
-    point_resid_kernel(PointTempl T, const double *__restrict__ polysT,
-                       const double *__restrict__ spec,
-                       const double *__restrict__ espec, int npix,
-                       const int32_t *__restrict__ job_spec,
-                       const int32_t *__restrict__ job_templ, int J,
-                       const double *__restrict__ vel, double espec_sys,
-                       int nsl, const double *__restrict__ part,
-                       double *__restrict__ res, double *__restrict__ aux) {
+__global__ void __launch_bounds__(256)
+    point_solve_kernel(int J, int nsl, double *__restrict__ scratch) {
   constexpr int NT = P * (P + 1) / 2;
-  const int j0 = blockIdx.x * 64 + threadIdx.x;
+  constexpr int NV = NT + P;
+  __shared__ double sh[NV][65];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * 64 + lane;
   const bool active = j0 < J;
   const int j = active ? j0 : J - 1;
-  const int s = job_spec ? job_spec[j] : j;
-  const int t = job_templ ? job_templ[j] : j;
-  const int sl = blockIdx.y;
+  double *base = scratch + (int64_t)blockIdx.z * point_arm_doubles(P, J, nsl);
+  const double *part = base;
+  double *sol = base + (int64_t)nsl * NV * J;  // [P+2][J]
+  for (int v = w; v < NV; v += 4) {
+    double sum = 0;
+    for (int q = 0; q < nsl; q++)
+      sum += part[((int64_t)q * NV + v) * J + j];
+    sh[v][lane] = sum;
+  }
+  __syncthreads();
+  if (w != 0) return;
   double acc[NT];
   double av[P];
 #pragma unroll
-  for (int i = 0; i < NT; i++) acc[i] = 0;
+  for (int i = 0; i < NT; i++) acc[i] = sh[i][lane];
 #pragma unroll
-  for (int i = 0; i < P; i++) av[i] = 0;
-  for (int q = 0; q < nsl; q++) {
-    const double *o = part + (int64_t)q * (NT + P) * J + j;
-#pragma unroll
-    for (int i = 0; i < NT; i++) acc[i] += o[(int64_t)i * J];
-#pragma unroll
-    for (int i = 0; i < P; i++) av[i] += o[(int64_t)(NT + i) * J];
-  }
+  for (int i = 0; i < P; i++) av[i] = sh[NT + i][lane];
   bool ok = true;
   double ldet = 0;
 #pragma unroll
@@ -1170,11 +1178,41 @@ __global__ void __launch_bounds__(64)
     for (int q = i + 1; q < P; q++) sum -= acc[TRI(q, i)] * av[q];
     av[i] = sum / acc[TRI(i, i)];
   }
+  if (!active) return;
+#pragma unroll
+  for (int i = 0; i < P; i++) sol[(int64_t)i * J + j] = av[i];
+  sol[(int64_t)P * J + j] = ldet;
+  sol[(int64_t)(P + 1) * J + j] = ok ? 1.0 : 0.0;
+}
+
+template <int P>
+__global__ void __launch_bounds__(64)
+    point_resid_kernel(PointArms A, const int32_t *__restrict__ job_spec,
+                       const int32_t *__restrict__ job_templ, int J,
+                       const double *__restrict__ vel, double espec_sys,
+                       int nsl, double *__restrict__ scratch) {
+  constexpr int NT = P * (P + 1) / 2;
+  constexpr int NV = NT + P;
+  const rvs_point_arm &T = A.a[blockIdx.z];
+  const int npix = T.npix;
+  const int j0 = blockIdx.x * 64 + threadIdx.x;
+  const bool active = j0 < J;
+  const int j = active ? j0 : J - 1;
+  const int s = job_spec ? job_spec[j] : j;
+  const int t = job_templ ? job_templ[j] : j;
+  const int sl = blockIdx.y;
+  double *base = scratch + (int64_t)blockIdx.z * point_arm_doubles(P, J, nsl);
+  const double *sol = base + (int64_t)nsl * NV * J;
+  double *res = base + (int64_t)nsl * NV * J + (int64_t)(P + 2) * J;
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = sol[(int64_t)i * J + j];
   const int k0 = (int)((int64_t)npix * sl / nsl);
   const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
-  const double *sp = spec + (int64_t)s * npix;
-  const double *es = espec + (int64_t)s * npix;
-  const double4 *cf = T.coef + (int64_t)t * T.ntp;
+  const double *sp = T.spec + (int64_t)s * npix;
+  const double *es = T.espec + (int64_t)s * npix;
+  const double4 *cf = reinterpret_cast<const double4 *>(T.coef) +
+                      (int64_t)t * T.ntp;
   const double bb = vel[j] / RVS_C_KMS;
   const double f = sqrt((1.0 - bb) / (1.0 + bb));
   const double x0 = T.knots[0];
@@ -1187,96 +1225,96 @@ __global__ void __launch_bounds__(64)
     double e = es[k];
     if (espec_sys > 0) e = sqrt(sys2 + e * e);
     const double ie = 1.0 / e;
-    const double *pr = polysT + (int64_t)k * P;
+    const double *pr = T.polysT + (int64_t)k * P;
     double m = 0;
 #pragma unroll
     for (int i = 0; i < P; i++) m = fma(av[i], pr[i], m);
     const double r = sp[k] * ie - m * (tv * ie);
     rr = fma(r, r, rr);
   }
-  if (!active) return;
-  res[(int64_t)sl * J + j] = rr;
-  if (sl == 0) {
-    aux[j] = ldet;
-    aux[J + j] = ok ? 1.0 : 0.0;
-  }
+  if (active) res[(int64_t)sl * J + j] = rr;
 }
 
-__global__ void point_fold_kernel(PointTempl T, const double *__restrict__ work,
-                                  int npix, int S,
+__global__ void point_fold_kernel(PointArms A, int P,
                                   const int32_t *__restrict__ job_spec, int J,
-                                  const double *__restrict__ vel,
-                                  const double *__restrict__ penalty,
-                                  double badchi, int nsl,
-                                  const double *__restrict__ res,
-                                  const double *__restrict__ aux, double beta,
+                                  const double *__restrict__ vel, double badchi,
+                                  int nsl, const double *__restrict__ scratch,
                                   double *__restrict__ out,
                                   int32_t *__restrict__ status) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= J) return;
   const int s = job_spec ? job_spec[j] : j;
-  const double base = (beta != 0.0) ? beta * out[j] : 0.0;
-  const double pen = penalty ? penalty[j] : 0.0;
-  if (!(pen == pen) || isinf(pen)) {  // spec_fit.py:888-893
-    out[j] = base + 1000.0 * badchi;
-    return;
-  }
-  double rr = 0;
-  for (int q = 0; q < nsl; q++) rr += res[(int64_t)q * J + j];
-  const double lz = work[npix + 2ll * S * npix + 2 * s];
-  double chi = 2.0 * aux[j] + 2.0 * lz + rr;
-  int st = 0;
+  const int64_t nv = (int64_t)P * (P + 1) / 2 + P;
   const double bb = vel[j] / RVS_C_KMS;
   const double f = sqrt((1.0 - bb) / (1.0 + bb));
-  const double xa = T.lam[0] * f, xb = T.lam[npix - 1] * f;
-  const double x0 = T.knots[0], xlast = T.knots[T.ntp - 1];
-  if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) {
-    st |= RVS_ST_SPLINE_RANGE;
-    chi = __builtin_nan("");
+  double tot = 0;
+  int st = 0;
+  for (int ia = 0; ia < A.n; ia++) {
+    const rvs_point_arm &T = A.a[ia];
+    const double pen = T.penalty ? T.penalty[j] : 0.0;
+    if (!(pen == pen) || isinf(pen)) {  // spec_fit.py:888-893
+      tot += 1000.0 * badchi;
+      continue;
+    }
+    const double *base = scratch + (int64_t)ia * point_arm_doubles(P, J, nsl);
+    const double *sol = base + (int64_t)nsl * nv * J;
+    const double *res = sol + (int64_t)(P + 2) * J;
+    double rr = 0;
+    for (int q = 0; q < nsl; q++) rr += res[(int64_t)q * J + j];
+    const double lz = T.work[T.npix + 2ll * T.S * T.npix + 2 * s];
+    double chi = 2.0 * sol[(int64_t)P * J + j] + 2.0 * lz + rr;
+    const double xa = T.lam[0] * f, xb = T.lam[T.npix - 1] * f;
+    const double x0 = T.knots[0], xlast = T.knots[T.ntp - 1];
+    if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) {
+      st |= RVS_ST_SPLINE_RANGE;
+      chi = __builtin_nan("");
+    }
+    const bool ok = sol[(int64_t)(P + 1) * J + j] != 0.0;
+    if (!ok) st |= RVS_ST_CHOL_FALLBACK;
+    if (!ok || !(fabs(chi) <= 1.79e308)) {
+      st |= RVS_ST_NONFINITE;
+      chi = __builtin_nan("");
+    }
+    tot += chi + pen;
   }
-  if (aux[J + j] == 0.0) st |= RVS_ST_CHOL_FALLBACK;
-  if (aux[J + j] == 0.0 || !(fabs(chi) <= 1.79e308)) {
-    st |= RVS_ST_NONFINITE;
-    chi = __builtin_nan("");
-  }
-  out[j] = base + chi + pen;
+  out[j] = tot;
   if (st) atomicOr(&status[j], st);
 }
 
-extern "C" int64_t rvs_chisq_point_work_size(int npoly, int J) {
-  if (npoly < 1 || J < 1) return 0;
-  const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly;
-  return ((int64_t)cont_nslice(J) * (nv + 1) + 2) * J * (int64_t)sizeof(double);
+extern "C" int64_t rvs_chisq_point_work_size(int npoly, int J, int narm) {
+  if (npoly < 1 || J < 1 || narm < 1) return 0;
+  return narm * point_arm_doubles(npoly, J, cont_nslice(J)) *
+         (int64_t)sizeof(double);
 }
 
-extern "C" int rvs_chisq_point(const double *lam, const double *polysT,
-                               const double *spec, const double *espec,
-                               const double *work, int npix, int npoly, int S,
-                               const double *knots, const double *coef, int ntp,
-                               int Tn, int log_step, const int32_t *job_spec,
+extern "C" int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
+                               const int32_t *job_spec,
                                const int32_t *job_templ, int J,
-                               const double *vel, const double *penalty,
-                               double badchi, double espec_sys, void *scratch,
-                               double beta, double *out, int32_t *status,
-                               void *stream) {
-  if (J < 1 || npix < 1 || ntp < 3 || Tn < 1 || !scratch) return RVS_E_ARG;
+                               const double *vel, double badchi,
+                               double espec_sys, void *scratch, double *out,
+                               int32_t *status, void *stream) {
+  if (J < 1 || narm < 1 || narm > RVS_MAX_ARMS || !scratch || !arms)
+    return RVS_E_ARG;
+  PointArms A;
+  A.n = narm;
+  for (int i = 0; i < narm; i++) {
+    A.a[i] = arms[i];
+    if (arms[i].npix < 1 || arms[i].ntp < 3) return RVS_E_ARG;
+  }
+  for (int i = narm; i < RVS_MAX_ARMS; i++) A.a[i] = arms[0];
   hipStream_t st = rvs_stream(stream);
   const int nsl = cont_nslice(J);
-  const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly;
-  double *part = (double *)scratch;
-  double *res = part + (int64_t)nsl * nv * J;
-  double *aux = res + (int64_t)nsl * J;
-  PointTempl T{lam, knots, reinterpret_cast<const double4 *>(coef), work, ntp,
-               log_step};
-  dim3 grid((J + 63) / 64, nsl);
+  double *scr = (double *)scratch;
+  dim3 grid((J + 63) / 64, nsl, narm);
+  dim3 gsolve((J + 63) / 64, 1, narm);
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \
-    hipLaunchKernelGGL(point_normal_kernel<PP>, grid, dim3(64), 0, st, T,      \
-                       polysT, spec, espec, npix, job_spec, job_templ, J, vel, \
-                       espec_sys, nsl, part);                                  \
-    hipLaunchKernelGGL(point_resid_kernel<PP>, grid, dim3(64), 0, st, T,       \
-                       polysT, spec, espec, npix, job_spec, job_templ, J, vel, \
-                       espec_sys, nsl, part, res, aux);                        \
+    hipLaunchKernelGGL(point_normal_kernel<PP>, grid, dim3(64), 0, st, A,      \
+                       job_spec, job_templ, J, vel, espec_sys, nsl, scr);      \
+    hipLaunchKernelGGL(point_solve_kernel<PP>, gsolve, dim3(256), 0, st, J,    \
+                       nsl, scr);                                              \
+    hipLaunchKernelGGL(point_resid_kernel<PP>, grid, dim3(64), 0, st, A,       \
+                       job_spec, job_templ, J, vel, espec_sys, nsl, scr);      \
     break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
@@ -1287,8 +1325,7 @@ extern "C" int rvs_chisq_point(const double *lam, const double *polysT,
   }
 #undef RVS_CASE
   hipLaunchKernelGGL(point_fold_kernel, dim3((J + 255) / 256), dim3(256), 0, st,
-                     T, work, npix, S, job_spec, J, vel, penalty, badchi, nsl,
-                     res, aux, beta, out, status);
+                     A, npoly, job_spec, J, vel, badchi, nsl, scr, out, status);
   RVS_LAUNCH_CHECK();
   return 0;
 }

@@ -449,10 +449,129 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---------------------------------------------------------------------------
+// A7 construct, windowed variant for (log-)uniform knots (form bit 1).
+// With neighbouring spacings equal to ~1 % both Thomas recurrences contract by
+// ~0.268 per row, so a row's value depends on rows further than 40 away by
+// < 1e-22: every thread can start its chunk SW_W rows early from zero and be
+// exact to rounding on its own rows -- no carries, no serial section (the
+// exact kernel above spends most of its time in two 256-step serial carries).
+// One block per (segment of SW_SEG knots, template); three barrier-separated
+// passes over LDS: pivots (knots only), forward, backward; then coalesced
+// 32-B records.
+// ---------------------------------------------------------------------------
+#define SW_W 40
+#define SW_SEG 2048
+#define SW_RMAX (SW_SEG + 3 * SW_W + 8)
+
+__global__ void __launch_bounds__(256)
+    spline_construct_win_kernel(const double *__restrict__ knots,
+                                const double *__restrict__ ys, int ntp, int form,
+                                double4 *__restrict__ coef) {
+  __shared__ double ysh[SW_RMAX + 2];
+  __shared__ double idn[SW_RMAX];  // 1/den_u
+  __shared__ double dp[SW_RMAX];   // forward rhs, then z
+  const int N = ntp, m = N - 2;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int k0 = blockIdx.x * SW_SEG, k1 = min(N, k0 + SW_SEG);
+  // unknown u <-> z at knot u+1; records of knots [k0,k1) need z of knots [k0,k1]
+  const int u0 = max(0, k0 - 1), u1 = min(m, k1);
+  const int r0 = max(0, u0 - 2 * SW_W), r1 = min(m, u1 + SW_W);
+  const int nr = r1 - r0;
+  const double *y = ys + (int64_t)b * N;
+  for (int i = tid; i < nr + 2; i += 256) ysh[i] = y[r0 + i];
+  const int CH = (nr + 255) / 256;
+  const int a0 = r0 + tid * CH, a1 = min(r1, a0 + CH);
+  // pass 0: pivots.  den_u = 2(h0+h1) - h0*cp_{u-1}, cp_u = h1/den_u
+  if (a0 < a1) {
+    int s = max(0, a0 - SW_W);
+    double c = 0;
+    double xa = knots[s], xb = knots[s + 1];
+    for (int u = s; u < a1; u++) {
+      const double xc = knots[u + 2];
+      const double h0 = xb - xa, h1 = xc - xb;
+      const double den = 2 * (h1 + h0) - h0 * c;  // c == 0 at u == 0
+      const double inv = 1.0 / den;
+      c = h1 * inv;
+      if (u >= a0) idn[u - r0] = inv;
+      xa = xb;
+      xb = xc;
+    }
+  }
+  __syncthreads();
+  // pass 1: forward elimination d_u = (rhs_u - h0 d_{u-1}) / den_u
+  if (a0 < a1) {
+    int s = max(r0, a0 - SW_W);
+    double d = 0;
+    double xa = knots[s], xb = knots[s + 1];
+    double ya = ysh[s - r0], yb = ysh[s + 1 - r0];
+    double s0 = (yb - ya) / (xb - xa);
+    for (int u = s; u < a1; u++) {
+      const double xc = knots[u + 2], yc = ysh[u + 2 - r0];
+      const double h0 = xb - xa, h1 = xc - xb;
+      const double s1 = (yc - yb) / h1;
+      const double rhs = 6 * (s1 - s0);
+      d = (u == 0) ? rhs * idn[u - r0] : (rhs - h0 * d) * idn[u - r0];
+      if (u >= a0) dp[u - r0] = d;
+      xa = xb;
+      xb = xc;
+      yb = yc;
+      s0 = s1;
+    }
+  }
+  __syncthreads();
+  // pass 2: back substitution z_u = d_u - cp_u z_{u+1}; warm-up first (reads
+  // the neighbours' d), barrier, then the own chunk in place
+  double z = 0;
+  const int e = min(r1, a1 + SW_W);
+  if (a0 < a1) {
+    for (int u = e - 1; u >= a1; u--) {
+      const double h1 = knots[u + 2] - knots[u + 1];
+      z = (u == m - 1) ? dp[u - r0] : dp[u - r0] - h1 * idn[u - r0] * z;
+    }
+  }
+  __syncthreads();
+  if (a0 < a1) {
+    for (int u = a1 - 1; u >= a0; u--) {
+      const double h1 = knots[u + 2] - knots[u + 1];
+      z = (u == m - 1) ? dp[u - r0] : dp[u - r0] - h1 * idn[u - r0] * z;
+      dp[u - r0] = z;
+    }
+  }
+  __syncthreads();
+  // coefficients (spliner.c:52-59)
+  double4 *cf = coef + (int64_t)b * N;
+  for (int i = k0 + tid; i < k1; i += 256) {
+    if (i >= N - 1) {
+      cf[i] = make_double4(0, 0, 0, 0);
+      continue;
+    }
+    const double h = knots[i + 1] - knots[i], hinv = 1.0 / h;
+    const double zi = (i == 0) ? 0.0 : dp[i - 1 - r0];
+    const double zi1 = (i + 1 == N - 1) ? 0.0 : dp[i - r0];
+    const double yi = ysh[i - r0], yi1 = ysh[i + 1 - r0];
+    const double t1 = hinv * (1.0 / 6), t2 = h * (1.0 / 6);
+    if ((form & 1) == 0)
+      cf[i] = make_double4(zi1 * t1, zi * t1, yi1 * hinv - zi1 * t2,
+                           yi * hinv - zi * t2);
+    else
+      cf[i] = make_double4(yi, (yi1 - yi) * hinv - t2 * (2 * zi + zi1),
+                           0.5 * zi, (zi1 - zi) * t1);
+  }
+}
+
 extern "C" int rvs_spline_construct(const double *knots, const double *ys,
                                     int ntp, int B, int form, double *coef,
                                     void *stream) {
-  if (ntp < 4 || B < 1 || form < 0 || form > 1) return RVS_E_ARG;
+  if (ntp < 4 || B < 1 || form < 0 || form > 3) return RVS_E_ARG;
+  if (form & 2) {
+    dim3 grid((ntp + SW_SEG - 1) / SW_SEG, B);
+    hipLaunchKernelGGL(spline_construct_win_kernel, grid, dim3(256), 0,
+                       rvs_stream(stream), knots, ys, ntp, form,
+                       reinterpret_cast<double4 *>(coef));
+    RVS_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t shm = sizeof(double) * (2 * (size_t)(ntp - 2) + 2 * 257);
   if (shm > 159 * 1024) return RVS_E_ARG;
   static bool attr_set = false;

@@ -258,9 +258,10 @@ def build_templates(lib, params, vsini=None, return_templ=False):
         _lib.check(rc, 'rvs_vsini_convolve')
         templ = out
     coef = torch.empty((J, lib.ntp, 4), dtype=torch.float64, device=lib.device)
-    # form 1: power-form records {y, b, c, d} consumed by the chi^2 kernels
+    # form 1: power-form records {y, b, c, d} consumed by the chi^2 kernels;
+    # | 2: windowed solve, valid for the (log-)uniform grid of a library
     rc = L.rvs_spline_construct(_lib.ptr(lib.knots), _lib.ptr(templ), lib.ntp, J,
-                                1, _lib.ptr(coef), _lib.stream())
+                                lib.spline_form, _lib.ptr(coef), _lib.stream())
     _lib.check(rc, 'rvs_spline_construct')
     if return_templ:
         return coef, outside, templ
@@ -385,17 +386,21 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
 def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
                 job_spec=None, job_templ=None, espec_sys=0.0,
                 outside_penalty=True):
-    """get_chisq for J (spectrum, template, velocity) triples, summed over the
-    arms (rvs_chisq_point: lane per job, explicit residual norm).
+    """get_chisq for J (spectrum, template, velocity) triples, all arms in one
+    launch set (rvs_chisq_point: lane per job, explicit residual norm).
     vel [J]; returns chisq [J], status int32 [J]."""
+    import ctypes
     L = _lib.lib()
     dev = batch.device
     vel = vel.to(device=dev, dtype=torch.float64).contiguous()
     J = vel.shape[0]
+    narm = len(batch.arms)
     out = torch.empty(J, dtype=torch.float64, device=dev)
     status = torch.zeros(J, dtype=torch.int32, device=dev)
-    nb = L.rvs_chisq_point_work_size(npoly, J)
+    nb = L.rvs_chisq_point_work_size(npoly, J, narm)
     scratch = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+    arr = (_lib.PointArm * narm)()
+    keep = []
     for ia, arm in enumerate(batch.arms):
         lib = libs[arm.name]
         work = arm.work(lib, espec_sys)
@@ -407,16 +412,21 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
             torch.isfinite(o), torch.zeros_like(o), o)
         pen = pen.contiguous()
         coef = coefs[ia]
-        with _ktime('chisq_point', J):
-            rc = L.rvs_chisq_point(
-                _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(arm.spec),
-                _lib.ptr(arm.espec), _lib.ptr(work), arm.npix, npoly, arm.S,
-                _lib.ptr(lib.knots), _lib.ptr(coef), lib.ntp, coef.shape[0],
-                int(lib.log_step), _lib.ptr(job_spec), _lib.ptr(job_templ), J,
-                _lib.ptr(vel), _lib.ptr(pen), float(batch.badchi),
-                float(espec_sys), _lib.ptr(scratch), 0.0 if ia == 0 else 1.0,
-                _lib.ptr(out), _lib.ptr(status), _lib.stream())
-            _lib.check(rc, 'rvs_chisq_point')
+        keep.append((work, polysT, pen, coef))
+        a = arr[ia]
+        a.lam, a.polysT = arm.lam.data_ptr(), polysT.data_ptr()
+        a.spec, a.espec = arm.spec.data_ptr(), arm.espec.data_ptr()
+        a.work, a.knots = work.data_ptr(), lib.knots.data_ptr()
+        a.coef, a.penalty = coef.data_ptr(), pen.data_ptr()
+        a.npix, a.S, a.ntp = arm.npix, arm.S, lib.ntp
+        a.log_step = int(lib.log_step)
+    with _ktime('chisq_point', J):
+        rc = L.rvs_chisq_point(ctypes.addressof(arr), narm, npoly,
+                               _lib.ptr(job_spec), _lib.ptr(job_templ), J,
+                               _lib.ptr(vel), float(batch.badchi),
+                               float(espec_sys), _lib.ptr(scratch),
+                               _lib.ptr(out), _lib.ptr(status), _lib.stream())
+        _lib.check(rc, 'rvs_chisq_point')
     return out, status
 
 

@@ -44,6 +44,11 @@ class TemplateLibrary:
         self.knots = _dev(self.lam, torch.float64, device)
         self.knots3 = np.ascontiguousarray(self.lam[:3])
         self.lnstep = float(np.log(self.lam[1] / self.lam[0]))
+        # rvs_spline_construct form: 1 = power-form records; | 2 = windowed
+        # solve, allowed when neighbouring knot spacings agree to ~1 %
+        hh = np.diff(self.lam)
+        near_uniform = bool(np.all(np.abs(hh[1:] / hh[:-1] - 1) < 5e-3))
+        self.spline_form = 3 if near_uniform else 1
         self.kind = 'regulargrid'
         if 'dats' in d:
             idgrid = np.asarray(d['idgrid'], dtype=np.int64)

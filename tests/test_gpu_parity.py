@@ -85,6 +85,51 @@ def test_spline_desi_size_vs_oracle(gpu):
     np.testing.assert_allclose(ret, oret, rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize('ntp', [4, 5, 37, 300, 2047, 2048, 2049, 6215, 9001])
+def test_spline_construct_forms(gpu, ntp):
+    """exact (chunk carries) and windowed (form | 2) solves, A,B,C,D and power
+    form, against the oracle's restatement of spliner.c construct"""
+    from rvspecfit_amd import _lib
+    rng = np.random.RandomState(ntp)
+    B = 3
+    for log_step in (True, False):
+        xs = np.linspace(np.log(3500.), np.log(5900.), ntp)
+        xs = np.exp(xs) if log_step else np.linspace(3500., 5900., ntp)
+        ys = 1 + 0.3 * rng.standard_normal((B, ntp))
+        ys[1] = np.exp(-0.5 * ((xs - 4500.) / 30.)**2) * 1e3   # smooth, big
+        kn = torch.as_tensor(xs).to('cuda')
+        yt = torch.as_tensor(ys).to('cuda')
+        out = {}
+        for form in (0, 1, 2, 3):
+            coef = torch.empty((B, ntp, 4), dtype=torch.float64, device='cuda')
+            rc = _lib.lib().rvs_spline_construct(_lib.ptr(kn), _lib.ptr(yt), ntp,
+                                                 B, form, _lib.ptr(coef),
+                                                 _lib.stream())
+            assert rc == 0
+            out[form] = coef.cpu().numpy()
+        for b in range(B):
+            O = orc.Spline(xs, ys[b], log_step=log_step)
+            sc = np.abs(ys[b]).max() / np.diff(xs).min()
+            for form in (0, 2):
+                for i, k in enumerate('ABCD'):
+                    np.testing.assert_allclose(out[form][b, :-1, i],
+                                               getattr(O, k), rtol=1e-9,
+                                               atol=1e-11 * sc)
+            # power form: same cubic -> same values at interior points
+            h = np.diff(xs)
+            for form in (1, 3):
+                c = out[form][b, :-1]
+                for fr in (0.0, 0.3, 0.99):
+                    dl = fr * h
+                    v = c[:, 0] + dl * (c[:, 1] + dl * (c[:, 2] + dl * c[:, 3]))
+                    dr = h - dl
+                    w = O.A * dl**3 + O.B * dr**3 + O.C * dl + O.D * dr
+                    np.testing.assert_allclose(v, w, rtol=1e-10,
+                                               atol=1e-11 * np.abs(ys[b]).max())
+            np.testing.assert_allclose(out[3][b], out[1][b], rtol=1e-9,
+                                       atol=1e-11 * sc)
+
+
 def test_spline_error_codes(gpu):
     from rvspecfit_amd import spec_fit
     xs = np.exp(np.linspace(1, 2, 50))

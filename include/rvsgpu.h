@@ -301,6 +301,66 @@ int rvs_template_nn(const double *params, int B, int ndim, uint32_t log_mask,
                     const int32_t *dims, float *act0, float *act1,
                     double *templ, void *stream);
 
+/* ------------------------------------------------------------------------
+ * the optimiser stage of vel_fit.process
+ * (vel_fit.py:596-650).  S Nelder-Mead simplices (scipy's algorithm, which the
+ * reference calls through scipy.optimize.minimize(method='Nelder-Mead',
+ * options={fatol, xatol, initial_simplex, maxiter, maxfev=inf}), :627-637) live
+ * in device memory and advance in lock-step; between the calls below the
+ * caller evaluates the objective on (list, X) with the entry points above.
+ *   sim [S, N+1, N], fsim [S, N+1] ordered ascending on entry; nit, nfev [S];
+ *   flags [S]: bit0 active, bit1 converged, bit2 shrink pending;
+ *   counts int32[8] (device): [0] |list1|, [1] |list2|, [2] |list3|,
+ *   [3] simplices stepping this round, [4] simplices parked for a shrink.
+ * Every call takes `jbound`, a host-side upper bound of the job count (the
+ * live count is read from `counts` on the device), so no host synchronisation
+ * is needed inside a round; list/X entries in [count, jbound) are padded with
+ * a copy of entry 0.
+ * ---------------------------------------------------------------------- */
+int rvs_nm_begin(int S, int N, double xatol, double fatol, int maxiter,
+                 const double *sim, const double *fsim, const int32_t *nit,
+                 int32_t *flags, int32_t *list1, double *X1, int32_t *counts,
+                 int jbound, void *stream);
+int rvs_nm_decide(int N, const double *sim, const double *fsim,
+                  const int32_t *list1, const double *F1, int32_t *cases,
+                  int32_t *pos2, int32_t *list2, double *X2, int32_t *counts,
+                  int jbound, void *stream);
+int rvs_nm_update(int N, double *sim, double *fsim, int32_t *nit, int32_t *nfev,
+                  const int32_t *list1, const double *X1, const double *F1,
+                  const int32_t *cases, const int32_t *pos2, const double *X2,
+                  const double *F2, int32_t *flags, int32_t *counts, int jbound,
+                  void *stream);
+int rvs_nm_collect(int S, const int32_t *flags, int32_t *list3, int32_t *counts,
+                   void *stream);
+int rvs_nm_shrink_point(int N, int k, double *sim, const int32_t *list3,
+                        double *X3, const int32_t *counts, int jbound,
+                        void *stream);
+int rvs_nm_shrink_store(int N, int k, double *sim, double *fsim, int32_t *nit,
+                        int32_t *nfev, int32_t *flags, const int32_t *list3,
+                        const double *F3, int32_t *counts, int jbound,
+                        void *stream);
+
+/* vel_fit.ParamMapper.forward + the range/finiteness guard of chisq_func +
+ * VSiniMapper.to_vsini + the priors of chisq_func0 (vel_fit.py:95-254) for J
+ * rows X [J, n] = (vel, [vsini], free stellar parameters).  src [ndim] (host):
+ * column of X feeding stellar parameter i or -1 (fixed: fixed[S, ndim]);
+ * vsini_col < 0: vsini_fixed[S]; vsini == NULL: no rotation.  Rows that
+ * chisq_func answers with 1e30 get bad = 1 and harmless inputs (vel 0, safe[S,
+ * ndim]).  rvs_proc_finish: F = bad ? 1e30 : chi + extra; job status bits of
+ * the live rows (j < counts[cidx], or all when counts == NULL) are OR-ed into
+ * spec_status[job_spec[j]]. */
+int rvs_proc_map(int J, int n, int ndim, const double *X, const int32_t *list,
+                 const int32_t *src, int vsini_col, const double *fixed,
+                 const double *vsini_fixed, const double *safe,
+                 const double *prior_mean, const double *prior_isig,
+                 double min_vel, double max_vel, double max_vsini,
+                 int32_t *job_spec, double *vel, double *vsini, double *params,
+                 double *extra, int32_t *bad, void *stream);
+int rvs_proc_finish(int J, const int32_t *counts, int cidx, const double *chi,
+                    const double *extra, const int32_t *bad,
+                    const int32_t *job_spec, const int32_t *job_status,
+                    double *F, int32_t *spec_status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

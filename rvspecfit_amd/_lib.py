@@ -36,6 +36,15 @@ SIGNATURES = {
     'rvs_chisq_continuum': (I, [P, P, P, P, I, I, I, P, P, P, P, P, P]),
     'rvs_chisq_point_work_size': (L, [I, I, I]),
     'rvs_chisq_point': (I, [P, I, I, P, P, I, P, D, D, P, P, P, P]),
+    'rvs_nm_begin': (I, [I, I, D, D, I, P, P, P, P, P, P, P, I, P]),
+    'rvs_nm_decide': (I, [I, P, P, P, P, P, P, P, P, P, I, P]),
+    'rvs_nm_update': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P]),
+    'rvs_nm_collect': (I, [I, P, P, P, P]),
+    'rvs_nm_shrink_point': (I, [I, I, P, P, P, P, I, P]),
+    'rvs_nm_shrink_store': (I, [I, I, P, P, P, P, P, P, P, P, I, P]),
+    'rvs_proc_map': (I, [I, I, I, P, P, P, I, P, P, P, P, P, D, D, D, P, P, P, P,
+                          P, P, P]),
+    'rvs_proc_finish': (I, [I, P, I, P, P, P, P, P, P, P, P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),

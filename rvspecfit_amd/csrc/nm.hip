@@ -1,0 +1,527 @@
+// Device-resident lock-step Nelder-Mead for S independent simplices, and the
+// parameter mapping of vel_fit.chisq_func around the batched objective.
+//
+// vel_fit.process runs scipy's Nelder-Mead once per spectrum (vel_fit.py:627-637);
+// here the S state machines live in HBM and advance together.  One round is
+//   rvs_nm_begin   termination test, centroid, reflection point  -> list1, X1
+//   <objective>    F1 = f(X1)
+//   rvs_nm_decide  branch per simplex; expansion / contraction point -> list2, X2
+//   <objective>    F2 = f(X2)
+//   rvs_nm_update  accept / replace / order; a simplex that must shrink is parked
+//   (rare: rvs_nm_collect -> list3, then per vertex rvs_nm_shrink_point +
+//    <objective> + rvs_nm_shrink_store, whenever the host next looks)
+// Every kernel reads its job count from DEVICE memory (`counts`), so the host
+// never has to synchronise inside a round: it launches with the last count it
+// has seen as an upper bound (active sets only shrink) and refreshes that bound
+// every few rounds.  List entries beyond the live count are padded with a copy
+// of entry 0, so the objective kernels in between can run the full bound.
+//
+// The branch structure, constants (rho=1, chi=2, psi=0.5, sigma=0.5), stable
+// vertex ordering (NaN last) and the order of the floating-point operations
+// follow scipy/optimize/_optimize.py::_minimize_neldermead, the same as
+// rvspecfit_amd/neldermead.py (which tests/ checks against scipy itself).
+#include "common.h"
+
+// numpy evaluates every product and sum of the simplex arithmetic separately;
+// a fused multiply-add would change the last bit and, eventually, the path
+#pragma clang fp contract(off)
+
+#define NM_MAXN 8
+#define NM_NT 1024
+
+// counts layout (int32[8]): [0] jobs of list1, [1] jobs of list2, [2] length
+// of list3, [3] simplices stepping this round, [4] simplices parked for a shrink
+// flags: bit 0 active, bit 1 converged (success), bit 2 shrink pending
+__device__ __forceinline__ int block_excl_scan(int flag, int *total,
+                                               int *sh /*[NM_NT/64 + 1]*/) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(flag);
+  const int pre = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) sh[w] = __popcll(m);
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int i = 0; i < NM_NT / 64; i++) {
+    const int c = sh[i];
+    if (i < w) off += c;
+    tot += c;
+  }
+  __syncthreads();
+  *total = tot;
+  return off + pre;
+}
+
+// stable insertion sort of the N+1 vertices by f (NaN last), np.argsort order
+__device__ void nm_order(double *sim, double *f, int N) {
+  for (int a = 1; a <= N; a++) {
+    const double fa = f[a];
+    const double ka = (fa != fa) ? __builtin_inf() : fa;
+    double xa[NM_MAXN];
+    for (int i = 0; i < N; i++) xa[i] = sim[a * N + i];
+    int b = a - 1;
+    while (b >= 0) {
+      const double fb = f[b];
+      const double kb = (fb != fb) ? __builtin_inf() : fb;
+      if (!(kb > ka)) break;
+      f[b + 1] = fb;
+      for (int i = 0; i < N; i++) sim[(b + 1) * N + i] = sim[b * N + i];
+      b--;
+    }
+    f[b + 1] = fa;
+    for (int i = 0; i < N; i++) sim[(b + 1) * N + i] = xa[i];
+  }
+}
+
+__global__ void __launch_bounds__(NM_NT)
+    nm_begin_kernel(int S, int N, double xatol, double fatol, int maxiter,
+                    const double *__restrict__ sim,
+                    const double *__restrict__ fsim,
+                    const int32_t *__restrict__ nit, int32_t *__restrict__ flags,
+                    int32_t *__restrict__ list1, double *__restrict__ X1,
+                    int32_t *__restrict__ counts, int jbound) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  int base_out = 0;
+  for (int r0 = 0; r0 < S; r0 += NM_NT) {
+    const int r = r0 + threadIdx.x;
+    int go = 0;
+    double xr[NM_MAXN];
+    if (r < S && (flags[r] & 5) == 1) {  // active and no shrink pending
+      const double *s = sim + (int64_t)r * (N + 1) * N;
+      const double *f = fsim + (int64_t)r * (N + 1);
+      if (nit[r] >= maxiter) {
+        flags[r] &= ~1;  // scipy: while-condition fails -> warnflag 2
+      } else {
+        double dx = 0, df = 0;
+        for (int k = 1; k <= N; k++) {
+          for (int i = 0; i < N; i++)
+            dx = fmax(dx, fabs(s[k * N + i] - s[i]));
+          df = fmax(df, fabs(f[0] - f[k]));
+        }
+        // NaN propagates like np.max: a NaN difference never passes the test
+        bool anynan = false;
+        for (int k = 1; k <= N; k++) {
+          if (f[k] != f[k] || f[0] != f[0]) anynan = true;
+          for (int i = 0; i < N; i++)
+            if (s[k * N + i] != s[k * N + i] || s[i] != s[i]) anynan = true;
+        }
+        if (!anynan && dx <= xatol && df <= fatol) {
+          flags[r] = (flags[r] & ~1) | 2;  // converged: success
+        } else {
+          go = 1;
+          for (int i = 0; i < N; i++) {
+            double xb = s[i];
+            for (int k = 1; k < N; k++) xb = xb + s[k * N + i];
+            xb = xb / N;
+            xr[i] = (1 + 1.0) * xb - 1.0 * s[N * N + i];
+          }
+        }
+      }
+    }
+    int tot;
+    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    if (go) {
+      list1[pos] = r;
+      for (int i = 0; i < N; i++) X1[(int64_t)pos * N + i] = xr[i];
+    }
+    base_out += tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counts[0] = base_out;
+    counts[3] = base_out;
+  }
+  // pad the unused tail with a copy of entry 0 (or simplex 0's best vertex)
+  if (base_out == 0 && threadIdx.x == 0) {
+    list1[0] = 0;
+    for (int i = 0; i < N; i++) X1[i] = sim[i];
+  }
+  __syncthreads();
+  for (int j = max(base_out, 1) + threadIdx.x; j < jbound; j += NM_NT) {
+    list1[j] = list1[0];
+    for (int i = 0; i < N; i++) X1[(int64_t)j * N + i] = X1[i];
+  }
+}
+
+// cases: 0 accept reflection, 1 expansion, 2 outside contraction, 3 inside
+__global__ void __launch_bounds__(NM_NT)
+    nm_decide_kernel(int N, const double *__restrict__ sim,
+                     const double *__restrict__ fsim,
+                     const int32_t *__restrict__ list1,
+                     const double *__restrict__ F1, int32_t *__restrict__ cases,
+                     int32_t *__restrict__ pos2, int32_t *__restrict__ list2,
+                     double *__restrict__ X2, int32_t *__restrict__ counts,
+                     int jbound) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  const int J = min(counts[0], jbound);
+  int base_out = 0;
+  for (int j0 = 0; j0 < J; j0 += NM_NT) {
+    const int j = j0 + threadIdx.x;
+    int go = 0;
+    double x2[NM_MAXN];
+    int r = 0;
+    if (j < J) {
+      r = list1[j];
+      const double *s = sim + (int64_t)r * (N + 1) * N;
+      const double *f = fsim + (int64_t)r * (N + 1);
+      const double fxr = F1[j];
+      int c;
+      if (fxr < f[0])
+        c = 1;
+      else if (fxr < f[N - 1])
+        c = 0;
+      else if (fxr < f[N])
+        c = 2;
+      else
+        c = 3;
+      cases[j] = c;
+      if (c != 0) {
+        go = 1;
+        for (int i = 0; i < N; i++) {
+          double xb = s[i];
+          for (int k = 1; k < N; k++) xb = xb + s[k * N + i];
+          xb = xb / N;
+          const double w = s[N * N + i];
+          if (c == 1)
+            x2[i] = (1 + 1.0 * 2.0) * xb - 1.0 * 2.0 * w;
+          else if (c == 2)
+            x2[i] = (1 + 0.5 * 1.0) * xb - 0.5 * 1.0 * w;
+          else
+            x2[i] = (1 - 0.5) * xb + 0.5 * w;
+        }
+      }
+    }
+    int tot;
+    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    if (j < J) pos2[j] = go ? pos : -1;
+    if (go) {
+      list2[pos] = r;
+      for (int i = 0; i < N; i++) X2[(int64_t)pos * N + i] = x2[i];
+    }
+    base_out += tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counts[1] = base_out;
+  if (base_out == 0 && threadIdx.x == 0) {
+    list2[0] = 0;
+    for (int i = 0; i < N; i++) X2[i] = sim[i];
+  }
+  __syncthreads();
+  for (int j = max(base_out, 1) + threadIdx.x; j < jbound; j += NM_NT) {
+    list2[j] = list2[0];
+    for (int i = 0; i < N; i++) X2[(int64_t)j * N + i] = X2[i];
+  }
+}
+
+__global__ void __launch_bounds__(NM_NT)
+    nm_update_kernel(int N, double *__restrict__ sim, double *__restrict__ fsim,
+                     int32_t *__restrict__ nit, int32_t *__restrict__ nfev,
+                     const int32_t *__restrict__ list1,
+                     const double *__restrict__ X1,
+                     const double *__restrict__ F1,
+                     const int32_t *__restrict__ cases,
+                     const int32_t *__restrict__ pos2,
+                     const double *__restrict__ X2,
+                     const double *__restrict__ F2, int32_t *__restrict__ flags,
+                     int32_t *__restrict__ counts, int jbound) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  const int J = min(counts[0], jbound);
+  int base_out = 0;
+  for (int j0 = 0; j0 < J; j0 += NM_NT) {
+    const int j = j0 + threadIdx.x;
+    int go = 0, r = 0;
+    if (j < J) {
+      r = list1[j];
+      double *s = sim + (int64_t)r * (N + 1) * N;
+      double *f = fsim + (int64_t)r * (N + 1);
+      const int c = cases[j];
+      const double fxr = F1[j];
+      const int p2 = pos2[j];
+      const double f2 = (p2 >= 0) ? F2[p2] : __builtin_inf();
+      bool take2 = false, taker = false;
+      if (c == 0)
+        taker = true;
+      else if (c == 1) {
+        if (f2 < fxr)
+          take2 = true;
+        else
+          taker = true;
+      } else if (c == 2)
+        take2 = (f2 <= fxr);
+      else
+        take2 = (f2 < f[N]);
+      nfev[r] += (c == 0) ? 1 : 2;
+      if (take2 || taker) {
+        const double *src = take2 ? (X2 + (int64_t)p2 * N) : (X1 + (int64_t)j * N);
+        for (int i = 0; i < N; i++) s[N * N + i] = src[i];
+        f[N] = take2 ? f2 : fxr;
+        nm_order(s, f, N);
+        nit[r] += 1;
+      } else {
+        go = 1;  // shrink: parked (flag bit 2) until the host runs the shrink
+      }
+    }
+    int tot;
+    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    if (go) flags[r] |= 4;
+    (void)pos;
+    base_out += tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counts[4] += base_out;  // simplices waiting to shrink
+}
+
+// list3 = simplices with a pending shrink (flag bit 2), counts[2] = how many
+__global__ void __launch_bounds__(NM_NT)
+    nm_collect_kernel(int S, const int32_t *__restrict__ flags,
+                      int32_t *__restrict__ list3,
+                      int32_t *__restrict__ counts) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  int base_out = 0;
+  for (int r0 = 0; r0 < S; r0 += NM_NT) {
+    const int r = r0 + threadIdx.x;
+    const int go = (r < S && (flags[r] & 4)) ? 1 : 0;
+    int tot;
+    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    if (go) list3[pos] = r;
+    base_out += tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counts[2] = base_out;
+}
+
+// vertex k (1..N) of every shrinking simplex: sim[k] = sim[0] + 0.5 (sim[k]-sim[0])
+__global__ void __launch_bounds__(256)
+    nm_shrink_point_kernel(int N, int k, double *__restrict__ sim,
+                           const int32_t *__restrict__ list3,
+                           double *__restrict__ X3,
+                           const int32_t *__restrict__ counts, int jbound) {
+  const int J = min(counts[2], jbound);
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= jbound) return;
+  const int jj = (j < J) ? j : 0;
+  const int r = (J > 0) ? list3[jj] : 0;
+  double *s = sim + (int64_t)r * (N + 1) * N;
+  for (int i = 0; i < N; i++) {
+    double v = s[i];
+    if (J > 0) {
+      v = s[i] + 0.5 * (s[k * N + i] - s[i]);
+      if (j < J) s[k * N + i] = v;
+    }
+    X3[(int64_t)j * N + i] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    nm_shrink_store_kernel(int N, int k, double *__restrict__ sim,
+                           double *__restrict__ fsim,
+                           int32_t *__restrict__ nit, int32_t *__restrict__ nfev,
+                           int32_t *__restrict__ flags,
+                           const int32_t *__restrict__ list3,
+                           const double *__restrict__ F3,
+                           int32_t *__restrict__ counts, int jbound) {
+  const int J = min(counts[2], jbound);
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= J) return;
+  const int r = list3[j];
+  fsim[(int64_t)r * (N + 1) + k] = F3[j];
+  if (k == N) {
+    nm_order(sim + (int64_t)r * (N + 1) * N, fsim + (int64_t)r * (N + 1), N);
+    nit[r] += 1;
+    nfev[r] += N;
+    flags[r] &= ~4;
+    if (j == 0) counts[4] = 0;
+  }
+}
+
+extern "C" int rvs_nm_begin(int S, int N, double xatol, double fatol,
+                            int maxiter, const double *sim, const double *fsim,
+                            const int32_t *nit, int32_t *flags, int32_t *list1,
+                            double *X1, int32_t *counts, int jbound,
+                            void *stream) {
+  if (S < 1 || N < 1 || N > NM_MAXN || jbound < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(nm_begin_kernel, dim3(1), dim3(NM_NT), 0,
+                     rvs_stream(stream), S, N, xatol, fatol, maxiter, sim, fsim,
+                     nit, flags, list1, X1, counts, jbound);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rvs_nm_decide(int N, const double *sim, const double *fsim,
+                             const int32_t *list1, const double *F1,
+                             int32_t *cases, int32_t *pos2, int32_t *list2,
+                             double *X2, int32_t *counts, int jbound,
+                             void *stream) {
+  if (N < 1 || N > NM_MAXN || jbound < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(nm_decide_kernel, dim3(1), dim3(NM_NT), 0,
+                     rvs_stream(stream), N, sim, fsim, list1, F1, cases, pos2,
+                     list2, X2, counts, jbound);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rvs_nm_update(int N, double *sim, double *fsim, int32_t *nit,
+                             int32_t *nfev, const int32_t *list1,
+                             const double *X1, const double *F1,
+                             const int32_t *cases, const int32_t *pos2,
+                             const double *X2, const double *F2, int32_t *flags,
+                             int32_t *counts, int jbound, void *stream) {
+  if (N < 1 || N > NM_MAXN || jbound < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(nm_update_kernel, dim3(1), dim3(NM_NT), 0,
+                     rvs_stream(stream), N, sim, fsim, nit, nfev, list1, X1, F1,
+                     cases, pos2, X2, F2, flags, counts, jbound);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rvs_nm_collect(int S, const int32_t *flags, int32_t *list3,
+                              int32_t *counts, void *stream) {
+  if (S < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(nm_collect_kernel, dim3(1), dim3(NM_NT), 0,
+                     rvs_stream(stream), S, flags, list3, counts);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rvs_nm_shrink_point(int N, int k, double *sim,
+                                   const int32_t *list3, double *X3,
+                                   const int32_t *counts, int jbound,
+                                   void *stream) {
+  if (N < 1 || N > NM_MAXN || k < 1 || k > N || jbound < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(nm_shrink_point_kernel, dim3((jbound + 255) / 256),
+                     dim3(256), 0, rvs_stream(stream), N, k, sim, list3, X3,
+                     counts, jbound);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rvs_nm_shrink_store(int N, int k, double *sim, double *fsim,
+                                   int32_t *nit, int32_t *nfev, int32_t *flags,
+                                   const int32_t *list3, const double *F3,
+                                   int32_t *counts, int jbound, void *stream) {
+  if (N < 1 || N > NM_MAXN || k < 1 || k > N || jbound < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(nm_shrink_store_kernel, dim3((jbound + 255) / 256),
+                     dim3(256), 0, rvs_stream(stream), N, k, sim, fsim, nit,
+                     nfev, flags, list3, F3, counts, jbound);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// vel_fit.ParamMapper.forward + the range / finiteness guard of chisq_func +
+// VSiniMapper.to_vsini + the Normal priors of chisq_func0 (vel_fit.py:95-254)
+// for J rows of the optimiser's parameter vectors.
+//   X [J, n]: (vel, [vsini], free stellar parameters in specParams order)
+//   src [ndim]: column of X feeding stellar parameter i, or -1 = fixed
+//   fixed [S, ndim], vsini_fixed [S] (used when vsini_col < 0, nullable = no
+//   rotation), prior_mean / prior_isig [S, ndim] (nullable; isig 0 = no prior)
+// out: job_spec[j] = list[j], vel, vsini (nullable), params [J, ndim],
+//      extra[j] = vsini penalty + priors, bad[j] (row answered with 1e30; its
+//      vel/params are replaced by vel 0 / the fixed+start values `safe`)
+// ---------------------------------------------------------------------------
+struct MapSrc {
+  int src[NM_MAXN];
+};
+
+__global__ void __launch_bounds__(256)
+    proc_map_kernel(int J, int n, int ndim, const double *__restrict__ X,
+                    const int32_t *__restrict__ list, MapSrc M, int vsini_col,
+                    const double *__restrict__ fixed,
+                    const double *__restrict__ vsini_fixed,
+                    const double *__restrict__ safe,
+                    const double *__restrict__ prior_mean,
+                    const double *__restrict__ prior_isig, double min_vel,
+                    double max_vel, double max_vsini,
+                    int32_t *__restrict__ job_spec, double *__restrict__ vel,
+                    double *__restrict__ vsini, double *__restrict__ params,
+                    double *__restrict__ extra, int32_t *__restrict__ bad) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= J) return;
+  const int r = list[j];
+  const double *x = X + (int64_t)j * n;
+  double v = x[0];
+  double pen = 0;
+  if (vsini) {
+    double vs;
+    if (vsini_col >= 0) {
+      const double v0 = x[vsini_col];
+      vs = fmin(fmax(v0, 0.0), max_vsini);  // np.clip
+      if (v0 < 0 || v0 > max_vsini) pen += (vs - v0) * (vs - v0);
+      if (v0 != v0) vs = v0;
+    } else {
+      vs = vsini_fixed[r];
+    }
+    vsini[j] = vs;
+  }
+  bool isbad = (v > max_vel) || (v < min_vel);
+  double p[NM_MAXN];
+  for (int i = 0; i < ndim; i++) {
+    p[i] = (M.src[i] >= 0) ? x[M.src[i]] : fixed[(int64_t)r * ndim + i];
+    if (!(fabs(p[i]) <= 1.79e308)) isbad = true;
+  }
+  if (isbad) {
+    v = 0;
+    for (int i = 0; i < ndim; i++) p[i] = safe[(int64_t)r * ndim + i];
+  }
+  if (prior_mean)
+    for (int i = 0; i < ndim; i++) {
+      const double d = (prior_mean[(int64_t)r * ndim + i] - p[i]) *
+                       prior_isig[(int64_t)r * ndim + i];
+      pen += d * d;
+    }
+  job_spec[j] = r;
+  vel[j] = v;
+  for (int i = 0; i < ndim; i++) params[(int64_t)j * ndim + i] = p[i];
+  extra[j] = pen;
+  bad[j] = isbad ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+    proc_finish_kernel(int J, const int32_t *__restrict__ counts, int cidx,
+                       const double *__restrict__ chi,
+                       const double *__restrict__ extra,
+                       const int32_t *__restrict__ bad,
+                       const int32_t *__restrict__ job_spec,
+                       const int32_t *__restrict__ job_status,
+                       double *__restrict__ F,
+                       int32_t *__restrict__ spec_status) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= J) return;
+  F[j] = bad[j] ? 1e30 : chi[j] + extra[j];
+  const int live = counts ? counts[cidx] : J;
+  if (j < live && job_status[j] && !bad[j])
+    atomicOr(&spec_status[job_spec[j]], job_status[j]);
+}
+
+extern "C" int rvs_proc_map(int J, int n, int ndim, const double *X,
+                            const int32_t *list, const int32_t *src,
+                            int vsini_col, const double *fixed,
+                            const double *vsini_fixed, const double *safe,
+                            const double *prior_mean, const double *prior_isig,
+                            double min_vel, double max_vel, double max_vsini,
+                            int32_t *job_spec, double *vel, double *vsini,
+                            double *params, double *extra, int32_t *bad,
+                            void *stream) {
+  if (J < 1 || n < 1 || n > NM_MAXN || ndim < 1 || ndim > NM_MAXN)
+    return RVS_E_ARG;
+  MapSrc M;
+  for (int i = 0; i < NM_MAXN; i++) M.src[i] = (i < ndim) ? src[i] : -1;
+  hipLaunchKernelGGL(proc_map_kernel, dim3((J + 255) / 256), dim3(256), 0,
+                     rvs_stream(stream), J, n, ndim, X, list, M, vsini_col,
+                     fixed, vsini_fixed, safe, prior_mean, prior_isig, min_vel,
+                     max_vel, max_vsini, job_spec, vel, vsini, params, extra,
+                     bad);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rvs_proc_finish(int J, const int32_t *counts, int cidx,
+                               const double *chi, const double *extra,
+                               const int32_t *bad, const int32_t *job_spec,
+                               const int32_t *job_status, double *F,
+                               int32_t *spec_status, void *stream) {
+  if (J < 1) return RVS_E_ARG;
+  hipLaunchKernelGGL(proc_finish_kernel, dim3((J + 255) / 256), dim3(256), 0,
+                     rvs_stream(stream), J, counts, cidx, chi, extra, bad,
+                     job_spec, job_status, F, spec_status);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}

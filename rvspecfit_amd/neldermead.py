@@ -66,7 +66,9 @@ def minimize(func, simplex, fatol=1e-3, xatol=1e-2, maxiter=10000,
         xbar = s[:, 0].clone()
         for j in range(1, N):
             xbar = xbar + s[:, j]
-        xbar = xbar / N
+        # a true division: torch's GPU kernel turns `tensor / python_scalar`
+        # into a multiplication by the reciprocal, numpy does not
+        xbar = xbar / torch.full_like(xbar, N)
         worst = s[:, -1]
         xr = (1 + RHO) * xbar - RHO * worst
         fxr = func(idx, xr.contiguous())

@@ -1,0 +1,268 @@
+"""Device-resident optimiser stage of vel_fit.process.
+
+`DeviceNelderMead` drives the rvs_nm_* kernels (csrc/nm.hip): the S simplices
+and all their bookkeeping live in HBM, a round is a fixed sequence of launches
+whose job counts are read on the device, and the host only looks at the counts
+every `sync_every` rounds (to shrink its launch bound, to run parked shrinks and
+to notice that everything has converged).  `ProcessObjective` is chisq_func of
+vel_fit.py:229-254 as a fixed launch sequence on preallocated buffers:
+rvs_proc_map -> per arm rvs_template_polylinear, rvs_vsini_convolve,
+rvs_spline_construct -> rvs_chisq_point (all arms) -> rvs_proc_finish.
+
+The pure-torch neldermead.minimize is the same state machine (and is what the
+tests compare with scipy); this module exists because its ~70 small torch
+calls and three host synchronisations per round cost more than the GPU work.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class ProcessObjective:
+    """chisq_func for rows (list[j], X[j]) on preallocated buffers."""
+
+    def __init__(self, batch, libs, names, pd0, fixParam, fitVsini, config,
+                 options, priors, safe_params):
+        L = _lib.lib()
+        self.L = L
+        self.batch, self.libs = batch, libs
+        dev = batch.device
+        S = batch.S
+        self.S, self.dev = S, dev
+        self.npoly = options.get('npoly') or 5
+        self.rbf = options.get('rbf_continuum', True)
+        self.ndim = len(names)
+        for arm in batch.arms:
+            if libs[arm.name].kind != 'regulargrid':
+                raise NotImplementedError('device optimiser: polylinear only')
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        # parameter vector layout (vel, [vsini], free stellar parameters)
+        k = 1
+        self.vsini_col = -1
+        self.has_vsini = 'vsini' in pd0
+        if fitVsini:
+            self.vsini_col = k
+            k += 1
+        src = []
+        for x in names:
+            if x in fixParam:
+                src.append(-1)
+            else:
+                src.append(k)
+                k += 1
+        self.n = k
+        self.src = (ctypes.c_int32 * self.ndim)(*src)
+        self.fixed = torch.stack([pd0[_] for _ in names], dim=1).contiguous()
+        self.vsini_fixed = pd0['vsini'].contiguous() if (
+            self.has_vsini and not fitVsini) else None
+        self.safe = safe_params.contiguous()
+        self.prior_mean = self.prior_isig = None
+        if priors:
+            pm = torch.zeros((S, self.ndim), **f64)
+            ps = torch.zeros((S, self.ndim), **f64)
+            for i, x in enumerate(names):
+                if x in priors:
+                    m, sg = priors[x]
+                    pm[:, i] = torch.as_tensor(m, **f64)
+                    ps[:, i] = 1.0 / torch.as_tensor(sg, **f64)
+            self.prior_mean, self.prior_isig = pm, ps
+        self.min_vel, self.max_vel = float(config['min_vel']), float(
+            config['max_vel'])
+        self.max_vsini = float(config['max_vsini'])
+        cap = S
+        self.cap = cap
+        self.job_spec = torch.zeros(cap, **i32)
+        self.vel = torch.zeros(cap, **f64)
+        self.vsini = torch.zeros(cap, **f64) if self.has_vsini else None
+        self.params = torch.zeros((cap, self.ndim), **f64)
+        self.extra = torch.zeros(cap, **f64)
+        self.bad = torch.zeros(cap, **i32)
+        self.chi = torch.zeros(cap, **f64)
+        self.jstatus = torch.zeros(cap, **i32)
+        self.status = torch.zeros(S, **i32)
+        self.arm_buf = []
+        narm = len(batch.arms)
+        self.arr = (_lib.PointArm * narm)()
+        self.badchi = float(batch.badchi)
+        for ia, arm in enumerate(batch.arms):
+            lib = libs[arm.name]
+            b = dict(templ=torch.empty((cap, lib.ntp), **f64),
+                     templ2=torch.empty((cap, lib.ntp), **f64)
+                     if self.has_vsini else None,
+                     coef=torch.empty((cap, lib.ntp, 4), **f64),
+                     outside=torch.empty(cap, **f64),
+                     pen=torch.empty(cap, **f64),
+                     work=arm.work(lib, 0.0), polysT=arm.basis(self.npoly,
+                                                               self.rbf))
+            self.arm_buf.append(b)
+            a = self.arr[ia]
+            a.lam, a.polysT = arm.lam.data_ptr(), b['polysT'].data_ptr()
+            a.spec, a.espec = arm.spec.data_ptr(), arm.espec.data_ptr()
+            a.work, a.knots = b['work'].data_ptr(), lib.knots.data_ptr()
+            a.coef, a.penalty = b['coef'].data_ptr(), b['pen'].data_ptr()
+            a.npix, a.S, a.ntp = arm.npix, arm.S, lib.ntp
+            a.log_step = int(lib.log_step)
+        nb = L.rvs_chisq_point_work_size(self.npoly, cap, narm)
+        self.scratch = torch.empty(nb // 8, **f64)
+        self.calls = 0
+        self.jobs = 0
+
+    def eval(self, list_t, X, J, counts, cidx, F):
+        """F[:J] = chisq_func(X[j]) for spectrum list_t[j]; rows >= the device
+        count are padding (evaluated, ignored)."""
+        L = self.L
+        st = _lib.stream()
+        rc = L.rvs_proc_map(J, self.n, self.ndim, _p(X), _p(list_t), self.src,
+                            self.vsini_col, _p(self.fixed),
+                            _p(self.vsini_fixed), _p(self.safe),
+                            _p(self.prior_mean), _p(self.prior_isig),
+                            self.min_vel, self.max_vel, self.max_vsini,
+                            _p(self.job_spec), _p(self.vel), _p(self.vsini),
+                            _p(self.params), _p(self.extra), _p(self.bad), st)
+        _lib.check(rc, 'rvs_proc_map')
+        for arm, b in zip(self.batch.arms, self.arm_buf):
+            lib = self.libs[arm.name]
+            rc = L.rvs_template_polylinear(
+                _p(lib.dats), lib.ngrid, lib.ntp, _p(lib.idgrid), _p(lib.uvecs),
+                _lib.ptr(lib.lens), lib.ndim, _p(lib.vecs_s),
+                _lib.ptr(lib.inv_ptp), lib.log_mask, lib.exp_flag,
+                _p(self.params), J, _p(b['templ']), _p(b['outside']), None, None,
+                st)
+            _lib.check(rc, 'rvs_template_polylinear')
+            y = b['templ']
+            if self.has_vsini:
+                rc = L.rvs_vsini_convolve(_p(y), _p(self.vsini), _p(b['outside']),
+                                          lib.lnstep, 0.6, lib.ntp, J,
+                                          _p(b['templ2']), st)
+                _lib.check(rc, 'rvs_vsini_convolve')
+                y = b['templ2']
+            rc = L.rvs_spline_construct(_p(lib.knots), _p(y), lib.ntp, J,
+                                        lib.spline_form, _p(b['coef']), st)
+            _lib.check(rc, 'rvs_spline_construct')
+            torch.mul(b['outside'], self.badchi, out=b['pen'])
+        self.jstatus.zero_()
+        rc = L.rvs_chisq_point(ctypes.addressof(self.arr), len(self.arm_buf),
+                               self.npoly, _p(self.job_spec), None, J,
+                               _p(self.vel), self.badchi, 0.0, _p(self.scratch),
+                               _p(self.chi), _p(self.jstatus), st)
+        _lib.check(rc, 'rvs_chisq_point')
+        rc = L.rvs_proc_finish(J, _p(counts), cidx, _p(self.chi), _p(self.extra),
+                               _p(self.bad), _p(self.job_spec), _p(self.jstatus),
+                               _p(F), _p(self.status), st)
+        _lib.check(rc, 'rvs_proc_finish')
+        self.calls += 1
+        self.jobs += J
+
+
+class DeviceNelderMead:
+
+    def __init__(self, S, N, dev):
+        self.S, self.N, self.dev = S, N, dev
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.fsim = torch.empty((S, N + 1), **f64)
+        self.nit = torch.ones(S, **i32)
+        self.nfev = torch.full((S, ), N + 1, **i32)
+        self.flags = torch.ones(S, **i32)
+        self.list1 = torch.zeros(S, **i32)
+        self.list2 = torch.zeros(S, **i32)
+        self.list3 = torch.zeros(S, **i32)
+        self.X1 = torch.zeros((S, N), **f64)
+        self.X2 = torch.zeros((S, N), **f64)
+        self.F1 = torch.zeros(S, **f64)
+        self.F2 = torch.zeros(S, **f64)
+        self.cases = torch.zeros(S, **i32)
+        self.pos2 = torch.zeros(S, **i32)
+        self.counts = torch.zeros(8, **i32)
+
+    def minimize(self, objective, simplex, fatol=1e-3, xatol=1e-2,
+                 maxiter=10000, sync_every=4, stats=None):
+        from .neldermead import _order
+        L = _lib.lib()
+        S, N = self.S, self.N
+        sim = simplex.clone().to(torch.float64).contiguous()
+        allidx = torch.arange(S, dtype=torch.int32, device=self.dev)
+        for k in range(N + 1):
+            self.X1.copy_(sim[:, k])
+            objective.eval(allidx, self.X1, S, None, 0, self.F1)
+            self.fsim[:, k] = self.F1
+        sim, fsim = _order(sim, self.fsim)
+        sim = sim.contiguous()
+        self.fsim.copy_(fsim)
+        fs = self.fsim
+        st = _lib.stream()
+        jb = S
+        rounds = 0
+        while True:
+            rc = L.rvs_nm_begin(S, N, xatol, fatol, maxiter, _p(sim), _p(fs),
+                                _p(self.nit), _p(self.flags), _p(self.list1),
+                                _p(self.X1), _p(self.counts), jb, st)
+            _lib.check(rc, 'rvs_nm_begin')
+            if rounds % sync_every == 0:
+                c = self.counts.cpu().numpy()
+                live, parked = int(c[0]), int(c[4])
+                if parked > 0:
+                    self._shrink(objective, sim, parked)
+                    continue  # re-run begin: the shrunk simplices step again
+                if live == 0:
+                    break
+                jb = live
+            rounds += 1
+            objective.eval(self.list1, self.X1, jb, self.counts, 0, self.F1)
+            rc = L.rvs_nm_decide(N, _p(sim), _p(fs), _p(self.list1),
+                                 _p(self.F1), _p(self.cases), _p(self.pos2),
+                                 _p(self.list2), _p(self.X2), _p(self.counts), jb,
+                                 st)
+            _lib.check(rc, 'rvs_nm_decide')
+            objective.eval(self.list2, self.X2, jb, self.counts, 1, self.F2)
+            rc = L.rvs_nm_update(N, _p(sim), _p(fs), _p(self.nit),
+                                 _p(self.nfev), _p(self.list1), _p(self.X1),
+                                 _p(self.F1), _p(self.cases), _p(self.pos2),
+                                 _p(self.X2), _p(self.F2), _p(self.flags),
+                                 _p(self.counts), jb, st)
+            _lib.check(rc, 'rvs_nm_update')
+        if stats is not None:
+            stats['rounds'] = stats.get('rounds', 0) + rounds
+        success = (self.flags & 2) != 0
+        return dict(x=sim[:, 0].clone(), fun=fs.min(dim=1)[0],
+                    nit=self.nit.long(), nfev=self.nfev.long(), success=success,
+                    final_simplex=(sim, fs))
+
+    def _shrink(self, objective, sim, parked):
+        """scipy's shrink step for the parked simplices: N objective calls"""
+        L = _lib.lib()
+        N = self.N
+        st = _lib.stream()
+        rc = L.rvs_nm_collect(self.S, _p(self.flags), _p(self.list3),
+                              _p(self.counts), st)
+        _lib.check(rc, 'rvs_nm_collect')
+        jb = parked
+        for k in range(1, N + 1):
+            rc = L.rvs_nm_shrink_point(N, k, _p(sim), _p(self.list3),
+                                       _p(self.X2), _p(self.counts), jb, st)
+            _lib.check(rc, 'rvs_nm_shrink_point')
+            objective.eval(self.list3, self.X2, jb, self.counts, 2, self.F2)
+            rc = L.rvs_nm_shrink_store(N, k, _p(sim), _p(self.fsim),
+                                       _p(self.nit), _p(self.nfev),
+                                       _p(self.flags), _p(self.list3),
+                                       _p(self.F2), _p(self.counts), jb, st)
+            _lib.check(rc, 'rvs_nm_shrink_store')
+
+
+class TorchObjective:
+    """adapter: a torch callable f(idx long [J], X [J,N]) -> [J] behind the
+    ProcessObjective.eval interface (tests of DeviceNelderMead)"""
+
+    def __init__(self, func):
+        self.func = func
+
+    def eval(self, list_t, X, J, counts, cidx, F):
+        F[:J] = self.func(list_t[:J].long(), X[:J])

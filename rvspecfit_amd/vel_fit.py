@@ -286,6 +286,10 @@ def _uncertainties_from_hessian(hessian):
     return diag_err, hessian_inv, bad_hessian
 
 
+# lock-step simplices driven by the rvs_nm_* kernels (optimizer.py); False = the
+# pure-torch state machine of neldermead.py (same path, ~3x slower)
+USE_DEVICE_NM = True
+
 _SIMPLEX_STD = {'logg': 0.5, 'teff': 300, 'feh': 0.5, 'alpha': 0.25}
 HESS_BASE_STEP = {'vsini': 1 / 100, 'logg': 0.1 / 100, 'feh': 0.1 / 100,
                   'alpha': .01 / 100, 'teff': 1 / 100, 'vrad': 1 / 100}
@@ -460,8 +464,21 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
     obj.safe_params = curparam
     stats = {}
     # vel_fit.py:624-649: a second run restarts from the final simplex
-    nm = neldermead.minimize(obj, simplex, fatol=1e-3, xatol=1e-2,
-                             maxiter=10000, stats=stats)
+    libs = spec_inter.get_libs(batch.names, config)
+    use_device_nm = USE_DEVICE_NM and all(
+        libs[a.name].kind == 'regulargrid' for a in batch.arms)
+    if use_device_nm:
+        from . import optimizer
+        pobj = optimizer.ProcessObjective(batch, libs, names, pd0, fixParam,
+                                          fitVsini, config, options, priors,
+                                          curparam)
+        nm = optimizer.DeviceNelderMead(S, simplex.shape[2], dev).minimize(
+            pobj, simplex, fatol=1e-3, xatol=1e-2, maxiter=10000, stats=stats)
+        obj.status |= pobj.status
+        obj.nfev += pobj.jobs
+    else:
+        nm = neldermead.minimize(obj, simplex, fatol=1e-3, xatol=1e-2,
+                                 maxiter=10000, stats=stats)
     success = nm['success']
     x, nit, nfev = nm['x'], nm['nit'], nm['nfev']
     redo = torch.nonzero(~success).reshape(-1)

@@ -96,11 +96,16 @@ int rvs_vsini_convolve(const double *templ, const double *vsini,
  *     the form the fused chi^2 kernels consume.  form | 2: the caller asserts
  *     that neighbouring knot spacings agree to ~1 % (uniform or log-uniform
  *     grids, what `evaler` requires anyway): both Thomas recurrences then
- *     contract by ~0.27 per row and are evaluated in independent 40-row-overlap
- *     windows (error < 1e-22 relative) instead of by exact chunk carries.
+ *     contract by ~0.27 per row and are evaluated in independent 32-row-overlap
+ *     windows (error < 1e-18 relative) instead of by exact chunk carries; this
+ *     needs `factors` [5*ntp] from rvs_spline_factors (pivots, h, 1/h of the
+ *     knot grid, computed once per template grid); NULL otherwise.
  * ---------------------------------------------------------------------- */
+int rvs_spline_factors(const double *knots, int ntp, double *factors,
+                       void *stream);
 int rvs_spline_construct(const double *knots, const double *ys, int ntp, int B,
-                         int form, double *coef, void *stream);
+                         int form, const double *factors, double *coef,
+                         void *stream);
 
 /* A7  replaces `evaler` (src/spliner.c:71-108) for B splines sharing the
  * knots: ret[b, i] = S_b(evalx[b, i]); pos (nullable) receives the integer
@@ -195,7 +200,7 @@ int rvs_chisq_continuum(const double *polysT, const double *spec,
  * A11 at one velocity per job: the objective of the optimiser stage,
  * chisq_func0 (vel_fit.py:205-226) = get_chisq (spec_fit.py:797-989) for J
  * (spectrum, template, velocity) triples, ALL arms of the spectrum in one
- * launch set.  One lane per job, one wave per (pixel slice, arm); the residual
+ * launch.  One 256-thread block per (job, arm), threads = pixels; the residual
  * norm ||D - a.ST||^2 is formed explicitly (spec_fit.py:249) so the value can
  * be finite-differenced (Hessian, vel_fit.py:699-725).
  * Per arm (plain struct of device pointers, passed by value from the host):
@@ -203,7 +208,7 @@ int rvs_chisq_continuum(const double *polysT, const double *spec,
  *   spec, espec [S, npix], work = the rvs_chisq_prepare buffer of the arm,
  *   knots [ntp], coef [Tn, ntp, 4] form-1 records, penalty [J] (nullable;
  *   a NaN/inf entry means "template unusable": + 1000*badchi, arm skipped).
- * scratch: rvs_chisq_point_work_size(npoly, J, narm) bytes.
+ * scratch: rvs_chisq_point_work_size(J, narm) bytes.
  * out[j] = sum over arms of (chisq + penalty).
  * ---------------------------------------------------------------------- */
 #define RVS_MAX_ARMS 4
@@ -211,7 +216,7 @@ typedef struct rvs_point_arm {
   const double *lam, *polysT, *spec, *espec, *work, *knots, *coef, *penalty;
   int32_t npix, S, ntp, log_step;
 } rvs_point_arm;
-int64_t rvs_chisq_point_work_size(int npoly, int J, int narm);
+int64_t rvs_chisq_point_work_size(int J, int narm);
 int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
                     const int32_t *job_spec, const int32_t *job_templ, int J,
                     const double *vel, double badchi, double espec_sys,

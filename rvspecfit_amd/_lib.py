@@ -24,7 +24,8 @@ SIGNATURES = {
     'rvs_template_polylinear': (I, [P, L, I, P, P, P, I, P, P, U, I, P, I, P, P,
                                     P, P, P]),
     'rvs_vsini_convolve': (I, [P, P, P, D, D, I, I, P, P]),
-    'rvs_spline_construct': (I, [P, P, I, I, I, P, P]),
+    'rvs_spline_factors': (I, [P, I, P, P]),
+    'rvs_spline_construct': (I, [P, P, I, I, I, P, P, P]),
     'rvs_spline_eval': (I, [P, P, I, I, P, I, I, P, P, P, P]),
     'rvs_chisq_work_size': (L, [I, I]),
     'rvs_chisq_prepare': (I, [P, P, P, I, I, P, I, D, P, P]),
@@ -34,7 +35,7 @@ SIGNATURES = {
                            P, D, P, P, P, P, P, P, P, P]),
     'rvs_chisq_continuum_work_size': (L, [I, I]),
     'rvs_chisq_continuum': (I, [P, P, P, P, I, I, I, P, P, P, P, P, P]),
-    'rvs_chisq_point_work_size': (L, [I, I, I]),
+    'rvs_chisq_point_work_size': (L, [I, I]),
     'rvs_chisq_point': (I, [P, I, I, P, P, I, P, D, D, P, P, P, P]),
     'rvs_nm_begin': (I, [I, I, D, D, I, P, P, P, P, P, P, P, I, P]),
     'rvs_nm_decide': (I, [I, P, P, P, P, P, P, P, P, P, I, P]),

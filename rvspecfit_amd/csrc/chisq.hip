@@ -1019,16 +1019,16 @@ extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
 
 // ---------------------------------------------------------------------------
 // A11 at ONE velocity per job (the optimiser's objective, vel_fit.py:205-254):
-// one LANE per job (spectrum idx, own template, own velocity), one WAVE per
-// (64 jobs, pixel slice, arm) -- the velocity-grid kernel would run one lane of
-// 64 here.  All arms of the spectrum go in ONE launch set (grid.z = arm):
-//   normal : per-slice partial normal equations      part[arm][slice][NV][J]
-//   solve  : fold the slices in order, Cholesky, coefficients a[arm][P][J]
-//   resid  : per-slice ||D - a.ST||^2 (formed explicitly, spec_fit.py:249, so
-//            the value has no D.D - y.y cancellation and can be
-//            finite-differenced at any S/N)          res[arm][slice][J]
-//   fold   : slices and arms summed in order, penalties, status.
-// scratch per arm: nsl*NV*J + (P+2)*J + nsl*J doubles, NV = P(P+1)/2 + P.
+// one 256-thread BLOCK per (job, arm) -- job = (spectrum idx, own template, own
+// velocity) -- threads = pixels, all arms in one launch (grid.y).  Every global
+// read is coalesced (spectrum row, basis rows, spline records of neighbouring
+// pixels); the P(P+1)/2 + P normal-equation sums are kept per lane, folded
+// across each wave with 64-lane butterflies and across the four waves through
+// LDS in a fixed order (the velocity-grid kernel needs no reduction because a
+// lane owns a velocity; with ONE velocity it would run 1 lane of 64).  Wave 0
+// factors the P x P matrix, and a second pass over the pixels forms the
+// residual norm ||D - a.ST||^2 explicitly (spec_fit.py:249): no D.D - y.y
+// cancellation, so the value can be finite-differenced at any S/N.
 // ---------------------------------------------------------------------------
 struct PointArms {
   rvs_point_arm a[RVS_MAX_ARMS];
@@ -1048,179 +1048,126 @@ __device__ __forceinline__ double point_tv(const rvs_point_arm &T,
   return fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
 }
 
-__host__ __device__ static inline int64_t point_arm_doubles(int P, int J,
-                                                            int nsl) {
-  const int64_t nv = (int64_t)P * (P + 1) / 2 + P;
-  return (int64_t)nsl * nv * J + (int64_t)(P + 2) * J + (int64_t)nsl * J;
-}
-
 template <int P>
-__global__ void __launch_bounds__(64)
-    point_normal_kernel(PointArms A, const int32_t *__restrict__ job_spec,
-                        const int32_t *__restrict__ job_templ, int J,
-                        const double *__restrict__ vel, double espec_sys,
-                        int nsl, double *__restrict__ scratch) {
+__global__ void __launch_bounds__(256)
+    point_block_kernel(PointArms A, const int32_t *__restrict__ job_spec,
+                       const int32_t *__restrict__ job_templ, int J,
+                       const double *__restrict__ vel, double espec_sys,
+                       double *__restrict__ armchi,
+                       int32_t *__restrict__ armst) {
   constexpr int NT = P * (P + 1) / 2;
-  const rvs_point_arm &T = A.a[blockIdx.z];
-  const int npix = T.npix;
-  const int j0 = blockIdx.x * 64 + threadIdx.x;
-  const bool active = j0 < J;
-  const int j = active ? j0 : J - 1;
+  constexpr int NV = NT + P;
+  __shared__ double red[4][NV + 1];
+  __shared__ double coefs[P + 2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x;
+  const rvs_point_arm &T = A.a[blockIdx.y];
   const int s = job_spec ? job_spec[j] : j;
   const int t = job_templ ? job_templ[j] : j;
-  const int sl = blockIdx.y;
-  const int k0 = (int)((int64_t)npix * sl / nsl);
-  const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
+  const double bb = vel[j] / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double sys2 = espec_sys * espec_sys;
+  const int npix = T.npix;
   const double *sp = T.spec + (int64_t)s * npix;
   const double *es = T.espec + (int64_t)s * npix;
   const double4 *cf = reinterpret_cast<const double4 *>(T.coef) +
                       (int64_t)t * T.ntp;
-  const double bb = vel[j] / RVS_C_KMS;
-  const double f = sqrt((1.0 - bb) / (1.0 + bb));
-  const double x0 = T.knots[0];
+  const double x0 = T.knots[0], xlast = T.knots[T.ntp - 1];
   const double shift = T.log_step ? log(f) / log(T.knots[1] / x0) : 0.0;
   const double lin_inv_step = T.log_step ? 0.0 : 1.0 / (T.knots[1] - x0);
-  const double sys2 = espec_sys * espec_sys;
   double acc[NT];
   double av[P];
 #pragma unroll
   for (int i = 0; i < NT; i++) acc[i] = 0;
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = 0;
-  for (int k = k0; k < k1; k++) {
+  for (int k = threadIdx.x; k < npix; k += 256) {
     const double tv = point_tv(T, cf, k, f, shift, x0, lin_inv_step);
     double e = es[k];
     if (espec_sys > 0) e = sqrt(sys2 + e * e);
     const double ie = 1.0 / e;
     const double te = tv * ie;
-    const double w = te * te, u = te * (sp[k] * ie);
+    const double wt = te * te, u = te * (sp[k] * ie);
     const double *pr = T.polysT + (int64_t)k * P;
-    double pw[P];
-#pragma unroll
-    for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
+    double pv[P], pw[P];
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      av[i] = fma(pr[i], u, av[i]);
+      pv[i] = pr[i];
+      pw[i] = pv[i] * wt;
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      av[i] = fma(pv[i], u, av[i]);
 #pragma unroll
       for (int jj = 0; jj <= i; jj++)
-        acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
+        acc[TRI(i, jj)] = fma(pv[i], pw[jj], acc[TRI(i, jj)]);
     }
   }
-  if (!active) return;
-  double *part = scratch + (int64_t)blockIdx.z * point_arm_doubles(P, J, nsl);
-  double *o = part + (int64_t)sl * (NT + P) * J + j;
 #pragma unroll
-  for (int i = 0; i < NT; i++) o[(int64_t)i * J] = acc[i];
+  for (int i = 0; i < NT; i++) {
+    const double v = wave_sum(acc[i]);
+    if (lane == 0) red[w][i] = v;
+  }
 #pragma unroll
-  for (int i = 0; i < P; i++) o[(int64_t)(NT + i) * J] = av[i];
-}
-
-// fold + factor + solve: 256 threads = 4 waves per 64 jobs; each wave folds a
-// quarter of the NV values over the slices (in slice order), hands them over
-// through LDS, wave 0 does the in-lane Cholesky and the two triangular solves
-template <int P>
-__global__ void __launch_bounds__(256)
-    point_solve_kernel(int J, int nsl, double *__restrict__ scratch) {
-  constexpr int NT = P * (P + 1) / 2;
-  constexpr int NV = NT + P;
-  __shared__ double sh[NV][65];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int j0 = blockIdx.x * 64 + lane;
-  const bool active = j0 < J;
-  const int j = active ? j0 : J - 1;
-  double *base = scratch + (int64_t)blockIdx.z * point_arm_doubles(P, J, nsl);
-  const double *part = base;
-  double *sol = base + (int64_t)nsl * NV * J;  // [P+2][J]
-  for (int v = w; v < NV; v += 4) {
-    double sum = 0;
-    for (int q = 0; q < nsl; q++)
-      sum += part[((int64_t)q * NV + v) * J + j];
-    sh[v][lane] = sum;
+  for (int i = 0; i < P; i++) {
+    const double v = wave_sum(av[i]);
+    if (lane == 0) red[w][NT + i] = v;
   }
   __syncthreads();
-  if (w != 0) return;
-  double acc[NT];
-  double av[P];
+  if (w == 0) {
+    // every lane of wave 0 factors the same matrix (waves summed in order)
 #pragma unroll
-  for (int i = 0; i < NT; i++) acc[i] = sh[i][lane];
+    for (int i = 0; i < NT; i++)
+      acc[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
 #pragma unroll
-  for (int i = 0; i < P; i++) av[i] = sh[NT + i][lane];
-  bool ok = true;
-  double ldet = 0;
+    for (int i = 0; i < P; i++)
+      av[i] = ((red[0][NT + i] + red[1][NT + i]) + red[2][NT + i]) +
+              red[3][NT + i];
+    bool ok = true;
+    double ldet = 0;
 #pragma unroll
-  for (int i = 0; i < P; i++) {
+    for (int i = 0; i < P; i++) {
 #pragma unroll
-    for (int jj = 0; jj <= i; jj++) {
-      double sum = acc[TRI(i, jj)];
+      for (int jj = 0; jj <= i; jj++) {
+        double sum = acc[TRI(i, jj)];
 #pragma unroll
-      for (int q = 0; q < jj; q++) sum -= acc[TRI(i, q)] * acc[TRI(jj, q)];
-      if (jj == i) {
-        if (!(sum > 0)) ok = false;
-        const double d = sqrt(sum);
-        acc[TRI(i, i)] = d;
-        ldet += log(d);
-      } else {
-        acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
+        for (int q = 0; q < jj; q++) sum -= acc[TRI(i, q)] * acc[TRI(jj, q)];
+        if (jj == i) {
+          if (!(sum > 0)) ok = false;
+          const double d = sqrt(sum);
+          acc[TRI(i, i)] = d;
+          ldet += log(d);
+        } else {
+          acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
+        }
       }
     }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      double sum = av[i];
+#pragma unroll
+      for (int q = 0; q < i; q++) sum -= acc[TRI(i, q)] * av[q];
+      av[i] = sum / acc[TRI(i, i)];
+    }
+#pragma unroll
+    for (int i = P - 1; i >= 0; i--) {
+      double sum = av[i];
+#pragma unroll
+      for (int q = i + 1; q < P; q++) sum -= acc[TRI(q, i)] * av[q];
+      av[i] = sum / acc[TRI(i, i)];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < P; i++) coefs[i] = av[i];
+      coefs[P] = ldet;
+      coefs[P + 1] = ok ? 1.0 : 0.0;
+    }
   }
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < P; i++) {
-    double sum = av[i];
-#pragma unroll
-    for (int q = 0; q < i; q++) sum -= acc[TRI(i, q)] * av[q];
-    av[i] = sum / acc[TRI(i, i)];
-  }
-#pragma unroll
-  for (int i = P - 1; i >= 0; i--) {
-    double sum = av[i];
-#pragma unroll
-    for (int q = i + 1; q < P; q++) sum -= acc[TRI(q, i)] * av[q];
-    av[i] = sum / acc[TRI(i, i)];
-  }
-  if (!active) return;
-#pragma unroll
-  for (int i = 0; i < P; i++) sol[(int64_t)i * J + j] = av[i];
-  sol[(int64_t)P * J + j] = ldet;
-  sol[(int64_t)(P + 1) * J + j] = ok ? 1.0 : 0.0;
-}
-
-template <int P>
-__global__ void __launch_bounds__(64)
-    point_resid_kernel(PointArms A, const int32_t *__restrict__ job_spec,
-                       const int32_t *__restrict__ job_templ, int J,
-                       const double *__restrict__ vel, double espec_sys,
-                       int nsl, double *__restrict__ scratch) {
-  constexpr int NT = P * (P + 1) / 2;
-  constexpr int NV = NT + P;
-  const rvs_point_arm &T = A.a[blockIdx.z];
-  const int npix = T.npix;
-  const int j0 = blockIdx.x * 64 + threadIdx.x;
-  const bool active = j0 < J;
-  const int j = active ? j0 : J - 1;
-  const int s = job_spec ? job_spec[j] : j;
-  const int t = job_templ ? job_templ[j] : j;
-  const int sl = blockIdx.y;
-  double *base = scratch + (int64_t)blockIdx.z * point_arm_doubles(P, J, nsl);
-  const double *sol = base + (int64_t)nsl * NV * J;
-  double *res = base + (int64_t)nsl * NV * J + (int64_t)(P + 2) * J;
-  double av[P];
-#pragma unroll
-  for (int i = 0; i < P; i++) av[i] = sol[(int64_t)i * J + j];
-  const int k0 = (int)((int64_t)npix * sl / nsl);
-  const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
-  const double *sp = T.spec + (int64_t)s * npix;
-  const double *es = T.espec + (int64_t)s * npix;
-  const double4 *cf = reinterpret_cast<const double4 *>(T.coef) +
-                      (int64_t)t * T.ntp;
-  const double bb = vel[j] / RVS_C_KMS;
-  const double f = sqrt((1.0 - bb) / (1.0 + bb));
-  const double x0 = T.knots[0];
-  const double shift = T.log_step ? log(f) / log(T.knots[1] / x0) : 0.0;
-  const double lin_inv_step = T.log_step ? 0.0 : 1.0 / (T.knots[1] - x0);
-  const double sys2 = espec_sys * espec_sys;
+  for (int i = 0; i < P; i++) av[i] = coefs[i];
   double rr = 0;
-  for (int k = k0; k < k1; k++) {
+  for (int k = threadIdx.x; k < npix; k += 256) {
     const double tv = point_tv(T, cf, k, f, shift, x0, lin_inv_step);
     double e = es[k];
     if (espec_sys > 0) e = sqrt(sys2 + e * e);
@@ -1232,59 +1179,58 @@ __global__ void __launch_bounds__(64)
     const double r = sp[k] * ie - m * (tv * ie);
     rr = fma(r, r, rr);
   }
-  if (active) res[(int64_t)sl * J + j] = rr;
-}
-
-__global__ void point_fold_kernel(PointArms A, int P,
-                                  const int32_t *__restrict__ job_spec, int J,
-                                  const double *__restrict__ vel, double badchi,
-                                  int nsl, const double *__restrict__ scratch,
-                                  double *__restrict__ out,
-                                  int32_t *__restrict__ status) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= J) return;
-  const int s = job_spec ? job_spec[j] : j;
-  const int64_t nv = (int64_t)P * (P + 1) / 2 + P;
-  const double bb = vel[j] / RVS_C_KMS;
-  const double f = sqrt((1.0 - bb) / (1.0 + bb));
-  double tot = 0;
-  int st = 0;
-  for (int ia = 0; ia < A.n; ia++) {
-    const rvs_point_arm &T = A.a[ia];
-    const double pen = T.penalty ? T.penalty[j] : 0.0;
-    if (!(pen == pen) || isinf(pen)) {  // spec_fit.py:888-893
-      tot += 1000.0 * badchi;
-      continue;
-    }
-    const double *base = scratch + (int64_t)ia * point_arm_doubles(P, J, nsl);
-    const double *sol = base + (int64_t)nsl * nv * J;
-    const double *res = sol + (int64_t)(P + 2) * J;
-    double rr = 0;
-    for (int q = 0; q < nsl; q++) rr += res[(int64_t)q * J + j];
-    const double lz = T.work[T.npix + 2ll * T.S * T.npix + 2 * s];
-    double chi = 2.0 * sol[(int64_t)P * J + j] + 2.0 * lz + rr;
-    const double xa = T.lam[0] * f, xb = T.lam[T.npix - 1] * f;
-    const double x0 = T.knots[0], xlast = T.knots[T.ntp - 1];
+  rr = wave_sum(rr);
+  __syncthreads();
+  if (lane == 0) red[w][0] = rr;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rr = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+    const double lz = T.work[npix + 2ll * T.S * npix + 2 * s];
+    double chi = 2.0 * coefs[P] + 2.0 * lz + rr;
+    int st = 0;
+    const double xa = T.lam[0] * f, xb = T.lam[npix - 1] * f;
     if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) {
       st |= RVS_ST_SPLINE_RANGE;
       chi = __builtin_nan("");
     }
-    const bool ok = sol[(int64_t)(P + 1) * J + j] != 0.0;
+    const bool ok = coefs[P + 1] != 0.0;
     if (!ok) st |= RVS_ST_CHOL_FALLBACK;
     if (!ok || !(fabs(chi) <= 1.79e308)) {
       st |= RVS_ST_NONFINITE;
       chi = __builtin_nan("");
     }
-    tot += chi + pen;
+    armchi[(int64_t)blockIdx.y * J + j] = chi;
+    armst[(int64_t)blockIdx.y * J + j] = st;
+  }
+}
+
+// arms summed in order; penalties of A11 (spec_fit.py:888-896)
+__global__ void point_sum_kernel(PointArms A, int J, double badchi,
+                                 const double *__restrict__ armchi,
+                                 const int32_t *__restrict__ armst,
+                                 double *__restrict__ out,
+                                 int32_t *__restrict__ status) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= J) return;
+  double tot = 0;
+  int st = 0;
+  for (int ia = 0; ia < A.n; ia++) {
+    const double *pp = A.a[ia].penalty;
+    const double pen = pp ? pp[j] : 0.0;
+    if (!(pen == pen) || isinf(pen)) {
+      tot += 1000.0 * badchi;
+      continue;
+    }
+    tot += armchi[(int64_t)ia * J + j] + pen;
+    st |= armst[(int64_t)ia * J + j];
   }
   out[j] = tot;
   if (st) atomicOr(&status[j], st);
 }
 
-extern "C" int64_t rvs_chisq_point_work_size(int npoly, int J, int narm) {
-  if (npoly < 1 || J < 1 || narm < 1) return 0;
-  return narm * point_arm_doubles(npoly, J, cont_nslice(J)) *
-         (int64_t)sizeof(double);
+extern "C" int64_t rvs_chisq_point_work_size(int J, int narm) {
+  if (J < 1 || narm < 1) return 0;
+  return (int64_t)narm * J * (int64_t)(sizeof(double) + sizeof(int32_t));
 }
 
 extern "C" int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
@@ -1293,7 +1239,7 @@ extern "C" int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
                                const double *vel, double badchi,
                                double espec_sys, void *scratch, double *out,
                                int32_t *status, void *stream) {
-  if (J < 1 || narm < 1 || narm > RVS_MAX_ARMS || !scratch || !arms)
+  if (J < 1 || narm < 1 || narm > RVS_MAX_ARMS || !arms || !scratch)
     return RVS_E_ARG;
   PointArms A;
   A.n = narm;
@@ -1303,18 +1249,13 @@ extern "C" int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
   }
   for (int i = narm; i < RVS_MAX_ARMS; i++) A.a[i] = arms[0];
   hipStream_t st = rvs_stream(stream);
-  const int nsl = cont_nslice(J);
-  double *scr = (double *)scratch;
-  dim3 grid((J + 63) / 64, nsl, narm);
-  dim3 gsolve((J + 63) / 64, 1, narm);
+  double *armchi = (double *)scratch;
+  int32_t *armst = (int32_t *)(armchi + (int64_t)narm * J);
+  dim3 grid(J, narm);
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \
-    hipLaunchKernelGGL(point_normal_kernel<PP>, grid, dim3(64), 0, st, A,      \
-                       job_spec, job_templ, J, vel, espec_sys, nsl, scr);      \
-    hipLaunchKernelGGL(point_solve_kernel<PP>, gsolve, dim3(256), 0, st, J,    \
-                       nsl, scr);                                              \
-    hipLaunchKernelGGL(point_resid_kernel<PP>, grid, dim3(64), 0, st, A,       \
-                       job_spec, job_templ, J, vel, espec_sys, nsl, scr);      \
+    hipLaunchKernelGGL(point_block_kernel<PP>, grid, dim3(256), 0, st, A,      \
+                       job_spec, job_templ, J, vel, espec_sys, armchi, armst); \
     break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
@@ -1324,8 +1265,8 @@ extern "C" int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
       return RVS_E_ARG;
   }
 #undef RVS_CASE
-  hipLaunchKernelGGL(point_fold_kernel, dim3((J + 255) / 256), dim3(256), 0, st,
-                     A, npoly, job_spec, J, vel, badchi, nsl, scr, out, status);
+  hipLaunchKernelGGL(point_sum_kernel, dim3((J + 255) / 256), dim3(256), 0, st,
+                     A, J, badchi, armchi, armst, out, status);
   RVS_LAUNCH_CHECK();
   return 0;
 }

@@ -452,92 +452,118 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 // A7 construct, windowed variant for (log-)uniform knots (form bit 1).
 // With neighbouring spacings equal to ~1 % both Thomas recurrences contract by
-// ~0.268 per row, so a row's value depends on rows further than 40 away by
-// < 1e-22: every thread can start its chunk SW_W rows early from zero and be
+// ~0.268 per row, so a row's value depends on rows further than 32 away by
+// < 1e-18: every thread can start its chunk SW_W rows early from zero and be
 // exact to rounding on its own rows -- no carries, no serial section (the
 // exact kernel above spends most of its time in two 256-step serial carries).
-// One block per (segment of SW_SEG knots, template); three barrier-separated
-// passes over LDS: pivots (knots only), forward, backward; then coalesced
-// 32-B records.
+// The pivots depend on the knots only: rvs_spline_factors computes them once
+// per template grid, so the per-template work has no division and each
+// recurrence step is one LDS read pair + one fma.
+// One block per (segment of <= SW_SEG knots, template); barrier-separated
+// passes over LDS (rhs, forward, backward), then coalesced 32-B records.
+// factors layout, 5 arrays of ntp doubles:
+//   g_u = 1/den_u, e_u = h_u/den_u (e_0 = 0), c_u = h_{u+1}/den_u (c_{m-1} = 0),
+//   h_i, 1/h_i            (u < m = ntp-2 unknowns, i < ntp-1 intervals)
+// forward: d_u = g_u rhs_u - e_u d_{u-1};  backward: z_u = d_u - c_u z_{u+1}
 // ---------------------------------------------------------------------------
-#define SW_W 40
-#define SW_SEG 2048
-#define SW_RMAX (SW_SEG + 3 * SW_W + 8)
+#define SW_W 32
+#define SW_SEG 3200
+#define SW_RMAX (SW_SEG + 2 * SW_W + 8)
+
+__global__ void spline_factors_kernel(const double *__restrict__ knots, int ntp,
+                                      double *__restrict__ fac) {
+  // one thread: the reference's own elimination order (spliner.c:20-38)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int m = ntp - 2;
+  double *g = fac, *e = fac + ntp, *cc = fac + 2 * ntp, *hh = fac + 3 * ntp,
+         *ih = fac + 4 * ntp;
+  double c = 0;
+  for (int u = 0; u < m; u++) {
+    const double h0 = knots[u + 1] - knots[u], h1 = knots[u + 2] - knots[u + 1];
+    const double den = 2 * (h1 + h0) - h0 * c;  // c == 0 at u == 0
+    const double inv = 1.0 / den;
+    c = h1 * inv;
+    g[u] = inv;
+    e[u] = (u == 0) ? 0.0 : h0 * inv;
+    cc[u] = (u == m - 1) ? 0.0 : c;
+  }
+  for (int u = m; u < ntp; u++) g[u] = e[u] = cc[u] = 0;
+  for (int i = 0; i < ntp - 1; i++) {
+    const double h = knots[i + 1] - knots[i];
+    hh[i] = h;
+    ih[i] = 1.0 / h;
+  }
+  hh[ntp - 1] = ih[ntp - 1] = 0;
+}
+
+extern "C" int rvs_spline_factors(const double *knots, int ntp, double *factors,
+                                  void *stream) {
+  if (ntp < 4) return RVS_E_ARG;
+  hipLaunchKernelGGL(spline_factors_kernel, dim3(1), dim3(64), 0,
+                     rvs_stream(stream), knots, ntp, factors);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
 
 __global__ void __launch_bounds__(256)
-    spline_construct_win_kernel(const double *__restrict__ knots,
-                                const double *__restrict__ ys, int ntp, int form,
-                                double4 *__restrict__ coef) {
-  __shared__ double ysh[SW_RMAX + 2];
-  __shared__ double idn[SW_RMAX];  // 1/den_u
-  __shared__ double dp[SW_RMAX];   // forward rhs, then z
+    spline_construct_win_kernel(const double *__restrict__ fac,
+                                const double *__restrict__ ys, int ntp, int seg,
+                                int form, double4 *__restrict__ coef) {
+  __shared__ double dp[SW_RMAX];  // g*rhs -> d -> z
+  __shared__ double ec[SW_RMAX];  // e during the forward pass, c afterwards
   const int N = ntp, m = N - 2;
+  const double *g = fac, *e = fac + N, *cc = fac + 2 * N, *hh = fac + 3 * N,
+               *ih = fac + 4 * N;
   const int b = blockIdx.y, tid = threadIdx.x;
-  const int k0 = blockIdx.x * SW_SEG, k1 = min(N, k0 + SW_SEG);
+  const int k0 = blockIdx.x * seg, k1 = min(N, k0 + seg);
   // unknown u <-> z at knot u+1; records of knots [k0,k1) need z of knots [k0,k1]
   const int u0 = max(0, k0 - 1), u1 = min(m, k1);
-  const int r0 = max(0, u0 - 2 * SW_W), r1 = min(m, u1 + SW_W);
+  const int r0 = max(0, u0 - SW_W), r1 = min(m, u1 + SW_W);
   const int nr = r1 - r0;
   const double *y = ys + (int64_t)b * N;
-  for (int i = tid; i < nr + 2; i += 256) ysh[i] = y[r0 + i];
+  for (int i = tid; i < nr; i += 256) {
+    const int u = r0 + i;
+    const double y1 = y[u + 1];
+    const double s0 = (y1 - y[u]) * ih[u], s1 = (y[u + 2] - y1) * ih[u + 1];
+    dp[i] = 6 * (s1 - s0) * g[u];
+    ec[i] = e[u];
+  }
+  __syncthreads();
   const int CH = (nr + 255) / 256;
-  const int a0 = r0 + tid * CH, a1 = min(r1, a0 + CH);
-  // pass 0: pivots.  den_u = 2(h0+h1) - h0*cp_{u-1}, cp_u = h1/den_u
-  if (a0 < a1) {
-    int s = max(0, a0 - SW_W);
-    double c = 0;
-    double xa = knots[s], xb = knots[s + 1];
-    for (int u = s; u < a1; u++) {
-      const double xc = knots[u + 2];
-      const double h0 = xb - xa, h1 = xc - xb;
-      const double den = 2 * (h1 + h0) - h0 * c;  // c == 0 at u == 0
-      const double inv = 1.0 / den;
-      c = h1 * inv;
-      if (u >= a0) idn[u - r0] = inv;
-      xa = xb;
-      xb = xc;
-    }
-  }
-  __syncthreads();
-  // pass 1: forward elimination d_u = (rhs_u - h0 d_{u-1}) / den_u
-  if (a0 < a1) {
-    int s = max(r0, a0 - SW_W);
+  const int a0 = tid * CH, a1 = min(nr, a0 + CH);  // local indices
+  double loc[16];
+  {
     double d = 0;
-    double xa = knots[s], xb = knots[s + 1];
-    double ya = ysh[s - r0], yb = ysh[s + 1 - r0];
-    double s0 = (yb - ya) / (xb - xa);
-    for (int u = s; u < a1; u++) {
-      const double xc = knots[u + 2], yc = ysh[u + 2 - r0];
-      const double h0 = xb - xa, h1 = xc - xb;
-      const double s1 = (yc - yb) / h1;
-      const double rhs = 6 * (s1 - s0);
-      d = (u == 0) ? rhs * idn[u - r0] : (rhs - h0 * d) * idn[u - r0];
-      if (u >= a0) dp[u - r0] = d;
-      xa = xb;
-      xb = xc;
-      yb = yc;
-      s0 = s1;
-    }
+    for (int i = max(0, a0 - SW_W); i < min(a0, nr); i++) d = dp[i] - ec[i] * d;
+    // own chunk: stored after the barrier so the neighbours' warm-ups read rhs
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+      if (a0 + q < a1) {
+        d = dp[a0 + q] - ec[a0 + q] * d;
+        loc[q] = d;
+      }
   }
   __syncthreads();
-  // pass 2: back substitution z_u = d_u - cp_u z_{u+1}; warm-up first (reads
-  // the neighbours' d), barrier, then the own chunk in place
-  double z = 0;
-  const int e = min(r1, a1 + SW_W);
-  if (a0 < a1) {
-    for (int u = e - 1; u >= a1; u--) {
-      const double h1 = knots[u + 2] - knots[u + 1];
-      z = (u == m - 1) ? dp[u - r0] : dp[u - r0] - h1 * idn[u - r0] * z;
-    }
+#pragma unroll
+  for (int q = 0; q < 16; q++)
+    if (a0 + q < a1) dp[a0 + q] = loc[q];
+  __syncthreads();
+  for (int i = tid; i < nr; i += 256) ec[i] = cc[r0 + i];
+  __syncthreads();
+  {
+    double z = 0;
+    for (int i = min(nr, a1 + SW_W) - 1; i >= a1; i--) z = dp[i] - ec[i] * z;
+#pragma unroll
+    for (int q = 15; q >= 0; q--)
+      if (a0 + q < a1) {
+        z = dp[a0 + q] - ec[a0 + q] * z;
+        loc[q] = z;
+      }
   }
   __syncthreads();
-  if (a0 < a1) {
-    for (int u = a1 - 1; u >= a0; u--) {
-      const double h1 = knots[u + 2] - knots[u + 1];
-      z = (u == m - 1) ? dp[u - r0] : dp[u - r0] - h1 * idn[u - r0] * z;
-      dp[u - r0] = z;
-    }
-  }
+#pragma unroll
+  for (int q = 0; q < 16; q++)
+    if (a0 + q < a1) dp[a0 + q] = loc[q];
   __syncthreads();
   // coefficients (spliner.c:52-59)
   double4 *cf = coef + (int64_t)b * N;
@@ -546,10 +572,10 @@ __global__ void __launch_bounds__(256)
       cf[i] = make_double4(0, 0, 0, 0);
       continue;
     }
-    const double h = knots[i + 1] - knots[i], hinv = 1.0 / h;
+    const double h = hh[i], hinv = ih[i];
     const double zi = (i == 0) ? 0.0 : dp[i - 1 - r0];
     const double zi1 = (i + 1 == N - 1) ? 0.0 : dp[i - r0];
-    const double yi = ysh[i - r0], yi1 = ysh[i + 1 - r0];
+    const double yi = y[i], yi1 = y[i + 1];
     const double t1 = hinv * (1.0 / 6), t2 = h * (1.0 / 6);
     if ((form & 1) == 0)
       cf[i] = make_double4(zi1 * t1, zi * t1, yi1 * hinv - zi1 * t2,
@@ -561,13 +587,17 @@ __global__ void __launch_bounds__(256)
 }
 
 extern "C" int rvs_spline_construct(const double *knots, const double *ys,
-                                    int ntp, int B, int form, double *coef,
+                                    int ntp, int B, int form,
+                                    const double *factors, double *coef,
                                     void *stream) {
   if (ntp < 4 || B < 1 || form < 0 || form > 3) return RVS_E_ARG;
   if (form & 2) {
-    dim3 grid((ntp + SW_SEG - 1) / SW_SEG, B);
+    if (!factors) return RVS_E_ARG;
+    const int nseg = (ntp + SW_SEG - 1) / SW_SEG;
+    const int seg = (ntp + nseg - 1) / nseg;
+    dim3 grid(nseg, B);
     hipLaunchKernelGGL(spline_construct_win_kernel, grid, dim3(256), 0,
-                       rvs_stream(stream), knots, ys, ntp, form,
+                       rvs_stream(stream), factors, ys, ntp, seg, form,
                        reinterpret_cast<double4 *>(coef));
     RVS_LAUNCH_CHECK();
     return 0;

@@ -261,7 +261,8 @@ def build_templates(lib, params, vsini=None, return_templ=False):
     # form 1: power-form records {y, b, c, d} consumed by the chi^2 kernels;
     # | 2: windowed solve, valid for the (log-)uniform grid of a library
     rc = L.rvs_spline_construct(_lib.ptr(lib.knots), _lib.ptr(templ), lib.ntp, J,
-                                lib.spline_form, _lib.ptr(coef), _lib.stream())
+                                lib.spline_form, _lib.ptr(lib.spline_factors),
+                                _lib.ptr(coef), _lib.stream())
     _lib.check(rc, 'rvs_spline_construct')
     if return_templ:
         return coef, outside, templ
@@ -397,8 +398,8 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
     narm = len(batch.arms)
     out = torch.empty(J, dtype=torch.float64, device=dev)
     status = torch.zeros(J, dtype=torch.int32, device=dev)
-    nb = L.rvs_chisq_point_work_size(npoly, J, narm)
-    scratch = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+    nb = L.rvs_chisq_point_work_size(J, narm)
+    scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
     arr = (_lib.PointArm * narm)()
     keep = []
     for ia, arm in enumerate(batch.arms):

@@ -49,6 +49,14 @@ class TemplateLibrary:
         hh = np.diff(self.lam)
         near_uniform = bool(np.all(np.abs(hh[1:] / hh[:-1] - 1) < 5e-3))
         self.spline_form = 3 if near_uniform else 1
+        self.spline_factors = None
+        if near_uniform and str(device) != 'cpu':
+            self.spline_factors = torch.empty(5 * self.ntp, dtype=torch.float64,
+                                              device=device)
+            rc = _lib.lib().rvs_spline_factors(
+                _lib.ptr(self.knots), self.ntp, _lib.ptr(self.spline_factors),
+                _lib.stream())
+            _lib.check(rc, 'rvs_spline_factors')
         self.kind = 'regulargrid'
         if 'dats' in d:
             idgrid = np.asarray(d['idgrid'], dtype=np.int64)

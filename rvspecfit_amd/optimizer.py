@@ -110,8 +110,11 @@ class ProcessObjective:
             a.coef, a.penalty = b['coef'].data_ptr(), b['pen'].data_ptr()
             a.npix, a.S, a.ntp = arm.npix, arm.S, lib.ntp
             a.log_step = int(lib.log_step)
-        nb = L.rvs_chisq_point_work_size(self.npoly, cap, narm)
-        self.scratch = torch.empty(nb // 8, **f64)
+        nb = L.rvs_chisq_point_work_size(cap, narm)
+        self.scratch = torch.empty((nb + 7) // 8, **f64)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in batch.arms]
+        self.ev_in = torch.cuda.Event()
+        self.ev_out = [torch.cuda.Event() for _ in batch.arms]
         self.calls = 0
         self.jobs = 0
 
@@ -128,26 +131,37 @@ class ProcessObjective:
                             _p(self.job_spec), _p(self.vel), _p(self.vsini),
                             _p(self.params), _p(self.extra), _p(self.bad), st)
         _lib.check(rc, 'rvs_proc_map')
-        for arm, b in zip(self.batch.arms, self.arm_buf):
+        # the arms are independent until the point kernel: one stream each
+        main = torch.cuda.current_stream()
+        self.ev_in.record(main)
+        for arm, b, side, ev in zip(self.batch.arms, self.arm_buf, self.streams,
+                                    self.ev_out):
             lib = self.libs[arm.name]
+            side.wait_event(self.ev_in)
+            ss = ctypes.c_void_p(side.cuda_stream)
             rc = L.rvs_template_polylinear(
                 _p(lib.dats), lib.ngrid, lib.ntp, _p(lib.idgrid), _p(lib.uvecs),
                 _lib.ptr(lib.lens), lib.ndim, _p(lib.vecs_s),
                 _lib.ptr(lib.inv_ptp), lib.log_mask, lib.exp_flag,
                 _p(self.params), J, _p(b['templ']), _p(b['outside']), None, None,
-                st)
+                ss)
             _lib.check(rc, 'rvs_template_polylinear')
             y = b['templ']
             if self.has_vsini:
                 rc = L.rvs_vsini_convolve(_p(y), _p(self.vsini), _p(b['outside']),
                                           lib.lnstep, 0.6, lib.ntp, J,
-                                          _p(b['templ2']), st)
+                                          _p(b['templ2']), ss)
                 _lib.check(rc, 'rvs_vsini_convolve')
                 y = b['templ2']
             rc = L.rvs_spline_construct(_p(lib.knots), _p(y), lib.ntp, J,
-                                        lib.spline_form, _p(b['coef']), st)
+                                        lib.spline_form, _p(lib.spline_factors),
+                                        _p(b['coef']), ss)
             _lib.check(rc, 'rvs_spline_construct')
-            torch.mul(b['outside'], self.badchi, out=b['pen'])
+            with torch.cuda.stream(side):
+                torch.mul(b['outside'], self.badchi, out=b['pen'])
+            ev.record(side)
+        for ev in self.ev_out:
+            main.wait_event(ev)
         self.jstatus.zero_()
         rc = L.rvs_chisq_point(ctypes.addressof(self.arr), len(self.arm_buf),
                                self.npoly, _p(self.job_spec), None, J,

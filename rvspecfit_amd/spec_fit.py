@@ -167,8 +167,8 @@ class _DeviceSpline:
                                 device='cuda')
         # form 0: the reference's A, B, C, D (spliner.c:52-59)
         rc = _lib.lib().rvs_spline_construct(_lib.ptr(self.knots), _lib.ptr(y),
-                                             self.N, 1, 0, _lib.ptr(self.coef),
-                                             _lib.stream())
+                                             self.N, 1, 0, None,
+                                             _lib.ptr(self.coef), _lib.stream())
         _lib.check(rc, 'rvs_spline_construct')
 
     def __call__(self, evalx, return_pos=False):

@@ -46,7 +46,8 @@ def test_abi_version_and_work_size(lib):
 
 def test_argument_validation_without_gpu(lib):
     # shape errors are detected on the host before any launch
-    assert lib.rvs_spline_construct(None, None, 2, 1, 0, None, None) == -1
+    assert lib.rvs_spline_construct(None, None, 2, 1, 0, None, None, None) == -1
+    assert lib.rvs_spline_construct(None, None, 9, 1, 3, None, None, None) == -1
     assert lib.rvs_chisq_grid(None, None, None, 10, 99, 1, None, None, 10, 1, 1,
                               None, None, 1, None, 0, 4, None, 0., 0., 0, None,
                               None, None) == -1

@@ -100,10 +100,15 @@ def test_spline_construct_forms(gpu, ntp):
         kn = torch.as_tensor(xs).to('cuda')
         yt = torch.as_tensor(ys).to('cuda')
         out = {}
+        fac = torch.empty(5 * ntp, dtype=torch.float64, device='cuda')
+        assert _lib.lib().rvs_spline_factors(_lib.ptr(kn), ntp, _lib.ptr(fac),
+                                             _lib.stream()) == 0
         for form in (0, 1, 2, 3):
             coef = torch.empty((B, ntp, 4), dtype=torch.float64, device='cuda')
             rc = _lib.lib().rvs_spline_construct(_lib.ptr(kn), _lib.ptr(yt), ntp,
-                                                 B, form, _lib.ptr(coef),
+                                                 B, form,
+                                                 _lib.ptr(fac) if form & 2
+                                                 else None, _lib.ptr(coef),
                                                  _lib.stream())
             assert rc == 0
             out[form] = coef.cpu().numpy()
@@ -666,6 +671,7 @@ def test_device_neldermead_equals_torch(gpu):
                     q = q + d[:, i] * Ai[:, i, k] * d[:, k]
                 # a non-smooth term makes shrinks happen
                 q = q + 3.0 * d[:, i].abs() + 2.0 * torch.sin(5 * d[:, i]).abs()
+                q = q + 1.5 * torch.floor(3 * d[:, i]).abs()   # steps
             return torch.where(X[:, 0] > 4.0, torch.full_like(q, 1e30), q)
 
         simp = torch.as_tensor(rng.normal(size=(S, N + 1, N)) * 2).to('cuda')
@@ -679,4 +685,6 @@ def test_device_neldermead_equals_torch(gpu):
         assert torch.equal(r0['success'], r1['success'])
         assert torch.equal(r0['final_simplex'][0], r1['final_simplex'][0])
         assert torch.equal(r0['final_simplex'][1], r1['final_simplex'][1])
-        assert int(r0['nfev'].sum()) > int(r0['nit'].sum()) * 2  # shrinks seen
+        shrunk = (r0['nfev'] - (N + 1)) > 2 * (r0['nit'] - 1)
+        if N > 2:
+            assert bool(shrunk.any())   # the shrink branch was exercised

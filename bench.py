@@ -143,14 +143,15 @@ def cpu_worker(args):
     _W = dict(libs={k: orc.Library(v) for k, v in dicts.items()}, d=d)
     ncore = max(1, min(args.cpu_cores or (os.cpu_count() or 1), n))
     t0 = time.time()
+    one_fn = _cpu_one_process if args.cpu_process else _cpu_one
     if ncore > 1:
         with mp.get_context('fork').Pool(ncore) as pool:
-            recs = pool.map(_cpu_one, range(n))
+            recs = pool.map(one_fn, range(n))
     else:
-        recs = [_cpu_one(i) for i in range(n)]
+        recs = [one_fn(i) for i in range(n)]
     wall = time.time() - t0
     t1 = time.time()
-    _cpu_one(0)
+    one_fn(0)
     one = time.time() - t1
     print(json.dumps(dict(n=n, wall=wall, cores=ncore, one_spectrum_s=one,
                           lib_s=tlib, recs=[list(map(float, r)) for r in recs])))
@@ -174,9 +175,29 @@ def _cpu_one(i):
             s['best_chi']] + list(c['chisq_array'])
 
 
-def run_cpu_baseline(arms, n, args):
+def _cpu_one_process(i):
+    """oracle vel_fit.process from the (GPU) CCF parameters of spectrum i"""
+    from oracle import rvs_oracle as orc
+    libs, d = _W['libs'], _W['d']
+    sds = [orc.SpecData(arm_name(a), obs_lam(a), d['spec_' + a][i],
+                        d['espec_' + a][i], badmask=d['bad_' + a][i] != 0)
+           for a in ARMS]
+    names = ['teff', 'logg', 'feh', 'alpha']
+    pd0 = {k: float(d['start'][i, j]) for j, k in enumerate(names)}
+    pd0['vsini'] = float(d['start'][i, 4])
+    cfg = dict(CONFIG)
+    cfg.setdefault('max_vsini', 500)
+    r = orc.process(sds, pd0, None, OPTIONS, cfg, libs)
+    return [r['vel'], r['vel_err'], r['chisq'], r['vsini']] + \
+        [r['param'][k] for k in names] + [r['param_err'][k] for k in names] + \
+        [sum(r['nm_nit']), sum(r['nm_nfev'])]
+
+
+def run_cpu_baseline(arms, n, args, start=None):
     path = '/tmp/rvs_bench_cpu_sample_%d.npz' % os.getpid()
     sample = dict(n=n)
+    if start is not None:
+        sample['start'] = start[:n]
     for (name, lam, spec, es, bad), a in zip(arms, ARMS):
         sample['spec_' + a] = spec[:n].cpu().numpy()
         sample['espec_' + a] = es[:n].cpu().numpy()
@@ -185,6 +206,8 @@ def run_cpu_baseline(arms, n, args):
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', path,
            '--ccf-every', str(args.ccf_every), '--cpu-cores',
            str(args.cpu_cores), '--workload', args.workload]
+    if start is not None:
+        cmd.append('--cpu-process')
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=1500)
     os.unlink(path)
@@ -209,6 +232,14 @@ def main():
     ap.add_argument('--refine', action='store_true',
                     help='also run the _minimum_sampler refinement (add-on)')
     ap.add_argument('--cpu-worker', type=str, default=None)
+    ap.add_argument('--process', type=int, default=0,
+                    help='add-on: also run vel_fit.process (Nelder-Mead + '
+                         'Hessian, SURVEY 8(f) rank 1) on this many spectra '
+                         'starting from the CCF parameters; reported under '
+                         '"process", never part of `value`')
+    ap.add_argument('--process-cpu-sample', type=int, default=8)
+    ap.add_argument('--cpu-process', action='store_true',
+                    help='(cpu worker) run the oracle process stage')
     ap.add_argument('--workload', choices=['desi', 'cfg2'], default='desi',
                     help='desi: BASELINE configs[2] (3 arms); cfg2: configs[1] '
                          '(1 arm, 2001 px, N_fft 4096)')
@@ -392,6 +423,10 @@ def main():
                           np.abs(g[same, 11] - o[same, 4]).max())
                       if same.any() else None)
 
+    proc = None
+    if args.process > 0 and EVALUATOR == 'polylinear':
+        proc = run_process_addon(batch, rec, arms, args, dev)
+
     line = dict(
         metric='spectra/sec (CCF+chi2 grid) DESI 3-arm',
         value=round(value, 1), unit='spectra/s', n_gpus=world, steps=args.steps,
@@ -411,9 +446,74 @@ def main():
                     % world),
         roofline=roof, cpu_baseline=cpu, stage_ms=stage_round(stage),
         kernels=kernels, parity_sample=parity, setup_s=round(t_setup, 1))
+    if proc is not None:
+        line['process'] = proc
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_process_addon(batch, rec, arms, args, dev):
+    """vel_fit.process on the first n spectra of the batch,
+    started from the CCF parameters as desi_fit.py:289-309 does; the oracle's
+    process (scipy Nelder-Mead) on a small sample beside it."""
+    import torch
+    from rvspecfit_amd import engine, pipeline, vel_fit
+    n = min(args.process, batch.S)
+    idx = torch.arange(n, device=dev)
+    sub = engine.SpecBatch([engine.ArmData(a.name, a.lam_host, a.spec[idx],
+                                           a.espec[idx], a.badmask[idx],
+                                           device=dev) for a in batch.arms])
+    F = pipeline.RECORD_FIELDS
+    names = ['teff', 'logg', 'feh', 'alpha']
+    r0 = rec[:n]
+    pd0 = {k: r0[:, F.index('p%d' % i)].contiguous() for i, k in enumerate(names)}
+    vs = r0[:, F.index('vsini')]
+    pd0['vsini'] = torch.where(torch.isfinite(vs), vs,
+                               torch.zeros_like(vs)).contiguous()
+    cfg = dict(CONFIG)
+    cfg.setdefault('max_vsini', 500)
+    vel_fit.process(sub, pd0, options=OPTIONS, config=cfg)   # warm-up
+    tm = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = vel_fit.process(sub, pd0, options=OPTIONS, config=cfg, timers=tm)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = dict(spectra=n, spectra_per_s=round(n / dt, 1), seconds=round(dt, 2),
+               stage_s={k: round(v, 3) for k, v in tm.items()},
+               nm_rounds=int(r['nm_rounds']),
+               nm_iterations_mean=round(float(r['nm_nit'].float().mean()), 1),
+               nm_iterations_max=int(r['nm_nit'].max()),
+               objective_evals=int(r['objective_evals']),
+               minimize_success=round(float(
+                   r['minimize_success'].float().mean()), 4),
+               bad_hessian=round(float(np.mean(r['bad_hessian'])), 4),
+               note='add-on, not part of `value`; second_minimizer (BFGS) not '
+                    'run, Hessian by central differences (see DESIGN.md)')
+    m = min(args.process_cpu_sample, n)
+    if m > 0 and not args.no_cpu_baseline:
+        start = torch.stack([pd0[k] for k in names] + [pd0['vsini']],
+                            dim=1).cpu().numpy()
+        cb = run_cpu_baseline(arms, m, args, start=start)
+        o = np.array(cb['recs'])
+        gv = r['vel'][:m].cpu().numpy()
+        gc = r['chisq'][:m].cpu().numpy()
+        gp = np.stack([r['param'][k][:m].cpu().numpy() for k in names], axis=1)
+        perr = o[:, 8:12]
+        out['cpu'] = dict(value=round(cb['n'] / cb['wall'], 3),
+                          unit='spectra/s', cores=cb['cores'], kind='port',
+                          one_spectrum_seconds_1core=round(
+                              cb['one_spectrum_s'], 2),
+                          sample='%d spectra, oracle process (scipy Nelder-Mead '
+                                 'on the C port of get_chisq)' % m)
+        with np.errstate(all='ignore'):
+            out['parity'] = dict(
+                n=m, max_abs_dvel=float(np.abs(gv - o[:, 0]).max()),
+                max_abs_dchisq=float(np.abs(gc - o[:, 2]).max()),
+                max_dparam_over_sigma=float(np.nanmax(
+                    np.abs(gp - o[:, 4:8]) / np.where(perr > 0, perr, np.nan))))
+    return out
 
 
 def stage_round(d):

@@ -264,6 +264,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     _lib.require_gpu()
+    if os.environ.get('RVS_SHARE_GPU'):
+        local = 0   # functional multi-rank run on ONE GPU (with RVS_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     rdist.init_from_env(backend='nccl')
     dev = torch.device('cuda', local)
@@ -316,7 +318,8 @@ def main():
     kt = engine.ktimers_summary()
     engine.KTIMERS = None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdev = dev if dist.get_backend() == 'nccl' else 'cpu'
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

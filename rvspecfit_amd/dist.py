@@ -29,6 +29,7 @@ def init_from_env(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        backend = os.environ.get('RVS_DIST_BACKEND') or backend
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         dist.init_process_group(backend)
@@ -48,12 +49,13 @@ def gather_records(rec, S_total, rank=None, world=None):
     pad = torch.zeros((per, nrec), dtype=rec.dtype, device=rec.device)
     pad[:rec.shape[0]] = rec
     full = torch.empty((world * per, nrec), dtype=rec.dtype, device=rec.device)
-    if rec.is_cuda:
-        dist.all_gather_into_tensor(full, pad)
-    else:  # gloo (CPU tests)
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad)
-        full = torch.cat(parts, dim=0)
+    if rec.is_cuda and dist.get_backend() == 'nccl':
+        dist.all_gather_into_tensor(full, pad)   # RCCL over xGMI
+    else:  # gloo (CPU tests, or a functional multi-rank run without RCCL)
+        hpad = pad.cpu()
+        parts = [torch.empty_like(hpad) for _ in range(world)]
+        dist.all_gather(parts, hpad)
+        full = torch.cat(parts, dim=0).to(rec.device)
     return full[:S_total]
 
 

@@ -232,6 +232,9 @@ def main():
     ap.add_argument('--refine', action='store_true',
                     help='also run the _minimum_sampler refinement (add-on)')
     ap.add_argument('--cpu-worker', type=str, default=None)
+    ap.add_argument('--resolution-matrix', action='store_true',
+                    help='add-on workload: every spectrum carries an 11-diagonal '
+                         'resolution matrix (DESI --resolution_matrix mode, A9)')
     ap.add_argument('--process', type=int, default=0,
                     help='add-on: also run vel_fit.process (Nelder-Mead + '
                          'Hessian, SURVEY 8(f) rank 1) on this many spectra '
@@ -288,6 +291,24 @@ def main():
     arms = make_spectra_device(tp, dev)
     batch = engine.SpecBatch([engine.ArmData(n, lam, sp, es, bad, device=dev)
                               for n, lam, sp, es, bad in arms])
+    if args.resolution_matrix:
+        # per-spectrum Gaussian rows, sigma 0.45-0.65 px-units of 0.8 A, 11 taps,
+        # rows normalised (what desi_fit.construct_resolution_sparse_matrix
+        # hands over); built directly on the device
+        g = torch.Generator(device=dev)
+        g.manual_seed(991 + rank)
+        for a in batch.arms:
+            sig = 0.45 + 0.2 * torch.rand((S, 1, 1), device=dev, generator=g,
+                                          dtype=torch.float64)
+            d = torch.arange(-5, 6, device=dev, dtype=torch.float64)[None, None]
+            k = torch.arange(a.npix, device=dev)[None, :, None]
+            t = torch.exp(-0.5 * (d / (sig / 0.8 * 1.0))**2).expand(
+                S, a.npix, 11).clone()
+            q = k + d.long()
+            t = torch.where((q >= 0) & (q < a.npix), t, torch.zeros_like(t))
+            t = t / t.sum(dim=2, keepdim=True)
+            a.resol = dict(taps=t.contiguous(), nd=11, stride=a.npix * 11,
+                           unit=t.sum(dim=2).contiguous())
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
@@ -396,7 +417,8 @@ def main():
     # ---- CPU baseline + parity on the sample ---------------------------
     cpu = None
     parity = None
-    if not args.no_cpu_baseline and EVALUATOR == 'polylinear':
+    if not args.no_cpu_baseline and EVALUATOR == 'polylinear' and \
+            not args.resolution_matrix:
         n = min(args.cpu_sample, S)
         cb = run_cpu_baseline(arms, n, args)
         cpu = dict(value=round(cb['n'] / cb['wall'], 3), unit='spectra/s',
@@ -445,8 +467,9 @@ def main():
                                  '1 arm 4000-5000 A 2001 px (BASELINE configs[1])',
                                  S, EVALUATOR, Tccf, nfft),
                     spectra_per_gpu=S, ccf_templates=Tccf, nfft=nfft,
-                    refine=bool(args.refine), parallelism='spectra-sharded x%d'
-                    % world),
+                    refine=bool(args.refine),
+                    resolution_matrix=bool(args.resolution_matrix),
+                    parallelism='spectra-sharded x%d' % world),
         roofline=roof, cpu_baseline=cpu, stage_ms=stage_round(stage),
         kernels=kernels, parity_sample=parity, setup_s=round(t_setup, 1))
     if proc is not None:

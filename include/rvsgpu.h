@@ -161,11 +161,28 @@ int rvs_chisq_grid(const double *lam, const double *polysT, const double *work,
                    const double *penalty, double badchi, double beta, int chunk,
                    double *out, int32_t *status, void *stream);
 
+/* A9  the same with a banded resolution matrix applied to the resampled
+ * template before the fit: replaces convolve_resol / ResolMatrix
+ * (spec_fit.py:54-67, 474-492) as used by get_chisq (:920-929).
+ * taps [S or 1, npix, nd] row-major: taps[s, k, d] = R_s[k, k - (nd-1)/2 + d]
+ * (0 outside the matrix), nd odd <= 33; taps_stride = npix*nd, or 0 when every
+ * spectrum shares one matrix (the `resol_params` case). */
+int rvs_chisq_grid_resol(const double *lam, const double *polysT,
+                         const double *work, int npix, int npoly, int S,
+                         const double *knots, const double *coef, int ntp,
+                         int Tn, int log_step, const double *taps, int nd,
+                         int64_t taps_stride, const int32_t *job_spec,
+                         const int32_t *job_templ, int J, const double *vels,
+                         int64_t vel_stride, int Nv, const double *penalty,
+                         double badchi, double beta, double *out,
+                         int32_t *status, void *stream);
+
 /* ------------------------------------------------------------------------
  * get_chisq(full_output=True) for one velocity per job and one arm
  * (spec_fit.py:941-961), and get_chisq_continuum (spec_fit.py:739-783) when
  * unit_template != 0 (template == 1, knots/coef ignored).  cform = the form of
- * the spline records (see rvs_spline_construct).
+ * the spline records (see rvs_spline_construct).  taps (nullable): resolution
+ * matrix rows as in rvs_chisq_grid_resol, applied to the template (or to 1).
  * coeffs [J, npoly], model/raw_model [J, npix] (nullable), chisq [J] (-2logL
  * of the arm), true_chisq [J] over pixels with badmask==0, ngood int32 [J].
  * ---------------------------------------------------------------------- */
@@ -174,10 +191,10 @@ int rvs_chisq_full(const double *lam, const double *polysT, const double *spec,
                    int npoly, int S, const double *knots, const double *coef,
                    int ntp, int Tn, int log_step, int cform, int unit_template,
                    const int32_t *job_spec, const int32_t *job_templ, int J,
-                   const double *vel, double espec_sys, double *chisq,
-                   double *coeffs, double *model, double *raw_model,
-                   double *true_chisq, int32_t *ngood, int32_t *status,
-                   void *stream);
+                   const double *vel, double espec_sys, const double *taps,
+                   int nd, int64_t taps_stride, double *chisq, double *coeffs,
+                   double *model, double *raw_model, double *true_chisq,
+                   int32_t *ngood, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------
  * A13  get_chisq_continuum (spec_fit.py:739-783) for a whole batch of one arm:
@@ -186,13 +203,16 @@ int rvs_chisq_full(const double *lam, const double *polysT, const double *spec,
  * singular basis) is flagged and gives NaN -- rvs_chisq_full(unit_template=1)
  * is the slower entry point with the eigen (SVD) fallback.
  * polysT [npix, npoly]; spec, espec [S, npix]; badmask uint8 [S, npix] (nullable)
+ * unit_templ [S, npix] (nullable): R_s @ 1 when the spectra carry a resolution
+ * matrix (spec_fit.py:765-767)
  * work: scratch of rvs_chisq_continuum_work_size(npoly, S) bytes
  * chisq [S] (-2 log L, nullable), true_chisq [S], ngood int32 [S]
  * ---------------------------------------------------------------------- */
 int64_t rvs_chisq_continuum_work_size(int npoly, int S);
 int rvs_chisq_continuum(const double *polysT, const double *spec,
-                        const double *espec, const uint8_t *badmask, int npix,
-                        int npoly, int S, void *work, double *chisq,
+                        const double *espec, const uint8_t *badmask,
+                        const double *unit_templ, int npix, int npoly, int S,
+                        void *work, double *chisq,
                         double *true_chisq, int32_t *ngood, int32_t *status,
                         void *stream);
 
@@ -214,7 +234,9 @@ int rvs_chisq_continuum(const double *polysT, const double *spec,
 #define RVS_MAX_ARMS 4
 typedef struct rvs_point_arm {
   const double *lam, *polysT, *spec, *espec, *work, *knots, *coef, *penalty;
-  int32_t npix, S, ntp, log_step;
+  const double *taps;   /* A9 resolution matrix rows [S or 1, npix, nd] or NULL */
+  int64_t taps_stride;  /* npix*nd, or 0 when all spectra share one matrix */
+  int32_t npix, S, ntp, log_step, nd, pad_;
 } rvs_point_arm;
 int64_t rvs_chisq_point_work_size(int J, int narm);
 int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,

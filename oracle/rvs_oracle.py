@@ -134,7 +134,9 @@ def load_reference_spliner():
 # --------------------------------------------------------------------------
 class SpecData:
 
-    def __init__(self, name, lam, spec, espec, badmask=None):
+    def __init__(self, name, lam, spec, espec, badmask=None, resolution=None):
+        # resolution: scipy.sparse matrix (ResolMatrix.mat, spec_fit.py:54-67)
+        self.resolution = resolution
         self.name = name
         self.lam, self.spec, self.espec = _c(lam), _c(spec), _c(espec)
         if badmask is None:
@@ -374,9 +376,34 @@ def eval_rv(spl, vel, lam):  # spec_fit.py:707-727
     return spl(lam * np.sqrt((1 - beta) / (1 + beta)))
 
 
+def construct_resol_mat(lam, resol=None, width=None):
+    """A9: spec_fit.construct_resol_mat (spec_fit.py:410-471) -> scipy.sparse"""
+    import scipy.sparse
+    lam = np.asarray(lam, dtype=float)
+    if resol is not None:
+        sigs = lam / resol / 2.35
+    else:
+        sigs = np.zeros(len(lam)) + width
+    n = len(lam)
+    i1 = np.maximum(np.searchsorted(lam, lam - 5 * sigs, 'left'), 0)
+    i2 = np.minimum(np.searchsorted(lam, lam + 5 * sigs, 'right'), n - 1)
+    pix = np.arange(n)
+    maxl = min(n, max(np.max(i2 - pix), np.max(pix - i1)))
+    offsets = np.arange(-maxl, maxl + 1)
+    xs2d = pix[None, :] + offsets[:, None]
+    mask = (xs2d >= 0) & (xs2d < n)
+    xs2d[~mask] = 0
+    XL = np.exp(-0.5 * ((lam[xs2d] - lam[None, :]) / sigs[None, :])**2) * mask
+    XL = XL / XL.sum(axis=0)[None, :]
+    yids = (pix[None, :] + (n - offsets)[:, None]) % n
+    xids = yids * 0 + maxl + offsets[:, None]
+    return scipy.sparse.spdiags(XL[xids, yids], offsets, n, n)
+
+
 def get_chisq(specdata, vel, atm_params, rot_params=None, options=None,
               config=None, libs=None, cache=None, full_output=False,
-              espec_systematic=None, outside_penalty=True, use_c=False):
+              espec_systematic=None, outside_penalty=True, use_c=False,
+              resol_params=None):
     npoly = options.get('npoly') or 5
     rbf = options.get('rbf_continuum', True)
     accum = 0
@@ -407,6 +434,13 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, options=None,
             if cache is not None:
                 cache[key] = (outside, tspec, spl)
         ev = eval_rv(spl, vel, sd.lam)
+        # A9: resolution matrix (spec_fit.py:920-929)
+        if resol_params is not None:
+            ev = resol_params[sd.name] @ ev
+        if sd.resolution is not None:
+            if resol_params is not None:
+                raise ValueError('resol_params together with SpecData.resolution')
+            ev = sd.resolution @ ev
         polys = get_poly_basis(sd.lam, npoly, rbf=rbf)
         if espec_systematic is not None:
             es = np.sqrt(espec_systematic**2 + sd.espec**2)
@@ -468,14 +502,14 @@ def grid_summary(vel_grid, chisq, quadratic=True):
 
 
 def chisq_grid(specdata, vel_grid, params_list, rot_params, options, config,
-               libs, use_c=True):
+               libs, use_c=True, resol_params=None):
     cache = {}
     grid = np.zeros((len(vel_grid), len(params_list)))
     for j, p in enumerate(params_list):
         for i, v in enumerate(vel_grid):
             grid[i, j] = get_chisq(specdata, v, p, rot_params, options=options,
                                    config=config, libs=libs, cache=cache,
-                                   use_c=use_c)
+                                   use_c=use_c, resol_params=resol_params)
     return grid
 
 
@@ -512,9 +546,10 @@ def chisq_grid_fast(specdata, vel_grid, params, rot_params, options, config,
 
 
 def find_best(specdata, vel_grid, params_list, rot_params=None, options=None,
-              config=None, libs=None, quadratic=True, use_c=True):
+              config=None, libs=None, quadratic=True, use_c=True,
+              resol_params=None):
     grid = chisq_grid(specdata, vel_grid, params_list, rot_params, options,
-                      config, libs, use_c=use_c)
+                      config, libs, use_c=use_c, resol_params=resol_params)
     ret = grid_summary(vel_grid, grid, quadratic=quadratic)
     ret['best_param'] = params_list[ret.pop('i2')]
     ret['chisq_grid'] = grid
@@ -531,6 +566,8 @@ def get_chisq_continuum(specdata, options=None):
     for i, sd in enumerate(specdata):
         polys = get_poly_basis(sd.lam, npoly, rbf=rbf)
         templ = np.ones(len(sd.spec))
+        if sd.resolution is not None:  # spec_fit.py:765-767
+            templ = sd.resolution @ templ
         _, co = get_chisq0(sd.spec, templ, polys, get_coeffs=True,
                            espec=sd.espec)
         dev = (np.dot(co, polys * templ) - sd.spec) / sd.espec

@@ -31,10 +31,12 @@ SIGNATURES = {
     'rvs_chisq_prepare': (I, [P, P, P, I, I, P, I, D, P, P]),
     'rvs_chisq_grid': (I, [P, P, P, I, I, I, P, P, I, I, I, P, P, I, P, L, I, P,
                            D, D, I, P, P, P]),
+    'rvs_chisq_grid_resol': (I, [P, P, P, I, I, I, P, P, I, I, I, P, I, L, P, P,
+                                 I, P, L, I, P, D, D, P, P, P]),
     'rvs_chisq_full': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, P, P, I,
-                           P, D, P, P, P, P, P, P, P, P]),
+                           P, D, P, I, L, P, P, P, P, P, P, P, P]),
     'rvs_chisq_continuum_work_size': (L, [I, I]),
-    'rvs_chisq_continuum': (I, [P, P, P, P, I, I, I, P, P, P, P, P, P]),
+    'rvs_chisq_continuum': (I, [P, P, P, P, P, I, I, I, P, P, P, P, P, P]),
     'rvs_chisq_point_work_size': (L, [I, I]),
     'rvs_chisq_point': (I, [P, I, I, P, P, I, P, D, D, P, P, P, P]),
     'rvs_nm_begin': (I, [I, I, D, D, I, P, P, P, P, P, P, P, I, P]),
@@ -85,8 +87,9 @@ class PointArm(ctypes.Structure):
     """rvs_point_arm of include/rvsgpu.h"""
     _fields_ = [(k, ctypes.c_void_p) for k in
                 ('lam', 'polysT', 'spec', 'espec', 'work', 'knots', 'coef',
-                 'penalty')] + [(k, ctypes.c_int32) for k in
-                                ('npix', 'S', 'ntp', 'log_step')]
+                 'penalty', 'taps')] + [('taps_stride', ctypes.c_int64)] + [
+                    (k, ctypes.c_int32) for k in
+                    ('npix', 'S', 'ntp', 'log_step', 'nd', 'pad_')]
 
 
 def ptr(t):

@@ -444,6 +444,154 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   }
 }
 
+// ---------------------------------------------------------------------------
+// A9: the same kernel with a banded resolution matrix applied to the resampled
+// template (convolve_resol, spec_fit.py:474-492, 920-929): model_k =
+// sum_d taps[k][d] * raw(k - m + d), m = (nd-1)/2.  A lane owns a velocity and
+// walks the pixels in order, so the nd raw values it needs form a sliding
+// window: a lane-private ring buffer in LDS (slot = pixel mod nd, [slot][tid]
+// layout -> conflict-free), one new spline evaluation per pixel.  The taps of a
+// pixel are wave-uniform (scalar loads).  taps [S or 1, npix, nd] row-major,
+// taps_stride = npix*nd or 0 when all spectra share one matrix.
+// ---------------------------------------------------------------------------
+#define RES_MAXND 33
+
+template <int P>
+__global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
+    chisq_grid_resol_kernel(const double *__restrict__ lam,
+                            const double *__restrict__ polysT,
+                            const double *__restrict__ work, int npix, int S,
+                            const double *__restrict__ knots,
+                            const double4 *__restrict__ coef, int ntp,
+                            int log_step, const double *__restrict__ taps,
+                            int nd, int64_t taps_stride,
+                            const int32_t *__restrict__ job_spec,
+                            const int32_t *__restrict__ job_templ,
+                            const double *__restrict__ vels, int64_t vel_stride,
+                            int Nv, const double *__restrict__ penalty,
+                            double badchi, double beta_out,
+                            double *__restrict__ out,
+                            int32_t *__restrict__ status) {
+  extern __shared__ double ring[];  // [nd][256]
+  const int j = blockIdx.y;
+  const int wave_v0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+  if (wave_v0 >= Nv) return;
+  const int iv = blockIdx.x * 256 + threadIdx.x;
+  const bool active = iv < Nv;
+  const int s = job_spec ? job_spec[j] : j;
+  const int t = job_templ ? job_templ[j] : j;
+  double *outp = out + (int64_t)j * Nv;
+  const double pen = penalty ? penalty[j] : 0.0;
+  if (!(pen == pen) || isinf(pen)) {
+    if (active) {
+      const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
+      outp[iv] = base + 1000.0 * badchi;
+    }
+    return;
+  }
+  const double *pixa = work;
+  const double2 *W = reinterpret_cast<const double2 *>(work + npix) +
+                     (int64_t)s * npix;
+  const double *scal = work + npix + 2ll * S * npix + 2 * s;
+  const double4 *cf = coef + (int64_t)t * ntp;
+  const double *tp = taps + (int64_t)s * taps_stride;
+  const int m = (nd - 1) / 2;
+  const double vel = vels[(int64_t)j * vel_stride + (active ? iv : 0)];
+  const double bb = vel / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double x0 = knots[0], xlast = knots[ntp - 1];
+  const double shift = log_step ? log(f) / log(knots[1] / x0) : 0.0;
+  const double lin_inv_step = log_step ? 0.0 : 1.0 / (knots[1] - x0);
+  int32_t st = 0;
+  {
+    const double xa = lam[0] * f, xb = lam[npix - 1] * f;
+    if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast)
+      st |= RVS_ST_SPLINE_RANGE;
+  }
+  auto raw_at = [&](int p) {
+    const double x = lam[p] * f;
+    int pos = log_step ? (int)(pixa[p] + shift) : (int)((x - x0) * lin_inv_step);
+    pos = min(max(pos, 0), ntp - 2);
+    const double dl = x - knots[pos];
+    const double4 c = cf[pos];
+    return fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
+  };
+  double *mine = ring + threadIdx.x;
+  for (int d = 0; d < nd; d++) mine[d * 256] = 0.0;
+  for (int p = 0; p < min(m, npix); p++) mine[(p % nd) * 256] = raw_at(p);
+
+  double acc[P * (P + 1) / 2];
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < P * (P + 1) / 2; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = 0;
+  for (int k = 0; k < npix; k++) {
+    if (k + m < npix) mine[((k + m) % nd) * 256] = raw_at(k + m);
+    const double *tk = tp + (int64_t)k * nd;
+    double tv = 0;
+    int slot = (k - m + nd) % nd;  // k - m >= -m > -nd
+    for (int d = 0; d < nd; d++) {
+      tv = fma(tk[d], mine[slot * 256], tv);
+      slot = (slot + 1 == nd) ? 0 : slot + 1;
+    }
+    const double2 wk = W[k];
+    const double w = tv * tv * wk.x;
+    const double u = tv * wk.y;
+    const double *pr = polysT + (int64_t)k * P;
+    double pw[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      av[i] = fma(pr[i], u, av[i]);
+#pragma unroll
+      for (int jj = 0; jj <= i; jj++)
+        acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
+    }
+  }
+  bool ok = true;
+  double ldet = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+#pragma unroll
+    for (int jj = 0; jj <= i; jj++) {
+      double sum = acc[TRI(i, jj)];
+#pragma unroll
+      for (int k = 0; k < jj; k++) sum -= acc[TRI(i, k)] * acc[TRI(jj, k)];
+      if (jj == i) {
+        if (!(sum > 0)) ok = false;
+        const double d = sqrt(sum);
+        acc[TRI(i, i)] = d;
+        ldet += log(d);
+      } else {
+        acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
+      }
+    }
+  }
+  double yy = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    double sum = av[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) sum -= acc[TRI(i, k)] * av[k];
+    av[i] = sum / acc[TRI(i, i)];
+    yy = fma(av[i], av[i], yy);
+  }
+  double chi = 2.0 * ldet + 2.0 * scal[0] + (scal[1] - yy);
+  if (st & RVS_ST_SPLINE_RANGE) chi = __builtin_nan("");
+  if (!ok) st |= RVS_ST_CHOL_FALLBACK;
+  if (!ok || !(fabs(chi) <= 1.79e308)) {
+    st |= RVS_ST_NONFINITE;
+    chi = __builtin_nan("");
+  }
+  if (active) {
+    const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
+    outp[iv] = base + chi + pen;
+    if (st) atomicOr(&status[j], st);
+  }
+}
+
 template <int P>
 static int launch_grid(const double *lam, const double *polysT,
                        const double *work, int npix, int S, const double *knots,
@@ -531,6 +679,47 @@ extern "C" int rvs_chisq_grid(const double *lam, const double *polysT,
 #undef RVS_CASE
 }
 
+extern "C" int rvs_chisq_grid_resol(
+    const double *lam, const double *polysT, const double *work, int npix,
+    int npoly, int S, const double *knots, const double *coef, int ntp, int Tn,
+    int log_step, const double *taps, int nd, int64_t taps_stride,
+    const int32_t *job_spec, const int32_t *job_templ, int J, const double *vels,
+    int64_t vel_stride, int Nv, const double *penalty, double badchi,
+    double beta, double *out, int32_t *status, void *stream) {
+  if (npix < 1 || J < 1 || Nv < 1 || ntp < 3 || Tn < 1 || !taps || nd < 1 ||
+      nd > RES_MAXND || (nd & 1) == 0 || J > 65535)
+    return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  dim3 grid((Nv + 255) / 256, J);
+  const size_t shm = (size_t)nd * 256 * sizeof(double);
+#define RVS_CASE(PP)                                                           \
+  case PP: {                                                                   \
+    static bool attr_set = false;                                              \
+    if (!attr_set) {                                                           \
+      (void)hipFuncSetAttribute((const void *)chisq_grid_resol_kernel<PP>,     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                RES_MAXND * 256 * 8);                          \
+      (void)hipGetLastError();                                                 \
+      attr_set = true;                                                         \
+    }                                                                          \
+    hipLaunchKernelGGL(chisq_grid_resol_kernel<PP>, grid, dim3(256), shm, st,  \
+                       lam, polysT, work, npix, S, knots,                      \
+                       reinterpret_cast<const double4 *>(coef), ntp, log_step, \
+                       taps, nd, taps_stride, job_spec, job_templ, vels,       \
+                       vel_stride, Nv, penalty, badchi, beta, out, status);    \
+  } break;
+  switch (npoly) {
+    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
+    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
+    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
+    default:
+      return RVS_E_ARG;
+  }
+#undef RVS_CASE
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // full output for one velocity per job (spec_fit.py:941-961) and the
 // continuum-only fit (spec_fit.py:739-783).  One 256-thread block per job.
@@ -583,6 +772,8 @@ __global__ void __launch_bounds__(256)
                       const int32_t *__restrict__ job_spec,
                       const int32_t *__restrict__ job_templ,
                       const double *__restrict__ vel, double espec_sys,
+                      const double *__restrict__ taps, int nd,
+                      int64_t taps_stride,
                       double *__restrict__ chisq, double *__restrict__ coeffs,
                       double *__restrict__ model, double *__restrict__ raw_model,
                       double *__restrict__ true_chisq, int32_t *__restrict__ ngood,
@@ -619,9 +810,41 @@ __global__ void __launch_bounds__(256)
       atomicOr(&sh_st, RVS_ST_SPLINE_RANGE);
   }
   double lz = 0;
+  if (taps) {
+    // A9: raw resampled template (or 1) into Ds, then the banded resolution
+    // matrix (convolve_resol, spec_fit.py:474-492): tv_k = sum_d taps[k][d] raw[k-m+d]
+    for (int k = tid; k < npix; k += 256) {
+      double tv = 1.0;
+      if (!unit_template) {
+        const double x = lam[k] * f;
+        int pos = log_step ? (int)((log(x) - lx0) * inv_step)
+                           : (int)((x - x0) * inv_step);
+        pos = min(max(pos, 0), ntp - 2);
+        const double4 c = cf[pos];
+        const double dl = x - knots[pos], dr = knots[pos + 1] - x;
+        tv = cform ? fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x)
+                   : c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
+      }
+      Ds[k] = tv;
+    }
+    __syncthreads();
+    const double *tp = taps + (int64_t)s * taps_stride;
+    const int m = (nd - 1) / 2;
+    for (int k = tid; k < npix; k += 256) {
+      double tv = 0;
+      for (int d = 0; d < nd; d++) {
+        const int q = k - m + d;
+        if (q >= 0 && q < npix) tv = fma(tp[(int64_t)k * nd + d], Ds[q], tv);
+      }
+      tvs[k] = tv;
+    }
+    __syncthreads();
+  }
   for (int k = tid; k < npix; k += 256) {
     double tv = 1.0;
-    if (!unit_template) {
+    if (taps) {
+      tv = tvs[k];
+    } else if (!unit_template) {
       const double x = lam[k] * f;
       int pos = log_step ? (int)((log(x) - lx0) * inv_step)
                          : (int)((x - x0) * inv_step);
@@ -768,13 +991,15 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
                               int ntp, int Tn, int log_step, int cform,
                               int unit_template, const int32_t *job_spec,
                               const int32_t *job_templ, int J, const double *vel,
-                              double espec_sys,
+                              double espec_sys, const double *taps, int nd,
+                              int64_t taps_stride,
                               double *chisq, double *coeffs, double *model,
                               double *raw_model, double *true_chisq,
                               int32_t *ngood, int32_t *status, void *stream) {
   (void)S;
   (void)Tn;
   if (npoly < 1 || npoly > FULL_MAXP || J < 1 || npix < 1) return RVS_E_ARG;
+  if (taps && (nd < 1 || (nd & 1) == 0)) return RVS_E_ARG;
   const size_t shm = sizeof(double) * (2 * (size_t)npix + FULL_MAXP * FULL_MAXP +
                                        2 * FULL_MAXP + 8 +
                                        2 * FULL_MAXP * FULL_MAXP + FULL_MAXP);
@@ -790,8 +1015,8 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
                      rvs_stream(stream), lam, polysT, spec, espec, badmask,
                      npix, npoly, knots, reinterpret_cast<const double4 *>(coef),
                      ntp, log_step, cform, unit_template, job_spec, job_templ,
-                     vel, espec_sys, chisq, coeffs, model, raw_model, true_chisq,
-                     ngood, status);
+                     vel, espec_sys, taps, nd, taps_stride, chisq, coeffs, model,
+                     raw_model, true_chisq, ngood, status);
   RVS_LAUNCH_CHECK();
   return 0;
 }
@@ -816,8 +1041,9 @@ template <int P>
 __global__ void __launch_bounds__(64)
     continuum_normal_kernel(const double *__restrict__ polysT,
                             const double *__restrict__ spec,
-                            const double *__restrict__ espec, int npix, int S,
-                            int nsl, double *__restrict__ part) {
+                            const double *__restrict__ espec,
+                            const double *__restrict__ unit_templ, int npix,
+                            int S, int nsl, double *__restrict__ part) {
   constexpr int NT = P * (P + 1) / 2;
   const int s0 = blockIdx.x * 64 + threadIdx.x;
   const bool active = s0 < S;
@@ -827,6 +1053,8 @@ __global__ void __launch_bounds__(64)
   const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
   const double *sp = spec + (int64_t)s * npix;
   const double *es = espec + (int64_t)s * npix;
+  // A9: templ = R @ 1 (spec_fit.py:765-767) instead of 1
+  const double *ut = unit_templ ? unit_templ + (int64_t)s * npix : nullptr;
   double acc[NT];
   double av[P];
 #pragma unroll
@@ -837,7 +1065,8 @@ __global__ void __launch_bounds__(64)
   for (int k = k0; k < k1; k++) {
     const double e = es[k], x = sp[k];
     const double ie = 1.0 / e;
-    const double w = ie * ie, u = x * w;
+    const double tv = ut ? ut[k] : 1.0;
+    const double w = (tv * ie) * (tv * ie), u = (tv * ie) * (x * ie);
     lz += log(e);
     dd = fma(x * ie, x * ie, dd);
     const double *pr = polysT + (int64_t)k * P;
@@ -867,6 +1096,7 @@ __global__ void __launch_bounds__(64)
     continuum_resid_kernel(const double *__restrict__ polysT,
                            const double *__restrict__ spec,
                            const double *__restrict__ espec,
+                           const double *__restrict__ unit_templ,
                            const uint8_t *__restrict__ badmask, int npix, int S,
                            int nsl, const double *__restrict__ part,
                            double *__restrict__ res, double *__restrict__ chisq,
@@ -935,6 +1165,7 @@ __global__ void __launch_bounds__(64)
   const double *sp = spec + (int64_t)s * npix;
   const double *es = espec + (int64_t)s * npix;
   const uint8_t *bm = badmask ? badmask + (int64_t)s * npix : nullptr;
+  const double *ut = unit_templ ? unit_templ + (int64_t)s * npix : nullptr;
   double tc = 0;
   int ng = 0;
   for (int k = k0; k < k1; k++) {
@@ -942,6 +1173,7 @@ __global__ void __launch_bounds__(64)
     double m = 0;
 #pragma unroll
     for (int i = 0; i < P; i++) m = fma(av[i], pr[i], m);
+    if (ut) m *= ut[k];
     const double dev = (m - sp[k]) / es[k];
     const bool good = bm ? (bm[k] == 0) : true;
     if (good) {
@@ -984,7 +1216,8 @@ extern "C" int64_t rvs_chisq_continuum_work_size(int npoly, int S) {
 
 extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
                                    const double *espec, const uint8_t *badmask,
-                                   int npix, int npoly, int S, void *work,
+                                   const double *unit_templ, int npix, int npoly,
+                                   int S, void *work,
                                    double *chisq, double *true_chisq,
                                    int32_t *ngood, int32_t *status,
                                    void *stream) {
@@ -998,10 +1231,10 @@ extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \
     hipLaunchKernelGGL(continuum_normal_kernel<PP>, grid, dim3(64), 0, st,     \
-                       polysT, spec, espec, npix, S, nsl, part);               \
+                       polysT, spec, espec, unit_templ, npix, S, nsl, part);   \
     hipLaunchKernelGGL(continuum_resid_kernel<PP>, grid, dim3(64), 0, st,      \
-                       polysT, spec, espec, badmask, npix, S, nsl, part, res,  \
-                       chisq, status);                                         \
+                       polysT, spec, espec, unit_templ, badmask, npix, S, nsl, \
+                       part, res, chisq, status);                              \
     break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
@@ -1059,6 +1292,7 @@ __global__ void __launch_bounds__(256)
   constexpr int NV = NT + P;
   __shared__ double red[4][NV + 1];
   __shared__ double coefs[P + 2];
+  extern __shared__ double rawsh[];  // [npix] only with a resolution matrix
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int j = blockIdx.x;
   const rvs_point_arm &T = A.a[blockIdx.y];
@@ -1075,6 +1309,23 @@ __global__ void __launch_bounds__(256)
   const double x0 = T.knots[0], xlast = T.knots[T.ntp - 1];
   const double shift = T.log_step ? log(f) / log(T.knots[1] / x0) : 0.0;
   const double lin_inv_step = T.log_step ? 0.0 : 1.0 / (T.knots[1] - x0);
+  // A9: banded resolution matrix on the resampled template (spec_fit.py:920-929)
+  const double *tp = T.taps ? T.taps + (int64_t)s * T.taps_stride : nullptr;
+  const int nd = T.nd, mres = (T.nd - 1) / 2;
+  if (tp) {
+    for (int k = threadIdx.x; k < npix; k += 256)
+      rawsh[k] = point_tv(T, cf, k, f, shift, x0, lin_inv_step);
+    __syncthreads();
+  }
+  auto tv_at = [&](int k) {
+    if (!tp) return point_tv(T, cf, k, f, shift, x0, lin_inv_step);
+    double v = 0;
+    for (int d = 0; d < nd; d++) {
+      const int q = k - mres + d;
+      if (q >= 0 && q < npix) v = fma(tp[(int64_t)k * nd + d], rawsh[q], v);
+    }
+    return v;
+  };
   double acc[NT];
   double av[P];
 #pragma unroll
@@ -1082,7 +1333,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = 0;
   for (int k = threadIdx.x; k < npix; k += 256) {
-    const double tv = point_tv(T, cf, k, f, shift, x0, lin_inv_step);
+    const double tv = tv_at(k);
     double e = es[k];
     if (espec_sys > 0) e = sqrt(sys2 + e * e);
     const double ie = 1.0 / e;
@@ -1168,7 +1419,7 @@ __global__ void __launch_bounds__(256)
   for (int i = 0; i < P; i++) av[i] = coefs[i];
   double rr = 0;
   for (int k = threadIdx.x; k < npix; k += 256) {
-    const double tv = point_tv(T, cf, k, f, shift, x0, lin_inv_step);
+    const double tv = tv_at(k);
     double e = es[k];
     if (espec_sys > 0) e = sqrt(sys2 + e * e);
     const double ie = 1.0 / e;
@@ -1252,9 +1503,16 @@ extern "C" int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
   double *armchi = (double *)scratch;
   int32_t *armst = (int32_t *)(armchi + (int64_t)narm * J);
   dim3 grid(J, narm);
+  size_t shm = 0;
+  for (int i = 0; i < narm; i++)
+    if (arms[i].taps) {
+      if (arms[i].nd < 1 || (arms[i].nd & 1) == 0) return RVS_E_ARG;
+      shm = max(shm, (size_t)arms[i].npix * sizeof(double));
+    }
+  if (shm > 60 * 1024) return RVS_E_ARG;
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \
-    hipLaunchKernelGGL(point_block_kernel<PP>, grid, dim3(256), 0, st, A,      \
+    hipLaunchKernelGGL(point_block_kernel<PP>, grid, dim3(256), shm, st, A,    \
                        job_spec, job_templ, J, vel, espec_sys, armchi, armst); \
     break;
   switch (npoly) {

@@ -73,10 +73,48 @@ def get_poly_basis(lam, npoly, rbf=True):
     return out
 
 
-class ArmData:
-    """One spectral arm of a batch: S spectra on a common wavelength grid."""
+RES_MAXND = 33
 
-    def __init__(self, name, lam, spec, espec, badmask=None, device='cuda'):
+
+def resol_taps(mats, npix):
+    """A9: banded resolution matrices (scipy.sparse, e.g. the dia matrices of
+    construct_resol_mat / desi_fit.construct_resolution_sparse_matrix) as row
+    taps for the kernels: taps[s, k, d] = R_s[k, k - m + d], m = (nd-1)/2.
+    Returns (taps float64 [len(mats), npix, nd], nd)."""
+    import scipy.sparse
+    m = 0
+    dias = []
+    for M in mats:
+        D = scipy.sparse.dia_matrix(M)
+        assert D.shape == (npix, npix)
+        offs = [int(o) for o, row in zip(D.offsets, D.data) if np.any(row != 0)]
+        if offs:
+            m = max(m, max(abs(o) for o in offs))
+        dias.append(D)
+    nd = 2 * m + 1
+    if nd > RES_MAXND:
+        raise NotImplementedError('resolution matrix wider than %d diagonals'
+                                  % RES_MAXND)
+    taps = np.zeros((len(mats), npix, nd))
+    k = np.arange(npix)
+    for i, D in enumerate(dias):
+        for o, row in zip(D.offsets, D.data):
+            o = int(o)
+            if abs(o) > m:
+                continue
+            # dia storage: data[d, j] = R[j - o, j]  ->  R[k, k + o] = row[k + o]
+            ok = (k + o >= 0) & (k + o < npix)
+            taps[i, k[ok], m + o] += row[k[ok] + o]
+    return taps, nd
+
+
+class ArmData:
+    """One spectral arm of a batch: S spectra on a common wavelength grid.
+    resolution: None, or a list of S scipy.sparse matrices (SpecData.resolution
+    .mat, spec_fit.py:54-67) applied to the resampled template (A9)."""
+
+    def __init__(self, name, lam, spec, espec, badmask=None, device='cuda',
+                 resolution=None):
         _lib.require_gpu()
         self.name = name
         self.device = device
@@ -96,6 +134,28 @@ class ArmData:
         self._basis = {}
         self._work = {}
         self._ccf = {}
+        self.resol = None
+        if resolution is not None:
+            self.set_resolution(resolution)
+
+    def set_resolution(self, mats):
+        assert len(mats) in (1, self.S)
+        taps, nd = resol_taps(mats, self.npix)
+        self.resol = make_resol(taps, nd, self.S, self.device)
+
+    def subset(self, idx):
+        """ArmData of the spectra idx (device long tensor)"""
+        a = ArmData(self.name, self.lam_host, self.spec[idx], self.espec[idx],
+                    self.badmask[idx], device=self.device)
+        if self.resol is not None:
+            r = self.resol
+            if r['stride'] == 0:
+                a.resol = dict(r)
+            else:
+                a.resol = dict(taps=r['taps'][idx].contiguous(), nd=r['nd'],
+                               stride=r['stride'],
+                               unit=r['unit'][idx].contiguous())
+        return a
 
     def _as2d(self, a, dtype):
         if isinstance(a, torch.Tensor):
@@ -204,6 +264,18 @@ class ArmData:
         return T
 
 
+def make_resol(taps, nd, S, device):
+    """device form of row taps [n, npix, nd] (n = 1: shared by all spectra)"""
+    t = torch.as_tensor(np.ascontiguousarray(taps)).to(device)
+    n, npix = t.shape[0], t.shape[1]
+    unit = t.sum(dim=2)  # R @ 1
+    if n == 1:
+        unit = unit.expand(S, npix)
+    return dict(taps=t.contiguous(), nd=int(nd),
+                stride=0 if n == 1 else npix * int(nd),
+                unit=unit.contiguous())
+
+
 class SpecBatch:
     """A batch of S spectra, each observed in the same list of arms."""
 
@@ -226,13 +298,22 @@ class SpecBatch:
                 if not np.array_equal(sl[ia].lam, sd0.lam):
                     raise ValueError('spectra of one arm must share the '
                                      'wavelength grid to be batched')
+            res = [getattr(sl[ia], 'resolution', None) for sl in specdata_lists]
+            if any(r is not None for r in res) and any(r is None for r in res):
+                raise ValueError('either every spectrum of an arm carries a '
+                                 'resolution matrix or none does')
             arms.append(
                 ArmData(sd0.name, sd0.lam,
                         np.stack([sl[ia].spec for sl in specdata_lists]),
                         np.stack([sl[ia].espec for sl in specdata_lists]),
                         np.stack([np.asarray(sl[ia].badmask, dtype=np.uint8)
-                                  for sl in specdata_lists]), device=device))
+                                  for sl in specdata_lists]), device=device,
+                        resolution=None if res[0] is None else
+                        [r.mat for r in res]))
         return cls(arms)
+
+    def subset(self, idx):
+        return SpecBatch([a.subset(idx) for a in self.arms])
 
 
 def _chunks(n, size):
@@ -324,9 +405,19 @@ def lds_chunk(arm, lib, vmin, vmax):
     return best
 
 
+def _arm_resol(arm, ia, resols):
+    """resolution of arm ia: the `resol_params` override or the spectra's own"""
+    if resols is not None and resols[ia] is not None:
+        if arm.resol is not None:
+            raise ValueError('You are not allowed to set resol_param together '
+                             'with the resolution of each SpecData')
+        return resols[ia]
+    return arm.resol
+
+
 def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
                job_spec=None, job_templ=None, espec_sys=0.0,
-               outside_penalty=True, out=None, vel_bounds=None):
+               outside_penalty=True, out=None, vel_bounds=None, resols=None):
     """chi^2 of J jobs on a velocity grid, summed over the arms of `batch`.
 
     coefs[a]    [Tn, ntp_a, 4]   spline records of arm a
@@ -366,16 +457,29 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
         # a non finite penalty stays non finite (unusable template)
         pen = (pen + logdet_off).contiguous()
         coef = coefs[ia]
+        rs = _arm_resol(arm, ia, resols)
         for a, b in _chunks(J, 65535):
           with _ktime('chisq_grid', (b - a)):
+            js = _lib.ptr(job_spec[a:b]) if job_spec is not None else \
+                (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None)
+            jt = _lib.ptr(job_templ[a:b]) if job_templ is not None else \
+                (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None)
+            if rs is not None:   # A9: banded resolution matrix
+                rc = L.rvs_chisq_grid_resol(
+                    _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(work),
+                    arm.npix, npoly, arm.S, _lib.ptr(lib.knots), _lib.ptr(coef),
+                    lib.ntp, coef.shape[0], int(lib.log_step),
+                    _lib.ptr(rs['taps']), rs['nd'], rs['stride'], js, jt, b - a,
+                    _lib.ptr(vels if shared else vels[a:b]), vstride, Nv,
+                    _lib.ptr(pen[a:b]), float(batch.badchi),
+                    0.0 if ia == 0 else 1.0, _lib.ptr(out[a:b]),
+                    _lib.ptr(status[a:b]), _lib.stream())
+                _lib.check(rc, 'rvs_chisq_grid_resol')
+                continue
             rc = L.rvs_chisq_grid(
                 _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(work), arm.npix,
                 npoly, arm.S, _lib.ptr(lib.knots), _lib.ptr(coef), lib.ntp,
-                coef.shape[0], int(lib.log_step),
-                _lib.ptr(job_spec[a:b]) if job_spec is not None else
-                (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None),
-                _lib.ptr(job_templ[a:b]) if job_templ is not None else
-                (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None), b - a,
+                coef.shape[0], int(lib.log_step), js, jt, b - a,
                 _lib.ptr(vels if shared else vels[a:b]), vstride, Nv,
                 _lib.ptr(pen[a:b]), float(batch.badchi),
                 0.0 if ia == 0 else 1.0, chunk, _lib.ptr(out[a:b]),
@@ -386,7 +490,7 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
 
 def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
                 job_spec=None, job_templ=None, espec_sys=0.0,
-                outside_penalty=True):
+                outside_penalty=True, resols=None):
     """get_chisq for J (spectrum, template, velocity) triples, all arms in one
     launch set (rvs_chisq_point: lane per job, explicit residual norm).
     vel [J]; returns chisq [J], status int32 [J]."""
@@ -421,6 +525,10 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
         a.coef, a.penalty = coef.data_ptr(), pen.data_ptr()
         a.npix, a.S, a.ntp = arm.npix, arm.S, lib.ntp
         a.log_step = int(lib.log_step)
+        rs = _arm_resol(arm, ia, resols)
+        if rs is not None:
+            a.taps, a.taps_stride, a.nd = rs['taps'].data_ptr(), rs['stride'], \
+                rs['nd']
     with _ktime('chisq_point', J):
         rc = L.rvs_chisq_point(ctypes.addressof(arr), narm, npoly,
                                _lib.ptr(job_spec), _lib.ptr(job_templ), J,
@@ -462,7 +570,7 @@ def grid_moments(chisq, vels, Np=1, nvel=None, quadratic=True):
 
 def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
                job_templ=None, espec_sys=0.0, unit_template=False,
-               want_models=True):
+               want_models=True, resols=None):
     """Per-arm full output (spec_fit.py:941-961) for one velocity per job."""
     L = _lib.lib()
     dev = batch.device
@@ -481,6 +589,7 @@ def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
             model = torch.empty((J, arm.npix), dtype=torch.float64, device=dev)
             raw = torch.empty((J, arm.npix), dtype=torch.float64, device=dev)
         coef = None if unit_template else coefs[ia]
+        rs = _arm_resol(arm, ia, resols)
         rc = L.rvs_chisq_full(
             _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(arm.spec),
             _lib.ptr(arm.espec), _lib.ptr(arm.badmask), arm.npix, npoly, arm.S,
@@ -489,7 +598,9 @@ def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
             int(lib.log_step) if lib else 1, 1, int(unit_template),
             _lib.ptr(job_spec), _lib.ptr(job_templ), J,
             _lib.ptr(vel.contiguous()) if vel is not None else None,
-            float(espec_sys), _lib.ptr(chisq), _lib.ptr(coeffs),
+            float(espec_sys), _lib.ptr(rs['taps']) if rs else None,
+            rs['nd'] if rs else 0, rs['stride'] if rs else 0,
+            _lib.ptr(chisq), _lib.ptr(coeffs),
             _lib.ptr(model), _lib.ptr(raw), _lib.ptr(tchi), _lib.ptr(ngood),
             _lib.ptr(status), _lib.stream())
         _lib.check(rc, 'rvs_chisq_full')
@@ -515,9 +626,11 @@ def chisq_continuum(batch, npoly=5, rbf=True):
         if npoly <= 16:
             nb = L.rvs_chisq_continuum_work_size(npoly, S)
             work = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+            ut = arm.resol['unit'] if arm.resol is not None else None
             rc = L.rvs_chisq_continuum(_lib.ptr(polysT), _lib.ptr(arm.spec),
                                        _lib.ptr(arm.espec), _lib.ptr(arm.badmask),
-                                       arm.npix, npoly, S, _lib.ptr(work), None,
+                                       _lib.ptr(ut), arm.npix, npoly, S,
+                                       _lib.ptr(work), None,
                                        _lib.ptr(tchi),
                                        _lib.ptr(ngood), _lib.ptr(status),
                                        _lib.stream())
@@ -535,9 +648,7 @@ def chisq_continuum_fix(batch, res, npoly=5, rbf=True):
         bad = torch.nonzero(res[ia]['status'] & _lib.ST_CHOL_FALLBACK).reshape(-1)
         if bad.numel() == 0:
             continue
-        sub = SpecBatch([ArmData(arm.name, arm.lam_host, arm.spec[bad],
-                                 arm.espec[bad], arm.badmask[bad],
-                                 device=batch.device)])
+        sub = SpecBatch([arm.subset(bad)])
         full = chisq_full(sub, None, None, None, npoly=npoly, rbf=rbf,
                           unit_template=True, want_models=False)[0]
         res[ia]['true_chisq'][bad] = full['true_chisq']

@@ -29,7 +29,7 @@ class ProcessObjective:
     """chisq_func for rows (list[j], X[j]) on preallocated buffers."""
 
     def __init__(self, batch, libs, names, pd0, fixParam, fitVsini, config,
-                 options, priors, safe_params):
+                 options, priors, safe_params, resols=None):
         L = _lib.lib()
         self.L = L
         self.batch, self.libs = batch, libs

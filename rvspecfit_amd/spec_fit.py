@@ -19,20 +19,72 @@ from . import spec_inter
 from .engine import SpecBatch, get_poly_basis, SPEED_OF_LIGHT  # noqa: F401
 
 
+class ResolMatrix:
+    """spec_fit.ResolMatrix (spec_fit.py:54-67): a (banded, scipy.sparse)
+    resolution matrix applied to the resampled template"""
+
+    def __init__(self, mat):
+        self.fd = {'mat': mat}
+        self.objid = random.getrandbits(128)
+
+    def __hash__(self):
+        return self.objid
+
+    @property
+    def mat(self):
+        return self.fd['mat']
+
+
+def construct_resol_mat(lam, resol=None, width=None):
+    """spec_fit.construct_resol_mat (spec_fit.py:410-471): Gaussian rows of
+    sigma lam/resol/2.35 (or `width` Angstrom), truncated at 5 sigma, each row
+    normalised; host code (built once per grid)."""
+    import scipy.sparse
+    assert (resol is None or width is None)
+    assert (resol is not None or width is not None)
+    lam = np.asarray(lam, dtype=np.float64)
+    if resol is not None:
+        sigs = lam / resol / 2.35
+    elif np.isscalar(width):
+        sigs = np.zeros(len(lam)) + width
+    else:
+        sigs = np.asarray(width, dtype=np.float64)
+    thresh = 5
+    assert (np.all(np.diff(lam) > 0))
+    n = len(lam)
+    i1 = np.maximum(np.searchsorted(lam, lam - thresh * sigs, 'left'), 0)
+    i2 = np.minimum(np.searchsorted(lam, lam + thresh * sigs, 'right'), n - 1)
+    pix = np.arange(n)
+    maxl = min(n, max(np.max(i2 - pix), np.max(pix - i1)))
+    offsets = np.arange(-maxl, maxl + 1)
+    xs2d = pix[None, :] + offsets[:, None]
+    mask = (xs2d >= 0) & (xs2d < n)
+    xs2d[~mask] = 0
+    XL = np.exp(-0.5 * ((lam[xs2d] - lam[None, :]) / sigs[None, :])**2) * mask
+    XL = XL / XL.sum(axis=0)[None, :]
+    yids = (pix[None, :] + (n - offsets)[:, None]) % n
+    xids = yids * 0 + maxl + offsets[:, None]
+    XL = XL[xids, yids]
+    return ResolMatrix(scipy.sparse.spdiags(XL, offsets, n, n))
+
+
+def convolve_resol(spec, resol_matrix):
+    """spec_fit.convolve_resol (spec_fit.py:474-492); host API.  Inside the
+    likelihood kernels the matrix is applied on the device (rvs_chisq_grid_resol
+    and the `taps` argument of rvs_chisq_full / rvs_chisq_point)."""
+    return resol_matrix.mat @ spec
+
+
 class SpecData:
     """spec_fit.SpecData (spec_fit.py:70-145): one spectroscopic dataset."""
 
     def __init__(self, name, lam, spec, espec, badmask=None, resolution=None,
                  dtype=np.float64):
-        if resolution is not None:
-            raise NotImplementedError(
-                'resolution matrices are outside the accelerated hot path '
-                '(SURVEY 8(f) rank 4)')
         self.name = name
         self.lam = np.ascontiguousarray(lam, dtype=dtype)
         self.spec = np.ascontiguousarray(spec, dtype=dtype)
         self.espec = np.ascontiguousarray(espec, dtype=dtype)
-        self.resolution = None
+        self.resolution = resolution
         self.spec_error_ratio = self.spec / self.espec
         if badmask is None:
             badmask = np.zeros(len(self.spec), dtype=bool)
@@ -99,6 +151,31 @@ def _vsini_tensor(rot_params, S, dev):
     if v.numel() == 1:
         v = v.expand(S)
     return v.contiguous()
+
+
+_resol_cache = None
+
+
+def _resols(batch, resol_params):
+    """`resol_params` {setup: ResolMatrix} (shared by every spectrum of the arm,
+    spec_fit.py:866-867, 922-923) -> per-arm device taps, or None"""
+    if resol_params is None:
+        return None
+    global _resol_cache
+    if _resol_cache is None:
+        _resol_cache = LRUDict(16)
+    out = []
+    for arm in batch.arms:
+        R = resol_params[arm.name]
+        if arm.resol is not None:
+            raise ValueError('You are not allowed to set resol_param together '
+                             'with the resolution of each SpecData')
+        key = (hash(R), arm.S, str(batch.device))
+        if key not in _resol_cache:
+            taps, nd = engine.resol_taps([R.mat], arm.npix)
+            _resol_cache[key] = engine.make_resol(taps, nd, arm.S, batch.device)
+        out.append(_resol_cache[key])
+    return out
 
 
 def _overlap_check(templ_l0, templ_l1, spec_l0, spec_l1, min_vel, max_vel):
@@ -213,8 +290,6 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
     SpecBatch: vel [S], atm_params [S, ndim] (or one tuple), rot_params None or
     vsini [S]; returns a device tensor [S] (or dict of tensors) and never
     raises for per-spectrum conditions (see 'status')."""
-    if resol_params is not None:
-        raise NotImplementedError('resolution matrices: SURVEY 8(f) rank 4')
     if fast_interp:
         raise NotImplementedError('fast_interp (nearest pixel) is not on the '
                                   'accelerated path')
@@ -225,6 +300,7 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
     rbf = options.get('rbf_continuum', True)
     batch, is_batch = as_batch(specdata)
     S, dev = batch.S, batch.device
+    resols = _resols(batch, resol_params)
     libs = spec_inter.get_libs(batch.names, config)
     ndim = libs[batch.names[0]].ndim
     params = _params_tensor(atm_params, S, ndim, dev)
@@ -244,7 +320,8 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
         outs.append(o)
     chisq, status = engine.chisq_grid(batch, libs, coefs, outs, velt,
                                       npoly=npoly, rbf=rbf, espec_sys=esys,
-                                      outside_penalty=outside_penalty)
+                                      outside_penalty=outside_penalty,
+                                      resols=resols)
     chisq = chisq[:, 0]
     # reference: a non finite arm value of an OUTSIDE template is skipped with
     # a warning instead of raising (spec_fit.py:963-969); we flag it in status
@@ -256,7 +333,7 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
     if not full_output:
         return chisq if is_batch else float(chisq[0].item())
     full = engine.chisq_full(batch, libs, coefs, velt[:, 0].contiguous(),
-                             npoly=npoly, rbf=rbf, espec_sys=esys)
+                             npoly=npoly, rbf=rbf, espec_sys=esys, resols=resols)
     ret = {}
     ret['chisq'] = chisq if is_batch else float(chisq[0].item())
     ret['logl'] = -0.5 * ret['chisq']
@@ -282,7 +359,7 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
 
 
 def chisq_jobs(batch, idx, vel, params, vsini, options, config,
-               outside_penalty=True, espec_systematic=None):
+               outside_penalty=True, espec_systematic=None, resol_params=None):
     """get_chisq for J jobs: job j is spectrum idx[j] against its own template
     (params[j], vsini[j]) at velocity vel[j] (rvs_chisq_point: one lane per
     job, residual norm formed explicitly as in spec_fit.py:249).
@@ -300,11 +377,13 @@ def chisq_jobs(batch, idx, vel, params, vsini, options, config,
     esys = float(espec_systematic) if espec_systematic is not None else 0.0
     return engine.chisq_point(batch, libs, coefs, outs, vel, npoly=npoly,
                               rbf=rbf, job_spec=idx.to(torch.int32).contiguous(),
-                              espec_sys=esys, outside_penalty=outside_penalty)
+                              espec_sys=esys, outside_penalty=outside_penalty,
+                              resols=_resols(batch, resol_params))
 
 
 def chisq_grid_jobs(batch, vel_grid, params, vsini, options, config,
-                    outside_penalty=True, espec_systematic=None):
+                    outside_penalty=True, espec_systematic=None,
+                    resol_params=None):
     """chi^2 [S, Np, Nv] for params [S, Np, ndim] (device) on a shared or
     per-spectrum velocity grid: the double loop of find_best as one launch set."""
     options = options or {}
@@ -331,7 +410,8 @@ def chisq_grid_jobs(batch, vel_grid, params, vsini, options, config,
     chisq, status = engine.chisq_grid(batch, libs, coefs, outs, vg,
                                       npoly=npoly, rbf=rbf, job_spec=job_spec,
                                       espec_sys=esys,
-                                      outside_penalty=outside_penalty)
+                                      outside_penalty=outside_penalty,
+                                      resols=_resols(batch, resol_params))
     return chisq.reshape(S, Np, -1), status.reshape(S, Np), outs
 
 
@@ -342,8 +422,6 @@ def find_best(specdata, vel_grid, params_list, rot_params=None,
     One spectrum: same dict as the reference (numpy / floats).
     SpecBatch: params_list is [Np][ndim] (shared) or a tensor [S, Np, ndim];
     values are device tensors with a leading S axis."""
-    if resol_params is not None:
-        raise NotImplementedError('resolution matrices: SURVEY 8(f) rank 4')
     batch, is_batch = as_batch(specdata)
     S, dev = batch.S, batch.device
     if isinstance(params_list, torch.Tensor):
@@ -362,7 +440,8 @@ def find_best(specdata, vel_grid, params_list, rot_params=None,
                        float(vg.max().item()))
     vsini = _vsini_tensor(rot_params, S, dev)
     chisq, status, outs = chisq_grid_jobs(batch, vg, params.contiguous(), vsini,
-                                          options, config)
+                                          options, config,
+                                          resol_params=resol_params)
     res, probs, mst = engine.grid_moments(chisq.reshape(S * Np, -1), vg, Np=Np,
                                           quadratic=quadratic)
     i2 = res[:, 6].long()

@@ -24,8 +24,6 @@ def firstguess(specdata, options=None, config=None, resolParams=None,
                vsinigrid=(None, 10, 100), paramsgrid=None):
     """vel_fit.firstguess (vel_fit.py:13-94).  One spectrum -> dict of best
     parameters; SpecBatch -> dict of [S] tensors."""
-    if resolParams is not None:
-        raise NotImplementedError('resolution matrices: SURVEY 8(f) rank 4')
     options = options or {}
     if paramsgrid is None:
         paramsgrid = {'logg': [1, 2, 3, 4, 5], 'teff': [3000, 5000, 8000, 10000],
@@ -44,7 +42,8 @@ def firstguess(specdata, options=None, config=None, resolParams=None,
     for vs in vsinigrid:
         rot = None if vs is None else (vs, )
         r = spec_fit.find_best(batch, vg, params, rot_params=rot,
-                               config=config, options=options)
+                               resol_params=resolParams, config=config,
+                               options=options)
         better = r['best_chi'] < best_chi
         best_chi = torch.where(better, r['best_chi'], best_chi)
         best_par = torch.where(better[:, None], r['best_param'], best_par)
@@ -70,7 +69,8 @@ def firstguess(specdata, options=None, config=None, resolParams=None,
 
 
 def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
-                           crit_ratio=5, goal_width=10, max_points=2048):
+                           crit_ratio=5, goal_width=10, max_points=2048,
+                           resolParams=None):
     """Batched _minimum_sampler (vel_fit.py:358-439): every spectrum carries
     its own (min_vel, max_vel, step) state; per round all spectra that are not
     converged are evaluated on their own velocity grids in one launch set.
@@ -119,7 +119,8 @@ def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
         p = params[idt][:, None, :].contiguous()
         vs = None if vsini is None else vsini[idt]
         chisq, status, _ = spec_fit.chisq_grid_jobs(sub, vgt, p, vs, options,
-                                                    config)
+                                                    config,
+                                                    resol_params=resolParams)
         res, _, _ = engine.grid_moments(chisq.reshape(len(idx), -1), vgt, Np=1,
                                         nvel=torch.as_tensor(nv).to(dev))
         r = res.cpu().numpy()
@@ -148,11 +149,7 @@ def _sub_batch(batch, idx):
     """view of a subset of spectra as a SpecBatch (full batch -> itself)"""
     if len(idx) == batch.S:
         return batch
-    idt = torch.as_tensor(idx).to(batch.device)
-    arms = [engine.ArmData(a.name, a.lam_host, a.spec[idt], a.espec[idt],
-                           a.badmask[idt], device=batch.device)
-            for a in batch.arms]
-    return engine.SpecBatch(arms)
+    return batch.subset(torch.as_tensor(idx).to(batch.device))
 
 
 def _find_best_vel_iterate(best_vel, min_vel, max_vel, vel_step0, specdata=None,
@@ -170,7 +167,7 @@ def _find_best_vel_iterate(best_vel, min_vel, max_vel, vel_step0, specdata=None,
     cfg.update(min_vel=min_vel, max_vel=max_vel, vel_step0=vel_step0,
                min_vel_step=min_vel_step)
     r = _minimum_sampler_batch(batch, [best_vel], best_param['params'], vs, cfg,
-                               options)
+                               options, resolParams=resolParams)
     return (float(r['best_vel'][0]), float(r['vel_err'][0]),
             float(r['skewness'][0]), float(r['kurtosis'][0]))
 
@@ -321,7 +318,9 @@ def _get_simplex_start(best_vel, fixParam, specParamNames, paramDict0,
 class _Objective:
     """chisq_func / chisq_func0 (vel_fit.py:205-254) for J jobs at a time."""
 
-    def __init__(self, batch, mapper, config, options, priors):
+    def __init__(self, batch, mapper, config, options, priors,
+                 resolParams=None):
+        self.resolParams = resolParams
         self.batch, self.mapper = batch, mapper
         self.config, self.options, self.priors = config, options, priors
         self.min_vel, self.max_vel = config['min_vel'], config['max_vel']
@@ -339,7 +338,8 @@ class _Objective:
                     sg = sg[idx] if isinstance(sg, torch.Tensor) else sg
                     chisq = chisq + ((m - params[:, i]) / sg)**2
         c, st = spec_fit.chisq_jobs(self.batch, idx, vel, params, vsini,
-                                    self.options, self.config)
+                                    self.options, self.config,
+                                    resol_params=self.resolParams)
         self.status[idx] |= st
         self.nfev += idx.numel()
         return chisq + c
@@ -418,8 +418,6 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
     from . import neldermead
     if config is None:
         raise RuntimeError('Config must be provided')
-    if resolParams is not None:
-        raise NotImplementedError('resolution matrices: SURVEY 8(f) rank 4')
     options = options or {}
     batch, is_batch = as_batch(specdata)
     S, dev = batch.S, batch.device
@@ -451,7 +449,8 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
     vg = torch.as_tensor(np.arange(min_vel, max_vel, vel_step0,
                                    dtype=np.float64)).to(dev)
     chisq, st0, _ = spec_fit.chisq_grid_jobs(batch, vg, curparam[:, None, :],
-                                             vsini0, options, config)
+                                             vsini0, options, config,
+                                             resol_params=resolParams)
     res, _, mst = engine.grid_moments(chisq.reshape(S, -1), vg, Np=1)
     best_vel = res[:, 1].contiguous()
     _tick('grid0', t0)
@@ -460,7 +459,7 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
     curval, simplex = _get_simplex_start(best_vel, fixParam, names, pd0,
                                          vsiniMapper, fitVsini)
     mapper = ParamMapper(names, pd0, fixParam, vsiniMapper, fitVsini=fitVsini)
-    obj = _Objective(batch, mapper, config, options, priors)
+    obj = _Objective(batch, mapper, config, options, priors, resolParams)
     obj.safe_params = curparam
     stats = {}
     # vel_fit.py:624-649: a second run restarts from the final simplex
@@ -469,9 +468,9 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
         libs[a.name].kind == 'regulargrid' for a in batch.arms)
     if use_device_nm:
         from . import optimizer
-        pobj = optimizer.ProcessObjective(batch, libs, names, pd0, fixParam,
-                                          fitVsini, config, options, priors,
-                                          curparam)
+        pobj = optimizer.ProcessObjective(
+            batch, libs, names, pd0, fixParam, fitVsini, config, options, priors,
+            curparam, resols=spec_fit._resols(batch, resolParams))
         nm = optimizer.DeviceNelderMead(S, simplex.shape[2], dev).minimize(
             pobj, simplex, fatol=1e-3, xatol=1e-2, maxiter=10000, stats=stats)
         obj.status |= pobj.status
@@ -501,14 +500,15 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
     # vel_fit.py:672-682
     t0 = time.time()
     vel_in = nm_vel.cpu().numpy()
-    r = _minimum_sampler_batch(batch, vel_in, bparams, bvsini, config, options)
+    r = _minimum_sampler_batch(batch, vel_in, bparams, bvsini, config, options,
+                               resolParams=resolParams)
     best_vel = torch.as_tensor(r['best_vel']).to(dev)
     _tick('vel_refine', t0)
 
     # vel_fit.py:689-696
     t0 = time.time()
     outp = spec_fit.get_chisq(batch, best_vel, bparams,
-                              None if bvsini is None else bvsini,
+                              None if bvsini is None else bvsini, resolParams,
                               options=options, config=config, full_output=True)
     _tick('full_output', t0)
 

@@ -311,3 +311,62 @@ def test_process_oracle_vs_reference(cases, gold_libs, gold_config, t):
     np.testing.assert_allclose(gerr[ok], err[ok], rtol=1e-3)
     assert r['bad_hessian'] == bool(g[t + '/bad_hessian'])
     assert r['minimize_success'] == bool(g[t + '/minimize_success'])
+
+
+# --------------------------------------------------------------------------
+# A9: resolution matrices
+# --------------------------------------------------------------------------
+def _dia(g, key, n):
+    import scipy.sparse
+    return scipy.sparse.dia_matrix((g[key + '/data'], g[key + '/offsets']),
+                                   shape=(n, n))
+
+
+@pytest.mark.parametrize('tag', ['c1', 'c2'])
+def test_resolution_matrix_oracle(cases, gold_libs, gold_config, tag):
+    import os
+    from conftest import GOLD
+    g = np.load(os.path.join(GOLD, 'resol_cases.npz'))
+    names = [str(_) for _ in cases[tag + '/names']]
+    sds = gold_specdata(cases, tag, orc.SpecData)
+    opt = dict(npoly=10)
+    # the oracle's construct_resol_mat against the reference's matrices
+    rp = {}
+    for sd in sds:
+        n = len(sd.lam)
+        ref = _dia(g, '%s/rp/%s' % (tag, sd.name), n)
+        mine = orc.construct_resol_mat(sd.lam, resol=2500.)
+        np.testing.assert_allclose(mine.toarray(), ref.toarray(), rtol=1e-13,
+                                   atol=1e-300)
+        rp[sd.name] = ref
+    for i in range(3):
+        vs = float(g['%s/rp/t%d/vsini' % (tag, i)])
+        rot = None if np.isnan(vs) else (vs, )
+        val = orc.get_chisq(sds, float(g['%s/rp/t%d/vel' % (tag, i)]),
+                            tuple(g['%s/rp/t%d/param' % (tag, i)]), rot,
+                            options=opt, config=gold_config, libs=gold_libs,
+                            resol_params=rp)
+        want = float(g['%s/rp/t%d/value' % (tag, i)])
+        assert abs(val - want) < 1e-8 * max(abs(want), 1e3)
+    fb = orc.find_best(sds, g['vel_grid'], [tuple(cases[tag + '/truth'])],
+                       options=opt, config=gold_config, libs=gold_libs,
+                       resol_params=rp)
+    np.testing.assert_allclose(fb['chisq_grid'][:, 0], g[tag + '/rp/grid'],
+                               rtol=1e-8)
+    np.testing.assert_allclose([fb['best_vel'], fb['vel_err'], fb['best_chi']],
+                               g[tag + '/rp/find_best'], rtol=1e-7, atol=1e-9)
+    # per-spectrum matrices + continuum
+    sds2 = [orc.SpecData(sd.name, sd.lam, sd.spec, sd.espec, badmask=sd.badmask,
+                         resolution=_dia(g, '%s/own/%s' % (tag, sd.name),
+                                         len(sd.lam))) for sd in sds]
+    for i in range(3):
+        vs = float(g['%s/rp/t%d/vsini' % (tag, i)])
+        rot = None if np.isnan(vs) else (vs, )
+        val = orc.get_chisq(sds2, float(g['%s/rp/t%d/vel' % (tag, i)]),
+                            tuple(g['%s/rp/t%d/param' % (tag, i)]), rot,
+                            options=opt, config=gold_config, libs=gold_libs)
+        want = float(g['%s/own/t%d/value' % (tag, i)])
+        assert abs(val - want) < 1e-8 * max(abs(want), 1e3)
+    c = orc.get_chisq_continuum(sds2, options=opt)
+    np.testing.assert_allclose(c['chisq_array'], g[tag + '/own/cont/chisq_array'],
+                               rtol=1e-9)

@@ -383,7 +383,10 @@ def main():
             traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
-    roof = dict(bound='hbm', kernel='ccf_xcorr_kernel', achieved=round(ccf_gbs, 1),
+    roof = dict(bound='hbm', kernel='ccf_xcorr_kernel',
+                timed='rvs_ccf_xcorr call = ccf_rfft_kernel + ccf_xcorr_kernel '
+                      '(HIP events on the launch stream)',
+                achieved=round(ccf_gbs, 1),
                 peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ccf_gbs / HBM_PEAK_GBS, 4),
                 traffic=traffic,
                 bytes_per_spectrum=b_ccf_unit,

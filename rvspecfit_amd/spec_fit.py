@@ -383,13 +383,16 @@ def chisq_jobs(batch, idx, vel, params, vsini, options, config,
 
 def chisq_grid_jobs(batch, vel_grid, params, vsini, options, config,
                     outside_penalty=True, espec_systematic=None,
-                    resol_params=None):
+                    resol_params=None, spec_idx=None):
     """chi^2 [S, Np, Nv] for params [S, Np, ndim] (device) on a shared or
-    per-spectrum velocity grid: the double loop of find_best as one launch set."""
+    per-spectrum velocity grid: the double loop of find_best as one launch set.
+    spec_idx (device int [S']): rows refer to these spectra of the batch (the
+    batch's per-spectrum preparation is reused, nothing is copied)."""
     options = options or {}
     npoly = options.get('npoly') or 5
     rbf = options.get('rbf_continuum', True)
-    S, dev = batch.S, batch.device
+    dev = batch.device
+    S = batch.S if spec_idx is None else int(spec_idx.shape[0])
     libs = spec_inter.get_libs(batch.names, config)
     Np = params.shape[1]
     flat = params.reshape(S * Np, -1).contiguous()
@@ -401,8 +404,9 @@ def chisq_grid_jobs(batch, vel_grid, params, vsini, options, config,
         c, o = engine.build_templates(libs[arm.name], flat, vs)
         coefs.append(c)
         outs.append(o)
-    job_spec = torch.arange(S, dtype=torch.int32, device=dev
-                            ).repeat_interleave(Np).contiguous()
+    rows = torch.arange(S, dtype=torch.int32, device=dev) \
+        if spec_idx is None else spec_idx.to(torch.int32)
+    job_spec = rows.repeat_interleave(Np).contiguous()
     vg = vel_grid
     if vg.dim() == 2:  # per spectrum grids -> per job
         vg = vg.repeat_interleave(Np, dim=0).contiguous()

@@ -70,7 +70,7 @@ def firstguess(specdata, options=None, config=None, resolParams=None,
 
 def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
                            crit_ratio=5, goal_width=10, max_points=2048,
-                           resolParams=None):
+                           resolParams=None, keep_grids=False):
     """Batched _minimum_sampler (vel_fit.py:358-439): every spectrum carries
     its own (min_vel, max_vel, step) state; per round all spectra that are not
     converged are evaluated on their own velocity grids in one launch set.
@@ -93,51 +93,51 @@ def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
         torch.as_tensor(np.asarray(best_param, dtype=np.float64)).to(dev)
     if params.dim() == 1:
         params = params[None].expand(S, -1)
-    all_grids = [[] for _ in range(S)]
+    all_grids = [[] for _ in range(S)] if keep_grids else None
     for it in range(10):
         idx = np.nonzero(active)[0]
         if len(idx) == 0:
             break
-        grids = []
-        for i in idx:
-            g = np.arange(math.ceil((min_vel[i] - bv[i]) / step[i]) * step[i],
-                          max_vel[i] - bv[i], step[i]) + bv[i]
-            grids.append(g)
-            all_grids[i].append(g)
-        nmax = max(len(g) for g in grids)
+        # np.arange(start, stop, step) + bv for every active spectrum at once:
+        # values start + i*step (numpy's own formula), length ceil((stop-start)/step)
+        st_, bv_ = step[idx], bv[idx]
+        start = np.ceil((min_vel[idx] - bv_) / st_) * st_
+        stop = max_vel[idx] - bv_
+        nv = np.maximum(np.ceil((stop - start) / st_), 0).astype(np.int64)
+        nmax = int(nv.max())
         if nmax > max_points:
             raise RuntimeError('velocity grid too long')
-        vg = np.zeros((len(idx), nmax))
-        nv = np.zeros(len(idx), dtype=np.int32)
-        for k, g in enumerate(grids):
-            vg[k, :len(g)] = g
-            vg[k, len(g):] = g[-1]  # padding, ignored through nvel
-            nv[k] = len(g)
-        sub = _sub_batch(batch, idx)
+        ii = np.arange(nmax, dtype=np.float64)
+        vg = (start[:, None] + ii[None, :] * st_[:, None]) + bv_[:, None]
+        last = vg[np.arange(len(idx)), np.maximum(nv - 1, 0)]
+        vg = np.where(ii[None, :] < nv[:, None], vg, last[:, None])  # padding
+        if keep_grids:
+            for k, i in enumerate(idx):
+                all_grids[i].append(vg[k, :nv[k]].copy())
         vgt = torch.as_tensor(vg).to(dev)
         idt = torch.as_tensor(idx).to(dev)
         p = params[idt][:, None, :].contiguous()
         vs = None if vsini is None else vsini[idt]
-        chisq, status, _ = spec_fit.chisq_grid_jobs(sub, vgt, p, vs, options,
-                                                    config,
-                                                    resol_params=resolParams)
+        chisq, status, _ = spec_fit.chisq_grid_jobs(
+            batch, vgt, p, vs, options, config, resol_params=resolParams,
+            spec_idx=None if len(idx) == S else idt)
         res, _, _ = engine.grid_moments(chisq.reshape(len(idx), -1), vgt, Np=1,
-                                        nvel=torch.as_tensor(nv).to(dev))
+                                        nvel=torch.as_tensor(
+                                            nv.astype(np.int32)).to(dev))
         r = res.cpu().numpy()
-        for k, i in enumerate(idx):
-            bv[i], err[i], kur[i], skw[i] = r[k, 1], r[k, 2], r[k, 3], r[k, 4]
-            ngrids[i] += 1
-            ngrid_pts[i] += nv[k]
-            if step[i] < err[i] / crit_ratio or step[i] < min_vel_step:
-                active[i] = False
-                continue
-            if step[i] > err[i]:
-                new_step, width = step[i] / crit_ratio, step[i] * goal_width
-            else:
-                new_step, width = err[i] / crit_ratio * 0.8, err[i] * goal_width
-            min_vel[i] = max(bv[i] - width, min_vel[i])
-            max_vel[i] = min(bv[i] + width, max_vel[i])
-            step[i] = new_step
+        bv[idx], err[idx], kur[idx], skw[idx] = r[:, 1], r[:, 2], r[:, 3], r[:, 4]
+        ngrids[idx] += 1
+        ngrid_pts[idx] += nv
+        e_ = err[idx]
+        done = (st_ < e_ / crit_ratio) | (st_ < min_vel_step)
+        coarse = st_ > e_
+        new_step = np.where(coarse, st_ / crit_ratio, e_ / crit_ratio * 0.8)
+        width = np.where(coarse, st_ * goal_width, e_ * goal_width)
+        go = idx[~done]
+        active[idx[done]] = False
+        min_vel[go] = np.maximum(bv[go] - width[~done], min_vel[go])
+        max_vel[go] = np.minimum(bv[go] + width[~done], max_vel[go])
+        step[go] = new_step[~done]
     return dict(best_vel=bv, vel_err=err, skewness=skw, kurtosis=kur,
                 ngrids=ngrids, npoints=ngrid_pts, grids=all_grids)
 

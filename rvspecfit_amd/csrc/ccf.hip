@@ -73,6 +73,9 @@ __device__ __forceinline__ double median11(double *a) {
 }
 
 #define CCF_MAXNODE 24
+#ifndef RVS_LM_MAXIT
+#define RVS_LM_MAXIT 60
+#endif
 
 struct LMShared {
   double p[CCF_MAXNODE];                  // node values (start / result)
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(PP_NT)
       S.stop = 0;
     }
     double cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true);
-    for (int it = 0; it < 60; it++) {
+    for (int it = 0; it < RVS_LM_MAXIT; it++) {
       lm_normal(S, Eb, istart, m, gw, hw);
       // damped step; retry with larger damping until the cost does not grow
       for (int tries = 0; tries < 40; tries++) {

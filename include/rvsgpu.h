@@ -90,8 +90,8 @@ int rvs_vsini_convolve(const double *templ, const double *vsini,
 /* ------------------------------------------------------------------------
  * A7  natural cubic spline through (knots, ys[b]); replaces `construct`
  *     (src/spliner.c:7-60).  form 0: coef[b, i, 0..3] = A,B,C,D of interval i
- *     exactly as the reference (i < ntp-1; row ntp-1 is zero padding; h is
- *     implied by knots).  form 1: the SAME cubic in powers of dl = x - x_i,
+ *     exactly as the reference (i < ntp-1; row ntp-1 is zero padding -- in
+ *     form 1 it holds {y_last, 0, 0, 0}; h is implied by knots).  form 1: the SAME cubic in powers of dl = x - x_i,
  *     {y_i, b, c, d} with S = y + dl (b + dl (c + dl d)) -- 3 fma per evaluation,
  *     the form the fused chi^2 kernels consume.  form | 2: the caller asserts
  *     that neighbouring knot spacings agree to ~1 % (uniform or log-uniform
@@ -181,7 +181,9 @@ int rvs_chisq_grid_resol(const double *lam, const double *polysT,
  * get_chisq(full_output=True) for one velocity per job and one arm
  * (spec_fit.py:941-961), and get_chisq_continuum (spec_fit.py:739-783) when
  * unit_template != 0 (template == 1, knots/coef ignored).  cform = the form of
- * the spline records (see rvs_spline_construct).  taps (nullable): resolution
+ * the spline records (see rvs_spline_construct).  fast_interp: the template
+ * value is the nearest knot at or above x instead of the spline
+ * (spec_fit.py:913-918; needs cform = 1).  taps (nullable): resolution
  * matrix rows as in rvs_chisq_grid_resol, applied to the template (or to 1).
  * coeffs [J, npoly], model/raw_model [J, npix] (nullable), chisq [J] (-2logL
  * of the arm), true_chisq [J] over pixels with badmask==0, ngood int32 [J].
@@ -191,8 +193,9 @@ int rvs_chisq_full(const double *lam, const double *polysT, const double *spec,
                    int npoly, int S, const double *knots, const double *coef,
                    int ntp, int Tn, int log_step, int cform, int unit_template,
                    const int32_t *job_spec, const int32_t *job_templ, int J,
-                   const double *vel, double espec_sys, const double *taps,
-                   int nd, int64_t taps_stride, double *chisq, double *coeffs,
+                   const double *vel, double espec_sys, int fast_interp,
+                   const double *taps, int nd, int64_t taps_stride,
+                   double *chisq, double *coeffs,
                    double *model, double *raw_model, double *true_chisq,
                    int32_t *ngood, int32_t *status, void *stream);
 
@@ -236,13 +239,16 @@ typedef struct rvs_point_arm {
   const double *lam, *polysT, *spec, *espec, *work, *knots, *coef, *penalty;
   const double *taps;   /* A9 resolution matrix rows [S or 1, npix, nd] or NULL */
   int64_t taps_stride;  /* npix*nd, or 0 when all spectra share one matrix */
-  int32_t npix, S, ntp, log_step, nd, pad_;
+  double espec_sys;     /* systematic error in quadrature (spec_fit.py:933-940);
+                           `work` must have been prepared with the same value */
+  int32_t npix, S, ntp, log_step, nd;
+  int32_t fast_interp;  /* nearest-knot template instead of the spline (:913-918) */
 } rvs_point_arm;
 int64_t rvs_chisq_point_work_size(int J, int narm);
 int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
                     const int32_t *job_spec, const int32_t *job_templ, int J,
-                    const double *vel, double badchi, double espec_sys,
-                    void *scratch, double *out, int32_t *status, void *stream);
+                    const double *vel, double badchi, void *scratch,
+                    double *out, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------
  * A12  grid summary; replaces the tail of spec_fit.find_best

@@ -34,11 +34,11 @@ SIGNATURES = {
     'rvs_chisq_grid_resol': (I, [P, P, P, I, I, I, P, P, I, I, I, P, I, L, P, P,
                                  I, P, L, I, P, D, D, P, P, P]),
     'rvs_chisq_full': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, P, P, I,
-                           P, D, P, I, L, P, P, P, P, P, P, P, P]),
+                           P, D, I, P, I, L, P, P, P, P, P, P, P, P]),
     'rvs_chisq_continuum_work_size': (L, [I, I]),
     'rvs_chisq_continuum': (I, [P, P, P, P, P, I, I, I, P, P, P, P, P, P]),
     'rvs_chisq_point_work_size': (L, [I, I]),
-    'rvs_chisq_point': (I, [P, I, I, P, P, I, P, D, D, P, P, P, P]),
+    'rvs_chisq_point': (I, [P, I, I, P, P, I, P, D, P, P, P, P]),
     'rvs_nm_begin': (I, [I, I, D, D, I, P, P, P, P, P, P, P, I, P]),
     'rvs_nm_decide': (I, [I, P, P, P, P, P, P, P, P, P, I, P]),
     'rvs_nm_update': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P]),
@@ -87,9 +87,10 @@ class PointArm(ctypes.Structure):
     """rvs_point_arm of include/rvsgpu.h"""
     _fields_ = [(k, ctypes.c_void_p) for k in
                 ('lam', 'polysT', 'spec', 'espec', 'work', 'knots', 'coef',
-                 'penalty', 'taps')] + [('taps_stride', ctypes.c_int64)] + [
+                 'penalty', 'taps')] + [('taps_stride', ctypes.c_int64),
+                                        ('espec_sys', ctypes.c_double)] + [
                     (k, ctypes.c_int32) for k in
-                    ('npix', 'S', 'ntp', 'log_step', 'nd', 'pad_')]
+                    ('npix', 'S', 'ntp', 'log_step', 'nd', 'fast_interp')]
 
 
 def ptr(t):

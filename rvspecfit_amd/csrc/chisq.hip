@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(256)
                       const int32_t *__restrict__ job_spec,
                       const int32_t *__restrict__ job_templ,
                       const double *__restrict__ vel, double espec_sys,
-                      const double *__restrict__ taps, int nd,
+                      int fast_interp, const double *__restrict__ taps, int nd,
                       int64_t taps_stride,
                       double *__restrict__ chisq, double *__restrict__ coeffs,
                       double *__restrict__ model, double *__restrict__ raw_model,
@@ -824,6 +824,8 @@ __global__ void __launch_bounds__(256)
         const double dl = x - knots[pos], dr = knots[pos + 1] - x;
         tv = cform ? fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x)
                    : c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
+        if (fast_interp)  // nearest knot at or above x (spec_fit.py:913-918)
+          tv = cf[min(pos + (dl > 0 ? 1 : 0), ntp - 1)].x;
       }
       Ds[k] = tv;
     }
@@ -853,6 +855,8 @@ __global__ void __launch_bounds__(256)
       const double dl = x - knots[pos], dr = knots[pos + 1] - x;
       tv = cform ? fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x)
                  : c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
+      if (fast_interp)  // nearest knot at or above x (spec_fit.py:913-918)
+        tv = cf[min(pos + (dl > 0 ? 1 : 0), ntp - 1)].x;
     }
     if (raw_model) raw_model[(int64_t)j * npix + k] = tv;
     double e = es[k];
@@ -991,8 +995,8 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
                               int ntp, int Tn, int log_step, int cform,
                               int unit_template, const int32_t *job_spec,
                               const int32_t *job_templ, int J, const double *vel,
-                              double espec_sys, const double *taps, int nd,
-                              int64_t taps_stride,
+                              double espec_sys, int fast_interp,
+                              const double *taps, int nd, int64_t taps_stride,
                               double *chisq, double *coeffs, double *model,
                               double *raw_model, double *true_chisq,
                               int32_t *ngood, int32_t *status, void *stream) {
@@ -1000,6 +1004,7 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
   (void)Tn;
   if (npoly < 1 || npoly > FULL_MAXP || J < 1 || npix < 1) return RVS_E_ARG;
   if (taps && (nd < 1 || (nd & 1) == 0)) return RVS_E_ARG;
+  if (fast_interp && !cform) return RVS_E_ARG;  // needs y_i in the records
   const size_t shm = sizeof(double) * (2 * (size_t)npix + FULL_MAXP * FULL_MAXP +
                                        2 * FULL_MAXP + 8 +
                                        2 * FULL_MAXP * FULL_MAXP + FULL_MAXP);
@@ -1015,8 +1020,8 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
                      rvs_stream(stream), lam, polysT, spec, espec, badmask,
                      npix, npoly, knots, reinterpret_cast<const double4 *>(coef),
                      ntp, log_step, cform, unit_template, job_spec, job_templ,
-                     vel, espec_sys, taps, nd, taps_stride, chisq, coeffs, model,
-                     raw_model, true_chisq, ngood, status);
+                     vel, espec_sys, fast_interp, taps, nd, taps_stride, chisq,
+                     coeffs, model, raw_model, true_chisq, ngood, status);
   RVS_LAUNCH_CHECK();
   return 0;
 }
@@ -1277,6 +1282,12 @@ __device__ __forceinline__ double point_tv(const rvs_point_arm &T,
                        : (int)((x - x0) * lin_inv_step);
   pos = min(max(pos, 0), T.ntp - 2);
   const double dl = x - T.knots[pos];
+  if (T.fast_interp) {
+    // templ_spec[np.searchsorted(templ_lam, x)] (spec_fit.py:913-918): the
+    // first knot >= x; form-1 records carry y_i in .x (also the last row)
+    const int idx = min(pos + (dl > 0 ? 1 : 0), T.ntp - 1);
+    return cf[idx].x;
+  }
   const double4 c = cf[pos];
   return fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
 }
@@ -1285,7 +1296,7 @@ template <int P>
 __global__ void __launch_bounds__(256)
     point_block_kernel(PointArms A, const int32_t *__restrict__ job_spec,
                        const int32_t *__restrict__ job_templ, int J,
-                       const double *__restrict__ vel, double espec_sys,
+                       const double *__restrict__ vel,
                        double *__restrict__ armchi,
                        int32_t *__restrict__ armst) {
   constexpr int NT = P * (P + 1) / 2;
@@ -1300,6 +1311,7 @@ __global__ void __launch_bounds__(256)
   const int t = job_templ ? job_templ[j] : j;
   const double bb = vel[j] / RVS_C_KMS;
   const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double espec_sys = T.espec_sys;
   const double sys2 = espec_sys * espec_sys;
   const int npix = T.npix;
   const double *sp = T.spec + (int64_t)s * npix;
@@ -1487,9 +1499,8 @@ extern "C" int64_t rvs_chisq_point_work_size(int J, int narm) {
 extern "C" int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
                                const int32_t *job_spec,
                                const int32_t *job_templ, int J,
-                               const double *vel, double badchi,
-                               double espec_sys, void *scratch, double *out,
-                               int32_t *status, void *stream) {
+                               const double *vel, double badchi, void *scratch,
+                               double *out, int32_t *status, void *stream) {
   if (J < 1 || narm < 1 || narm > RVS_MAX_ARMS || !arms || !scratch)
     return RVS_E_ARG;
   PointArms A;
@@ -1513,7 +1524,7 @@ extern "C" int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \
     hipLaunchKernelGGL(point_block_kernel<PP>, grid, dim3(256), shm, st, A,    \
-                       job_spec, job_templ, J, vel, espec_sys, armchi, armst); \
+                       job_spec, job_templ, J, vel, armchi, armst);            \
     break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)

@@ -432,8 +432,8 @@ __global__ void __launch_bounds__(256)
   // ---- coefficients (spliner.c:52-59)
   double4 *cf = coef + (int64_t)b * N;
   for (int i = tid; i < N; i += 256) {
-    if (i >= N - 1) {
-      cf[i] = make_double4(0, 0, 0, 0);
+    if (i >= N - 1) {  // padding row; form 1 keeps y there (fast_interp)
+      cf[i] = make_double4((form & 1) ? y[i] : 0.0, 0, 0, 0);
       continue;
     }
     const double h = knots[i + 1] - knots[i], hinv = 1.0 / h;
@@ -568,8 +568,8 @@ __global__ void __launch_bounds__(256)
   // coefficients (spliner.c:52-59)
   double4 *cf = coef + (int64_t)b * N;
   for (int i = k0 + tid; i < k1; i += 256) {
-    if (i >= N - 1) {
-      cf[i] = make_double4(0, 0, 0, 0);
+    if (i >= N - 1) {  // padding row; form 1 keeps y there (fast_interp)
+      cf[i] = make_double4((form & 1) ? y[i] : 0.0, 0, 0, 0);
       continue;
     }
     const double h = hh[i], hinv = ih[i];

@@ -488,9 +488,17 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
     return out, status
 
 
+def _per_arm(v, n):
+    """scalar or per-arm sequence -> list of n floats"""
+    if isinstance(v, (list, tuple)):
+        assert len(v) == n
+        return [float(_) for _ in v]
+    return [float(v)] * n
+
+
 def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
                 job_spec=None, job_templ=None, espec_sys=0.0,
-                outside_penalty=True, resols=None):
+                outside_penalty=True, resols=None, fast_interp=False):
     """get_chisq for J (spectrum, template, velocity) triples, all arms in one
     launch set (rvs_chisq_point: lane per job, explicit residual norm).
     vel [J]; returns chisq [J], status int32 [J]."""
@@ -506,9 +514,10 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
     scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
     arr = (_lib.PointArm * narm)()
     keep = []
+    esys = _per_arm(espec_sys, narm)
     for ia, arm in enumerate(batch.arms):
         lib = libs[arm.name]
-        work = arm.work(lib, espec_sys)
+        work = arm.work(lib, esys[ia])
         polysT = arm.basis(npoly, rbf)
         o = outsides[ia]
         if job_templ is not None:
@@ -525,6 +534,7 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
         a.coef, a.penalty = coef.data_ptr(), pen.data_ptr()
         a.npix, a.S, a.ntp = arm.npix, arm.S, lib.ntp
         a.log_step = int(lib.log_step)
+        a.espec_sys, a.fast_interp = esys[ia], int(bool(fast_interp))
         rs = _arm_resol(arm, ia, resols)
         if rs is not None:
             a.taps, a.taps_stride, a.nd = rs['taps'].data_ptr(), rs['stride'], \
@@ -533,8 +543,8 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
         rc = L.rvs_chisq_point(ctypes.addressof(arr), narm, npoly,
                                _lib.ptr(job_spec), _lib.ptr(job_templ), J,
                                _lib.ptr(vel), float(batch.badchi),
-                               float(espec_sys), _lib.ptr(scratch),
-                               _lib.ptr(out), _lib.ptr(status), _lib.stream())
+                               _lib.ptr(scratch), _lib.ptr(out),
+                               _lib.ptr(status), _lib.stream())
         _lib.check(rc, 'rvs_chisq_point')
     return out, status
 
@@ -570,12 +580,13 @@ def grid_moments(chisq, vels, Np=1, nvel=None, quadratic=True):
 
 def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
                job_templ=None, espec_sys=0.0, unit_template=False,
-               want_models=True, resols=None):
+               want_models=True, resols=None, fast_interp=False):
     """Per-arm full output (spec_fit.py:941-961) for one velocity per job."""
     L = _lib.lib()
     dev = batch.device
     J = batch.S if job_spec is None else job_spec.shape[0]
     res = []
+    esys = _per_arm(espec_sys, len(batch.arms))
     for ia, arm in enumerate(batch.arms):
         lib = None if unit_template else libs[arm.name]
         polysT = arm.basis(npoly, rbf)
@@ -598,7 +609,8 @@ def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
             int(lib.log_step) if lib else 1, 1, int(unit_template),
             _lib.ptr(job_spec), _lib.ptr(job_templ), J,
             _lib.ptr(vel.contiguous()) if vel is not None else None,
-            float(espec_sys), _lib.ptr(rs['taps']) if rs else None,
+            esys[ia], int(bool(fast_interp)),
+            _lib.ptr(rs['taps']) if rs else None,
             rs['nd'] if rs else 0, rs['stride'] if rs else 0,
             _lib.ptr(chisq), _lib.ptr(coeffs),
             _lib.ptr(model), _lib.ptr(raw), _lib.ptr(tchi), _lib.ptr(ngood),

@@ -165,7 +165,7 @@ class ProcessObjective:
         self.jstatus.zero_()
         rc = L.rvs_chisq_point(ctypes.addressof(self.arr), len(self.arm_buf),
                                self.npoly, _p(self.job_spec), None, J,
-                               _p(self.vel), self.badchi, 0.0, _p(self.scratch),
+                               _p(self.vel), self.badchi, _p(self.scratch),
                                _p(self.chi), _p(self.jstatus), st)
         _lib.check(rc, 'rvs_chisq_point')
         rc = L.rvs_proc_finish(J, _p(counts), cidx, _p(self.chi), _p(self.extra),

@@ -290,11 +290,6 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
     SpecBatch: vel [S], atm_params [S, ndim] (or one tuple), rot_params None or
     vsini [S]; returns a device tensor [S] (or dict of tensors) and never
     raises for per-spectrum conditions (see 'status')."""
-    if fast_interp:
-        raise NotImplementedError('fast_interp (nearest pixel) is not on the '
-                                  'accelerated path')
-    if isinstance(espec_systematic, dict):
-        raise NotImplementedError('per-setup espec_systematic dict')
     options = options or {}
     npoly = options.get('npoly') or 5
     rbf = options.get('rbf_continuum', True)
@@ -312,17 +307,20 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
         velt = velt.reshape(-1, 1).expand(S, 1).contiguous()
     vmin, vmax = float(velt.min().item()), float(velt.max().item())
     _check_overlap_all(batch, libs, config, vmin, vmax)
-    esys = float(espec_systematic) if espec_systematic is not None else 0.0
+    # spec_fit.py:933-940: one value, or one per setup
+    if isinstance(espec_systematic, dict):
+        esys = [float(espec_systematic[n]) for n in batch.names]
+    else:
+        esys = float(espec_systematic) if espec_systematic is not None else 0.0
     coefs, outs = [], []
     for arm in batch.arms:
         c, o = engine.build_templates(libs[arm.name], params, vsini)
         coefs.append(c)
         outs.append(o)
-    chisq, status = engine.chisq_grid(batch, libs, coefs, outs, velt,
-                                      npoly=npoly, rbf=rbf, espec_sys=esys,
-                                      outside_penalty=outside_penalty,
-                                      resols=resols)
-    chisq = chisq[:, 0]
+    chisq, status = engine.chisq_point(batch, libs, coefs, outs, velt[:, 0],
+                                       npoly=npoly, rbf=rbf, espec_sys=esys,
+                                       outside_penalty=outside_penalty,
+                                       resols=resols, fast_interp=fast_interp)
     # reference: a non finite arm value of an OUTSIDE template is skipped with
     # a warning instead of raising (spec_fit.py:963-969); we flag it in status
     if not is_batch:
@@ -333,7 +331,8 @@ def get_chisq(specdata, vel, atm_params, rot_params=None, resol_params=None,
     if not full_output:
         return chisq if is_batch else float(chisq[0].item())
     full = engine.chisq_full(batch, libs, coefs, velt[:, 0].contiguous(),
-                             npoly=npoly, rbf=rbf, espec_sys=esys, resols=resols)
+                             npoly=npoly, rbf=rbf, espec_sys=esys, resols=resols,
+                             fast_interp=fast_interp)
     ret = {}
     ret['chisq'] = chisq if is_batch else float(chisq[0].item())
     ret['logl'] = -0.5 * ret['chisq']

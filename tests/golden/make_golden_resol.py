@@ -95,6 +95,19 @@ def main():
                                 options=opt, config=config)
         out[tag + '/own/find_best'] = np.array([fb['best_vel'], fb['vel_err'],
                                                 fb['best_chi']])
+        # (c) A7 fast_interp (nearest knot) and a per-setup espec_systematic dict
+        for i, (v, p, rot) in enumerate(trials):
+            out['%s/fast/t%d/value' % (tag, i)] = np.array(spec_fit.get_chisq(
+                sds, v, p, rot, options=opt, config=config, fast_interp=True))
+        esd = {n: 0.02 * (1 + k) for k, n in enumerate(s['names'])}
+        out[tag + '/esys_dict/vals'] = np.array([esd[n] for n in s['names']])
+        out[tag + '/esys_dict/value'] = np.array(spec_fit.get_chisq(
+            sds, s['vel'], s['truth'], None, options=opt, config=config,
+            espec_systematic=esd))
+        full = spec_fit.get_chisq(sds, s['vel'], s['truth'], None, options=opt,
+                                  config=config, fast_interp=True,
+                                  full_output=True)
+        out[tag + '/fast/full/chisq_array'] = np.array(full['chisq_array'])
         print(tag, 'rp', [float(out['%s/rp/t%d/value' % (tag, i)])
                           for i in range(3)], 'own',
               [float(out['%s/own/t%d/value' % (tag, i)]) for i in range(3)],

@@ -782,3 +782,32 @@ def test_resolution_matrix(cases, rcases, config, tag):
     assert abs(fb['best_chi'] / want[2] - 1) < 1e-7
     with pytest.raises(ValueError):
         spec_fit.get_chisq(sds2, 0., truth, None, rp, options=opt, config=config)
+
+
+@pytest.mark.parametrize('tag', ['c1', 'c2'])
+def test_fast_interp_and_espec_dict(cases, rcases, config, tag):
+    """get_chisq(fast_interp=True) (nearest template pixel, spec_fit.py:913-918)
+    and a per-setup espec_systematic dict (spec_fit.py:933-937)"""
+    from rvspecfit_amd import spec_fit
+    g = rcases
+    sds = _sds(cases, tag)
+    opt = dict(npoly=10)
+    for i in range(3):
+        vs = float(g['%s/rp/t%d/vsini' % (tag, i)])
+        rot = None if np.isnan(vs) else (vs, )
+        val = spec_fit.get_chisq(sds, float(g['%s/rp/t%d/vel' % (tag, i)]),
+                                 tuple(g['%s/rp/t%d/param' % (tag, i)]), rot,
+                                 options=opt, config=config, fast_interp=True)
+        want = float(g['%s/fast/t%d/value' % (tag, i)])
+        assert abs(val - want) < 1e-7 * max(abs(want), 1e3), (i, val, want)
+    full = spec_fit.get_chisq(sds, float(cases[tag + '/vel']),
+                              tuple(cases[tag + '/truth']), None, options=opt,
+                              config=config, fast_interp=True, full_output=True)
+    np.testing.assert_allclose(full['chisq_array'],
+                               g[tag + '/fast/full/chisq_array'], rtol=1e-6)
+    esd = {sd.name: float(v) for sd, v in zip(sds, g[tag + '/esys_dict/vals'])}
+    val = spec_fit.get_chisq(sds, float(cases[tag + '/vel']),
+                             tuple(cases[tag + '/truth']), None, options=opt,
+                             config=config, espec_systematic=esd)
+    want = float(g[tag + '/esys_dict/value'])
+    assert abs(val - want) < 1e-7 * max(abs(want), 1e3)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch/profile_round.sh <tag>: default bench line, rocprofv3 kernel stats of
+# tools/perf/profile_round.sh <tag>: default bench line, rocprofv3 kernel stats of
 # the same command, and FETCH_SIZE / WRITE_SIZE counter passes (separate runs).
 tag=$1
 R=$GRAFT_REPO_ROOT

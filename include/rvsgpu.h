@@ -77,6 +77,27 @@ int rvs_template_polylinear(const float *dats, int64_t ngrid, int ntp,
                             double *weights, void *stream);
 
 /* ------------------------------------------------------------------------
+ * A3 on an irregular grid: Delaunay evaluator, replaces spec_inter.TriInterp
+ * (spec_inter.py:11-59) for `interpolation_type = 'triangulation'` libraries
+ * (make_nd without --regulargrid): find_simplex (exhaustive, scipy's inside
+ * test with eps = 100*DBL_EPSILON, lowest simplex id) + barycentric blend of
+ * ndim+1 rows + exp, and the same blend of `extraflags` as outside flag
+ * (+ the MAX_VAL guard of getCurTempl).  No containing simplex -> NaN template,
+ * NaN outside flag.
+ * dats       float64 [npts, ntp]      log-flux rows incl. the padded edge points
+ * simplices  int32   [nsimplex, ndim+1]
+ * transform  float64 [nsimplex, ndim+1, ndim]  scipy Delaunay.transform
+ * extraflags float64 [npts]
+ * simplex    int32   [B]   out (required): simplex id or 0x7fffffff
+ * weights    float64 [B, ndim+1] out (nullable)
+ * ---------------------------------------------------------------------- */
+int rvs_template_tri(const double *dats, int ntp, const int32_t *simplices,
+                     const double *transform, const double *extraflags,
+                     int nsimplex, int ndim, uint32_t log_mask, int exp_flag,
+                     const double *params, int B, double *templ, double *outside,
+                     int32_t *simplex, double *weights, void *stream);
+
+/* ------------------------------------------------------------------------
  * A6  rotational broadening; replaces spec_fit.convolve_vsini /
  *     compute_vsini_kernel (spec_fit.py:495-682).  vsini[b] <= 0, NaN or
  *     R < 1e-9 copies the row (as does a non finite `outside[b]`, nullable,

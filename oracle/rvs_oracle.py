@@ -296,6 +296,69 @@ class Library:
         return spec
 
 
+class TriLibrary:
+    """`interpolation_type = 'triangulation'` setup: spec_inter.TriInterp
+    (spec_inter.py:11-59) on the exported arrays of the reference's Delaunay
+    object; find_simplex restated as scipy's exhaustive search
+    (_find_simplex_bruteforce: all barycentric coordinates in [-eps, 1+eps])."""
+
+    def __init__(self, npz):
+        d = dict(npz)
+        self.lam = _c(d['lam'])
+        self.dats = np.asarray(d['dats'], dtype=np.float64)
+        self.simplices = np.asarray(d['simplices'])
+        self.transform = np.asarray(d['transform'], dtype=np.float64)
+        self.extraflags = np.asarray(d['extraflags'], dtype=np.float64)
+        self.log_step = bool(d['log_step'])
+        self.log_ids = [int(_) for _ in np.atleast_1d(d['log_ids'])]
+        self.parnames = tuple(str(_) for _ in d['parnames'])
+        self.ndim = self.transform.shape[2]
+        self.exp = True
+
+    map_params = Library.map_params
+
+    def find_simplex(self, mp):
+        if not np.isfinite(mp).all():
+            return -1
+        nd = self.ndim
+        eps = 100 * np.finfo(float).eps
+        c = np.einsum('sij,sj->si', self.transform[:, :nd, :],
+                      mp[None, :] - self.transform[:, nd, :])
+        cl = 1 - c.sum(axis=1)
+        ok = np.all((c >= -eps) & (c <= 1 + eps), axis=1) & (cl >= -eps) & \
+            (cl <= 1 + eps)
+        w = np.nonzero(ok)[0]
+        return int(w[0]) if len(w) else -1
+
+    def _bary(self, mp, xid):
+        nd = self.ndim
+        b = np.empty(nd + 1)
+        b[:nd] = self.transform[xid, :nd, :].dot(mp - self.transform[xid, nd, :])
+        b[nd] = 1 - b[:nd].sum()
+        return b
+
+    def eval(self, p, details=False):
+        mp = self.map_params(p)
+        xid = self.find_simplex(mp)
+        if xid == -1:
+            spec = np.full(len(self.lam), np.nan)
+            return (spec, dict(simplex=-1)) if details else spec
+        b = self._bary(mp, xid)
+        spec = (self.dats[self.simplices[xid], :] * b[:, None]).sum(axis=0)
+        spec = np.exp(spec) if self.exp else spec
+        if details:
+            return spec, dict(simplex=xid, weights=b)
+        return np.ascontiguousarray(spec)
+
+    def outside_flag(self, p):
+        mp = self.map_params(p)
+        xid = self.find_simplex(mp)
+        if xid == -1:
+            return np.nan
+        b = self._bary(mp, xid)
+        return float((self.extraflags[self.simplices[xid]] * b).sum())
+
+
 # --------------------------------------------------------------------------
 # A6  rotational broadening   (spec_fit.py:495-682)
 # --------------------------------------------------------------------------

@@ -23,6 +23,7 @@ SIGNATURES = {
     'rvs_abi_version': (I, []),
     'rvs_template_polylinear': (I, [P, L, I, P, P, P, I, P, P, U, I, P, I, P, P,
                                     P, P, P]),
+    'rvs_template_tri': (I, [P, I, P, P, P, I, I, U, I, P, I, P, P, P, P, P]),
     'rvs_vsini_convolve': (I, [P, P, P, D, D, I, I, P, P]),
     'rvs_spline_factors': (I, [P, I, P, P]),
     'rvs_spline_construct': (I, [P, P, I, I, I, P, P, P]),

@@ -226,6 +226,164 @@ extern "C" int rvs_template_polylinear(
 }
 
 // ---------------------------------------------------------------------------
+// A3 on an irregular grid: spec_inter.TriInterp (spec_inter.py:11-59), the
+// Delaunay evaluator of `interpolation_type = 'triangulation'` libraries.
+// The triangulation itself (simplices + barycentric transforms of the
+// reference's scipy.spatial.Delaunay object) is an artefact of template
+// preparation; here:
+//  tri_locate_kernel: find_simplex by exhaustive search, the way scipy's
+//    _find_simplex_bruteforce decides "inside" (all ndim+1 barycentric
+//    coordinates within [-eps, 1+eps], eps = 100*DBL_EPSILON).  One LANE per
+//    query point, the simplex transform is wave-uniform (scalar cache), the
+//    simplices are split over grid.y; the lowest matching simplex id wins
+//    (atomicMin), so the result does not depend on the launch shape.  On a
+//    shared face several simplices match; the interpolant is continuous there.
+//  tri_eval_kernel: b = T (p - r), spec = sum_i b_i dats[simplex_i] in vertex
+//    order with separately rounded products (numpy's (dats*b[:,None]).sum(0)),
+//    exp; outside = the same blend of `extraflags`; no simplex -> NaN.
+// ---------------------------------------------------------------------------
+#define TRI_MAXDIM 6
+
+__device__ __forceinline__ double tri_map(double v, int d, uint32_t log_mask) {
+  return ((log_mask >> d) & 1u) ? log10(v) : v;
+}
+
+__global__ void __launch_bounds__(64)
+    tri_locate_kernel(const double *__restrict__ transform, int ns, int nd,
+                      uint32_t log_mask, const double *__restrict__ params,
+                      int B, int nslice, int32_t *__restrict__ simplex) {
+  const int b0 = blockIdx.x * 64 + threadIdx.x;
+  const bool active = b0 < B;
+  const int b = active ? b0 : B - 1;
+  double p[TRI_MAXDIM];
+  bool finite = true;
+  for (int d = 0; d < nd; d++) {
+    p[d] = tri_map(params[(int64_t)b * nd + d], d, log_mask);
+    if (!(fabs(p[d]) <= 1.79e308)) finite = false;
+  }
+  const int s0 = (int)((int64_t)ns * blockIdx.y / nslice);
+  const int s1 = (int)((int64_t)ns * (blockIdx.y + 1) / nslice);
+  const double eps = 100.0 * 2.220446049250313e-16;
+  int found = 0x7fffffff;
+  for (int s = s0; s < s1; s++) {
+    const double *T = transform + (int64_t)s * (nd + 1) * nd;  // wave-uniform
+    const double *r = T + nd * nd;
+    bool in = true;
+    double sum = 0;
+    for (int i = 0; i < nd; i++) {
+      double c = 0;
+      for (int jj = 0; jj < nd; jj++) c += T[i * nd + jj] * (p[jj] - r[jj]);
+      sum += c;
+      if (!(c >= -eps && c <= 1 + eps)) in = false;
+    }
+    const double cl = 1.0 - sum;
+    if (!(cl >= -eps && cl <= 1 + eps)) in = false;
+    if (in && s < found) found = s;
+  }
+  if (active && finite && found != 0x7fffffff) atomicMin(&simplex[b], found);
+}
+
+__global__ void __launch_bounds__(256)
+    tri_eval_kernel(const double *__restrict__ dats, int ntp,
+                    const int32_t *__restrict__ simplices,
+                    const double *__restrict__ transform,
+                    const double *__restrict__ extraflags, int nd,
+                    uint32_t log_mask, int exp_flag,
+                    const double *__restrict__ params,
+                    const int32_t *__restrict__ simplex,
+                    double *__restrict__ templ, double *__restrict__ outside,
+                    double *__restrict__ weights) {
+  __shared__ double sh_b[TRI_MAXDIM + 1];
+  __shared__ int sh_id[TRI_MAXDIM + 1];
+  __shared__ double red_m[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int sx = simplex[b];
+  double *out = templ + (int64_t)b * ntp;
+  if (sx == 0x7fffffff || sx < 0) {  // TriInterp returns nan (spec_inter.py:45-47)
+    for (int k = tid; k < ntp; k += 256) out[k] = __builtin_nan("");
+    if (tid == 0) outside[b] = __builtin_nan("");
+    if (weights && tid <= nd) weights[(int64_t)b * (nd + 1) + tid] = 0.0;
+    return;
+  }
+  if (tid == 0) {
+    const double *T = transform + (int64_t)sx * (nd + 1) * nd;
+    const double *r = T + nd * nd;
+    double p[TRI_MAXDIM];
+    for (int d = 0; d < nd; d++)
+      p[d] = tri_map(params[(int64_t)b * nd + d], d, log_mask) - r[d];
+    double sum = 0;
+    for (int i = 0; i < nd; i++) {
+      // numpy dot of a row with (p - r): sequential products and sums
+      double c = 0;
+      for (int jj = 0; jj < nd; jj++) c = __dadd_rn(c, __dmul_rn(T[i * nd + jj], p[jj]));
+      sh_b[i] = c;
+      sum = __dadd_rn(sum, c);
+    }
+    sh_b[nd] = 1.0 - sum;
+    for (int i = 0; i <= nd; i++) sh_id[i] = simplices[(int64_t)sx * (nd + 1) + i];
+  }
+  __syncthreads();
+  double mx = 0;
+  bool anynan = false;
+  for (int k = tid; k < ntp; k += 256) {
+    double acc = __dmul_rn(dats[(int64_t)sh_id[0] * ntp + k], sh_b[0]);
+    for (int i = 1; i <= nd; i++)
+      acc = __dadd_rn(acc, __dmul_rn(dats[(int64_t)sh_id[i] * ntp + k], sh_b[i]));
+    const double val = exp_flag ? exp(acc) : acc;
+    out[k] = val;
+    if (!(val == val)) anynan = true;
+    mx = fmax(mx, fabs(val));
+  }
+  mx = wave_max(mx);
+  const double nanf = wave_sum(anynan ? 1.0 : 0.0);
+  if ((tid & 63) == 0) {
+    red_m[tid >> 6] = mx;
+    red_m[4 + (tid >> 6)] = nanf;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double o = __dmul_rn(extraflags[sh_id[0]], sh_b[0]);
+    for (int i = 1; i <= nd; i++)
+      o = __dadd_rn(o, __dmul_rn(extraflags[sh_id[i]], sh_b[i]));
+    // MAX_VAL guard of getCurTempl (spec_fit.py:392-397)
+    const double m = fmax(fmax(red_m[0], red_m[1]), fmax(red_m[2], red_m[3]));
+    const double nn = red_m[4] + red_m[5] + red_m[6] + red_m[7];
+    if (o > 0 && (m > 1e100 || nn > 0 || isinf(m))) o = __builtin_nan("");
+    outside[b] = o;
+  }
+  if (weights && tid <= nd) weights[(int64_t)b * (nd + 1) + tid] = sh_b[tid];
+}
+
+extern "C" int rvs_template_tri(const double *dats, int ntp,
+                                const int32_t *simplices,
+                                const double *transform,
+                                const double *extraflags, int nsimplex, int ndim,
+                                uint32_t log_mask, int exp_flag,
+                                const double *params, int B, double *templ,
+                                double *outside, int32_t *simplex,
+                                double *weights, void *stream) {
+  if (ndim < 1 || ndim > TRI_MAXDIM || B < 1 || ntp < 1 || nsimplex < 1 ||
+      !simplex)
+    return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  if (hipMemsetD32Async((hipDeviceptr_t)simplex, 0x7fffffff, B, st) !=
+      hipSuccess)
+    return RVS_E_LAUNCH;
+  const int groups = (B + 63) / 64;
+  int nslice = 2048 / groups;
+  nslice = nslice < 1 ? 1 : (nslice > 256 ? 256 : nslice);
+  if (nslice > nsimplex) nslice = nsimplex;
+  hipLaunchKernelGGL(tri_locate_kernel, dim3(groups, nslice), dim3(64), 0, st,
+                     transform, nsimplex, ndim, log_mask, params, B, nslice,
+                     simplex);
+  hipLaunchKernelGGL(tri_eval_kernel, dim3(B), dim3(256), 0, st, dats, ntp,
+                     simplices, transform, extraflags, ndim, log_mask, exp_flag,
+                     params, simplex, templ, outside, weights);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // A6: rotational broadening (spec_fit.py:495-682)
 // ---------------------------------------------------------------------------
 #define VSINI_MAXTAP 2048  // one-sided taps kept in LDS

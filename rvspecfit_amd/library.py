@@ -58,7 +58,18 @@ class TemplateLibrary:
                 _lib.stream())
             _lib.check(rc, 'rvs_spline_factors')
         self.kind = 'regulargrid'
-        if 'dats' in d:
+        if 'simplices' in d:
+            # interpolation_type 'triangulation' (make_nd without --regulargrid):
+            # the reference's Delaunay object, exported as arrays
+            self.kind = 'triangulation'
+            self.tri_simplices = _dev(d['simplices'], torch.int32, device)
+            self.tri_transform = _dev(d['transform'], torch.float64, device)
+            self.tri_extraflags = _dev(np.asarray(d['extraflags']).reshape(-1),
+                                       torch.float64, device)
+            self.tri_nsimplex = int(np.asarray(d['simplices']).shape[0])
+            self.dats = _dev(d['dats'], torch.float64, device)
+            self.exp_flag = int(bool(d.get('log_spec', True)))
+        elif 'dats' in d:
             idgrid = np.asarray(d['idgrid'], dtype=np.int64)
             self.lens = np.array(idgrid.shape, dtype=np.int32)
             uvecs = [np.asarray(d['uvec%d' % i], dtype=np.float64)
@@ -130,6 +141,20 @@ class TemplateLibrary:
         outside = torch.empty(J, dtype=torch.float64, device=self.device)
         if self.kind == 'nn':
             return self._eval_nn(params, templ, outside)
+        if self.kind == 'triangulation':
+            sx = torch.empty(J, dtype=torch.int32, device=self.device)
+            wts = torch.zeros((J, self.ndim + 1), dtype=torch.float64,
+                              device=self.device) if details else None
+            rc = L.rvs_template_tri(
+                _lib.ptr(self.dats), self.ntp, _lib.ptr(self.tri_simplices),
+                _lib.ptr(self.tri_transform), _lib.ptr(self.tri_extraflags),
+                self.tri_nsimplex, self.ndim, self.log_mask, self.exp_flag,
+                _lib.ptr(params), J, _lib.ptr(templ), _lib.ptr(outside),
+                _lib.ptr(sx), _lib.ptr(wts), _lib.stream())
+            _lib.check(rc, 'rvs_template_tri')
+            if details:
+                return templ, outside, sx, wts
+            return templ, outside
         nv = 1 << self.ndim
         cell = wts = None
         if details:

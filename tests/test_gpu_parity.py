@@ -811,3 +811,59 @@ def test_fast_interp_and_espec_dict(cases, rcases, config, tag):
                              config=config, espec_systematic=esd)
     want = float(g[tag + '/esys_dict/value'])
     assert abs(val - want) < 1e-7 * max(abs(want), 1e3)
+
+
+# --------------------------------------------------------------------------
+# Delaunay (triangulation) evaluator: spec_inter.TriInterp -> rvs_template_tri
+# --------------------------------------------------------------------------
+def test_triangulation(cases, gpu):
+    from rvspecfit_amd import spec_fit, spec_inter
+    from rvspecfit_amd.library import TemplateLibrary
+    g = dict(np.load(os.path.join(GOLD, 'tri_cases.npz')))
+    cfg = dict(GOLD_CONFIG)
+    cfg['template_lib'] = 'golden-tri://'
+    olibs = {}
+    for n in ('gold_b', 'gold_r'):
+        d = np.load(os.path.join(GOLD, 'lib_tri_%s.npz' % n))
+        spec_inter.register_library(TemplateLibrary(n, d), 'golden-tri://')
+        olibs[n] = orc.TriLibrary(d)
+    P = g['params']
+    for n in ('gold_b', 'gold_r'):
+        it = spec_inter.getInterpolator(n, cfg)
+        assert it.lib.kind == 'triangulation'
+        with np.errstate(all='ignore'):
+            templ, outside, sx, wts = it.lib.eval_batch(
+                torch.as_tensor(P).to('cuda'), details=True)
+        templ, outside = templ.cpu().numpy(), outside.cpu().numpy()
+        sx = sx.cpu().numpy()
+        for i, p in enumerate(P):
+            ref_sx = int(g[n + '/simplex'][i])
+            if ref_sx < 0:
+                assert sx[i] == 0x7fffffff
+                assert np.isnan(outside[i]) and np.isnan(templ[i]).all()
+                continue
+            # integer work: the simplex of the exhaustive search (oracle); the
+            # reference's walk may stop in a neighbour on a shared face, where
+            # the interpolant is the same
+            with np.errstate(all='ignore'):
+                _, info = olibs[n].eval(p, details=True)
+            assert sx[i] == info['simplex']
+            np.testing.assert_allclose(templ[i], g[n + '/eval'][i], rtol=1e-12)
+            assert abs(outside[i] - g[n + '/outside'][i]) < 1e-12
+    sds = _sds(cases, 'c1')
+    for i in range(4):
+        vs = float(g['c1/t%d/vsini' % i])
+        with np.errstate(all='ignore'):
+            val = spec_fit.get_chisq(sds, float(g['c1/t%d/vel' % i]),
+                                     tuple(g['c1/t%d/param' % i]),
+                                     None if np.isnan(vs) else (vs, ),
+                                     options=dict(npoly=10), config=cfg)
+        want = float(g['c1/t%d/value' % i])
+        assert abs(val - want) < 1e-7 * max(abs(want), 1e3), (i, val, want)
+    truth = tuple(cases['c1/truth'])
+    fb = spec_fit.find_best(sds, g['vel_grid'], [truth, tuple(P[3]), tuple(P[0])],
+                            None, options=dict(npoly=10), config=cfg)
+    want = g['c1/find_best']
+    assert abs(fb['best_vel'] - want[0]) < 1e-3
+    assert abs(fb['best_chi'] / want[2] - 1) < 1e-7
+    np.testing.assert_allclose(fb['best_param'], g['c1/best_param'])

@@ -370,3 +370,37 @@ def test_resolution_matrix_oracle(cases, gold_libs, gold_config, tag):
     c = orc.get_chisq_continuum(sds2, options=opt)
     np.testing.assert_allclose(c['chisq_array'], g[tag + '/own/cont/chisq_array'],
                                rtol=1e-9)
+
+
+# --------------------------------------------------------------------------
+# Delaunay (triangulation) evaluator: spec_inter.TriInterp
+# --------------------------------------------------------------------------
+def test_triangulation_oracle(cases):
+    import os
+    from conftest import GOLD, GOLD_CONFIG
+    g = np.load(os.path.join(GOLD, 'tri_cases.npz'))
+    libs = {n: orc.TriLibrary(np.load(os.path.join(GOLD, 'lib_tri_%s.npz' % n)))
+            for n in ('gold_b', 'gold_r')}
+    P = g['params']
+    for n, lib in libs.items():
+        for i, p in enumerate(P):
+            with np.errstate(all='ignore'):
+                spec, info = lib.eval(p, details=True)
+                o = lib.outside_flag(p)
+            ref = g[n + '/eval'][i]
+            if int(g[n + '/simplex'][i]) < 0:
+                assert info['simplex'] == -1 and np.isnan(o)
+                continue
+            np.testing.assert_allclose(spec, ref, rtol=1e-13)
+            assert abs(o - g[n + '/outside'][i]) < 1e-12
+    sds = gold_specdata(cases, 'c1', orc.SpecData)
+    for i in range(4):
+        vs = float(g['c1/t%d/vsini' % i])
+        with np.errstate(all='ignore'):
+            val = orc.get_chisq(sds, float(g['c1/t%d/vel' % i]),
+                                tuple(g['c1/t%d/param' % i]),
+                                None if np.isnan(vs) else (vs, ),
+                                options=dict(npoly=10), config=GOLD_CONFIG,
+                                libs=libs)
+        want = float(g['c1/t%d/value' % i])
+        assert abs(val - want) < 1e-8 * max(abs(want), 1e3)

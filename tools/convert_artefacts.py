@@ -52,7 +52,14 @@ def _h5_to_dict(group):
             out[key] = arr if typ == 'ndarray' else (
                 list(arr) if typ in ('list', 'empty_array') else tuple(arr))
         elif typ == 'pickle':
-            out[key] = None  # Delaunay objects: outside the accelerated path
+            # the serializer's escape hatch (serializer.py): a pickled object in
+            # a uint8 dataset -- used for the scipy.spatial.Delaunay object of
+            # triangulation libraries (make_nd.py:137-138, 174-175)
+            import pickle
+            try:
+                out[key] = pickle.loads(np.asarray(val).tobytes())
+            except Exception:
+                out[key] = None
         else:
             out[key] = val.item() if hasattr(val, 'item') and np.ndim(val) == 0 \
                 else val
@@ -93,9 +100,23 @@ def convert(tdir, setup, continuum=True):
                                   (kw['nlayers'] + 1) + [kw['npc'], kw['npix']],
                                   dtype=np.int32)
         out['nn_file'] = np.array(str(fd['nn_file']))
+    elif itype == 'triangulation':
+        tri = fd.get('triang')
+        if tri is None:
+            raise SystemExit('cannot unpickle the Delaunay object of %s with '
+                             'this scipy; run the converter under the '
+                             'interpreter that wrote it' % setup)
+        out['log_ids'] = np.asarray(fd['mapper_args'][0], dtype=np.int64).ravel()
+        out['dats'] = np.load(os.path.join(tdir, 'interpdat_%s.npy' % setup)
+                              ).astype(np.float64)
+        out['vec'] = np.asarray(fd['vec'], dtype=np.float64)
+        out['simplices'] = np.asarray(tri.simplices, dtype=np.int32)
+        out['transform'] = np.asarray(tri.transform, dtype=np.float64)
+        out['extraflags'] = np.asarray(fd['extraflags'],
+                                       dtype=np.float64).reshape(-1)
+        out['log_spec'] = np.array(bool(fd.get('log_spec', True)))
     else:
-        raise SystemExit('interpolation_type %s is outside the accelerated '
-                         'path (SURVEY 8(f) rank 4)' % itype)
+        raise SystemExit('unknown interpolation_type %s' % itype)
     pref = '' if continuum else 'nocont_'
     cinfo = os.path.join(tdir, 'ccf_%s%s.h5' % (pref, setup))
     if os.path.exists(cinfo):

@@ -172,6 +172,31 @@ class TemplateLibrary:
             return templ, outside, cell, wts
         return templ, outside
 
+    def eval_into(self, params, J, templ, outside, stream, scratch=None):
+        """launch-only variant of eval_batch on caller-owned buffers (no
+        allocation, no synchronisation): params [>=J, ndim], templ [>=J, ntp],
+        outside [>=J]; scratch: int32 [>=J] for triangulation libraries.
+        regulargrid and triangulation kinds only."""
+        L = _lib.lib()
+        if self.kind == 'regulargrid':
+            rc = L.rvs_template_polylinear(
+                _lib.ptr(self.dats), self.ngrid, self.ntp, _lib.ptr(self.idgrid),
+                _lib.ptr(self.uvecs), _lib.ptr(self.lens), self.ndim,
+                _lib.ptr(self.vecs_s), _lib.ptr(self.inv_ptp), self.log_mask,
+                self.exp_flag, _lib.ptr(params), J, _lib.ptr(templ),
+                _lib.ptr(outside), None, None, stream)
+            _lib.check(rc, 'rvs_template_polylinear')
+        elif self.kind == 'triangulation':
+            rc = L.rvs_template_tri(
+                _lib.ptr(self.dats), self.ntp, _lib.ptr(self.tri_simplices),
+                _lib.ptr(self.tri_transform), _lib.ptr(self.tri_extraflags),
+                self.tri_nsimplex, self.ndim, self.log_mask, self.exp_flag,
+                _lib.ptr(params), J, _lib.ptr(templ), _lib.ptr(outside),
+                _lib.ptr(scratch), None, stream)
+            _lib.check(rc, 'rvs_template_tri')
+        else:
+            raise NotImplementedError(self.kind)
+
     def _eval_nn(self, params, templ, outside):
         import ctypes
         L = _lib.lib()

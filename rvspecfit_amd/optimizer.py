@@ -40,8 +40,8 @@ class ProcessObjective:
         self.rbf = options.get('rbf_continuum', True)
         self.ndim = len(names)
         for arm in batch.arms:
-            if libs[arm.name].kind != 'regulargrid':
-                raise NotImplementedError('device optimiser: polylinear only')
+            if libs[arm.name].kind not in ('regulargrid', 'triangulation'):
+                raise NotImplementedError('device optimiser: grid evaluators')
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         # parameter vector layout (vel, [vsini], free stellar parameters)
@@ -99,6 +99,7 @@ class ProcessObjective:
                      if self.has_vsini else None,
                      coef=torch.empty((cap, lib.ntp, 4), **f64),
                      outside=torch.empty(cap, **f64),
+                     sx=torch.empty(cap, **i32),
                      pen=torch.empty(cap, **f64),
                      work=arm.work(lib, 0.0), polysT=arm.basis(self.npoly,
                                                                self.rbf))
@@ -139,13 +140,8 @@ class ProcessObjective:
             lib = self.libs[arm.name]
             side.wait_event(self.ev_in)
             ss = ctypes.c_void_p(side.cuda_stream)
-            rc = L.rvs_template_polylinear(
-                _p(lib.dats), lib.ngrid, lib.ntp, _p(lib.idgrid), _p(lib.uvecs),
-                _lib.ptr(lib.lens), lib.ndim, _p(lib.vecs_s),
-                _lib.ptr(lib.inv_ptp), lib.log_mask, lib.exp_flag,
-                _p(self.params), J, _p(b['templ']), _p(b['outside']), None, None,
-                ss)
-            _lib.check(rc, 'rvs_template_polylinear')
+            lib.eval_into(self.params, J, b['templ'], b['outside'], ss,
+                          scratch=b['sx'])
             y = b['templ']
             if self.has_vsini:
                 rc = L.rvs_vsini_convolve(_p(y), _p(self.vsini), _p(b['outside']),

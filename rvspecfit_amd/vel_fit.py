@@ -465,7 +465,8 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
     # vel_fit.py:624-649: a second run restarts from the final simplex
     libs = spec_inter.get_libs(batch.names, config)
     use_device_nm = USE_DEVICE_NM and all(
-        libs[a.name].kind == 'regulargrid' for a in batch.arms)
+        libs[a.name].kind in ('regulargrid', 'triangulation')
+        for a in batch.arms)
     if use_device_nm:
         from . import optimizer
         pobj = optimizer.ProcessObjective(

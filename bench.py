@@ -241,6 +241,8 @@ def main():
                          'starting from the CCF parameters; reported under '
                          '"process", never part of `value`')
     ap.add_argument('--process-cpu-sample', type=int, default=8)
+    ap.add_argument('--process-bfgs', action='store_true',
+                    help='run the second_minimizer (BFGS) polish in --process')
     ap.add_argument('--cpu-process', action='store_true',
                     help='(cpu worker) run the oracle process stage')
     ap.add_argument('--workload', choices=['desi', 'cfg2'], default='desi',
@@ -502,6 +504,7 @@ def run_process_addon(batch, rec, arms, args, dev):
                                torch.zeros_like(vs)).contiguous()
     cfg = dict(CONFIG)
     cfg.setdefault('max_vsini', 500)
+    cfg['second_minimizer'] = bool(args.process_bfgs)
     vel_fit.process(sub, pd0, options=OPTIONS, config=cfg)   # warm-up
     tm = {}
     torch.cuda.synchronize()
@@ -518,8 +521,15 @@ def run_process_addon(batch, rec, arms, args, dev):
                minimize_success=round(float(
                    r['minimize_success'].float().mean()), 4),
                bad_hessian=round(float(np.mean(r['bad_hessian'])), 4),
-               note='add-on, not part of `value`; second_minimizer (BFGS) not '
-                    'run, Hessian by central differences (see DESIGN.md)')
+               second_minimizer=bool(args.process_bfgs),
+               note='add-on, not part of `value`; Hessian by central '
+                    'differences (see DESIGN.md)')
+    if 'bfgs' in r:
+        out['bfgs'] = dict(rounds=int(r['bfgs']['rounds']),
+                           nfev_mean=round(float(np.mean(r['bfgs']['nfev'])), 1),
+                           nit_mean=round(float(np.mean(r['bfgs']['nit'])), 2),
+                           status_counts=np.bincount(
+                               r['bfgs']['status'], minlength=4).tolist())
     m = min(args.process_cpu_sample, n)
     if m > 0 and not args.no_cpu_baseline:
         start = torch.stack([pd0[k] for k in names] + [pd0['vsini']],

@@ -898,3 +898,29 @@ def test_fit_fake(cases, config, kind, snr, feh0):
             (seed, res['vel'], v0, res['vel_err'])
         assert res['minimize_success']
         assert len(res['yfit'][0]) == len(lam)
+
+
+def test_process_second_minimizer(cases, pcases, config):
+    """config second_minimizer=True (the reference default): BFGS from the
+    simplex optimum.  The reference's own BFGS (golden p4; scipy 1.7 there,
+    1.15 here) ends in 'precision loss' after moving chi^2 by 1e-11; ours must
+    do the same kind of nothing: not increase chi^2, stay within the contract."""
+    from rvspecfit_amd import vel_fit
+    g = pcases
+    sds = _sds(cases, 'c1')
+    pd0, fix, pri = _process_args(g, 'p4')
+    cfg = dict(config)
+    cfg['second_minimizer'] = False
+    r0 = vel_fit.process(sds, pd0, fixParam=fix, options=dict(npoly=10),
+                         config=cfg, priors=pri)
+    cfg['second_minimizer'] = True
+    r1 = vel_fit.process(sds, pd0, fixParam=fix, options=dict(npoly=10),
+                         config=cfg, priors=pri)
+    assert r1['second_minimizer_run'] and not r0['second_minimizer_run']
+    assert r1['bfgs']['status'][0] in (0, 2)
+    assert r1['chisq'] <= r0['chisq'] + 1e-6
+    assert abs(r1['vel'] - g['p4/vel']) < 0.01
+    assert abs(r1['chisq'] / g['p4/chisq'] - 1) < 1e-6
+    err = g['p4/param_err']
+    got = np.array([r1['param'][_] for _ in ('teff', 'logg', 'feh', 'alpha')])
+    assert np.all(np.abs(got - g['p4/param']) < 0.02 * err)

@@ -120,3 +120,40 @@ def test_lockstep_neldermead_equals_scipy():
             np.testing.assert_array_equal(q.final_simplex[0],
                                           r['final_simplex'][0][i].numpy())
             np.testing.assert_array_equal(q.x, r['x'][i].numpy())
+
+
+def test_lockstep_bfgs_equals_scipy():
+    """rvspecfit_amd.bfgs restates scipy's BFGS (vel_fit.py:653-658) with its
+    Wolfe line searches and 2-point gradient: identical nit, nfev, status and
+    iterates, on a smooth objective and on one with 1e-9 of deterministic noise
+    (the regime of the real objective: precision-loss exit through
+    line_search_wolfe2)"""
+    import warnings
+    import scipy.optimize as so
+    from rvspecfit_amd import bfgs
+    rng = np.random.RandomState(2)
+    S, N = 12, 5
+    A = rng.normal(size=(S, N, N))
+    A = np.einsum('sij,skj->sik', A, A) + np.eye(N)
+    c = rng.normal(size=(S, N))
+
+    def f1(i, x, nz):
+        d = x - c[i]
+        v = 0.5 * d @ A[i] @ d + 0.1 * np.sum(d**4) + np.sum(np.cos(d))
+        return v + nz * np.sin(1e9 * np.sum(x))
+
+    H0 = np.diag(rng.uniform(0.5, 2, N))
+    x0 = rng.normal(size=(S, N)) * 2
+    for nz, want_status in ((0.0, 0), (1e-9, 2)):
+        r = bfgs.minimize_lockstep(
+            lambda idx, X: np.array([f1(int(i), x, nz) for i, x in zip(idx, X)]),
+            x0, hess_inv0=H0, max_rows=17)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for i in range(S):
+                q = so.minimize(lambda x: f1(i, x, nz), x0[i], method='BFGS',
+                                options=dict(hess_inv0=H0))
+                assert q.nit == r['nit'][i] and q.nfev == r['nfev'][i]
+                assert q.status == r['status'][i] == want_status
+                np.testing.assert_array_equal(q.x, r['x'][i])
+                assert q.fun == r['fun'][i]

@@ -272,6 +272,41 @@ int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
                     double *out, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------
+ * The same objective as ONE kernel per evaluation for regular-grid libraries:
+ * polylinear gather + exp (A3/A5), rotational FIR (A6), windowed natural-spline
+ * solve (A7) and the chi^2 of rvs_chisq_point (A10/A11), one 512-thread block
+ * per (job, arm) with the whole template in LDS (3*ntp doubles <= 154 KB); no
+ * spline record goes to HBM.  Replaces, for the optimiser's ~850 calls per
+ * spectrum, the chain rvs_template_polylinear -> rvs_vsini_convolve ->
+ * rvs_spline_construct -> rvs_chisq_point (same arithmetic per phase).
+ * Per arm: `pt` as in rvs_chisq_point (coef, penalty, taps unused; no
+ * fast_interp), the polylinear library as in rvs_template_polylinear, the
+ * rvs_spline_factors of the template grid, ln-step of the grid for the
+ * rotational kernel.  params [J, ndim], vsini [J] (nullable = no rotation),
+ * vel [J]; scratch: rvs_objective_work_size(J, narm) bytes;
+ * out[j] = sum over arms of chisq + outside*badchi (NaN outside: + 1000*badchi).
+ * ---------------------------------------------------------------------- */
+typedef struct rvs_objective_arm {
+  rvs_point_arm pt;
+  const float *dats;
+  const int64_t *idgrid;
+  const double *uvecs, *vecs_s, *factors;
+  int64_t ngrid;
+  double lnstep;
+  double inv_ptp[6];
+  int32_t lens[6];
+  int32_t ntp, ndim;
+  uint32_t log_mask;
+  int32_t exp_flag;
+} rvs_objective_arm;
+int64_t rvs_objective_work_size(int J, int narm);
+int rvs_objective_fused(const rvs_objective_arm *arms, int narm, int npoly,
+                        const double *params, const double *vsini,
+                        const int32_t *job_spec, int J, const double *vel,
+                        double badchi, int outside_penalty, void *scratch,
+                        double *out, int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------
  * A12  grid summary; replaces the tail of spec_fit.find_best
  * (spec_fit.py:1072-1092) and _quadratic_interp_min (:992-1015).
  * chisq [G, Np, Nv] (velocity fastest); vels + g*vel_stride -> [Nv];

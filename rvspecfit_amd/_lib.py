@@ -49,6 +49,8 @@ SIGNATURES = {
     'rvs_proc_map': (I, [I, I, I, P, P, P, I, P, P, P, P, P, D, D, D, P, P, P, P,
                           P, P, P]),
     'rvs_proc_finish': (I, [I, P, I, P, P, P, P, P, P, P, P]),
+    'rvs_objective_work_size': (L, [I, I]),
+    'rvs_objective_fused': (I, [P, I, I, P, P, P, I, P, D, I, P, P, P, P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),
@@ -92,6 +94,17 @@ class PointArm(ctypes.Structure):
                                         ('espec_sys', ctypes.c_double)] + [
                     (k, ctypes.c_int32) for k in
                     ('npix', 'S', 'ntp', 'log_step', 'nd', 'fast_interp')]
+
+
+class ObjectiveArm(ctypes.Structure):
+    """rvs_objective_arm of include/rvsgpu.h"""
+    _fields_ = [('pt', PointArm), ('dats', ctypes.c_void_p),
+                ('idgrid', ctypes.c_void_p), ('uvecs', ctypes.c_void_p),
+                ('vecs_s', ctypes.c_void_p), ('factors', ctypes.c_void_p),
+                ('ngrid', ctypes.c_int64), ('lnstep', ctypes.c_double),
+                ('inv_ptp', ctypes.c_double * 6), ('lens', ctypes.c_int32 * 6),
+                ('ntp', ctypes.c_int32), ('ndim', ctypes.c_int32),
+                ('log_mask', ctypes.c_uint32), ('exp_flag', ctypes.c_int32)]
 
 
 def ptr(t):

@@ -1,0 +1,458 @@
+// objective.hip -- the optimiser's objective, get_chisq (spec_fit.py:797-989) at
+// ONE (template parameters, vsini, velocity) point per job, as a single kernel.
+//
+// vel_fit.process evaluates chisq_func ~850 times per spectrum, each time with
+// a NEW template (vel_fit.py:205-254).  Built from the stand-alone kernels this
+// is a chain of ~12 small dependent launches per evaluation (gather, FIR, spline
+// solve, records to HBM and back, chi^2), and the optimiser's rounds end up
+// bound by that chain's latency.  Here one 512-thread block owns a (job, arm)
+// and keeps the whole template in LDS (3 x ntp doubles = 155 KB for the DESI z
+// arm, which is why this only exists on a 160-KB-LDS part):
+//   A  <- polylinear gather of the 2^ndim float32 rows + exp     (A3, A5)
+//   B  <- rotational-broadening FIR of A, taps built in C        (A6)
+//   dp,ec <- windowed Thomas solve of the natural spline of y    (A7 construct)
+//   chi^2 <- threads = pixels: spline value from (y, z) on the fly, normal
+//         equations per lane, wave butterflies + fixed-order fold, Cholesky,
+//         explicit residual norm                                  (A7 eval, A10, A11)
+// No spline record ever goes to HBM.  Each phase repeats the arithmetic of the
+// stand-alone kernel it replaces (template.hip, chisq.hip), so the values agree
+// to rounding (tests/test_gpu_parity.py::test_objective_fused).
+#include "template_dev.h"
+
+#define OBJ_NT 512
+#define OBJ_NW (OBJ_NT / 64)
+#define OBJ_MAXDYN (160 * 1024 - 6144)
+#define OBJ_W 32  // warm-up rows of the windowed recurrences (see template.hip)
+#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+
+struct ObjArms {
+  rvs_objective_arm a[RVS_MAX_ARMS];
+  int n;
+};
+
+template <int P>
+__global__ void __launch_bounds__(OBJ_NT)
+    objective_kernel(ObjArms A, const double *__restrict__ params,
+                     const double *__restrict__ vsini,
+                     const int32_t *__restrict__ job_spec, int J,
+                     const double *__restrict__ vel, double eps_ld,
+                     double *__restrict__ armchi, int32_t *__restrict__ armst,
+                     double *__restrict__ armout) {
+  constexpr int NT = P * (P + 1) / 2;
+  constexpr int NV = NT + P;
+  extern __shared__ double lds[];
+  __shared__ PolyLoc PL;
+  __shared__ double red[OBJ_NW][NV + 1];
+  __shared__ double coefs[P + 2];
+  __shared__ double red8[16];
+  const rvs_objective_arm &T = A.a[blockIdx.y];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int N = T.ntp, m = N - 2;
+  double *bufA = lds, *bufB = lds + N, *bufC = lds + 2 * N;
+  const int nd = T.ndim, nv = 1 << nd;
+  GridDesc G;
+  G.ndim = nd;
+  G.log_mask = T.log_mask;
+  {
+    int off = 0;
+    for (int d = 0; d < nd; d++) {
+      G.lens[d] = T.lens[d];
+      G.uoff[d] = off;
+      off += T.lens[d];
+      G.inv_ptp[d] = T.inv_ptp[d];
+    }
+    int64_t st = 1;
+    for (int d = nd - 1; d >= 0; d--) {
+      G.gstride[d] = st;
+      st *= T.lens[d];
+    }
+  }
+  // ---- A3/A5: polylinear template into bufA -------------------------------
+  poly_locate<OBJ_NT>(PL, G, params + (int64_t)j * nd, T.idgrid, T.uvecs,
+                      T.vecs_s, T.ngrid);
+  const int mode = PL.mode;
+  double mx = 0;
+  bool anynan = false;
+  if (mode == 0) {
+    for (int k = tid; k < N; k += OBJ_NT) {
+      double acc = 0;
+      for (int v = 0; v < nv; v++)
+        acc = fma(PL.w[v], (double)T.dats[PL.id[v] * N + k], acc);
+      bufA[k] = T.exp_flag ? exp(acc) : acc;
+    }
+  } else {
+    const float *row = T.dats + (int64_t)PL.nearest * N;
+    for (int k = tid; k < N; k += OBJ_NT) {
+      const double val = T.exp_flag ? (double)(float)exp((double)row[k])
+                                    : (double)row[k];
+      bufA[k] = val;
+      if (!(val == val)) anynan = true;
+      mx = fmax(mx, fabs(val));
+    }
+  }
+  double outside = 0.0;
+  if (mode != 0) {  // MAX_VAL guard of getCurTempl (spec_fit.py:392-397)
+    mx = wave_max(mx);
+    const double nanf = wave_sum(anynan ? 1.0 : 0.0);
+    if (lane == 0) {
+      red8[w] = mx;
+      red8[8 + w] = nanf;
+    }
+    __syncthreads();
+    double mm = 0, nn = 0;
+    for (int i = 0; i < OBJ_NW; i++) {
+      mm = fmax(mm, red8[i]);
+      nn += red8[8 + i];
+    }
+    outside = PL.dist;
+    if (outside > 0 && (mm > 1e100 || nn > 0 || isinf(mm)))
+      outside = __builtin_nan("");
+  }
+  __syncthreads();
+  if (!(fabs(outside) <= 1.79e308)) {  // unusable template: arm skipped
+    if (tid == 0) {
+      armout[(int64_t)blockIdx.y * J + j] = __builtin_nan("");
+      armchi[(int64_t)blockIdx.y * J + j] = 0.0;
+      armst[(int64_t)blockIdx.y * J + j] = 0;
+    }
+    return;
+  }
+  // ---- A6: rotational broadening bufA -> bufB (taps in bufC) ---------------
+  double *y = bufA, *dp = bufB;
+  int st_extra = 0;
+  if (vsini) {
+    const double vs = vsini[j];
+    const double R = (vs / RVS_C_KMS) / T.lnstep;
+    bool copy = !(vs > 0) || (R < 1e-9);
+    int kmax = 0;
+    if (!copy) {
+      kmax = (int)ceil(R + 1);
+      if (kmax >= N) {
+        st_extra = RVS_ST_NONFINITE;
+        copy = true;
+      }
+    }
+    if (!copy) {
+      double psum = 0;
+      for (int k = tid; k <= kmax; k += OBJ_NT) {
+        double ww = 0;
+        double lo = fmin(fmax(k / R, -1.0), 1.0),
+               hi = fmin(fmax((k + 1) / R, -1.0), 1.0);
+        if (hi > lo) ww += rot_segment(lo, hi, -R, 1.0 + k, eps_ld);
+        lo = fmin(fmax((k - 1) / R, -1.0), 1.0);
+        hi = fmin(fmax(k / R, -1.0), 1.0);
+        if (hi > lo) ww += rot_segment(lo, hi, R, 1.0 - k, eps_ld);
+        bufC[k] = ww;
+        psum += (k == 0) ? ww : 2 * ww;
+      }
+      psum = block_sum<OBJ_NW>(psum, red8);
+      __syncthreads();
+      const double inv = 1.0 / psum;
+      for (int i = tid; i < N; i += OBJ_NT) {
+        double acc = 0;
+        for (int q = max(0, i - kmax); q <= min(N - 1, i + kmax); q++) {
+          const int mm = q - i;
+          acc = fma(bufA[q], bufC[mm < 0 ? -mm : mm] * inv, acc);
+        }
+        bufB[i] = acc;
+      }
+      y = bufB;
+      dp = bufA;
+      __syncthreads();
+    }
+  }
+  // ---- A7 construct: natural spline of y, windowed Thomas (template.hip) ---
+  double *ec = bufC;
+  const double *g = T.factors, *e = T.factors + N, *cc = T.factors + 2 * N,
+               *hh = T.factors + 3 * N, *ih = T.factors + 4 * N;
+  for (int i = tid; i < m; i += OBJ_NT) {
+    const double y1 = y[i + 1];
+    const double s0 = (y1 - y[i]) * ih[i], s1 = (y[i + 2] - y1) * ih[i + 1];
+    dp[i] = 6 * (s1 - s0) * g[i];
+    ec[i] = e[i];
+  }
+  __syncthreads();
+  const int CH = (m + OBJ_NT - 1) / OBJ_NT;  // <= 16 (ntp <= 8192)
+  const int a0 = min(m, tid * CH), a1 = min(m, a0 + CH);
+  double loc[16];
+  {
+    double d = 0;
+    for (int i = max(0, a0 - OBJ_W); i < a0; i++) d = dp[i] - ec[i] * d;
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+      if (a0 + q < a1) {
+        d = dp[a0 + q] - ec[a0 + q] * d;
+        loc[q] = d;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; q++)
+    if (a0 + q < a1) dp[a0 + q] = loc[q];
+  __syncthreads();
+  for (int i = tid; i < m; i += OBJ_NT) ec[i] = cc[i];
+  __syncthreads();
+  {
+    double z = 0;
+    for (int i = min(m, a1 + OBJ_W) - 1; i >= a1; i--) z = dp[i] - ec[i] * z;
+#pragma unroll
+    for (int q = 15; q >= 0; q--)
+      if (a0 + q < a1) {
+        z = dp[a0 + q] - ec[a0 + q] * z;
+        loc[q] = z;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; q++)
+    if (a0 + q < a1) dp[a0 + q] = loc[q];
+  __syncthreads();
+  // dp[u] = z at knot u+1; spline piece i in powers of dl = x - x_i exactly as
+  // rvs_spline_construct(form 1) stores it
+  const rvs_point_arm &S = T.pt;
+  const int npix = S.npix;
+  const int s = job_spec ? job_spec[j] : j;
+  const double bb = vel[j] / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double espec_sys = S.espec_sys;
+  const double sys2 = espec_sys * espec_sys;
+  const double *sp = S.spec + (int64_t)s * npix;
+  const double *es = S.espec + (int64_t)s * npix;
+  const double x0 = S.knots[0], xlast = S.knots[N - 1];
+  const double shift = S.log_step ? log(f) / log(S.knots[1] / x0) : 0.0;
+  const double lin_inv_step = S.log_step ? 0.0 : 1.0 / (S.knots[1] - x0);
+  auto tv_at = [&](int k) {
+    const double x = S.lam[k] * f;
+    int pos = S.log_step ? (int)(S.work[k] + shift)
+                         : (int)((x - x0) * lin_inv_step);
+    pos = min(max(pos, 0), N - 2);
+    const double dl = x - S.knots[pos];
+    const double h = hh[pos], hinv = ih[pos];
+    const double zi = (pos == 0) ? 0.0 : dp[pos - 1];
+    const double zi1 = (pos + 1 == N - 1) ? 0.0 : dp[pos];
+    const double yi = y[pos], yi1 = y[pos + 1];
+    const double t1 = hinv * (1.0 / 6), t2 = h * (1.0 / 6);
+    const double cb = (yi1 - yi) * hinv - t2 * (2 * zi + zi1);
+    const double c2 = 0.5 * zi, c3 = (zi1 - zi) * t1;
+    return fma(fma(fma(c3, dl, c2), dl, cb), dl, yi);
+  };
+  // ---- A10/A11: continuum-marginalised chi^2 (as point_block_kernel) -------
+  double acc[NT];
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = 0;
+  for (int k = tid; k < npix; k += OBJ_NT) {
+    const double tv = tv_at(k);
+    double ee = es[k];
+    if (espec_sys > 0) ee = sqrt(sys2 + ee * ee);
+    const double ie = 1.0 / ee;
+    const double te = tv * ie;
+    const double wt = te * te, u = te * (sp[k] * ie);
+    const double *pr = S.polysT + (int64_t)k * P;
+    double pv[P], pw[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      pv[i] = pr[i];
+      pw[i] = pv[i] * wt;
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      av[i] = fma(pv[i], u, av[i]);
+#pragma unroll
+      for (int jj = 0; jj <= i; jj++)
+        acc[TRI(i, jj)] = fma(pv[i], pw[jj], acc[TRI(i, jj)]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NT; i++) {
+    const double v = wave_sum(acc[i]);
+    if (lane == 0) red[w][i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    const double v = wave_sum(av[i]);
+    if (lane == 0) red[w][NT + i] = v;
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      double v = red[0][i];
+#pragma unroll
+      for (int q = 1; q < OBJ_NW; q++) v += red[q][i];
+      if (i < NT)
+        acc[i] = v;
+      else
+        av[i - NT] = v;
+    }
+    bool ok = true;
+    double ldet = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+#pragma unroll
+      for (int jj = 0; jj <= i; jj++) {
+        double sum = acc[TRI(i, jj)];
+#pragma unroll
+        for (int q = 0; q < jj; q++) sum -= acc[TRI(i, q)] * acc[TRI(jj, q)];
+        if (jj == i) {
+          if (!(sum > 0)) ok = false;
+          const double d = sqrt(sum);
+          acc[TRI(i, i)] = d;
+          ldet += log(d);
+        } else {
+          acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      double sum = av[i];
+#pragma unroll
+      for (int q = 0; q < i; q++) sum -= acc[TRI(i, q)] * av[q];
+      av[i] = sum / acc[TRI(i, i)];
+    }
+#pragma unroll
+    for (int i = P - 1; i >= 0; i--) {
+      double sum = av[i];
+#pragma unroll
+      for (int q = i + 1; q < P; q++) sum -= acc[TRI(q, i)] * av[q];
+      av[i] = sum / acc[TRI(i, i)];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < P; i++) coefs[i] = av[i];
+      coefs[P] = ldet;
+      coefs[P + 1] = ok ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = coefs[i];
+  double rr = 0;
+  for (int k = tid; k < npix; k += OBJ_NT) {
+    const double tv = tv_at(k);
+    double ee = es[k];
+    if (espec_sys > 0) ee = sqrt(sys2 + ee * ee);
+    const double ie = 1.0 / ee;
+    const double *pr = S.polysT + (int64_t)k * P;
+    double mdl = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) mdl = fma(av[i], pr[i], mdl);
+    const double r = sp[k] * ie - mdl * (tv * ie);
+    rr = fma(r, r, rr);
+  }
+  rr = wave_sum(rr);
+  __syncthreads();
+  if (lane == 0) red[w][0] = rr;
+  __syncthreads();
+  if (tid == 0) {
+    rr = red[0][0];
+    for (int q = 1; q < OBJ_NW; q++) rr += red[q][0];
+    const double lz = S.work[npix + 2ll * S.S * npix + 2 * s];
+    double chi = 2.0 * coefs[P] + 2.0 * lz + rr;
+    int st = st_extra;
+    const double xa = S.lam[0] * f, xb = S.lam[npix - 1] * f;
+    if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) {
+      st |= RVS_ST_SPLINE_RANGE;
+      chi = __builtin_nan("");
+    }
+    const bool ok = coefs[P + 1] != 0.0;
+    if (!ok) st |= RVS_ST_CHOL_FALLBACK;
+    if (!ok || !(fabs(chi) <= 1.79e308)) {
+      st |= RVS_ST_NONFINITE;
+      chi = __builtin_nan("");
+    }
+    armchi[(int64_t)blockIdx.y * J + j] = chi;
+    armst[(int64_t)blockIdx.y * J + j] = st;
+    armout[(int64_t)blockIdx.y * J + j] = outside;
+  }
+}
+
+// arms in order; penalties of A11 (spec_fit.py:888-896)
+__global__ void objective_sum_kernel(int narm, int J, double badchi,
+                                     int outside_penalty,
+                                     const double *__restrict__ armchi,
+                                     const int32_t *__restrict__ armst,
+                                     const double *__restrict__ armout,
+                                     double *__restrict__ out,
+                                     int32_t *__restrict__ status) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= J) return;
+  double tot = 0;
+  int st = 0;
+  for (int ia = 0; ia < narm; ia++) {
+    const double o = armout[(int64_t)ia * J + j];
+    if (!(fabs(o) <= 1.79e308)) {
+      tot += 1000.0 * badchi;
+      continue;
+    }
+    tot += armchi[(int64_t)ia * J + j] + (outside_penalty ? o * badchi : 0.0);
+    st |= armst[(int64_t)ia * J + j];
+  }
+  out[j] = tot;
+  if (st) atomicOr(&status[j], st);
+}
+
+extern "C" int64_t rvs_objective_work_size(int J, int narm) {
+  if (J < 1 || narm < 1) return 0;
+  return (int64_t)narm * J * (int64_t)(2 * sizeof(double) + sizeof(int32_t));
+}
+
+extern "C" int rvs_objective_fused(const rvs_objective_arm *arms, int narm,
+                                   int npoly, const double *params,
+                                   const double *vsini, const int32_t *job_spec,
+                                   int J, const double *vel, double badchi,
+                                   int outside_penalty, void *scratch,
+                                   double *out, int32_t *status, void *stream) {
+  if (J < 1 || narm < 1 || narm > RVS_MAX_ARMS || !arms || !scratch)
+    return RVS_E_ARG;
+  ObjArms A;
+  A.n = narm;
+  size_t shm = 0;
+  for (int i = 0; i < narm; i++) {
+    A.a[i] = arms[i];
+    if (arms[i].pt.npix < 1 || arms[i].ntp < 4 || arms[i].ntp > 8192 ||
+        arms[i].ndim < 1 || arms[i].ndim > MAXDIM || arms[i].pt.taps ||
+        arms[i].pt.fast_interp || !arms[i].factors)
+      return RVS_E_ARG;
+    shm = max(shm, (size_t)3 * arms[i].ntp * sizeof(double));
+  }
+  for (int i = narm; i < RVS_MAX_ARMS; i++) A.a[i] = arms[0];
+  // static LDS of the kernel is ~6 KB; 160 KB per workgroup on gfx950
+  if (shm > OBJ_MAXDYN) return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  double *armchi = (double *)scratch;
+  double *armout = armchi + (int64_t)narm * J;
+  int32_t *armst = (int32_t *)(armout + (int64_t)narm * J);
+  dim3 grid(J, narm);
+#define RVS_CASE(PP)                                                           \
+  case PP: {                                                                   \
+    static bool attr_set = false;                                              \
+    if (!attr_set) {                                                           \
+      (void)hipFuncSetAttribute((const void *)objective_kernel<PP>,            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                OBJ_MAXDYN);                                   \
+      (void)hipGetLastError();                                                 \
+      attr_set = true;                                                         \
+    }                                                                          \
+    hipLaunchKernelGGL(objective_kernel<PP>, grid, dim3(OBJ_NT), shm, st, A,   \
+                       params, vsini, job_spec, J, vel, 0.6, armchi, armst,    \
+                       armout);                                                \
+  } break;
+  switch (npoly) {
+    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
+    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
+    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
+    default:
+      return RVS_E_ARG;
+  }
+#undef RVS_CASE
+  hipLaunchKernelGGL(objective_sum_kernel, dim3((J + 255) / 256), dim3(256), 0,
+                     st, narm, J, badchi, outside_penalty, armchi, armst, armout,
+                     out, status);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}

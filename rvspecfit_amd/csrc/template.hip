@@ -6,30 +6,7 @@
 // spec_fit.py:357-407 (getCurTempl), :495-682 (vsini), src/spliner.c:7-108.
 #include "common.h"
 
-#define MAXDIM 6
-
-struct GridDesc {
-  int ndim;
-  int lens[MAXDIM];
-  int uoff[MAXDIM];       // offset of dimension d in the concatenated uvecs
-  int64_t gstride[MAXDIM];  // C-order strides of idgrid
-  double inv_ptp[MAXDIM];
-  uint32_t log_mask;
-};
-
-// np.searchsorted(u, x, 'right') - 1  == np.digitize(x, u) - 1
-__device__ __forceinline__ int cell_index(const double *u, int n, double x) {
-  if (!(x == x)) return n - 1;  // NaN sorts to the end
-  int lo = 0, hi = n;           // first index with u[idx] > x
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (u[mid] <= x)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  return lo - 1;
-}
+#include "template_dev.h"
 
 // One 256-thread block per spectrum.  The 2^ndim vertex rows are contiguous
 // float32 rows of `dats`: consecutive lanes read consecutive pixels (coalesced
@@ -43,107 +20,16 @@ __global__ void __launch_bounds__(256)
                       const double *__restrict__ params, double *__restrict__ templ,
                       double *__restrict__ outside, int32_t *__restrict__ cellinfo,
                       double *__restrict__ weights) {
-  __shared__ double sh_w[1 << MAXDIM];
-  __shared__ int64_t sh_id[1 << MAXDIM];
-  __shared__ int sh_mode, sh_nearest;
-  __shared__ double sh_dist;
-  __shared__ double sh_mp[MAXDIM];
-  __shared__ double red_d[4];
-  __shared__ int red_i[4];
+  __shared__ PolyLoc PL;
   __shared__ double red_m[8];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int nd = G.ndim, nv = 1 << nd;
-  if (tid == 0) {
-    bool finite = true, outsidebox = false;
-    int pos[MAXDIM];
-    for (int d = 0; d < nd; d++) {
-      double v = params[(int64_t)b * nd + d];
-      if (G.log_mask & (1u << d)) v = log10(v);
-      sh_mp[d] = v;
-      if (!(fabs(v) <= 1.79e308)) finite = false;
-      pos[d] = cell_index(uvecs + G.uoff[d], G.lens[d], v);
-      if (pos[d] < 0 || pos[d] >= G.lens[d] - 1) outsidebox = true;
-    }
-    int mode = 0;
-    if (outsidebox) {
-      mode = finite ? 1 : 2;
-    } else {
-      // vertices in itertools.product([0,1]^ndim) order: first dim slowest
-      for (int v = 0; v < nv; v++) {
-        int64_t off = 0;
-        for (int d = 0; d < nd; d++) {
-          const int bit = (v >> (nd - 1 - d)) & 1;
-          off += (int64_t)(pos[d] + bit) * G.gstride[d];
-        }
-        const int64_t id = idgrid[off];
-        sh_id[v] = id;
-        if (id < 0) mode = 1;
-      }
-      if (mode == 0) {
-        double x[MAXDIM];
-        for (int d = 0; d < nd; d++) {
-          const double *u = uvecs + G.uoff[d];
-          x[d] = (sh_mp[d] - u[pos[d]]) / (u[pos[d] + 1] - u[pos[d]]);
-        }
-        for (int v = 0; v < nv; v++) {
-          double w = 1;
-          for (int d = 0; d < nd; d++)
-            w *= ((v >> (nd - 1 - d)) & 1) ? x[d] : (1 - x[d]);
-          sh_w[v] = w;
-        }
-      }
-    }
-    sh_mode = mode;
-  }
-  __syncthreads();
-  const int mode = sh_mode;
-  if (mode == 1) {
-    // brute-force nearest neighbour in ptp-scaled space (== cKDTree.query,
-    // spec_inter.py:127-132); first minimum wins
-    double q[MAXDIM];
-    for (int d = 0; d < nd; d++) q[d] = sh_mp[d] * G.inv_ptp[d];
-    double bd = __builtin_inf();
-    int bi = 0x7fffffff;
-    for (int64_t g = tid; g < ngrid; g += 256) {
-      double d2 = 0;
-      for (int d = 0; d < nd; d++) {
-        const double df = vecs_s[g * nd + d] - q[d];
-        d2 += df * df;
-      }
-      if (d2 < bd) {
-        bd = d2;
-        bi = (int)g;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double od = __shfl_xor(bd, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (od < bd || (od == bd && oi < bi)) {
-        bd = od;
-        bi = oi;
-      }
-    }
-    if ((tid & 63) == 0) {
-      red_d[tid >> 6] = bd;
-      red_i[tid >> 6] = bi;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < 4; w++)
-        if (red_d[w] < bd || (red_d[w] == bd && red_i[w] < bi)) {
-          bd = red_d[w];
-          bi = red_i[w];
-        }
-      sh_nearest = bi;
-      sh_dist = sqrt(bd);
-    }
-    __syncthreads();
-  } else if (tid == 0) {
-    sh_nearest = (mode == 2) ? 0 : -1;
-    sh_dist = (mode == 2) ? __builtin_inf() : 0.0;
-  }
-  __syncthreads();
+  poly_locate<256>(PL, G, params + (int64_t)b * nd, idgrid, uvecs, vecs_s, ngrid);
+  const int mode = PL.mode;
+  double *sh_w = PL.w;
+  int64_t *sh_id = PL.id;
+  const int sh_nearest = PL.nearest;
+  const double sh_dist = PL.dist;
   double *out = templ + (int64_t)b * ntp;
   double mx = 0;
   bool anynan = false;
@@ -387,27 +273,6 @@ extern "C" int rvs_template_tri(const double *dats, int ntp,
 // A6: rotational broadening (spec_fit.py:495-682)
 // ---------------------------------------------------------------------------
 #define VSINI_MAXTAP 2048  // one-sided taps kept in LDS
-
-__device__ __forceinline__ void rot_prim(double x, double eps, double &k0,
-                                         double &k1) {
-  x = fmin(fmax(x, -1.0), 1.0);
-  const double pi = 3.141592653589793;
-  const double norm = pi * (1 - eps / 3.0);
-  const double c1 = 2 * (1 - eps) / norm;
-  const double c2 = (pi / 2.0) * eps / norm;
-  const double s = sqrt(1 - x * x);
-  k0 = c1 * (0.5 * (x * s + asin(x))) + c2 * (x - x * x * x / 3.0);
-  k1 = c1 * (-1.0 / 3.0 * (1 - x * x) * s) +
-       c2 * (x * x / 2.0 - x * x * x * x / 4.0);
-}
-
-__device__ __forceinline__ double rot_segment(double xa, double xb, double slope,
-                                              double icpt, double eps) {
-  double a0, a1, b0, b1;
-  rot_prim(xb, eps, b0, b1);
-  rot_prim(xa, eps, a0, a1);
-  return slope * (b1 - a1) + icpt * (b0 - a0);
-}
 
 __global__ void __launch_bounds__(256)
     vsini_kernel(const double *__restrict__ templ,

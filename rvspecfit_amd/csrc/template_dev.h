@@ -1,0 +1,166 @@
+// Device helpers shared by template.hip and objective.hip (gfx950 only).
+#pragma once
+#include "common.h"
+
+#define MAXDIM 6
+
+struct GridDesc {
+  int ndim;
+  int lens[MAXDIM];
+  int uoff[MAXDIM];       // offset of dimension d in the concatenated uvecs
+  int64_t gstride[MAXDIM];  // C-order strides of idgrid
+  double inv_ptp[MAXDIM];
+  uint32_t log_mask;
+};
+
+// np.searchsorted(u, x, 'right') - 1  == np.digitize(x, u) - 1
+__device__ __forceinline__ int cell_index(const double *u, int n, double x) {
+  if (!(x == x)) return n - 1;  // NaN sorts to the end
+  int lo = 0, hi = n;           // first index with u[idx] > x
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (u[mid] <= x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo - 1;
+}
+
+// LDS-resident result of the polylinear cell search
+struct PolyLoc {
+  double w[1 << MAXDIM];
+  int64_t id[1 << MAXDIM];
+  double mp[MAXDIM];
+  double red_d[16];
+  int red_i[16];
+  double dist;
+  int mode, nearest;
+};
+
+// GridInterp.__call__ index work (spec_inter.py:134-194) for one parameter
+// vector: mode 0 = polylinear (vertex ids in itertools.product order + weights),
+// 1 = nearest neighbour (brute-force first minimum == cKDTree.query on
+// ptp-scaled coordinates, :127-132), 2 = non-finite parameters.  Called by ALL
+// NT threads of the block (contains barriers).
+template <int NT>
+__device__ void poly_locate(PolyLoc &L, const GridDesc &G,
+                            const double *__restrict__ prow,
+                            const int64_t *__restrict__ idgrid,
+                            const double *__restrict__ uvecs,
+                            const double *__restrict__ vecs_s, int64_t ngrid) {
+  const int tid = threadIdx.x;
+  const int nd = G.ndim, nv = 1 << nd;
+  if (tid == 0) {
+    bool finite = true, outsidebox = false;
+    int pos[MAXDIM];
+    for (int d = 0; d < nd; d++) {
+      double v = prow[d];
+      if (G.log_mask & (1u << d)) v = log10(v);
+      L.mp[d] = v;
+      if (!(fabs(v) <= 1.79e308)) finite = false;
+      pos[d] = cell_index(uvecs + G.uoff[d], G.lens[d], v);
+      if (pos[d] < 0 || pos[d] >= G.lens[d] - 1) outsidebox = true;
+    }
+    int mode = 0;
+    if (outsidebox) {
+      mode = finite ? 1 : 2;
+    } else {
+      // vertices in itertools.product([0,1]^ndim) order: first dim slowest
+      for (int v = 0; v < nv; v++) {
+        int64_t off = 0;
+        for (int d = 0; d < nd; d++) {
+          const int bit = (v >> (nd - 1 - d)) & 1;
+          off += (int64_t)(pos[d] + bit) * G.gstride[d];
+        }
+        const int64_t id = idgrid[off];
+        L.id[v] = id;
+        if (id < 0) mode = 1;
+      }
+      if (mode == 0) {
+        double x[MAXDIM];
+        for (int d = 0; d < nd; d++) {
+          const double *u = uvecs + G.uoff[d];
+          x[d] = (L.mp[d] - u[pos[d]]) / (u[pos[d] + 1] - u[pos[d]]);
+        }
+        for (int v = 0; v < nv; v++) {
+          double w = 1;
+          for (int d = 0; d < nd; d++)
+            w *= ((v >> (nd - 1 - d)) & 1) ? x[d] : (1 - x[d]);
+          L.w[v] = w;
+        }
+      }
+    }
+    L.mode = mode;
+  }
+  __syncthreads();
+  const int mode = L.mode;
+  if (mode == 1) {
+    double q[MAXDIM];
+    for (int d = 0; d < nd; d++) q[d] = L.mp[d] * G.inv_ptp[d];
+    double bd = __builtin_inf();
+    int bi = 0x7fffffff;
+    for (int64_t g = tid; g < ngrid; g += NT) {
+      double d2 = 0;
+      for (int d = 0; d < nd; d++) {
+        const double df = vecs_s[g * nd + d] - q[d];
+        d2 += df * df;
+      }
+      if (d2 < bd) {
+        bd = d2;
+        bi = (int)g;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double od = __shfl_xor(bd, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (od < bd || (od == bd && oi < bi)) {
+        bd = od;
+        bi = oi;
+      }
+    }
+    if ((tid & 63) == 0) {
+      L.red_d[tid >> 6] = bd;
+      L.red_i[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < NT / 64; w++)
+        if (L.red_d[w] < bd || (L.red_d[w] == bd && L.red_i[w] < bi)) {
+          bd = L.red_d[w];
+          bi = L.red_i[w];
+        }
+      L.nearest = bi;
+      L.dist = sqrt(bd);
+    }
+    __syncthreads();
+  } else if (tid == 0) {
+    L.nearest = (mode == 2) ? 0 : -1;
+    L.dist = (mode == 2) ? __builtin_inf() : 0.0;
+  }
+  __syncthreads();
+}
+
+// ---- rotational kernel primitives (spec_fit.py:495-562) --------------------
+__device__ __forceinline__ void rot_prim(double x, double eps, double &k0,
+                                         double &k1) {
+  x = fmin(fmax(x, -1.0), 1.0);
+  const double pi = 3.141592653589793;
+  const double norm = pi * (1 - eps / 3.0);
+  const double c1 = 2 * (1 - eps) / norm;
+  const double c2 = (pi / 2.0) * eps / norm;
+  const double s = sqrt(1 - x * x);
+  k0 = c1 * (0.5 * (x * s + asin(x))) + c2 * (x - x * x * x / 3.0);
+  k1 = c1 * (-1.0 / 3.0 * (1 - x * x) * s) +
+       c2 * (x * x / 2.0 - x * x * x * x / 4.0);
+}
+
+__device__ __forceinline__ double rot_segment(double xa, double xb, double slope,
+                                              double icpt, double eps) {
+  double a0, a1, b0, b1;
+  rot_prim(xb, eps, b0, b1);
+  rot_prim(xa, eps, a0, a1);
+  return slope * (b1 - a1) + icpt * (b0 - a0);
+}
+

@@ -549,6 +549,88 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
     return out, status
 
 
+def fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys=0.0):
+    """rvs_objective_arm descriptors of every arm (ctypes array `arr`); returns
+    the tensors that must stay alive while the descriptors are used"""
+    keep = []
+    esys = _per_arm(espec_sys, len(batch.arms))
+    for ia, arm in enumerate(batch.arms):
+        lib = libs[arm.name]
+        work = arm.work(lib, esys[ia])
+        polysT = arm.basis(npoly, rbf)
+        keep.append((work, polysT))
+        a = arr[ia]
+        p = a.pt
+        p.lam, p.polysT = arm.lam.data_ptr(), polysT.data_ptr()
+        p.spec, p.espec = arm.spec.data_ptr(), arm.espec.data_ptr()
+        p.work, p.knots = work.data_ptr(), lib.knots.data_ptr()
+        p.coef = p.penalty = p.taps = None
+        p.taps_stride, p.espec_sys = 0, esys[ia]
+        p.npix, p.S, p.ntp = arm.npix, arm.S, lib.ntp
+        p.log_step, p.nd, p.fast_interp = int(lib.log_step), 0, 0
+        a.dats, a.idgrid = lib.dats.data_ptr(), lib.idgrid.data_ptr()
+        a.uvecs, a.vecs_s = lib.uvecs.data_ptr(), lib.vecs_s.data_ptr()
+        a.factors = lib.spline_factors.data_ptr()
+        a.ngrid, a.lnstep = lib.ngrid, lib.lnstep
+        for d in range(lib.ndim):
+            a.inv_ptp[d] = float(lib.inv_ptp[d])
+            a.lens[d] = int(lib.lens[d])
+        a.ntp, a.ndim = lib.ntp, lib.ndim
+        a.log_mask, a.exp_flag = lib.log_mask, lib.exp_flag
+    return keep
+
+
+def can_fuse_objective(batch, libs, resols=None, fast_interp=False):
+    """the single-kernel objective needs regular-grid libraries on a (log-)uniform
+    template grid that fits LDS, and neither resolution matrices nor fast_interp"""
+    if fast_interp or not FUSED_OBJECTIVE:
+        return False
+    for ia, arm in enumerate(batch.arms):
+        lib = libs[arm.name]
+        if lib.kind != 'regulargrid' or lib.spline_factors is None:
+            return False
+        if 3 * lib.ntp * 8 > 160 * 1024 - 6144:
+            return False
+        if _arm_resol(arm, ia, resols) is not None:
+            return False
+    return True
+
+
+FUSED_OBJECTIVE = _os.environ.get('RVS_FUSED_OBJECTIVE', '1') != '0'
+
+
+def objective_fused(batch, libs, params, vsini, vel, npoly=5, rbf=True,
+                    job_spec=None, espec_sys=0.0, outside_penalty=True):
+    """get_chisq for J (spectrum, parameters, vsini, velocity) jobs as ONE kernel
+    per call (rvs_objective_fused): no template or spline record in HBM.
+    Returns chisq [J], status int32 [J]."""
+    import ctypes
+    L = _lib.lib()
+    dev = batch.device
+    vel = vel.to(device=dev, dtype=torch.float64).contiguous()
+    params = params.to(device=dev, dtype=torch.float64).contiguous()
+    J = vel.shape[0]
+    narm = len(batch.arms)
+    arr = (_lib.ObjectiveArm * narm)()
+    keep = fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys)
+    out = torch.empty(J, dtype=torch.float64, device=dev)
+    status = torch.zeros(J, dtype=torch.int32, device=dev)
+    nb = L.rvs_objective_work_size(J, narm)
+    scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
+    if vsini is not None:
+        vsini = vsini.to(device=dev, dtype=torch.float64).contiguous()
+    with _ktime('objective_fused', J):
+        rc = L.rvs_objective_fused(ctypes.addressof(arr), narm, npoly,
+                                   _lib.ptr(params), _lib.ptr(vsini),
+                                   _lib.ptr(job_spec), J, _lib.ptr(vel),
+                                   float(batch.badchi), int(outside_penalty),
+                                   _lib.ptr(scratch), _lib.ptr(out),
+                                   _lib.ptr(status), _lib.stream())
+        _lib.check(rc, 'rvs_objective_fused')
+    del keep
+    return out, status
+
+
 _ar_cache = {}
 
 

@@ -114,6 +114,14 @@ class ProcessObjective:
             a.log_step = int(lib.log_step)
         nb = L.rvs_chisq_point_work_size(cap, narm)
         self.scratch = torch.empty((nb + 7) // 8, **f64)
+        from . import engine
+        self.fused = engine.can_fuse_objective(batch, libs, resols)
+        if self.fused:
+            self.oarr = (_lib.ObjectiveArm * narm)()
+            self._keep = engine.fill_objective_arms(self.oarr, batch, libs,
+                                                    self.npoly, self.rbf, 0.0)
+            nb = L.rvs_objective_work_size(cap, narm)
+            self.oscratch = torch.empty((nb + 7) // 8, **f64)
         self.streams = [torch.cuda.Stream(device=dev) for _ in batch.arms]
         self.ev_in = torch.cuda.Event()
         self.ev_out = [torch.cuda.Event() for _ in batch.arms]
@@ -133,6 +141,22 @@ class ProcessObjective:
                             _p(self.job_spec), _p(self.vel), _p(self.vsini),
                             _p(self.params), _p(self.extra), _p(self.bad), st)
         _lib.check(rc, 'rvs_proc_map')
+        if self.fused:   # one kernel: gather, FIR, spline solve, chi^2
+            self.jstatus.zero_()
+            rc = L.rvs_objective_fused(
+                ctypes.addressof(self.oarr), len(self.arm_buf), self.npoly,
+                _p(self.params), _p(self.vsini), _p(self.job_spec), J,
+                _p(self.vel), self.badchi, 1, _p(self.oscratch), _p(self.chi),
+                _p(self.jstatus), st)
+            _lib.check(rc, 'rvs_objective_fused')
+            rc = L.rvs_proc_finish(J, _p(counts), cidx, _p(self.chi),
+                                   _p(self.extra), _p(self.bad),
+                                   _p(self.job_spec), _p(self.jstatus), _p(F),
+                                   _p(self.status), st)
+            _lib.check(rc, 'rvs_proc_finish')
+            self.calls += 1
+            self.jobs += J
+            return
         # the arms are independent until the point kernel: one stream each
         main = torch.cuda.current_stream()
         self.ev_in.record(main)

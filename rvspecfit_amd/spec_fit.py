@@ -368,16 +368,22 @@ def chisq_jobs(batch, idx, vel, params, vsini, options, config,
     rbf = options.get('rbf_continuum', True)
     libs = spec_inter.get_libs(batch.names, config)
     params = params.contiguous()
+    esys = float(espec_systematic) if espec_systematic is not None else 0.0
+    resols = _resols(batch, resol_params)
+    js = idx.to(torch.int32).contiguous()
+    if engine.can_fuse_objective(batch, libs, resols):
+        return engine.objective_fused(batch, libs, params, vsini, vel,
+                                      npoly=npoly, rbf=rbf, job_spec=js,
+                                      espec_sys=esys,
+                                      outside_penalty=outside_penalty)
     coefs, outs = [], []
     for arm in batch.arms:
         c, o = engine.build_templates(libs[arm.name], params, vsini)
         coefs.append(c)
         outs.append(o)
-    esys = float(espec_systematic) if espec_systematic is not None else 0.0
     return engine.chisq_point(batch, libs, coefs, outs, vel, npoly=npoly,
-                              rbf=rbf, job_spec=idx.to(torch.int32).contiguous(),
-                              espec_sys=esys, outside_penalty=outside_penalty,
-                              resols=_resols(batch, resol_params))
+                              rbf=rbf, job_spec=js, espec_sys=esys,
+                              outside_penalty=outside_penalty, resols=resols)
 
 
 def chisq_grid_jobs(batch, vel_grid, params, vsini, options, config,

@@ -924,3 +924,49 @@ def test_process_second_minimizer(cases, pcases, config):
     err = g['p4/param_err']
     got = np.array([r1['param'][_] for _ in ('teff', 'logg', 'feh', 'alpha')])
     assert np.all(np.abs(got - g['p4/param']) < 0.02 * err)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_objective_fused(cases, config, tag):
+    """rvs_objective_fused (gather + FIR + spline solve + chi^2 in one kernel,
+    template in LDS) against the chain of stand-alone kernels and the
+    reference's get_chisq values"""
+    from rvspecfit_amd import engine, spec_fit
+    sds = _sds(cases, tag)
+    b, _ = spec_fit.as_batch(sds)
+    for npoly, rbf in ((10, True), (15, True), (5, True), (7, False)):
+        for with_rot in (False, True):
+            ii = [i for i in range(7)
+                  if int(cases['%s/chisq/t%d/npoly' % (tag, i)]) == npoly and
+                  bool(cases['%s/chisq/t%d/rbf' % (tag, i)]) == rbf and
+                  np.isfinite(cases['%s/chisq/t%d/vsini' % (tag, i)]) == with_rot]
+            if not ii:
+                continue
+            vel = torch.as_tensor([float(cases['%s/chisq/t%d/vel' % (tag, i)])
+                                   for i in ii], dtype=torch.float64).to('cuda')
+            par = torch.as_tensor(np.array(
+                [cases['%s/chisq/t%d/param' % (tag, i)] for i in ii])).to('cuda')
+            vs = None
+            if with_rot:
+                vs = torch.as_tensor([float(
+                    cases['%s/chisq/t%d/vsini' % (tag, i)]) for i in ii],
+                    dtype=torch.float64).to('cuda')
+            idx = torch.zeros(len(ii), dtype=torch.long, device='cuda')
+            opt = dict(npoly=npoly, rbf_continuum=rbf)
+            out = {}
+            for fused in (True, False):
+                engine.FUSED_OBJECTIVE = fused
+                try:
+                    with np.errstate(all='ignore'):
+                        out[fused] = spec_fit.chisq_jobs(b, idx, vel, par, vs,
+                                                         opt, config)
+                finally:
+                    engine.FUSED_OBJECTIVE = True
+            c1, s1 = out[True]
+            c0, s0 = out[False]
+            assert torch.equal(s0, s1)
+            for k, i in enumerate(ii):
+                want = float(cases['%s/chisq/t%d/value' % (tag, i)])
+                sc = max(abs(want), 1e3)
+                assert abs(c1[k].item() - c0[k].item()) < 1e-11 * sc, (i, k)
+                assert abs(c1[k].item() - want) < 1e-6 * sc, (i, c1[k].item())

@@ -299,6 +299,7 @@ typedef struct rvs_objective_arm {
   uint32_t log_mask;
   int32_t exp_flag;
 } rvs_objective_arm;
+int rvs_objective_max_ntp(int npoly); /* largest template grid that fits LDS */
 int64_t rvs_objective_work_size(int J, int narm);
 int rvs_objective_fused(const rvs_objective_arm *arms, int narm, int npoly,
                         const double *params, const double *vsini,

@@ -49,6 +49,7 @@ SIGNATURES = {
     'rvs_proc_map': (I, [I, I, I, P, P, P, I, P, P, P, P, P, D, D, D, P, P, P, P,
                           P, P, P]),
     'rvs_proc_finish': (I, [I, P, I, P, P, P, P, P, P, P, P]),
+    'rvs_objective_max_ntp': (I, [I]),
     'rvs_objective_work_size': (L, [I, I]),
     'rvs_objective_fused': (I, [P, I, I, P, P, P, I, P, D, I, P, P, P, P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),

@@ -1368,13 +1368,13 @@ __global__ void __launch_bounds__(256)
   }
 #pragma unroll
   for (int i = 0; i < NT; i++) {
-    const double v = wave_sum(acc[i]);
-    if (lane == 0) red[w][i] = v;
+    const double v = wave_sum_to63(acc[i]);
+    if (lane == 63) red[w][i] = v;
   }
 #pragma unroll
   for (int i = 0; i < P; i++) {
-    const double v = wave_sum(av[i]);
-    if (lane == 0) red[w][NT + i] = v;
+    const double v = wave_sum_to63(av[i]);
+    if (lane == 63) red[w][NT + i] = v;
   }
   __syncthreads();
   if (w == 0) {

@@ -21,9 +21,30 @@
 
 #define OBJ_NT 512
 #define OBJ_NW (OBJ_NT / 64)
-#define OBJ_MAXDYN (160 * 1024 - 6144)
 #define OBJ_W 32  // warm-up rows of the windowed recurrences (see template.hip)
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+
+#ifdef RVS_OBJ_TIMING
+// debug build only (tools/perf/obj_phases.sh): clock budget of the phases
+__device__ unsigned long long obj_dbg[16];
+#define OBJ_T(i)                                                         \
+  do {                                                                   \
+    __syncthreads();                                                     \
+    if (threadIdx.x == 0) {                                              \
+      const unsigned long long t_ = wall_clock64();                      \
+      atomicAdd(&obj_dbg[i], t_ - t_prev);                               \
+      t_prev = t_;                                                       \
+    }                                                                    \
+  } while (0)
+extern "C" int rvs_dbg_read(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(obj_dbg), sizeof(obj_dbg)) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}
+#else
+#define OBJ_T(i)
+#endif
 
 struct ObjArms {
   rvs_objective_arm a[RVS_MAX_ARMS];
@@ -44,6 +65,8 @@ __global__ void __launch_bounds__(OBJ_NT)
   __shared__ PolyLoc PL;
   __shared__ double red[OBJ_NW][NV + 1];
   __shared__ double coefs[P + 2];
+  __shared__ double Lm[P][P + 1];
+  __shared__ double yv[P], ldv[P];
   __shared__ double red8[16];
   const rvs_objective_arm &T = A.a[blockIdx.y];
   const int j = blockIdx.x, tid = threadIdx.x;
@@ -68,14 +91,36 @@ __global__ void __launch_bounds__(OBJ_NT)
       st *= T.lens[d];
     }
   }
+#ifdef RVS_OBJ_TIMING
+  unsigned long long t_prev = wall_clock64();
+#endif
   // ---- A3/A5: polylinear template into bufA -------------------------------
   poly_locate<OBJ_NT>(PL, G, params + (int64_t)j * nd, T.idgrid, T.uvecs,
                       T.vecs_s, T.ngrid);
   const int mode = PL.mode;
+  OBJ_T(0);
   double mx = 0;
   bool anynan = false;
   if (mode == 0) {
-    for (int k = tid; k < N; k += OBJ_NT) {
+    // four CONSECUTIVE pixels per thread: one 16-byte load per vertex row
+    // (rows start on 4-byte boundaries only: dword-aligned x4 loads), 1 KiB per
+    // wave instruction instead of 256 B
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int N4 = N & ~3;
+    for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
+      double a4[4] = {0, 0, 0, 0};
+      for (int v = 0; v < nv; v++) {
+        const f4u r = *reinterpret_cast<const f4u *>(T.dats + PL.id[v] * N + k);
+        const double wv = PL.w[v];
+        a4[0] = fma(wv, (double)r.x, a4[0]);
+        a4[1] = fma(wv, (double)r.y, a4[1]);
+        a4[2] = fma(wv, (double)r.z, a4[2]);
+        a4[3] = fma(wv, (double)r.w, a4[3]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) bufA[k + q] = T.exp_flag ? exp(a4[q]) : a4[q];
+    }
+    for (int k = N4 + tid; k < N; k += OBJ_NT) {
       double acc = 0;
       for (int v = 0; v < nv; v++)
         acc = fma(PL.w[v], (double)T.dats[PL.id[v] * N + k], acc);
@@ -118,6 +163,7 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
     return;
   }
+  OBJ_T(1);
   // ---- A6: rotational broadening bufA -> bufB (taps in bufC) ---------------
   double *y = bufA, *dp = bufB;
   int st_extra = 0;
@@ -162,6 +208,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       __syncthreads();
     }
   }
+  OBJ_T(2);
   // ---- A7 construct: natural spline of y, windowed Thomas (template.hip) ---
   double *ec = bufC;
   const double *g = T.factors, *e = T.factors + N, *cc = T.factors + 2 * N,
@@ -208,6 +255,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   for (int q = 0; q < 16; q++)
     if (a0 + q < a1) dp[a0 + q] = loc[q];
   __syncthreads();
+  OBJ_T(3);
   // dp[u] = z at knot u+1; spline piece i in powers of dl = x - x_i exactly as
   // rvs_spline_construct(form 1) stores it
   const rvs_point_arm &S = T.pt;
@@ -266,69 +314,91 @@ __global__ void __launch_bounds__(OBJ_NT)
         acc[TRI(i, jj)] = fma(pv[i], pw[jj], acc[TRI(i, jj)]);
     }
   }
+  OBJ_T(4);
 #pragma unroll
   for (int i = 0; i < NT; i++) {
-    const double v = wave_sum(acc[i]);
-    if (lane == 0) red[w][i] = v;
+    const double v = wave_sum_to63(acc[i]);
+    if (lane == 63) red[w][i] = v;
   }
 #pragma unroll
   for (int i = 0; i < P; i++) {
-    const double v = wave_sum(av[i]);
-    if (lane == 0) red[w][NT + i] = v;
+    const double v = wave_sum_to63(av[i]);
+    if (lane == 63) red[w][NT + i] = v;
   }
   __syncthreads();
   if (w == 0) {
+    // Cholesky + the two triangular solves with ROW i on lane i (i < P): the
+    // same operations in the same order as the in-lane version of the other
+    // chi^2 kernels (left-looking, sums over q ascending), but the rows advance
+    // side by side: the serial chain is P columns instead of P(P+1)/2 entries.
+    // L is mirrored in LDS so that a lane can read another row (same wave:
+    // LDS operations of one wave complete in order).
+    const int i = lane < P ? lane : P - 1;
+    double row[P];
+    double vi = 0;
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
-      double v = red[0][i];
+    for (int jj = 0; jj < P; jj++) {
+      double v = 0;
+      if (jj <= i) {
+        v = red[0][TRI(i, jj)];
 #pragma unroll
-      for (int q = 1; q < OBJ_NW; q++) v += red[q][i];
-      if (i < NT)
-        acc[i] = v;
-      else
-        av[i - NT] = v;
-    }
-    bool ok = true;
-    double ldet = 0;
-#pragma unroll
-    for (int i = 0; i < P; i++) {
-#pragma unroll
-      for (int jj = 0; jj <= i; jj++) {
-        double sum = acc[TRI(i, jj)];
-#pragma unroll
-        for (int q = 0; q < jj; q++) sum -= acc[TRI(i, q)] * acc[TRI(jj, q)];
-        if (jj == i) {
-          if (!(sum > 0)) ok = false;
-          const double d = sqrt(sum);
-          acc[TRI(i, i)] = d;
-          ldet += log(d);
-        } else {
-          acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
-        }
+        for (int q = 1; q < OBJ_NW; q++) v += red[q][TRI(i, jj)];
       }
+      row[jj] = v;
     }
+    vi = red[0][NT + i];
 #pragma unroll
-    for (int i = 0; i < P; i++) {
-      double sum = av[i];
+    for (int q = 1; q < OBJ_NW; q++) vi += red[q][NT + i];
+    bool ok = true;
 #pragma unroll
-      for (int q = 0; q < i; q++) sum -= acc[TRI(i, q)] * av[q];
-      av[i] = sum / acc[TRI(i, i)];
+    for (int jj = 0; jj < P; jj++) {
+      double sum = row[jj];
+#pragma unroll
+      for (int q = 0; q < jj; q++) sum -= row[q] * Lm[jj][q];
+      if (lane == jj) {
+        if (!(sum > 0)) ok = false;
+        const double d = sqrt(sum);
+        row[jj] = d;
+        Lm[jj][jj] = d;
+        ldv[jj] = log(d);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (i > jj) {
+        row[jj] = sum / Lm[jj][jj];
+        Lm[i][jj] = row[jj];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
+    // L y = v
+    double si = vi;
 #pragma unroll
-    for (int i = P - 1; i >= 0; i--) {
-      double sum = av[i];
-#pragma unroll
-      for (int q = i + 1; q < P; q++) sum -= acc[TRI(q, i)] * av[q];
-      av[i] = sum / acc[TRI(i, i)];
+    for (int q = 0; q < P; q++) {
+      if (lane == q) yv[q] = si / row[q];
+      __builtin_amdgcn_wave_barrier();
+      if (i > q) si -= row[q] * yv[q];
     }
+    // L^T a = y: a_i = (y_i - sum_{q>i} L[q][i] a_q) / L[i][i], q ascending
+#pragma unroll
+    for (int ii = P - 1; ii >= 0; ii--) {
+      if (lane == ii) {
+        double sum = yv[ii];
+#pragma unroll
+        for (int q = ii + 1; q < P; q++) sum -= Lm[q][ii] * coefs[q];
+        coefs[ii] = sum / row[ii];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const unsigned long long okm = __ballot(ok || lane >= P);
     if (lane == 0) {
+      double ldet = 0;
 #pragma unroll
-      for (int i = 0; i < P; i++) coefs[i] = av[i];
+      for (int q = 0; q < P; q++) ldet += ldv[q];
       coefs[P] = ldet;
-      coefs[P + 1] = ok ? 1.0 : 0.0;
+      coefs[P + 1] = (okm == ~0ull) ? 1.0 : 0.0;
     }
   }
   __syncthreads();
+  OBJ_T(5);
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = coefs[i];
   double rr = 0;
@@ -344,6 +414,7 @@ __global__ void __launch_bounds__(OBJ_NT)
     const double r = sp[k] * ie - mdl * (tv * ie);
     rr = fma(r, r, rr);
   }
+  OBJ_T(6);
   rr = wave_sum(rr);
   __syncthreads();
   if (lane == 0) red[w][0] = rr;
@@ -396,6 +467,32 @@ __global__ void objective_sum_kernel(int narm, int J, double badchi,
   if (st) atomicOr(&status[j], st);
 }
 
+// largest template grid (knots) the kernel can hold in LDS for this npoly:
+// 160 KB per workgroup minus the kernel's static LDS, three doubles per knot
+extern "C" int rvs_objective_max_ntp(int npoly) {
+  hipFuncAttributes at;
+  const void *fn = nullptr;
+#define RVS_CASE(PP)                               \
+  case PP:                                         \
+    fn = (const void *)objective_kernel<PP>;       \
+    break;
+  switch (npoly) {
+    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
+    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
+    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
+    default:
+      return 0;
+  }
+#undef RVS_CASE
+  if (hipFuncGetAttributes(&at, fn) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  const int64_t room = 160 * 1024 - (int64_t)at.sharedSizeBytes;
+  int n = (int)(room / (3 * (int64_t)sizeof(double)));
+  return n > 8192 ? 8192 : (n < 0 ? 0 : n);
+}
+
 extern "C" int64_t rvs_objective_work_size(int J, int narm) {
   if (J < 1 || narm < 1) return 0;
   return (int64_t)narm * J * (int64_t)(2 * sizeof(double) + sizeof(int32_t));
@@ -421,8 +518,8 @@ extern "C" int rvs_objective_fused(const rvs_objective_arm *arms, int narm,
     shm = max(shm, (size_t)3 * arms[i].ntp * sizeof(double));
   }
   for (int i = narm; i < RVS_MAX_ARMS; i++) A.a[i] = arms[0];
-  // static LDS of the kernel is ~6 KB; 160 KB per workgroup on gfx950
-  if (shm > OBJ_MAXDYN) return RVS_E_ARG;
+  if (shm > (size_t)3 * rvs_objective_max_ntp(npoly) * sizeof(double))
+    return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
   double *armchi = (double *)scratch;
   double *armout = armchi + (int64_t)narm * J;
@@ -434,7 +531,7 @@ extern "C" int rvs_objective_fused(const rvs_objective_arm *arms, int narm,
     if (!attr_set) {                                                           \
       (void)hipFuncSetAttribute((const void *)objective_kernel<PP>,            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                OBJ_MAXDYN);                                   \
+                                160 * 1024 - 1024);                            \
       (void)hipGetLastError();                                                 \
       attr_set = true;                                                         \
     }                                                                          \

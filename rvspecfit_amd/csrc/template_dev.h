@@ -32,6 +32,9 @@ struct PolyLoc {
   double w[1 << MAXDIM];
   int64_t id[1 << MAXDIM];
   double mp[MAXDIM];
+  double x[MAXDIM];
+  int pos[MAXDIM];
+  int flag[MAXDIM];
   double red_d[16];
   int red_i[16];
   double dist;
@@ -51,47 +54,55 @@ __device__ void poly_locate(PolyLoc &L, const GridDesc &G,
                             const double *__restrict__ vecs_s, int64_t ngrid) {
   const int tid = threadIdx.x;
   const int nd = G.ndim, nv = 1 << nd;
-  if (tid == 0) {
-    bool finite = true, outsidebox = false;
-    int pos[MAXDIM];
-    for (int d = 0; d < nd; d++) {
-      double v = prow[d];
-      if (G.log_mask & (1u << d)) v = log10(v);
-      L.mp[d] = v;
-      if (!(fabs(v) <= 1.79e308)) finite = false;
-      pos[d] = cell_index(uvecs + G.uoff[d], G.lens[d], v);
-      if (pos[d] < 0 || pos[d] >= G.lens[d] - 1) outsidebox = true;
-    }
-    int mode = 0;
-    if (outsidebox) {
-      mode = finite ? 1 : 2;
-    } else {
+  // the index work is spread over a few threads so that its dependent loads
+  // (binary searches, idgrid look-ups) run side by side instead of in one chain
+  if (tid < nd) {
+    const int d = tid;
+    double v = prow[d];
+    if (G.log_mask & (1u << d)) v = log10(v);
+    L.mp[d] = v;
+    const int p = cell_index(uvecs + G.uoff[d], G.lens[d], v);
+    L.pos[d] = p;
+    L.flag[d] = ((fabs(v) <= 1.79e308) ? 0 : 1) |
+                ((p < 0 || p >= G.lens[d] - 1) ? 2 : 0);
+  }
+  __syncthreads();
+  bool finite = true, outsidebox = false;
+  for (int d = 0; d < nd; d++) {
+    if (L.flag[d] & 1) finite = false;
+    if (L.flag[d] & 2) outsidebox = true;
+  }
+  if (!outsidebox) {
+    if (tid < nv) {
       // vertices in itertools.product([0,1]^ndim) order: first dim slowest
-      for (int v = 0; v < nv; v++) {
-        int64_t off = 0;
-        for (int d = 0; d < nd; d++) {
-          const int bit = (v >> (nd - 1 - d)) & 1;
-          off += (int64_t)(pos[d] + bit) * G.gstride[d];
-        }
-        const int64_t id = idgrid[off];
-        L.id[v] = id;
-        if (id < 0) mode = 1;
+      const int v = tid;
+      int64_t off = 0;
+      for (int d = 0; d < nd; d++) {
+        const int bit = (v >> (nd - 1 - d)) & 1;
+        off += (int64_t)(L.pos[d] + bit) * G.gstride[d];
       }
-      if (mode == 0) {
-        double x[MAXDIM];
-        for (int d = 0; d < nd; d++) {
-          const double *u = uvecs + G.uoff[d];
-          x[d] = (L.mp[d] - u[pos[d]]) / (u[pos[d] + 1] - u[pos[d]]);
-        }
-        for (int v = 0; v < nv; v++) {
-          double w = 1;
-          for (int d = 0; d < nd; d++)
-            w *= ((v >> (nd - 1 - d)) & 1) ? x[d] : (1 - x[d]);
-          L.w[v] = w;
-        }
-      }
+      L.id[v] = idgrid[off];
     }
-    L.mode = mode;
+    if (tid >= 64 && tid < 64 + nd) {
+      const int d = tid - 64;
+      const double *u = uvecs + G.uoff[d];
+      const int p = L.pos[d];
+      L.x[d] = (L.mp[d] - u[p]) / (u[p + 1] - u[p]);
+    }
+    __syncthreads();
+    bool hole = false;
+    for (int v = 0; v < nv; v++)
+      if (L.id[v] < 0) hole = true;
+    if (!hole && tid < nv) {
+      const int v = tid;
+      double w = 1;
+      for (int d = 0; d < nd; d++)
+        w *= ((v >> (nd - 1 - d)) & 1) ? L.x[d] : (1 - L.x[d]);
+      L.w[v] = w;
+    }
+    if (tid == 0) L.mode = hole ? 1 : 0;
+  } else if (tid == 0) {
+    L.mode = finite ? 1 : 2;
   }
   __syncthreads();
   const int mode = L.mode;

@@ -580,16 +580,21 @@ def fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys=0.0):
     return keep
 
 
-def can_fuse_objective(batch, libs, resols=None, fast_interp=False):
+_max_ntp = {}
+
+
+def can_fuse_objective(batch, libs, resols=None, fast_interp=False, npoly=10):
     """the single-kernel objective needs regular-grid libraries on a (log-)uniform
     template grid that fits LDS, and neither resolution matrices nor fast_interp"""
     if fast_interp or not FUSED_OBJECTIVE:
         return False
+    if npoly not in _max_ntp:
+        _max_ntp[npoly] = _lib.lib().rvs_objective_max_ntp(npoly)
     for ia, arm in enumerate(batch.arms):
         lib = libs[arm.name]
         if lib.kind != 'regulargrid' or lib.spline_factors is None:
             return False
-        if 3 * lib.ntp * 8 > 160 * 1024 - 6144:
+        if lib.ntp > _max_ntp[npoly]:
             return False
         if _arm_resol(arm, ia, resols) is not None:
             return False

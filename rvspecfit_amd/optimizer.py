@@ -115,7 +115,8 @@ class ProcessObjective:
         nb = L.rvs_chisq_point_work_size(cap, narm)
         self.scratch = torch.empty((nb + 7) // 8, **f64)
         from . import engine
-        self.fused = engine.can_fuse_objective(batch, libs, resols)
+        self.fused = engine.can_fuse_objective(batch, libs, resols,
+                                               npoly=self.npoly)
         if self.fused:
             self.oarr = (_lib.ObjectiveArm * narm)()
             self._keep = engine.fill_objective_arms(self.oarr, batch, libs,

@@ -371,7 +371,7 @@ def chisq_jobs(batch, idx, vel, params, vsini, options, config,
     esys = float(espec_systematic) if espec_systematic is not None else 0.0
     resols = _resols(batch, resol_params)
     js = idx.to(torch.int32).contiguous()
-    if engine.can_fuse_objective(batch, libs, resols):
+    if engine.can_fuse_objective(batch, libs, resols, npoly=npoly):
         return engine.objective_fused(batch, libs, params, vsini, vel,
                                       npoly=npoly, rbf=rbf, job_spec=js,
                                       espec_sys=esys,

@@ -34,12 +34,28 @@ __global__ void __launch_bounds__(256)
   double mx = 0;
   bool anynan = false;
   if (mode == 0) {
-    for (int k = tid; k < ntp; k += 256) {
+    // four consecutive pixels per thread: one 16-byte load per vertex row (rows
+    // start on 4-byte boundaries only, hence the dword-aligned vector type)
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int n4 = ntp & ~3;
+    for (int k = 4 * tid; k < n4; k += 4 * 256) {
+      double a4[4] = {0, 0, 0, 0};
+      for (int v = 0; v < nv; v++) {
+        const f4u r = *reinterpret_cast<const f4u *>(dats + sh_id[v] * ntp + k);
+        const double wv = sh_w[v];
+        a4[0] = fma(wv, (double)r.x, a4[0]);
+        a4[1] = fma(wv, (double)r.y, a4[1]);
+        a4[2] = fma(wv, (double)r.z, a4[2]);
+        a4[3] = fma(wv, (double)r.w, a4[3]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) out[k + q] = exp_flag ? exp(a4[q]) : a4[q];
+    }
+    for (int k = n4 + tid; k < ntp; k += 256) {
       double acc = 0;
       for (int v = 0; v < nv; v++)
         acc = fma(sh_w[v], (double)dats[sh_id[v] * ntp + k], acc);
-      const double val = exp_flag ? exp(acc) : acc;
-      out[k] = val;
+      out[k] = exp_flag ? exp(acc) : acc;
     }
   } else {
     // FF(self.dats[ret]) on a float32 row: numpy evaluates exp in float32

@@ -50,25 +50,109 @@ __device__ __forceinline__ int block_excl_scan(int flag, int *total,
   return off + pre;
 }
 
-// stable insertion sort of the N+1 vertices by f (NaN last), np.argsort order
-__device__ void nm_order(double *sim, double *f, int N) {
+// stable insertion sort of the N+1 vertices by f (NaN last), np.argsort order.
+// The simplex is pulled into registers first (N is a template parameter, all
+// loops unroll): sorting it in place in global memory is a chain of ~50
+// dependent loads/stores, which made the bookkeeping kernels latency-bound.
+template <int N>
+__device__ void nm_order_t(double *gsim, double *gf) {
+  double s[N + 1][N], f[N + 1];
+#pragma unroll
+  for (int a = 0; a <= N; a++) {
+    f[a] = gf[a];
+#pragma unroll
+    for (int i = 0; i < N; i++) s[a][i] = gsim[a * N + i];
+  }
+#pragma unroll
   for (int a = 1; a <= N; a++) {
     const double fa = f[a];
     const double ka = (fa != fa) ? __builtin_inf() : fa;
-    double xa[NM_MAXN];
-    for (int i = 0; i < N; i++) xa[i] = sim[a * N + i];
-    int b = a - 1;
-    while (b >= 0) {
-      const double fb = f[b];
-      const double kb = (fb != fb) ? __builtin_inf() : fb;
-      if (!(kb > ka)) break;
-      f[b + 1] = fb;
-      for (int i = 0; i < N; i++) sim[(b + 1) * N + i] = sim[b * N + i];
-      b--;
+    double xa[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) xa[i] = s[a][i];
+    bool placed = false;
+#pragma unroll
+    for (int b = a - 1; b >= 0; b--) {
+      if (!placed) {
+        const double fb = f[b];
+        const double kb = (fb != fb) ? __builtin_inf() : fb;
+        if (kb > ka) {
+          f[b + 1] = fb;
+#pragma unroll
+          for (int i = 0; i < N; i++) s[b + 1][i] = s[b][i];
+          if (b == 0) {
+            f[0] = fa;
+#pragma unroll
+            for (int i = 0; i < N; i++) s[0][i] = xa[i];
+            placed = true;
+          }
+        } else {
+          f[b + 1] = fa;
+#pragma unroll
+          for (int i = 0; i < N; i++) s[b + 1][i] = xa[i];
+          placed = true;
+        }
+      }
     }
-    f[b + 1] = fa;
-    for (int i = 0; i < N; i++) sim[(b + 1) * N + i] = xa[i];
   }
+#pragma unroll
+  for (int a = 0; a <= N; a++) {
+    gf[a] = f[a];
+#pragma unroll
+    for (int i = 0; i < N; i++) gsim[a * N + i] = s[a][i];
+  }
+}
+
+__device__ void nm_order(double *sim, double *f, int N) {
+  switch (N) {
+    case 1: nm_order_t<1>(sim, f); break;
+    case 2: nm_order_t<2>(sim, f); break;
+    case 3: nm_order_t<3>(sim, f); break;
+    case 4: nm_order_t<4>(sim, f); break;
+    case 5: nm_order_t<5>(sim, f); break;
+    case 6: nm_order_t<6>(sim, f); break;
+    case 7: nm_order_t<7>(sim, f); break;
+    default: nm_order_t<8>(sim, f); break;
+  }
+}
+
+// termination test and reflection point of one simplex, all loads up front
+// (N compile-time); returns 1 when converged
+template <int N>
+__device__ __forceinline__ int nm_begin_row(const double *__restrict__ gs,
+                                            const double *__restrict__ gf,
+                                            double xatol, double fatol,
+                                            double *xr) {
+  double s[N + 1][N], f[N + 1];
+#pragma unroll
+  for (int k = 0; k <= N; k++) {
+    f[k] = gf[k];
+#pragma unroll
+    for (int i = 0; i < N; i++) s[k][i] = gs[k * N + i];
+  }
+  double dx = 0, df = 0;
+  bool anynan = (f[0] != f[0]);
+#pragma unroll
+  for (int k = 1; k <= N; k++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      dx = fmax(dx, fabs(s[k][i] - s[0][i]));
+      if (s[k][i] != s[k][i] || s[0][i] != s[0][i]) anynan = true;
+    }
+    df = fmax(df, fabs(f[0] - f[k]));
+    if (f[k] != f[k]) anynan = true;
+  }
+  // NaN propagates like np.max: a NaN difference never passes the test
+  if (!anynan && dx <= xatol && df <= fatol) return 1;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double xb = s[0][i];
+#pragma unroll
+    for (int k = 1; k < N; k++) xb = xb + s[k][i];
+    xb = xb / N;
+    xr[i] = (1 + 1.0) * xb - 1.0 * s[N][i];
+  }
+  return 0;
 }
 
 __global__ void __launch_bounds__(NM_NT)
@@ -90,30 +174,21 @@ __global__ void __launch_bounds__(NM_NT)
       if (nit[r] >= maxiter) {
         flags[r] &= ~1;  // scipy: while-condition fails -> warnflag 2
       } else {
-        double dx = 0, df = 0;
-        for (int k = 1; k <= N; k++) {
-          for (int i = 0; i < N; i++)
-            dx = fmax(dx, fabs(s[k * N + i] - s[i]));
-          df = fmax(df, fabs(f[0] - f[k]));
+        int conv = 0;
+        switch (N) {
+          case 1: conv = nm_begin_row<1>(s, f, xatol, fatol, xr); break;
+          case 2: conv = nm_begin_row<2>(s, f, xatol, fatol, xr); break;
+          case 3: conv = nm_begin_row<3>(s, f, xatol, fatol, xr); break;
+          case 4: conv = nm_begin_row<4>(s, f, xatol, fatol, xr); break;
+          case 5: conv = nm_begin_row<5>(s, f, xatol, fatol, xr); break;
+          case 6: conv = nm_begin_row<6>(s, f, xatol, fatol, xr); break;
+          case 7: conv = nm_begin_row<7>(s, f, xatol, fatol, xr); break;
+          default: conv = nm_begin_row<8>(s, f, xatol, fatol, xr); break;
         }
-        // NaN propagates like np.max: a NaN difference never passes the test
-        bool anynan = false;
-        for (int k = 1; k <= N; k++) {
-          if (f[k] != f[k] || f[0] != f[0]) anynan = true;
-          for (int i = 0; i < N; i++)
-            if (s[k * N + i] != s[k * N + i] || s[i] != s[i]) anynan = true;
-        }
-        if (!anynan && dx <= xatol && df <= fatol) {
+        if (conv)
           flags[r] = (flags[r] & ~1) | 2;  // converged: success
-        } else {
+        else
           go = 1;
-          for (int i = 0; i < N; i++) {
-            double xb = s[i];
-            for (int k = 1; k < N; k++) xb = xb + s[k * N + i];
-            xb = xb / N;
-            xr[i] = (1 + 1.0) * xb - 1.0 * s[N * N + i];
-          }
-        }
       }
     }
     int tot;

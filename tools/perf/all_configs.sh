@@ -1,0 +1,23 @@
+#!/bin/bash
+# one bench line per configuration of DESIGN.md section 5 -> gpurun_out/configs_<tag>.jsonl
+tag=${1:-x}
+cd $GRAFT_REPO_ROOT
+out=gpurun_out/configs_$tag.jsonl
+: > $out
+run() { python bench.py "$@" 2>/dev/null | tail -1 >> $out; }
+run --steps 3 --warmup 1
+run --spectra 2000 --ccf-every 9 --steps 3 --warmup 1 --no-cpu-baseline
+run --workload cfg2 --spectra 1000 --steps 5 --warmup 1 --no-cpu-baseline
+run --evaluator nn --steps 3 --warmup 1 --no-cpu-baseline
+run --refine --steps 2 --warmup 1 --no-cpu-baseline
+run --resolution-matrix --steps 2 --warmup 1 --no-cpu-baseline
+run --spectra 2000 --steps 1 --warmup 1 --cpu-sample 8 --process 2000 --process-cpu-sample 8
+run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000 --process-bfgs
+python - <<PY
+import json
+for l in open("$out"):
+    d = json.loads(l)
+    c = d["config"]
+    print(round(d["value"]), d["ms_per_step"], c["spectra_per_gpu"], c["ccf_templates"], c.get("refine"), c.get("resolution_matrix"),
+          d["roofline"]["frac"], d["kernels"].get("template_nn"), (d.get("process") or {}).get("spectra_per_s"))
+PY

@@ -422,8 +422,9 @@ def main():
     # ---- CPU baseline + parity on the sample ---------------------------
     cpu = None
     parity = None
+    # the CPU leg is timed on rank 0 at N = 1 only
     if not args.no_cpu_baseline and EVALUATOR == 'polylinear' and \
-            not args.resolution_matrix:
+            not args.resolution_matrix and world == 1:
         n = min(args.cpu_sample, S)
         cb = run_cpu_baseline(arms, n, args)
         cpu = dict(value=round(cb['n'] / cb['wall'], 3), unit='spectra/s',

@@ -592,6 +592,155 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   }
 }
 
+// ---- the same, window in registers, for a compile-time number of diagonals ----
+template <int P, int ND>
+__global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
+    chisq_grid_resol_reg_kernel(const double *__restrict__ lam,
+                            const double *__restrict__ polysT,
+                            const double *__restrict__ work, int npix, int S,
+                            const double *__restrict__ knots,
+                            const double4 *__restrict__ coef, int ntp,
+                            int log_step, const double *__restrict__ taps,
+                            int nd, int64_t taps_stride,
+                            const int32_t *__restrict__ job_spec,
+                            const int32_t *__restrict__ job_templ,
+                            const double *__restrict__ vels, int64_t vel_stride,
+                            int Nv, const double *__restrict__ penalty,
+                            double badchi, double beta_out,
+                            double *__restrict__ out,
+                            int32_t *__restrict__ status) {
+  const int j = blockIdx.y;
+  const int wave_v0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+  if (wave_v0 >= Nv) return;
+  const int iv = blockIdx.x * 256 + threadIdx.x;
+  const bool active = iv < Nv;
+  const int s = job_spec ? job_spec[j] : j;
+  const int t = job_templ ? job_templ[j] : j;
+  double *outp = out + (int64_t)j * Nv;
+  const double pen = penalty ? penalty[j] : 0.0;
+  if (!(pen == pen) || isinf(pen)) {
+    if (active) {
+      const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
+      outp[iv] = base + 1000.0 * badchi;
+    }
+    return;
+  }
+  const double *pixa = work;
+  const double2 *W = reinterpret_cast<const double2 *>(work + npix) +
+                     (int64_t)s * npix;
+  const double *scal = work + npix + 2ll * S * npix + 2 * s;
+  const double4 *cf = coef + (int64_t)t * ntp;
+  const double *tp = taps + (int64_t)s * taps_stride;
+  const double vel = vels[(int64_t)j * vel_stride + (active ? iv : 0)];
+  const double bb = vel / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double x0 = knots[0], xlast = knots[ntp - 1];
+  const double shift = log_step ? log(f) / log(knots[1] / x0) : 0.0;
+  const double lin_inv_step = log_step ? 0.0 : 1.0 / (knots[1] - x0);
+  int32_t st = 0;
+  {
+    const double xa = lam[0] * f, xb = lam[npix - 1] * f;
+    if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast)
+      st |= RVS_ST_SPLINE_RANGE;
+  }
+  auto raw_at = [&](int p) {
+    const double x = lam[p] * f;
+    int pos = log_step ? (int)(pixa[p] + shift) : (int)((x - x0) * lin_inv_step);
+    pos = min(max(pos, 0), ntp - 2);
+    const double dl = x - knots[pos];
+    const double4 c = cf[pos];
+    return fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
+  };
+  // window of raw values around the current pixel, in REGISTERS: the pixel loop
+  // is unrolled WIN-fold so that every slot index (pixel mod WIN) is a
+  // compile-time constant -- no LDS ring, no moves.  WIN = ND + 1: the value
+  // fetched in an iteration (pixel k + M + 1) is first used in the NEXT one, so
+  // its gather latency hides behind this iteration's ~90 fp64 operations.
+  constexpr int M = (ND - 1) / 2;
+  constexpr int WIN = ND + 1;
+  double win[WIN];
+#pragma unroll
+  for (int d = 0; d < WIN; d++) win[d] = 0.0;
+#pragma unroll
+  for (int p = 0; p <= M; p++)
+    if (p < npix) win[p % WIN] = raw_at(p);
+
+  double acc[P * (P + 1) / 2];
+  double av[P];
+#pragma unroll
+  for (int i = 0; i < P * (P + 1) / 2; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) av[i] = 0;
+  for (int k0 = 0; k0 < npix; k0 += WIN) {
+#pragma unroll
+    for (int j = 0; j < WIN; j++) {
+      const int k = k0 + j;
+      if (k < npix) {  // wave-uniform
+        if (k + M + 1 < npix) win[(j + M + 1) % WIN] = raw_at(k + M + 1);
+        const double *tk = tp + (int64_t)k * ND;
+        double tv = 0;
+#pragma unroll
+        for (int d = 0; d < ND; d++)
+          tv = fma(tk[d], win[(j + WIN - M + d) % WIN], tv);
+        const double2 wk = W[k];
+        const double w = tv * tv * wk.x;
+        const double u = tv * wk.y;
+        const double *pr = polysT + (int64_t)k * P;
+        double pw[P];
+#pragma unroll
+        for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+          av[i] = fma(pr[i], u, av[i]);
+#pragma unroll
+          for (int jj = 0; jj <= i; jj++)
+            acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
+        }
+      }
+    }
+  }
+  bool ok = true;
+  double ldet = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+#pragma unroll
+    for (int jj = 0; jj <= i; jj++) {
+      double sum = acc[TRI(i, jj)];
+#pragma unroll
+      for (int k = 0; k < jj; k++) sum -= acc[TRI(i, k)] * acc[TRI(jj, k)];
+      if (jj == i) {
+        if (!(sum > 0)) ok = false;
+        const double d = sqrt(sum);
+        acc[TRI(i, i)] = d;
+        ldet += log(d);
+      } else {
+        acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
+      }
+    }
+  }
+  double yy = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    double sum = av[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) sum -= acc[TRI(i, k)] * av[k];
+    av[i] = sum / acc[TRI(i, i)];
+    yy = fma(av[i], av[i], yy);
+  }
+  double chi = 2.0 * ldet + 2.0 * scal[0] + (scal[1] - yy);
+  if (st & RVS_ST_SPLINE_RANGE) chi = __builtin_nan("");
+  if (!ok) st |= RVS_ST_CHOL_FALLBACK;
+  if (!ok || !(fabs(chi) <= 1.79e308)) {
+    st |= RVS_ST_NONFINITE;
+    chi = __builtin_nan("");
+  }
+  if (active) {
+    const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
+    outp[iv] = base + chi + pen;
+    if (st) atomicOr(&status[j], st);
+  }
+}
+
 template <int P>
 static int launch_grid(const double *lam, const double *polysT,
                        const double *work, int npix, int S, const double *knots,
@@ -702,11 +851,20 @@ extern "C" int rvs_chisq_grid_resol(
       (void)hipGetLastError();                                                 \
       attr_set = true;                                                         \
     }                                                                          \
-    hipLaunchKernelGGL(chisq_grid_resol_kernel<PP>, grid, dim3(256), shm, st,  \
-                       lam, polysT, work, npix, S, knots,                      \
-                       reinterpret_cast<const double4 *>(coef), ntp, log_step, \
-                       taps, nd, taps_stride, job_spec, job_templ, vels,       \
-                       vel_stride, Nv, penalty, badchi, beta, out, status);    \
+    if (nd == 11)                                                              \
+      hipLaunchKernelGGL((chisq_grid_resol_reg_kernel<PP, 11>), grid,          \
+                         dim3(256), 0, st, lam, polysT, work, npix, S, knots,  \
+                         reinterpret_cast<const double4 *>(coef), ntp,         \
+                         log_step, taps, nd, taps_stride, job_spec, job_templ, \
+                         vels, vel_stride, Nv, penalty, badchi, beta, out,     \
+                         status);                                              \
+    else                                                                       \
+      hipLaunchKernelGGL(chisq_grid_resol_kernel<PP>, grid, dim3(256), shm,    \
+                         st, lam, polysT, work, npix, S, knots,                \
+                         reinterpret_cast<const double4 *>(coef), ntp,         \
+                         log_step, taps, nd, taps_stride, job_spec, job_templ, \
+                         vels, vel_stride, Nv, penalty, badchi, beta, out,     \
+                         status);                                              \
   } break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)

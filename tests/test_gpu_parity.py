@@ -970,3 +970,32 @@ def test_objective_fused(cases, config, tag):
                 sc = max(abs(want), 1e3)
                 assert abs(c1[k].item() - c0[k].item()) < 1e-11 * sc, (i, k)
                 assert abs(c1[k].item() - want) < 1e-6 * sc, (i, c1[k].item())
+
+
+def test_resolution_matrix_grid_nd11(cases, config, gold_libs, gold_config):
+    """11-diagonal matrices (the DESI width) take the register-window variant of
+    the grid kernel; against the oracle's get_chisq on a velocity grid"""
+    from rvspecfit_amd import spec_fit, engine
+    sds = _sds(cases, 'c1')
+    truth = tuple(cases['c1/truth'])
+    sds2, osds = [], []
+    for sd in sds:
+        R = spec_fit.construct_resol_mat(sd.lam, width=0.75)
+        taps, nd = engine.resol_taps([R.mat], len(sd.lam))
+        assert nd == 11
+        sds2.append(spec_fit.SpecData(sd.name, sd.lam, sd.spec, sd.espec,
+                                      badmask=sd.badmask, resolution=R))
+        osds.append(orc.SpecData(sd.name, sd.lam, sd.spec, sd.espec,
+                                 badmask=sd.badmask, resolution=R.mat))
+    vg = np.arange(-400., 0., 7.)
+    b, _ = spec_fit.as_batch(sds2)
+    par = torch.as_tensor(np.array([truth]))[None].to('cuda')
+    chisq, st, _ = spec_fit.chisq_grid_jobs(
+        b, torch.as_tensor(vg).to('cuda'), par,
+        torch.as_tensor([30.], dtype=torch.float64).to('cuda'), dict(npoly=10),
+        config)
+    got = chisq[0, 0].cpu().numpy()
+    want = orc.chisq_grid(osds, vg, [truth], (30., ), dict(npoly=10),
+                          gold_config, gold_libs)[:, 0]
+    np.testing.assert_allclose(got, want, rtol=1e-8)
+    assert int(st.sum().item()) == 0

@@ -59,19 +59,27 @@ def gather_records(rec, S_total, rank=None, world=None):
     return full[:S_total]
 
 
-def fit_sharded(make_batch, S_total, config, options=None, refine=False):
+def fit_sharded(make_batch, S_total, config, options=None, refine=False,
+                process=False):
     """Every rank fits its index block and all ranks receive the full table.
 
     make_batch(lo, hi) -> engine.SpecBatch holding spectra lo..hi-1 on this
-    rank's GPU (the template libraries are replicated per rank)."""
+    rank's GPU (the template libraries are replicated per rank).  process=True
+    appends the optimiser stage (pipeline.process_batch): the gathered record is
+    then [S_total, NREC + NPROC]."""
     from . import pipeline
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     lo, hi = shard_range(S_total, rank, world)
+    width = pipeline.NREC + (pipeline.NPROC if process else 0)
     if hi > lo:
-        rec = pipeline.fit_batch(make_batch(lo, hi), config, options=options,
-                                 refine=refine)
+        batch = make_batch(lo, hi)
+        rec = pipeline.fit_batch(batch, config, options=options, refine=refine)
+        if process:
+            rec = torch.cat([rec, pipeline.process_batch(batch, rec, config,
+                                                         options=options)],
+                            dim=1)
     else:
         dev = 'cuda' if torch.cuda.is_available() else 'cpu'
-        rec = torch.zeros((0, pipeline.NREC), dtype=torch.float64, device=dev)
+        rec = torch.zeros((0, width), dtype=torch.float64, device=dev)
     return gather_records(rec, S_total, rank, world)

@@ -92,6 +92,45 @@ def fit_batch(batch, config, options=None, refine=False, timers=None):
     return rec
 
 
+PROCESS_FIELDS = ('vel', 'vel_err', 'vel_skewness', 'vel_kurtosis', 'vsini',
+                  'teff', 'logg', 'feh', 'alpha', 'teff_err', 'logg_err',
+                  'feh_err', 'alpha_err', 'chisq', 'minimize_success',
+                  'bad_hessian', 'status')
+NPROC = len(PROCESS_FIELDS)
+
+
+def process_batch(batch, rec, config, options=None, fixParam=None, priors=None):
+    """The optimiser stage (vel_fit.process, as desi_fit.py:289-309 calls it)
+    for a batch, started from the CCF parameters of `rec` (fit_batch).  Returns
+    a fixed-size float64 record [S, NPROC] (PROCESS_FIELDS) so that multi-GPU
+    runs gather one tensor, like fit_batch."""
+    options = options or {}
+    S, dev = batch.S, batch.device
+    names = spec_inter.getSpecParams(batch.names[0], config)
+    pd0 = {k: rec[:, 2 + i].contiguous() for i, k in enumerate(names)}
+    vs = rec[:, 6]
+    pd0['vsini'] = torch.where(torch.isfinite(vs), vs,
+                               torch.zeros_like(vs)).contiguous()
+    r = vel_fit.process(batch, pd0, fixParam=fixParam, options=options,
+                        config=config, priors=priors)
+    out = torch.full((S, NPROC), float('nan'), dtype=torch.float64, device=dev)
+    out[:, 0] = r['vel']
+    out[:, 1] = r['vel_err']
+    out[:, 2] = r['vel_skewness']
+    out[:, 3] = r['vel_kurtosis']
+    if 'vsini' in r:
+        out[:, 4] = r['vsini']
+    for i, k in enumerate(('teff', 'logg', 'feh', 'alpha')):
+        if k in r['param']:
+            out[:, 5 + i] = r['param'][k]
+            out[:, 9 + i] = torch.as_tensor(r['param_err'][k]).to(dev)
+    out[:, 13] = r['chisq']
+    out[:, 14] = r['minimize_success'].double()
+    out[:, 15] = torch.as_tensor(r['bad_hessian'].astype(np.float64)).to(dev)
+    out[:, 16] = r['status'].double()
+    return out
+
+
 class _Ev:
 
     def __init__(self, timers):

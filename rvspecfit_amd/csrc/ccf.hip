@@ -50,6 +50,33 @@ __device__ void bitonic_sort(double *v, short *bin, int n2) {
   __syncthreads();
 }
 
+// wave-local bitonic sort of 256 doubles (4 per lane) in a wave-private LDS
+// segment: no block barrier -- the LDS operations of one wave execute in order,
+// the fence only stops the compiler from moving them across a stage
+__device__ void wave_bitonic256(double *v) {
+  const int lane = threadIdx.x & 63;
+  for (int k = 2; k <= 256; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int t = lane + 64 * h;  // pair index 0..127
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int ixj = i | j;
+        const double a = v[i], b = v[ixj];
+        const bool up = ((i & k) == 0);
+        if (up ? (b < a) : (a < b)) {
+          v[i] = b;
+          v[ixj] = a;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // numpy median of the first n sorted values (mean of the middle two if even)
 __device__ __forceinline__ double sorted_median(const double *s, int n) {
   if (n <= 0) return __builtin_nan("");
@@ -71,6 +98,28 @@ __device__ __forceinline__ double median11(double *a) {
   }
   return a[5];
 }
+
+#ifdef RVS_PP_TIMING
+// debug build only (tools/perf/pp_phases.sh): clock budget of the phases
+__device__ unsigned long long pp_dbg[16];
+#define PP_T(i)                                                  \
+  do {                                                           \
+    __syncthreads();                                             \
+    if (threadIdx.x == 0) {                                      \
+      const unsigned long long t_ = wall_clock64();              \
+      atomicAdd(&pp_dbg[i], t_ - t_prev);                        \
+      t_prev = t_;                                               \
+    }                                                            \
+  } while (0)
+extern "C" int rvs_dbg_read_pp(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_dbg), sizeof(pp_dbg)) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}
+#else
+#define PP_T(i)
+#endif
 
 #define CCF_MAXNODE 24
 #ifndef RVS_LM_MAXIT
@@ -252,6 +301,9 @@ __global__ void __launch_bounds__(PP_NT)
   const double *sp0 = spec + (int64_t)b * npix;
   const double *es0 = espec + (int64_t)b * npix;
   const double nanv = __builtin_nan("");
+#ifdef RVS_PP_TIMING
+  unsigned long long t_prev = wall_clock64();
+#endif
 
   for (int k = tid; k < npix; k += PP_NT) {
     cs[k] = sp0[k];
@@ -300,6 +352,7 @@ __global__ void __launch_bounds__(PP_NT)
     }
   }
   __syncthreads();
+  PP_T(0);  // load + nanmedian(espec) sort + medfilt + masks
   // ---- inflate masked errors, fill gaps (interp_masker, make_ccf.py:288-327) --
   {
     int ng = 0, fg = npix, lg = -1;
@@ -356,6 +409,7 @@ __global__ void __launch_bounds__(PP_NT)
     __syncthreads();
   }
 
+  PP_T(1);  // gap filling
   // ---- median of the filled spectrum ----------------------------------------
   {
     for (int k = tid; k < np2; k += PP_NT)
@@ -377,42 +431,73 @@ __global__ void __launch_bounds__(PP_NT)
 
   if (continuum) {
     const int m = nnode;
+    PP_T(2);  // median sort
     // ---- binned medians -> p0 (make_ccf.py:141-143) -------------------------
-    for (int k = tid; k < np2; k += PP_NT) {
-      double v = __builtin_inf();
-      short bn = (short)(m + 1);
-      if (k < npix) {
-        v = cs[k];
-        bn = (short)m;  // outside every bin
-        if (k >= bin_start[0] && k < bin_start[m]) {
-          int lo = 0, hi = m;  // last j with bin_start[j] <= k
-          while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (bin_start[mid] <= k)
-              lo = mid;
-            else
-              hi = mid;
-          }
-          bn = (short)lo;
+    // bins of <= 256 pixels (the usual case: ~140): every wave sorts whole bins
+    // in its own 256-double LDS segment, 16 bins at a time, no block barriers;
+    // otherwise ONE block-wide sort keyed by (bin, value)
+    bool small = true;
+    for (int jb = 0; jb < m; jb++)
+      if (bin_start[jb + 1] - bin_start[jb] > 256) small = false;
+    if (small && np2 >= PP_NW * 256) {
+      const int lane = tid & 63, wv = tid >> 6;
+      double *seg = sb + wv * 256;
+      for (int jb = wv; jb < m; jb += PP_NW) {
+        const int b0 = bin_start[jb], cnt = bin_start[jb + 1] - b0;
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+          const int q = lane + 64 * h;
+          seg[q] = (q < cnt) ? cs[b0 + q] : __builtin_inf();
         }
+        wave_bitonic256(seg);
+        if (lane == 0) {
+          double stat = sorted_median(seg, cnt);
+          double p0 = log(fmax(stat, 1e-3 * S.medspec));
+          if (!(stat == stat)) p0 = nanv;  // np.maximum propagates NaN
+          if (!(fabs(p0) <= 1.79e308)) p0 = log(S.medspec);
+          S.p[jb] = p0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
-      sb[k] = v;
-      binkey[k] = bn;
-    }
-    bitonic_sort<true>(sb, binkey, np2);
-    if (tid < m) {
-      // pixels of bin j sit, sorted, at [bin_start[j], bin_start[j+1]) shifted by
-      // the number of pixels in front of the first bin (they sort to the end)
-      const int s0 = bin_start[tid] - bin_start[0];
-      const int cnt = bin_start[tid + 1] - bin_start[tid];
-      double stat = sorted_median(sb + s0, cnt);
-      double p0 = log(fmax(stat, 1e-3 * S.medspec));
-      if (!(stat == stat)) p0 = nanv;  // np.maximum propagates NaN
-      if (!(fabs(p0) <= 1.79e308)) p0 = log(S.medspec);
-      S.p[tid] = p0;
+    } else {
+      for (int k = tid; k < np2; k += PP_NT) {
+        double v = __builtin_inf();
+        short bn = (short)(m + 1);
+        if (k < npix) {
+          v = cs[k];
+          bn = (short)m;  // outside every bin
+          if (k >= bin_start[0] && k < bin_start[m]) {
+            int lo = 0, hi = m;  // last j with bin_start[j] <= k
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if (bin_start[mid] <= k)
+                lo = mid;
+              else
+                hi = mid;
+            }
+            bn = (short)lo;
+          }
+        }
+        sb[k] = v;
+        binkey[k] = bn;
+      }
+      bitonic_sort<true>(sb, binkey, np2);
+      if (tid < m) {
+        // pixels of bin j sit, sorted, at [bin_start[j], bin_start[j+1]) shifted by
+        // the number of pixels in front of the first bin (they sort to the end)
+        const int s0 = bin_start[tid] - bin_start[0];
+        const int cnt = bin_start[tid + 1] - bin_start[tid];
+        double stat = sorted_median(sb + s0, cnt);
+        double p0 = log(fmax(stat, 1e-3 * S.medspec));
+        if (!(stat == stat)) p0 = nanv;  // np.maximum propagates NaN
+        if (!(fabs(p0) <= 1.79e308)) p0 = log(S.medspec);
+        S.p[tid] = p0;
+      }
     }
     __syncthreads();
 
+    PP_T(3);  // binned-median sort
     // ---- Levenberg-Marquardt on the soft-L1 objective -----------------------
     // unknowns: the B-spline coefficients c = C^-1 p of the interpolating spline
     // (a linear bijection of the reference's node values p, same minimum)
@@ -468,6 +553,7 @@ __global__ void __launch_bounds__(PP_NT)
     }
   }
 
+  PP_T(4);  // LM
   // ---- normalise (make_ccf.py:380-392) ----------------------------------------
   for (int k = tid; k < npix; k += PP_NT) {
     double cont = 1.0;
@@ -495,6 +581,7 @@ __global__ void __launch_bounds__(PP_NT)
     sb[k] = iv;  // its inverse variance
   }
   __syncthreads();
+  PP_T(5);  // normalise
   // ---- rebin to the FFT grid (make_ccf.py:394-409) -----------------------------
   double ss = 0;
   for (int n = tid; n < nfft; n += PP_NT) {
@@ -515,6 +602,7 @@ __global__ void __launch_bounds__(PP_NT)
     sse[b] = ss;
     if (S.flag && status) atomicOr(&status[b], S.flag);
   }
+  PP_T(6);  // rebin
 }
 
 static inline int next_pow2(int n) {

@@ -360,6 +360,13 @@ int rvs_ccf_preprocess(const double *lam, const double *spec,
  * ilo int32 [nvel], vgrid float64 [nvel]        linear-interp tables
  * chisq [B, T, nvel]: out = beta*out + interp(-2 c0 + c1) (continuum) or
  *                      interp(-c0^2/c1)
+ * prune uint8 [n2/64 + n2/8], n2 = nfft/2 (nullable; used when n2 is a power of
+ *         8): only the lags in lag_pos are read back, so the last two radix-8
+ *         passes compute selected outputs only.  With p as above,
+ *         prune[n2/64 + (p>>3)] has bit (p&7) set for every needed p, and
+ *         prune[p>>6] has bit ((p>>3)&7) set (the outputs of the second-last
+ *         pass that feed a needed 8-group).  Values are bit-identical to the
+ *         unpruned transform.
  * work  complex128 [B, 2, nfft/2+1] scratch for conj rfft of spec*ivar, ivar
  * ---------------------------------------------------------------------- */
 int rvs_ccf_fft_pos(int nfft, int f);  /* host helper, see lag_pos */
@@ -367,8 +374,9 @@ int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar, int nfft,
                   int B, const double *tfft, const double *tfft2, int T,
                   const double *twid, int continuum, const int32_t *lag_pos,
                   const double *lag_vel, int nlag, const int32_t *ilo,
-                  const double *vgrid, int nvel, double beta, double *chisq,
-                  double *work, void *stream);
+                  const double *vgrid, int nvel, double beta,
+                  const uint8_t *prune, double *chisq, double *work,
+                  void *stream);
 
 /* argmin over (template, velocity) + 3-point parabola (fitter_ccf.py:218-236).
  * sse [B] is added to every entry (total_sse).  res [B,4] = best_id, best_vel,

@@ -57,7 +57,7 @@ SIGNATURES = {
                                P, P, P, P, P, P, P]),
     'rvs_ccf_fft_pos': (I, [I, I]),
     'rvs_ccf_xcorr': (I, [P, P, I, I, P, P, I, P, I, P, P, I, P, P, I, D, P, P,
-                          P]),
+                          P, P]),
     'rvs_ccf_select': (I, [P, P, I, I, I, P, I, P, P, P, P]),
     'rvs_template_nn': (I, [P, I, I, U, P, P, I, P, P, P, P, P, P, P]),
 }

@@ -117,11 +117,21 @@ __device__ __forceinline__ double2 twid(const double2 *__restrict__ tw, int e,
 }
 
 // in-place DIF transform of the padded LDS image a[] (n2 points)
+// prune (nullable): output masks for the LAST TWO passes when both are radix 8
+// (n2 a power of 8).  Only ~100 of the n2 outputs of the inverse transform are
+// ever read (the lags inside +-max_vel), so
+//   pass np-2: prune[blk]          bit q set -> output q of every butterfly of
+//              64-block blk is needed (the others are neither twiddled nor
+//              stored: 1-2 writes and twiddles instead of 8 and 7),
+//   pass np-1: prune[n2/64 + grp]  bit q set -> output q of 8-group grp is needed
+//              (groups with an empty mask are skipped: ~64 of 512 remain).
 template <int SIGN, int NT>
-__device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw) {
+__device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
+                        const uint8_t *__restrict__ prune = nullptr) {
   const int n2 = 1 << log2n, nfft = n2 << 1;
   int rad[8];
   const int np = xc_plan(log2n, rad);
+  const bool pr = prune && np >= 2 && rad[np - 1] == 8 && rad[np - 2] == 8;
   int M = n2;
   for (int p = 0; p < np; p++) {
     const int R = rad[p], Mp = M / R;
@@ -129,6 +139,42 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw) {
     for (int u = threadIdx.x; u < n2 / R; u += NT) {
       const int blk = u / Mp, r = u - blk * Mp;
       const int base = blk * M + r;
+      if (pr && p == np - 2) {  // M = 64, Mp = 8: selected outputs only
+        const unsigned mask = prune[blk];
+        if (mask == 0) continue;
+        double2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = a[XC_PAD(base + Mp * j)];
+        dft8<SIGN>(v);
+        // the same product tree for the twiddle powers as the full pass, so
+        // the stored values are bit-identical to it
+        double2 wp[8];
+        wp[0] = make_double2(1.0, 0.0);
+        wp[1] = twid<SIGN>(tw, r * (nfft / M), nfft);
+        wp[2] = cmul(wp[1], wp[1]);
+        wp[3] = cmul(wp[2], wp[1]);
+        wp[4] = cmul(wp[2], wp[2]);
+        wp[7] = cmul(wp[4], wp[3]);
+        wp[5] = cmul(wp[4], wp[1]);
+        wp[6] = cmul(wp[4], wp[2]);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (mask & (1u << q))
+            a[XC_PAD(base + Mp * q)] = (q == 0) ? v[0] : cmul(v[q], wp[q]);
+        continue;
+      }
+      if (pr && p == np - 1) {  // M = 8, Mp = 1: no twiddles
+        const unsigned mask = prune[(n2 >> 6) + u];
+        if (mask == 0) continue;
+        double2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = a[XC_PAD(base + j)];
+        dft8<SIGN>(v);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (mask & (1u << q)) a[XC_PAD(base + q)] = v[q];
+        continue;
+      }
       if (R == 8) {
         double2 v[8];
 #pragma unroll
@@ -251,6 +297,7 @@ __global__ void __launch_bounds__(XB_NT)
                      const double *__restrict__ lag_vel, int nlag,
                      const int32_t *__restrict__ ilo,
                      const double *__restrict__ vgrid, int nvel, double beta,
+                     const uint8_t *__restrict__ prune,
                      double *__restrict__ chisq) {
   extern __shared__ double2 fa[];
   const int n2 = nfft >> 1, npair = n2 >> 1;
@@ -291,7 +338,7 @@ __global__ void __launch_bounds__(XB_NT)
         if (m != k) fa[XC_PAD(m)] = make_double2(e.x + q.y, -e.y + q.x);
       }
     }
-    fft_lds<1, XB_NT>(fa, log2n, tw);
+    fft_lds<1, XB_NT>(fa, log2n, tw, prune);
     const double *fr = reinterpret_cast<const double *>(fa);
     double *dst = (pass == 0) ? c0 : c1;
     for (int l = tid; l < nlag; l += XB_NT) dst[l] = fr[lag_pos[l]] * inv_n;
@@ -317,7 +364,8 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
                              int continuum, const int32_t *lag_pos,
                              const double *lag_vel, int nlag, const int32_t *ilo,
                              const double *vgrid, int nvel, double beta,
-                             double *chisq, double *work, void *stream) {
+                             const uint8_t *prune, double *chisq, double *work,
+                             void *stream) {
   int log2n = 0;
   while ((2 << log2n) < nfft) log2n++;
   if ((2 << log2n) != nfft || nfft < 64 || nfft > 16384) return RVS_E_ARG;
@@ -350,7 +398,8 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
         reinterpret_cast<const double2 *>(work) + (int64_t)b0 * 2 * (n2 + 1),
         nfft, log2n, reinterpret_cast<const double2 *>(tfft),
         reinterpret_cast<const double2 *>(tfft2), T, tw, continuum, lag_pos,
-        lag_vel, nlag, ilo, vgrid, nvel, beta, chisq + (int64_t)b0 * T * nvel);
+        lag_vel, nlag, ilo, vgrid, nvel, beta, prune,
+        chisq + (int64_t)b0 * T * nvel);
     RVS_LAUNCH_CHECK();
   }
   return 0;

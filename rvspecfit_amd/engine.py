@@ -234,6 +234,17 @@ class ArmData:
                        dtype=np.int64)
         T['lag_pos'] = torch.as_tensor(
             (2 * (pos + (pos >> 3)) + (ind & 1)).astype(np.int32)).to(dev)
+        # output masks of the last two radix-8 passes (rvs_ccf_xcorr `prune`):
+        # only these lags are read back from the inverse transform
+        n2 = nfft // 2
+        T['prune'] = None
+        l2 = n2.bit_length() - 1
+        if (1 << l2) == n2 and l2 % 3 == 0 and l2 >= 6 and XCORR_PRUNE:
+            pm = np.zeros(n2 // 64 + n2 // 8, dtype=np.uint8)
+            for p_ in pos:
+                pm[n2 // 64 + (int(p_) >> 3)] |= 1 << (int(p_) & 7)
+                pm[int(p_) >> 6] |= 1 << ((int(p_) >> 3) & 7)
+            T['prune'] = torch.as_tensor(pm).to(dev)
         T['lag_vel'] = torch.as_tensor(sub).to(dev)
         T['nlag'] = len(ind)
         T['ilo'] = torch.as_tensor(ccf_tables.interp_tables(sub, vgrid)).to(dev)
@@ -368,6 +379,7 @@ def convolve_vsini(lib_or_lam, templ, vsini, eps=0.6):
 # --------------------------------------------------------------------------
 # chi^2 grid over velocities: A7-eval + A10 + A11 (+ penalties of A11)
 # --------------------------------------------------------------------------
+XCORR_PRUNE = True     # prune the last two FFT passes to the lags that are read
 CG_WMAX = 512          # knots per LDS window of chisq_grid_lds_kernel
 import os as _os
 # chi^2-grid kernel variant: 'plain' (default) gathers the spline records
@@ -838,8 +850,8 @@ def ccf_fit(batch, libs, config, keep_all=False, max_chunk=None):
                 _lib.ptr(T['twid']), int(cc['continuum']),
                 _lib.ptr(T['lag_pos']), _lib.ptr(T['lag_vel']), T['nlag'],
                 _lib.ptr(T['ilo']), _lib.ptr(T['vgrid']), nvel,
-                0.0 if ia == 0 else 1.0, _lib.ptr(acc), _lib.ptr(work),
-                _lib.stream())
+                0.0 if ia == 0 else 1.0, _lib.ptr(T['prune']), _lib.ptr(acc),
+                _lib.ptr(work), _lib.stream())
             _lib.check(rc, 'rvs_ccf_xcorr')
         sse_c = sse[:, a:b].contiguous()
         rc = L.rvs_ccf_select(_lib.ptr(acc), _lib.ptr(sse_c), len(batch.arms),

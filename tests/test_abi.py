@@ -52,7 +52,7 @@ def test_argument_validation_without_gpu(lib):
                               None, None, 1, None, 0, 4, None, 0., 0., 0, None,
                               None, None) == -1
     assert lib.rvs_ccf_xcorr(None, None, 1000, 1, None, None, 1, None, 1, None,
-                             None, 5, None, None, 5, 0., None, None,
+                             None, 5, None, None, 5, 0., None, None, None,
                              None) == -1   # nfft not a power of two
     k3 = np.array([1.0, 2.0, 4.1])
     assert lib.rvs_chisq_prepare(None, None, None, 10, 1, k3.ctypes.data, 1, 0.,

@@ -1,0 +1,1120 @@
+"""DESI survey driver: ingestion, conditioning, warning bits and the rvtab/rvmod
+products -- mirror of py/rvspecfit/desi/desi_fit.py, with the per-fibre
+`poolex.submit(proc_onespec, ...)` loop (desi_fit.py:1176-1217) replaced by ONE
+batched call per file: every selected fibre of a coadd/spectra file is
+conditioned on the host, uploaded once, and fitted in lock-step on the GPU
+(fitter_ccf.fit -> vel_fit.process -> spec_fit.get_chisq_continuum on a
+SpecBatch).
+
+What is restated here (reference lines in each docstring):
+  bitmasks, get_rvs_warn            the RVS_WARN bits
+  get_sns, fiberstatus_select,
+  select_fibers_to_fit              fibre selection
+  interpolate_bad_regions,
+  get_specdata(_batch)              masking / sigma-clamping rules
+  resolution_mat_*, deconvolve_*,
+  construct_resolution_sparse_matrix  DESI resolution data -> banded matrix
+  get_column_desc, get_prim_header,
+  proc_onespec, proc_desi, proc_desi_wrapper, proc_many
+                                    the RVTAB / RVMOD schema and files
+
+File I/O goes through fits_min (astropy is not part of the image).  Outside
+the path and not built: the argparse front end (`main`), plots (`make_plot`;
+doplot is accepted and ignored with a warning), the desitarget object-type
+filter (the reference ignores `objtypes` itself when desitarget is missing,
+desi_fit.py:584-587, 617-623 -- so does this module, always).
+
+Arithmetic note: the flux/ivar images are float32 and the reference conditions
+them with numpy expressions whose result types depend on numpy's scalar
+promotion rules.  The golden vectors were produced with numpy 1.26 (legacy
+value-based casting); the casts are written out explicitly below so that the
+result is the same under numpy 2.
+"""
+import enum
+import logging
+import os
+import sys
+import time
+import traceback
+import warnings
+
+import numpy as np
+import scipy.linalg
+import scipy.sparse
+
+from .. import fits_min as pyfits
+from .. import spec_fit, spec_inter, utils
+
+
+class ProcessStatus(enum.Enum):
+    SUCCESS = 0
+    FAILURE = 1
+    EXISTING = 2
+
+    def __str__(self):
+        return self.name
+
+
+class GlobalConfig:
+    table_prefix = 'rvtab'
+    model_prefix = 'rvmod'
+
+
+DEPEND_PACKAGES = ['numpy', 'scipy', 'torch', 'pyyaml']
+
+# desi_fit.py:50-58
+bitmasks = {
+    'CHISQ_WARN': 1,  # delta chi-square vs continuum is too small
+    'RV_WARN': 2,  # rv is too close to the edge
+    'RVERR_WARN': 4,  # RV error is too large
+    'PARAM_WARN': 8,  # parameters are too close to the edge
+    'VSINI_WARN': 16,  # vsini is too large
+    'BAD_SPECTRUM': 32,  # some issue with the spectrum
+    'BAD_HESSIAN': 64  # issue with the hessian matrix
+}
+
+# units the reference attaches through astropy.units (desi_fit.py:312-330, 353)
+COLUMN_UNITS = {
+    'VRAD': 'km s-1', 'VRAD_ERR': 'km s-1', 'VSINI': 'km s-1',
+    'VRAD_CCF': 'km s-1', 'TEFF': 'K', 'TEFF_ERR': 'K'
+}
+INT_NULL = 999999  # astropy's fill value for masked integer cells
+
+
+def update_process_status_file(status_fname, processed_file, status, nobjects,
+                               time_sec, start=False):
+    """desi_fit.py:61-74"""
+    if start:
+        with open(status_fname, 'w'):
+            pass
+        if processed_file is None:
+            return
+    with open(status_fname, 'a') as fp:
+        print(f'{processed_file} {status} {nobjects} {time_sec:.2f}', file=fp)
+
+
+def get_dep_versions():
+    """desi_fit.py:77-90"""
+    from importlib.metadata import version, PackageNotFoundError
+    ret = {}
+    for curp in DEPEND_PACKAGES:
+        try:
+            ret[curp] = version(curp)
+        except (ImportError, PackageNotFoundError):
+            pass
+    from .. import __version__ as v
+    ret['rvspecfit_amd'] = v
+    ret['python'] = str.split(sys.version, ' ')[0]
+    return ret
+
+
+def get_zbest_fname(fname):
+    """desi_fit.py:93-116: the redrock/zbest file next to a coadd-/spectra- file"""
+    paths = fname.split('/')
+    fname_end = paths[-1]
+    if fname_end[-3:] == '.gz':
+        fname_end = fname_end[:-3]
+    not_found = (None, None)
+    for curpref in ('coadd-', 'spectra-'):
+        if fname_end[:len(curpref)] == curpref:
+            break
+    else:
+        return not_found
+    for cur_zpref, cur_ext in zip(('redrock-', 'zbest-'),
+                                  ('REDSHIFTS', 'ZBEST')):
+        f1 = fname_end.replace(curpref, cur_zpref)
+        for postf in ('', '.gz'):
+            zbest_path = '/'.join(paths[:-1] + [f1]) + postf
+            if os.path.exists(zbest_path):
+                return zbest_path, cur_ext
+    return not_found
+
+
+def get_prim_header(versions=None, config=None, cmdline=None,
+                    spectrum_header=None, zbest_path=None):
+    """desi_fit.py:119-156"""
+    header = pyfits.Header()
+    for i, (k, v) in enumerate(get_dep_versions().items()):
+        header['DEPNAM%02d' % i] = (k, 'Software')
+        header['DEPVER%02d' % i] = (v, 'Version')
+    for i, (k, v) in enumerate((versions or {}).items()):
+        header['TMPLCON%d' % i] = (k, 'Spec arm config name')
+        header['TMPLREV%d' % i] = (v['revision'], 'Spec template revision')
+        header['TMPLSVR%d' % i] = (v['creation_soft_version'],
+                                   'Spec template soft version')
+    if config is not None:
+        header['RVS_CONF'] = config['config_file_path']
+    if cmdline is not None:
+        header['RVS_CMD'] = cmdline
+    header['RR_FILE'] = (zbest_path or '', 'Redrock redshift file')
+    copy_keys = [
+        'SPGRP', 'SPGRPVAL', 'TILEID', 'SPECTRO', 'PETAL', 'NIGHT', 'EXPID',
+        'HPXPIXEL', 'HPXNSIDE', 'HPXNEST'
+    ]
+    if spectrum_header is not None:
+        for key in copy_keys:
+            if key in spectrum_header:
+                header[key] = spectrum_header[key]
+    return header
+
+
+def valid_file(FP):
+    """desi_fit.py:225-245"""
+    extnames = [_.name for _ in FP]
+    reqnames = ['%s_%s' % (a, p) for a in ('B', 'R', 'Z')
+                for p in ('WAVELENGTH', 'FLUX', 'IVAR', 'MASK')] + ['FIBERMAP']
+    missing = [_ for _ in reqnames if _ not in extnames]
+    if missing:
+        logging.warning('Extensions %s are missing' % (','.join(missing)))
+        return False
+    return True
+
+
+# ------------------------------------------------------------- warning bits
+def _bad_edge_check(value, edges, threshold):
+    """desi_fit.py:433-441 (elementwise)"""
+    return (value < edges[0] + threshold) | (value > edges[1] - threshold)
+
+
+def rvs_warn_bits(chisq_tot, chisq_c_tot, vrad, vsini, vrad_err, bad_hessian,
+                  teff, feh, logg, config):
+    """get_rvs_warn (desi_fit.py:381-430) on arrays: int64 [n]."""
+    chisq_tot = np.asarray(chisq_tot, dtype=np.float64)
+    w = np.zeros(chisq_tot.shape, dtype=np.int64)
+    dchisq = np.asarray(chisq_c_tot, dtype=np.float64) - chisq_tot
+    w[dchisq < 50] |= bitmasks['CHISQ_WARN']
+    w[_bad_edge_check(np.asarray(vrad), [config['min_vel'], config['max_vel']],
+                      5)] |= bitmasks['RV_WARN']
+    w[np.asarray(vsini) > 100] |= bitmasks['VSINI_WARN']
+    w[np.asarray(vrad_err) > 100] |= bitmasks['RVERR_WARN']
+    w[np.asarray(bad_hessian, dtype=bool)] |= bitmasks['BAD_HESSIAN']
+    for val, edges, thresh in ((teff, [2300, 15000], 10), (feh, [-4, 1], 0.01),
+                               (logg, [-.5, 6.5], 0.01)):
+        w[_bad_edge_check(np.asarray(val), edges, thresh)] |= \
+            bitmasks['PARAM_WARN']
+    return w
+
+
+def get_rvs_warn(fit_res, outdict, config):
+    """desi_fit.py:381-430 for one fit (plain floats instead of Quantities)."""
+    p = fit_res['param']
+    return int(rvs_warn_bits([outdict['CHISQ_TOT']], [outdict['CHISQ_C_TOT']],
+                             [outdict['VRAD']], [outdict['VSINI']],
+                             [outdict['VRAD_ERR']], [fit_res['bad_hessian']],
+                             [p['teff']], [p['feh']], [p['logg']], config)[0])
+
+
+# --------------------------------------------------------- fibre selection
+def get_sns(data, ivars, masks):
+    """desi_fit.py:444-456: vector of per-fibre median S/N"""
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        xind = (ivars <= 0) | (masks > 0)
+        xsn = data * np.sqrt(ivars)
+        xsn[xind] = np.nan
+        sns = np.nanmedian(xsn, axis=1)
+        sns[~np.isfinite(sns)] = -1e9
+    return sns
+
+
+def read_data(FP, setups):
+    """desi_fit.py:459-492"""
+    fluxes, ivars, waves, masks, resolutions = {}, {}, {}, {}, {}
+    for s in setups:
+        S = s.upper()
+        fluxes[s] = FP['%s_FLUX' % S].data
+        ivars[s] = FP['%s_IVAR' % S].data
+        masks[s] = FP['%s_MASK' % S].data
+        waves[s] = FP['%s_WAVELENGTH' % S].data
+        resolutions[s] = FP['%s_RESOLUTION' % S].data \
+            if ('%s_RESOLUTION' % S) in FP else None
+    return fluxes, ivars, masks, waves, resolutions
+
+
+def fiberstatus_select(fibermap):
+    """desi_fit.py:524-543: only RESTRICTED (3) | VARIABLE (20) bits allowed"""
+    good_fiberstatus = int(np.sum(1 << np.array([3, 20], dtype=int)))
+    names = fibermap.columns.names
+    if 'FIBERSTATUS' in names:
+        col = fibermap['FIBERSTATUS']
+    elif 'COADD_FIBERSTATUS' in names:
+        col = fibermap['COADD_FIBERSTATUS']
+    else:
+        raise Exception('Fiberstatus column not found')
+    return (col & good_fiberstatus) == col
+
+
+def select_fibers_to_fit(fibermap, sns, zbest_path=None, zbest_ext=None,
+                         minsn=None, objtypes=None, expid_range=None,
+                         fit_targetid=None, zbest_select=False,
+                         zbest_include=False):
+    """desi_fit.py:546-679.  Returns (subset, rr_z, rr_spectype, rr_subtype)."""
+    zbest_maxvel = 1500
+    zbest_type = 'STAR'
+    n = len(fibermap)
+    subset = np.ones(n, dtype=bool)
+    mine, maxe = -1, np.inf
+    if expid_range is not None:
+        mine, maxe = expid_range
+        mine = -1 if mine is None else mine
+        maxe = np.inf if maxe is None else maxe
+    if 'EXPID' in fibermap.columns.names:
+        subset = subset & (fibermap['EXPID'] > mine) & (fibermap['EXPID']
+                                                        <= maxe)
+    subset = subset & fiberstatus_select(fibermap)
+    subset = subset & (fibermap['OBJTYPE'] != 'SKY') & (fibermap['OBJTYPE']
+                                                        != 'BAD')
+    if fit_targetid is not None:
+        subset = subset & np.isin(fibermap['TARGETID'], fit_targetid)
+    if minsn is not None:
+        maxsn = np.max(np.array(list(sns.values())), axis=0)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            subset = subset & (maxsn > minsn)
+    # no desitarget: never selecting by type (see the module docstring)
+    types_subset = np.zeros(n, dtype=bool)
+    selecting_by_type = False
+    selecting_by_zbest = False
+    rr_z = rr_spectype = rr_subtype = None
+    zbest_subset = None
+    if zbest_select or zbest_include:
+        if zbest_path is None:
+            logging.warning(
+                'zbest selection requested, but the zbest file not found')
+        else:
+            if zbest_select:
+                selecting_by_zbest = True
+            logging.info('Using redshift file %s', zbest_path)
+            zb = pyfits.open(zbest_path)[zbest_ext].data
+            rr_spectype = zb['SPECTYPE']
+            rr_subtype = zb['SUBTYPE']
+            rr_z = zb['Z']
+            zbest_subset = ((rr_spectype == zbest_type) |
+                            ((np.abs(rr_z)) < zbest_maxvel / 3e5))
+            if len(zb) == n:
+                assert np.all(zb['TARGETID'] == fibermap['TARGETID'])
+            else:
+                # match by id (spectra- file with a coadd redshift file)
+                order = {int(t): i for i, t in enumerate(zb['TARGETID'])}
+                zbest_subset = np.isin(fibermap['TARGETID'],
+                                       zb['TARGETID'][zbest_subset])
+                pos = np.array([order.get(int(t), -1)
+                                for t in fibermap['TARGETID']])
+                hit = pos >= 0
+                z2 = np.zeros(n, dtype=rr_z.dtype) + np.nan
+                st2 = np.zeros(n, dtype=rr_spectype.dtype)
+                sub2 = np.zeros(n, dtype=rr_subtype.dtype)
+                z2[hit] = rr_z[pos[hit]]
+                st2[hit] = rr_spectype[pos[hit]]
+                sub2[hit] = rr_subtype[pos[hit]]
+                rr_z, rr_spectype, rr_subtype = z2, st2, sub2
+    if not selecting_by_zbest:
+        zbest_subset = np.zeros(n, dtype=bool)
+    if selecting_by_zbest or selecting_by_type:
+        subset = subset & (zbest_subset | types_subset)
+    return subset, rr_z, rr_spectype, rr_subtype
+
+
+# ------------------------------------------------------ resolution matrices
+def resolution_mat_torows(mat):
+    """desi_fit.py:682-685: [w, npix] DESI column band -> rows;
+    out[r, j] = R[j, j + r - w//2] (np.roll wrap-around at the two ends)"""
+    w = mat.shape[0]
+    w2 = w // 2
+    return np.array([np.roll(mat[_], _ - w2) for _ in range(w)])[::-1]
+
+
+def resolution_mat_tocolumns(mat):
+    """desi_fit.py:688-691: inverse of resolution_mat_torows"""
+    w = mat.shape[0]
+    w2 = w // 2
+    return np.array([np.roll(mat[::-1][_], w2 - _) for _ in range(w)])
+
+
+def _gau_mat(width, sigma0_angstrom, pix_size_angstrom):
+    sig_pix = sigma0_angstrom / pix_size_angstrom
+    xs = np.arange(width)
+    return np.array([
+        1. / np.sqrt(2 * np.pi) / sig_pix * np.exp(-0.5 *
+                                                   ((xs - i) / sig_pix)**2)
+        for i in range(len(xs))
+    ])
+
+
+def deconvolve_resolution_matrix(mat0, sigma0_angstrom=0.5,
+                                 pix_size_angstrom=0.8):
+    """desi_fit.py:694-720: take the template LSF (Gaussian sigma0) out of the
+    DESI resolution band, row by row"""
+    width, npix = mat0.shape
+    gau_mat = _gau_mat(width, sigma0_angstrom, pix_size_angstrom)
+    w2 = width // 2
+    mat_rows = resolution_mat_torows(mat0)
+    for i in range(w2):
+        mat_rows[:w2 - i - 1, i] = 0
+        j = npix - 1 - i
+        mat_rows[w2 + 1 + i:, j] = 0
+    mat_rows1 = scipy.linalg.solve(gau_mat, mat_rows)
+    return resolution_mat_tocolumns(mat_rows1)
+
+
+def _renormalise_rows(mat_rows):
+    """the edge renormalisation of desi_fit.py:735-745 on [..., w, npix] rows"""
+    w, npix = mat_rows.shape[-2:]
+    w2 = w // 2
+    mult = np.median(mat_rows.sum(axis=-2), axis=-1)
+    mult = np.where(mult == 0, 1, mult)
+    for i in range(w2):
+        N1 = mat_rows[..., w2 - i:, i].sum(axis=-1)
+        mat_rows[..., :, i] = mat_rows[..., :, i] / (
+            N1 + (N1 == 0))[..., None] * mult[..., None]
+        j = npix - 1 - i
+        N2 = mat_rows[..., :w2 + 1 + i, j].sum(axis=-1)
+        mat_rows[..., :, j] = mat_rows[..., :, j] / (
+            N2 + (N2 == 0))[..., None] * mult[..., None]
+    return mat_rows
+
+
+def construct_resolution_sparse_matrix(mat, pix_size_angstrom=None,
+                                       sigma0_angstrom=None):
+    """desi_fit.py:723-748: scipy dia_matrix [npix, npix]"""
+    width, npix = mat.shape
+    w2 = width // 2
+    mat = deconvolve_resolution_matrix(mat.copy(),
+                                       pix_size_angstrom=pix_size_angstrom,
+                                       sigma0_angstrom=sigma0_angstrom)
+    mat_rows = _renormalise_rows(resolution_mat_torows(mat))
+    mat = resolution_mat_tocolumns(mat_rows)
+    return scipy.sparse.dia_matrix((mat, np.arange(w2, -w2 - 1, -1)),
+                                   (npix, npix))
+
+
+def resolution_row_taps(mats, pix_size_angstrom, sigma0_angstrom):
+    """construct_resolution_sparse_matrix for a stack of fibres, straight into
+    the row-tap layout of the kernels (engine.resol_taps):
+    mats [n, w, npix] -> taps float64 [n, npix, w], taps[s, k, d] = R_s[k, k-w2+d]
+    (entries that fall outside the matrix are zero, as in the dia matrix)."""
+    mats = np.asarray(mats)
+    n, w, npix = mats.shape
+    w2 = w // 2
+    # torows for the stack: rows[:, r, j] = mats[:, w-1-r, j + r - w2] (wrapped)
+    rows = np.stack([np.roll(mats[:, w - 1 - r], (w - 1 - r) - w2, axis=-1)
+                     for r in range(w)], axis=1)
+    for i in range(w2):
+        rows[:, :w2 - i - 1, i] = 0
+        rows[:, w2 + 1 + i:, npix - 1 - i] = 0
+    gau = _gau_mat(w, sigma0_angstrom, pix_size_angstrom)
+    rows = np.linalg.solve(gau[None], rows.astype(np.float64))
+    # the reference goes rows -> columns -> rows between the two steps; the
+    # round trip is the identity (pure index shuffles)
+    rows = _renormalise_rows(rows)
+    taps = np.ascontiguousarray(np.swapaxes(rows, 1, 2))
+    k = np.arange(npix)[:, None] + np.arange(-w2, w2 + 1)[None, :]
+    taps[:, (k < 0) | (k >= npix)] = 0
+    return taps
+
+
+# ------------------------------------------------------------ conditioning
+def interpolate_bad_regions(spec, mask):
+    """desi_fit.py:751-778: linear interpolation over masked runs, constant
+    continuation at the two ends (one spectrum)"""
+    spec = np.asarray(spec)
+    return _interp_bad_rows(spec[None, :], np.asarray(mask, dtype=bool)[None, :])[0]
+
+
+def _interp_bad_rows(spec, mask):
+    """interpolate_bad_regions on rows [n, npix]; dtype of `spec` is kept
+    (np.interp works in float64 and the result is stored back)."""
+    n, npix = spec.shape
+    out = spec * 1
+    idx = np.arange(npix)[None, :]
+    good = ~mask
+    prev = np.maximum.accumulate(np.where(good, idx, -1), axis=1)
+    nxt = np.minimum.accumulate(np.where(good, idx, npix)[:, ::-1],
+                                axis=1)[:, ::-1]
+    rr, cc = np.nonzero(mask & good.any(axis=1)[:, None])
+    if len(rr) == 0:
+        return out
+    L, R = prev[rr, cc], nxt[rr, cc]
+    Lc, Rc = np.maximum(L, 0), np.minimum(R, npix - 1)
+    yl = spec[rr, Lc].astype(np.float64)
+    yr = spec[rr, Rc].astype(np.float64)
+    with np.errstate(all='ignore'):
+        slope = (yr - yl) / (Rc - Lc).astype(np.float64)
+        mid = slope * (cc - Lc).astype(np.float64) + yl  # numpy's interp formula
+    val = np.where(L < 0, yr, np.where(R >= npix, yl, mid))
+    out[rr, cc] = val.astype(out.dtype)
+    return out
+
+
+LARGE_ERROR = 1000  # sets the error of masked pixels
+MINERR_FRAC = 0.3  # errors below this times the median are clamped
+
+
+def _medspec(spec, badmask):
+    """median flux of one arm with the fall-backs of desi_fit.py:833-843;
+    None when the arm has to be skipped"""
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if badmask.all():
+            return None
+        medspec = np.nanmedian(spec)
+        if medspec == 0:
+            medspec = np.nanmedian(spec[(spec > 0) & (~badmask)])
+            if not np.isfinite(medspec):
+                medspec = np.nanmedian(np.abs(spec))
+    if not np.isfinite(medspec) or medspec == 0:
+        return None
+    return medspec
+
+
+def get_specdata_batch(waves, fluxes, ivars, masks, resolutions, seqids, setups,
+                       use_resolution_matrix=False, mask_dicroic=True,
+                       lsf_sigma0_angstrom=None):
+    """get_specdata (desi_fit.py:781-888) for the fibres `seqids` at once.
+
+    Returns {setup: dict(spec, espec float64 [n, npix]; badmask bool [n, npix];
+    ok bool [n] -- False where the reference skips the arm (all masked, or an
+    insane median); taps float64 [n, npix, w] or None)}."""
+    seqids = np.asarray(seqids, dtype=np.int64)
+    out = {}
+    for s in setups:
+        spec = np.array(fluxes[s][seqids])
+        curivars = np.array(ivars[s][seqids])
+        badmask = masks[s][seqids] > 0
+        n, npix = spec.shape
+        med = np.ones(n, dtype=np.float64)
+        ok = np.zeros(n, dtype=bool)
+        for i in range(n):
+            m = _medspec(spec[i], badmask[i])
+            if m is not None:
+                med[i], ok[i] = m, True
+        with np.errstate(all='ignore'):
+            baddat = ~np.isfinite(spec + curivars)
+        if mask_dicroic:
+            dicroicmask = (waves[s] > 4300) & (waves[s] < 4450)
+        else:
+            dicroicmask = np.zeros(npix, dtype=bool)
+        baderr = curivars <= 0
+        edge_mask = np.zeros(npix, dtype=bool)
+        taps = None
+        if use_resolution_matrix:
+            dwave = waves[s][1] - waves[s][0]
+            taps = resolution_row_taps(resolutions[s][seqids], dwave,
+                                       lsf_sigma0_angstrom[s])
+            edge_pixels = 5  # the resolution matrix is corrupted at the edges
+            edge_mask[:edge_pixels] = True
+            edge_mask[-edge_pixels:] = True
+        badall_interp = baddat | badmask | baderr
+        badall = badall_interp | dicroicmask[None, :] | edge_mask[None, :]
+        # 1. / medspec**2 / large_error**2 is float64 in the reference's numpy
+        fill = (1. / med**2 / LARGE_ERROR**2).astype(curivars.dtype)
+        curivars = np.where(badall, fill[:, None], curivars)
+        spec = _interp_bad_rows(spec, badall_interp)
+        with np.errstate(all='ignore'):
+            espec = (1. / np.sqrt(curivars)).astype(curivars.dtype)
+        for i in range(n):
+            if not ok[i]:
+                continue
+            if badall[i].all():
+                logging.warning('The whole spectrum was masked...')
+                continue
+            goodespec = espec[i][~badall[i]]
+            thresh = np.float64(np.median(goodespec)) * MINERR_FRAC
+            # float32 array against a float64 scalar: compared in float32
+            replace_idx = (espec[i] < espec.dtype.type(thresh)) & (~badall[i])
+            if replace_idx.sum() / (~badall[i]).sum() > .01:
+                logging.warning(
+                    'More than 1% of spectra had the uncertainty clamped')
+            espec[i][replace_idx] = thresh
+        out[s] = dict(spec=spec.astype(np.float64), espec=espec.astype(np.float64),
+                      badmask=badall, ok=ok, taps=taps)
+    return out
+
+
+def get_specdata(waves, fluxes, ivars, masks, resolutions, seqid, setups,
+                 use_resolution_matrix=False, mask_dicroic=True,
+                 lsf_sigma0_angstrom=None):
+    """desi_fit.py:781-888: tuple of spec_fit.SpecData for one fibre (arms that
+    are fully masked or have an insane median are left out), or None."""
+    c = get_specdata_batch(waves, fluxes, ivars, masks, resolutions, [seqid],
+                           setups, use_resolution_matrix=use_resolution_matrix,
+                           mask_dicroic=mask_dicroic,
+                           lsf_sigma0_angstrom=lsf_sigma0_angstrom)
+    sds = []
+    for s in setups:
+        a = c[s]
+        if not a['ok'][0]:
+            continue
+        resol = None
+        if use_resolution_matrix:
+            resol = spec_fit.ResolMatrix(_taps_to_dia(a['taps'][0]))
+        sds.append(spec_fit.SpecData('desi_%s' % s, waves[s], a['spec'][0],
+                                     a['espec'][0], resolution=resol,
+                                     badmask=a['badmask'][0]))
+    if len(sds) == 0:
+        logging.warning(f'No good data found for fiber {seqid}')
+        return None
+    return tuple(sds)
+
+
+def _taps_to_dia(taps):
+    """row taps [npix, w] -> scipy dia_matrix (R[k, k + o] = taps[k, w2 + o])"""
+    npix, w = taps.shape
+    w2 = w // 2
+    data = np.zeros((w, npix))
+    k = np.arange(npix)
+    for di in range(w):
+        o = w2 - di
+        ok = (k + o >= 0) & (k + o < npix)
+        data[di, k[ok] + o] = taps[k[ok], w2 + o]
+    return scipy.sparse.dia_matrix((data, np.arange(w2, -w2 - 1, -1)),
+                                   (npix, npix))
+
+
+# ----------------------------------------------------------------- schema
+def get_column_desc(setups):
+    """desi_fit.py:910-959: {column: (dtype, comment)} -- the comments go to the
+    TCOMMn cards of the RVTAB; the dtypes are informative (the reference writes
+    the columns with the dtype of the values)."""
+    columnDesc = dict([
+        ('VRAD', (np.float32, 'Radial velocity')),
+        ('VRAD_ERR', (np.float32, 'Radial velocity error')),
+        ('VRAD_SKEW', (np.float32, 'Radial velocity posterior skewness')),
+        ('VRAD_KURT', (np.float32, 'Radial velocity posterior kurtosis')),
+        ('VSINI', (np.float32, 'Stellar rotation velocity')),
+        ('LOGG', (np.float32, 'Log of surface gravity')),
+        ('TEFF', (np.float32, 'Effective temperature')),
+        ('FEH', (np.float32, '[Fe/H] from template fitting')),
+        ('ALPHAFE', (np.float32, '[alpha/Fe] from template fitting')),
+        ('LOGG_ERR', (np.float32, 'Log of surface gravity uncertainty')),
+        ('TEFF_ERR', (np.float32, 'Effective temperature uncertainty')),
+        ('FEH_ERR', (np.float32, '[Fe/H] uncertainty from template fitting')),
+        ('ALPHAFE_ERR', (np.float32,
+                         '[alpha/Fe] uncertainty from template fitting')),
+        ('CHISQ_TOT', (np.float64, 'Total chi-square for all arms')),
+        ('NPIX_TOT', (np.float64, 'Total number of unmasked pixels fitted')),
+        ('CHISQ_C_TOT',
+         (np.float64, 'Total chi-square for all arms for polynomial only fit')),
+        ('CHISQ_CCF', (np.float32, 'Total chi-square from CCF fit')),
+        ('TEFF_CCF', (np.float32, 'Effective temperature from CCF fit')),
+        ('LOGG_CCF', (np.float32, 'Log of surface gravity from CCF fit')),
+        ('FEH_CCF', (np.float32, '[Fe/H] from CCF fit')),
+        ('ALPHAFE_CCF', (np.float32, '[alpha/Fe] from CCF fit')),
+        ('VSINI_CCF', (np.float32, 'Vsini from CCF fit')),
+        ('VRAD_CCF', (np.float32, 'Initial velocity from cross-correlation')),
+        ('TARGETID', (np.int64, 'DESI targetid')),
+        ('EXPID', (np.int64, 'DESI exposure id')),
+        ('SUCCESS', (bool, 'Did we succeed or fail')),
+        ('RVS_WARN', (np.int64, 'RVSpecFit warning flag')),
+        ('RR_Z', (np.float64, 'Redrock redshift')),
+        ('RR_SPECTYPE', (str, 'Redrock spectype')),
+        ('RR_SUBTYPE', (str, 'Redrock spectroscopic subtype'))
+    ])
+    for curs in setups:
+        curs = curs.upper()
+        columnDesc['SN_%s' % curs] = (np.float32,
+                                      'Median S/N in the %s arm' % curs)
+        columnDesc['CHISQ_%s' % curs] = (np.float64,
+                                         'Chi-square in the %s arm' % curs)
+        columnDesc['CHISQ_C_%s' % curs] = (
+            np.float64,
+            'Chi-square in the %s arm after fitting continuum only' % curs)
+    return columnDesc
+
+
+def comment_filler(tab, desc):
+    """desi_fit.py:891-900"""
+    for i, name in enumerate(tab.data.columns.names):
+        comm = desc.get(name)
+        tab.header['TCOMM%d' % (i + 1)] = '' if comm is None else comm[1]
+    return tab
+
+
+def put_empty_file(fname):
+    """desi_fit.py:903-907"""
+    pyfits.HDUList([pyfits.PrimaryHDU(header=get_prim_header())]).writeto(
+        fname, overwrite=True, checksum=True)
+
+
+def write_hdulist(fname, hdulist):
+    """desi_fit.py:1302-1308: write through a temporary file"""
+    fname_tmp = fname + '.tmp'
+    hdulist.writeto(fname_tmp, overwrite=True, checksum=True)
+    os.rename(fname_tmp, fname)
+
+
+def rows_to_table(rows):
+    """list of dicts -> fits_min.FitsTable, the way astropy.table.Table(rows)
+    + BinTableHDU lay it out (desi_fit.py:1262, 1288): columns in order of
+    first appearance, cells a row does not have are NaN (floats), 999999
+    (integers, TNULL), '' (strings), False (logicals)."""
+    names = []
+    for r in rows:
+        for k in r:
+            if k not in names:
+                names.append(k)
+    tab = pyfits.FitsTable()
+    for k in names:
+        vals = [r[k] for r in rows if k in r]
+        proto = np.asarray(vals)
+        kind = proto.dtype.kind
+        if kind in 'SU':
+            col = np.array([str(r.get(k, '')) for r in rows])
+            if col.dtype.itemsize == 0:
+                col = col.astype('U1')
+            null = None
+        elif kind == 'b':
+            col = np.array([bool(r.get(k, False)) for r in rows])
+            null = None
+        elif kind in 'iu':
+            col = np.array([r.get(k, INT_NULL) for r in rows], dtype=proto.dtype)
+            null = INT_NULL
+        else:
+            col = np.array([r.get(k, np.nan) for r in rows], dtype=proto.dtype)
+            null = None
+        tab._cols.append(pyfits.Column(k, col, COLUMN_UNITS.get(k, ''),
+                                       null=null))
+    return tab
+
+
+# -------------------------------------------------------------- the fits
+NAME_MAPPINGS = (('logg', 'LOGG'), ('teff', 'TEFF'), ('feh', 'FEH'),
+                 ('alpha', 'ALPHAFE'))
+
+
+def fit_batch(batch, config, options, ccf_init=True):
+    """The body of proc_onespec (desi_fit.py:283-354) for a SpecBatch: the
+    starting point (CCF or brute-force grid), vel_fit.process, the continuum
+    chi^2.  Returns host arrays (dict) with a leading S axis plus `yfit`
+    (list over arms of [S, npix] float64)."""
+    import torch
+    from .. import fitter_ccf, vel_fit, _lib
+    S = batch.S
+    names = spec_inter.getSpecParams(batch.names[0], config)
+    if ccf_init:
+        res = fitter_ccf.fit(batch, config)
+        if bool((res['status'] & _lib.ST_CCF_FAILED).any().item()):
+            logging.error('Cross-correlation failed')
+            raise RuntimeError('Cross-correlation step failed')
+        pd0 = {k: res['best_par'][:, i].contiguous()
+               for i, k in enumerate(names)}
+        vs0 = res['best_vsini']
+        vrad_ccf = res['best_vel'].cpu().numpy()
+    else:
+        g = vel_fit.firstguess(batch, config=config, options=options)
+        pd0 = {k: g[k].contiguous() for k in names}
+        vs0 = g['vsini']
+        vrad_ccf = None
+    has_vs = torch.isfinite(vs0)
+    groups = []
+    if bool(has_vs.all().item()):
+        groups.append((None, True))
+    elif not bool(has_vs.any().item()):
+        groups.append((None, False))
+    else:  # templates with and without rotation: two lock-step runs
+        groups.append((torch.nonzero(has_vs).reshape(-1), True))
+        groups.append((torch.nonzero(~has_vs).reshape(-1), False))
+    out = dict(
+        vel=np.full(S, np.nan), vel_err=np.full(S, np.nan),
+        vel_skewness=np.full(S, np.nan), vel_kurtosis=np.full(S, np.nan),
+        vsini=np.full(S, np.nan), bad_hessian=np.zeros(S, dtype=bool),
+        chisq_array=np.zeros((S, len(batch.arms))),
+        npix_array=np.zeros((S, len(batch.arms)), dtype=np.int64),
+        param={k: np.full(S, np.nan) for k in names},
+        param_err={k: np.full(S, np.nan) for k in names})
+    yfit = [np.zeros((S, a.npix)) for a in batch.arms]
+    for idx, with_vs in groups:
+        sub = batch if idx is None else batch.subset(idx)
+        sel = slice(None) if idx is None else idx.cpu().numpy()
+        p0 = {k: (v if idx is None else v[idx].contiguous())
+              for k, v in pd0.items()}
+        if with_vs:
+            p0['vsini'] = (vs0 if idx is None else vs0[idx]).contiguous()
+        r = vel_fit.process(sub, p0, fixParam=[], config=config,
+                            options=options)
+        for k in ('vel', 'vel_err', 'vel_skewness', 'vel_kurtosis'):
+            out[k][sel] = r[k].cpu().numpy()
+        if 'vsini' in r and r['vsini'] is not None:
+            out['vsini'][sel] = r['vsini'].cpu().numpy()
+        out['bad_hessian'][sel] = np.asarray(r['bad_hessian'])
+        out['chisq_array'][sel] = r['chisq_array'].cpu().numpy()
+        out['npix_array'][sel] = r['npix_array'].cpu().numpy()
+        for k in names:
+            out['param'][k][sel] = r['param'][k].cpu().numpy()
+            out['param_err'][k][sel] = np.asarray(r['param_err'][k])
+        for ia in range(len(batch.arms)):
+            yfit[ia][sel] = r['yfit'][ia].cpu().numpy()
+    cont = spec_fit.get_chisq_continuum(batch, options=options)['chisq_array']
+    out['chisq_c_array'] = cont.cpu().numpy()
+    out['vrad_ccf'] = vrad_ccf
+    out['yfit'] = yfit
+    return out
+
+
+def _outdicts(fr, arm_names, config, ccf_init):
+    """outdict of proc_onespec (desi_fit.py:312-356) for every spectrum of a
+    fit_batch result; arm_names are the SpecData names ('desi_b', ...)."""
+    S = len(fr['vel'])
+    rows = []
+    tags = [n.replace('desi_', '').upper() for n in arm_names]
+    chisq_tot = fr['chisq_array'].sum(axis=1)
+    chisq_c_tot = fr['chisq_c_array'].sum(axis=1)
+    p = fr['param']
+    warn = rvs_warn_bits(chisq_tot, chisq_c_tot, fr['vel'], fr['vsini'],
+                         fr['vel_err'], fr['bad_hessian'],
+                         p.get('teff', np.full(S, 5000.)),
+                         p.get('feh', np.zeros(S)), p.get('logg', np.full(S, 3.)),
+                         config)
+    for i in range(S):
+        d = dict(VRAD=fr['vel'][i], VRAD_ERR=fr['vel_err'][i],
+                 VRAD_SKEW=fr['vel_skewness'][i],
+                 VRAD_KURT=fr['vel_kurtosis'][i], VSINI=fr['vsini'][i])
+        for name1, name2 in NAME_MAPPINGS:
+            if name1 in p:
+                d[name2] = p[name1][i]
+                d[name2 + '_ERR'] = fr['param_err'][name1][i]
+        d['CHISQ_TOT'] = chisq_tot[i]
+        d['CHISQ_C_TOT'] = chisq_c_tot[i]
+        d['NPIX_TOT'] = int(fr['npix_array'][i].sum())
+        for ia, t in enumerate(tags):
+            d['CHISQ_%s' % t] = fr['chisq_array'][i, ia]
+            d['CHISQ_C_%s' % t] = float(fr['chisq_c_array'][i, ia])
+        if ccf_init:
+            d['VRAD_CCF'] = fr['vrad_ccf'][i]
+        d['RVS_WARN'] = int(warn[i])
+        rows.append(d)
+    return rows
+
+
+def _template_versions(names, config):
+    """desi_fit.py:372-376: every interpolator in the process-wide cache (not
+    only the arms of this fibre), in the order they were loaded"""
+    for n in names:
+        spec_inter.getInterpolator(n, config)
+    return {
+        k: dict(revision=v.revision,
+                creation_soft_version=v.creation_soft_version)
+        for k, v in spec_inter.interp_cache.interps.items()
+    }
+
+
+def proc_onespec(specdata, setups, config, options, resolution_matrix=None,
+                 fig_fname='fig.png', ccf_init=True, doplot=True):
+    """desi_fit.py:248-378 for one fibre (a tuple of SpecData): returns
+    (outdict, yfit).  Values are plain floats; the units the reference attaches
+    are in COLUMN_UNITS."""
+    from ..spec_fit import as_batch
+    batch, _ = as_batch(list(specdata))
+    fr = fit_batch(batch, config, options, ccf_init=ccf_init)
+    outdict = _outdicts(fr, batch.names, config, ccf_init)[0]
+    if doplot:
+        logging.warning('plots are not produced by this build')
+    outdict['versions'] = _template_versions(batch.names, config)
+    return outdict, [y[0] for y in fr['yfit']]
+
+
+def _arm_batch(cond, setups, pattern, rows, waves, device):
+    """SpecBatch of the fibres `rows` (indices into the conditioned arrays)
+    over the arms of `pattern`"""
+    from .. import engine
+    arms = []
+    for s, use in zip(setups, pattern):
+        if not use:
+            continue
+        c = cond[s]
+        a = engine.ArmData('desi_%s' % s, waves[s], c['spec'][rows],
+                           c['espec'][rows],
+                           c['badmask'][rows].astype(np.uint8), device=device)
+        if c['taps'] is not None:
+            t = c['taps'][rows]
+            a.resol = engine.make_resol(t, t.shape[2], len(rows), device)
+        arms.append(a)
+    return engine.SpecBatch(arms)
+
+
+def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
+              fit_targetid=None, objtypes=None, doplot=True, minsn=-1e9,
+              expid_range=None, poolex=None, fitarm=None, cmdline=None,
+              zbest_select=False, zbest_include=False,
+              use_resolution_matrix=False, ccf_init=True, npoly=10,
+              device='cuda', max_batch=4096):
+    """desi_fit.py:962-1299: fit every selected fibre of one DESI file and write
+    the RVTAB and RVMOD products.  `poolex` is accepted for signature
+    compatibility and unused: the fibres of the file are one GPU batch (in
+    chunks of `max_batch`).  Returns the number of fibres selected, or -1."""
+    if npoly is None:
+        npoly = 10
+    options = {'npoly': npoly}
+    logging.info('Processing %s' % fname)
+    try:
+        FP = pyfits.open(fname)
+    except OSError:
+        logging.error('Cannot read file %s' % (fname))
+        return -1
+    if not valid_file(FP):
+        logging.error('Not valid file: %s' % (fname))
+        return -1
+    setups = ['b', 'r', 'z']
+    if fitarm is not None:
+        setups = [_ for _ in setups if _ in fitarm]
+        assert (len(setups) > 0)
+    spectrum_header = FP[0].header
+    fibermap = FP['FIBERMAP'].data
+    scores = FP['SCORES'].data
+    exp_fibermap = FP['EXP_FIBERMAP'].data if 'EXP_FIBERMAP' in FP else None
+
+    if fit_targetid is not None:
+        if not np.isin(fibermap['TARGETID'], fit_targetid).any():
+            logging.warning('No fibers selected in file %s' % (fname))
+            put_empty_file(tab_ofname)
+            put_empty_file(mod_ofname)
+            return 0
+    fluxes, ivars, masks, waves, resolutions = read_data(FP, setups)
+    sn_names = scores.columns.names
+    for pref in ('MEDIAN_CALIB_SNR_', 'MEDIAN_COADD_SNR_',
+                 'MEDIAN_COADD_FLUX_SNR_'):
+        if pref + setups[0].upper() in sn_names:
+            sns = {_: scores[pref + _.upper()] for _ in setups}
+            break
+    else:
+        sns = {_: get_sns(fluxes[_], ivars[_], masks[_]) for _ in setups}
+    for _ in setups:
+        if len(sns[_]) != len(fibermap):
+            logging.warning((
+                'WARNING the size of the data in arm %s' +
+                'does not match the size of the fibermap; file %s; skipping...'
+            ) % (_, fname))
+            return -1
+    columnDesc = get_column_desc(setups)
+    if zbest_select or zbest_include:
+        zbest_path, zbest_ext = get_zbest_fname(fname)
+    else:
+        zbest_path, zbest_ext = None, None
+    subset, rr_z, rr_spectype, rr_subtype = select_fibers_to_fit(
+        fibermap, sns, minsn=minsn, objtypes=objtypes, expid_range=expid_range,
+        fit_targetid=fit_targetid, zbest_path=zbest_path, zbest_ext=zbest_ext,
+        zbest_select=zbest_select, zbest_include=zbest_include)
+
+    fibermap_subset_hdu = pyfits.BinTableHDU(fibermap[subset], name='FIBERMAP')
+    exp_fibermap_subset_hdu = None
+    if exp_fibermap is not None:
+        tmp_sub = np.isin(exp_fibermap['TARGETID'],
+                          fibermap['TARGETID'][subset])
+        exp_fibermap_subset_hdu = pyfits.BinTableHDU(exp_fibermap[tmp_sub],
+                                                     name='EXP_FIBERMAP')
+    scores_subset_hdu = pyfits.BinTableHDU(scores[subset], name='SCORES')
+
+    def mod_hdus(versions, models):
+        hdus = [pyfits.PrimaryHDU(header=get_prim_header(
+            versions=versions, config=config, cmdline=cmdline,
+            spectrum_header=spectrum_header, zbest_path=zbest_path))]
+        for curs in setups:
+            hdus.append(pyfits.ImageHDU(waves[curs],
+                                        name='%s_WAVELENGTH' % curs.upper()))
+            hdus.append(pyfits.ImageHDU(
+                None if models is None else models['desi_%s' % curs],
+                name='%s_MODEL' % curs.upper()))
+        return hdus + [fibermap_subset_hdu]
+
+    def tab_hdus(versions, outtab):
+        hdus = [pyfits.PrimaryHDU(header=get_prim_header(
+            versions=versions, config=config, cmdline=cmdline,
+            zbest_path=zbest_path)),
+            comment_filler(pyfits.BinTableHDU(outtab, name='RVTAB'),
+                           columnDesc), fibermap_subset_hdu, scores_subset_hdu]
+        if exp_fibermap_subset_hdu is not None:
+            hdus.append(exp_fibermap_subset_hdu)
+        return hdus
+
+    if not subset.any():
+        logging.warning('No fibers selected in file %s' % (fname))
+        write_hdulist(mod_ofname, pyfits.HDUList(mod_hdus(None, None)))
+        write_hdulist(tab_ofname,
+                      pyfits.HDUList(tab_hdus(None, pyfits.FitsTable())))
+        return 0
+    logging.info('Selected %d fibers to fit' % (subset.sum()))
+
+    columnsCopy = ['FIBER', 'REF_ID', 'REF_CAT', 'TARGET_RA', 'TARGET_DEC',
+                   'TARGETID', 'EXPID']
+    seqid_to_fit = np.nonzero(subset)[0]
+    nsel = len(seqid_to_fit)
+    if rr_z is not None:
+        rr_z, rr_spectype, rr_subtype = (rr_z[seqid_to_fit],
+                                         rr_spectype[seqid_to_fit],
+                                         rr_subtype[seqid_to_fit])
+    else:
+        rr_z = np.zeros(nsel) + np.nan
+        rr_spectype = np.zeros(nsel, dtype='U1')
+        rr_subtype = np.zeros(nsel, dtype='U1')
+    sig0s = None
+    if use_resolution_matrix:
+        sig0s = {}
+        for s in setups:
+            if ('lsf_sigma0_angstrom' not in config
+                    or s not in config['lsf_sigma0_angstrom']):
+                sig0s[s] = 0.5
+                logging.warning('sigma0 of the templates is not specified '
+                                f'for setup {s} using {sig0s[s]}')
+            else:
+                sig0s[s] = config['lsf_sigma0_angstrom'][s]
+    if doplot:
+        logging.warning('plots are not produced by this build')
+
+    # ---- conditioning of all selected fibres, then one batch per arm pattern
+    cond = get_specdata_batch(waves, fluxes, ivars, masks, resolutions,
+                              seqid_to_fit, setups,
+                              use_resolution_matrix=use_resolution_matrix,
+                              lsf_sigma0_angstrom=sig0s)
+    okmat = np.stack([cond[s]['ok'] for s in setups], axis=1)
+    outdicts = [None] * nsel
+    curmodels = [None] * nsel
+    arms_of = [None] * nsel
+    for pattern in sorted({tuple(_) for _ in okmat.tolist()}, reverse=True):
+        rows_p = np.nonzero((okmat == np.array(pattern)[None, :]).all(axis=1))[0]
+        if not any(pattern):
+            for i in rows_p:
+                logging.warning('No good data found for fiber %d'
+                                % seqid_to_fit[i])
+            continue
+        names_p = ['desi_%s' % s for s, u in zip(setups, pattern) if u]
+        for c0 in range(0, len(rows_p), max_batch):
+            rows = rows_p[c0:c0 + max_batch]
+            batch = _arm_batch(cond, setups, pattern, rows, waves, device)
+            fr = fit_batch(batch, config, options, ccf_init=ccf_init)
+            for k, (i, d) in enumerate(zip(rows, _outdicts(fr, names_p, config,
+                                                           ccf_init))):
+                outdicts[i] = d
+                curmodels[i] = [y[k] for y in fr['yfit']]
+                arms_of[i] = names_p
+    nfibers_good = sum(_ is not None for _ in outdicts)
+    good_flags = [_ is not None for _ in outdicts]
+    # the reference indexes `models` (nfibers_good rows) by the ROW counter
+    # (desi_fit.py:1211-1252): identical shapes whenever it does not raise
+    # (no BAD_SPECTRUM fibre ahead of a good one); nsel rows otherwise
+    last_good = max([i for i, g in enumerate(good_flags) if g], default=-1)
+    nmod = nfibers_good if last_good < nfibers_good else nsel
+    models = {'desi_' + s: np.zeros((nmod, len(waves[s])), dtype=np.float32)
+              for s in setups}
+    versions = None
+    outdf = []
+    for ii in range(nsel):
+        outdict = outdicts[ii]
+        bad_row = outdict is None
+        if bad_row:
+            outdict = dict(RVS_WARN=bitmasks['BAD_SPECTRUM'])
+        cur_seqid = seqid_to_fit[ii]
+        for col in columnsCopy:
+            if col in fibermap.columns.names:
+                outdict[col] = fibermap[col][cur_seqid]
+        for curs in setups:
+            outdict['SN_%s' % curs.upper()] = sns[curs][cur_seqid]
+        outdict['SUCCESS'] = outdict['RVS_WARN'] == 0
+        outdict['RR_Z'] = rr_z[ii]
+        outdict['RR_SPECTYPE'] = rr_spectype[ii]
+        outdict['RR_SUBTYPE'] = rr_subtype[ii]
+        if not bad_row:
+            for jj, curs in enumerate(arms_of[ii]):
+                models[curs][ii] = curmodels[ii][jj]
+            if versions is None:
+                versions = _template_versions(arms_of[ii], config)
+        outdf.append(outdict)
+    outtab = rows_to_table(outdf)
+    assert (len(fibermap_subset_hdu.data) == len(outtab))
+    write_hdulist(mod_ofname, pyfits.HDUList(mod_hdus(versions, models)))
+    write_hdulist(tab_ofname, pyfits.HDUList(tab_hdus(versions, outtab)))
+    return nsel
+
+
+def proc_desi_wrapper(*args, **kwargs):
+    """desi_fit.py:1311-1350: status file + exception policy around proc_desi"""
+    status = ProcessStatus.SUCCESS
+    status_file = kwargs.pop('process_status_file', None)
+    throw_exceptions = kwargs.pop('throw_exceptions', None)
+    nfit = 0
+    t1 = time.time()
+    try:
+        nfit = proc_desi(*args, **kwargs)
+        if nfit < 0:
+            status = ProcessStatus.FAILURE
+            nfit = 0
+    except:  # noqa: E722
+        status = ProcessStatus.FAILURE
+        logging.exception('failed with these arguments' + str(args) +
+                          str(kwargs))
+        pid = os.getpid()
+        logfname = 'crash_%d_%s.log' % (pid, time.ctime().replace(' ', ''))
+        with open(logfname, 'w') as fd:
+            print('failed with these arguments', args, kwargs, file=fd)
+            traceback.print_exc(file=fd)
+        if throw_exceptions:
+            raise
+    finally:
+        t2 = time.time()
+        if status_file is not None:
+            if nfit is None:
+                nfit = 0
+            update_process_status_file(status_file, args[0], status, nfit,
+                                       t2 - t1)
+
+
+def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
+              figure_dir=None, figure_prefix=None, config_fname=None,
+              nthreads=1, fit_targetid=None, objtypes=None, minsn=-1e9,
+              doplot=True, expid_range=None, skipexisting=False, fitarm=None,
+              cmdline=None, zbest_select=False, zbest_include=False,
+              ccf_init=True, subdirs=True, ccf_continuum_normalize=True,
+              process_status_file=None, use_resolution_matrix=None, npoly=None,
+              throw_exceptions=None, log_level=None, log_filename=None,
+              shard=None):
+    """desi_fit.py:1392-1551: loop over files.  `nthreads` is accepted and
+    unused (one file is one GPU batch).  `shard=(rank, world)` -- or the
+    RANK/WORLD_SIZE environment of torch.distributed.run -- gives every GPU
+    process its own stride of the file list; files are independent, there is
+    no collective."""
+    override = dict(ccf_continuum_normalize=ccf_continuum_normalize)
+    config = utils.read_config(config_fname, override)
+    assert (config is not None)
+    assert ('template_lib' in config)
+    if shard is None:
+        shard = (int(os.environ.get('RANK', 0)),
+                 int(os.environ.get('WORLD_SIZE', 1)))
+    rank, world = shard
+    if process_status_file is not None:
+        if world > 1:
+            process_status_file = '%s.%d' % (process_status_file, rank)
+        update_process_status_file(process_status_file, None, None, None, None,
+                                   start=True)
+    for f in list(files)[rank::world]:
+        fname = f.split('/')[-1]
+        if subdirs:
+            fdirs = f.split('/')
+            if len(fdirs) < 3:
+                logging.warning(f'Invalid file {f}, it needs two be in the '
+                                'format dir1/dir2/fname')
+                continue
+            folder_path = output_dir + '/' + fdirs[-3] + '/' + fdirs[-2] + '/'
+        else:
+            folder_path = output_dir + '/'
+        os.makedirs(folder_path, exist_ok=True)
+        cur_figure_prefix = None
+        fname0 = fname[:-3] if fname[-3:] == '.gz' else fname
+        tab_ofname = folder_path + output_tab_prefix + '_' + fname0
+        mod_ofname = folder_path + output_mod_prefix + '_' + fname0
+        if (skipexisting and os.path.exists(tab_ofname)
+                and os.path.exists(mod_ofname)):
+            logging.info('skipping, products already exist %s' % f)
+            if process_status_file is not None:
+                update_process_status_file(process_status_file, f,
+                                           ProcessStatus.EXISTING, -1, 0)
+            continue
+        proc_desi_wrapper(
+            f, tab_ofname, mod_ofname, cur_figure_prefix, config,
+            fit_targetid=fit_targetid, objtypes=objtypes, doplot=doplot,
+            minsn=minsn, expid_range=expid_range, fitarm=fitarm,
+            cmdline=cmdline, zbest_select=zbest_select,
+            zbest_include=zbest_include,
+            process_status_file=process_status_file, npoly=npoly,
+            ccf_init=ccf_init,
+            use_resolution_matrix=bool(use_resolution_matrix),
+            throw_exceptions=throw_exceptions)
+    logging.info('Successfully finished processing')

@@ -41,6 +41,7 @@ class TemplateLibrary:
         for i in self.log_ids:
             self.log_mask |= (1 << i)
         self.revision = str(d.get('revision', ''))
+        self.creation_soft_version = str(d.get('creation_soft_version', ''))
         self.knots = _dev(self.lam, torch.float64, device)
         self.knots3 = np.ascontiguousarray(self.lam[:3])
         self.lnstep = float(np.log(self.lam[1] / self.lam[0]))

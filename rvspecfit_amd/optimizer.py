@@ -31,6 +31,7 @@ class ProcessObjective:
 
     def __init__(self, batch, libs, names, pd0, fixParam, fitVsini, config,
                  options, priors, safe_params, resols=None):
+        from . import engine
         L = _lib.lib()
         self.L = L
         self.batch, self.libs = batch, libs
@@ -112,9 +113,15 @@ class ProcessObjective:
             a.coef, a.penalty = b['coef'].data_ptr(), b['pen'].data_ptr()
             a.npix, a.S, a.ntp = arm.npix, arm.S, lib.ntp
             a.log_step = int(lib.log_step)
+            # A9: the spectra's own resolution matrices or the resol_params
+            # override, as engine.chisq_point wires them
+            rs = engine._arm_resol(arm, ia, resols)
+            if rs is not None:
+                a.taps, a.taps_stride, a.nd = rs['taps'].data_ptr(), \
+                    rs['stride'], rs['nd']
+                self._resol_keep = getattr(self, '_resol_keep', []) + [rs]
         nb = L.rvs_chisq_point_work_size(cap, narm)
         self.scratch = torch.empty((nb + 7) // 8, **f64)
-        from . import engine
         self.fused = engine.can_fuse_objective(batch, libs, resols,
                                                npoly=self.npoly)
         if self.fused:

@@ -38,7 +38,7 @@ class SpecInterpolator:
         self.log_step = lib.log_step
         self.revision = lib.revision
         self.filename = filename
-        self.creation_soft_version = ''
+        self.creation_soft_version = getattr(lib, 'creation_soft_version', '')
         self.objid = hash((self.name, self.parnames, self.revision, filename))
 
     def __hash__(self):

@@ -1,0 +1,336 @@
+"""DESI driver host logic against vectors produced by the
+reference's desi/desi_fit.py (tests/golden/make_golden_desi.py), and the FITS
+reader/writer against files written by astropy.  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+from rvspecfit_amd import fits_min as F
+from rvspecfit_amd.desi import desi_fit as D
+
+from conftest import GOLD
+
+ARMS = ['b', 'r', 'z']
+COADD = os.path.join(GOLD, 'coadd-golden.fits')
+SIG0 = dict(b=0.5, r=0.5, z=0.55)
+
+
+@pytest.fixture(scope='module')
+def dcases():
+    return dict(np.load(os.path.join(GOLD, 'desi_cases.npz')))
+
+
+@pytest.fixture(scope='module')
+def coadd():
+    FP = F.open(COADD, verify_checksum=True)
+    return FP, D.read_data(FP, ARMS)
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.dtype.kind in 'SUb':
+        return np.array_equal(a, b)
+    return np.array_equal(a, b, equal_nan=True)
+
+
+# ------------------------------------------------------------------ FITS
+def test_fits_reader_matches_astropy(dcases, coadd):
+    """every image and table column of the coadd as astropy read it, and the
+    CHECKSUM/DATASUM of every HDU astropy wrote (verify_checksum above)"""
+    FP, _ = coadd
+    assert D.valid_file(FP)
+    n = 0
+    for k, ref in dcases.items():
+        if not k.startswith('file/'):
+            continue
+        parts = k.split('/')
+        a = FP[parts[1]].data if len(parts) == 2 else FP[parts[1]].data[parts[2]]
+        assert _same(a, ref), k
+        assert a.dtype.kind == ref.dtype.kind and \
+            a.dtype.itemsize == ref.dtype.itemsize or a.dtype.kind == 'U', k
+        n += 1
+    assert n > 25
+    h = FP[0].header
+    assert h['SPGRP'] == 'healpix' and h['HPXPIXEL'] == 10378
+    assert h['HPXNEST'] is True
+
+
+def test_fits_reader_reference_rvtab(dcases):
+    """the reference's own RVTAB product: columns, formats, units, comments"""
+    T = F.open(os.path.join(GOLD, 'rvtab_ref.fits'), verify_checksum=True)
+    assert [h.name for h in T] == list(dcases['plain/tab/extnames'])
+    tab = T['RVTAB'].data
+    assert tab.columns.names == list(dcases['plain/tab/RVTAB/colnames'])
+    assert list(tab.columns.formats) == list(dcases['plain/tab/RVTAB/formats'])
+    assert [u or '' for u in tab.columns.units] == \
+        list(dcases['plain/tab/RVTAB/units'])
+    for i, n in enumerate(tab.columns.names):
+        assert _same(tab[n], dcases['plain/tab/RVTAB/col/' + n]), n
+        assert T['RVTAB'].header['TCOMM%d' % (i + 1)] == \
+            dcases['plain/tab/RVTAB/tcomm'][i]
+    keys = list(dcases['plain/tab/primary_keys'])
+    for k, v in zip(keys, dcases['plain/tab/primary_vals']):
+        assert str(T[0].header[k]) == v, k
+
+
+def test_fits_writer_roundtrip(tmp_path):
+    T = F.open(os.path.join(GOLD, 'rvtab_ref.fits'))
+    T[0].header['LONGKEY'] = ('x' * 150 + " it's", 'a comment')
+    T[0].header['AFLOAT'] = 1.5e-7
+    T[0].header['ABOOL'] = False
+    img = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    T.append(F.ImageHDU(img, name='CUBE'))
+    T.append(F.ImageHDU(np.arange(7, dtype=np.int64), name='INTS'))
+    T.append(F.ImageHDU(None, name='EMPTY'))
+    out = str(tmp_path / 'rt.fits')
+    T.writeto(out)
+    assert os.path.getsize(out) % F.BLOCK == 0
+    T2 = F.open(out, verify_checksum=True)  # raises on a bad CHECKSUM/DATASUM
+    assert [h.name for h in T2] == [h.name for h in T]
+    assert T2[0].header['LONGKEY'] == 'x' * 150 + " it's"
+    assert T2[0].header.comment('LONGKEY') == 'a comment'
+    assert T2[0].header['AFLOAT'] == 1.5e-7 and T2[0].header['ABOOL'] is False
+    assert _same(T2['CUBE'].data, img) and T2['CUBE'].data.dtype == np.float32
+    assert _same(T2['INTS'].data, np.arange(7)) and T2['EMPTY'].data is None
+    for h, h2 in zip(T, T2):
+        if isinstance(h, F.BinTableHDU):
+            assert h.data.columns.names == h2.data.columns.names
+            assert list(h.data.columns.formats) == list(h2.data.columns.formats)
+            for n in h.data.columns.names:
+                assert h.data[n].dtype == h2.data[n].dtype
+                assert _same(h.data[n], h2.data[n]), n
+
+
+def test_fits_checksum_detects_corruption(tmp_path):
+    raw = bytearray(open(os.path.join(GOLD, 'redrock-golden.fits'), 'rb').read())
+    raw[-2000] ^= 0x10
+    bad = str(tmp_path / 'bad.fits')
+    open(bad, 'wb').write(bytes(raw))
+    F.open(bad)
+    with pytest.raises(OSError):
+        F.open(bad, verify_checksum=True)
+
+
+# ------------------------------------------------------- fibre selection
+def test_get_sns_and_fiberstatus(dcases, coadd):
+    FP, (fluxes, ivars, masks, waves, resolutions) = coadd
+    for a in ARMS:
+        sn = D.get_sns(fluxes[a], ivars[a], masks[a])
+        assert _same(sn, dcases['sns/' + a]) and sn.dtype == np.float32
+    assert _same(D.fiberstatus_select(FP['FIBERMAP'].data),
+                 dcases['fiberstatus_select'])
+
+
+def test_select_fibers_to_fit(dcases, coadd):
+    FP, (fluxes, ivars, masks, waves, resolutions) = coadd
+    fm = FP['FIBERMAP'].data
+    sns = {a: D.get_sns(fluxes[a], ivars[a], masks[a]) for a in ARMS}
+    rrp, rre = D.get_zbest_fname(COADD)
+    assert rrp.endswith('redrock-golden.fits') and rre == 'REDSHIFTS'
+    assert D.get_zbest_fname('/x/other-golden.fits') == (None, None)
+    tid = fm['TARGETID']
+    cases = {
+        'plain': dict(minsn=2),
+        'nosn': dict(minsn=None),
+        'tid': dict(minsn=-1e9, fit_targetid=[int(tid[0]), int(tid[8]),
+                                              int(tid[7]), 12345]),
+        'zinc': dict(minsn=2, zbest_path=rrp, zbest_ext=rre,
+                     zbest_include=True),
+        'zsel': dict(minsn=2, zbest_path=rrp, zbest_ext=rre, zbest_select=True,
+                     objtypes=['MWS_ANY']),
+    }
+    for k, kw in cases.items():
+        sub, rz, rs, rsub = D.select_fibers_to_fit(fm, sns, **kw)
+        assert _same(sub, dcases['select/%s/subset' % k]), k
+        if rz is None:
+            assert 'select/%s/rr_z' % k not in dcases
+        else:
+            assert _same(rz, dcases['select/%s/rr_z' % k])
+            assert _same(rs, dcases['select/%s/rr_spectype' % k])
+            assert _same(rsub, dcases['select/%s/rr_subtype' % k])
+
+
+# ----------------------------------------------------------- conditioning
+def test_interpolate_bad_regions(dcases):
+    for i in range(8):
+        o = D.interpolate_bad_regions(dcases['ibr/%d/spec' % i],
+                                      dcases['ibr/%d/mask' % i])
+        assert _same(o, dcases['ibr/%d/out' % i]), i
+
+
+def test_resolution_matrix_helpers(dcases, coadd):
+    _, (fluxes, ivars, masks, waves, resolutions) = coadd
+    m0 = resolutions['b'][1]
+    rows = D.resolution_mat_torows(m0)
+    assert _same(rows, dcases['resol/torows'])
+    assert _same(D.resolution_mat_tocolumns(rows), dcases['resol/tocolumns'])
+    # LAPACK solves: not bit-reproducible across BLAS builds
+    dc = D.deconvolve_resolution_matrix(m0, 0.5, 0.8)
+    assert np.abs(dc - dcases['resol/deconv']).max() < 1e-13
+    sp = D.construct_resolution_sparse_matrix(m0, pix_size_angstrom=0.8,
+                                              sigma0_angstrom=0.5)
+    assert _same(sp.offsets, dcases['resol/sparse_offsets'])
+    assert np.abs(sp.data - dcases['resol/sparse_data']).max() < 1e-13
+    assert np.abs(sp @ dcases['resol/vec'] - dcases['resol/sparse_dot']
+                  ).max() < 1e-13
+
+
+@pytest.mark.parametrize('use_res', [False, True])
+def test_get_specdata(dcases, coadd, use_res):
+    """masking, sigma floor, bad-pixel interpolation, dropped arms: every fibre
+    of the synthetic coadd, bit for bit (float32 arithmetic of the reference
+    under numpy 1.26); resolution matrices to 1e-13"""
+    _, (fluxes, ivars, masks, waves, resolutions) = coadd
+    nfib = fluxes['b'].shape[0]
+    dropped = 0
+    for i in range(nfib):
+        with np.errstate(all='ignore'):
+            sds = D.get_specdata(waves, fluxes, ivars, masks, resolutions, i,
+                                 ARMS, use_resolution_matrix=use_res,
+                                 lsf_sigma0_angstrom=SIG0)
+        t = 'specdata/%d/%d/' % (int(use_res), i)
+        arms = [str(_) for _ in dcases[t + 'arms']]
+        assert ([] if sds is None else [s.name for s in sds]) == arms
+        dropped += 3 - len(arms)
+        for sd in (sds or []):
+            for k in ('spec', 'espec', 'badmask'):
+                assert _same(getattr(sd, k), dcases[t + sd.name + '/' + k]), \
+                    (i, sd.name, k)
+            assert sd.spec.dtype == np.float64
+            if use_res:
+                n = len(sd.spec)
+                ref = scipy.sparse.dia_matrix(
+                    (dcases[t + sd.name + '/resol_data'],
+                     dcases[t + sd.name + '/resol_offsets']),
+                    shape=(n, n)).toarray()
+                assert np.abs(sd.resolution.mat.toarray() - ref).max() < 1e-13
+            else:
+                assert sd.resolution is None
+    assert dropped >= 5  # fibres 4 (b), 5 (all), 13 (z) exercise the skips
+
+
+def test_get_specdata_batch_equals_single(coadd):
+    _, (fluxes, ivars, masks, waves, resolutions) = coadd
+    seq = [0, 3, 4, 5, 10, 13]
+    with np.errstate(all='ignore'):
+        c = D.get_specdata_batch(waves, fluxes, ivars, masks, resolutions, seq,
+                                 ARMS, use_resolution_matrix=True,
+                                 lsf_sigma0_angstrom=SIG0)
+        for k, i in enumerate(seq):
+            sds = D.get_specdata(waves, fluxes, ivars, masks, resolutions, i,
+                                 ARMS, use_resolution_matrix=True,
+                                 lsf_sigma0_angstrom=SIG0)
+            names = [] if sds is None else [s.name for s in sds]
+            for a in ARMS:
+                assert bool(c[a]['ok'][k]) == ('desi_' + a in names)
+            for sd in (sds or []):
+                a = sd.name[-1]
+                assert _same(c[a]['spec'][k], sd.spec)
+                assert _same(c[a]['espec'][k], sd.espec)
+                assert _same(c[a]['badmask'][k], sd.badmask)
+
+
+# ------------------------------------------------------- bits and schema
+def test_rvs_warn_bits(dcases):
+    cfg = dict(min_vel=-1000, max_vel=1000)
+    w = D.rvs_warn_bits(dcases['warn/CHISQ_TOT'], dcases['warn/CHISQ_C_TOT'],
+                        dcases['warn/VRAD'], dcases['warn/VSINI'],
+                        dcases['warn/VRAD_ERR'], dcases['warn/bad_hessian'],
+                        dcases['warn/teff'], dcases['warn/feh'],
+                        dcases['warn/logg'], cfg)
+    assert _same(w, dcases['warn/warn'])
+    assert set(np.unique(w)) >= {0, 1, 2, 4, 8, 16, 64}
+    for i in range(len(w)):
+        od = dict(CHISQ_TOT=dcases['warn/CHISQ_TOT'][i],
+                  CHISQ_C_TOT=dcases['warn/CHISQ_C_TOT'][i],
+                  VRAD=dcases['warn/VRAD'][i], VSINI=dcases['warn/VSINI'][i],
+                  VRAD_ERR=dcases['warn/VRAD_ERR'][i])
+        fr = dict(bad_hessian=bool(dcases['warn/bad_hessian'][i]),
+                  param=dict(teff=dcases['warn/teff'][i],
+                             feh=dcases['warn/feh'][i],
+                             logg=dcases['warn/logg'][i]))
+        assert D.get_rvs_warn(fr, od, cfg) == w[i]
+    assert D.bitmasks['BAD_SPECTRUM'] == 32
+
+
+def test_column_desc(dcases):
+    cd = D.get_column_desc(ARMS)
+    assert list(cd.keys()) == list(dcases['coldesc/names'])
+    assert [v[1] for v in cd.values()] == list(dcases['coldesc/comments'])
+
+
+def test_rows_to_table_missing_cells():
+    rows = [dict(A=1.5, N=3, S='ab', B=True), dict(N=4, C=2.0, S='abcd'),
+            dict(A=2.5)]
+    t = D.rows_to_table(rows)
+    assert t.columns.names == ['A', 'N', 'S', 'B', 'C']
+    assert _same(t['A'], [1.5, np.nan, 2.5])
+    assert _same(t['N'], [3, 4, D.INT_NULL]) and t.column('N').null == 999999
+    assert list(t['S']) == ['ab', 'abcd', '']
+    assert _same(t['C'], [np.nan, 2.0, np.nan])
+
+
+# ----------------------------------------- proc_desi paths without a fit
+CFG = dict(template_lib='golden-desi://', min_vel=-1000, max_vel=1000,
+           min_vel_step=0.2, vel_step0=5, min_vsini=0.1, max_vsini=500,
+           second_minimizer=True, config_file_path='/x/config.yaml',
+           lsf_sigma0_angstrom=SIG0)
+
+
+def test_proc_desi_nothing_selected(dcases, tmp_path):
+    """minsn above every fibre: RVTAB without rows, MODEL images without data"""
+    tab, mod = str(tmp_path / 't.fits'), str(tmp_path / 'm.fits')
+    n = D.proc_desi(COADD, tab, mod, None, CFG, doplot=False, minsn=1e9,
+                    cmdline='golden none')
+    assert n == 0 == int(dcases['none/nfit'])
+    T, M = F.open(tab, verify_checksum=True), F.open(mod, verify_checksum=True)
+    assert [h.name for h in T] == list(dcases['none/tab/extnames'])
+    assert [h.name for h in M] == list(dcases['none/mod/extnames'])
+    assert len(T['RVTAB'].data) == 0 and len(T['FIBERMAP'].data) == 0
+    assert M['B_MODEL'].data is None
+    assert _same(M['R_WAVELENGTH'].data, dcases['none/mod/R_WAVELENGTH'])
+    keys = list(dcases['none/mod/primary_keys'])
+    for k, v in zip(keys, dcases['none/mod/primary_vals']):
+        if k not in ('RVS_CONF', ):
+            assert str(M[0].header[k]) == v, k
+
+
+def test_proc_desi_unknown_targetid(dcases, tmp_path):
+    tab, mod = str(tmp_path / 't.fits'), str(tmp_path / 'm.fits')
+    n = D.proc_desi(COADD, tab, mod, None, CFG, doplot=False,
+                    fit_targetid=[77])
+    assert n == 0 == int(dcases['notid/nfit'])
+    assert [h.name for h in F.open(tab)] == list(dcases['notid/tab/extnames'])
+    assert [h.name for h in F.open(mod)] == ['PRIMARY']
+
+
+def test_proc_desi_invalid_inputs(tmp_path):
+    assert D.proc_desi(str(tmp_path / 'nope.fits'), 'a', 'b', None, CFG) == -1
+    rr = os.path.join(GOLD, 'redrock-golden.fits')  # readable, wrong layout
+    assert D.proc_desi(rr, 'a', 'b', None, CFG) == -1
+
+
+def test_proc_many_status_file(tmp_path):
+    """the wrapper's status file and the rank stride of the file list"""
+    import yaml
+    cfgf = str(tmp_path / 'c.yaml')
+    with open(cfgf, 'w') as fp:
+        yaml.safe_dump(dict(template_lib='golden-desi://'), fp)
+    st = str(tmp_path / 'status')
+    D.proc_many([COADD, str(tmp_path / 'x/y/missing.fits')], str(tmp_path),
+                'rvtab', 'rvmod', config_fname=cfgf, minsn=1e9, doplot=False,
+                subdirs=False, process_status_file=st, shard=(0, 1))
+    lines = open(st).read().split('\n')
+    assert lines[0].split()[:3] == [COADD, 'SUCCESS', '0']
+    assert lines[1].split()[1] == 'FAILURE'
+    assert os.path.exists(str(tmp_path / 'rvtab_coadd-golden.fits'))
+    st2 = str(tmp_path / 'status2')
+    D.proc_many([COADD, COADD, COADD], str(tmp_path), 'rvtab', 'rvmod',
+                config_fname=cfgf, minsn=1e9, doplot=False, subdirs=False,
+                process_status_file=st2, shard=(1, 2), skipexisting=True)
+    rows = open(st2 + '.1').read().strip().split('\n')
+    assert len(rows) == 1 and rows[0].split()[1] == 'EXISTING'

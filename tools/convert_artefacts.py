@@ -77,7 +77,9 @@ def convert(tdir, setup, continuum=True):
     out = dict(lam=np.asarray(fd['lam'], dtype=np.float64),
                log_step=np.array(bool(fd['log_step'])),
                parnames=np.array([str(_) for _ in fd['parnames']]),
-               revision=np.array(str(fd.get('revision') or '')))
+               revision=np.array(str(fd.get('revision') or '')),
+               creation_soft_version=np.array(
+                   str(fd.get('creation_soft_version') or '')))
     itype = fd.get('interpolation_type')
     if itype is None:
         itype = 'regulargrid' if 'regular' in fd else 'triangulation'

@@ -243,6 +243,11 @@ def main():
     ap.add_argument('--process-cpu-sample', type=int, default=8)
     ap.add_argument('--process-bfgs', action='store_true',
                     help='run the second_minimizer (BFGS) polish in --process')
+    ap.add_argument('--desi-file', type=int, default=0,
+                    help='add-on: write the first N spectra as a DESI coadd FITS '
+                         'file and run the driver (desi_fit.proc_desi) on it: '
+                         'read -> select -> condition -> CCF + process + '
+                         'continuum -> RVTAB/RVMOD')
     ap.add_argument('--cpu-process', action='store_true',
                     help='(cpu worker) run the oracle process stage')
     ap.add_argument('--workload', choices=['desi', 'cfg2'], default='desi',
@@ -457,6 +462,10 @@ def main():
     proc = None
     if args.process > 0 and EVALUATOR == 'polylinear':
         proc = run_process_addon(batch, rec, arms, args, dev)
+    desi = None
+    if args.desi_file > 0 and rank == 0 and EVALUATOR == 'polylinear' \
+            and args.workload == 'desi':
+        desi = run_desi_addon(arms, args, dev)
 
     line = dict(
         metric='spectra/sec (CCF+chi2 grid) DESI 3-arm',
@@ -480,6 +489,8 @@ def main():
         kernels=kernels, parity_sample=parity, setup_s=round(t_setup, 1))
     if proc is not None:
         line['process'] = proc
+    if desi is not None:
+        line['desi_file'] = desi
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
@@ -554,6 +565,81 @@ def run_process_addon(batch, rec, arms, args, dev):
                 max_dparam_over_sigma=float(np.nanmax(
                     np.abs(gp - o[:, 4:8]) / np.where(perr > 0, perr, np.nan))))
     return out
+
+
+def run_desi_addon(arms, args, dev):
+    """the survey driver end to end on one synthetic coadd
+    file of N fibres x 3 DESI arms (float32 flux/ivar, int32 mask, as the real
+    files), from the FITS bytes on disk to the RVTAB/RVMOD products."""
+    import tempfile
+    import torch
+    from rvspecfit_amd import fits_min as F
+    from rvspecfit_amd.desi import desi_fit as D
+    n = min(args.desi_file, arms[0][2].shape[0])
+    tmp = tempfile.mkdtemp(prefix='rvs_desi_')
+    fname = os.path.join(tmp, 'coadd-bench.fits')
+    hdus = [F.PrimaryHDU()]
+    hdus[0].header['SPGRP'] = 'healpix'
+    fm = F.FitsTable()
+    fm.add('TARGETID', np.arange(n, dtype=np.int64) + 39628000000000000)
+    fm.add('FIBER', np.arange(n, dtype=np.int32))
+    fm.add('TARGET_RA', np.linspace(150., 151., n))
+    fm.add('TARGET_DEC', np.linspace(2., 3., n))
+    fm.add('OBJTYPE', np.array(['TGT'] * n))
+    fm.add('COADD_FIBERSTATUS', np.zeros(n, dtype=np.int32))
+    fm.add('BRICKID', np.zeros(n, dtype=np.int32))
+    hdus.append(F.BinTableHDU(fm, name='FIBERMAP'))
+    sc = F.FitsTable()
+    sc.add('TARGETID', fm['TARGETID'])
+    nbytes = 0
+    for name, lam, spec, es, bad in arms:
+        A = name[-1].upper()
+        flux = spec[:n].float().cpu().numpy()
+        ivar = (1.0 / es[:n]**2).float().cpu().numpy()
+        mask = bad[:n].to(torch.int32).cpu().numpy()
+        hdus += [F.ImageHDU(np.asarray(lam, dtype=np.float64),
+                            name=A + '_WAVELENGTH'),
+                 F.ImageHDU(flux, name=A + '_FLUX'),
+                 F.ImageHDU(ivar, name=A + '_IVAR'),
+                 F.ImageHDU(mask, name=A + '_MASK')]
+        sc.add('MEDIAN_COADD_SNR_' + A, D.get_sns(flux, ivar, mask).astype(
+            np.float64))
+        nbytes += flux.nbytes + ivar.nbytes + mask.nbytes
+    hdus.append(F.BinTableHDU(sc, name='SCORES'))
+    F.HDUList(hdus).writeto(fname)
+    cfg = dict(CONFIG, second_minimizer=bool(args.process_bfgs),
+               config_file_path='synthetic')
+    tabf, modf = os.path.join(tmp, 'rvtab.fits'), os.path.join(tmp, 'rvmod.fits')
+    logging_off()
+    D.proc_desi(fname, tabf, modf, None, cfg, doplot=False, minsn=-1e9,
+                npoly=OPTIONS['npoly'], device=dev)      # warm-up
+    tm = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nfit = D.proc_desi(fname, tabf, modf, None, cfg, doplot=False, minsn=-1e9,
+                       npoly=OPTIONS['npoly'], device=dev, timers=tm)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tab = F.open(tabf, verify_checksum=True)['RVTAB'].data
+    warn = np.asarray(tab['RVS_WARN'])
+    out = dict(fibres=int(nfit), fibres_per_s=round(nfit / dt, 1),
+               seconds=round(dt, 2),
+               stage_s={k: round(v, 3) for k, v in tm.items()},
+               input_MB=round(os.path.getsize(fname) / 1e6, 1),
+               output_MB=round((os.path.getsize(tabf)
+                                + os.path.getsize(modf)) / 1e6, 1),
+               success_frac=round(float((warn == 0).mean()), 4),
+               second_minimizer=bool(args.process_bfgs),
+               note='add-on, not part of `value`: desi_fit.proc_desi on one '
+                    'synthetic coadd file, FITS in -> RVTAB/RVMOD out')
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def logging_off():
+    import logging
+    logging.getLogger().setLevel(logging.ERROR)
 
 
 def stage_round(d):

@@ -837,14 +837,23 @@ def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
               expid_range=None, poolex=None, fitarm=None, cmdline=None,
               zbest_select=False, zbest_include=False,
               use_resolution_matrix=False, ccf_init=True, npoly=10,
-              device='cuda', max_batch=4096):
+              device='cuda', max_batch=4096, timers=None):
     """desi_fit.py:962-1299: fit every selected fibre of one DESI file and write
     the RVTAB and RVMOD products.  `poolex` is accepted for signature
     compatibility and unused: the fibres of the file are one GPU batch (in
-    chunks of `max_batch`).  Returns the number of fibres selected, or -1."""
+    chunks of `max_batch`).  Returns the number of fibres selected, or -1.
+    `timers` (dict) receives the wall seconds of the stages read / select /
+    condition / fit / write."""
     if npoly is None:
         npoly = 10
     options = {'npoly': npoly}
+    tm = timers if timers is not None else {}
+    t_last = [time.time()]
+
+    def tick(k):
+        now = time.time()
+        tm[k] = tm.get(k, 0.) + now - t_last[0]
+        t_last[0] = now
     logging.info('Processing %s' % fname)
     try:
         FP = pyfits.open(fname)
@@ -870,6 +879,7 @@ def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
             put_empty_file(mod_ofname)
             return 0
     fluxes, ivars, masks, waves, resolutions = read_data(FP, setups)
+    tick('read')
     sn_names = scores.columns.names
     for pref in ('MEDIAN_CALIB_SNR_', 'MEDIAN_COADD_SNR_',
                  'MEDIAN_COADD_FLUX_SNR_'):
@@ -903,6 +913,7 @@ def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
         exp_fibermap_subset_hdu = pyfits.BinTableHDU(exp_fibermap[tmp_sub],
                                                      name='EXP_FIBERMAP')
     scores_subset_hdu = pyfits.BinTableHDU(scores[subset], name='SCORES')
+    tick('select')
 
     def mod_hdus(versions, models):
         hdus = [pyfits.PrimaryHDU(header=get_prim_header(
@@ -966,6 +977,7 @@ def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
                               use_resolution_matrix=use_resolution_matrix,
                               lsf_sigma0_angstrom=sig0s)
     okmat = np.stack([cond[s]['ok'] for s in setups], axis=1)
+    tick('condition')
     outdicts = [None] * nsel
     curmodels = [None] * nsel
     arms_of = [None] * nsel
@@ -986,6 +998,7 @@ def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
                 outdicts[i] = d
                 curmodels[i] = [y[k] for y in fr['yfit']]
                 arms_of[i] = names_p
+    tick('fit')
     nfibers_good = sum(_ is not None for _ in outdicts)
     good_flags = [_ is not None for _ in outdicts]
     # the reference indexes `models` (nfibers_good rows) by the ROW counter
@@ -1022,6 +1035,7 @@ def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
     assert (len(fibermap_subset_hdu.data) == len(outtab))
     write_hdulist(mod_ofname, pyfits.HDUList(mod_hdus(versions, models)))
     write_hdulist(tab_ofname, pyfits.HDUList(tab_hdus(versions, outtab)))
+    tick('write')
     return nsel
 
 

@@ -109,13 +109,25 @@ __global__ void __launch_bounds__(OBJ_NT)
     const int N4 = N & ~3;
     for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
       double a4[4] = {0, 0, 0, 0};
-      for (int v = 0; v < nv; v++) {
-        const f4u r = *reinterpret_cast<const f4u *>(T.dats + PL.id[v] * N + k);
-        const double wv = PL.w[v];
-        a4[0] = fma(wv, (double)r.x, a4[0]);
-        a4[1] = fma(wv, (double)r.y, a4[1]);
-        a4[2] = fma(wv, (double)r.z, a4[2]);
-        a4[3] = fma(wv, (double)r.w, a4[3]);
+      // the vertex rows of a batch are requested together (one L2 round trip
+      // per 16 rows instead of one per row); the sums run in vertex order
+      for (int v0 = 0; v0 < nv; v0 += 16) {
+        f4u r[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int v = min(v0 + u, nv - 1);
+          r[u] = *reinterpret_cast<const f4u *>(T.dats + PL.id[v] * N + k);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          if (v0 + u < nv) {
+            const double wv = PL.w[v0 + u];
+            a4[0] = fma(wv, (double)r[u].x, a4[0]);
+            a4[1] = fma(wv, (double)r[u].y, a4[1]);
+            a4[2] = fma(wv, (double)r[u].z, a4[2]);
+            a4[3] = fma(wv, (double)r[u].w, a4[3]);
+          }
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) bufA[k + q] = T.exp_flag ? exp(a4[q]) : a4[q];
@@ -213,11 +225,28 @@ __global__ void __launch_bounds__(OBJ_NT)
   double *ec = bufC;
   const double *g = T.factors, *e = T.factors + N, *cc = T.factors + 2 * N,
                *hh = T.factors + 3 * N, *ih = T.factors + 4 * N;
-  for (int i = tid; i < m; i += OBJ_NT) {
-    const double y1 = y[i + 1];
-    const double s0 = (y1 - y[i]) * ih[i], s1 = (y[i + 2] - y1) * ih[i + 1];
-    dp[i] = 6 * (s1 - s0) * g[i];
-    ec[i] = e[i];
+  // four rows per trip with their factor loads issued together (the factors
+  // come out of L2: one exposed round trip per trip instead of per row)
+  for (int i0 = tid; i0 < m; i0 += 4 * OBJ_NT) {
+    double f0[4], f1[4], fg[4], fe[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = min(i0 + c * OBJ_NT, m - 1);
+      f0[c] = ih[i];
+      f1[c] = ih[i + 1];
+      fg[c] = g[i];
+      fe[c] = e[i];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = i0 + c * OBJ_NT;
+      if (i < m) {
+        const double y1 = y[i + 1];
+        const double s0 = (y1 - y[i]) * f0[c], s1 = (y[i + 2] - y1) * f1[c];
+        dp[i] = 6 * (s1 - s0) * fg[c];
+        ec[i] = fe[c];
+      }
+    }
   }
   __syncthreads();
   const int CH = (m + OBJ_NT - 1) / OBJ_NT;  // <= 16 (ntp <= 8192)
@@ -238,7 +267,14 @@ __global__ void __launch_bounds__(OBJ_NT)
   for (int q = 0; q < 16; q++)
     if (a0 + q < a1) dp[a0 + q] = loc[q];
   __syncthreads();
-  for (int i = tid; i < m; i += OBJ_NT) ec[i] = cc[i];
+  for (int i0 = tid; i0 < m; i0 += 4 * OBJ_NT) {
+    double fc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) fc[c] = cc[min(i0 + c * OBJ_NT, m - 1)];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      if (i0 + c * OBJ_NT < m) ec[i0 + c * OBJ_NT] = fc[c];
+  }
   __syncthreads();
   {
     double z = 0;
@@ -292,13 +328,22 @@ __global__ void __launch_bounds__(OBJ_NT)
   for (int i = 0; i < NT; i++) acc[i] = 0;
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = 0;
+  // model / data in units of sigma are parked in the (now free) factor buffer
+  // for the residual pass when they fit: [npix] t_k/e_k, [npix] s_k/e_k
+  const bool cached = 2 * npix <= N;
+  double *tcache = bufC;
   for (int k = tid; k < npix; k += OBJ_NT) {
     const double tv = tv_at(k);
     double ee = es[k];
     if (espec_sys > 0) ee = sqrt(sys2 + ee * ee);
     const double ie = 1.0 / ee;
     const double te = tv * ie;
-    const double wt = te * te, u = te * (sp[k] * ie);
+    const double dk = sp[k] * ie;
+    const double wt = te * te, u = te * dk;
+    if (cached) {
+      tcache[k] = te;
+      tcache[npix + k] = dk;
+    }
     const double *pr = S.polysT + (int64_t)k * P;
     double pv[P], pw[P];
 #pragma unroll
@@ -315,15 +360,40 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
   }
   OBJ_T(4);
+  {
+    // wave reduction of the NV sums by halving: at the step with lane mask m
+    // the lanes l and l^m split the live sums between them (the lane with the
+    // bit clear keeps the lower half), so a step moves half as many values as
+    // the one before: ~NV exchanges in all instead of NV full butterflies.
+    // After the six steps every total sits in exactly one lane.
+    double vals[NV];
 #pragma unroll
-  for (int i = 0; i < NT; i++) {
-    const double v = wave_sum_to63(acc[i]);
-    if (lane == 63) red[w][i] = v;
-  }
+    for (int i = 0; i < NT; i++) vals[i] = acc[i];
 #pragma unroll
-  for (int i = 0; i < P; i++) {
-    const double v = wave_sum_to63(av[i]);
-    if (lane == 63) red[w][NT + i] = v;
+    for (int i = 0; i < P; i++) vals[NT + i] = av[i];
+    // slot i of a lane stands for sum number base + i; lim = end of the
+    // range that is really this lane's (an odd count leaves the upper lanes a
+    // zero slot whose number belongs to another lane group)
+    int cnt = NV, base = 0, lim = NV;
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) {
+      const int h = (cnt + 1) >> 1;
+      const bool up = (lane & mk) != 0;
+#pragma unroll
+      for (int i = 0; i < h; i++) {
+        const bool has_hi = (i + h < cnt);
+        const double lo = vals[i], hi = has_hi ? vals[i + h] : 0.0;
+        const double send = up ? lo : hi;
+        const double keep = up ? hi : lo;
+        vals[i] = keep + __shfl_xor(send, mk, 64);
+      }
+      lim = up ? lim : min(lim, base + h);
+      base += up ? h : 0;
+      cnt = h;
+    }
+#pragma unroll
+    for (int i = 0; i < (NV + 63) / 64 + 1; i++)
+      if (i < cnt && base + i < lim) red[w][base + i] = vals[i];
   }
   __syncthreads();
   if (w == 0) {
@@ -350,6 +420,7 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
     for (int q = 1; q < OBJ_NW; q++) vi += red[q][NT + i];
     bool ok = true;
+    double dg = 1.0;  // this lane's diagonal element of L
 #pragma unroll
     for (int jj = 0; jj < P; jj++) {
       double sum = row[jj];
@@ -360,7 +431,7 @@ __global__ void __launch_bounds__(OBJ_NT)
         const double d = sqrt(sum);
         row[jj] = d;
         Lm[jj][jj] = d;
-        ldv[jj] = log(d);
+        dg = d;
       }
       __builtin_amdgcn_wave_barrier();
       if (i > jj) {
@@ -369,6 +440,8 @@ __global__ void __launch_bounds__(OBJ_NT)
       }
       __builtin_amdgcn_wave_barrier();
     }
+    // log of the diagonal: all rows at once (not one per column of the loop)
+    if (lane < P) ldv[lane] = log(dg);
     // L y = v
     double si = vi;
 #pragma unroll
@@ -403,15 +476,23 @@ __global__ void __launch_bounds__(OBJ_NT)
   for (int i = 0; i < P; i++) av[i] = coefs[i];
   double rr = 0;
   for (int k = tid; k < npix; k += OBJ_NT) {
-    const double tv = tv_at(k);
-    double ee = es[k];
-    if (espec_sys > 0) ee = sqrt(sys2 + ee * ee);
-    const double ie = 1.0 / ee;
+    double te, dk;
+    if (cached) {
+      te = tcache[k];
+      dk = tcache[npix + k];
+    } else {
+      const double tv = tv_at(k);
+      double ee = es[k];
+      if (espec_sys > 0) ee = sqrt(sys2 + ee * ee);
+      const double ie = 1.0 / ee;
+      te = tv * ie;
+      dk = sp[k] * ie;
+    }
     const double *pr = S.polysT + (int64_t)k * P;
     double mdl = 0;
 #pragma unroll
     for (int i = 0; i < P; i++) mdl = fma(av[i], pr[i], mdl);
-    const double r = sp[k] * ie - mdl * (tv * ie);
+    const double r = dk - mdl * te;
     rr = fma(r, r, rr);
   }
   OBJ_T(6);
@@ -518,13 +599,13 @@ extern "C" int rvs_objective_fused(const rvs_objective_arm *arms, int narm,
     shm = max(shm, (size_t)3 * arms[i].ntp * sizeof(double));
   }
   for (int i = narm; i < RVS_MAX_ARMS; i++) A.a[i] = arms[0];
-  if (shm > (size_t)3 * rvs_objective_max_ntp(npoly) * sizeof(double))
-    return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
   double *armchi = (double *)scratch;
   double *armout = armchi + (int64_t)narm * J;
   int32_t *armst = (int32_t *)(armout + (int64_t)narm * J);
   dim3 grid(J, narm);
+  if (shm > (size_t)3 * rvs_objective_max_ntp(npoly) * sizeof(double))
+    return RVS_E_ARG;
 #define RVS_CASE(PP)                                                           \
   case PP: {                                                                   \
     static bool attr_set = false;                                              \

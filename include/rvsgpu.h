@@ -308,6 +308,33 @@ int rvs_objective_fused(const rvs_objective_arm *arms, int narm, int npoly,
                         double *out, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Host side of the second minimiser of vel_fit.process (vel_fit.py:653-658:
+ * scipy.optimize.minimize(method='BFGS', options={'hess_inv0': ...})): S
+ * independent BFGS runs (scipy's _minimize_bfgs with its wolfe1 / wolfe2 line
+ * searches and 2-point forward-difference gradients) advanced in lock-step.
+ * The caller owns the objective:
+ *     h = rvs_bfgs_begin(S, n, x0 [S,n], hess_inv0 [n,n] or NULL, gtol, c1, c2,
+ *                        xrtol, maxiter (<= 0: 200 n))
+ *     while ((rows = rvs_bfgs_pending(h, idx, X, cap)) > 0) {
+ *         F[r] = objective(spectrum idx[r], point X[r, :]),  r < rows
+ *         rvs_bfgs_feed(h, F, rows);
+ *     }
+ *     rvs_bfgs_result(h, x [S,n], fun [S], nit, nfev, status [S] (scipy's
+ *                     warnflag), hess_inv [S,n,n] or NULL, &rounds);
+ *     rvs_bfgs_end(h);
+ * cap >= S (n + 1) rows always suffices.  n <= 16.  No GPU work in here.
+ * ---------------------------------------------------------------------- */
+void *rvs_bfgs_begin(int S, int n, const double *x0, const double *hess_inv0,
+                     double gtol, double c1, double c2, double xrtol,
+                     int maxiter);
+int64_t rvs_bfgs_pending(void *h, int64_t *idx, double *X, int64_t cap_rows);
+int rvs_bfgs_feed(void *h, const double *F, int64_t nrows);
+int rvs_bfgs_result(void *h, double *x, double *fun, int32_t *nit,
+                    int32_t *nfev, int32_t *status, double *hess_inv,
+                    int64_t *rounds);
+void rvs_bfgs_end(void *h);
+
+/* ------------------------------------------------------------------------
  * A12  grid summary; replaces the tail of spec_fit.find_best
  * (spec_fit.py:1072-1092) and _quadratic_interp_min (:992-1015).
  * chisq [G, Np, Nv] (velocity fastest); vels + g*vel_stride -> [Nv];

@@ -49,6 +49,11 @@ SIGNATURES = {
     'rvs_proc_map': (I, [I, I, I, P, P, P, I, P, P, P, P, P, D, D, D, P, P, P, P,
                           P, P, P]),
     'rvs_proc_finish': (I, [I, P, I, P, P, P, P, P, P, P, P]),
+    'rvs_bfgs_begin': (P, [I, I, P, P, D, D, D, D, I]),
+    'rvs_bfgs_pending': (L, [P, P, P, L]),
+    'rvs_bfgs_feed': (I, [P, P, L]),
+    'rvs_bfgs_result': (I, [P, P, P, P, P, P, P, P]),
+    'rvs_bfgs_end': (None, [P]),
     'rvs_objective_max_ntp': (I, [I]),
     'rvs_objective_work_size': (L, [I, I]),
     'rvs_objective_fused': (I, [P, I, I, P, P, P, I, P, D, I, P, P, P, P]),

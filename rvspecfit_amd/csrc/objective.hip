@@ -254,7 +254,23 @@ __global__ void __launch_bounds__(OBJ_NT)
   double loc[16];
   {
     double d = 0;
-    for (int i = max(0, a0 - OBJ_W); i < a0; i++) d = dp[i] - ec[i] * d;
+    // warm-up rows, eight LDS pairs requested per trip (rows below 0 do not
+    // exist: the recurrence starts there with d = 0)
+#pragma unroll 1
+    for (int q0 = -OBJ_W; q0 < 0; q0 += 8) {
+      double pd[8], pe[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int ii = max(a0 + q0 + c, 0);
+        pd[c] = dp[ii];
+        pe[c] = ec[ii];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const double dn = pd[c] - pe[c] * d;
+        d = (a0 + q0 + c >= 0) ? dn : d;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 16; q++)
       if (a0 + q < a1) {
@@ -278,7 +294,21 @@ __global__ void __launch_bounds__(OBJ_NT)
   __syncthreads();
   {
     double z = 0;
-    for (int i = min(m, a1 + OBJ_W) - 1; i >= a1; i--) z = dp[i] - ec[i] * z;
+#pragma unroll 1
+    for (int q0 = OBJ_W - 1; q0 >= 0; q0 -= 8) {
+      double pd[8], pe[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int ii = min(a1 + q0 - c, m - 1);
+        pd[c] = dp[ii];
+        pe[c] = ec[ii];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const double zn = pd[c] - pe[c] * z;
+        z = (a1 + q0 - c < m) ? zn : z;
+      }
+    }
 #pragma unroll
     for (int q = 15; q >= 0; q--)
       if (a0 + q < a1) {
@@ -329,28 +359,92 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = 0;
   // model / data in units of sigma are parked in the (now free) factor buffer
-  // for the residual pass when they fit: [npix] t_k/e_k, [npix] s_k/e_k
+  // when they fit: [npix] t_k/e_k, [npix] s_k/e_k.  They are produced by a
+  // first pass that holds no accumulators, so it is unrolled over the pixels
+  // of a thread with each round of loads issued together (pixel terms, then
+  // the knot terms that depend on the interval index): two L2 round trips for
+  // six pixels instead of two per pixel.
   const bool cached = 2 * npix <= N;
   double *tcache = bufC;
-  for (int k = tid; k < npix; k += OBJ_NT) {
-    const double tv = tv_at(k);
-    double ee = es[k];
-    if (espec_sys > 0) ee = sqrt(sys2 + ee * ee);
-    const double ie = 1.0 / ee;
-    const double te = tv * ie;
-    const double dk = sp[k] * ie;
-    const double wt = te * te, u = te * dk;
-    if (cached) {
-      tcache[k] = te;
-      tcache[npix + k] = dk;
+  if (cached) {
+    constexpr int U = 6;
+    for (int kb = tid; kb < npix; kb += U * OBJ_NT) {
+      double lm[U], wk[U], e_[U], s_[U], kn[U], hk[U], ik[U];
+      int ps[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int k = min(kb + u * OBJ_NT, npix - 1);
+        lm[u] = S.lam[k];
+        wk[u] = S.log_step ? S.work[k] : 0.0;
+        e_[u] = es[k];
+        s_[u] = sp[k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        lm[u] *= f;
+        int pos = S.log_step ? (int)(wk[u] + shift)
+                             : (int)((lm[u] - x0) * lin_inv_step);
+        pos = min(max(pos, 0), N - 2);
+        ps[u] = pos;
+        kn[u] = S.knots[pos];
+        hk[u] = hh[pos];
+        ik[u] = ih[pos];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int k = kb + u * OBJ_NT, pos = ps[u];
+        const double dl = lm[u] - kn[u];
+        const double h = hk[u], hinv = ik[u];
+        const double zi = (pos == 0) ? 0.0 : dp[pos - 1];
+        const double zi1 = (pos + 1 == N - 1) ? 0.0 : dp[pos];
+        const double yi = y[pos], yi1 = y[pos + 1];
+        const double t1 = hinv * (1.0 / 6), t2 = h * (1.0 / 6);
+        const double cb = (yi1 - yi) * hinv - t2 * (2 * zi + zi1);
+        const double c2 = 0.5 * zi, c3 = (zi1 - zi) * t1;
+        const double tv = fma(fma(fma(c3, dl, c2), dl, cb), dl, yi);
+        double ee = e_[u];
+        if (espec_sys > 0) ee = sqrt(sys2 + ee * ee);
+        const double ie = 1.0 / ee;
+        if (k < npix) {
+          tcache[k] = tv * ie;
+          tcache[npix + k] = s_[u] * ie;
+        }
+      }
     }
-    const double *pr = S.polysT + (int64_t)k * P;
+  }
+  OBJ_T(7);
+  // basis rows one pixel ahead: the P loads of the next pixel are in flight
+  // while the P(P+3)/2 FMAs of the current one issue
+  double pn[P];
+  {
+    const double *pr = S.polysT + (int64_t)min(tid, npix - 1) * P;
+#pragma unroll
+    for (int i = 0; i < P; i++) pn[i] = pr[i];
+  }
+  for (int k = tid; k < npix; k += OBJ_NT) {
+    double te, dk;
+    if (cached) {  // written by this same thread above
+      te = tcache[k];
+      dk = tcache[npix + k];
+    } else {
+      const double tv = tv_at(k);
+      double ee = es[k];
+      if (espec_sys > 0) ee = sqrt(sys2 + ee * ee);
+      const double ie = 1.0 / ee;
+      te = tv * ie;
+      dk = sp[k] * ie;
+    }
+    const double wt = te * te, u = te * dk;
     double pv[P], pw[P];
 #pragma unroll
-    for (int i = 0; i < P; i++) {
-      pv[i] = pr[i];
-      pw[i] = pv[i] * wt;
+    for (int i = 0; i < P; i++) pv[i] = pn[i];
+    {
+      const double *pr = S.polysT + (int64_t)min(k + OBJ_NT, npix - 1) * P;
+#pragma unroll
+      for (int i = 0; i < P; i++) pn[i] = pr[i];
     }
+#pragma unroll
+    for (int i = 0; i < P; i++) pw[i] = pv[i] * wt;
 #pragma unroll
     for (int i = 0; i < P; i++) {
       av[i] = fma(pv[i], u, av[i]);
@@ -396,31 +490,31 @@ __global__ void __launch_bounds__(OBJ_NT)
       if (i < cnt && base + i < lim) red[w][base + i] = vals[i];
   }
   __syncthreads();
+  // fold of the waves' partial sums (wave order), one sum per thread
+  if (tid < NV) {
+    double v = red[0][tid];
+#pragma unroll
+    for (int q = 1; q < OBJ_NW; q++) v += red[q][tid];
+    red[0][tid] = v;
+  }
+  __syncthreads();
   if (w == 0) {
-    // Cholesky + the two triangular solves with ROW i on lane i (i < P): the
-    // same operations in the same order as the in-lane version of the other
-    // chi^2 kernels (left-looking, sums over q ascending), but the rows advance
-    // side by side: the serial chain is P columns instead of P(P+1)/2 entries.
-    // L is mirrored in LDS so that a lane can read another row (same wave:
-    // LDS operations of one wave complete in order).
+    // Cholesky + the two triangular solves with ROW i on lane i (i < P):
+    // left-looking, sums over q ascending as in the in-lane version of the
+    // other chi^2 kernels, but the rows advance side by side: the serial chain
+    // is P columns instead of P(P+1)/2 entries.  L is mirrored in LDS so that a
+    // lane can read another row (same wave: LDS operations complete in order).
     const int i = lane < P ? lane : P - 1;
     double row[P];
-    double vi = 0;
 #pragma unroll
-    for (int jj = 0; jj < P; jj++) {
-      double v = 0;
-      if (jj <= i) {
-        v = red[0][TRI(i, jj)];
-#pragma unroll
-        for (int q = 1; q < OBJ_NW; q++) v += red[q][TRI(i, jj)];
-      }
-      row[jj] = v;
-    }
-    vi = red[0][NT + i];
-#pragma unroll
-    for (int q = 1; q < OBJ_NW; q++) vi += red[q][NT + i];
+    for (int jj = 0; jj < P; jj++) row[jj] = (jj <= i) ? red[0][TRI(i, jj)] : 0.0;
+    const double vi = red[0][NT + i];
     bool ok = true;
-    double dg = 1.0;  // this lane's diagonal element of L
+    // dg / rdg: this lane's diagonal element of L and its reciprocal.  The
+    // off-diagonal elements and the two triangular solves multiply by the
+    // reciprocal (one division per column on the serial chain instead of
+    // three); against x / d this moves results by an ulp.
+    double dg = 1.0, rdg = 1.0;
 #pragma unroll
     for (int jj = 0; jj < P; jj++) {
       double sum = row[jj];
@@ -430,36 +524,36 @@ __global__ void __launch_bounds__(OBJ_NT)
         if (!(sum > 0)) ok = false;
         const double d = sqrt(sum);
         row[jj] = d;
-        Lm[jj][jj] = d;
         dg = d;
+        rdg = 1.0 / d;
+        Lm[jj][jj] = rdg;
       }
       __builtin_amdgcn_wave_barrier();
       if (i > jj) {
-        row[jj] = sum / Lm[jj][jj];
+        row[jj] = sum * Lm[jj][jj];
         Lm[i][jj] = row[jj];
       }
       __builtin_amdgcn_wave_barrier();
     }
     // log of the diagonal: all rows at once (not one per column of the loop)
     if (lane < P) ldv[lane] = log(dg);
-    // L y = v
+    // L y = v, column by column: lane q publishes y_q, the rows below take
+    // their share
     double si = vi;
 #pragma unroll
     for (int q = 0; q < P; q++) {
-      if (lane == q) yv[q] = si / row[q];
+      if (lane == q) yv[q] = si * rdg;
       __builtin_amdgcn_wave_barrier();
       if (i > q) si -= row[q] * yv[q];
     }
-    // L^T a = y: a_i = (y_i - sum_{q>i} L[q][i] a_q) / L[i][i], q ascending
+    // L^T a = y the same way from the last row up: lane ii publishes a_ii, the
+    // rows above subtract L[ii][i] a_ii (column i of L, read from the mirror)
+    double ti = (lane < P) ? yv[i] : 0.0;
 #pragma unroll
     for (int ii = P - 1; ii >= 0; ii--) {
-      if (lane == ii) {
-        double sum = yv[ii];
-#pragma unroll
-        for (int q = ii + 1; q < P; q++) sum -= Lm[q][ii] * coefs[q];
-        coefs[ii] = sum / row[ii];
-      }
+      if (lane == ii) coefs[ii] = ti * rdg;
       __builtin_amdgcn_wave_barrier();
+      if (i < ii) ti -= Lm[ii][i] * coefs[ii];
     }
     const unsigned long long okm = __ballot(ok || lane >= P);
     if (lane == 0) {

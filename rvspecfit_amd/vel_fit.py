@@ -9,6 +9,7 @@ rank 1); see its docstring for what differs from the reference.
 import itertools
 import logging
 import math
+import os
 import time
 
 import numpy as np
@@ -285,6 +286,7 @@ def _uncertainties_from_hessian(hessian):
 
 # vel_fit.py:653-658 second_minimizer (BFGS, bfgs.py) when the config asks for it
 RUN_SECOND_MINIMIZER = True
+BFGS_IMPL = os.environ.get('RVS_BFGS', 'native')
 
 # lock-step simplices driven by the rvs_nm_* kernels (optimizer.py); False = the
 # pure-torch state machine of neldermead.py (same path, ~3x slower)
@@ -507,8 +509,12 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
             return obj(it, torch.as_tensor(X_np).to(dev)).cpu().numpy()
 
         hess_inv0 = get_hess_inv(mapper.get_fitted_params())
-        br = bfgs.minimize_lockstep(rows, x.cpu().numpy(), hess_inv0=hess_inv0,
-                                    max_rows=max(S, 1024))
+        # C++ state machines by default (csrc/bfgs_host.cpp); RVS_BFGS=python
+        # runs the scipy-pinned generator version of the same algorithm
+        run = bfgs.minimize_lockstep if BFGS_IMPL == 'python' else \
+            bfgs.minimize_lockstep_native
+        br = run(rows, x.cpu().numpy(), hess_inv0=hess_inv0,
+                 max_rows=max(S, 1024))
         x = torch.as_tensor(br['x']).to(dev)
         second_run = True
         bfgs_info = dict(nit=br['nit'], nfev=br['nfev'], status=br['status'],

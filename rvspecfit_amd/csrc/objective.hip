@@ -107,30 +107,70 @@ __global__ void __launch_bounds__(OBJ_NT)
     // wave instruction instead of 256 B
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     const int N4 = N & ~3;
-    for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
-      double a4[4] = {0, 0, 0, 0};
-      // the vertex rows of a batch are requested together (one L2 round trip
-      // per 16 rows instead of one per row); the sums run in vertex order
-      for (int v0 = 0; v0 < nv; v0 += 16) {
+    if (nv <= 16) {
+      // up to 4-D grids: the 2^ndim vertex rows of a pixel group are requested
+      // together, and the group after it before this one is consumed (one L2
+      // round trip per group, hidden behind the conversions, FMAs and exps of
+      // the previous group); the sums run in vertex order
+      f4u rn[16];
+      int k = 4 * tid;
+      if (k < N4) {
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+          rn[u] = *reinterpret_cast<const f4u *>(
+              T.dats + PL.id[min(u, nv - 1)] * N + k);
+      }
+      for (; k < N4; k += 4 * OBJ_NT) {
         f4u r[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
-          const int v = min(v0 + u, nv - 1);
-          r[u] = *reinterpret_cast<const f4u *>(T.dats + PL.id[v] * N + k);
+        for (int u = 0; u < 16; u++) r[u] = rn[u];
+        const int kn = k + 4 * OBJ_NT;
+        if (kn < N4) {
+#pragma unroll
+          for (int u = 0; u < 16; u++)
+            rn[u] = *reinterpret_cast<const f4u *>(
+                T.dats + PL.id[min(u, nv - 1)] * N + kn);
         }
+        double a4[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-          if (v0 + u < nv) {
-            const double wv = PL.w[v0 + u];
+          if (u < nv) {
+            const double wv = PL.w[u];
             a4[0] = fma(wv, (double)r[u].x, a4[0]);
             a4[1] = fma(wv, (double)r[u].y, a4[1]);
             a4[2] = fma(wv, (double)r[u].z, a4[2]);
             a4[3] = fma(wv, (double)r[u].w, a4[3]);
           }
         }
-      }
 #pragma unroll
-      for (int q = 0; q < 4; q++) bufA[k + q] = T.exp_flag ? exp(a4[q]) : a4[q];
+        for (int q = 0; q < 4; q++)
+          bufA[k + q] = T.exp_flag ? exp(a4[q]) : a4[q];
+      }
+    } else {
+      for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
+        double a4[4] = {0, 0, 0, 0};
+        for (int v0 = 0; v0 < nv; v0 += 16) {
+          f4u r[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) {
+            const int v = min(v0 + u, nv - 1);
+            r[u] = *reinterpret_cast<const f4u *>(T.dats + PL.id[v] * N + k);
+          }
+#pragma unroll
+          for (int u = 0; u < 16; u++) {
+            if (v0 + u < nv) {
+              const double wv = PL.w[v0 + u];
+              a4[0] = fma(wv, (double)r[u].x, a4[0]);
+              a4[1] = fma(wv, (double)r[u].y, a4[1]);
+              a4[2] = fma(wv, (double)r[u].z, a4[2]);
+              a4[3] = fma(wv, (double)r[u].w, a4[3]);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          bufA[k + q] = T.exp_flag ? exp(a4[q]) : a4[q];
+      }
     }
     for (int k = N4 + tid; k < N; k += OBJ_NT) {
       double acc = 0;
@@ -249,40 +289,62 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
   }
   __syncthreads();
-  const int CH = (m + OBJ_NT - 1) / OBJ_NT;  // <= 16 (ntp <= 8192)
+  // Chunked Thomas with chunk transfer coefficients.  Thread t owns rows
+  // [a0, a1) (>= 12 of them).  Both recurrences are linear in the value that
+  // enters the chunk: d_i = d0_i + P_i d_in with d0 the run from zero and P_i
+  // the running product of the multipliers, so one pass over the chunk yields
+  // (alpha, beta) = (d0, P) at its last row, and
+  //   d_in(t) = alpha(t-1) + beta(t-1) (alpha(t-2) + beta(t-2) alpha(t-3))
+  // to |beta|^3 <= (0.268^12)^3 = 3e-21 (the multipliers of a (log-)uniform
+  // grid tend to 2 - sqrt 3).  Against warming every chunk up over 32 extra
+  // rows this reads each row once instead of 3.5 times (the phase is bound by
+  // LDS bandwidth) and takes two barriers fewer.
+  const int CH = max(12, (m + OBJ_NT - 1) / OBJ_NT);  // <= 16 (ntp <= 8192)
   const int a0 = min(m, tid * CH), a1 = min(m, a0 + CH);
-  double loc[16];
-  {
-    double d = 0;
-    // warm-up rows, eight LDS pairs requested per trip (rows below 0 do not
-    // exist: the recurrence starts there with d = 0)
-#pragma unroll 1
-    for (int q0 = -OBJ_W; q0 < 0; q0 += 8) {
-      double pd[8], pe[8];
+  double loc[16], pr[16];
+  // value entering a chunk from `dir` = -1 (lower threads) or +1 (upper): the
+  // three nearest chunks' coefficients through wave shuffles, across a wave
+  // boundary through red[] (static LDS, free until the reductions)
+  auto chain3 = [&](double al, double be, int dir) -> double {
+    double av3[3], bv3[3];
 #pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const int ii = max(a0 + q0 + c, 0);
-        pd[c] = dp[ii];
-        pe[c] = ec[ii];
-      }
+    for (int k = 1; k <= 3; k++) {
+      av3[k - 1] = (dir < 0) ? __shfl_up(al, k, 64) : __shfl_down(al, k, 64);
+      bv3[k - 1] = (dir < 0) ? __shfl_up(be, k, 64) : __shfl_down(be, k, 64);
+    }
+    const int edge = (dir < 0) ? (63 - lane) : lane;  // 0..2: published lanes
+    if (edge < 3) {
+      red[w][2 * edge] = al;
+      red[w][2 * edge + 1] = be;
+    }
+    __syncthreads();
+    const int mine = (dir < 0) ? lane : (63 - lane);  // distance to the boundary
 #pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const double dn = pd[c] - pe[c] * d;
-        d = (a0 + q0 + c >= 0) ? dn : d;
+    for (int k = 1; k <= 3; k++) {
+      if (mine < k) {  // neighbour k lives in the adjacent wave
+        const int ww = w + dir;
+        const int sl = k - 1 - mine;  // its distance from that wave's boundary
+        const bool have = (ww >= 0 && ww < OBJ_NW);
+        av3[k - 1] = have ? red[ww][2 * sl] : 0.0;
+        bv3[k - 1] = have ? red[ww][2 * sl + 1] : 0.0;
       }
     }
+    return av3[0] + bv3[0] * (av3[1] + bv3[1] * av3[2]);
+  };
+  double d_in;
+  {
+    double d = 0, pb = 1;
 #pragma unroll
     for (int q = 0; q < 16; q++)
       if (a0 + q < a1) {
-        d = dp[a0 + q] - ec[a0 + q] * d;
+        const double ei = ec[a0 + q];
+        d = dp[a0 + q] - ei * d;
+        pb = -ei * pb;
         loc[q] = d;
+        pr[q] = pb;
       }
+    d_in = chain3(d, pb, -1);  // (barrier inside: all reads of ec are done)
   }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 16; q++)
-    if (a0 + q < a1) dp[a0 + q] = loc[q];
-  __syncthreads();
   for (int i0 = tid; i0 < m; i0 += 4 * OBJ_NT) {
     double fc[4];
 #pragma unroll
@@ -291,35 +353,26 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int c = 0; c < 4; c++)
       if (i0 + c * OBJ_NT < m) ec[i0 + c * OBJ_NT] = fc[c];
   }
+#pragma unroll
+  for (int q = 0; q < 16; q++)
+    if (a0 + q < a1) loc[q] = loc[q] + pr[q] * d_in;  // d of the forward sweep
   __syncthreads();
   {
-    double z = 0;
-#pragma unroll 1
-    for (int q0 = OBJ_W - 1; q0 >= 0; q0 -= 8) {
-      double pd[8], pe[8];
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const int ii = min(a1 + q0 - c, m - 1);
-        pd[c] = dp[ii];
-        pe[c] = ec[ii];
-      }
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const double zn = pd[c] - pe[c] * z;
-        z = (a1 + q0 - c < m) ? zn : z;
-      }
-    }
+    double z = 0, pb = 1;
 #pragma unroll
     for (int q = 15; q >= 0; q--)
       if (a0 + q < a1) {
-        z = dp[a0 + q] - ec[a0 + q] * z;
+        const double ci = ec[a0 + q];
+        z = loc[q] - ci * z;
+        pb = -ci * pb;
         loc[q] = z;
+        pr[q] = pb;
       }
-  }
-  __syncthreads();
+    const double z_in = chain3(z, pb, +1);
 #pragma unroll
-  for (int q = 0; q < 16; q++)
-    if (a0 + q < a1) dp[a0 + q] = loc[q];
+    for (int q = 0; q < 16; q++)
+      if (a0 + q < a1) dp[a0 + q] = loc[q] + pr[q] * z_in;
+  }
   __syncthreads();
   OBJ_T(3);
   // dp[u] = z at knot u+1; spline piece i in powers of dl = x - x_i exactly as

@@ -426,10 +426,10 @@ def _interp_bad_rows(spec, mask):
     (np.interp works in float64 and the result is stored back)."""
     n, npix = spec.shape
     out = spec * 1
-    idx = np.arange(npix)[None, :]
+    idx = np.arange(npix, dtype=np.int32)[None, :]
     good = ~mask
-    prev = np.maximum.accumulate(np.where(good, idx, -1), axis=1)
-    nxt = np.minimum.accumulate(np.where(good, idx, npix)[:, ::-1],
+    prev = np.maximum.accumulate(np.where(good, idx, np.int32(-1)), axis=1)
+    nxt = np.minimum.accumulate(np.where(good, idx, np.int32(npix))[:, ::-1],
                                 axis=1)[:, ::-1]
     rr, cc = np.nonzero(mask & good.any(axis=1)[:, None])
     if len(rr) == 0:
@@ -467,6 +467,22 @@ def _medspec(spec, badmask):
     return medspec
 
 
+def _row_nanmedian(a):
+    """np.nanmedian(a[i]) for every row, without the per-row Python call:
+    sorted rows (NaNs last), the middle element or the mean of the two middle
+    ones in the array's own dtype -- the numbers np.median produces."""
+    n = a.shape[0]
+    srt = np.sort(a, axis=1)
+    cnt = (~np.isnan(a)).sum(axis=1)
+    r = np.arange(n)
+    lo = srt[r, np.maximum((cnt - 1) // 2, 0)]
+    hi = srt[r, np.maximum(cnt // 2, 0)]
+    with np.errstate(all='ignore'):
+        med = (lo + hi) / a.dtype.type(2)
+    med = np.where(lo == hi, lo, med)  # also keeps +-inf medians exact
+    return np.where(cnt > 0, med, a.dtype.type(np.nan)), cnt
+
+
 def get_specdata_batch(waves, fluxes, ivars, masks, resolutions, seqids, setups,
                        use_resolution_matrix=False, mask_dicroic=True,
                        lsf_sigma0_angstrom=None):
@@ -483,8 +499,11 @@ def get_specdata_batch(waves, fluxes, ivars, masks, resolutions, seqids, setups,
         badmask = masks[s][seqids] > 0
         n, npix = spec.shape
         med = np.ones(n, dtype=np.float64)
-        ok = np.zeros(n, dtype=bool)
-        for i in range(n):
+        rowmed, _ = _row_nanmedian(spec)
+        ok = ~badmask.all(axis=1) & np.isfinite(rowmed) & (rowmed != 0)
+        med[ok] = rowmed[ok]
+        # median exactly zero: the reference's fall-backs, row by row (rare)
+        for i in np.nonzero(~badmask.all(axis=1) & (rowmed == 0))[0]:
             m = _medspec(spec[i], badmask[i])
             if m is not None:
                 med[i], ok[i] = m, True
@@ -512,20 +531,22 @@ def get_specdata_batch(waves, fluxes, ivars, masks, resolutions, seqids, setups,
         spec = _interp_bad_rows(spec, badall_interp)
         with np.errstate(all='ignore'):
             espec = (1. / np.sqrt(curivars)).astype(curivars.dtype)
-        for i in range(n):
-            if not ok[i]:
-                continue
-            if badall[i].all():
-                logging.warning('The whole spectrum was masked...')
-                continue
-            goodespec = espec[i][~badall[i]]
-            thresh = np.float64(np.median(goodespec)) * MINERR_FRAC
-            # float32 array against a float64 scalar: compared in float32
-            replace_idx = (espec[i] < espec.dtype.type(thresh)) & (~badall[i])
-            if replace_idx.sum() / (~badall[i]).sum() > .01:
-                logging.warning(
-                    'More than 1% of spectra had the uncertainty clamped')
-            espec[i][replace_idx] = thresh
+        # sigma floor: 0.3 x the median error of the good pixels of the row
+        ngood = (~badall).sum(axis=1)
+        for i in np.nonzero(ok & (ngood == 0))[0]:
+            logging.warning('The whole spectrum was masked...')
+        gmed, _ = _row_nanmedian(np.where(badall, espec.dtype.type(np.nan),
+                                          espec))
+        thresh = gmed.astype(np.float64) * MINERR_FRAC
+        # float32 array against a float64 scalar: compared in float32
+        with np.errstate(all='ignore'):
+            replace = (espec < thresh.astype(espec.dtype)[:, None]) & ~badall & \
+                (ok & (ngood > 0))[:, None]
+        nrep = replace.sum(axis=1)
+        for i in np.nonzero(nrep / np.maximum(ngood, 1) > .01)[0]:
+            logging.warning(
+                'More than 1% of spectra had the uncertainty clamped')
+        espec = np.where(replace, thresh.astype(espec.dtype)[:, None], espec)
         out[s] = dict(spec=spec.astype(np.float64), espec=espec.astype(np.float64),
                       badmask=badall, ok=ok, taps=taps)
     return out

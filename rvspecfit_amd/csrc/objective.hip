@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   __shared__ double red[OBJ_NW][NV + 1];
   __shared__ double coefs[P + 2];
   __shared__ double Lm[P][P + 1];
-  __shared__ double yv[P], ldv[P];
+  __shared__ double ldv[P];
   __shared__ double red8[16];
   const rvs_objective_arm &T = A.a[blockIdx.y];
   const int j = blockIdx.x, tid = threadIdx.x;
@@ -563,50 +563,57 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int jj = 0; jj < P; jj++) row[jj] = (jj <= i) ? red[0][TRI(i, jj)] : 0.0;
     const double vi = red[0][NT + i];
     bool ok = true;
-    // dg / rdg: this lane's diagonal element of L and its reciprocal.  The
-    // off-diagonal elements and the two triangular solves multiply by the
-    // reciprocal (one division per column on the serial chain instead of
-    // three); against x / d this moves results by an ulp.
+    // dg / rdg: this lane's diagonal element of L and its reciprocal (the
+    // off-diagonal elements and both triangular solves multiply by it: one
+    // division per column on the serial chain).  A value of another row is a
+    // register of another lane with a compile-time lane number: v_readlane,
+    // no LDS round trip and no barrier on the chain.
+    auto bcast = [](double v, int src) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+      return __hiloint2double(hi, lo);
+    };
     double dg = 1.0, rdg = 1.0;
 #pragma unroll
     for (int jj = 0; jj < P; jj++) {
       double sum = row[jj];
 #pragma unroll
-      for (int q = 0; q < jj; q++) sum -= row[q] * Lm[jj][q];
+      for (int q = 0; q < jj; q++) sum -= row[q] * bcast(row[q], jj);  // L[jj][q]
+      // every lane runs the same instructions; lane jj's results are the ones
+      // that count
+      const double d = sqrt(sum);
+      const double rd = 1.0 / d;
       if (lane == jj) {
         if (!(sum > 0)) ok = false;
-        const double d = sqrt(sum);
-        row[jj] = d;
         dg = d;
-        rdg = 1.0 / d;
-        Lm[jj][jj] = rdg;
+        rdg = rd;
       }
-      __builtin_amdgcn_wave_barrier();
-      if (i > jj) {
-        row[jj] = sum * Lm[jj][jj];
-        Lm[i][jj] = row[jj];
-      }
-      __builtin_amdgcn_wave_barrier();
+      const double rdj = bcast(rd, jj);
+      row[jj] = (lane == jj) ? d : sum * rdj;
+      Lm[i][jj] = row[jj];  // mirror for the back-substitution (column reads)
     }
     // log of the diagonal: all rows at once (not one per column of the loop)
     if (lane < P) ldv[lane] = log(dg);
-    // L y = v, column by column: lane q publishes y_q, the rows below take
-    // their share
+    // L y = v, column by column: y_q from lane q, the rows below take their share
     double si = vi;
 #pragma unroll
     for (int q = 0; q < P; q++) {
-      if (lane == q) yv[q] = si * rdg;
-      __builtin_amdgcn_wave_barrier();
-      if (i > q) si -= row[q] * yv[q];
+      const double yq = bcast(si * rdg, q);
+      if (i > q) si -= row[q] * yq;
+      if (lane == q) si = yq;  // keep y_q: this lane's right-hand side below
     }
-    // L^T a = y the same way from the last row up: lane ii publishes a_ii, the
-    // rows above subtract L[ii][i] a_ii (column i of L, read from the mirror)
-    double ti = (lane < P) ? yv[i] : 0.0;
+    // L^T a = y from the last row up: a_ii from lane ii, the rows above subtract
+    // L[ii][i] a_ii (column i of L out of the mirror, fetched ahead of the chain)
+    __builtin_amdgcn_wave_barrier();
+    double col[P];
+#pragma unroll
+    for (int ii = 0; ii < P; ii++) col[ii] = Lm[ii][i];
+    double ti = si;
 #pragma unroll
     for (int ii = P - 1; ii >= 0; ii--) {
-      if (lane == ii) coefs[ii] = ti * rdg;
-      __builtin_amdgcn_wave_barrier();
-      if (i < ii) ti -= Lm[ii][i] * coefs[ii];
+      const double aii = bcast(ti * rdg, ii);
+      if (lane == 0) coefs[ii] = aii;
+      if (i < ii) ti -= col[ii] * aii;
     }
     const unsigned long long okm = __ballot(ok || lane >= P);
     if (lane == 0) {

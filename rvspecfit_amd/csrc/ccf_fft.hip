@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(XC_NT)
 // spectrum's S*, V* in registers across a chunk of templates halves the L2->CU
 // traffic but needs > 180 VGPRs (one block per CU or spills): 25-38 ms.
 __global__ void __launch_bounds__(XB_NT)
+    __attribute__((amdgpu_waves_per_eu(4, 4)))  // two 8-wave blocks per CU
     ccf_xcorr_kernel(const double2 *__restrict__ work, int nfft, int log2n,
                      const double2 *__restrict__ tfft,
                      const double2 *__restrict__ tfft2, int T,
@@ -310,7 +311,92 @@ __global__ void __launch_bounds__(XB_NT)
   const double2 *F2 = tfft2 + (int64_t)t * (n2 + 1);
   const double inv_n = 1.0 / nfft;
   const int npass = continuum ? 1 : 2;
+  // The read-back at the end of the block (lag gather, then interpolation onto
+  // the velocity grid, then `out = beta out + value`) was three dependent global
+  // round trips with most of the block idle.  Everything in it that does not
+  // depend on the transform is fetched now, into registers, while the operand
+  // stream is in flight (the common case nlag, nvel <= 512: one item per thread).
+  double *out = chisq + ((int64_t)b * T + t) * nvel;
+  const bool pre = (nlag <= XB_NT) && (nvel <= XB_NT);
+  int pre_pos = 0, pre_lo = 0;
+  double pre_x0 = 0, pre_x1 = 1, pre_xg = 0, pre_old = 0;
+  if (pre) {
+    if (tid < nlag) pre_pos = lag_pos[tid];
+    if (tid < nvel) {
+      pre_lo = ilo[tid];
+      pre_x0 = lag_vel[pre_lo];
+      pre_x1 = lag_vel[pre_lo + 1];
+      pre_xg = vgrid[tid];
+      if (beta != 0.0) pre_old = out[tid];
+    }
+  }
   for (int pass = 0; pass < npass; pass++) {
+    if (continuum) {
+      // Operand streaming is latency-bound (the operands come out of L2 and a
+      // wave had 9 loads in flight): bins k and k + XB_NT are fetched together,
+      // 18 x 16 B per lane, through buffer loads -- one 32-bit offset register
+      // serves the four arrays (F, S*, F2, V*) that are read at the same bin, so
+      // the batch fits the register budget of two blocks per CU.  Bins
+      // 1..npair take exactly npair / (2 XB_NT) trips (nfft = 8192: two); the
+      // DC/Nyquist pair k = 0 is wave-uniform and goes through the scalar cache.
+      typedef int v4i_t __attribute__((ext_vector_type(4)));
+      const int nbytes = (n2 + 1) * 16;
+      const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)F, 0, nbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rF2 = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)F2, 0, nbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)Sc, 0, nbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)Vc, 0, nbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)tw, 0, (npair + 1) * 16, 0x00020000);
+      auto ld = [](const __amdgpu_buffer_rsrc_t &r, int off) {
+        const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        return make_double2(__hiloint2double(v.y, v.x),
+                            __hiloint2double(v.w, v.z));
+      };
+      if (tid == 0) {
+        const double2 p1 = cmul(F[0], Sc[0]), p2 = cmul(F2[0], Vc[0]);
+        const double2 q1 = cmul(F[n2], Sc[n2]), q2 = cmul(F2[n2], Vc[n2]);
+        const double xk = p2.x - 2 * p1.x, xm = q2.x - 2 * q1.x;
+        // numpy irfft ignores the imaginary parts of the DC and Nyquist bins
+        fa[0] = make_double2(xk + xm, xk - xm);
+      }
+      for (int k0 = 1 + tid; k0 <= npair; k0 += 2 * XB_NT) {
+        double2 op[2][9];
+        bool live[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int kk = k0 + u * XB_NT;
+          live[u] = kk <= npair;
+          const int k = live[u] ? kk : k0;
+          const int ok = k * 16, om = (n2 - k) * 16;
+          op[u][0] = ld(rF, ok), op[u][1] = ld(rS, ok);
+          op[u][2] = ld(rF2, ok), op[u][3] = ld(rV, ok);
+          op[u][4] = ld(rF, om), op[u][5] = ld(rS, om);
+          op[u][6] = ld(rF2, om), op[u][7] = ld(rV, om);
+          op[u][8] = ld(rT, ok);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int k = k0 + u * XB_NT, m = n2 - k;
+          const double2 p1 = cmul(op[u][0], op[u][1]),
+                        p2 = cmul(op[u][2], op[u][3]);
+          const double2 Xk = make_double2(p2.x - 2 * p1.x, p2.y - 2 * p1.y);
+          const double2 q1 = cmul(op[u][4], op[u][5]),
+                        q2 = cmul(op[u][6], op[u][7]);
+          const double2 Xm = make_double2(q2.x - 2 * q1.x, q2.y - 2 * q1.y);
+          const double2 e = make_double2(Xk.x + Xm.x, Xk.y - Xm.y);
+          const double2 d = make_double2(Xk.x - Xm.x, Xk.y + Xm.y);
+          const double2 q = cmul(op[u][8], d);
+          if (live[u]) {
+            fa[XC_PAD(k)] = make_double2(e.x - q.y, e.y + q.x);
+            if (m != k) fa[XC_PAD(m)] = make_double2(e.x + q.y, -e.y + q.x);
+          }
+        }
+      }
+    } else
     for (int k = tid; k <= npair; k += XB_NT) {
       const int m = n2 - k;
       double2 Xk, Xm;
@@ -341,14 +427,25 @@ __global__ void __launch_bounds__(XB_NT)
     fft_lds<1, XB_NT>(fa, log2n, tw, prune);
     const double *fr = reinterpret_cast<const double *>(fa);
     double *dst = (pass == 0) ? c0 : c1;
-    for (int l = tid; l < nlag; l += XB_NT) dst[l] = fr[lag_pos[l]] * inv_n;
+    if (pre) {
+      if (tid < nlag) dst[tid] = fr[pre_pos] * inv_n;
+    } else {
+      for (int l = tid; l < nlag; l += XB_NT) dst[l] = fr[lag_pos[l]] * inv_n;
+    }
     __syncthreads();
   }
   if (!continuum) {
     for (int l = tid; l < nlag; l += XB_NT) c0[l] = -c0[l] * c0[l] / c1[l];
     __syncthreads();
   }
-  double *out = chisq + ((int64_t)b * T + t) * nvel;
+  if (pre) {
+    if (tid < nvel) {
+      const double sl = (c0[pre_lo + 1] - c0[pre_lo]) / (pre_x1 - pre_x0);
+      const double val = sl * (pre_xg - pre_x0) + c0[pre_lo];
+      out[tid] = (beta != 0.0) ? beta * pre_old + val : val;
+    }
+    return;
+  }
   for (int v = tid; v < nvel; v += XB_NT) {
     const int lo = ilo[v];
     const double x0 = lag_vel[lo], x1 = lag_vel[lo + 1];

@@ -116,6 +116,28 @@ __device__ __forceinline__ double2 twid(const double2 *__restrict__ tw, int e,
   return w;
 }
 
+#ifdef RVS_XC_TIMING
+// debug build only (tools/perf/xc_phases.sh): clock budget of ccf_xcorr_kernel
+__device__ unsigned long long xc_dbg[16];
+#define XC_T(i)                                        \
+  do {                                                 \
+    __syncthreads();                                   \
+    if (threadIdx.x == 0) {                            \
+      const unsigned long long t_ = wall_clock64();    \
+      atomicAdd(&xc_dbg[i], t_ - t_prev);              \
+      t_prev = t_;                                     \
+    }                                                  \
+  } while (0)
+extern "C" int rvs_dbg_read_xc(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(xc_dbg), sizeof(xc_dbg)) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}
+#else
+#define XC_T(i)
+#endif
+
 // in-place DIF transform of the padded LDS image a[] (n2 points)
 // prune (nullable): output masks for the LAST TWO passes when both are radix 8
 // (n2 a power of 8).  Only ~100 of the n2 outputs of the inverse transform are
@@ -311,6 +333,9 @@ __global__ void __launch_bounds__(XB_NT)
   const double2 *F2 = tfft2 + (int64_t)t * (n2 + 1);
   const double inv_n = 1.0 / nfft;
   const int npass = continuum ? 1 : 2;
+#ifdef RVS_XC_TIMING
+  unsigned long long t_prev = wall_clock64();
+#endif
   // The read-back at the end of the block (lag gather, then interpolation onto
   // the velocity grid, then `out = beta out + value`) was three dependent global
   // round trips with most of the block idle.  Everything in it that does not
@@ -424,7 +449,9 @@ __global__ void __launch_bounds__(XB_NT)
         if (m != k) fa[XC_PAD(m)] = make_double2(e.x + q.y, -e.y + q.x);
       }
     }
+    XC_T(0);  // operand stream + products + Hermitian fold into LDS
     fft_lds<1, XB_NT>(fa, log2n, tw, prune);
+    XC_T(1);  // the four radix-8 passes
     const double *fr = reinterpret_cast<const double *>(fa);
     double *dst = (pass == 0) ? c0 : c1;
     if (pre) {
@@ -444,6 +471,7 @@ __global__ void __launch_bounds__(XB_NT)
       const double val = sl * (pre_xg - pre_x0) + c0[pre_lo];
       out[tid] = (beta != 0.0) ? beta * pre_old + val : val;
     }
+    XC_T(2);  // lag gather + interpolation + store
     return;
   }
   for (int v = tid; v < nvel; v += XB_NT) {

@@ -334,3 +334,38 @@ def test_proc_many_status_file(tmp_path):
                 process_status_file=st2, shard=(1, 2), skipexisting=True)
     rows = open(st2 + '.1').read().strip().split('\n')
     assert len(rows) == 1 and rows[0].split()[1] == 'EXISTING'
+
+
+def test_select_expid_range_and_id_matched_redshifts(coadd, tmp_path):
+    """spectra- files: the EXPID window (desi_fit.py:590-597; open ends, and no
+    window at all -- where the reference trips over an unset variable -- select
+    everything), and a redshift table with a DIFFERENT row count, matched by
+    TARGETID (desi_fit.py:655-672)"""
+    FP, (fluxes, ivars, masks, waves, resolutions) = coadd
+    fm0 = FP['FIBERMAP'].data
+    n = len(fm0)
+    fm = F.FitsTable([F.Column(c.name, c.array, c.unit, c.tform)
+                      for c in fm0._cols])
+    fm.add('EXPID', np.arange(n, dtype=np.int32))
+    sns = {a: np.full(n, 10.0) for a in ARMS}
+    base = D.select_fibers_to_fit(fm, sns)[0]
+    assert base.sum() == n - 2  # the SKY fibre and the bad FIBERSTATUS one
+    sub = D.select_fibers_to_fit(fm, sns, expid_range=(5, 8))[0]
+    assert np.array_equal(np.nonzero(sub)[0], [8])  # (5, 8] minus fibres 6, 7
+    sub = D.select_fibers_to_fit(fm, sns, expid_range=(None, 3))[0]
+    assert np.array_equal(np.nonzero(sub)[0], [0, 1, 2, 3])
+    sub = D.select_fibers_to_fit(fm, sns, expid_range=(10, None))[0]
+    assert np.array_equal(np.nonzero(sub)[0], [11, 12, 13])
+    # redshift table with half the rows, in another order
+    rr0 = F.open(os.path.join(GOLD, 'redrock-golden.fits'))['REDSHIFTS'].data
+    keep = np.array([9, 3, 0, 12, 8, 1])
+    rr = F.FitsTable([F.Column(c.name, c.array[keep], c.unit)
+                      for c in rr0._cols])
+    path = str(tmp_path / 'redrock-part.fits')
+    F.HDUList([F.PrimaryHDU(), F.BinTableHDU(rr, name='REDSHIFTS')]).writeto(path)
+    sub, rz, rs, rsub = D.select_fibers_to_fit(
+        fm, sns, zbest_path=path, zbest_ext='REDSHIFTS', zbest_select=True)
+    # stars (or |z| small) among the listed ones: all but the galaxy (fibre 3)
+    assert np.array_equal(np.nonzero(sub)[0], [0, 1, 8, 9, 12])
+    assert np.isnan(rz[2]) and rs[2] == '' and rz[9] == rr0['Z'][9]
+    assert rs[3] == 'GALAXY' and rsub[0] == 'K'

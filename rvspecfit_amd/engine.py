@@ -73,7 +73,8 @@ def get_poly_basis(lam, npoly, rbf=True):
     return out
 
 
-RES_MAXND = 33
+RES_MAXND = 33   # widest band the velocity-grid kernel holds in its LDS ring;
+                 # wider matrices run the grid through the point kernel
 
 
 def resol_taps(mats, npix):
@@ -92,9 +93,6 @@ def resol_taps(mats, npix):
             m = max(m, max(abs(o) for o in offs))
         dias.append(D)
     nd = 2 * m + 1
-    if nd > RES_MAXND:
-        raise NotImplementedError('resolution matrix wider than %d diagonals'
-                                  % RES_MAXND)
     taps = np.zeros((len(mats), npix, nd))
     k = np.arange(npix)
     for i, D in enumerate(dias):
@@ -450,6 +448,35 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
     shared = vels.dim() == 1
     Nv = vels.shape[-1]
     vstride = 0 if shared else Nv
+    wide = [_arm_resol(arm, ia, resols) for ia, arm in enumerate(batch.arms)]
+    if any(r is not None and r['nd'] > RES_MAXND for r in wide):
+        # resolution matrix wider than the grid kernel's band (the reference's
+        # tests/test_sdss.py uses R = 50: 371 diagonals): every (job, velocity)
+        # is a job of the point kernel, which applies a band of any width
+        js = job_spec if job_spec is not None else _arange32(0, J, dev)
+        jt = job_templ if job_templ is not None else _arange32(0, J, dev)
+        vv = (vels[None, :].expand(J, Nv) if shared else vels).reshape(-1)
+        res = torch.empty(J * Nv, dtype=torch.float64, device=dev)
+        st = torch.zeros(J * Nv, dtype=torch.int32, device=dev)
+        js2 = js.repeat_interleave(Nv).contiguous()
+        jt2 = jt.repeat_interleave(Nv).contiguous()
+        step = 1 << 18
+        for a in range(0, J * Nv, step):
+            b = min(J * Nv, a + step)
+            res[a:b], st[a:b] = chisq_point(
+                batch, libs, coefs, outsides, vv[a:b].contiguous(), npoly=npoly,
+                rbf=rbf, job_spec=js2[a:b], job_templ=jt2[a:b],
+                espec_sys=espec_sys, outside_penalty=outside_penalty,
+                resols=resols)
+        res = res.reshape(J, Nv)
+        stj = torch.zeros(J, dtype=torch.int32, device=dev)
+        st = st.reshape(J, Nv)
+        for bit in range(12):
+            stj |= ((st >> bit) & 1).amax(dim=1).to(torch.int32) << bit
+        if out is not None:
+            out.copy_(res)
+            res = out
+        return res, stj
     if out is None:
         out = torch.empty((J, Nv), dtype=torch.float64, device=dev)
     status = torch.zeros(J, dtype=torch.int32, device=dev)

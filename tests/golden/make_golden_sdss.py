@@ -1,7 +1,8 @@
 #!/opt/conda/bin/python3.9
 """Golden vectors on the reference's own data fixture, tests/data/
 spec-0266-51602-0031.fits (a real SDSS spectrum, 3842 log-spaced pixels), following
-the reference's tests/test_fit.py call by call (build container only):
+the reference's tests/test_fit.py and tests/test_sdss.py call by call (build
+container only):
 
     /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden_sdss.py
 
@@ -161,6 +162,58 @@ def main():
                 rot_params=(19., ), config=config, options=op))
         R.put('continuum/chisq_array', spec_fit.get_chisq_continuum(
             specdata, options=options)['chisq_array'])
+    # ================= tests/test_sdss.py, call by call =====================
+    options = {'npoly': 10}
+    params_list = [[4000, 3, -1, 0], [5000, 3, -1, 0], [6000, 2, -2, 0],
+                   [5500, 5, 0, 0]]
+    vel_grid = np.linspace(-600, 600, 1000)
+    with np.errstate(all='ignore'):
+        # :41-51 find_best on a 1000-point grid, 4 templates
+        res = spec_fit.find_best(specdata, vel_grid, params_list,
+                                 rot_params=None, resol_params=None,
+                                 options=options, config=config)
+        for k in ('best_vel', 'best_chi', 'vel_err', 'kurtosis', 'skewness'):
+            R.put('t2/find_best/' + k, res[k])
+        R.put('t2/find_best/best_param', res['best_param'])
+        bestv, bestpar = res['best_vel'], res['best_param']
+        # :53-58 first guess (npoly 10) + process
+        param0 = vel_fit.firstguess(specdata, options=options, config=config)
+        R.put('t2/firstguess/keys', np.array(sorted(param0.keys())))
+        R.put('t2/firstguess/vals',
+              np.array([float(param0[k]) for k in sorted(param0.keys())]))
+        put_fit(R, 't2/process', vel_fit.process(
+            specdata, dict(param0), resolParams=None, options=options,
+            config=config))
+        # :66-73 get_chisq with vsini 300
+        ret = spec_fit.get_chisq(specdata, bestv, bestpar, rot_params=(300, ),
+                                 resol_params=None, options=options,
+                                 config=config, full_output=True)
+        R.put('t2/rot300/chisq', ret['chisq'])
+        R.put('t2/rot300/model', ret['models'][0])
+        # :79-90 resolution matrix R = 50 through resol_params
+        resol_mat = spec_fit.construct_resol_mat(specdata[0].lam, 50)
+        R.put('t2/resol/ndiag', len(resol_mat.mat.offsets))
+        rp = {'sdss1': resol_mat}
+        ret = spec_fit.get_chisq(specdata, bestv, bestpar, None, resol_params=rp,
+                                 options=options, config=config,
+                                 full_output=True)
+        R.put('t2/resol/chisq', ret['chisq'])
+        R.put('t2/resol/chisq_array', ret['chisq_array'])
+        R.put('t2/resol/model', ret['models'][0])
+        # :95-100 process with resolParams
+        put_fit(R, 't2/process_resol', vel_fit.process(
+            specdata, dict(param0), resolParams=rp, options=options,
+            config=config))
+        # :101-117 the same matrix carried by the SpecData
+        sd2 = [spec_fit.SpecData('sdss1', lam, dat['flux'], err,
+                                 resolution=resol_mat)]
+        ret = spec_fit.get_chisq(sd2, bestv, bestpar, None, options=options,
+                                 config=config, full_output=True)
+        R.put('t2/sdresol/chisq', ret['chisq'])
+        R.put('t2/sdresol/model', ret['models'][0])
+        # :121 continuum with the resolution matrix
+        R.put('t2/sdresol/continuum', spec_fit.get_chisq_continuum(
+            sd2, options=options)['chisq_array'])
     np.savez_compressed(HERE + '/sdss_cases.npz', **R.d)
     print('wrote', len(R.d), 'arrays')
 

@@ -131,3 +131,73 @@ def test_sdss_process(scases, sdss, tag):
         assert abs(res['vsini'] - vs) <= 0.05
     assert np.abs(res['yfit'][0] - scases[tag + '/yfit']).max() <= \
         1e-4 * np.abs(scases[tag + '/yfit']).max()
+
+
+@pytest.mark.gpu
+def test_reference_test_sdss_sequence(scases, sdss):
+    """tests/test_sdss.py of the reference, call by call: find_best on a
+    1000-point grid, first guess + process at npoly 10, vsini 300, and a
+    resolution matrix of R = 50 -- 377 diagonals, far wider than the band the
+    velocity-grid kernel keeps in LDS (33): the grid goes through the point
+    kernel -- as resol_params, inside process, and carried by the SpecData."""
+    from rvspecfit_amd import spec_fit, vel_fit
+    opt = dict(npoly=10)
+    t = 't2/'
+    params_list = [[4000, 3, -1, 0], [5000, 3, -1, 0], [6000, 2, -2, 0],
+                   [5500, 5, 0, 0]]
+    vel_grid = np.linspace(-600, 600, 1000)
+    r = spec_fit.find_best(sdss, vel_grid, params_list, rot_params=None,
+                           resol_params=None, options=opt, config=CFG)
+    assert abs(r['best_vel'] - scases[t + 'find_best/best_vel']) < 1e-3
+    assert np.isclose(r['best_chi'], scases[t + 'find_best/best_chi'], rtol=1e-7)
+    assert np.isclose(r['vel_err'], scases[t + 'find_best/vel_err'], rtol=1e-4)
+    assert np.isclose(r['kurtosis'], scases[t + 'find_best/kurtosis'], rtol=1e-4)
+    assert np.isclose(r['skewness'], scases[t + 'find_best/skewness'], rtol=1e-4)
+    assert list(r['best_param']) == list(scases[t + 'find_best/best_param'])
+    bestv, bestpar = float(scases[t + 'find_best/best_vel']), \
+        tuple(float(_) for _ in scases[t + 'find_best/best_param'])
+    g = vel_fit.firstguess(sdss, options=opt, config=CFG)
+    keys = [str(_) for _ in scases[t + 'firstguess/keys']]
+    assert [float(g[k]) for k in keys] == list(scases[t + 'firstguess/vals'])
+
+    def check_fit(res, tag, vtol=0.01):
+        assert abs(res['chisq'] - float(scases[tag + '/chisq'])) <= 2e-3
+        assert abs(res['vel'] - float(scases[tag + '/vel'])) <= vtol
+        got = np.array([res['param'][k] for k in NAMES])
+        assert np.all(np.abs(got - scases[tag + '/param']) <=
+                      np.array([0.5, 5e-3, 2e-3, 2e-3]))
+
+    check_fit(vel_fit.process(sdss, dict(g), resolParams=None, options=opt,
+                              config=CFG), t + 'process')
+    ret = spec_fit.get_chisq(sdss, bestv, bestpar, rot_params=(300, ),
+                             options=opt, config=CFG, full_output=True)
+    assert np.isclose(ret['chisq'], scases[t + 'rot300/chisq'], rtol=1e-7)
+    assert np.abs(ret['models'][0] - scases[t + 'rot300/model']).max() <= \
+        1e-6 * np.abs(scases[t + 'rot300/model']).max()
+    # ---- R = 50
+    rm = spec_fit.construct_resol_mat(sdss[0].lam, 50)
+    assert len(rm.mat.offsets) == int(scases[t + 'resol/ndiag']) == 377
+    rp = {'sdss1': rm}
+    ret = spec_fit.get_chisq(sdss, bestv, bestpar, None, resol_params=rp,
+                             options=opt, config=CFG, full_output=True)
+    assert np.isclose(ret['chisq'], scases[t + 'resol/chisq'], rtol=1e-7)
+    assert np.allclose(ret['chisq_array'], scases[t + 'resol/chisq_array'],
+                       rtol=1e-7)
+    assert np.abs(ret['models'][0] - scases[t + 'resol/model']).max() <= \
+        1e-6 * np.abs(scases[t + 'resol/model']).max()
+    # the velocity grid with the wide matrix (point-kernel route) against the
+    # point evaluation itself
+    fb = spec_fit.find_best(sdss, np.array([bestv - 5., bestv, bestv + 5.]),
+                            [list(bestpar)], resol_params=rp, options=opt,
+                            config=CFG)
+    assert fb['best_chi'] <= float(scases[t + 'resol/chisq']) + 1e-6 * 8000
+    check_fit(vel_fit.process(sdss, dict(g), resolParams=rp, options=opt,
+                              config=CFG), t + 'process_resol', vtol=0.05)
+    sd2 = [spec_fit.SpecData('sdss1', sdss[0].lam, sdss[0].spec, sdss[0].espec,
+                             resolution=rm)]
+    ret = spec_fit.get_chisq(sd2, bestv, bestpar, None, options=opt, config=CFG,
+                             full_output=True)
+    assert np.isclose(ret['chisq'], scases[t + 'sdresol/chisq'], rtol=1e-7)
+    cc = spec_fit.get_chisq_continuum(sd2, options=opt)
+    assert np.allclose(cc['chisq_array'], scases[t + 'sdresol/continuum'],
+                       rtol=1e-8)

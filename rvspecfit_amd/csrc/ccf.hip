@@ -190,24 +190,40 @@ __device__ void lm_normal(LMShared &S, const double *__restrict__ Eb,
     double a[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) a[q] = 0;
-    for (int k = istart[t] + lane; k < istart[t + 1]; k += 64) {
-      const double e0 = Eb[3 * k], e1 = Eb[3 * k + 1], e2 = Eb[3 * k + 2];
-      const double h = hw[k], gg = gw[k];
-      a[0] = fma(h * e0, e0, a[0]);
-      a[1] = fma(h * e0, e1, a[1]);
-      a[2] = fma(h * e0, e2, a[2]);
-      a[3] = fma(h * e1, e1, a[3]);
-      a[4] = fma(h * e1, e2, a[4]);
-      a[5] = fma(h * e2, e2, a[5]);
-      a[6] = fma(gg, e0, a[6]);
-      a[7] = fma(gg, e1, a[7]);
-      a[8] = fma(gg, e2, a[8]);
+    // four pixels per lane per trip, their basis rows requested together (the
+    // rows come out of L2: one exposed round trip per trip instead of per pixel)
+    const int k1 = istart[t + 1];
+    for (int k0 = istart[t] + lane; k0 < k1; k0 += 4 * 64) {
+      double e[4][3];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int k = min(k0 + 64 * c, k1 - 1);
+        e[c][0] = Eb[3 * k];
+        e[c][1] = Eb[3 * k + 1];
+        e[c][2] = Eb[3 * k + 2];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int k = k0 + 64 * c;
+        if (k < k1) {
+          const double e0 = e[c][0], e1 = e[c][1], e2 = e[c][2];
+          const double h = hw[k], gg = gw[k];
+          a[0] = fma(h * e0, e0, a[0]);
+          a[1] = fma(h * e0, e1, a[1]);
+          a[2] = fma(h * e0, e2, a[2]);
+          a[3] = fma(h * e1, e1, a[3]);
+          a[4] = fma(h * e1, e2, a[4]);
+          a[5] = fma(h * e2, e2, a[5]);
+          a[6] = fma(gg, e0, a[6]);
+          a[7] = fma(gg, e1, a[7]);
+          a[8] = fma(gg, e2, a[8]);
+        }
+      }
     }
 #pragma unroll
-    for (int q = 0; q < 9; q++) a[q] = wave_sum(a[q]);
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 9; q++) S.isum[t * 9 + q] = a[q];
+    for (int q = 0; q < 9; q++) {
+      const double v = wave_sum_to63(a[q]);  // DPP on the VALU, total in lane 63
+      if (lane == 63) S.isum[t * 9 + q] = v;
     }
   }
   __syncthreads();
@@ -237,40 +253,70 @@ __device__ void lm_normal(LMShared &S, const double *__restrict__ Eb,
 }
 
 // (B + lamd diag B) dl = -bvec with B pentadiagonal SPD: LDL^T with a sliding
-// window, ONE thread, O(m).  Levenberg-Marquardt damping in B-spline space.
+// window, O(m).  Levenberg-Marquardt damping in B-spline space.
+// Run by ONE WAVE (all lanes execute the same chain).  Row i of the banded
+// system lives in lane i's registers; the serial chain fetches it with
+// v_readlane and parks its results (l1_i, l2_i, w_i) in lane i (a select:
+// all lanes hold the same value), so neither sweep touches LDS (as a single-lane loop over LDS
+// every row cost four dependent LDS round trips and three divisions; here one
+// division, 1 / d_i, serves the three quotients by d_i, d_{i-1}, d_{i-2}).
+__device__ inline double lane_get(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                          __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// every lane holds the same v: lane `lane` keeps it
+__device__ inline double lane_put(double dst, double v, int lane) {
+  return ((int)(threadIdx.x & 63) == lane) ? v : dst;
+}
+
 __device__ void lm_band_solve(LMShared &S, int m) {
+  const int lane = threadIdx.x & 63;
+  const int r = min(lane, m - 1);
   const double ld = 1.0 + S.lamd;
-  double d1 = 0, d2 = 0, l1p = 0;       // d_{i-1}, d_{i-2}, l1_{i-1}
-  double z1 = 0, z2 = 0;                // z_{i-1}, z_{i-2}
+  // this lane's row: diagonal (damped), first and second sub-diagonal, gradient
+  const double ra0 = S.Bd[r * 3] * ld, ra1 = S.Bd[r * 3 + 1],
+               ra2 = S.Bd[r * 3 + 2], rb = S.bvec[r];
+  double d1 = 0, d2 = 0, l1p = 0;  // d_{i-1}, d_{i-2}, l1_{i-1}
+  double r1 = 0, r2 = 0;           // 1 / d_{i-1}, 1 / d_{i-2}
+  double z1 = 0, z2 = 0;           // z_{i-1}, z_{i-2}
+  double lb1 = 0, lb2 = 0, w = 0;  // row results, one row per lane
   bool ok = true;
   for (int i = 0; i < m; i++) {
-    const double a0 = S.Bd[i * 3] * ld, a1 = S.Bd[i * 3 + 1], a2 = S.Bd[i * 3 + 2];
-    const double l2 = (i >= 2) ? a2 / d2 : 0.0;
-    const double l1 = (i >= 1) ? (a1 - l2 * l1p * d2) / d1 : 0.0;
+    const double a0 = lane_get(ra0, i), a1 = lane_get(ra1, i),
+                 a2 = lane_get(ra2, i), bi = lane_get(rb, i);
+    const double l2 = (i >= 2) ? a2 * r2 : 0.0;
+    const double l1 = (i >= 1) ? (a1 - l2 * l1p * d2) * r1 : 0.0;
     const double d = a0 - l1 * l1 * d1 - l2 * l2 * d2;
     if (!(d > 0)) ok = false;
-    const double z = -S.bvec[i] - l1 * z1 - l2 * z2;
-    S.Lb[i * 3] = d;
-    S.Lb[i * 3 + 1] = l1;
-    S.Lb[i * 3 + 2] = l2;
-    S.dl[i] = z / d;   // w_i = z_i / d_i
+    const double z = -bi - l1 * z1 - l2 * z2;
+    const double rd = 1.0 / d;
+    lb1 = lane_put(lb1, l1, i);
+    lb2 = lane_put(lb2, l2, i);
+    w = lane_put(w, z * rd, i);  // w_i = z_i / d_i
     d2 = d1;
     d1 = d;
+    r2 = r1;
+    r1 = rd;
     l1p = l1;
     z2 = z1;
     z1 = z;
   }
   double x1 = 0, x2 = 0;  // x_{i+1}, x_{i+2}
+  double xs = 0;          // solution, one component per lane
   for (int i = m - 1; i >= 0; i--) {
-    const double l1n = (i + 1 < m) ? S.Lb[(i + 1) * 3 + 1] : 0.0;
-    const double l2n = (i + 2 < m) ? S.Lb[(i + 2) * 3 + 2] : 0.0;
-    const double x = S.dl[i] - l1n * x1 - l2n * x2;
-    S.dl[i] = ok ? x : 0.0;
+    const double l1n = (i + 1 < m) ? lane_get(lb1, i + 1) : 0.0;
+    const double l2n = (i + 2 < m) ? lane_get(lb2, i + 2) : 0.0;
+    const double x = lane_get(w, i) - l1n * x1 - l2n * x2;
+    xs = lane_put(xs, x, i);
     x2 = x1;
     x1 = x;
   }
-  for (int i = 0; i < m; i++) S.cn[i] = S.c[i] + S.dl[i];
-  S.ok = ok ? 1 : 0;
+  if (lane < m) {
+    const double dl = ok ? xs : 0.0;
+    S.dl[lane] = dl;
+    S.cn[lane] = S.c[lane] + dl;
+  }
+  if (lane == 0) S.ok = ok ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(PP_NT)
@@ -512,12 +558,16 @@ __global__ void __launch_bounds__(PP_NT)
       S.stop = 0;
     }
     double cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true);
+    PP_T(7);  // (debug) LM set-up + first evaluation
     for (int it = 0; it < RVS_LM_MAXIT; it++) {
       lm_normal(S, Eb, istart, m, gw, hw);
+      PP_T(8);  // (debug) normal equations
       // damped step; retry with larger damping until the cost does not grow
       for (int tries = 0; tries < 40; tries++) {
-        if (tid == 0) lm_band_solve(S, m);
+        if (tid < 64) lm_band_solve(S, m);
+        PP_T(9);  // (debug) band solve
         const double cn = lm_eval(S, S.cn, Eb, El, npix, cs, ce, gw, hw, false);
+        PP_T(10);  // (debug) trial evaluation
         if (cn <= cost) {  // accept (block-uniform decision)
           double mx = 0;
           for (int i = 0; i < m; i++) mx = fmax(mx, fabs(S.dl[i]));
@@ -542,6 +592,7 @@ __global__ void __launch_bounds__(PP_NT)
       __syncthreads();
       if (S.stop) break;
       cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true);
+      PP_T(11);  // (debug) accept + evaluation with weights
     }
     __syncthreads();
     if (pfit && tid < m) {

@@ -16,8 +16,8 @@ L = _lib.lib()
 buf = (ctypes.c_ulonglong * 16)()
 L.rvs_dbg_read_pp.argtypes = [ctypes.c_void_p]
 L.rvs_dbg_read_pp(ctypes.addressof(buf))
-t = np.array(buf[:7], dtype=float)
-names = ['load+errmedian+medfilt', 'gapfill', 'median sort', 'binned sort', 'LM', 'normalise', 'rebin']
+t = np.array(buf[:12], dtype=float)
+names = ['load+errmedian+medfilt', 'gapfill', 'median sort', 'binned sort', 'LM tail', 'normalise', 'rebin', 'LM: setup+eval0', 'LM: normal eq', 'LM: band solve', 'LM: trial eval', 'LM: accept+eval']
 print({n: round(float(v / t.sum()), 3) for n, v in zip(names, t)}, 'total ticks', t.sum())
 PY
 cp /tmp/librvsgpu_orig.so rvspecfit_amd/librvsgpu.so

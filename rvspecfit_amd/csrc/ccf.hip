@@ -149,14 +149,46 @@ struct LMShared {
 // the B-spline coefficients cc.  If store, also the Gauss-Newton weights
 //   gw[k] = (m/e) f / sqrt(1+z),  hw[k] = (m/e)^2 (1+z)^-1.5
 // (rho' f and rho' + 2 rho'' f^2, the scaling scipy applies for robust losses)
-__device__ double lm_eval(LMShared &S, const double *cc,
-                          const double *__restrict__ Eb,
-                          const int32_t *__restrict__ El, int npix,
-                          const double *cs, const double *ce, double *gw,
-                          double *hw, bool store) {
+// px: this thread's first LM_PIX pixels' basis rows and interval indices, read
+// once before the iteration (the objective is evaluated ~2x per iteration and
+// every evaluation started with two dependent L2 round trips for them); pixels
+// beyond LM_PIX * PP_NT fall back to the loads.
+struct LMPix {
+  double e0, e1, e2;
+  int l;
+};
+#define LM_PIX 3
+
+__device__ __forceinline__ double lm_eval(
+    LMShared &S, const double *cc, const double *__restrict__ Eb,
+    const int32_t *__restrict__ El, int npix, const double *cs, const double *ce,
+    double *gw, double *hw, bool store, const LMPix (&px)[LM_PIX]) {
   __syncthreads();  // cc (LDS) was just written
   double c = 0;
-  for (int k = threadIdx.x; k < npix; k += PP_NT) {
+#pragma unroll
+  for (int i = 0; i < LM_PIX; i++) {
+    const int k = threadIdx.x + i * PP_NT;
+    if (k < npix) {
+      const int l = px[i].l;
+      double s = px[i].e0 * cc[l];
+      s = fma(px[i].e1, cc[l + 1], s);
+      s = fma(px[i].e2, cc[l + 2], s);
+      const bool clipped = (s < -100.0) || (s > 100.0);
+      s = fmin(fmax(s, -100.0), 100.0);
+      const double mod = exp(s);
+      const double e = ce[k];
+      const double f = (mod - cs[k]) / e;
+      const double z = f * f;
+      const double r = sqrt(1 + z);
+      c += 2 * (r - 1);
+      if (store) {
+        const double d = clipped ? 0.0 : mod / e;
+        gw[k] = d * f / r;
+        hw[k] = d * d / (r * r * r);
+      }
+    }
+  }
+  for (int k = threadIdx.x + LM_PIX * PP_NT; k < npix; k += PP_NT) {
     const int l = El[k];
     double s = Eb[3 * k] * cc[l];
     s = fma(Eb[3 * k + 1], cc[l + 1], s);
@@ -557,7 +589,16 @@ __global__ void __launch_bounds__(PP_NT)
       S.lamd = 1e-3;
       S.stop = 0;
     }
-    double cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true);
+    LMPix px[LM_PIX];
+#pragma unroll
+    for (int i = 0; i < LM_PIX; i++) {
+      const int k = min(tid + i * PP_NT, npix - 1);
+      px[i].e0 = Eb[3 * k];
+      px[i].e1 = Eb[3 * k + 1];
+      px[i].e2 = Eb[3 * k + 2];
+      px[i].l = El[k];
+    }
+    double cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true, px);
     PP_T(7);  // (debug) LM set-up + first evaluation
     for (int it = 0; it < RVS_LM_MAXIT; it++) {
       lm_normal(S, Eb, istart, m, gw, hw);
@@ -566,7 +607,8 @@ __global__ void __launch_bounds__(PP_NT)
       for (int tries = 0; tries < 40; tries++) {
         if (tid < 64) lm_band_solve(S, m);
         PP_T(9);  // (debug) band solve
-        const double cn = lm_eval(S, S.cn, Eb, El, npix, cs, ce, gw, hw, false);
+        const double cn =
+            lm_eval(S, S.cn, Eb, El, npix, cs, ce, gw, hw, false, px);
         PP_T(10);  // (debug) trial evaluation
         if (cn <= cost) {  // accept (block-uniform decision)
           double mx = 0;
@@ -591,7 +633,7 @@ __global__ void __launch_bounds__(PP_NT)
       }
       __syncthreads();
       if (S.stop) break;
-      cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true);
+      cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true, px);
       PP_T(11);  // (debug) accept + evaluation with weights
     }
     __syncthreads();

@@ -215,3 +215,23 @@ def test_native_bfgs_follows_scipy_restatement():
     # argument checks
     with pytest.raises(ValueError):
         bfgs.minimize_lockstep_native(quartic, np.zeros((2, 17)))
+
+
+def test_native_bfgs_under_sanitizers(tmp_path):
+    """csrc/bfgs_host.cpp (C++20 coroutines, hand-managed frames) built with
+    g++ -fsanitize=address,undefined and driven through 200 Rosenbrock runs,
+    some of them with noise: no report, all runs end"""
+    import shutil
+    import subprocess
+    if shutil.which('g++') is None:
+        pytest.skip('no g++')
+    exe = str(tmp_path / 'bfgs_san')
+    cmd = ['g++', '-std=c++20', '-O1', '-g', '-fsanitize=address,undefined',
+           '-fno-omit-frame-pointer', '-I' + os.path.join(REPO, 'include'), '-o',
+           exe, os.path.join(REPO, 'tests', 'bfgs_sanitizer_main.cpp'),
+           os.path.join(REPO, 'rvspecfit_amd', 'csrc', 'bfgs_host.cpp')]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'rounds' in out.stdout and 'ERROR' not in out.stderr
+    assert 'runtime error' not in out.stderr

@@ -1119,3 +1119,25 @@ def test_reference_test_fit_nn_sequence(gpu):
     assert res['free']['chisq'] <= res['fixed']['chisq'] + 0.05
     g = vel_fit.firstguess(sd, config=cfg)
     assert set(g) >= {'teff', 'logg', 'feh', 'alpha'}
+
+
+def test_ccf_readback_paths_agree(cases, config):
+    """the cross-correlation kernel has two read-back paths: tables prefetched
+    into registers (<= 512 lags and velocities, the normal case) and the loop
+    (more).  A 2 km/s grid (1001 velocities) takes the loop; where the two grids
+    share a velocity the interpolated CCF must be the same number."""
+    from rvspecfit_amd import spec_fit, fitter_ccf
+    sds = gold_specdata(cases, 'c1', spec_fit.SpecData)
+    out = {}
+    for step in (5, 2):
+        cfg = dict(config)
+        cfg['vel_step0'] = step
+        r = fitter_ccf.fit(sds, cfg)
+        out[step] = (np.round(np.asarray(r['vel_grid']), 6),
+                     np.asarray(r['best_ccf']))
+    assert len(out[5][0]) <= 512 < len(out[2][0])
+    common = np.intersect1d(out[5][0], out[2][0])
+    assert len(common) > 100
+    a = out[5][1][np.searchsorted(out[5][0], common)]
+    b = out[2][1][np.searchsorted(out[2][0], common)]
+    np.testing.assert_array_equal(a, b)

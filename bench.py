@@ -248,6 +248,10 @@ def main():
                          'file and run the driver (desi_fit.proc_desi) on it: '
                          'read -> select -> condition -> CCF + process + '
                          'continuum -> RVTAB/RVMOD')
+    ap.add_argument('--desi-nfiles', type=int, default=1,
+                    help='with --desi-file: this many copies of the file are '
+                         'processed as one group (desi_fit.proc_desi_group, what '
+                         'proc_many does with files_per_batch)')
     ap.add_argument('--cpu-process', action='store_true',
                     help='(cpu worker) run the oracle process stage')
     ap.add_argument('--workload', choices=['desi', 'cfg2'], default='desi',
@@ -616,14 +620,39 @@ def run_desi_addon(arms, args, dev):
     tm = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nfit = D.proc_desi(fname, tabf, modf, None, cfg, doplot=False, minsn=-1e9,
-                       npoly=OPTIONS['npoly'], device=dev, timers=tm)
+    nfiles = max(1, args.desi_nfiles)
+    if nfiles == 1:
+        nfit = D.proc_desi(fname, tabf, modf, None, cfg, doplot=False,
+                           minsn=-1e9, npoly=OPTIONS['npoly'], device=dev,
+                           timers=tm)
+    else:
+        # the driver's file loop: groups of 4 files fitted together, the next
+        # group read and conditioned by a worker thread meanwhile
+        import yaml
+        cfgf = os.path.join(tmp, 'config.yaml')
+        with open(cfgf, 'w') as fp:
+            yaml.safe_dump({k: v for k, v in cfg.items()
+                            if k != 'config_file_path'}, fp)
+        links = [fname]
+        for i in range(1, nfiles):
+            links.append(os.path.join(tmp, 'coadd-bench%d.fits' % i))
+            os.symlink(fname, links[-1])
+        st = os.path.join(tmp, 'status')
+        D.proc_many(links, tmp, 'rvtab', 'rvmod', config_fname=cfgf, minsn=-1e9,
+                    doplot=False, subdirs=False, npoly=OPTIONS['npoly'],
+                    process_status_file=st, shard=(0, 1),
+                    files_per_batch=min(4, nfiles))
+        rows = [l.split() for l in open(st).read().strip().split('\n')]
+        assert all(r[1] == 'SUCCESS' for r in rows), rows
+        nfit = sum(int(r[2]) for r in rows)
+        tabf = os.path.join(tmp, 'rvtab_coadd-bench.fits')
+        modf = os.path.join(tmp, 'rvmod_coadd-bench.fits')
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tab = F.open(tabf, verify_checksum=True)['RVTAB'].data
     warn = np.asarray(tab['RVS_WARN'])
-    out = dict(fibres=int(nfit), fibres_per_s=round(nfit / dt, 1),
-               seconds=round(dt, 2),
+    out = dict(fibres=int(nfit), files=nfiles,
+               fibres_per_s=round(nfit / dt, 1), seconds=round(dt, 2),
                stage_s={k: round(v, 3) for k, v in tm.items()},
                input_MB=round(os.path.getsize(fname) / 1e6, 1),
                output_MB=round((os.path.getsize(tabf)

@@ -853,21 +853,18 @@ def _arm_batch(cond, setups, pattern, rows, waves, device):
     return engine.SpecBatch(arms)
 
 
-def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
-              fit_targetid=None, objtypes=None, doplot=True, minsn=-1e9,
-              expid_range=None, poolex=None, fitarm=None, cmdline=None,
-              zbest_select=False, zbest_include=False,
-              use_resolution_matrix=False, ccf_init=True, npoly=10,
-              device='cuda', max_batch=4096, timers=None):
-    """desi_fit.py:962-1299: fit every selected fibre of one DESI file and write
-    the RVTAB and RVMOD products.  `poolex` is accepted for signature
-    compatibility and unused: the fibres of the file are one GPU batch (in
-    chunks of `max_batch`).  Returns the number of fibres selected, or -1.
-    `timers` (dict) receives the wall seconds of the stages read / select /
-    condition / fit / write."""
+def _proc_desi_steps(fname, tab_ofname, mod_ofname, fig_prefix, config,
+                     fit_targetid=None, objtypes=None, doplot=True, minsn=-1e9,
+                     expid_range=None, poolex=None, fitarm=None, cmdline=None,
+                     zbest_select=False, zbest_include=False,
+                     use_resolution_matrix=False, ccf_init=True, npoly=10,
+                     device='cuda', max_batch=4096, timers=None):
+    """proc_desi as a generator: everything up to the conditioned spectra, then
+    ONE yield of a fit request (see _fit_requests) that is answered with the
+    per-fibre results, then the products.  The return value (StopIteration
+    .value) is proc_desi's.  Files that need no fit return before the yield."""
     if npoly is None:
         npoly = 10
-    options = {'npoly': npoly}
     tm = timers if timers is not None else {}
     t_last = [time.time()]
 
@@ -999,26 +996,10 @@ def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
                               lsf_sigma0_angstrom=sig0s)
     okmat = np.stack([cond[s]['ok'] for s in setups], axis=1)
     tick('condition')
-    outdicts = [None] * nsel
-    curmodels = [None] * nsel
-    arms_of = [None] * nsel
-    for pattern in sorted({tuple(_) for _ in okmat.tolist()}, reverse=True):
-        rows_p = np.nonzero((okmat == np.array(pattern)[None, :]).all(axis=1))[0]
-        if not any(pattern):
-            for i in rows_p:
-                logging.warning('No good data found for fiber %d'
-                                % seqid_to_fit[i])
-            continue
-        names_p = ['desi_%s' % s for s, u in zip(setups, pattern) if u]
-        for c0 in range(0, len(rows_p), max_batch):
-            rows = rows_p[c0:c0 + max_batch]
-            batch = _arm_batch(cond, setups, pattern, rows, waves, device)
-            fr = fit_batch(batch, config, options, ccf_init=ccf_init)
-            for k, (i, d) in enumerate(zip(rows, _outdicts(fr, names_p, config,
-                                                           ccf_init))):
-                outdicts[i] = d
-                curmodels[i] = [y[k] for y in fr['yfit']]
-                arms_of[i] = names_p
+    for i in np.nonzero(~okmat.any(axis=1))[0]:
+        logging.warning('No good data found for fiber %d' % seqid_to_fit[i])
+    outdicts, curmodels, arms_of = yield dict(
+        cond=cond, okmat=okmat, setups=setups, waves=waves, nsel=nsel)
     tick('fit')
     nfibers_good = sum(_ is not None for _ in outdicts)
     good_flags = [_ is not None for _ in outdicts]
@@ -1058,6 +1039,110 @@ def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config,
     write_hdulist(tab_ofname, pyfits.HDUList(tab_hdus(versions, outtab)))
     tick('write')
     return nsel
+
+
+def _fit_requests(reqs, config, options, ccf_init=True, device='cuda',
+                  max_batch=4096):
+    """Fit the conditioned fibres of one or several files (the requests that
+    _proc_desi_steps yields).  Files that share arms and wavelength grids are
+    fitted TOGETHER -- one batch per pattern of usable arms -- because the
+    lock-step optimiser is bound by round latency at a few hundred fibres
+    (a 500-fibre coadd) and by throughput from a few thousand on.  Every fibre's
+    result is independent of what else is in its batch.
+    Returns, per request, (outdicts, curmodels, arms_of): lists over its fibres
+    (None for fibres without a usable arm)."""
+    out = [([None] * r['nsel'], [None] * r['nsel'], [None] * r['nsel'])
+           for r in reqs]
+    groups = {}
+    for ir, r in enumerate(reqs):
+        key = (tuple(r['setups']),
+               tuple(r['waves'][s].tobytes() for s in r['setups']),
+               tuple(r['cond'][s]['taps'] is not None for s in r['setups']))
+        groups.setdefault(key, []).append(ir)
+    for (setups, _, _), members in groups.items():
+        setups = list(setups)
+        waves = reqs[members[0]]['waves']
+        okmat = np.concatenate([reqs[ir]['okmat'] for ir in members], axis=0)
+        owner = np.concatenate([np.full(reqs[ir]['nsel'], ir) for ir in members])
+        local = np.concatenate([np.arange(reqs[ir]['nsel']) for ir in members])
+        if len(members) == 1:
+            cond = reqs[members[0]]['cond']
+        else:
+            cond = {}
+            for s in setups:
+                cs = [reqs[ir]['cond'][s] for ir in members]
+                cond[s] = {k: (None if cs[0][k] is None else
+                               np.concatenate([c[k] for c in cs], axis=0))
+                           for k in ('spec', 'espec', 'badmask', 'ok', 'taps')}
+        for pattern in sorted({tuple(_) for _ in okmat.tolist()}, reverse=True):
+            if not any(pattern):
+                continue
+            rows_p = np.nonzero(
+                (okmat == np.array(pattern)[None, :]).all(axis=1))[0]
+            names_p = ['desi_%s' % s for s, u in zip(setups, pattern) if u]
+            for c0 in range(0, len(rows_p), max_batch):
+                rows = rows_p[c0:c0 + max_batch]
+                batch = _arm_batch(cond, setups, pattern, rows, waves, device)
+                fr = fit_batch(batch, config, options, ccf_init=ccf_init)
+                for k, (i, d) in enumerate(zip(rows, _outdicts(
+                        fr, names_p, config, ccf_init))):
+                    o = out[owner[i]]
+                    o[0][local[i]] = d
+                    o[1][local[i]] = [y[k] for y in fr['yfit']]
+                    o[2][local[i]] = names_p
+    return out
+
+
+def proc_desi(fname, tab_ofname, mod_ofname, fig_prefix, config, **kwargs):
+    """desi_fit.py:962-1299: fit every selected fibre of one DESI file and write
+    the RVTAB and RVMOD products (same keyword arguments as the reference, plus
+    device / max_batch / timers).  `poolex` is accepted for signature
+    compatibility and unused: the fibres of the file are one GPU batch (in
+    chunks of `max_batch`).  Returns the number of fibres selected, or -1.
+    `timers` (dict) receives the wall seconds of the stages read / select /
+    condition / fit / write."""
+    return proc_desi_group([(fname, tab_ofname, mod_ofname, fig_prefix)], config,
+                           **kwargs)[0]
+
+
+def _group_prepare(files, config, kwargs):
+    """read, select and condition every file of the group (host only): the
+    generators parked at their fit request, and the return values of the files
+    that needed no fit"""
+    gens, rets = [], [None] * len(files)
+    for i, f in enumerate(files):
+        g = _proc_desi_steps(*f, config, **kwargs)
+        try:
+            gens.append((i, g, next(g)))
+        except StopIteration as e:
+            rets[i] = e.value
+    return gens, rets
+
+
+def _group_finish(state, config, kwargs):
+    """fit the parked requests together and let every file write its products"""
+    gens, rets = state
+    npoly = kwargs.get('npoly')
+    options = {'npoly': 10 if npoly is None else npoly}
+    res = _fit_requests([r for _, _, r in gens], config, options,
+                        ccf_init=kwargs.get('ccf_init', True),
+                        device=kwargs.get('device', 'cuda'),
+                        max_batch=kwargs.get('max_batch', 4096))
+    for (i, g, _), r in zip(gens, res):
+        try:
+            g.send(r)
+            raise RuntimeError('proc_desi generator did not finish')
+        except StopIteration as e:
+            rets[i] = e.value
+    return rets
+
+
+def proc_desi_group(files, config, **kwargs):
+    """proc_desi for several files at once: `files` is a list of (fname,
+    tab_ofname, mod_ofname, fig_prefix); the selected fibres of ALL of them go
+    through the GPU together (_fit_requests), the products are written per file
+    as by proc_desi.  Returns the list of proc_desi return values."""
+    return _group_finish(_group_prepare(files, config, kwargs), config, kwargs)
 
 
 def proc_desi_wrapper(*args, **kwargs):
@@ -1100,12 +1185,15 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
               ccf_init=True, subdirs=True, ccf_continuum_normalize=True,
               process_status_file=None, use_resolution_matrix=None, npoly=None,
               throw_exceptions=None, log_level=None, log_filename=None,
-              shard=None):
+              shard=None, files_per_batch=4):
     """desi_fit.py:1392-1551: loop over files.  `nthreads` is accepted and
-    unused (one file is one GPU batch).  `shard=(rank, world)` -- or the
-    RANK/WORLD_SIZE environment of torch.distributed.run -- gives every GPU
-    process its own stride of the file list; files are independent, there is
-    no collective."""
+    unused.  `files_per_batch` files are read and conditioned one after the
+    other and FITTED TOGETHER (proc_desi_group: a single 500-fibre coadd leaves
+    the lock-step optimiser latency-bound); should the group fail, its files
+    are retried one by one so that the failure lands on the file that caused
+    it.  `shard=(rank, world)` -- or the RANK/WORLD_SIZE environment of
+    torch.distributed.run -- gives every GPU process its own stride of the file
+    list; files are independent, there is no collective."""
     override = dict(ccf_continuum_normalize=ccf_continuum_normalize)
     config = utils.read_config(config_fname, override)
     assert (config is not None)
@@ -1119,6 +1207,58 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
             process_status_file = '%s.%d' % (process_status_file, rank)
         update_process_status_file(process_status_file, None, None, None, None,
                                    start=True)
+    kw = dict(fit_targetid=fit_targetid, objtypes=objtypes, doplot=doplot,
+              minsn=minsn, expid_range=expid_range, fitarm=fitarm,
+              cmdline=cmdline, zbest_select=zbest_select,
+              zbest_include=zbest_include, npoly=npoly, ccf_init=ccf_init,
+              use_resolution_matrix=bool(use_resolution_matrix))
+    # Groups of files_per_batch files.  While the GPU fits group g, a worker
+    # thread reads and conditions group g + 1 (numpy and file I/O release the
+    # GIL; the fit thread spends its time inside the library).
+    import concurrent.futures
+    pool = concurrent.futures.ThreadPoolExecutor(1)
+    pending = []
+    inflight = []   # [(group, future of _group_prepare)]
+
+    def one_by_one(group):
+        for f, t, m in group:
+            proc_desi_wrapper(f, t, m, None, config,
+                              process_status_file=process_status_file,
+                              throw_exceptions=throw_exceptions, **kw)
+
+    def finish_oldest():
+        group, fut = inflight.pop(0)
+        t1 = time.time()
+        try:
+            rets = _group_finish(fut.result(), config, kw)
+        except Exception:  # noqa: BLE001 -- retried per file
+            logging.exception('group of %d files failed; retrying one by one'
+                              % len(group))
+            one_by_one(group)
+            return
+        if process_status_file is not None:
+            dt = (time.time() - t1) / len(group)
+            for (f, _, _), n in zip(group, rets):
+                update_process_status_file(
+                    process_status_file, f,
+                    ProcessStatus.SUCCESS if n >= 0 else ProcessStatus.FAILURE,
+                    max(n, 0), dt)
+
+    def flush():
+        if not pending:
+            return
+        group = list(pending)
+        del pending[:]
+        if len(group) == 1:
+            while inflight:
+                finish_oldest()
+            one_by_one(group)
+            return
+        inflight.append((group, pool.submit(
+            _group_prepare, [(f, t, m, None) for f, t, m in group], config, kw)))
+        if len(inflight) > 1:   # group g + 1 is being prepared: fit group g
+            finish_oldest()
+
     for f in list(files)[rank::world]:
         fname = f.split('/')[-1]
         if subdirs:
@@ -1131,7 +1271,6 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
         else:
             folder_path = output_dir + '/'
         os.makedirs(folder_path, exist_ok=True)
-        cur_figure_prefix = None
         fname0 = fname[:-3] if fname[-3:] == '.gz' else fname
         tab_ofname = folder_path + output_tab_prefix + '_' + fname0
         mod_ofname = folder_path + output_mod_prefix + '_' + fname0
@@ -1142,14 +1281,11 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
                 update_process_status_file(process_status_file, f,
                                            ProcessStatus.EXISTING, -1, 0)
             continue
-        proc_desi_wrapper(
-            f, tab_ofname, mod_ofname, cur_figure_prefix, config,
-            fit_targetid=fit_targetid, objtypes=objtypes, doplot=doplot,
-            minsn=minsn, expid_range=expid_range, fitarm=fitarm,
-            cmdline=cmdline, zbest_select=zbest_select,
-            zbest_include=zbest_include,
-            process_status_file=process_status_file, npoly=npoly,
-            ccf_init=ccf_init,
-            use_resolution_matrix=bool(use_resolution_matrix),
-            throw_exceptions=throw_exceptions)
+        pending.append((f, tab_ofname, mod_ofname))
+        if len(pending) >= max(1, files_per_batch):
+            flush()
+    flush()
+    while inflight:
+        finish_oldest()
+    pool.shutdown()
     logging.info('Successfully finished processing')

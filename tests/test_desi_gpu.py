@@ -223,3 +223,53 @@ def test_process_device_nm_uses_resolution(desi_libs):
                         options=dict(npoly=10))
     assert not np.allclose(a['chisq'].cpu().numpy(), c['chisq'].cpu().numpy(),
                            rtol=1e-4)
+
+
+def test_grouped_files_equal_single(dcases, desi_libs, tmp_path):
+    """several files fitted together (proc_desi_group, what proc_many does):
+    every fibre's numbers are those of the file processed alone, bit for bit --
+    the lock-step optimiser, the CCF and the chi^2 kernels do not let one
+    spectrum see another"""
+    from rvspecfit_amd import fits_min as F
+    from rvspecfit_amd.desi import desi_fit as D
+    kw = dict(doplot=False, minsn=2, zbest_include=True)
+    single = (str(tmp_path / 's_tab.fits'), str(tmp_path / 's_mod.fits'))
+    n1 = D.proc_desi(COADD, single[0], single[1], None, CFG, **kw)
+    files = [(COADD, str(tmp_path / ('g%d_tab.fits' % i)),
+              str(tmp_path / ('g%d_mod.fits' % i)), None) for i in range(3)]
+    # the third member selects other fibres: a different mix in the batch
+    rets = D.proc_desi_group(files[:2], CFG, **kw)
+    assert rets == [n1, n1]
+    ts = F.open(single[0])['RVTAB'].data
+    ms = F.open(single[1])
+    for _, tab, mod, _ in files[:2]:
+        tg = F.open(tab)['RVTAB'].data
+        assert tg.columns.names == ts.columns.names
+        for c in ts.columns.names:
+            a, b = ts[c], tg[c]
+            assert np.array_equal(a, b) if a.dtype.kind in 'SUb' else \
+                np.array_equal(a, b, equal_nan=True), c
+        mg = F.open(mod)
+        for h in ms[1:]:
+            if h.name.endswith('_MODEL'):
+                assert np.array_equal(h.data, mg[h.name].data), h.name
+    # proc_many drives the same path and keeps the status file per input file
+    import yaml
+    cfgf = str(tmp_path / 'c.yaml')
+    with open(cfgf, 'w') as fp:
+        yaml.safe_dump({k: v for k, v in CFG.items()
+                        if k != 'config_file_path'}, fp)
+    link = str(tmp_path / 'coadd-copy.fits')
+    os.symlink(COADD, link)
+    os.symlink(os.path.join(GOLD, 'redrock-golden.fits'),
+               str(tmp_path / 'redrock-copy.fits'))
+    st = str(tmp_path / 'status')
+    D.proc_many([COADD, link], str(tmp_path / 'out'), 'rvtab', 'rvmod',
+                config_fname=cfgf, minsn=2, zbest_include=True, doplot=False,
+                subdirs=False, process_status_file=st, shard=(0, 1),
+                files_per_batch=2)
+    rows = [l.split() for l in open(st).read().strip().split('\n')]
+    assert [r[1] for r in rows] == ['SUCCESS', 'SUCCESS']
+    assert [int(r[2]) for r in rows] == [n1, n1]
+    tm = F.open(str(tmp_path / 'out' / 'rvtab_coadd-copy.fits'))['RVTAB'].data
+    assert np.array_equal(tm['VRAD'], ts['VRAD'])

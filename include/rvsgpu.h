@@ -285,7 +285,11 @@ int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
  * rotational kernel.  params [J, ndim], vsini [J] (nullable = no rotation),
  * vel [J]; scratch: rvs_objective_work_size(J, narm) bytes;
  * out[j] = sum over arms of chisq + outside*badchi (NaN outside: + 1000*badchi).
+ * outside_penalty: bit 0 = add the outside*badchi penalty; bit 1
+ * (RVS_OBJ_STATUS_STORE) = status[j] is overwritten instead of OR-ed into (the
+ * optimiser's per-call scratch needs no clearing launch).
  * ---------------------------------------------------------------------- */
+#define RVS_OBJ_STATUS_STORE 2
 typedef struct rvs_objective_arm {
   rvs_point_arm pt;
   const float *dats;

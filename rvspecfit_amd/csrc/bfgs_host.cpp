@@ -20,7 +20,6 @@
 #include <coroutine>
 #include <cstdint>
 #include <cstring>
-#include <limits>
 #include <vector>
 
 #include "../../include/rvsgpu.h"
@@ -29,7 +28,6 @@ namespace {
 
 constexpr int MAXN = 16;
 constexpr double EPS_FD = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON)
-const double NaN = std::numeric_limits<double>::quiet_NaN();
 
 struct Task {
   struct promise_type {

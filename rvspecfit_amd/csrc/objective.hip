@@ -695,11 +695,15 @@ __global__ void objective_sum_kernel(int narm, int J, double badchi,
       tot += 1000.0 * badchi;
       continue;
     }
-    tot += armchi[(int64_t)ia * J + j] + (outside_penalty ? o * badchi : 0.0);
+    tot += armchi[(int64_t)ia * J + j] +
+           ((outside_penalty & 1) ? o * badchi : 0.0);
     st |= armst[(int64_t)ia * J + j];
   }
   out[j] = tot;
-  if (st) atomicOr(&status[j], st);
+  if (outside_penalty & 2)
+    status[j] = st;  // RVS_OBJ_STATUS_STORE: the caller's buffer is scratch
+  else if (st)
+    atomicOr(&status[j], st);
 }
 
 // largest template grid (knots) the kernel can hold in LDS for this npoly:

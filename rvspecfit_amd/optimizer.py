@@ -150,11 +150,11 @@ class ProcessObjective:
                             _p(self.params), _p(self.extra), _p(self.bad), st)
         _lib.check(rc, 'rvs_proc_map')
         if self.fused:   # one kernel: gather, FIR, spline solve, chi^2
-            self.jstatus.zero_()
+            # 1 | RVS_OBJ_STATUS_STORE: jstatus is overwritten, no clearing launch
             rc = L.rvs_objective_fused(
                 ctypes.addressof(self.oarr), len(self.arm_buf), self.npoly,
                 _p(self.params), _p(self.vsini), _p(self.job_spec), J,
-                _p(self.vel), self.badchi, 1, _p(self.oscratch), _p(self.chi),
+                _p(self.vel), self.badchi, 3, _p(self.oscratch), _p(self.chi),
                 _p(self.jstatus), st)
             _lib.check(rc, 'rvs_objective_fused')
             rc = L.rvs_proc_finish(J, _p(counts), cidx, _p(self.chi),

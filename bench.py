@@ -252,6 +252,10 @@ def main():
                     help='with --desi-file: this many copies of the file are '
                          'processed as one group (desi_fit.proc_desi_group, what '
                          'proc_many does with files_per_batch)')
+    ap.add_argument('--desi-workers', type=int, default=1,
+                    help='with --desi-nfiles: worker processes sharing the GPU '
+                         '(proc_many nthreads); the synthetic template libraries '
+                         'are written to disk for them')
     ap.add_argument('--cpu-process', action='store_true',
                     help='(cpu worker) run the oracle process stage')
     ap.add_argument('--workload', choices=['desi', 'cfg2'], default='desi',
@@ -474,7 +478,7 @@ def main():
     desi = None
     if args.desi_file > 0 and rank == 0 and EVALUATOR == 'polylinear' \
             and args.workload == 'desi':
-        desi = run_desi_addon(arms, args, dev)
+        desi = run_desi_addon(arms, args, dev, dicts)
 
     line = dict(
         metric='spectra/sec (CCF+chi2 grid) DESI 3-arm',
@@ -576,7 +580,7 @@ def run_process_addon(batch, rec, arms, args, dev):
     return out
 
 
-def run_desi_addon(arms, args, dev):
+def run_desi_addon(arms, args, dev, dicts):
     """the survey driver end to end on one synthetic coadd
     file of N fibres x 3 DESI arms (float32 flux/ivar, int32 mask, as the real
     files), from the FITS bytes on disk to the RVTAB/RVMOD products."""
@@ -634,10 +638,19 @@ def run_desi_addon(arms, args, dev):
         # the driver's file loop: groups of 4 files fitted together, the next
         # group read and conditioned by a worker thread meanwhile
         import yaml
+        cfgy = {k: v for k, v in cfg.items() if k != 'config_file_path'}
+        if args.desi_workers > 1:
+            # worker processes load the libraries from disk (untimed)
+            tl = os.path.join(tmp, 'templ')
+            os.makedirs(tl)
+            for name, d in dicts.items():
+                np.savez(os.path.join(tl, 'rvsgpu_%s.npz' % name), **d)
+            cfgy['template_lib'] = tl + '/'
         cfgf = os.path.join(tmp, 'config.yaml')
         with open(cfgf, 'w') as fp:
-            yaml.safe_dump({k: v for k, v in cfg.items()
-                            if k != 'config_file_path'}, fp)
+            yaml.safe_dump(cfgy, fp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         links = [fname]
         for i in range(1, nfiles):
             links.append(os.path.join(tmp, 'coadd-bench%d.fits' % i))
@@ -646,7 +659,8 @@ def run_desi_addon(arms, args, dev):
         D.proc_many(links, tmp, 'rvtab', 'rvmod', config_fname=cfgf, minsn=-1e9,
                     doplot=False, subdirs=False, npoly=OPTIONS['npoly'],
                     process_status_file=st, shard=(0, 1),
-                    files_per_batch=min(4, nfiles))
+                    files_per_batch=min(4, nfiles),
+                    nthreads=max(1, args.desi_workers))
         rows = [l.split() for l in open(st).read().strip().split('\n')]
         assert all(r[1] == 'SUCCESS' for r in rows), rows
         nfit = sum(int(r[2]) for r in rows)
@@ -657,6 +671,7 @@ def run_desi_addon(arms, args, dev):
     tab = F.open(tabf, verify_checksum=True)['RVTAB'].data
     warn = np.asarray(tab['RVS_WARN'])
     out = dict(fibres=int(nfit), files=nfiles,
+               workers=max(1, args.desi_workers) if nfiles > 1 else 1,
                fibres_per_s=round(nfit / dt, 1), seconds=round(dt, 2),
                stage_s={k: round(v, 3) for k, v in tm.items()},
                input_MB=round(os.path.getsize(fname) / 1e6, 1),

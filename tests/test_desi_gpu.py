@@ -273,3 +273,47 @@ def test_grouped_files_equal_single(dcases, desi_libs, tmp_path):
     assert [int(r[2]) for r in rows] == [n1, n1]
     tm = F.open(str(tmp_path / 'out' / 'rvtab_coadd-copy.fits'))['RVTAB'].data
     assert np.array_equal(tm['VRAD'], ts['VRAD'])
+
+
+def test_proc_many_worker_processes(dcases, tmp_path):
+    """nthreads = 2: two worker processes share the GPU, each with its stride
+    of the file list (the library comes from disk: converted-artefact files in
+    config['template_lib']); products identical to the single-process run"""
+    import shutil
+    import yaml
+    from rvspecfit_amd import fits_min as F
+    from rvspecfit_amd.desi import desi_fit as D
+    tl = tmp_path / 'templ'
+    tl.mkdir()
+    for n in ('desi_b', 'desi_r', 'desi_z'):
+        shutil.copy(os.path.join(GOLD, 'lib_%s.npz' % n),
+                    str(tl / ('rvsgpu_%s.npz' % n)))
+    cfgf = str(tmp_path / 'c.yaml')
+    cfg = {k: v for k, v in CFG.items() if k != 'config_file_path'}
+    cfg['template_lib'] = str(tl) + '/'
+    with open(cfgf, 'w') as fp:
+        yaml.safe_dump(cfg, fp)
+    links = []
+    for i in range(4):
+        links.append(str(tmp_path / ('coadd-c%d.fits' % i)))
+        os.symlink(COADD, links[-1])
+        os.symlink(os.path.join(GOLD, 'redrock-golden.fits'),
+                   str(tmp_path / ('redrock-c%d.fits' % i)))
+    outs = {}
+    for nthr in (1, 2):
+        od = str(tmp_path / ('out%d' % nthr))
+        st = str(tmp_path / ('status%d' % nthr))
+        D.proc_many(links, od, 'rvtab', 'rvmod', config_fname=cfgf, minsn=2,
+                    zbest_include=True, doplot=False, subdirs=False,
+                    process_status_file=st, shard=(0, 1), files_per_batch=2,
+                    nthreads=nthr)
+        rows = sorted(l.split()[:3] for l in open(st).read().strip().split('\n'))
+        assert [r[0] for r in rows] == sorted(links)
+        assert all(r[1] == 'SUCCESS' and int(r[2]) == 10 for r in rows)
+        outs[nthr] = [F.open(os.path.join(od, 'rvtab_coadd-c%d.fits' % i)
+                             )['RVTAB'].data for i in range(4)]
+    for a, b in zip(outs[1], outs[2]):
+        for c in a.columns.names:
+            x, y = a[c], b[c]
+            assert np.array_equal(x, y) if x.dtype.kind in 'SUb' else \
+                np.array_equal(x, y, equal_nan=True), c

@@ -15,7 +15,6 @@ calls and three host synchronisations per round cost more than the GPU work.
 """
 import ctypes
 
-import numpy as np
 import torch
 
 from . import _lib

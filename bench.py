@@ -531,13 +531,22 @@ def run_process_addon(batch, rec, arms, args, dev):
     cfg.setdefault('max_vsini', 500)
     cfg['second_minimizer'] = bool(args.process_bfgs)
     vel_fit.process(sub, pd0, options=OPTIONS, config=cfg)   # warm-up
-    tm = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    r = vel_fit.process(sub, pd0, options=OPTIONS, config=cfg, timers=tm)
+    r = vel_fit.process(sub, pd0, options=OPTIONS, config=cfg)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the stage breakdown comes from a second, single-stream run (stage timers
+    # switch off the two-halves split of vel_fit.process)
+    tm = {}
+    t1 = time.perf_counter()
+    vel_fit.process(sub, pd0, options=OPTIONS, config=cfg, timers=tm)
+    torch.cuda.synchronize()
+    dt1 = time.perf_counter() - t1
     out = dict(spectra=n, spectra_per_s=round(n / dt, 1), seconds=round(dt, 2),
+               streams=vel_fit.PROCESS_STREAMS if n >= vel_fit.PROCESS_SPLIT_MIN
+               else 1,
+               single_stream_seconds=round(dt1, 2),
                stage_s={k: round(v, 3) for k, v in tm.items()},
                nm_rounds=int(r['nm_rounds']),
                nm_iterations_mean=round(float(r['nm_nit'].float().mean()), 1),

@@ -490,6 +490,32 @@ int rvs_proc_finish(int J, const int32_t *counts, int cidx, const double *chi,
                     const int32_t *job_spec, const int32_t *job_status,
                     double *F, int32_t *spec_status, void *stream);
 
+/* The rounds themselves, driven from C (what a caller of the entry points above
+ * does per round, with the fused objective as chisq_func): blocks the calling
+ * host thread until every simplex has stopped.  `m` holds the state arrays of
+ * rvs_nm_* (fsim ordered, as for rvs_nm_begin), `o` the arguments of
+ * rvs_proc_map / rvs_objective_fused / rvs_proc_finish and their row buffers
+ * (capacity S rows; scratch: rvs_objective_work_size(S, narm) bytes).
+ * stats (nullable) int64[3] = rounds, objective calls, rows evaluated. */
+typedef struct rvs_nm_state {
+  double *sim, *fsim, *X1, *X2, *F1, *F2;
+  int32_t *nit, *nfev, *flags, *list1, *list2, *list3, *cases, *pos2, *counts;
+  int32_t S, N;
+} rvs_nm_state;
+typedef struct rvs_nm_objective {
+  const rvs_objective_arm *arms;
+  const double *fixed, *vsini_fixed, *safe, *prior_mean, *prior_isig;
+  double *vel, *vsini, *params, *extra, *chi;
+  int32_t *job_spec, *bad, *jstatus, *status;
+  void *scratch;
+  double min_vel, max_vel, max_vsini, badchi;
+  int32_t narm, npoly, n, ndim, vsini_col;
+  int32_t src[8];
+} rvs_nm_objective;
+int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o, double xatol,
+               double fatol, int maxiter, int sync_every, int64_t *stats,
+               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,7 @@ SIGNATURES = {
     'rvs_proc_map': (I, [I, I, I, P, P, P, I, P, P, P, P, P, D, D, D, P, P, P, P,
                           P, P, P]),
     'rvs_proc_finish': (I, [I, P, I, P, P, P, P, P, P, P, P]),
+    'rvs_nm_run': (I, [P, P, D, D, I, I, P, P]),
     'rvs_bfgs_begin': (P, [I, I, P, P, D, D, D, D, I]),
     'rvs_bfgs_pending': (L, [P, P, P, L]),
     'rvs_bfgs_feed': (I, [P, P, L]),
@@ -90,6 +91,27 @@ def lib():
             fn.argtypes = args
         _lib = L_
     return _lib
+
+
+class NmState(ctypes.Structure):
+    """rvs_nm_state of include/rvsgpu.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ('sim', 'fsim', 'X1', 'X2', 'F1', 'F2', 'nit', 'nfev', 'flags',
+                 'list1', 'list2', 'list3', 'cases', 'pos2', 'counts')] + [
+                    ('S', ctypes.c_int32), ('N', ctypes.c_int32)]
+
+
+class NmObjective(ctypes.Structure):
+    """rvs_nm_objective of include/rvsgpu.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ('arms', 'fixed', 'vsini_fixed', 'safe', 'prior_mean',
+                 'prior_isig', 'vel', 'vsini', 'params', 'extra', 'chi',
+                 'job_spec', 'bad', 'jstatus', 'status', 'scratch')] + [
+                    (k, ctypes.c_double) for k in
+                    ('min_vel', 'max_vel', 'max_vsini', 'badchi')] + [
+                    (k, ctypes.c_int32) for k in
+                    ('narm', 'npoly', 'n', 'ndim', 'vsini_col')] + [
+                    ('src', ctypes.c_int32 * 8)]
 
 
 class PointArm(ctypes.Structure):

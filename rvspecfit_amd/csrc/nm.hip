@@ -600,3 +600,110 @@ extern "C" int rvs_proc_finish(int J, const int32_t *counts, int cidx,
   RVS_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------
+// The rounds of the lock-step optimiser driven from C: what optimizer.py's
+// DeviceNelderMead.minimize + ProcessObjective.eval do per round (begin -> map ->
+// objective -> finish -> decide -> map -> objective -> finish -> update, the
+// host looking at the counters every `sync_every` rounds, parked shrinks run at
+// that look), without ~25 interpreter round trips per round.  The call blocks
+// its host thread but not the interpreter (ctypes releases the GIL), so two
+// optimiser instances on two streams can be driven by two Python threads.
+// ---------------------------------------------------------------------------
+static int nm_eval(const rvs_nm_objective *o, const int32_t *list,
+                   const double *X, int J, const int32_t *counts, int cidx,
+                   double *F, hipStream_t st) {
+  int rc = rvs_proc_map(J, o->n, o->ndim, X, list, o->src, o->vsini_col,
+                        o->fixed, o->vsini_fixed, o->safe, o->prior_mean,
+                        o->prior_isig, o->min_vel, o->max_vel, o->max_vsini,
+                        o->job_spec, o->vel, o->vsini, o->params, o->extra,
+                        o->bad, st);
+  if (rc) return rc;
+  rc = rvs_objective_fused(o->arms, o->narm, o->npoly, o->params, o->vsini,
+                           o->job_spec, J, o->vel, o->badchi,
+                           1 | RVS_OBJ_STATUS_STORE, o->scratch, o->chi,
+                           o->jstatus, st);
+  if (rc) return rc;
+  return rvs_proc_finish(J, counts, cidx, o->chi, o->extra, o->bad, o->job_spec,
+                         o->jstatus, F, o->status, st);
+}
+
+static int nm_bucket(int n, int S) {
+  // quantised launch bound (1/8 steps of the next power of two), as optimizer.py
+  if (n <= 64) return S < 64 ? S : 64;
+  int p2 = 1;
+  while (p2 < n) p2 <<= 1;
+  const int stepq = (p2 / 8 > 1) ? p2 / 8 : 1;
+  const int b = ((n + stepq - 1) / stepq) * stepq;
+  return b < S ? b : S;
+}
+
+extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
+                          double xatol, double fatol, int maxiter,
+                          int sync_every, int64_t *stats, void *stream) {
+  if (!m || !o || m->S < 1 || m->N < 1 || m->N > NM_MAXN || sync_every < 1)
+    return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  const int S = m->S, N = m->N;
+  int64_t rounds = 0, calls = 0, jobs = 0;
+  int32_t c[8];
+  int rc = rvs_nm_begin(S, N, xatol, fatol, maxiter, m->sim, m->fsim, m->nit,
+                        m->flags, m->list1, m->X1, m->counts, S, st);
+  if (rc) return rc;
+  while (true) {
+    if (hipMemcpyAsync(c, m->counts, sizeof(c), hipMemcpyDeviceToHost, st) !=
+            hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return RVS_E_LAUNCH;
+    const int live = c[0], parked = c[4];
+    if (parked > 0) {  // scipy's shrink step for the parked simplices
+      rc = rvs_nm_collect(S, m->flags, m->list3, m->counts, st);
+      if (rc) return rc;
+      for (int k = 1; k <= N; k++) {
+        rc = rvs_nm_shrink_point(N, k, m->sim, m->list3, m->X2, m->counts,
+                                 parked, st);
+        if (rc) return rc;
+        rc = nm_eval(o, m->list3, m->X2, parked, m->counts, 2, m->F2, st);
+        if (rc) return rc;
+        calls++;
+        jobs += parked;
+        rc = rvs_nm_shrink_store(N, k, m->sim, m->fsim, m->nit, m->nfev,
+                                 m->flags, m->list3, m->F2, m->counts, parked,
+                                 st);
+        if (rc) return rc;
+      }
+      rc = rvs_nm_begin(S, N, xatol, fatol, maxiter, m->sim, m->fsim, m->nit,
+                        m->flags, m->list1, m->X1, m->counts, S, st);
+      if (rc) return rc;
+      continue;
+    }
+    if (live == 0) break;
+    const int jb = nm_bucket(live, S);
+    for (int r = 0; r < sync_every; r++) {
+      rc = rvs_nm_begin(S, N, xatol, fatol, maxiter, m->sim, m->fsim, m->nit,
+                        m->flags, m->list1, m->X1, m->counts, jb, st);
+      if (rc) return rc;
+      rc = nm_eval(o, m->list1, m->X1, jb, m->counts, 0, m->F1, st);
+      if (rc) return rc;
+      rc = rvs_nm_decide(N, m->sim, m->fsim, m->list1, m->F1, m->cases,
+                         m->pos2, m->list2, m->X2, m->counts, jb, st);
+      if (rc) return rc;
+      rc = nm_eval(o, m->list2, m->X2, jb, m->counts, 1, m->F2, st);
+      if (rc) return rc;
+      rc = rvs_nm_update(N, m->sim, m->fsim, m->nit, m->nfev, m->list1, m->X1,
+                         m->F1, m->cases, m->pos2, m->X2, m->F2, m->flags,
+                         m->counts, jb, st);
+      if (rc) return rc;
+      calls += 2;
+      jobs += 2 * (int64_t)jb;
+    }
+    rounds += sync_every;
+  }
+  if (stats) {
+    stats[0] = rounds;
+    stats[1] = calls;
+    stats[2] = jobs;
+  }
+  return 0;
+}
+

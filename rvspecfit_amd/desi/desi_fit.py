@@ -1282,7 +1282,11 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
         group, fut = inflight.pop(0)
         t1 = time.time()
         try:
-            rets = _group_finish(fut.result(), config, kw)
+            from .. import vel_fit
+            state = fut.result()
+            # the worker thread is conditioning the next group meanwhile
+            with vel_fit.single_stream():
+                rets = _group_finish(state, config, kw)
         except Exception:  # noqa: BLE001 -- retried per file
             logging.exception('group of %d files failed; retrying one by one'
                               % len(group))

@@ -681,7 +681,10 @@ _ar_cache = {}
 def _arange32(a, b, dev):
     key = (a, b, str(dev))
     if key not in _ar_cache:
-        _ar_cache[key] = torch.arange(a, b, dtype=torch.int32, device=dev)
+        t = torch.arange(a, b, dtype=torch.int32, device=dev)
+        # shared by later callers on other streams (vel_fit._process_split)
+        torch.cuda.current_stream(t.device).synchronize()
+        _ar_cache[key] = t
     return _ar_cache[key]
 
 

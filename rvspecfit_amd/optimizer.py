@@ -135,6 +135,27 @@ class ProcessObjective:
         self.calls = 0
         self.jobs = 0
 
+    def native_desc(self):
+        """rvs_nm_objective: this objective for the C round driver"""
+        o = _lib.NmObjective()
+        o.arms = ctypes.addressof(self.oarr)
+        for k, t in (('fixed', self.fixed), ('vsini_fixed', self.vsini_fixed),
+                     ('safe', self.safe), ('prior_mean', self.prior_mean),
+                     ('prior_isig', self.prior_isig), ('vel', self.vel),
+                     ('vsini', self.vsini), ('params', self.params),
+                     ('extra', self.extra), ('chi', self.chi),
+                     ('job_spec', self.job_spec), ('bad', self.bad),
+                     ('jstatus', self.jstatus), ('status', self.status),
+                     ('scratch', self.oscratch)):
+            setattr(o, k, None if t is None else t.data_ptr())
+        o.min_vel, o.max_vel = self.min_vel, self.max_vel
+        o.max_vsini, o.badchi = self.max_vsini, self.badchi
+        o.narm, o.npoly = len(self.arm_buf), self.npoly
+        o.n, o.ndim, o.vsini_col = self.n, self.ndim, self.vsini_col
+        for i in range(8):
+            o.src[i] = self.src[i] if i < self.ndim else -1
+        return o
+
     def eval(self, list_t, X, J, counts, cidx, F):
         """F[:J] = chisq_func(X[j]) for spectrum list_t[j]; rows >= the device
         count are padding (evaluated, ignored)."""
@@ -205,6 +226,9 @@ class ProcessObjective:
 
 
 import os as _os
+# RVS_NM_NATIVE=0: the rounds driven from Python (one_round below) instead of
+# rvs_nm_run
+NATIVE_ROUNDS = _os.environ.get('RVS_NM_NATIVE', '1') != '0'
 # RVS_NM_GRAPH=1: replay each round from a HIP graph.  Measured: same wall time
 # (3.1 s per 2000 spectra either way) -- the rounds are bound by the GPU-side
 # chain of ~25 small dependent kernels, not by host launches -- so it is off.
@@ -247,6 +271,34 @@ class DeviceNelderMead:
         sim = sim.contiguous()
         self.fsim.copy_(fsim)
         fs = self.fsim
+        if NATIVE_ROUNDS and isinstance(objective, ProcessObjective) and \
+                objective.fused:
+            # the rounds in C (rvs_nm_run): same launches, no interpreter
+            m = _lib.NmState()
+            for k, t in (('sim', sim), ('fsim', fs), ('X1', self.X1),
+                         ('X2', self.X2), ('F1', self.F1), ('F2', self.F2),
+                         ('nit', self.nit), ('nfev', self.nfev),
+                         ('flags', self.flags), ('list1', self.list1),
+                         ('list2', self.list2), ('list3', self.list3),
+                         ('cases', self.cases), ('pos2', self.pos2),
+                         ('counts', self.counts)):
+                setattr(m, k, t.data_ptr())
+            m.S, m.N = S, N
+            o = objective.native_desc()
+            st3 = (ctypes.c_int64 * 3)()
+            rc = L.rvs_nm_run(ctypes.addressof(m), ctypes.addressof(o),
+                              float(xatol), float(fatol), int(maxiter),
+                              int(sync_every), st3, _lib.stream())
+            _lib.check(rc, 'rvs_nm_run')
+            objective.calls += int(st3[1])
+            objective.jobs += int(st3[2])
+            if stats is not None:
+                stats['rounds'] = stats.get('rounds', 0) + int(st3[0])
+            success = (self.flags & 2) != 0
+            return dict(x=sim[:, 0].clone(), fun=fs.min(dim=1)[0],
+                        nit=self.nit.long(), nfev=self.nfev.long(),
+                        success=success, final_simplex=(sim, fs))
+
         def one_round(jb):
             st = _lib.stream()
             rc = L.rvs_nm_begin(S, N, xatol, fatol, maxiter, _p(sim), _p(fs),

@@ -6,10 +6,12 @@ _find_best_vel_iterate (:315-355) and the first step of process (:571-602).
 simplices (neldermead.py) over batched objective evaluations (SURVEY 8(f)
 rank 1); see its docstring for what differs from the reference.
 """
+import contextlib
 import itertools
 import logging
 import math
 import os
+import threading
 import time
 
 import numpy as np
@@ -18,6 +20,7 @@ import torch
 from . import engine
 from . import spec_fit
 from . import spec_inter
+from .engine import SpecBatch
 from .spec_fit import as_batch
 
 
@@ -401,8 +404,128 @@ def _as_param_tensors(paramDict0, S, dev):
     return out
 
 
+# A SpecBatch of at least PROCESS_SPLIT_MIN spectra is fitted as two interleaved
+# halves by two host threads on two HIP streams: the optimiser's rounds run in C
+# (rvs_nm_run, no interpreter lock), so while one half is in the latency-bound
+# tail of its rounds the other's kernels fill the CUs.  Results are those of the
+# unsplit run, bit for bit (no spectrum sees another).  RVS_PROCESS_STREAMS=1
+# switches it off.
+PROCESS_STREAMS = int(os.environ.get('RVS_PROCESS_STREAMS', '2'))
+PROCESS_SPLIT_MIN = 256
+
+
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def single_stream():
+    """process() calls of this thread inside the block are not split: for
+    callers whose own host threads already keep the GPU and the interpreter busy
+    (desi_fit.proc_many, which conditions the next group of files meanwhile --
+    there the split measured 5 % slower)."""
+    old = getattr(_tls, 'single', False)
+    _tls.single = True
+    try:
+        yield
+    finally:
+        _tls.single = old
+
+
+def _merge_parts(parts, idxs, S):
+    """results of process() on the spectra idxs[k] -> one result over S"""
+    first = parts[0]
+    n0 = len(idxs[0])
+
+    def merge(vals):
+        v = vals[0]
+        if isinstance(v, dict):
+            return {k: merge([x[k] for x in vals]) for k in v}
+        if isinstance(v, (list, tuple)):
+            return [merge([x[i] for x in vals]) for i in range(len(v))]
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n0:
+            out = torch.empty((S, ) + tuple(v.shape[1:]), dtype=v.dtype,
+                              device=v.device)
+            for x, ix in zip(vals, idxs):
+                out[ix] = x
+            return out
+        if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == n0:
+            out = np.empty((S, ) + v.shape[1:], dtype=v.dtype)
+            for x, ix in zip(vals, idxs):
+                out[ix.cpu().numpy()] = x
+            return out
+        return v
+    out = {k: merge([p[k] for p in parts]) for k in first}
+    out['nm_rounds'] = max(p['nm_rounds'] for p in parts)
+    out['objective_evals'] = sum(p['objective_evals'] for p in parts)
+    if 'bfgs' in first:
+        out['bfgs']['rounds'] = max(p['bfgs']['rounds'] for p in parts)
+    return out
+
+
+_SPLIT_STREAMS = {}
+
+
+def _split_stream(dev, k):
+    # kept: the caching allocator's pools are per stream
+    key = (dev.index, k)
+    if key not in _SPLIT_STREAMS:
+        _SPLIT_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SPLIT_STREAMS[key]
+
+
+def _process_split(batch, paramDict0, kwargs):
+    S, dev = batch.S, batch.device
+    idxs = [torch.arange(k, S, 2, device=dev) for k in range(2)]
+    pd = _as_param_tensors(paramDict0, S, dev)
+    pri = kwargs.get('priors')
+    torch.cuda.current_stream().synchronize()
+    parts, errs = [None, None], [None, None]
+
+    def run(k):
+        try:
+            st = _split_stream(dev, k)
+            with torch.cuda.stream(st):
+                sub = batch.subset(idxs[k])
+                pdk = {n: v[idxs[k]].contiguous() for n, v in pd.items()}
+                kw = dict(kwargs)
+                if pri:
+                    # per-spectrum priors are tensors (see _Objective.chisq0)
+                    kw['priors'] = {
+                        n: tuple(x[idxs[k]].contiguous()
+                                 if isinstance(x, torch.Tensor) and x.dim()
+                                 else x for x in mv) for n, mv in pri.items()}
+                parts[k] = _process_one(sub, pdk, **kw)
+            st.synchronize()
+        except BaseException as e:  # noqa: BLE001 -- re-raised by the caller
+            errs[k] = e
+    th = [threading.Thread(target=run, args=(k, )) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    return _merge_parts(parts, idxs, S)
+
+
 def process(specdata, paramDict0, fixParam=None, options=None, config=None,
             resolParams=None, priors=None, timers=None):
+    """vel_fit.process (see _process_one); a large SpecBatch is fitted as two
+    concurrent halves (PROCESS_STREAMS)."""
+    if (PROCESS_STREAMS == 2 and isinstance(specdata, SpecBatch)
+            and specdata.S >= PROCESS_SPLIT_MIN and timers is None
+            and not getattr(_tls, 'single', False)):
+        return _process_split(specdata, paramDict0, dict(
+            fixParam=fixParam, options=options, config=config,
+            resolParams=resolParams, priors=priors))
+    return _process_one(specdata, paramDict0, fixParam=fixParam, options=options,
+                        config=config, resolParams=resolParams, priors=priors,
+                        timers=timers)
+
+
+def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
+                 resolParams=None, priors=None, timers=None):
     """vel_fit.process (vel_fit.py:505-737): velocity grid at the starting
     parameters -> Nelder-Mead (deterministic start simplex, fatol 1e-3, xatol
     1e-2, up to two runs) -> [BFGS] -> velocity refinement -> full output ->

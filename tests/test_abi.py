@@ -76,3 +76,35 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(root, f)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt, f
                 assert 'oracle_core' not in txt, f
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """the ctypes mirrors of the header's structs (rvspecfit_amd/_lib.py) have
+    the size and field offsets a C compiler gives them -- which also shows that
+    include/rvsgpu.h is plain C"""
+    import ctypes
+    from rvspecfit_amd import _lib
+    pairs = [('rvs_point_arm', _lib.PointArm),
+             ('rvs_objective_arm', _lib.ObjectiveArm),
+             ('rvs_nm_state', _lib.NmState),
+             ('rvs_nm_objective', _lib.NmObjective)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rvsgpu.h"',
+             'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));'
+                         % (cname, f[0], cname, f[0]))
+    lines += ['return 0; }']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = str(tmp_path / 'layout')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I',
+                           os.path.join(REPO, 'include'), str(src), '-o', exe])
+    got = dict(l.split() for l in
+               subprocess.check_output([exe]).decode().splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f in cls._fields_:
+            assert int(got['%s.%s' % (cname, f[0])]) == \
+                getattr(cls, f[0]).offset, (cname, f[0])

@@ -647,6 +647,54 @@ def test_process_batch_equals_singles(cases, pcases, config):
             [rb['param_err'][k][i] for k in ('teff', 'logg', 'feh', 'alpha')])
 
 
+def test_process_two_halves_equal_one_batch(cases, pcases, config):
+    """vel_fit.process fits a large SpecBatch as two interleaved halves on two
+    streams (two host threads over the native round driver): every result is that
+    of the single-stream run, bit for bit, priors and the second minimiser
+    included"""
+    from rvspecfit_amd import vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    S = 2 * vel_fit.PROCESS_SPLIT_MIN // 2 + 45
+    rng = np.random.RandomState(11)
+    base = [_sds(cases, t) for t in ('c1', 'c3')]
+    lists = [base[i % 2] for i in range(S)]
+    batch = SpecBatch.from_specdata(lists)
+    # different noise per spectrum, so that the paths differ
+    for a in batch.arms:
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.02 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pd0 = dict(teff=rng.uniform(5000, 6800, S), logg=rng.uniform(1.5, 4.5, S),
+               feh=rng.uniform(-1.5, -0.1, S), alpha=rng.uniform(0, 0.4, S),
+               vsini=rng.uniform(1, 60, S))
+    pri = {'teff': (torch.as_tensor(rng.uniform(5500, 6500, S)).to('cuda'), 300.)}
+    names = ('teff', 'logg', 'feh', 'alpha')
+    for cfg, kw in ((dict(config), {}), (dict(config, second_minimizer=True), {}),
+                    (dict(config), dict(priors=pri))):
+        out = []
+        for ns in (1, 2):
+            vel_fit.PROCESS_STREAMS = ns
+            try:
+                out.append(vel_fit.process(batch, dict(pd0),
+                                           options=dict(npoly=10), config=cfg,
+                                           **kw))
+            finally:
+                vel_fit.PROCESS_STREAMS = 2
+        a, b = out
+        for k in ('vel', 'vel_err', 'vel_skewness', 'vel_kurtosis', 'chisq',
+                  'vsini', 'nm_nit', 'nm_nfev', 'chisq_array', 'npix_array',
+                  'minimize_success'):
+            assert torch.equal(a[k], b[k]), k
+        for k in names:
+            assert torch.equal(a['param'][k], b['param'][k]), k
+            np.testing.assert_array_equal(a['param_err'][k], b['param_err'][k])
+        np.testing.assert_array_equal(a['bad_hessian'], b['bad_hessian'])
+        for x, y in zip(a['yfit'], b['yfit']):
+            assert torch.equal(x, y)
+        if 'bfgs' in a:
+            for k in ('nfev', 'nit', 'status'):
+                np.testing.assert_array_equal(a['bfgs'][k], b['bfgs'][k])
+
+
 def test_device_neldermead_equals_torch(gpu):
     """the rvs_nm_* kernels take the same path as neldermead.minimize (which the
     CPU suite pins to scipy): same nit, nfev, simplices, bit for bit -- including

@@ -9,6 +9,7 @@ on a leading batch axis.
 import logging
 import random
 import collections
+import threading
 
 import numpy as np
 import torch
@@ -100,6 +101,7 @@ class LRUDict:
     def __init__(self, N):
         self.N = N
         self.D = collections.OrderedDict()
+        self.lock = threading.RLock()
 
     def __contains__(self, x):
         return x in self.D
@@ -114,6 +116,18 @@ class LRUDict:
         self.D.move_to_end(x)
         return self.D[x]
 
+    def get_or_create(self, key, make):
+        """cache[key], made by make() under the cache's lock if absent.  Device
+        tensors made here are complete before another host thread (on another
+        stream, vel_fit._process_split) can see the entry."""
+        with self.lock:
+            if key not in self.D:
+                val = make()
+                if torch.cuda.is_available():
+                    torch.cuda.current_stream().synchronize()
+                self[key] = val
+            return self[key]
+
 
 _batch_cache = LRUDict(16)
 
@@ -125,9 +139,8 @@ def as_batch(specdata):
     if isinstance(specdata, SpecData):
         specdata = [specdata]
     key = tuple(sd.objid for sd in specdata)
-    if key not in _batch_cache:
-        _batch_cache[key] = SpecBatch.from_specdata([list(specdata)])
-    return _batch_cache[key], False
+    return _batch_cache.get_or_create(
+        key, lambda: SpecBatch.from_specdata([list(specdata)])), False
 
 
 def _params_tensor(atm_params, S, ndim, dev):
@@ -153,7 +166,7 @@ def _vsini_tensor(rot_params, S, dev):
     return v.contiguous()
 
 
-_resol_cache = None
+_resol_cache = LRUDict(16)
 
 
 def _resols(batch, resol_params):
@@ -161,9 +174,6 @@ def _resols(batch, resol_params):
     spec_fit.py:866-867, 922-923) -> per-arm device taps, or None"""
     if resol_params is None:
         return None
-    global _resol_cache
-    if _resol_cache is None:
-        _resol_cache = LRUDict(16)
     out = []
     for arm in batch.arms:
         R = resol_params[arm.name]
@@ -171,10 +181,10 @@ def _resols(batch, resol_params):
             raise ValueError('You are not allowed to set resol_param together '
                              'with the resolution of each SpecData')
         key = (hash(R), arm.S, str(batch.device))
-        if key not in _resol_cache:
+        def make(R=R, arm=arm):
             taps, nd = engine.resol_taps([R.mat], arm.npix)
-            _resol_cache[key] = engine.make_resol(taps, nd, arm.S, batch.device)
-        out.append(_resol_cache[key])
+            return engine.make_resol(taps, nd, arm.S, batch.device)
+        out.append(_resol_cache.get_or_create(key, make))
     return out
 
 

@@ -478,6 +478,8 @@ def _process_split(batch, paramDict0, kwargs):
     idxs = [torch.arange(k, S, 2, device=dev) for k in range(2)]
     pd = _as_param_tensors(paramDict0, S, dev)
     pri = kwargs.get('priors')
+    # template libraries are loaded (uploaded) here, before either thread
+    spec_inter.get_libs(batch.names, kwargs['config'])
     torch.cuda.current_stream().synchronize()
     parts, errs = [None, None], [None, None]
 
@@ -513,6 +515,8 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
             resolParams=None, priors=None, timers=None):
     """vel_fit.process (see _process_one); a large SpecBatch is fitted as two
     concurrent halves (PROCESS_STREAMS)."""
+    if config is None:
+        raise RuntimeError('Config must be provided')
     if (PROCESS_STREAMS == 2 and isinstance(specdata, SpecBatch)
             and specdata.S >= PROCESS_SPLIT_MIN and timers is None
             and not getattr(_tls, 'single', False)):

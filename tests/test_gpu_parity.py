@@ -668,8 +668,12 @@ def test_process_two_halves_equal_one_batch(cases, pcases, config):
                vsini=rng.uniform(1, 60, S))
     pri = {'teff': (torch.as_tensor(rng.uniform(5500, 6500, S)).to('cuda'), 300.)}
     names = ('teff', 'logg', 'feh', 'alpha')
+    from rvspecfit_amd import spec_fit
+    rp = {a.name: spec_fit.construct_resol_mat(a.lam_host, 2500.)
+          for a in batch.arms}
     for cfg, kw in ((dict(config), {}), (dict(config, second_minimizer=True), {}),
-                    (dict(config), dict(priors=pri))):
+                    (dict(config), dict(priors=pri)),
+                    (dict(config), dict(resolParams=rp))):
         out = []
         for ns in (1, 2):
             vel_fit.PROCESS_STREAMS = ns

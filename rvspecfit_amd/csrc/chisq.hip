@@ -1188,17 +1188,22 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
 // ---------------------------------------------------------------------------
 // A13: get_chisq_continuum for a whole batch (spec_fit.py:739-783): template == 1.
 // One LANE per spectrum (the basis row is wave-uniform -> scalar cache, exactly
-// as in chisq_grid_kernel) and one WAVE per (64 spectra, pixel slice): pass 1
-// writes per-slice normal-equation partials, pass 2 sums them in slice order
-// (deterministic), factors in-lane and accumulates the model residuals of its
-// slice over the unmasked pixels, pass 3 folds the slices.
+// as in chisq_grid_kernel) and one WAVE per (64 spectra, run of pixel slices):
+// pass 1 writes per-slice normal-equation partials, continuum_sum_kernel folds
+// them in slice order, pass 2 factors in-lane and accumulates the model residuals
+// of its slices over the unmasked pixels, pass 3 folds those.
 // work layout: part[slice][value][S] doubles, value < NV = P(P+1)/2 + P + 2,
-// then res[slice][2][S] (true chi^2 partial, good-pixel count).
+// then res[slice][2][S] (true chi^2 partial, good-pixel count), then tot[NV][S].
 // ---------------------------------------------------------------------------
+// The SUMS are sliced canonically: CONT_NC pixel slices whatever the batch, each
+// accumulated from zero and folded in slice order, so a spectrum's result is the
+// same bit for bit alone or among 10 000 others (tests/test_full_size.py).  Only
+// the number of waves sharing the slices of a 64-spectrum group depends on S.
+#define CONT_NC 32
 __host__ __device__ static inline int cont_nslice(int S) {
   int groups = (S + 63) / 64;
   int n = 2048 / groups;
-  return n < 1 ? 1 : (n > 32 ? 32 : n);
+  return n < 1 ? 1 : (n > CONT_NC ? CONT_NC : n);
 }
 
 template <int P>
@@ -1213,12 +1218,13 @@ __global__ void __launch_bounds__(64)
   const bool active = s0 < S;
   const int s = active ? s0 : S - 1;
   const int sl = blockIdx.y;
-  const int k0 = (int)((int64_t)npix * sl / nsl);
-  const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
   const double *sp = spec + (int64_t)s * npix;
   const double *es = espec + (int64_t)s * npix;
   // A9: templ = R @ 1 (spec_fit.py:765-767) instead of 1
   const double *ut = unit_templ ? unit_templ + (int64_t)s * npix : nullptr;
+  for (int c = CONT_NC * sl / nsl; c < CONT_NC * (sl + 1) / nsl; c++) {
+  const int k0 = (int)((int64_t)npix * c / CONT_NC);
+  const int k1 = (int)((int64_t)npix * (c + 1) / CONT_NC);
   double acc[NT];
   double av[P];
 #pragma unroll
@@ -1245,14 +1251,28 @@ __global__ void __launch_bounds__(64)
         acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
     }
   }
-  if (!active) return;
-  double *o = part + (int64_t)sl * (NT + P + 2) * S + s;
+  if (active) {
+    double *o = part + (int64_t)c * (NT + P + 2) * S + s;
 #pragma unroll
-  for (int i = 0; i < NT; i++) o[(int64_t)i * S] = acc[i];
+    for (int i = 0; i < NT; i++) o[(int64_t)i * S] = acc[i];
 #pragma unroll
-  for (int i = 0; i < P; i++) o[(int64_t)(NT + i) * S] = av[i];
-  o[(int64_t)(NT + P) * S] = lz;
-  o[(int64_t)(NT + P + 1) * S] = dd;
+    for (int i = 0; i < P; i++) o[(int64_t)(NT + i) * S] = av[i];
+    o[(int64_t)(NT + P) * S] = lz;
+    o[(int64_t)(NT + P + 1) * S] = dd;
+  }
+  }
+}
+
+// folds the CONT_NC slice partials of every (value, spectrum) in slice order
+__global__ void __launch_bounds__(256)
+    continuum_sum_kernel(const double *__restrict__ part, int64_t n,
+                         double *__restrict__ tot) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double a = 0;
+#pragma unroll 8
+  for (int q = 0; q < CONT_NC; q++) a += part[(int64_t)q * n + i];
+  tot[i] = a;
 }
 
 template <int P>
@@ -1262,31 +1282,23 @@ __global__ void __launch_bounds__(64)
                            const double *__restrict__ espec,
                            const double *__restrict__ unit_templ,
                            const uint8_t *__restrict__ badmask, int npix, int S,
-                           int nsl, const double *__restrict__ part,
+                           int nsl, const double *__restrict__ tot,
                            double *__restrict__ res, double *__restrict__ chisq,
                            int32_t *__restrict__ status) {
   constexpr int NT = P * (P + 1) / 2;
-  constexpr int NV = NT + P + 2;
   const int s0 = blockIdx.x * 64 + threadIdx.x;
   const bool active = s0 < S;
   const int s = active ? s0 : S - 1;
   const int sl = blockIdx.y;
   double acc[NT];
   double av[P];
+  const double *o = tot + s;   // continuum_sum_kernel's [NV][S]
 #pragma unroll
-  for (int i = 0; i < NT; i++) acc[i] = 0;
+  for (int i = 0; i < NT; i++) acc[i] = o[(int64_t)i * S];
 #pragma unroll
-  for (int i = 0; i < P; i++) av[i] = 0;
-  double lz = 0, dd = 0;
-  for (int q = 0; q < nsl; q++) {
-    const double *o = part + (int64_t)q * NV * S + s;
-#pragma unroll
-    for (int i = 0; i < NT; i++) acc[i] += o[(int64_t)i * S];
-#pragma unroll
-    for (int i = 0; i < P; i++) av[i] += o[(int64_t)(NT + i) * S];
-    lz += o[(int64_t)(NT + P) * S];
-    dd += o[(int64_t)(NT + P + 1) * S];
-  }
+  for (int i = 0; i < P; i++) av[i] = o[(int64_t)(NT + i) * S];
+  const double lz = o[(int64_t)(NT + P) * S];
+  const double dd = o[(int64_t)(NT + P + 1) * S];
   bool ok = true;
   double ldet = 0;
 #pragma unroll
@@ -1324,30 +1336,34 @@ __global__ void __launch_bounds__(64)
     for (int q = i + 1; q < P; q++) sum -= acc[TRI(q, i)] * av[q];
     av[i] = sum / acc[TRI(i, i)];
   }
-  const int k0 = (int)((int64_t)npix * sl / nsl);
-  const int k1 = (int)((int64_t)npix * (sl + 1) / nsl);
   const double *sp = spec + (int64_t)s * npix;
   const double *es = espec + (int64_t)s * npix;
   const uint8_t *bm = badmask ? badmask + (int64_t)s * npix : nullptr;
   const double *ut = unit_templ ? unit_templ + (int64_t)s * npix : nullptr;
-  double tc = 0;
-  int ng = 0;
-  for (int k = k0; k < k1; k++) {
-    const double *pr = polysT + (int64_t)k * P;
-    double m = 0;
+  for (int c = CONT_NC * sl / nsl; c < CONT_NC * (sl + 1) / nsl; c++) {
+    const int k0 = (int)((int64_t)npix * c / CONT_NC);
+    const int k1 = (int)((int64_t)npix * (c + 1) / CONT_NC);
+    double tc = 0;
+    int ng = 0;
+    for (int k = k0; k < k1; k++) {
+      const double *pr = polysT + (int64_t)k * P;
+      double m = 0;
 #pragma unroll
-    for (int i = 0; i < P; i++) m = fma(av[i], pr[i], m);
-    if (ut) m *= ut[k];
-    const double dev = (m - sp[k]) / es[k];
-    const bool good = bm ? (bm[k] == 0) : true;
-    if (good) {
-      tc = fma(dev, dev, tc);
-      ng++;
+      for (int i = 0; i < P; i++) m = fma(av[i], pr[i], m);
+      if (ut) m *= ut[k];
+      const double dev = (m - sp[k]) / es[k];
+      const bool good = bm ? (bm[k] == 0) : true;
+      if (good) {
+        tc = fma(dev, dev, tc);
+        ng++;
+      }
+    }
+    if (active) {
+      res[((int64_t)c * 2 + 0) * S + s] = ok ? tc : __builtin_nan("");
+      res[((int64_t)c * 2 + 1) * S + s] = (double)ng;
     }
   }
   if (!active) return;
-  res[((int64_t)sl * 2 + 0) * S + s] = ok ? tc : __builtin_nan("");
-  res[((int64_t)sl * 2 + 1) * S + s] = (double)ng;
   if (sl == 0) {
     int st = 0;
     const double chi = 2.0 * ldet + 2.0 * lz + (dd - yy);
@@ -1375,7 +1391,7 @@ __global__ void continuum_fold_kernel(const double *__restrict__ res, int S,
 extern "C" int64_t rvs_chisq_continuum_work_size(int npoly, int S) {
   if (npoly < 1 || S < 1) return 0;
   const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly + 2;
-  return (int64_t)cont_nslice(S) * (nv + 2) * S * (int64_t)sizeof(double);
+  return ((int64_t)CONT_NC * (nv + 2) + nv) * S * (int64_t)sizeof(double);
 }
 
 extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
@@ -1390,15 +1406,19 @@ extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
   const int nsl = cont_nslice(S);
   const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly + 2;
   double *part = (double *)work;
-  double *res = part + (int64_t)nsl * nv * S;
+  double *res = part + (int64_t)CONT_NC * nv * S;
+  double *tot = res + (int64_t)CONT_NC * 2 * S;
   dim3 grid((S + 63) / 64, nsl);
+  const int64_t ntot = nv * S;
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \
     hipLaunchKernelGGL(continuum_normal_kernel<PP>, grid, dim3(64), 0, st,     \
                        polysT, spec, espec, unit_templ, npix, S, nsl, part);   \
+    hipLaunchKernelGGL(continuum_sum_kernel, dim3((ntot + 255) / 256),         \
+                       dim3(256), 0, st, part, ntot, tot);                     \
     hipLaunchKernelGGL(continuum_resid_kernel<PP>, grid, dim3(64), 0, st,      \
                        polysT, spec, espec, unit_templ, badmask, npix, S, nsl, \
-                       part, res, chisq, status);                              \
+                       tot, res, chisq, status);                               \
     break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
@@ -1409,7 +1429,7 @@ extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
   }
 #undef RVS_CASE
   hipLaunchKernelGGL(continuum_fold_kernel, dim3((S + 255) / 256), dim3(256), 0,
-                     st, res, S, nsl, true_chisq, ngood);
+                     st, res, S, CONT_NC, true_chisq, ngood);
   RVS_LAUNCH_CHECK();
   return 0;
 }

@@ -126,3 +126,91 @@ def test_sample_against_oracle(full):
     rel = np.abs(g[:, F.index('best_chi')] - o[:, 4]) / \
         np.maximum(np.abs(o[:, 4]), npix_tot)
     assert rel.max() < 1e-6
+
+
+def _check_invariance(fit, batch, S, dev):
+    """records of a permuted batch and of two subsets == rows of the full run"""
+    rec = fit(batch)
+    g = torch.Generator(device='cpu')
+    g.manual_seed(2)
+    perm = torch.randperm(S, generator=g).to(dev)
+    assert np.array_equal(fit(batch.subset(perm)).cpu().numpy(),
+                          rec[perm].cpu().numpy(), equal_nan=True)
+    for ix in (torch.arange(0, 65, device=dev),
+               torch.arange(S // 2 - 150, S // 2 + 151, device=dev)):
+        r = fit(batch.subset(ix))
+        want = rec[ix]
+        bad = [(k, int((r[:, c] != want[:, c]).sum()))
+               for c, k in enumerate(_fields())
+               if not np.array_equal(r[:, c].cpu().numpy(),
+                                     want[:, c].cpu().numpy(), equal_nan=True)]
+        assert not bad, bad
+    return rec
+
+
+def _fields():
+    from rvspecfit_amd import pipeline
+    return pipeline.RECORD_FIELDS
+
+
+def test_invariance_with_refinement(full):
+    """the _minimum_sampler refinement (SURVEY A12 iterate) on 2000 spectra"""
+    from rvspecfit_amd import pipeline
+    b = full['bench']
+    S = 2000
+    batch = full['batch'].subset(torch.arange(S, device=full['dev']))
+    _check_invariance(lambda x: pipeline.fit_batch(
+        x, b.CONFIG, options=b.OPTIONS, refine=True), batch, S, full['dev'])
+
+
+def test_invariance_with_resolution_matrix(full):
+    """per-spectrum 11-diagonal resolution matrices (A9) on 2000 spectra"""
+    b, dev = full['bench'], full['dev']
+    S = 2000
+    batch = full['batch'].subset(torch.arange(S, device=dev))
+    g = torch.Generator(device=dev)
+    g.manual_seed(991)
+    for a in batch.arms:
+        sig = 0.45 + 0.2 * torch.rand((S, 1, 1), device=dev, generator=g,
+                                      dtype=torch.float64)
+        d = torch.arange(-5, 6, device=dev, dtype=torch.float64)[None, None]
+        k = torch.arange(a.npix, device=dev)[None, :, None]
+        t = torch.exp(-0.5 * (d / (sig / 0.8))**2).expand(S, a.npix, 11).clone()
+        q = k + d.long()
+        t = torch.where((q >= 0) & (q < a.npix), t, torch.zeros_like(t))
+        t = t / t.sum(dim=2, keepdim=True)
+        a.resol = dict(taps=t.contiguous(), nd=11, stride=a.npix * 11,
+                       unit=t.sum(dim=2).contiguous())
+    _check_invariance(full['fit'], batch, S, dev)
+
+
+def test_invariance_with_nn_evaluator(full):
+    """BASELINE configs[3]: the MLP template evaluator (MFMA kernel) in the
+    template stage, 3000 spectra"""
+    from rvspecfit_amd import engine, pipeline, spec_inter
+    from rvspecfit_amd.library import TemplateLibrary
+    b, dev = full['bench'], full['dev']
+
+    def gpu_convolve(lam, templ, vsini):
+        t = torch.as_tensor(np.ascontiguousarray(templ)).to(dev)
+        v = torch.as_tensor(np.ascontiguousarray(vsini)).to(dev)
+        return engine.convolve_vsini(lam, t, v).cpu().numpy()
+    old = b.EVALUATOR
+    b.EVALUATOR = 'nn'
+    try:
+        dicts = b.build_library_dicts(64, gpu_convolve)
+    finally:
+        b.EVALUATOR = old
+    cfg = dict(b.CONFIG, template_lib='synthetic://desi_nn')
+    for name, d in dicts.items():
+        spec_inter.register_library(TemplateLibrary(name, d, device=dev),
+                                    cfg['template_lib'])
+    S = 3000
+    batch = full['batch'].subset(torch.arange(S, device=dev))
+    try:
+        rec = _check_invariance(lambda x: pipeline.fit_batch(
+            x, cfg, options=b.OPTIONS), batch, S, dev)
+    finally:
+        # the process-wide interpolator cache goes back to the polylinear set
+        spec_inter.get_libs(batch.names, b.CONFIG)
+    assert torch.isfinite(rec[:, _fields().index('best_chi')]).all()

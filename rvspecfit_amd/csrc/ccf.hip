@@ -603,6 +603,23 @@ __global__ void __launch_bounds__(PP_NT)
     for (int it = 0; it < RVS_LM_MAXIT; it++) {
       lm_normal(S, Eb, istart, m, gw, hw);
       PP_T(8);  // (debug) normal equations
+      if (it == 0) {
+        // least_squares' gtol exit at the starting point (make_ccf.py:146-150,
+        // gtol = 1e-8 absolute): with |J^T rho' f|_inf below it TRF returns p0
+        // untouched -- what happens when the errors dwarf the flux.  The
+        // gradient with respect to the node values p is C^-T (E^T gw).
+        if (tid < 64) {
+          double g = 0;
+          if (tid < m)
+            for (int i = 0; i < m; i++) g = fma(Cinv[i * m + tid], S.bvec[i], g);
+          g = fabs(g);
+          if (!(g == g)) g = 1.0;  // NaN gradient: not an exit
+          for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o));
+          if (tid == 0 && g < 1e-8) S.stop = 1;
+        }
+        __syncthreads();
+        if (S.stop) break;
+      }
       // damped step; retry with larger damping until the cost does not grow
       for (int tries = 0; tries < 40; tries++) {
         if (tid < 64) lm_band_solve(S, m);

@@ -1,0 +1,119 @@
+"""Pathological spectra inside an ordinary batch (DESI shape): every pixel masked
+(one arm / all arms), errors of 1e30, zero / constant / negated flux, every second
+pixel masked.  The HIP path must give what the oracle gives for each of them --
+including the oracle's failure values (CCF at the edge of the velocity range,
+template 0) -- and must leave the ordinary spectra of the same batch untouched."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MODS = dict(
+    clean=lambda a, sp, es, bad: (sp, es, bad),
+    badarm=lambda a, sp, es, bad: (sp, es, np.ones_like(bad) if a == 'r' else bad),
+    allbad=lambda a, sp, es, bad: (sp, es, np.ones_like(bad)),
+    hugeerr=lambda a, sp, es, bad: (sp, np.full_like(es, 1e30), bad),
+    zeroflux=lambda a, sp, es, bad: (np.zeros_like(sp), es, bad),
+    negflux=lambda a, sp, es, bad: (-sp, es, bad),
+    halfbad=lambda a, sp, es, bad: (sp, es, bad | (np.arange(len(sp)) % 2 == 0)),
+    constflux=lambda a, sp, es, bad: (np.full_like(sp, 3.0), es, bad),
+)
+BASE = (1, 5)      # spectra of the generator the modifications are applied to
+NCLEAN = 40        # ordinary spectra in the same batch
+
+
+@pytest.fixture(scope='module')
+def setup():
+    import bench
+    from oracle import rvs_oracle as orc
+    from rvspecfit_amd import _lib, engine, pipeline, spec_inter
+    from rvspecfit_amd.library import TemplateLibrary
+    _lib.require_gpu()
+    dev = torch.device('cuda', 0)
+
+    def gpu_convolve(lam, templ, vsini):
+        t = torch.as_tensor(np.ascontiguousarray(templ)).to(dev)
+        v = torch.as_tensor(np.ascontiguousarray(vsini)).to(dev)
+        return engine.convolve_vsini(lam, t, v).cpu().numpy()
+    dicts = bench.build_library_dicts(64, gpu_convolve)
+    for name, d in dicts.items():
+        spec_inter.register_library(TemplateLibrary(name, d, device=dev),
+                                    bench.CONFIG['template_lib'])
+    olibs = {k: orc.Library(v) for k, v in dicts.items()}
+    arms = bench.make_spectra_device(bench.truth_params(NCLEAN, seed=5), dev)
+    host = {a: [x.cpu().numpy() for x in arm[2:]]
+            for a, arm in zip(bench.ARMS, arms)}
+    cases = []     # (name, base, {arm: (spec, espec, bad)})
+    for i in BASE:
+        for name, mod in MODS.items():
+            cases.append((name, i, {
+                a: mod(a, host[a][0][i].copy(), host[a][1][i].copy(),
+                       host[a][2][i] != 0) for a in bench.ARMS}))
+    # the batch: the ordinary spectra, then the cases
+    built = []
+    for a in bench.ARMS:
+        sp = np.concatenate([host[a][0]] + [c[2][a][0][None] for c in cases])
+        es = np.concatenate([host[a][1]] + [c[2][a][1][None] for c in cases])
+        bad = np.concatenate([host[a][2] != 0] +
+                             [c[2][a][2][None] for c in cases])
+        built.append(engine.ArmData(bench.arm_name(a), bench.obs_lam(a), sp, es,
+                                    bad, device=dev))
+    batch = engine.SpecBatch(built)
+    fit = lambda b: pipeline.fit_batch(b, bench.CONFIG, options=bench.OPTIONS)
+    return dict(bench=bench, orc=orc, olibs=olibs, cases=cases, batch=batch,
+                fit=fit, dev=dev, rec=fit(batch), F=pipeline.RECORD_FIELDS)
+
+
+def _oracle(su, arrs):
+    b, orc = su['bench'], su['orc']
+    sds = [orc.SpecData(b.arm_name(a), b.obs_lam(a), *arrs[a][:2],
+                        badmask=arrs[a][2]) for a in b.ARMS]
+    with np.errstate(all='ignore'):
+        o = orc.ccf_fit(sds, b.CONFIG, su['olibs'])
+        vg = np.arange(b.CONFIG['min_vel'], b.CONFIG['max_vel'],
+                       b.CONFIG['vel_step0']).astype(float)
+        vs = o['best_vsini']
+        grid = orc.chisq_grid_fast(sds, vg, o['best_par'],
+                                   None if np.isnan(vs) else (vs, ), b.OPTIONS,
+                                   b.CONFIG, su['olibs'])
+        s = orc.grid_summary(vg, grid[:, None])
+        c = orc.get_chisq_continuum(sds, options=b.OPTIONS)
+    return o, s, c
+
+
+def test_ordinary_spectra_untouched(setup):
+    ix = torch.arange(NCLEAN, device=setup['dev'])
+    alone = setup['fit'](setup['batch'].subset(ix))
+    assert np.array_equal(alone.cpu().numpy(),
+                          setup['rec'][:NCLEAN].cpu().numpy(), equal_nan=True)
+
+
+@pytest.mark.parametrize('k', range(len(BASE) * len(MODS)))
+def test_case_vs_oracle(setup, k):
+    F = setup['F']
+    name, base, arrs = setup['cases'][k]
+    g = setup['rec'][NCLEAN + k].cpu().numpy()
+    o, s, c = _oracle(setup, arrs)
+    tag = '%s/%d' % (name, base)
+    assert int(g[F.index('best_id')]) == int(o['best_id']), tag
+    assert abs(g[F.index('vrad_ccf')] - o['best_vel']) < 1e-2, tag
+    npix_tot = sum(len(arrs[a][0]) for a in arrs)
+    for key, ref, tol in (('best_vel', s['best_vel'], 1e-2),
+                          ('vel_err', s['vel_err'], None),
+                          ('best_chi', s['best_chi'], None)):
+        got = g[F.index(key)]
+        if not np.isfinite(ref):
+            assert not np.isfinite(got) or got == ref, (tag, key, got, ref)
+        elif key == 'best_vel':
+            assert abs(got - ref) < tol, (tag, key, got, ref)
+        elif key == 'vel_err':
+            assert abs(got / ref - 1) < 1e-4, (tag, key, got, ref)
+        else:   # -2 log L passes through zero: relative to the pixel count
+            assert abs(got - ref) / max(abs(ref), npix_tot) < 1e-6, \
+                (tag, key, got, ref)
+    for ia, ref in enumerate(c['chisq_array']):
+        got = g[F.index('chisq_c%d' % ia)]
+        # (a spectrum the basis fits exactly leaves rounding noise, not a chi^2)
+        assert abs(got - ref) <= 1e-6 * abs(ref) + 1e-12, \
+            (tag, 'chisq_c%d' % ia, got, ref)

@@ -117,3 +117,82 @@ def test_case_vs_oracle(setup, k):
         # (a spectrum the basis fits exactly leaves rounding noise, not a chi^2)
         assert abs(got - ref) <= 1e-6 * abs(ref) + 1e-12, \
             (tag, 'chisq_c%d' % ia, got, ref)
+
+
+# ---------------------------------------------------------------------------
+# the optimiser stage (vel_fit.process) on the same kind of input
+# ---------------------------------------------------------------------------
+PCASES = {
+    # name: (modification, start point)
+    'clean': ('clean', dict(teff=6000., logg=3., feh=-1., alpha=0.3, vsini=10.)),
+    'negflux': ('negflux', dict(teff=6000., logg=3., feh=-1., alpha=0.3,
+                                vsini=10.)),
+    'halfbad': ('halfbad', dict(teff=6000., logg=3., feh=-1., alpha=0.3,
+                                vsini=10.)),
+    # start on the edge of the template grid / beyond max_vsini
+    'edge': ('clean', dict(teff=11500., logg=4.7, feh=-0.1, alpha=0.95,
+                           vsini=600.)),
+    'cool': ('clean', dict(teff=3500., logg=0.3, feh=-1.9, alpha=0.05,
+                           vsini=0.)),
+}
+
+
+@pytest.fixture(scope='module')
+def presults(setup):
+    """all process cases in ONE device batch"""
+    from rvspecfit_amd import engine, vel_fit
+    b, dev = setup['bench'], setup['dev']
+    byname = {(n, i): arrs for n, i, arrs in setup['cases']}
+    keys = list(PCASES)
+    sel = [byname[(PCASES[k][0], BASE[0])] for k in keys]
+    built = []
+    for a in b.ARMS:
+        built.append(engine.ArmData(
+            b.arm_name(a), b.obs_lam(a), np.stack([x[a][0] for x in sel]),
+            np.stack([x[a][1] for x in sel]), np.stack([x[a][2] for x in sel]),
+            device=dev))
+    batch = engine.SpecBatch(built)
+    pd0 = {p: np.array([PCASES[k][1][p] for k in keys])
+           for p in ('teff', 'logg', 'feh', 'alpha', 'vsini')}
+    cfg = dict(b.CONFIG, second_minimizer=False)
+    r = vel_fit.process(batch, pd0, options=b.OPTIONS, config=cfg)
+    return keys, sel, r, cfg
+
+
+@pytest.mark.parametrize('name', list(PCASES))
+def test_process_case_vs_oracle(setup, presults, name):
+    b, orc = setup['bench'], setup['orc']
+    keys, sel, r, cfg = presults
+    k = keys.index(name)
+    arrs = sel[k]
+    sds = [orc.SpecData(b.arm_name(a), b.obs_lam(a), *arrs[a][:2],
+                        badmask=arrs[a][2]) for a in b.ARMS]
+    with np.errstate(all='ignore'):
+        o = orc.process(sds, dict(PCASES[name][1]), None, b.OPTIONS, cfg,
+                        setup['olibs'])
+    names = ('teff', 'logg', 'feh', 'alpha')
+    # (1) the reported optimum is a value of the reference's objective: the
+    #     oracle's get_chisq at the point the device optimiser ended in
+    gv, gvs = float(r['vel'][k]), float(r['vsini'][k])
+    gp = [float(r['param'][p][k]) for p in names]
+    with np.errstate(all='ignore'):
+        at = orc.get_chisq(sds, gv, gp, (gvs, ), b.OPTIONS, cfg, setup['olibs'])
+    assert abs(float(r['chisq'][k]) / at - 1) < 1e-6, (name, 'objective')
+    # (2) and it is the oracle's optimum: Nelder-Mead stops when the simplex
+    #     spans fatol = 1e-3 in chi^2; rounding lets the two simplex paths part
+    #     after ~1000 iterations (nit within 2 %), so the end points agree to
+    #     the optimiser's own resolution -- 0.1 in chi^2 where the optimum sits
+    #     on the edge of the template grid ('cool'), far below one sigma in
+    #     every parameter
+    assert abs(gv - o['vel']) < 1e-2, (name, 'vel')
+    assert abs(float(r['chisq'][k]) - o['chisq']) < \
+        1e-6 * abs(o['chisq']) + 0.1, (name, 'chisq')
+    assert abs(gvs - o['vsini']) < 1e-3 * max(1.0, abs(o['vsini'])), \
+        (name, 'vsini')
+    for p, g in zip(names, gp):
+        sg = o['param_err'][p]
+        tol = 5e-3 * sg if np.isfinite(sg) and sg > 0 else 1e-6 * max(
+            1.0, abs(o['param'][p]))
+        assert abs(g - o['param'][p]) < max(tol, 1e-9), (name, p)
+    nit = int(np.sum(o['nm_nit']))
+    assert abs(int(r['nm_nit'][k]) - nit) <= 0.02 * nit, (name, 'nit')

@@ -214,3 +214,21 @@ def test_invariance_with_nn_evaluator(full):
         # the process-wide interpolator cache goes back to the polylinear set
         spec_inter.get_libs(batch.names, b.CONFIG)
     assert torch.isfinite(rec[:, _fields().index('best_chi')]).all()
+
+
+def test_ccf_chunking_does_not_matter(full):
+    """the CCF accumulator is filled in chunks of spectra sized from the memory
+    it needs; the chunk size must not show in any result"""
+    from rvspecfit_amd import engine, spec_inter
+    b = full['bench']
+    libs = spec_inter.get_libs(full['batch'].names, b.CONFIG)
+    S = 3000
+    batch = full['batch'].subset(torch.arange(S, device=full['dev']))
+    ref = engine.ccf_fit(batch, libs, b.CONFIG)
+    for mc in (1, 777, 2999):
+        r = engine.ccf_fit(batch, libs, b.CONFIG, max_chunk=mc) if mc > 1 else \
+            engine.ccf_fit(batch.subset(torch.arange(3, device=full['dev'])),
+                           libs, b.CONFIG, max_chunk=1)
+        n = S if mc > 1 else 3
+        for k in ('best_id', 'best_vel', 'best_ccf', 'status'):
+            assert torch.equal(r[k], ref[k][:n]), (mc, k)

@@ -137,16 +137,68 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   for (int i = 0; i < P; i++) av[i] = 0;
 
   // The per-lane gather of the spline record and knot of a pixel is waited for
-  // in the same iteration; its latency is covered by the other two waves of the
-  // SIMD (3 waves x ~95 issue slots).  Requesting pixel k+1's record before the
-  // arithmetic of pixel k (a one-deep software pipeline, same 166 VGPRs) was
-  // measured: 132.8 instead of 125.0 ms per step.
+  // in the trip that requests it; the other two waves of the SIMD cover most of
+  // its latency (3 waves x ~95 issue slots per pixel), two pixels per trip (below)
+  // halve the number of exposed round trips.  Requesting pixel k+1's record
+  // before the arithmetic of pixel k (a one-deep software pipeline, same 166
+  // VGPRs) was measured: 132.8 instead of 125.0 ms per step.
   // pos = (int)((log x - log x0)/step) evaluated as pixel coordinate + velocity
   // shift; it can differ from the reference's value only when x is within
   // rounding (~1e-11 knot spacings) of a knot, where the two adjacent cubics agree
   // to O(dx^3) ~ 1e-33 -- exactly the ambiguity the reference's own libm log
   // has (rvs_spline_eval keeps the reference formula verbatim).  The cubic is
   // evaluated in powers of dl = x - x_i (records built with form 1): 3 fma.
+#ifndef RVS_CG_PLAIN  // -DRVS_CG_PLAIN: one pixel per trip (the loop below)
+  auto knot_of = [&](int k, double &x) {
+    x = lam[k] * f;
+    int pos;
+    if (log_step)
+      pos = (int)(pixa[k] + shift);
+    else
+      pos = (int)((x - x0) * lin_inv_step);
+    return min(max(pos, 0), ntp - 2);
+  };
+  auto accumulate = [&](int k, double tv) {
+    const double2 wk = W[k];
+    const double w = tv * tv * wk.x;   // (t/e)^2
+    const double u = tv * wk.y;        // t s / e^2
+    const double *pr = polysT + (int64_t)k * P;
+#pragma unroll
+    for (int jj = 0; jj < P; jj++) {
+      const double pwj = pr[jj] * w;
+      av[jj] = fma(pr[jj], u, av[jj]);
+#pragma unroll
+      for (int i = jj; i < P; i++)
+        acc[TRI(i, jj)] = fma(pr[i], pwj, acc[TRI(i, jj)]);
+    }
+  };
+  // Two pixels per trip: both pixels' knot and record gathers are requested
+  // before either is used, both template values are formed before the first
+  // 75-FMA block (the records are dead by then: same 166 VGPRs, 3 waves/SIMD).
+  // 125.8 -> 117.0 ms per step.  The shape matters more than the idea: the same
+  // trip written with arrays and loops over q (identical loads and arithmetic)
+  // gave 121-122 ms, three pixels per trip 123-127 ms (either
+  // way of writing it), four need 186 VGPRs.
+  int k = 0;
+  for (; k + 1 < npix; k += 2) {
+    double xa, xb;
+    const int pa = knot_of(k, xa), pb = knot_of(k + 1, xb);
+    const double ka = knots[pa], kb = knots[pb];
+    const double4 ca = cf[pa], cb = cf[pb];
+    const double da = xa - ka, db = xb - kb;
+    const double ta = fma(fma(fma(ca.w, da, ca.z), da, ca.y), da, ca.x);
+    const double tb = fma(fma(fma(cb.w, db, cb.z), db, cb.y), db, cb.x);
+    accumulate(k, ta);
+    accumulate(k + 1, tb);
+  }
+  if (k < npix) {
+    double xa;
+    const int pa = knot_of(k, xa);
+    const double da = xa - knots[pa];
+    const double4 ca = cf[pa];
+    accumulate(k, fma(fma(fma(ca.w, da, ca.z), da, ca.y), da, ca.x));
+  }
+#else
   for (int k = 0; k < npix; k++) {
     const double x = lam[k] * f;
     int pos;
@@ -173,6 +225,7 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
         acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
     }
   }
+#endif
 
   // in-lane Cholesky of the packed normal matrix (spec_fit.py:230-247)
   bool ok = true;
@@ -218,7 +271,7 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
 }
 
 // ---------------------------------------------------------------------------
-// LDS-DMA variant (the default): the four waves of a block fit 256 velocities
+// LDS-DMA variant (RVS_CHISQ_VARIANT=lds; measured slower): the four waves of a block fit 256 velocities
 // of ONE job, so they share the template.  The observed pixels are walked in
 // chunks of `chunk` pixels; for every chunk the window of spline records
 // [p_lo, p_lo + WMAX) that ANY of the block's velocities can touch is copied

@@ -13,11 +13,17 @@ run --refine --steps 2 --warmup 1 --no-cpu-baseline
 run --resolution-matrix --steps 2 --warmup 1 --no-cpu-baseline
 run --spectra 2000 --steps 1 --warmup 1 --cpu-sample 8 --process 2000 --process-cpu-sample 8
 run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000 --process-bfgs
+run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500
+run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --process-bfgs
+run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --desi-nfiles 16
+run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --desi-nfiles 16 --process-bfgs
+run --spectra 62500 --steps 2 --warmup 1 --no-cpu-baseline
 python - <<PY
 import json
 for l in open("$out"):
     d = json.loads(l)
     c = d["config"]
     print(round(d["value"]), d["ms_per_step"], c["spectra_per_gpu"], c["ccf_templates"], c.get("refine"), c.get("resolution_matrix"),
-          d["roofline"]["frac"], d["kernels"].get("template_nn"), (d.get("process") or {}).get("spectra_per_s"))
+          d["roofline"]["frac"], d["kernels"].get("template_nn"), (d.get("process") or {}).get("spectra_per_s"),
+          (d.get("desi_file") or {}).get("fibres_per_s"))
 PY

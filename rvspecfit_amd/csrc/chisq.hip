@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   // 125.8 -> 117.0 ms per step.  The shape matters more than the idea: the same
   // trip written with arrays and loops over q (identical loads and arithmetic)
   // gave 121-122 ms, three pixels per trip 123-127 ms (either
-  // way of writing it), four need 186 VGPRs.
+  // way of writing it), four need 186 VGPRs,
+  // this loop unrolled twice 171 (2 waves/SIMD either way).
   int k = 0;
   for (; k + 1 < npix; k += 2) {
     double xa, xb;

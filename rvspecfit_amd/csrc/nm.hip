@@ -678,7 +678,9 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
       continue;
     }
     if (live == 0) break;
-    const int jb = nm_bucket(live, S);
+    // the live count only falls between two looks (finished and parked
+    // simplices leave the list), so it bounds the launches of the window
+    const int jb = getenv("RVS_NM_BUCKET") ? nm_bucket(live, S) : live;
     for (int r = 0; r < sync_every; r++) {
       rc = rvs_nm_begin(S, N, xatol, fatol, maxiter, m->sim, m->fsim, m->nit,
                         m->flags, m->list1, m->X1, m->counts, jb, st);

@@ -261,6 +261,7 @@ class DeviceNelderMead:
         from .neldermead import _order
         L = _lib.lib()
         S, N = self.S, self.N
+        sync_every = int(_os.environ.get('RVS_NM_SYNC', sync_every))
         sim = simplex.clone().to(torch.float64).contiguous()
         allidx = torch.arange(S, dtype=torch.int32, device=self.dev)
         for k in range(N + 1):

@@ -20,6 +20,7 @@
 // v_i = sum_k (P_i t/e)(s/e); -2logL = logdet + 2 sum log e + (D.D - y.y),
 // y = L^-1 v, which equals |D - a^T ST|^2 of spec_fit.py:249/298.
 #include "common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------
 // work buffer layout (doubles): [0, npix) pixel knot coordinate
@@ -149,15 +150,6 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   // has (rvs_spline_eval keeps the reference formula verbatim).  The cubic is
   // evaluated in powers of dl = x - x_i (records built with form 1): 3 fma.
 #ifndef RVS_CG_PLAIN  // -DRVS_CG_PLAIN: one pixel per trip (the loop below)
-  auto knot_of = [&](int k, double &x) {
-    x = lam[k] * f;
-    int pos;
-    if (log_step)
-      pos = (int)(pixa[k] + shift);
-    else
-      pos = (int)((x - x0) * lin_inv_step);
-    return min(max(pos, 0), ntp - 2);
-  };
   auto accumulate = [&](int k, double tv) {
     const double2 wk = W[k];
     const double w = tv * tv * wk.x;   // (t/e)^2
@@ -171,6 +163,21 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
       for (int i = jj; i < P; i++)
         acc[TRI(i, jj)] = fma(pr[i], pwj, acc[TRI(i, jj)]);
     }
+  };
+  // The loop is instantiated per knot spacing: with `log_step` tested inside it
+  // the compiler kept the test as scalar BRANCHES per pixel, each arm with its
+  // own s_load + s_waitcnt lgkmcnt(0) -- two to four serialised scalar-cache
+  // round trips at the head of every trip, before the gathers could be issued.
+  auto trips = [&](auto log_c) {
+  constexpr bool LOG = decltype(log_c)::value;
+  auto knot_of = [&](int k, double &x) {
+    x = lam[k] * f;
+    int pos;
+    if (LOG)
+      pos = (int)(pixa[k] + shift);
+    else
+      pos = (int)((x - x0) * lin_inv_step);
+    return min(max(pos, 0), ntp - 2);
   };
   // Two pixels per trip: both pixels' knot and record gathers are requested
   // before either is used, both template values are formed before the first
@@ -199,6 +206,11 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
     const double4 ca = cf[pa];
     accumulate(k, fma(fma(fma(ca.w, da, ca.z), da, ca.y), da, ca.x));
   }
+  };
+  if (log_step)
+    trips(std::true_type{});
+  else
+    trips(std::false_type{});
 #else
   for (int k = 0; k < npix; k++) {
     const double x = lam[k] * f;

@@ -710,9 +710,15 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
     if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast)
       st |= RVS_ST_SPLINE_RANGE;
   }
+  double acc[P * (P + 1) / 2];
+  double av[P];
+  // instantiated per knot spacing (see chisq_grid_kernel: a test of log_step
+  // inside the loop becomes scalar branches with serialised s_loads)
+  auto pixels = [&](auto log_c) {
+  constexpr bool LOG = decltype(log_c)::value;
   auto raw_at = [&](int p) {
     const double x = lam[p] * f;
-    int pos = log_step ? (int)(pixa[p] + shift) : (int)((x - x0) * lin_inv_step);
+    int pos = LOG ? (int)(pixa[p] + shift) : (int)((x - x0) * lin_inv_step);
     pos = min(max(pos, 0), ntp - 2);
     const double dl = x - knots[pos];
     const double4 c = cf[pos];
@@ -732,8 +738,6 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   for (int p = 0; p <= M; p++)
     if (p < npix) win[p % WIN] = raw_at(p);
 
-  double acc[P * (P + 1) / 2];
-  double av[P];
 #pragma unroll
   for (int i = 0; i < P * (P + 1) / 2; i++) acc[i] = 0;
 #pragma unroll
@@ -766,6 +770,11 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
       }
     }
   }
+  };
+  if (log_step)
+    pixels(std::true_type{});
+  else
+    pixels(std::false_type{});
   bool ok = true;
   double ldet = 0;
 #pragma unroll

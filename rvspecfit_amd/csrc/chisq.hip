@@ -171,7 +171,13 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   auto trips = [&](auto log_c) {
   constexpr bool LOG = decltype(log_c)::value;
   auto knot_of = [&](int k, double &x) {
-    x = lam[k] * f;
+    // rounded product, as numpy's lam * f in the reference: left to itself
+    // the compiler contracts x - knot into fma(lam, f, -knot) in the
+    // LOG instance (x has no other use there) and chi^2 moves by ~1e-10
+    {
+#pragma clang fp contract(off)
+      x = lam[k] * f;
+    }
     int pos;
     if (LOG)
       pos = (int)(pixa[k] + shift);
@@ -717,7 +723,11 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   auto pixels = [&](auto log_c) {
   constexpr bool LOG = decltype(log_c)::value;
   auto raw_at = [&](int p) {
-    const double x = lam[p] * f;
+    double x;
+    {  // rounded product, see chisq_grid_kernel
+#pragma clang fp contract(off)
+      x = lam[p] * f;
+    }
     int pos = LOG ? (int)(pixa[p] + shift) : (int)((x - x0) * lin_inv_step);
     pos = min(max(pos, 0), ntp - 2);
     const double dl = x - knots[pos];

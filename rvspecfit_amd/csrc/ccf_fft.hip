@@ -154,13 +154,17 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
   int rad[8];
   const int np = xc_plan(log2n, rad);
   const bool pr = prune && np >= 2 && rad[np - 1] == 8 && rad[np - 2] == 8;
-  int M = n2;
+  int lgM = log2n;
   for (int p = 0; p < np; p++) {
-    const int R = rad[p], Mp = M / R;
+    // every size is a power of two: shifts, not the ~30-instruction integer
+    // divisions a runtime divisor costs each thread in each pass
+    const int R = rad[p], lgR = (R == 8) ? 3 : (R == 4 ? 2 : 1);
+    const int lgMp = lgM - lgR, Mp = 1 << lgMp;
+    const int tws = log2n + 1 - lgM;  // twiddle stride nfft / M = 1 << tws
     __syncthreads();
-    for (int u = threadIdx.x; u < n2 / R; u += NT) {
-      const int blk = u / Mp, r = u - blk * Mp;
-      const int base = blk * M + r;
+    for (int u = threadIdx.x; u < (n2 >> lgR); u += NT) {
+      const int blk = u >> lgMp, r = u & (Mp - 1);
+      const int base = (blk << lgM) + r;
       if (pr && p == np - 2) {  // M = 64, Mp = 8: selected outputs only
         const unsigned mask = prune[blk];
         if (mask == 0) continue;
@@ -172,7 +176,7 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
         // the stored values are bit-identical to it
         double2 wp[8];
         wp[0] = make_double2(1.0, 0.0);
-        wp[1] = twid<SIGN>(tw, r * (nfft / M), nfft);
+        wp[1] = twid<SIGN>(tw, r << tws, nfft);
         wp[2] = cmul(wp[1], wp[1]);
         wp[3] = cmul(wp[2], wp[1]);
         wp[4] = cmul(wp[2], wp[2]);
@@ -206,7 +210,7 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
           // powers of w1 generated and consumed one at a time (short live
           // ranges: 3 complex instead of 7); every power is a product of at most
           // two squarings/multiplications of table values
-          const double2 w1 = twid<SIGN>(tw, r * (nfft / M), nfft);
+          const double2 w1 = twid<SIGN>(tw, r << tws, nfft);
           v[1] = cmul(v[1], w1);
           const double2 w2 = cmul(w1, w1);
           v[2] = cmul(v[2], w2);
@@ -226,7 +230,7 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
                 v2 = a[XC_PAD(base + 2 * Mp)], v3 = a[XC_PAD(base + 3 * Mp)];
         dft4<SIGN>(v0, v1, v2, v3);
         if (Mp > 1) {
-          const double2 w1 = twid<SIGN>(tw, r * (nfft / M), nfft);
+          const double2 w1 = twid<SIGN>(tw, r << tws, nfft);
           const double2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
           v1 = cmul(v1, w1);
           v2 = cmul(v2, w2);
@@ -239,12 +243,12 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
       } else {
         const double2 v0 = a[XC_PAD(base)], v1 = a[XC_PAD(base + Mp)];
         double2 d = csub(v0, v1);
-        if (Mp > 1) d = cmul(d, twid<SIGN>(tw, r * (nfft / M), nfft));
+        if (Mp > 1) d = cmul(d, twid<SIGN>(tw, r << tws, nfft));
         a[XC_PAD(base)] = cadd(v0, v1);
         a[XC_PAD(base + Mp)] = d;
       }
     }
-    M = Mp;
+    lgM = lgMp;
   }
   __syncthreads();
 }

@@ -216,6 +216,96 @@ def run_cpu_baseline(arms, n, args, start=None):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+# ------------------------------------------------------------------ launcher
+RANK_ENV = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
+            'HSA_ENABLE_IPC_MODE_LEGACY')
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start one FRESH
+    child process per rank (this very command line, with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set as torch.distributed.run would set them), relay
+    rank 0's result line and return non-zero if any rank failed.  The parent
+    imports neither torch nor the HIP library and never re-executes itself: a
+    process that has initialised the GPU must not be replaced by another.  One
+    process per GPU is the reference's own model of parallelism (one worker
+    per spectrum, desi/desi_fit.py:1215-1218, 1475-1479)."""
+    import socket
+    if 'MASTER_PORT' in os.environ:
+        port = int(os.environ['MASTER_PORT'])
+    else:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                       'HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+            stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    # rank 0's stdout is this command's stdout; the other ranks' goes to stderr
+    import threading
+
+    def relay():
+        for ln in procs[0].stdout:
+            # stdout carries the result line only (gloo prints its connection
+            # notes on stdout)
+            f = sys.stdout if ln.lstrip().startswith('{') else sys.stderr
+            f.write(ln)
+            f.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc = 0
+    deadline = time.time() + 3600
+    live = list(procs)
+    while live:
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0:
+                rc = rc or (c if c > 0 else 1)
+                # one rank down: the others would wait in a collective for ever
+                for q in live:
+                    q.terminate()
+        if time.time() > deadline:
+            for q in live:
+                q.kill()
+            return rc or 1
+        time.sleep(0.05)
+    th.join(timeout=10)
+    return rc
+
+
+def dry_launch():
+    """What a rank was started with, and the process group those variables
+    form (gloo, CPU only): the launch path without the GPU."""
+    info = {k: os.environ.get(k) for k in RANK_ENV}
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if os.environ.get('RVS_BENCH_FAIL_RANK') == os.environ.get('RANK', '0'):
+        sys.exit(3)   # (tests: a failing rank must fail the whole command)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+        got = [None] * world
+        dist.all_gather_object(got, (dist.get_rank(), os.getpid()))
+        info['n_gpus'] = dist.get_world_size()
+        info['ranks'] = [g[0] for g in got]
+        info['pids'] = [g[1] for g in got]
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        info['n_gpus'] = 1
+    if int(os.environ.get('RANK', '0')) == 0:
+        print(json.dumps(info), flush=True)
+
+
 # ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -264,6 +354,9 @@ def main():
     ap.add_argument('--evaluator', choices=['polylinear', 'nn'],
                     default='polylinear',
                     help='nn: BASELINE configs[3], MLP template evaluator on MFMA')
+    ap.add_argument('--dry-launch', action='store_true',
+                    help='with --gpus N: every rank prints the environment it '
+                         'was started with and exits (no GPU, no torch)')
     args = ap.parse_args()
     global ARMS, EVALUATOR
     if args.workload == 'cfg2':
@@ -271,6 +364,17 @@ def main():
     EVALUATOR = args.evaluator
     if args.cpu_worker:
         return cpu_worker(args)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process starts
+        # the N ranks itself and never touches the GPU
+        sys.exit(launch_ranks(args.gpus))
+    if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%s: refusing to '
+                         'report a line for a run that is not the one asked '
+                         'for\n' % (args.gpus, os.environ.get('WORLD_SIZE')))
+        sys.exit(2)
+    if args.dry_launch:
+        return dry_launch()
 
     import torch
     import torch.distributed as dist
@@ -284,8 +388,18 @@ def main():
     _lib.require_gpu()
     if os.environ.get('RVS_SHARE_GPU'):
         local = 0   # functional multi-rank run on ONE GPU (with RVS_DIST_BACKEND=gloo)
+    elif local >= torch.cuda.device_count():
+        sys.stderr.write('bench.py: rank %d has no GPU of its own (%d visible); '
+                         'set RVS_SHARE_GPU=1 RVS_DIST_BACKEND=gloo for a '
+                         'functional run on one GPU\n'
+                         % (rank, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local)
     rdist.init_from_env(backend='nccl')
+    if world > 1:
+        # what the line reports is what torch.distributed actually formed
+        world = dist.get_world_size()
+        rank = dist.get_rank()
     dev = torch.device('cuda', local)
     _lib.lib()
     S = args.spectra
@@ -453,7 +567,7 @@ def main():
                           'OMP_NUM_THREADS=1' % (cb['n'], S, cb['cores']),
                    spectra_per_s_per_core=round(cb['n'] / cb['wall'] / cb['cores'], 4),
                    one_spectrum_seconds_1core=round(cb['one_spectrum_s'], 3))
-        g = rec[:n].cpu().numpy() if world == 1 else rec[:n].cpu().numpy()
+        g = rec[:n].cpu().numpy()
         o = np.array(cb['recs'])
         same = (g[:, 0] == o[:, 0])
         parity = dict(n=n, best_id_equal=int(same.sum()),

@@ -68,3 +68,74 @@ def test_gather_records_gloo_world2(S):
     expect = (np.arange(S)[:, None] * 100 + np.arange(NREC)[None, :]).astype(float)
     for r in range(world):
         np.testing.assert_array_equal(got[r], expect)
+
+
+# ---- bench.py --gpus N: the command the driver's scaling run uses -----------
+import json
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, 'bench.py')
+
+
+def _bench(argv, **env):
+    e = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR',
+                      'MASTER_PORT')}
+    e.update(env)
+    return subprocess.run([sys.executable, BENCH] + argv, env=e, text=True,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=300)
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two fresh
+    rank processes that find each other (gloo group formed from the variables
+    the parent set) and relays exactly rank 0's line."""
+    out = _bench(['--gpus', '2', '--dry-launch'])
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['WORLD_SIZE'] == '2' and d['RANK'] == '0'
+    assert d['ranks'] == [0, 1]
+    assert d['MASTER_ADDR'] == '127.0.0.1'
+    assert len(set(d['pids'])) == 2 and os.getpid() not in d['pids']
+    assert d['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_bench_fails_when_a_rank_fails():
+    for bad in ('0', '1'):
+        out = _bench(['--gpus', '2', '--dry-launch'], RVS_BENCH_FAIL_RANK=bad)
+        assert out.returncode == 3, (bad, out.returncode, out.stderr)
+        assert not out.stdout.strip()
+
+
+def test_bench_refuses_gpus_different_from_world():
+    # under a launcher: --gpus must be the world the launcher formed
+    out = _bench(['--gpus', '2', '--dry-launch'], WORLD_SIZE='4', RANK='0')
+    assert out.returncode == 2 and 'refusing' in out.stderr
+    out = _bench(['--gpus', '1', '--dry-launch'], WORLD_SIZE='2', RANK='0')
+    assert out.returncode == 2
+    out = _bench(['--dry-launch'])
+    assert out.returncode == 0 and json.loads(out.stdout)['n_gpus'] == 1
+
+
+def test_bench_under_torch_distributed_run():
+    """the driver's N>1 command line: torch.distributed.run starts the ranks,
+    bench.py must then NOT start any of its own"""
+    e = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR',
+                      'MASTER_PORT')}
+    port = _free_port()
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', str(port), BENCH, '--gpus', '2', '--dry-launch'],
+        env=e, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+        timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    js = [json.loads(l) for l in out.stdout.splitlines()
+          if l.lstrip().startswith('{')]
+    assert len(js) == 1 and js[0]['n_gpus'] == 2 and js[0]['ranks'] == [0, 1]

@@ -40,7 +40,6 @@ extern "C" {
 #define RVS_ST_CCF_FAILED 0x20    /* non finite CCF minimum (fitter_ccf.py:234-236)                 */
 #define RVS_ST_ALLMASKED 0x40     /* every pixel masked in CCF preprocessing (make_ccf.py:311-315)  */
 #define RVS_ST_QUAD_ASSERT 0x80   /* parabola vertex outside its bracket (spec_fit.py:1014 assert)  */
-#define RVS_ST_WINDOW 0x100       /* internal: LDS spline window too small for the given chunk     */
 
 /* library version / build probe (host). */
 int rvs_abi_version(void);
@@ -162,11 +161,10 @@ int rvs_spline_eval(const double *knots, const double *coef, int ntp,
  *          spec_fit.py:895-896); a non finite penalty means "template not
  *          usable": the arm contributes 1000*badchi (spec_fit.py:888-893).
  * beta    out = beta*out + value  (0 first arm, 1 following arms)
- * chunk   > 0: LDS-DMA variant -- the block's spline window of every `chunk`
- *          observed pixels (<= 512 knots incl. the Doppler range of the
- *          block's 256 velocities; the caller sizes `chunk`, the kernel
- *          verifies and flags 0x100) is staged HBM->LDS asynchronously;
- *          0: every lane gathers its spline record through the vector L1.
+ * pack_min_jobs  the Nv % 64 left-over velocities of a job (16 of the 400-point
+ *          grid) share a wave with those of other jobs when J >= this
+ *          (0 = library default 4096, 1 = always, < 0 = never); where a
+ *          velocity is computed does not change its value.
  * out     [J, Nv];   status int32 [J] OR-ed (caller zeroes it)
  * ---------------------------------------------------------------------- */
 int64_t rvs_chisq_work_size(int npix, int S);
@@ -179,8 +177,9 @@ int rvs_chisq_grid(const double *lam, const double *polysT, const double *work,
                    const double *coef, int ntp, int Tn, int log_step,
                    const int32_t *job_spec, const int32_t *job_templ, int J,
                    const double *vels, int64_t vel_stride, int Nv,
-                   const double *penalty, double badchi, double beta, int chunk,
-                   double *out, int32_t *status, void *stream);
+                   const double *penalty, double badchi, double beta,
+                   int pack_min_jobs, double *out, int32_t *status,
+                   void *stream);
 
 /* A9  the same with a banded resolution matrix applied to the resampled
  * template before the fit: replaces convolve_resol / ResolMatrix

@@ -72,31 +72,64 @@ __global__ void __launch_bounds__(256)
 // packed lower-triangular index
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 
-template <int P>
-__global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
-    chisq_grid_kernel(const double *__restrict__ lam,
+// waves per SIMD the register budget is held to (168 / 256 VGPRs)
+#define CG_WAVES(P) ((P) <= 10 ? 3 : (P) <= 12 ? 2 : 1)
+
+// One WAVE per block.  With four waves per block the second block of a
+// 400-velocity job (64 + 64 + 16 lanes) held its CU slot as long as a full one:
+// 384, 400, 448 and 512 velocities all took the time of 512 (tools/perf/cg_bench).
+//
+// TAIL = false: the wave owns 64 consecutive velocities of ONE job; everything
+// that does not depend on the velocity (basis row, 1/e^2, s/e^2, pixel knot
+// coordinate) is wave-uniform and comes through the scalar cache.
+// TAIL = true: the Nv % 64 = r left-over velocities of 64/r DIFFERENT jobs share
+// a wave (r = 16 for the 400-point grid: four jobs per wave instead of a wave
+// with 16 live lanes per job).  Only the spectrum terms {1/e^2, s/e^2} differ
+// between the lanes of such a wave; they are fetched per lane (16 B, one
+// address per job, base in SGPRs + 32-bit lane offset) -- the basis row is
+// still wave-uniform.  A lane's arithmetic is the same sequence of operations
+// in both variants, so where a velocity is computed does not change its value.
+template <int P, bool TAIL>
+__device__ __forceinline__ void
+    chisq_grid_body(const int bx, const int by, const double *__restrict__ lam,
                       const double *__restrict__ polysT,
                       const double *__restrict__ work, int npix, int S,
                       const double *__restrict__ knots,
                       const double4 *__restrict__ coef, int ntp, int log_step,
                       const int32_t *__restrict__ job_spec,
-                      const int32_t *__restrict__ job_templ,
+                      const int32_t *__restrict__ job_templ, int J,
                       const double *__restrict__ vels, int64_t vel_stride,
-                      int Nv, const double *__restrict__ penalty, double badchi,
+                      int Nv, int iv0, int lpj,
+                      const double *__restrict__ penalty, double badchi,
                       double beta_out, double *__restrict__ out,
                       int32_t *__restrict__ status) {
-  const int j = blockIdx.y;
-  const int wave_v0 = blockIdx.x * 256 + (threadIdx.x & ~63);
-  if (wave_v0 >= Nv) return;  // whole wave idle
-  const int iv = blockIdx.x * 256 + threadIdx.x;
-  const bool active = iv < Nv;
+  // lane -> (job j, velocity index iv)
+  int j, iv;
+  bool active;
+  if (TAIL) {
+    const int jl = threadIdx.x / lpj;          // lpj lanes per job, 64/lpj jobs
+    const int jpw = 64 / lpj;
+    j = bx * jpw + jl;
+    iv = iv0 + (int)threadIdx.x - jl * lpj;
+    active = jl < jpw && j < J;
+    if (!active) {  // idle lanes shadow the wave's first lane (in-bounds loads)
+      j = bx * jpw;
+      iv = iv0;
+    }
+  } else {
+    j = by;
+    iv = bx * 64 + threadIdx.x;
+    active = iv < iv0;   // iv0 = number of velocities served by full waves
+    if (!active) iv = bx * 64;
+  }
   const int s = job_spec ? job_spec[j] : j;
   const int t = job_templ ? job_templ[j] : j;
   double *outp = out + (int64_t)j * Nv;
 
   const double pen = penalty ? penalty[j] : 0.0;
-  if (!(pen == pen) || isinf(pen)) {
-    // template unusable (non finite outside flag): spec_fit.py:888-893
+  // template unusable (non finite outside flag): spec_fit.py:888-893
+  const bool unusable = !(pen == pen) || isinf(pen);
+  if (!TAIL && unusable) {   // wave-uniform: the whole wave is done
     if (active) {
       const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
       outp[iv] = base + 1000.0 * badchi;
@@ -105,12 +138,15 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   }
 
   const double *pixa = work;
-  const double2 *W = reinterpret_cast<const double2 *>(work + npix) +
-                     (int64_t)s * npix;
+  const double2 *W0 = reinterpret_cast<const double2 *>(work + npix);
+  // TAIL: byte offset of the lane's spectrum inside the {1/e^2, s/e^2} block
+  // (the launcher checks that it fits 32 bits)
+  const uint32_t woff = TAIL ? (uint32_t)s * (uint32_t)npix * 16u : 0u;
+  const double2 *W = W0 + (TAIL ? 0 : (int64_t)s * npix);
   const double *scal = work + npix + 2ll * S * npix + 2 * s;
   const double4 *cf = coef + (int64_t)t * ntp;
 
-  const double vel = vels[(int64_t)j * vel_stride + (active ? iv : 0)];
+  const double vel = vels[(int64_t)j * vel_stride + iv];
   const double bb = vel / RVS_C_KMS;
   const double f = sqrt((1.0 - bb) / (1.0 + bb));
   const double x0 = knots[0], xlast = knots[ntp - 1];
@@ -149,9 +185,13 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   // to O(dx^3) ~ 1e-33 -- exactly the ambiguity the reference's own libm log
   // has (rvs_spline_eval keeps the reference formula verbatim).  The cubic is
   // evaluated in powers of dl = x - x_i (records built with form 1): 3 fma.
-#ifndef RVS_CG_PLAIN  // -DRVS_CG_PLAIN: one pixel per trip (the loop below)
-  auto accumulate = [&](int k, double tv) {
-    const double2 wk = W[k];
+  auto weights = [&](int k) -> double2 {
+    if (TAIL)
+      return *reinterpret_cast<const double2 *>(
+          reinterpret_cast<const char *>(W0 + k) + woff);
+    return W[k];
+  };
+  auto accumulate = [&](int k, double tv, const double2 wk) {
     const double w = tv * tv * wk.x;   // (t/e)^2
     const double u = tv * wk.y;        // t s / e^2
     const double *pr = polysT + (int64_t)k * P;
@@ -194,57 +234,34 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   // way of writing it), four need 186 VGPRs,
   // this loop unrolled twice 171 (2 waves/SIMD either way).
   int k = 0;
-  for (; k + 1 < npix; k += 2) {
+  // (packed waves take one pixel per trip: the per-lane spectrum terms of two
+  // pixels in flight would cost the third wave per SIMD)
+  for (; !TAIL && k + 1 < npix; k += 2) {
     double xa, xb;
     const int pa = knot_of(k, xa), pb = knot_of(k + 1, xb);
     const double ka = knots[pa], kb = knots[pb];
     const double4 ca = cf[pa], cb = cf[pb];
+    const double2 wa = weights(k), wb = weights(k + 1);
     const double da = xa - ka, db = xb - kb;
     const double ta = fma(fma(fma(ca.w, da, ca.z), da, ca.y), da, ca.x);
     const double tb = fma(fma(fma(cb.w, db, cb.z), db, cb.y), db, cb.x);
-    accumulate(k, ta);
-    accumulate(k + 1, tb);
+    accumulate(k, ta, wa);
+    accumulate(k + 1, tb, wb);
   }
-  if (k < npix) {
+#pragma unroll 1
+  for (; k < npix; k++) {
     double xa;
     const int pa = knot_of(k, xa);
     const double da = xa - knots[pa];
     const double4 ca = cf[pa];
-    accumulate(k, fma(fma(fma(ca.w, da, ca.z), da, ca.y), da, ca.x));
+    accumulate(k, fma(fma(fma(ca.w, da, ca.z), da, ca.y), da, ca.x),
+               weights(k));
   }
   };
   if (log_step)
     trips(std::true_type{});
   else
     trips(std::false_type{});
-#else
-  for (int k = 0; k < npix; k++) {
-    const double x = lam[k] * f;
-    int pos;
-    if (log_step)
-      pos = (int)(pixa[k] + shift);
-    else
-      pos = (int)((x - x0) * lin_inv_step);
-    pos = min(max(pos, 0), ntp - 2);
-    const double dl = x - knots[pos];
-    const double4 c = cf[pos];
-    const double2 wk = W[k];
-    const double tv = fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
-    const double w = tv * tv * wk.x;   // (t/e)^2
-    const double u = tv * wk.y;        // t s / e^2
-    const double *pr = polysT + (int64_t)k * P;
-    double pw[P];
-#pragma unroll
-    for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
-#pragma unroll
-    for (int i = 0; i < P; i++) {
-      av[i] = fma(pr[i], u, av[i]);
-#pragma unroll
-      for (int jj = 0; jj <= i; jj++)
-        acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
-    }
-  }
-#endif
 
   // in-lane Cholesky of the packed normal matrix (spec_fit.py:230-247)
   bool ok = true;
@@ -284,237 +301,53 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   }
   if (active) {
     const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
-    outp[iv] = base + chi + pen;
-    if (st) atomicOr(&status[j], st);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// LDS-DMA variant (RVS_CHISQ_VARIANT=lds; measured slower): the four waves of a block fit 256 velocities
-// of ONE job, so they share the template.  The observed pixels are walked in
-// chunks of `chunk` pixels; for every chunk the window of spline records
-// [p_lo, p_lo + WMAX) that ANY of the block's velocities can touch is copied
-// HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip, 1 KiB per wave
-// instruction, asynchronous), double buffered: the copy of chunk c+1 is in
-// flight while chunk c is computed.  Inside the pixel loop there is then no
-// vector-memory instruction at all: uniform data comes through the scalar cache,
-// spline records through ds_read.
-// ---------------------------------------------------------------------------
-#define CG_WMAX 512                       // knots per LDS window
-#define CG_COEF_BYTES (CG_WMAX * 32)      // double4 records
-#define CG_KNOT_BYTES ((CG_WMAX + 2) * 8 + 1008)  // rounded to 1 KiB pieces + pad
-#define CG_BUF_BYTES (CG_COEF_BYTES + 5 * 1024)
-
-__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(
-      (const __attribute__((address_space(1))) void *)g,
-      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-
-template <int P>
-__global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
-    chisq_grid_lds_kernel(const double *__restrict__ lam,
-                          const double *__restrict__ polysT,
-                          const double *__restrict__ work, int npix, int S,
-                          const double *__restrict__ knots,
-                          const double4 *__restrict__ coef, int ntp,
-                          int log_step, int chunk,
-                          const int32_t *__restrict__ job_spec,
-                          const int32_t *__restrict__ job_templ,
-                          const double *__restrict__ vels, int64_t vel_stride,
-                          int Nv, const double *__restrict__ penalty,
-                          double badchi, double beta_out,
-                          double *__restrict__ out,
-                          int32_t *__restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  __shared__ double sh_minmax[8];
-  const int j = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int iv = blockIdx.x * 256 + tid;
-  const bool active = iv < Nv;
-  const int s = job_spec ? job_spec[j] : j;
-  const int t = job_templ ? job_templ[j] : j;
-  double *outp = out + (int64_t)j * Nv;
-
-  const double pen = penalty ? penalty[j] : 0.0;
-  if (!(pen == pen) || isinf(pen)) {  // spec_fit.py:888-893 (block-uniform)
-    if (active) {
-      const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
+    if (TAIL && unusable) {
       outp[iv] = base + 1000.0 * badchi;
+    } else {
+      outp[iv] = base + chi + pen;
+      if (st) atomicOr(&status[j], st);
     }
-    return;
   }
-  const double *pixa = work;
-  const double2 *W = reinterpret_cast<const double2 *>(work + npix) +
-                     (int64_t)s * npix;
-  const double *scal = work + npix + 2ll * S * npix + 2 * s;
-  const double4 *cf = coef + (int64_t)t * ntp;
+}
 
-  // inactive lanes copy the block's first velocity so that min/max are unaffected
-  const double vel = vels[(int64_t)j * vel_stride + (active ? iv : blockIdx.x * 256)];
-  const double bb = vel / RVS_C_KMS;
-  const double f = sqrt((1.0 - bb) / (1.0 + bb));
-  const double x0 = knots[0], xlast = knots[ntp - 1];
-  const double inv_step = log_step ? 1.0 / log(knots[1] / x0) : 1.0 / (knots[1] - x0);
-  const double shift = log_step ? log(f) * inv_step : 0.0;
-
-  // block-wide extremes of the Doppler factor (window placement)
-  {
-    double fmn = f, fmx = f;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      fmn = fmin(fmn, __shfl_xor(fmn, o, 64));
-      fmx = fmax(fmx, __shfl_xor(fmx, o, 64));
-    }
-    if (lane == 0) {
-      sh_minmax[wave] = fmn;
-      sh_minmax[4 + wave] = fmx;
-    }
-    __syncthreads();
+// Two launches: nfull full waves per job, then the packed waves.  (One launch
+// with a block-uniform branch between the two bodies was measured: the full-wave
+// path lost 4 % to the shared register allocation, 32.5 against 31.6 ms per
+// 10 000 spectra.)
+template <int P, bool TAIL>
+// (the full-wave kernel is left at "at least two waves per SIMD": it lands on
+// 167 VGPRs = three by itself, while a demanded three changes the scheduler's
+// strategy -- the scalar loads at the head of a trip are then issued and waited
+// for one by one, 36.0 against 33.2 ms per 10 000 spectra)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(
+    TAIL ? CG_WAVES(P) : (P <= 10 ? 2 : 1))))
+    chisq_grid_kernel(const double *__restrict__ lam,
+                      const double *__restrict__ polysT,
+                      const double *__restrict__ work, int npix, int S,
+                      const double *__restrict__ knots,
+                      const double4 *__restrict__ coef, int ntp, int log_step,
+                      const int32_t *__restrict__ job_spec,
+                      const int32_t *__restrict__ job_templ, int J,
+                      const double *__restrict__ vels, int64_t vel_stride,
+                      int Nv, int iv0, int lpj, int nfull,
+                      const double *__restrict__ penalty, double badchi,
+                      double beta_out, double *__restrict__ out,
+                      int32_t *__restrict__ status) {
+  int bx = blockIdx.x, by = 0;
+  if (!TAIL) {
+    // blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one):
+    // the nfull waves of a job are 8 blocks apart so that the job's spline
+    // records are fetched into ONE L2, once
+    const int per = 8 * nfull;
+    const int g = bx / per, r = bx - g * per;
+    by = g * 8 + (r & 7);
+    bx = r >> 3;
+    if (by >= J) return;
   }
-  const double fmin_b = fmin(fmin(sh_minmax[0], sh_minmax[1]), fmin(sh_minmax[2], sh_minmax[3]));
-  const double fmax_b = fmax(fmax(sh_minmax[4], sh_minmax[5]), fmax(sh_minmax[6], sh_minmax[7]));
-  const double smin_b = log_step ? log(fmin_b) * inv_step : 0.0;
-  const double smax_b = log_step ? log(fmax_b) * inv_step : 0.0;
-
-  int32_t st = 0;
-  {
-    const double xa = lam[0] * f, xb = lam[npix - 1] * f;
-    if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) st |= RVS_ST_SPLINE_RANGE;
-  }
-
-  double acc[P * (P + 1) / 2];
-  double av[P];
-#pragma unroll
-  for (int i = 0; i < P * (P + 1) / 2; i++) acc[i] = 0;
-#pragma unroll
-  for (int i = 0; i < P; i++) av[i] = 0;
-
-  // window start of a chunk: knot coordinate of its first pixel at the block's
-  // smallest Doppler factor, minus a margin, even (16-B aligned knots copy)
-  auto window_lo = [&](int k0) -> int {
-    double c;
-    if (log_step)
-      c = pixa[k0] + smin_b;
-    else
-      c = (lam[k0] * fmin_b - x0) * inv_step;
-    int p = (int)floor(c) - 2;
-    p = min(p, ntp - CG_WMAX - 2);
-    p = max(p, 0);
-    return p & ~1;
-  };
-  auto stage = [&](int k0, int buf) {
-    const int plo = window_lo(k0);
-    char *base = lds + buf * CG_BUF_BYTES;
-    const char *gsrc = reinterpret_cast<const char *>(cf + plo);
-    const int64_t cmax = (int64_t)(ntp - plo) * 32 - 16;  // last valid 16-B piece
-#pragma unroll
-    for (int q = 0; q < CG_COEF_BYTES / 4096; q++) {
-      const int seg = q * 4 + wave;  // 1 KiB pieces, 4 waves
-      int64_t off = (int64_t)seg * 1024 + lane * 16;
-      off = (off < cmax) ? off : cmax;
-      glds16(gsrc + off, base + seg * 1024);
-    }
-    // knots: (CG_WMAX+2) doubles = 5 pieces of 1 KiB (the last partly used)
-    const char *ksrc = reinterpret_cast<const char *>(knots + plo);
-    const int64_t kmax = (int64_t)(ntp - plo) * 8 - 16;
-    for (int seg = wave; seg < 5; seg += 4) {
-      int64_t off = (int64_t)seg * 1024 + lane * 16;
-      off = (off < kmax) ? off : kmax;
-      glds16(ksrc + off, base + CG_COEF_BYTES + seg * 1024);
-    }
-  };
-
-  const int nchunk = (npix + chunk - 1) / chunk;
-  stage(0, 0);
-  __syncthreads();  // waits vmcnt(0): window 0 has landed
-  for (int c = 0; c < nchunk; c++) {
-    const int k0 = c * chunk, k1 = min(npix, k0 + chunk);
-    if (c + 1 < nchunk) stage(k1, (c + 1) & 1);  // async, lands during compute
-    const int plo = window_lo(k0);
-    const char *base = lds + (c & 1) * CG_BUF_BYTES;
-    const double4 *cw = reinterpret_cast<const double4 *>(base);
-    const double *kw = reinterpret_cast<const double *>(base + CG_COEF_BYTES);
-    {  // does the window cover the chunk for this block's velocities?
-      double chi;
-      if (log_step)
-        chi = pixa[k1 - 1] + smax_b;
-      else
-        chi = (lam[k1 - 1] * fmax_b - x0) * inv_step;
-      if ((int)chi + 2 >= plo + CG_WMAX && (int)chi + 2 < ntp) st |= 0x100;
-    }
-    for (int k = k0; k < k1; k++) {
-      const double lk = lam[k];
-      const double ak = pixa[k];
-      const double2 wk = W[k];
-      const double x = lk * f;
-      int pos;
-      if (log_step)
-        pos = (int)(ak + shift);
-      else
-        pos = (int)((x - x0) * inv_step);
-      pos = min(max(pos, 0), ntp - 2);
-      const int pl = min(max(pos - plo, 0), CG_WMAX - 1);
-      const double dl = x - kw[pl];
-      const double4 cc = cw[pl];
-      const double tv = fma(fma(fma(cc.w, dl, cc.z), dl, cc.y), dl, cc.x);
-      const double w = tv * tv * wk.x;
-      const double u = tv * wk.y;
-      const double *pr = polysT + (int64_t)k * P;
-      double pw[P];
-#pragma unroll
-      for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
-#pragma unroll
-      for (int i = 0; i < P; i++) {
-        av[i] = fma(pr[i], u, av[i]);
-#pragma unroll
-        for (int jj = 0; jj <= i; jj++)
-          acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
-      }
-    }
-    __syncthreads();  // next window landed (vmcnt) and this one is free again
-  }
-
-  bool ok = true;
-  double ldet = 0;
-#pragma unroll
-  for (int i = 0; i < P; i++) {
-#pragma unroll
-    for (int jj = 0; jj <= i; jj++) {
-      double sum = acc[TRI(i, jj)];
-#pragma unroll
-      for (int k = 0; k < jj; k++) sum -= acc[TRI(i, k)] * acc[TRI(jj, k)];
-      if (jj == i) {
-        if (!(sum > 0)) ok = false;
-        const double d = sqrt(sum);
-        acc[TRI(i, i)] = d;
-        ldet += log(d);
-      } else {
-        acc[TRI(i, jj)] = sum / acc[TRI(jj, jj)];
-      }
-    }
-  }
-  double yy = 0;
-#pragma unroll
-  for (int i = 0; i < P; i++) {
-    double sum = av[i];
-#pragma unroll
-    for (int k = 0; k < i; k++) sum -= acc[TRI(i, k)] * av[k];
-    av[i] = sum / acc[TRI(i, i)];
-    yy = fma(av[i], av[i], yy);
-  }
-  double chi = 2.0 * ldet + 2.0 * scal[0] + (scal[1] - yy);
-  if (st & (RVS_ST_SPLINE_RANGE | 0x100)) chi = __builtin_nan("");
-  if (!ok) st |= RVS_ST_CHOL_FALLBACK;
-  if (!ok || !(fabs(chi) <= 1.79e308)) {
-    st |= RVS_ST_NONFINITE;
-    chi = __builtin_nan("");
-  }
-  if (active) {
-    const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
-    outp[iv] = base + chi + pen;
-    if (st) atomicOr(&status[j], st);
-  }
+  chisq_grid_body<P, TAIL>(bx, by, lam, polysT, work, npix, S,
+                           knots, coef, ntp, log_step, job_spec, job_templ, J,
+                           vels, vel_stride, Nv, iv0, lpj, penalty, badchi,
+                           beta_out, out, status);
 }
 
 // ---------------------------------------------------------------------------
@@ -834,31 +667,37 @@ static int launch_grid(const double *lam, const double *polysT,
                        const int32_t *job_spec, const int32_t *job_templ, int J,
                        const double *vels, int64_t vel_stride, int Nv,
                        const double *penalty, double badchi, double beta,
-                       double *out, int32_t *status, int chunk, hipStream_t st) {
-  dim3 grid((Nv + 255) / 256, J);
-  if (chunk > 0 && ntp >= CG_WMAX + 2) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void *)chisq_grid_lds_kernel<P>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * CG_BUF_BYTES);
-      (void)hipGetLastError();
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(chisq_grid_lds_kernel<P>, grid, dim3(256),
-                       2 * CG_BUF_BYTES, st, lam, polysT, work, npix, S, knots,
-                       reinterpret_cast<const double4 *>(coef), ntp, log_step,
-                       chunk, job_spec, job_templ, vels, vel_stride, Nv, penalty,
-                       badchi, beta, out, status);
+                       double *out, int32_t *status, int pack_min_jobs,
+                       hipStream_t st) {
+  // left-over velocities of a job (Nv % 64): up to 32 of them are packed with
+  // those of other jobs, 64/r jobs per wave; more than 32 keep a wave of their own
+  // (below ~4000 jobs the packed launch -- one wave time whatever its size --
+  // costs more than J ragged waves inside the main launch)
+  int r = Nv % 64;
+  if (pack_min_jobs == 0) pack_min_jobs = 4096;
+  if (r > 32 || pack_min_jobs < 0 || J < pack_min_jobs ||
+      (int64_t)S * npix * 16 >= (1ll << 32))
+    r = 0;
+  const int nfull = r ? Nv / 64 : (Nv + 63) / 64;   // waves per job, TAIL=false
+  const int iv0 = r ? Nv - r : Nv;
+  const double4 *cf = reinterpret_cast<const double4 *>(coef);
+  if (nfull > 0) {
+    const int64_t nb = (int64_t)((J + 7) / 8) * 8 * nfull;
+    if (nb > 0x7fffffffll) return RVS_E_ARG;
+    hipLaunchKernelGGL((chisq_grid_kernel<P, false>), dim3((unsigned)nb),
+                       dim3(64), 0, st, lam, polysT, work, npix, S, knots, cf,
+                       ntp, log_step, job_spec, job_templ, J, vels, vel_stride,
+                       Nv, iv0, 64, nfull, penalty, badchi, beta, out, status);
     RVS_LAUNCH_CHECK();
-    return 0;
   }
-  hipLaunchKernelGGL(chisq_grid_kernel<P>, grid, dim3(256), 0, st, lam, polysT,
-                     work, npix, S, knots,
-                     reinterpret_cast<const double4 *>(coef), ntp, log_step,
-                     job_spec, job_templ, vels, vel_stride, Nv, penalty, badchi,
-                     beta, out, status);
-  RVS_LAUNCH_CHECK();
+  if (r) {
+    const int jpw = 64 / r;
+    hipLaunchKernelGGL((chisq_grid_kernel<P, true>), dim3((J + jpw - 1) / jpw),
+                       dim3(64), 0, st, lam, polysT, work, npix, S, knots, cf,
+                       ntp, log_step, job_spec, job_templ, J, vels, vel_stride,
+                       Nv, iv0, r, 0, penalty, badchi, beta, out, status);
+    RVS_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -893,17 +732,17 @@ extern "C" int rvs_chisq_grid(const double *lam, const double *polysT,
                               const int32_t *job_templ, int J,
                               const double *vels, int64_t vel_stride, int Nv,
                               const double *penalty, double badchi, double beta,
-                              int chunk, double *out, int32_t *status,
+                              int pack_min_jobs, double *out, int32_t *status,
                               void *stream) {
   (void)Tn;
-  if (J < 1 || Nv < 1 || npix < 1 || ntp < 3 || chunk < 0) return RVS_E_ARG;
-  if (J > 65535) return RVS_E_ARG;  // grid.y limit; callers chunk
+  if (J < 1 || Nv < 1 || npix < 1 || ntp < 3) return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
 #define RVS_CASE(PP)                                                          \
   case PP:                                                                    \
     return launch_grid<PP>(lam, polysT, work, npix, S, knots, coef, ntp,      \
                            log_step, job_spec, job_templ, J, vels, vel_stride, \
-                           Nv, penalty, badchi, beta, out, status, chunk, st);
+                           Nv, penalty, badchi, beta, out, status,       \
+                           pack_min_jobs, st);
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
     RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)

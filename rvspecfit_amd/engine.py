@@ -378,41 +378,10 @@ def convolve_vsini(lib_or_lam, templ, vsini, eps=0.6):
 # chi^2 grid over velocities: A7-eval + A10 + A11 (+ penalties of A11)
 # --------------------------------------------------------------------------
 XCORR_PRUNE = True     # prune the last two FFT passes to the lags that are read
-CG_WMAX = 512          # knots per LDS window of chisq_grid_lds_kernel
 import os as _os
-# chi^2-grid kernel variant: 'plain' (default) gathers the spline records
-# through the vector L1; 'lds' stages spline windows HBM->LDS with LDS-DMA
-# (bit-compatible, measured slower: DESIGN.md section 4.2)
-CHISQ_VARIANT = _os.environ.get('RVS_CHISQ_VARIANT', 'plain')
-
-
-def lds_chunk(arm, lib, vmin, vmax):
-    """Largest pixel chunk whose spline window (incl. the Doppler range
-    [vmin, vmax]) fits the 512-knot LDS window of the staged chi^2 kernel, or 0
-    when the L1-gather variant has to be used."""
-    if CHISQ_VARIANT != 'lds' or lib.ntp < CG_WMAX + 2:
-        return 0
-    key = ('chunk', lib.name, id(lib), float(vmin), float(vmax))
-    if key in arm._ccf:
-        return arm._ccf[key]
-    beta = np.array([vmin, vmax], dtype=np.float64) / SPEED_OF_LIGHT
-    f = np.sqrt((1 - beta) / (1 + beta))  # f[0] >= f[1]
-    lam = arm.lam_host
-    if lib.log_step:
-        a = (np.log(lam) - np.log(lib.lam[0])) / lib.lnstep
-        lo, hi = a + np.log(f[1]) / lib.lnstep, a + np.log(f[0]) / lib.lnstep
-    else:
-        st = lib.lam[1] - lib.lam[0]
-        lo, hi = (lam * f[1] - lib.lam[0]) / st, (lam * f[0] - lib.lam[0]) / st
-    best = 0
-    for ch in (256, 224, 192, 160, 128, 96, 64, 48, 32, 16):
-        k0 = np.arange(0, len(lam), ch)
-        k1 = np.minimum(k0 + ch, len(lam)) - 1
-        if np.all(hi[k1] - lo[k0] + 8 <= CG_WMAX - 2):
-            best = ch
-            break
-    arm._ccf[key] = best
-    return best
+# rvs_chisq_grid's pack_min_jobs: 0 = library default (pack the Nv % 64
+# left-over velocities of >= 4096 jobs), 1 = always, -1 = never (tests)
+CG_PACK_MIN_JOBS = 0
 
 
 def _arm_resol(arm, ia, resols):
@@ -485,7 +454,6 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
     for ia, arm in enumerate(batch.arms):
         lib = libs[arm.name]
         work = arm.work(lib, espec_sys)
-        chunk = lds_chunk(arm, lib, vel_bounds[0], vel_bounds[1])
         polysT, logdet_off = arm.basis_ortho(npoly, rbf)
         o = outsides[ia]
         if job_templ is not None:
@@ -521,7 +489,7 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
                 coef.shape[0], int(lib.log_step), js, jt, b - a,
                 _lib.ptr(vels if shared else vels[a:b]), vstride, Nv,
                 _lib.ptr(pen[a:b]), float(batch.badchi),
-                0.0 if ia == 0 else 1.0, chunk, _lib.ptr(out[a:b]),
+                0.0 if ia == 0 else 1.0, CG_PACK_MIN_JOBS, _lib.ptr(out[a:b]),
                 _lib.ptr(status[a:b]), _lib.stream())
             _lib.check(rc, 'rvs_chisq_grid')
     return out, status

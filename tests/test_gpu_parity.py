@@ -437,36 +437,43 @@ def test_overlap_error(cases, config):
                            options=dict(npoly=10), config=config)
 
 
-def test_chisq_kernel_variants_agree(cases, config):
-    """the two chi^2-grid kernel variants are the same arithmetic (differences:
-    fma contraction only)"""
-    from rvspecfit_amd import spec_fit, engine
+def test_chisq_grid_wave_placement_bit_identical(cases, config):
+    """A velocity's chi^2 does not depend on where the kernel computes it: in a
+    wave of 64 velocities of one spectrum, or in a wave that packs the left-over
+    velocities (Nv % 64) of several jobs (chisq_grid_kernel<P, TAIL>)."""
+    from rvspecfit_amd import spec_fit
     sds = _sds(cases, 'c1')
-    vg = cases['vel_grid'].astype(np.float64)
+    vg = cases['vel_grid'].astype(np.float64)          # 400 velocities: 6 x 64 + 16
+    assert len(vg) % 64 == 16
     pl = [tuple(_) for _ in cases['c1/g3/params_list']]
-    out = {}
-    keep = engine.CHISQ_VARIANT
-    for var in ('plain', 'lds'):
-        engine.CHISQ_VARIANT = var
+    b, _ = spec_fit.as_batch(sds)
+    par = torch.as_tensor(np.array(pl))[None].to('cuda')
+
+    from rvspecfit_amd import engine
+
+    def grid(v, npoly, pack):
+        keep = engine.CG_PACK_MIN_JOBS
+        engine.CG_PACK_MIN_JOBS = pack
         try:
-            b, _ = spec_fit.as_batch(sds)
-            for a in b.arms:
-                a._ccf = {k: v for k, v in a._ccf.items()
-                          if not (isinstance(k, tuple) and k[0] == 'chunk')}
-            par = torch.as_tensor(np.array(pl))[None].to('cuda')
-            for npoly in (10, 7, 15):
-                chisq, st, _ = spec_fit.chisq_grid_jobs(
-                    b, torch.as_tensor(vg).to('cuda'), par, None,
-                    dict(npoly=npoly), config)
-                out[(var, npoly)] = chisq.cpu().numpy()
-                assert int(st.sum().item()) == 0
+            chisq, st, _ = spec_fit.chisq_grid_jobs(
+                b, torch.as_tensor(np.ascontiguousarray(v)).to('cuda'), par,
+                None, dict(npoly=npoly), config)
         finally:
-            engine.CHISQ_VARIANT = keep
+            engine.CG_PACK_MIN_JOBS = keep
+        assert int(st.sum().item()) == 0
+        return chisq.cpu().numpy().reshape(-1, len(v))
     for npoly in (10, 7, 15):
-        ref = out[('plain', npoly)]
-        for var in ('lds', ):
-            # chi^2 crosses zero on the grid: compare on the scale of the grid
-            assert np.max(np.abs(out[(var, npoly)] - ref)) < 1e-11 * np.abs(ref).max()
+        ragged = grid(vg, npoly, -1)     # 7 waves per job, the last with 16 lanes
+        packed = grid(vg, npoly, 1)      # 6 waves per job + 4 jobs per packed wave
+        np.testing.assert_array_equal(packed, ragged)
+        # the last 64 as a grid of their own: all in one full wave
+        np.testing.assert_array_equal(grid(vg[-64:], npoly, 1), ragged[:, -64:])
+        # 24 left-over velocities: 2 jobs per packed wave
+        np.testing.assert_array_equal(grid(vg[-24:], npoly, 1), ragged[:, -24:])
+        # 5 left-over velocities: 12 jobs per packed wave
+        np.testing.assert_array_equal(grid(vg[:69], npoly, 1), ragged[:, :69])
+        # more than 32 left over: never packed
+        np.testing.assert_array_equal(grid(vg[-40:], npoly, 1), ragged[:, -40:])
 
 
 def _nn_lib(d, lam):

@@ -140,7 +140,7 @@ def cpu_worker(args):
     dicts = build_library_dicts(args.ccf_every, orc.convolve_vsini_rows)
     tlib = time.time() - t0
     global _W
-    _W = dict(libs={k: orc.Library(v) for k, v in dicts.items()}, d=d)
+    _W = dict(libs={k: orc.make_library(v) for k, v in dicts.items()}, d=d)
     ncore = max(1, min(args.cpu_cores or (os.cpu_count() or 1), n))
     t0 = time.time()
     one_fn = _cpu_one_process if args.cpu_process else _cpu_one
@@ -205,7 +205,8 @@ def run_cpu_baseline(arms, n, args, start=None):
     np.savez(path, **sample)
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', path,
            '--ccf-every', str(args.ccf_every), '--cpu-cores',
-           str(args.cpu_cores), '--workload', args.workload]
+           str(args.cpu_cores), '--workload', args.workload, '--evaluator',
+           args.evaluator]
     if start is not None:
         cmd.append('--cpu-process')
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -509,26 +510,53 @@ def main():
     grid_gbs = (units2 / len(ARMS)) * b_grid_unit / (ms2 * 1e-3) / 1e9 if ms2 else 0
     flop_grid_unit = 400 * npix_tot * (2 * 65 + 40)
     grid_tflops = (units2 / len(ARMS)) * flop_grid_unit / (ms2 * 1e-3) / 1e12 if ms2 else 0
-    dominant = 'ccf_xcorr_kernel' if ms >= ms2 else 'chisq_grid_kernel'
-    traffic = None
-    prof = os.path.join(REPO, 'profiles', 'r01_pmc_ccf_xcorr.json')
-    if os.path.exists(prof):
+    # ---- roofline of the DOMINANT kernel: the fp64 chi^2 grid ----------------
+    # algorithmic flops per spectrum: Nv * sum_arm npix * (2*65 + 40) at npoly 10
+    # (65 FMAs of the normal-equation sums per pixel-velocity + 40 for the spline
+    # value, weights, products); one launch = one rvs_chisq_grid
+    # call over one arm (full-wave kernel + packed-wave kernel)
+    FP64_PEAK_TF = 78.6   # datasheet fp64 vector rate (256 CUs x 128 flop/clk x 2.4 GHz)
+
+    def pmc_traffic(kernel):
+        """HBM bytes per launch from the committed PMC passes of this build's
+        profile (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 runs): measured
+        by tools/perf/profile_round.sh, NOT by this run"""
+        f = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
         try:
-            traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+            d = json.load(open(f))[kernel]
+            return d['hbm_bytes_per_launch'], 'profiles/r02_pmc_traffic.json (%s)' % d['source']
         except Exception:
-            traffic = None
-    roof = dict(bound='hbm', kernel='ccf_xcorr_kernel',
-                timed='rvs_ccf_xcorr call = ccf_rfft_kernel + ccf_xcorr_kernel '
-                      '(HIP events on the launch stream)',
-                achieved=round(ccf_gbs, 1),
-                peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ccf_gbs / HBM_PEAK_GBS, 4),
-                traffic=traffic,
-                bytes_per_spectrum=b_ccf_unit,
-                avg_launch_ms=round(ms / max(nl, 1), 3), launches=nl,
-                dominant_by_time=dominant,
-                note='algorithmic bytes = CCF template block streamed once per '
-                     'spectrum (SURVEY 8(d) D3); the block is shared by every '
-                     'spectrum so most of it is served by L2/Infinity Cache')
+            return None, None
+    tr_grid, src_grid = pmc_traffic('chisq_grid')
+    tr_ccf, src_ccf = pmc_traffic('ccf_xcorr')
+    roof = dict(bound='fp64_valu', kernel='chisq_grid_kernel',
+                timed='rvs_chisq_grid call = chisq_grid_kernel<10,false> (full '
+                      'waves) + <10,true> (packed left-over velocities), HIP '
+                      'events on the launch stream',
+                achieved=round(grid_tflops, 2), peak=FP64_PEAK_TF,
+                unit='TFLOP/s', frac=round(grid_tflops / FP64_PEAK_TF, 4),
+                traffic=tr_grid, traffic_source=src_grid,
+                flop_per_spectrum=flop_grid_unit,
+                bytes_per_spectrum=b_grid_unit,
+                avg_launch_ms=round(ms2 / max(nl2, 1), 3), launches=nl2,
+                share_of_step=round(ms2 / args.steps / (dt / args.steps * 1e3), 3),
+                peak_sustained_ubench=70.6,
+                note='fp64 vector-ALU bound (0.07 TB/s algorithmic): flops = 170 '
+                     'per pixel-velocity; peak = datasheet fp64 vector rate, a '
+                     'pure v_fma_f64 loop sustains 70.6 TF on this chip '
+                     '(tools/perf/ubench.hip)')
+    roof_ccf = dict(bound='hbm', kernel='ccf_xcorr_kernel',
+                    timed='rvs_ccf_xcorr call = ccf_rfft_kernel + ccf_xcorr_kernel '
+                          '(HIP events on the launch stream)',
+                    achieved=round(ccf_gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=round(ccf_gbs / HBM_PEAK_GBS, 4),
+                    traffic=tr_ccf, traffic_source=src_ccf,
+                    bytes_per_spectrum=b_ccf_unit,
+                    avg_launch_ms=round(ms / max(nl, 1), 3), launches=nl,
+                    share_of_step=round(ms / args.steps / (dt / args.steps * 1e3), 3),
+                    note='algorithmic bytes = CCF template block streamed once per '
+                         'spectrum (SURVEY 8(d) D3); the block is shared by every '
+                         'spectrum so most of it is served by L2/Infinity Cache')
     kernels = {
         'ccf_xcorr': dict(ms_per_step=round(ms / args.steps, 2),
                           alg_GBps=round(ccf_gbs, 1)),
@@ -555,8 +583,7 @@ def main():
     cpu = None
     parity = None
     # the CPU leg is timed on rank 0 at N = 1 only
-    if not args.no_cpu_baseline and EVALUATOR == 'polylinear' and \
-            not args.resolution_matrix and world == 1:
+    if not args.no_cpu_baseline and not args.resolution_matrix and world == 1:
         n = min(args.cpu_sample, S)
         cb = run_cpu_baseline(arms, n, args)
         cpu = dict(value=round(cb['n'] / cb['wall'], 3), unit='spectra/s',
@@ -612,7 +639,8 @@ def main():
                     refine=bool(args.refine),
                     resolution_matrix=bool(args.resolution_matrix),
                     parallelism='spectra-sharded x%d' % world),
-        roofline=roof, cpu_baseline=cpu, stage_ms=stage_round(stage),
+        roofline=roof, roofline_ccf=roof_ccf, cpu_baseline=cpu,
+        stage_ms=stage_round(stage),
         kernels=kernels, parity_sample=parity, setup_s=round(t_setup, 1))
     if proc is not None:
         line['process'] = proc

@@ -919,6 +919,70 @@ def nn_forward(weights, p, M, S, log_ids=(0, )):
     return np.exp(np.clip(h.astype(np.float64), -300, 300))
 
 
+class NNLibrary(Library):
+    """A spectral setup whose template evaluator is the MLP (interpolation_type
+    'generic' with nn.RVSInterpolator / nn.OutsideInterpolator,
+    spec_inter.py:371-378, nn/RVSInterpolator.py:36-71); the CCF part of the
+    setup is that of Library."""
+
+    def __init__(self, npz):
+        d = dict(npz)
+        self.lam = _c(d['lam'])
+        self.log_step = bool(d['log_step'])
+        self.log_ids = [int(_) for _ in np.atleast_1d(d['log_ids'])]
+        self.parnames = tuple(str(_) for _ in d['parnames'])
+        dims = [int(_) for _ in d['nn_dims']]
+        self.ndim = dims[0]
+        self.weights = [(np.asarray(d['nn_W%d' % i], dtype=np.float32),
+                         np.asarray(d['nn_b%d' % i], dtype=np.float32))
+                        for i in range(len(dims) - 1)]
+        self.M, self.S = _c(d['nn_M']), _c(d['nn_S'])
+        self.hull = None
+        if 'nn_pts' in d:
+            import scipy.spatial
+            pts = np.asarray(d['nn_pts'], dtype=np.float64)
+            self.hull = (scipy.spatial.ConvexHull(pts[:, :2]).equations,
+                         scipy.spatial.ConvexHull(pts[:, 2:]).equations)
+        if 'ccf_fft' in d:
+            self.ccf = dict(
+                fft=d['ccf_fft'], fft2=d['ccf_fft2'], mod=d['ccf_mod'],
+                params=_c(d['ccf_params']), vsinis=_c(d['ccf_vsinis']),
+                logl0=float(d['ccf_logl0']), logl1=float(d['ccf_logl1']),
+                npoints=int(d['ccf_npoints']),
+                continuum=bool(d['ccf_continuum']),
+                splinestep=float(d['ccf_splinestep']),
+                maxcontpts=int(d['ccf_maxcontpts']))
+
+    def eval(self, p, details=False):
+        spec = np.ascontiguousarray(
+            nn_forward(self.weights, np.asarray(p, dtype=np.float64)[None],
+                       self.M, self.S, self.log_ids)[0], dtype=np.float64)
+        return (spec, dict()) if details else spec
+
+    # nn/RVSInterpolator.py:63-71 on the Mapper-transformed point
+    def outside_flag(self, p):
+        if self.hull is None:
+            return 0.
+        x1 = np.asarray(p, dtype=np.float32)
+        y = x1 * 1
+        with np.errstate(all='ignore'):
+            for i in self.log_ids:
+                y[i] = np.log10(x1[i])
+        q = (y.astype(np.float64) - self.M) / self.S
+        dx = (self.hull[0][:, :-1] @ q[:2] + self.hull[0][:, -1]).max()
+        dy = (self.hull[1][:, :-1] @ q[2:] + self.hull[1][:, -1]).max()
+        return max(dx, dy, 0.)**2
+
+
+def make_library(npz):
+    """Library / NNLibrary / TriLibrary by the keys of the converted artefact"""
+    if 'nn_dims' in npz:
+        return NNLibrary(npz)
+    if 'simplices' in npz:
+        return TriLibrary(npz)
+    return Library(npz)
+
+
 def convolve_vsini_rows(lam, templ, vsini, eps=0.6):
     """convolve_vsini applied to every row (bench helper)."""
     return np.array([convolve_vsini(lam, t, v, eps) for t, v in zip(templ, vsini)])

@@ -6,9 +6,9 @@ out=gpurun_out/configs_$tag.jsonl
 : > $out
 run() { python bench.py "$@" 2>/dev/null | tail -1 >> $out; }
 run --steps 3 --warmup 1
-run --spectra 2000 --ccf-every 9 --steps 3 --warmup 1 --no-cpu-baseline
-run --workload cfg2 --spectra 1000 --steps 5 --warmup 1 --no-cpu-baseline
-run --evaluator nn --steps 3 --warmup 1 --no-cpu-baseline
+run --ccf-every 9 --steps 2 --warmup 1 --cpu-sample 32
+run --workload cfg2 --spectra 1000 --steps 5 --warmup 1 --cpu-sample 256
+run --evaluator nn --steps 3 --warmup 1
 run --refine --steps 2 --warmup 1 --no-cpu-baseline
 run --resolution-matrix --steps 2 --warmup 1 --no-cpu-baseline
 run --spectra 2000 --steps 1 --warmup 1 --cpu-sample 8 --process 2000 --process-cpu-sample 8
@@ -24,6 +24,6 @@ for l in open("$out"):
     d = json.loads(l)
     c = d["config"]
     print(round(d["value"]), d["ms_per_step"], c["spectra_per_gpu"], c["ccf_templates"], c.get("refine"), c.get("resolution_matrix"),
-          d["roofline"]["frac"], d["kernels"].get("template_nn"), (d.get("process") or {}).get("spectra_per_s"),
+          d["roofline"]["frac"], d["roofline_ccf"]["frac"], (d.get("cpu_baseline") or {}).get("value"), d["kernels"].get("template_nn"), (d.get("process") or {}).get("spectra_per_s"),
           (d.get("desi_file") or {}).get("fibres_per_s"))
 PY

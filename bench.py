@@ -507,6 +507,9 @@ def main():
     ntp_tot = sum(len(dicts[arm_name(a)]['lam']) for a in ARMS)
     # chi^2 grid: spectrum terms (16 B/px) + spline records (32 B/knot) + out
     b_grid_unit = npix_tot * 16 + ntp_tot * 32 + 400 * 8
+    # (the timer counts job-velocities per arm launch; a contract unit is 400
+    # velocities on every arm, refinement rounds add shorter grids)
+    units2 = units2 / 400.0
     grid_gbs = (units2 / len(ARMS)) * b_grid_unit / (ms2 * 1e-3) / 1e9 if ms2 else 0
     flop_grid_unit = 400 * npix_tot * (2 * 65 + 40)
     grid_tflops = (units2 / len(ARMS)) * flop_grid_unit / (ms2 * 1e-3) / 1e12 if ms2 else 0

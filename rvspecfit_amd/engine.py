@@ -466,7 +466,7 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
         coef = coefs[ia]
         rs = _arm_resol(arm, ia, resols)
         for a, b in _chunks(J, 65535):
-          with _ktime('chisq_grid', (b - a)):
+          with _ktime('chisq_grid', (b - a) * Nv):   # units: job-velocities
             js = _lib.ptr(job_spec[a:b]) if job_spec is not None else \
                 (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None)
             jt = _lib.ptr(job_templ[a:b]) if job_templ is not None else \

@@ -114,7 +114,8 @@ def test_sample_against_oracle(full):
     ix = torch.as_tensor([0, 1999, 4242, 6001, 8765, 9999])
     arms = [(nm, lam, sp[ix.to(sp.device)], es[ix.to(sp.device)],
              bad[ix.to(sp.device)]) for nm, lam, sp, es, bad in full['arms']]
-    args = argparse.Namespace(ccf_every=64, cpu_cores=6, workload='desi')
+    args = argparse.Namespace(ccf_every=64, cpu_cores=6, workload='desi',
+                              evaluator='polylinear')
     cb = full['bench'].run_cpu_baseline(arms, len(ix), args)
     o = np.array(cb['recs'])
     g = full['rec'][ix.to(full['dev'])].cpu().numpy()

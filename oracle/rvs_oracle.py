@@ -203,6 +203,35 @@ def get_chisq0_c(spec, templ, polys, espec, get_coeffs=False):
 # A3  polylinear template interpolation
 #     (spec_inter.py:62-194, read_grid.py:127-145)
 # --------------------------------------------------------------------------
+def _ccf_sets(d):
+    """the CCF template sets of a converted artefact: keys ccf_* = continuum-
+    normalised, ccfnc_* = rvs_make_ccf --nocontinuum (make_ccf.py:19-36)"""
+    out = {}
+    for cont, pre in ((True, 'ccf_'), (False, 'ccfnc_')):
+        if pre + 'fft' not in d:
+            continue
+        out[cont] = dict(
+            fft=d[pre + 'fft'], fft2=d[pre + 'fft2'], mod=d[pre + 'mod'],
+            params=_c(d[pre + 'params']), vsinis=_c(d[pre + 'vsinis']),
+            logl0=float(d[pre + 'logl0']), logl1=float(d[pre + 'logl1']),
+            npoints=int(d[pre + 'npoints']),
+            continuum=bool(d[pre + 'continuum']),
+            splinestep=float(d[pre + 'splinestep'])
+            if pre + 'splinestep' in d else None,
+            maxcontpts=int(d[pre + 'maxcontpts']))
+    return out
+
+
+def _ccf_pick(lib, config):
+    """get_ccf_info's choice (fitter_ccf.py:40-47): config key
+    ccf_continuum_normalize, None / missing = True"""
+    cont = (config or {}).get('ccf_continuum_normalize')
+    cont = True if cont is None else bool(cont)
+    if cont not in lib.ccf_sets:
+        raise RuntimeError('no such CCF template set')
+    return lib.ccf_sets[cont]
+
+
 class Library:
     """One spectral setup loaded from the converted-artefact npz
     (same keys as tests/golden/lib_*.npz)."""
@@ -223,15 +252,11 @@ class Library:
         self.ptp = np.ptp(self.vec, axis=1)
         self.scaled = self.vec.T / self.ptp[None, :]
         self.exp = True  # log_spec default (spec_inter.py:331)
-        if 'ccf_fft' in d:
-            self.ccf = dict(
-                fft=d['ccf_fft'], fft2=d['ccf_fft2'], mod=d['ccf_mod'],
-                params=_c(d['ccf_params']), vsinis=_c(d['ccf_vsinis']),
-                logl0=float(d['ccf_logl0']), logl1=float(d['ccf_logl1']),
-                npoints=int(d['ccf_npoints']),
-                continuum=bool(d['ccf_continuum']),
-                splinestep=float(d['ccf_splinestep']),
-                maxcontpts=int(d['ccf_maxcontpts']))
+        self.ccf_sets = _ccf_sets(d)
+        self.ccf = self.ccf_sets.get(True)
+
+    def ccf_set(self, config):
+        return _ccf_pick(self, config)
 
     # read_grid.py:127-145
     def map_params(self, p):
@@ -778,7 +803,7 @@ def ccf_fit(specdata, config, libs, details=False):
     total_sse = 0
     states, proc = [], {}
     for sd in specdata:
-        cc = libs[sd.name].ccf
+        cc = _ccf_pick(libs[sd.name], config)
         ps, pi = preprocess_data(sd.lam, sd.spec, sd.espec, cc,
                                  badmask=sd.badmask)
         proc[sd.name] = (ps, pi)
@@ -943,15 +968,8 @@ class NNLibrary(Library):
             pts = np.asarray(d['nn_pts'], dtype=np.float64)
             self.hull = (scipy.spatial.ConvexHull(pts[:, :2]).equations,
                          scipy.spatial.ConvexHull(pts[:, 2:]).equations)
-        if 'ccf_fft' in d:
-            self.ccf = dict(
-                fft=d['ccf_fft'], fft2=d['ccf_fft2'], mod=d['ccf_mod'],
-                params=_c(d['ccf_params']), vsinis=_c(d['ccf_vsinis']),
-                logl0=float(d['ccf_logl0']), logl1=float(d['ccf_logl1']),
-                npoints=int(d['ccf_npoints']),
-                continuum=bool(d['ccf_continuum']),
-                splinestep=float(d['ccf_splinestep']),
-                maxcontpts=int(d['ccf_maxcontpts']))
+        self.ccf_sets = _ccf_sets(d)
+        self.ccf = self.ccf_sets.get(True)
 
     def eval(self, p, details=False):
         spec = np.ascontiguousarray(

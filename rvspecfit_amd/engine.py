@@ -214,9 +214,9 @@ class ArmData:
 
     def ccf_tables(self, lib, config):
         """Per-arm CCF tables (host-built once, see ccf_tables.py)."""
-        cc = lib.ccf
+        cc = lib.ccf_set(config)
         maxvel, vgrid = ccf_tables.ccf_vel_grid(config)
-        key = (lib.name, id(lib), maxvel, len(vgrid))
+        key = (lib.name, id(lib), maxvel, len(vgrid), cc['continuum'])
         if key in self._ccf:
             return self._ccf[key]
         dev = self.device
@@ -771,7 +771,7 @@ def chisq_continuum_fix(batch, res, npoly=5, rbf=True):
 def ccf_preprocess(arm, lib, config, details=False):
     L = _lib.lib()
     T = arm.ccf_tables(lib, config)
-    cc = lib.ccf
+    cc = lib.ccf_set(config)
     dev = arm.device
     nfft = cc['npoints']
     ps = torch.empty((arm.S, nfft), dtype=torch.float64, device=dev)
@@ -806,10 +806,10 @@ def ccf_fit(batch, libs, config, keep_all=False, max_chunk=None):
     L = _lib.lib()
     dev = batch.device
     S = batch.S
-    ref = libs[batch.names[0]].ccf
+    ref = libs[batch.names[0]].ccf_set(config)
     Tn = ref['T']
     for n in batch.names[1:]:
-        cc = libs[n].ccf
+        cc = libs[n].ccf_set(config)
         if cc['T'] != Tn:
             raise RuntimeError('CCF template counts are inconsistent across setups')
         if (not np.array_equal(ref['params'], cc['params'])
@@ -835,7 +835,7 @@ def ccf_fit(batch, libs, config, keep_all=False, max_chunk=None):
         n = b - a
         acc = torch.empty((n, Tn, nvel), dtype=torch.float64, device=dev)
         for ia, arm in enumerate(batch.arms):
-            cc = libs[arm.name].ccf
+            cc = libs[arm.name].ccf_set(config)
             T = tabs[ia]
             nfft = cc['npoints']
             work = torch.empty((n, 2, nfft // 2 + 1, 2), dtype=torch.float64,

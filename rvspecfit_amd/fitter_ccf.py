@@ -22,7 +22,7 @@ def fit(specdata, config):
     batch, is_batch = as_batch(specdata)
     libs = spec_inter.get_libs(batch.names, config)
     r = engine.ccf_fit(batch, libs, config)
-    ref = libs[batch.names[0]].ccf
+    ref = libs[batch.names[0]].ccf_set(config)
     best_id = r['best_id']
     par = ref['params_dev'][best_id]
     vs = ref['vsinis_dev'][best_id]
@@ -41,7 +41,7 @@ def fit(specdata, config):
     parnames = libs[batch.names[0]].parnames
     best_model = {}
     for name, step in zip(batch.names, r['steps']):
-        mod = libs[name].ccf['mod']
+        mod = libs[name].ccf_set(config)['mod']
         if mod is not None:
             best_model[name] = np.roll(mod[bid], int(best_vel / step))
     v = ref['vsinis'][bid]

@@ -103,29 +103,49 @@ class TemplateLibrary:
                 pts = np.asarray(d['nn_pts'], dtype=np.float64)
                 self.nn_hull = (scipy.spatial.ConvexHull(pts[:, :2]).equations,
                                 scipy.spatial.ConvexHull(pts[:, 2:]).equations)
-        self.ccf = None
-        if 'ccf_fft' in d:
-            fft = np.ascontiguousarray(d['ccf_fft'], dtype=np.complex128)
-            fft2 = np.ascontiguousarray(d['ccf_fft2'], dtype=np.complex128)
-            self.ccf = dict(
+        # the two CCF template sets of a setup: continuum-normalised (files
+        # ccf_<setup>.h5 ..., keys ccf_*) and not (rvs_make_ccf --nocontinuum,
+        # files ccf_nocont_<setup>.h5 ..., keys ccfnc_*); make_ccf.py:19-36
+        self.ccf_sets = {}
+        for cont, pre in ((True, 'ccf_'), (False, 'ccfnc_')):
+            if pre + 'fft' not in d:
+                continue
+            fft = np.ascontiguousarray(d[pre + 'fft'], dtype=np.complex128)
+            fft2 = np.ascontiguousarray(d[pre + 'fft2'], dtype=np.complex128)
+            self.ccf_sets[cont] = dict(
                 T=fft.shape[0],
-                nfft=int(d['ccf_npoints']),
+                nfft=int(d[pre + 'npoints']),
                 fft=_dev(fft.view(np.float64), torch.float64, device),
                 fft2=_dev(fft2.view(np.float64), torch.float64, device),
-                mod=np.asarray(d['ccf_mod']) if 'ccf_mod' in d else None,
-                params=np.asarray(d['ccf_params'], dtype=np.float64),
-                vsinis=np.asarray(d['ccf_vsinis'], dtype=np.float64),
-                params_dev=_dev(d['ccf_params'], torch.float64, device),
-                vsinis_dev=_dev(np.nan_to_num(np.asarray(d['ccf_vsinis'],
+                mod=np.asarray(d[pre + 'mod']) if pre + 'mod' in d else None,
+                params=np.asarray(d[pre + 'params'], dtype=np.float64),
+                vsinis=np.asarray(d[pre + 'vsinis'], dtype=np.float64),
+                params_dev=_dev(d[pre + 'params'], torch.float64, device),
+                vsinis_dev=_dev(np.nan_to_num(np.asarray(d[pre + 'vsinis'],
                                                          dtype=np.float64),
                                               nan=0.0), torch.float64, device),
-                logl0=float(d['ccf_logl0']), logl1=float(d['ccf_logl1']),
-                npoints=int(d['ccf_npoints']),
-                continuum=bool(d['ccf_continuum']),
-                splinestep=float(d['ccf_splinestep']) if 'ccf_splinestep' in d
-                else None,
-                maxcontpts=int(d['ccf_maxcontpts']) if 'ccf_maxcontpts' in d
-                else 20)
+                logl0=float(d[pre + 'logl0']), logl1=float(d[pre + 'logl1']),
+                npoints=int(d[pre + 'npoints']),
+                continuum=bool(d[pre + 'continuum']),
+                splinestep=float(d[pre + 'splinestep'])
+                if pre + 'splinestep' in d else None,
+                maxcontpts=int(d[pre + 'maxcontpts'])
+                if pre + 'maxcontpts' in d else 20)
+        self.ccf = self.ccf_sets.get(True)
+
+    def ccf_set(self, config):
+        """The CCF template set config['ccf_continuum_normalize'] selects
+        (get_ccf_info, fitter_ccf.py:40-47: missing / None = the
+        continuum-normalised one)."""
+        cont = (config or {}).get('ccf_continuum_normalize')
+        cont = True if cont is None else bool(cont)
+        if cont not in self.ccf_sets:
+            raise RuntimeError(
+                'setup %s has no %s CCF template set (ccf_%s%s.h5 was not '
+                'converted)' % (self.name, 'continuum-normalised' if cont
+                                else 'non-normalised',
+                                '' if cont else 'nocont_', self.name))
+        return self.ccf_sets[cont]
 
     @classmethod
     def from_npz(cls, name, path, device='cuda'):

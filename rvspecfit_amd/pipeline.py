@@ -36,7 +36,7 @@ def fit_batch(batch, config, options=None, refine=False, timers=None):
     ev.start('ccf')
     ccf = engine.ccf_fit(batch, libs, config)
     ev.stop('ccf')
-    ref = libs[batch.names[0]].ccf
+    ref = libs[batch.names[0]].ccf_set(config)
     params = ref['params_dev'][ccf['best_id']].contiguous()
     vsini = ref['vsinis_dev'][ccf['best_id']].contiguous()
 

@@ -28,13 +28,18 @@ def cases():
     return dict(np.load(os.path.join(GOLD, 'cases.npz')))
 
 
+def gold_lib_dict(n):
+    """converted artefact of a golden setup: interpolation data + both CCF
+    template sets (continuum-normalised ccf_*, non-normalised ccfnc_*)"""
+    d = dict(np.load(os.path.join(GOLD, 'lib_%s.npz' % n)))
+    d.update(np.load(os.path.join(GOLD, 'lib_nocont_%s.npz' % n)))
+    return d
+
+
 @pytest.fixture(scope='session')
 def gold_libs():
     from oracle import rvs_oracle as orc
-    return {
-        n: orc.Library(np.load(os.path.join(GOLD, 'lib_%s.npz' % n)))
-        for n in ('gold_b', 'gold_r')
-    }
+    return {n: orc.Library(gold_lib_dict(n)) for n in ('gold_b', 'gold_r')}
 
 
 GOLD_CONFIG = dict(min_vel=-1000, max_vel=1000, min_vel_step=0.2, vel_step0=5,

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLD, GOLD_CONFIG, gold_specdata
+from conftest import GOLD, GOLD_CONFIG, gold_specdata, gold_lib_dict
 from oracle import rvs_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -40,7 +40,7 @@ def config(gpu):
     cfg = dict(GOLD_CONFIG)
     cfg['template_lib'] = 'golden://'
     for n in ('gold_b', 'gold_r'):
-        lib = TemplateLibrary(n, np.load(os.path.join(GOLD, 'lib_%s.npz' % n)))
+        lib = TemplateLibrary(n, gold_lib_dict(n))
         spec_inter.register_library(lib, 'golden://')
     return cfg
 
@@ -359,6 +359,71 @@ def test_ccf_all_templates_vs_oracle(cases, config, gold_libs, gold_config,
     scale = np.abs(ref).max()
     assert np.max(np.abs(got - ref)) < 2e-5 * scale
     assert int(r['best_id'][0].item()) == o['best_id']
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_ccf_nocontinuum(cases, config, gold_libs, gold_config, tag):
+    """config['ccf_continuum_normalize'] = False selects the template set made
+    by `rvs_make_ccf --nocontinuum` (fitter_ccf.py:40-47): no continuum fit and
+    no error / negative-flux masks in preprocess_data (make_ccf.py:370-376),
+    chi^2 = -c0^2 / c1 (fitter_ccf.py:204-207: two inverse transforms per
+    template).  Against the reference's own run (nocont_cases.npz) and the
+    oracle."""
+    from rvspecfit_amd import fitter_ccf, spec_fit, spec_inter, engine
+    nc = dict(np.load(os.path.join(GOLD, 'nocont_cases.npz')))
+    cfg = dict(config, ccf_continuum_normalize=False)
+    ocfg = dict(gold_config, ccf_continuum_normalize=False)
+    sds = _sds(cases, tag)
+    osds = gold_specdata(cases, tag, orc.SpecData)
+    b, _ = spec_fit.as_batch(sds)
+    libs = spec_inter.get_libs(b.names, cfg)
+    for arm in b.arms:
+        assert not libs[arm.name].ccf_set(cfg)['continuum']
+        pre = engine.ccf_preprocess(arm, libs[arm.name], cfg)
+        gps = pre['proc_spec'][0].cpu().numpy()
+        gpi = pre['proc_ivar'][0].cpu().numpy()
+        k = '%s/%s/' % (tag, arm.name)
+        # masks are integer work: identical zero patterns
+        np.testing.assert_array_equal(gpi == 0, nc[k + 'proc_ivar'] == 0)
+        np.testing.assert_array_equal(gps == 0, nc[k + 'proc_spec'] == 0)
+        np.testing.assert_allclose(gps, nc[k + 'proc_spec'], rtol=1e-10,
+                                   atol=1e-11)
+        np.testing.assert_allclose(gpi, nc[k + 'proc_ivar'], rtol=1e-10)
+    r = engine.ccf_fit(b, libs, cfg, keep_all=True)
+    o = orc.ccf_fit(osds, ocfg, gold_libs, details=True)
+    got = r['all_chisqs'][0].cpu().numpy()
+    scale = np.abs(o['all_chisqs']).max()
+    assert np.max(np.abs(got - o['all_chisqs'])) < 2e-5 * scale
+    np.testing.assert_allclose(got.min(axis=1), nc[tag + '/template_min'],
+                               rtol=0, atol=2e-5 * scale)
+    assert int(r['best_id'][0].item()) == int(nc[tag + '/best_id']) == o['best_id']
+    f = fitter_ccf.fit(sds, cfg)
+    np.testing.assert_allclose([f['best_par'][k] for k in
+                                ('teff', 'logg', 'feh', 'alpha')],
+                               nc[tag + '/best_par'])
+    assert abs(f['best_vel'] - float(nc[tag + '/best_vel'])) < RV_ATOL
+    np.testing.assert_allclose(f['best_ccf'], nc[tag + '/best_ccf'], rtol=0,
+                               atol=2e-5 * scale)
+    v = float(nc[tag + '/best_vsini'])
+    assert (f['best_vsini'] is None and np.isnan(v)) or f['best_vsini'] == v
+    for arm in b.arms:
+        np.testing.assert_array_equal(
+            f['best_model'][arm.name], nc['%s/%s/best_model' % (tag, arm.name)])
+    # the default configuration still takes the continuum-normalised set
+    d = fitter_ccf.fit(sds, config)
+    np.testing.assert_allclose(d['best_ccf'], cases[tag + '/ccf/best_ccf'],
+                               rtol=0, atol=2e-5 * np.abs(
+                                   cases[tag + '/ccf/best_ccf']).max())
+
+
+def test_ccf_set_missing_raises(gpu):
+    """a setup converted without its --nocontinuum set: selecting it fails like
+    the reference's missing ccf_nocont_<setup>.h5"""
+    from rvspecfit_amd.library import TemplateLibrary
+    lib = TemplateLibrary('gold_b', np.load(os.path.join(GOLD, 'lib_gold_b.npz')))
+    assert lib.ccf_set({})['continuum']
+    with pytest.raises(RuntimeError):
+        lib.ccf_set(dict(ccf_continuum_normalize=False))
 
 
 @pytest.mark.parametrize('tag', TAGS)

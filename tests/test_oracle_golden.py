@@ -5,7 +5,8 @@ import pytest
 import scipy.interpolate
 
 from oracle import rvs_oracle as orc
-from conftest import gold_specdata
+from conftest import gold_specdata, GOLD
+import os
 
 TAGS = ['c0', 'c1', 'c2', 'c3']
 
@@ -404,3 +405,46 @@ def test_triangulation_oracle(cases):
                                 libs=libs)
         want = float(g['c1/t%d/value' % i])
         assert abs(val - want) < 1e-8 * max(abs(want), 1e3)
+
+
+# --------------------------------------------------------------------------
+# the non-continuum-normalised CCF set (config['ccf_continuum_normalize']=False)
+# --------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def nocont():
+    return dict(np.load(os.path.join(GOLD, 'nocont_cases.npz')))
+
+
+@pytest.mark.parametrize('tag', ['c0', 'c1', 'c2', 'c3'])
+def test_ccf_nocontinuum_oracle_vs_reference(cases, nocont, gold_libs,
+                                             gold_config, tag):
+    """fitter_ccf.py:40-47, 204-207 and the no-continuum branches of
+    preprocess_data (make_ccf.py:370-376) against the reference's own run with
+    an `rvs_make_ccf --nocontinuum` template set"""
+    sds = gold_specdata(cases, tag, orc.SpecData)
+    cfg = dict(gold_config, ccf_continuum_normalize=False)
+    for sd in sds:
+        cc = gold_libs[sd.name].ccf_set(cfg)
+        assert not cc['continuum']
+        ps, pi = orc.preprocess_data(sd.lam, sd.spec, sd.espec, cc,
+                                     badmask=sd.badmask)
+        k = '%s/%s/' % (tag, sd.name)
+        np.testing.assert_allclose(ps, nocont[k + 'proc_spec'], rtol=1e-11,
+                                   atol=1e-11)   # (numpy 1.26 there, 2.2 here)
+        np.testing.assert_allclose(pi, nocont[k + 'proc_ivar'], rtol=1e-11,
+                                   atol=0)
+    o = orc.ccf_fit(sds, cfg, gold_libs, details=True)
+    assert o['best_id'] == int(nocont[tag + '/best_id'])
+    np.testing.assert_allclose(o['all_chisqs'].min(axis=1),
+                               nocont[tag + '/template_min'], rtol=1e-9)
+    np.testing.assert_allclose(o['best_ccf'], nocont[tag + '/best_ccf'],
+                               rtol=1e-9)
+    assert abs(o['best_vel'] - float(nocont[tag + '/best_vel'])) < 1e-6
+    np.testing.assert_allclose(o['best_par'], nocont[tag + '/best_par'])
+    for sd in sds:
+        np.testing.assert_array_equal(o['best_model'][sd.name],
+                                      nocont['%s/%s/best_model' % (tag, sd.name)])
+    # the default (key missing or None) is the continuum-normalised set
+    assert gold_libs[sds[0].name].ccf_set(gold_config)['continuum']
+    assert gold_libs[sds[0].name].ccf_set(
+        dict(gold_config, ccf_continuum_normalize=None))['continuum']

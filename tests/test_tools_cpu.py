@@ -76,14 +76,20 @@ def test_convert_artefacts_reproduces_reference_loader(tmp_path):
                            os.path.join(REPO, 'tools', 'convert_artefacts.py'),
                            str(tmp_path), 'gold_b'], stdout=subprocess.DEVNULL)
     a = np.load(os.path.join(tmp_path, 'rvsgpu_gold_b.npz'))
-    b = np.load(os.path.join(REPO, 'tests', 'golden', 'lib_gold_b.npz'))
-    for k in b.files:
-        x, y = a[k], b[k]
-        assert x.shape == y.shape, k
-        if x.dtype.kind in 'USib':
-            assert np.array_equal(x, y), k
-        else:
-            np.testing.assert_array_equal(x, y, err_msg=k)
+    fixtures = [np.load(os.path.join(REPO, 'tests', 'golden', 'lib_gold_b.npz'))]
+    if os.path.exists(os.path.join(src, 'ccf_nocont_gold_b.h5')):
+        # the --nocontinuum set (make_golden_nocont.py) lands under ccfnc_*
+        fixtures.append(np.load(os.path.join(REPO, 'tests', 'golden',
+                                             'lib_nocont_gold_b.npz')))
+        assert 'ccfnc_fft' in a.files
+    for b in fixtures:
+        for k in b.files:
+            x, y = a[k], b[k]
+            assert x.shape == y.shape, k
+            if x.dtype.kind in 'USib':
+                assert np.array_equal(x, y), k
+            else:
+                np.testing.assert_array_equal(x, y, err_msg=k)
 
 
 def test_lockstep_neldermead_equals_scipy():

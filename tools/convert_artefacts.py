@@ -72,7 +72,7 @@ def load_h5(fname):
         return _h5_to_dict(fp)
 
 
-def convert(tdir, setup, continuum=True):
+def convert(tdir, setup):
     fd = load_h5(os.path.join(tdir, 'interp_%s.h5' % setup))
     out = dict(lam=np.asarray(fd['lam'], dtype=np.float64),
                log_step=np.array(bool(fd['log_step'])),
@@ -119,26 +119,32 @@ def convert(tdir, setup, continuum=True):
         out['log_spec'] = np.array(bool(fd.get('log_spec', True)))
     else:
         raise SystemExit('unknown interpolation_type %s' % itype)
-    pref = '' if continuum else 'nocont_'
-    cinfo = os.path.join(tdir, 'ccf_%s%s.h5' % (pref, setup))
-    if os.path.exists(cinfo):
+    # both CCF template sets of the setup, when present (make_ccf.py:19-36):
+    # ccf_<setup>.h5 ... -> keys ccf_*, ccf_nocont_<setup>.h5 ... -> keys ccfnc_*;
+    # config['ccf_continuum_normalize'] picks one at run time
+    # (fitter_ccf.py:40-47)
+    for pref, key in (('', 'ccf_'), ('nocont_', 'ccfnc_')):
+        cinfo = os.path.join(tdir, 'ccf_%s%s.h5' % (pref, setup))
+        if not os.path.exists(cinfo):
+            continue
         ci = load_h5(cinfo)
         cd = np.load(os.path.join(tdir, 'ccfdat_%s%s.npz' % (pref, setup)))
         cc = ci['ccfconf']
-        out.update(
-            ccf_fft=cd['fft'], ccf_fft2=cd['fft2'],
-            ccf_mod=np.load(os.path.join(tdir, 'ccfmod_%s%s.npy' % (pref, setup))),
-            ccf_params=np.asarray(ci['params'], dtype=np.float64),
-            ccf_vsinis=np.array([np.nan if _ is None else float(_)
-                                 for _ in ci['vsinis']]),
-            ccf_parnames=np.array([str(_) for _ in ci['parnames']]),
-            ccf_logl0=np.array(float(cc['logl0'])),
-            ccf_logl1=np.array(float(cc['logl1'])),
-            ccf_npoints=np.array(int(cc['npoints'])),
-            ccf_continuum=np.array(bool(cc['continuum'])),
-            ccf_maxcontpts=np.array(int(cc.get('maxcontpts', 20))))
+        out.update({
+            key + 'fft': cd['fft'], key + 'fft2': cd['fft2'],
+            key + 'mod': np.load(os.path.join(
+                tdir, 'ccfmod_%s%s.npy' % (pref, setup))),
+            key + 'params': np.asarray(ci['params'], dtype=np.float64),
+            key + 'vsinis': np.array([np.nan if _ is None else float(_)
+                                      for _ in ci['vsinis']]),
+            key + 'parnames': np.array([str(_) for _ in ci['parnames']]),
+            key + 'logl0': np.array(float(cc['logl0'])),
+            key + 'logl1': np.array(float(cc['logl1'])),
+            key + 'npoints': np.array(int(cc['npoints'])),
+            key + 'continuum': np.array(bool(cc['continuum'])),
+            key + 'maxcontpts': np.array(int(cc.get('maxcontpts', 20)))})
         if cc.get('splinestep') is not None:
-            out['ccf_splinestep'] = np.array(float(cc['splinestep']))
+            out[key + 'splinestep'] = np.array(float(cc['splinestep']))
     ofile = os.path.join(tdir, 'rvsgpu_%s.npz' % setup)
     np.savez(ofile, **out)
     return ofile
@@ -169,14 +175,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('template_dir')
     ap.add_argument('setups', nargs='+')
-    ap.add_argument('--nocontinuum', action='store_true')
     ap.add_argument('--nn-weights', action='store_true')
     a = ap.parse_args()
     for s in a.setups:
         if a.nn_weights:
             print(add_nn_weights(a.template_dir, s))
         else:
-            print(convert(a.template_dir, s, continuum=not a.nocontinuum))
+            print(convert(a.template_dir, s))
 
 
 if __name__ == '__main__':

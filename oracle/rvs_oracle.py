@@ -1164,13 +1164,17 @@ def process(specdata, paramDict0, fixParam, options, config, libs,
         tmp['params'] = list(p)
         return 0.5 * chisq0(tmp)
 
+    # vel_fit.py:710-725 with oracle/numdiff_restated.py standing for the
+    # numdifftools package: MinStepGenerator(base_step) first, the default
+    # generator (step=None) if the result is flagged
+    from . import numdiff_restated as ndf
     x = np.array(best['params'], dtype=float)
-    for scale in (1.0, 8.0):
-        h = scale * base * np.maximum(np.log1p(np.abs(x)), 1.0)
-        H = hessian_central(hess_func, x, h)
+    step_gen = ndf.MinStepGenerator(base_step=base)
+    for _ in range(2):
+        H = ndf.Hessian(hess_func, step=step_gen)(x)
         err, covar, bad = uncertainties_from_hessian(H)
-        if not bad:
-            break
+        if bad:
+            step_gen = None
     return dict(param=dict(zip(names, best['params'])), vsini=best['vsini'],
                 vel=bv, vel_err=be, vel_skewness=sk, vel_kurtosis=ku,
                 nm_x=r0['x'], nm_fun=r0['fun'], nm_nit=nits, nm_nfev=nfevs,

@@ -1,0 +1,154 @@
+"""Finite-difference Hessians as vel_fit.process asks numdifftools for them
+(vel_fit.py:699-725), for a whole batch of spectra at once.
+
+The reference calls
+    ndf.Hessian(f, step=ndf.MinStepGenerator(base_step=b))(x)      first try
+    ndf.Hessian(f, step=None)(x)                                   retry
+(numdifftools 0.9.41, 'central' method).  What those calls compute:
+
+* first try: MinStepGenerator's default number of steps for a central Hessian is
+  max((n + order - 1) // 2, 1) + num_extrap = 1, so there is ONE step
+  h = (b * s + 1) - 1 with s = max(log1p|x|, 1) and no extrapolation: the central
+  rule  H_ii = (f(x+2h_i) - 2 f(x) + f(x-2h_i)) / (4 h_i^2),
+        H_ij = (f(++) - f(+-) - f(-+) + f(--)) / (4 h_i h_j).
+* retry: MaxStepGenerator(base_step=None, step_ratio=None): 15 steps
+  h_k = EPS**(1/500) * s * 1.6**-k; the 15 central estimates are Richardson-
+  extrapolated (three consecutive steps, error terms h^2 and h^4), passed once
+  through Wynn's epsilon algorithm, and for every matrix element the estimate with
+  the smallest error bound (after outlier trimming) is taken.
+
+Every function evaluation of every spectrum of a stage goes through ONE batched
+objective call per displacement pattern (`func(idx, points)`), i.e. through
+rvs_chisq_point / rvs_objective_fused on the device; the extrapolation itself is
+a few hundred flops per spectrum and runs on the host, all spectra at once.
+"""
+import numpy as np
+import torch
+from scipy.ndimage import convolve1d
+
+EPS = float(np.finfo(float).eps)
+TINY = float(np.finfo(float).tiny)
+MAX_NUM_STEPS = 15
+MAX_SCALE = 500.
+HESS_STEP_RATIO = 1.6       # numdifftools' default ratio for derivatives of order > 1
+
+
+def nominal_step(x):
+    return torch.clamp(torch.log1p(x.abs()), min=1.0)
+
+
+def first_try_step(base_step, x):
+    """[S, n] the single step of MinStepGenerator(base_step=...) at x [S, n]"""
+    return (base_step[None, :] * nominal_step(x) + 1.0) - 1.0
+
+
+def retry_steps(x):
+    """[15, S, n] the steps of the default generator, largest first"""
+    base = EPS**(1. / MAX_SCALE) * nominal_step(x)
+    k = torch.arange(MAX_NUM_STEPS, dtype=torch.float64, device=x.device)
+    return base[None] * (HESS_STEP_RATIO**(-k))[:, None, None]
+
+
+def hessian_central(func, x, h):
+    """Central second differences of func at x [S, n] with steps h [S, n]:
+    [S, n, n].  func(idx, points) -> [len(idx)] evaluates rows idx."""
+    S, n = x.shape
+    dev = x.device
+    idx = torch.arange(S, device=dev)
+    fx = func(idx, x)
+    H = torch.empty((S, n, n), dtype=torch.float64, device=dev)
+    for i in range(n):
+        ei = torch.zeros_like(x)
+        ei[:, i] = h[:, i]
+        H[:, i, i] = (func(idx, x + 2 * ei) - 2 * fx + func(idx, x - 2 * ei)) / \
+            (4. * h[:, i] * h[:, i])
+        for j in range(i + 1, n):
+            ej = torch.zeros_like(x)
+            ej[:, j] = h[:, j]
+            v = (func(idx, x + ei + ej) - func(idx, x + ei - ej) -
+                 func(idx, x - ei + ej) + func(idx, x - ei - ej)) / \
+                (4. * h[:, i] * h[:, j])
+            H[:, i, j] = v
+            H[:, j, i] = v
+    return H
+
+
+# ---- extrapolation of a sequence of estimates (host, all columns at once) ----
+def _richardson_rule(step_ratio, nterms=2, step=2, order=2):
+    i, j = np.ogrid[0:nterms + 1, 0:nterms]
+    r = np.ones((nterms + 1, nterms + 1))
+    r[:, 1:] = (1.0 / step_ratio)**(i * (step * j + order))
+    return np.linalg.pinv(r)[0]
+
+
+def _richardson(seq, step_ratio):
+    """seq [K, M], K >= 3 -> extrapolated [K-2, M] and error bounds"""
+    K = seq.shape[0]
+    rule = _richardson_rule(step_ratio)
+    m = K - 2
+    new = convolve1d(seq, rule[::-1], axis=0, origin=1)[:m + 1]
+    fact = max(12.7062047361747 * np.sqrt(np.sum(rule**2)), EPS * 10.)
+    err = np.abs(np.diff(new, axis=0)) * fact
+    tol = np.maximum(np.abs(new[1:]), np.abs(new[:-1])) * EPS * fact
+    abserr = err + np.where(err <= tol, tol * 10,
+                            np.abs(new[:-1] - seq[1:m + 1]) * fact)
+    return new[:m], abserr[:m]
+
+
+def _wynn(seq):
+    """one pass of Wynn's epsilon algorithm over consecutive triples"""
+    e0, e1, e2 = seq[:-2], seq[1:-1], seq[2:]
+    with np.errstate(all='ignore'):
+        d2, d1 = e2 - e1, e1 - e0
+        err2, err1 = np.abs(d2), np.abs(d1)
+        tol2 = np.maximum(np.abs(e2), np.abs(e1)) * EPS
+        tol1 = np.maximum(np.abs(e1), np.abs(e0)) * EPS
+        d1 = np.where(err1 < TINY, TINY, d1)
+        d2 = np.where(err2 < TINY, TINY, d2)
+        ss = 1.0 / d2 - 1.0 / d1 + TINY
+        conv = ((err1 <= tol1) & (err2 <= tol2)) | (np.abs(ss * e1) <= 1.0e-3)
+        res = np.where(conv, e2, e1 + 1.0 / ss)
+        abserr = err1 + err2 + np.where(conv, tol2 * 10, np.abs(res - e2))
+    return res, abserr
+
+
+def _outlier_errors(der, trim_fact=10):
+    with np.errstate(all='ignore'):
+        med = np.nanmedian(der, axis=0)
+        p75 = np.nanpercentile(der, 75, axis=0)
+        p25 = np.nanpercentile(der, 25, axis=0)
+        iqr = np.abs(p75 - p25)
+        am = np.abs(med)
+        out = (((np.abs(der) < am / trim_fact) | (np.abs(der) > am * trim_fact))
+               & (am > 1e-8)) | (der < p25 - 1.5 * iqr) | (p75 + 1.5 * iqr < der)
+        return out * np.abs(der - med)
+
+
+def extrapolate(seq, step_ratio=HESS_STEP_RATIO):
+    """seq [K, ...]: K estimates at steps shrinking by step_ratio -> the best
+    extrapolated estimate per trailing element"""
+    shape = seq.shape[1:]
+    s2 = np.asarray(seq, dtype=np.float64).reshape(seq.shape[0], -1)
+    if s2.shape[0] < 3:
+        return s2[-1].reshape(shape)
+    der, err = _richardson(s2, step_ratio)
+    if der.shape[0] > 2:
+        der, err = _wynn(der)
+    err = err + _outlier_errors(der)
+    out = np.empty(der.shape[1])
+    for c in range(der.shape[1]):
+        col = err[:, c]
+        if np.all(np.isnan(col)):
+            out[c] = np.nan      # numdifftools falls back to an arbitrary row
+            continue
+        idx = np.flatnonzero(col == np.nanmin(col))
+        out[c] = der[idx[idx.size // 2], c]
+    return out.reshape(shape)
+
+
+def hessian_retry(func, x):
+    """ndf.Hessian(f)(x) with the default step generator, rows of x [S, n]"""
+    hs = retry_steps(x)
+    seq = torch.stack([hessian_central(func, x, hs[k])
+                       for k in range(hs.shape[0])]).cpu().numpy()
+    return extrapolate(seq)

@@ -13,11 +13,13 @@ import math
 import os
 import threading
 import time
+import types
 
 import numpy as np
 import torch
 
 from . import engine
+from . import numdiff
 from . import spec_fit
 from . import spec_inter
 from .engine import SpecBatch
@@ -365,32 +367,6 @@ class _Objective:
         return torch.where(bad, torch.full_like(ret, 1e30), ret)
 
 
-def _hessian_central(func, x, h):
-    """Central second differences of func at x [S, n] with steps h [S, n]
-    (numdifftools' 'central' Hessian rule, eq. 9 of its documentation:
-    H_ii = (f(x+2h_i) - 2f(x) + f(x-2h_i)) / (4 h_i^2),
-    H_ij = (f(++) - f(+-) - f(-+) + f(--)) / (4 h_i h_j)); one step size."""
-    S, n = x.shape
-    dev = x.device
-    idx = torch.arange(S, device=dev)
-    fx = func(idx, x)
-    H = torch.empty((S, n, n), dtype=torch.float64, device=dev)
-    for i in range(n):
-        ei = torch.zeros_like(x)
-        ei[:, i] = h[:, i]
-        H[:, i, i] = (func(idx, x + 2 * ei) - 2 * fx + func(idx, x - 2 * ei)) / \
-            (4. * h[:, i] * h[:, i])
-        for j in range(i + 1, n):
-            ej = torch.zeros_like(x)
-            ej[:, j] = h[:, j]
-            v = (func(idx, x + ei + ej) - func(idx, x + ei - ej) -
-                 func(idx, x - ei + ej) + func(idx, x - ei - ej)) / \
-                (4. * h[:, i] * h[:, j])
-            H[:, i, j] = v
-            H[:, j, i] = v
-    return H
-
-
 def _as_param_tensors(paramDict0, S, dev):
     out = {}
     for k, v in paramDict0.items():
@@ -402,6 +378,78 @@ def _as_param_tensors(paramDict0, S, dev):
         out[k] = t.expand(S).contiguous() if t.numel() == 1 else t.contiguous()
         assert out[k].shape[0] == S
     return out
+
+
+def _hessian_stage(obj, names, vel, params, vsini):
+    """vel_fit.py:699-725 for S spectra: the Hessian of 0.5 * chisq_func0 in the
+    stellar parameters at (vel, params, vsini), as numdifftools computes it
+    (numdiff.py), and vel_fit._uncertainties_from_hessian per spectrum.
+    First ndf.Hessian(step=MinStepGenerator(base_step)) = the central rule at
+    one step; rows flagged bad are redone with the default step generator
+    (15 steps, Richardson + Wynn extrapolation).  Returns numpy arrays
+    (param_err [S, n], param_covar [S, n, n], bad_hessian [S])."""
+    dev = params.device
+    S = params.shape[0]
+
+    def hess_func(idx, p):   # vel_fit.hess_func (vel_fit.py:257-269)
+        return 0.5 * obj.chisq0(idx, vel[idx], p.contiguous(),
+                                None if vsini is None else vsini[idx])
+
+    base = torch.as_tensor([HESS_BASE_STEP[_] for _ in names],
+                           dtype=torch.float64, device=dev)
+    bad_hessian = np.zeros(S, dtype=bool)
+    diag_err = np.zeros((S, len(names)))
+    covar = np.zeros((S, len(names), len(names)))
+    todo = np.arange(S)
+    for attempt in range(2):
+        if len(todo) == 0:
+            break
+        tt = torch.as_tensor(todo).to(dev)
+        xx = params[tt]
+        fn = lambda i, p: hess_func(tt[i], p)   # noqa: E731
+        if attempt == 0:
+            H = numdiff.hessian_central(fn, xx, numdiff.first_try_step(base, xx)
+                                        ).cpu().numpy()
+        else:
+            H = numdiff.hessian_retry(fn, xx)
+        for k, i in enumerate(todo):
+            diag_err[i], covar[i], bad_hessian[i] = \
+                _uncertainties_from_hessian(H[k])
+        todo = todo[bad_hessian[todo]]
+    return diag_err, covar, bad_hessian
+
+
+def param_uncertainties(specdata, vel, atm_params, vsini=None, options=None,
+                        config=None, resolParams=None, priors=None):
+    """The uncertainty stage of `process` on its own (vel_fit.py:699-725): the
+    finite-difference Hessian of 0.5 chi^2 in the stellar parameters at the given
+    point.  One spectrum (list of SpecData; atm_params a dict or sequence in
+    the interpolator's parameter order): dict(param_err {name: sigma},
+    param_covar, bad_hessian); a SpecBatch with [S] / [S, n] tensors: arrays
+    with a leading S axis."""
+    batch, is_batch = as_batch(specdata)
+    options = options or {}
+    dev = batch.device
+    S = batch.S
+    names = list(spec_inter.getSpecParams(batch.names[0], config))
+    if isinstance(atm_params, dict):
+        atm_params = [atm_params[k] for k in names]
+    pt = torch.as_tensor(np.asarray(
+        atm_params.cpu() if isinstance(atm_params, torch.Tensor) else atm_params,
+        dtype=np.float64)).to(dev).reshape(-1, len(names))
+    pt = pt.expand(S, len(names)).contiguous()
+    pd = _as_param_tensors(dict(vel=vel), S, dev)
+    vs = None
+    if vsini is not None:
+        vs = _as_param_tensors(dict(vsini=vsini), S, dev)['vsini']
+    mapper = types.SimpleNamespace(specParams=names)
+    obj = _Objective(batch, mapper, config, options, priors, resolParams)
+    err, covar, bad = _hessian_stage(obj, names, pd['vel'], pt, vs)
+    if is_batch:
+        return dict(param_err={k: err[:, i] for i, k in enumerate(names)},
+                    param_covar=covar, bad_hessian=bad, status=obj.status)
+    return dict(param_err=dict(zip(names, err[0])), param_covar=covar[0],
+                bad_hessian=bool(bad[0]))
 
 
 # A SpecBatch of at least PROCESS_SPLIT_MIN spectra is fitted as two interleaved
@@ -671,29 +719,8 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     # at the optimiser's velocity (best_param is not updated by the refinement)
     t0 = time.time()
 
-    def hess_func(idx, p):
-        return 0.5 * obj.chisq0(idx, nm_vel[idx], p.contiguous(),
-                                None if bvsini is None else bvsini[idx])
-
-    base = torch.as_tensor([HESS_BASE_STEP[_] for _ in names],
-                           dtype=torch.float64, device=dev)
-    bad_hessian = np.zeros(S, dtype=bool)
-    diag_err = np.zeros((S, len(names)))
-    covar = np.zeros((S, len(names), len(names)))
-    todo = np.arange(S)
-    for attempt in range(2):
-        if len(todo) == 0:
-            break
-        tt = torch.as_tensor(todo).to(dev)
-        xx = bparams[tt]
-        scale = 1.0 if attempt == 0 else 8.0
-        h = scale * base[None, :] * torch.clamp(torch.log1p(xx.abs()), min=1.0)
-        H = _hessian_central(lambda i, p: hess_func(tt[i], p), xx, h
-                             ).cpu().numpy()
-        for k, i in enumerate(todo):
-            diag_err[i], covar[i], bad_hessian[i] = \
-                _uncertainties_from_hessian(H[k])
-        todo = todo[bad_hessian[todo]]
+    diag_err, covar, bad_hessian = _hessian_stage(obj, names, nm_vel, bparams,
+                                                  bvsini)
     _tick('hessian', t0)
 
     ret = {}

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   } else {
     const float *row = T.dats + (int64_t)PL.nearest * N;
     for (int k = tid; k < N; k += OBJ_NT) {
-      const double val = T.exp_flag ? (double)(float)exp((double)row[k])
+      const double val = T.exp_flag ? (double)np_expf(row[k])
                                     : (double)row[k];
       bufA[k] = val;
       if (!(val == val)) anynan = true;

@@ -61,9 +61,8 @@ __global__ void __launch_bounds__(256)
     // FF(self.dats[ret]) on a float32 row: numpy evaluates exp in float32
     const float *row = dats + (int64_t)sh_nearest * ntp;
     for (int k = tid; k < ntp; k += 256) {
-      // float32 result of exp, correctly rounded via float64 (numpy's float32
-      // exp is within 1 ulp of this; ocml expf is not always)
-      const double val = exp_flag ? (double)(float)exp((double)row[k]) : (double)row[k];
+      // numpy's own float32 exp, operation for operation (common.h)
+      const double val = exp_flag ? (double)np_expf(row[k]) : (double)row[k];
       out[k] = val;
       if (!(val == val)) anynan = true;
       mx = fmax(mx, fabs(val));

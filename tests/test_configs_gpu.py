@@ -42,7 +42,8 @@ def _gpu_convolve(dev):
     return f
 
 
-def _compare_with_oracle(bench, arms, rec, ix, workload, evaluator, npix_tot):
+def _compare_with_oracle(bench, arms, rec, ix, workload, evaluator, npix_tot,
+                         chi_rtol):
     from rvspecfit_amd import pipeline
     F = pipeline.RECORD_FIELDS
     dev = rec.device
@@ -60,7 +61,7 @@ def _compare_with_oracle(bench, arms, rec, ix, workload, evaluator, npix_tot):
     # -2 log L passes through zero: relative to max(|chi|, pixel count)
     rel = np.abs(g[:, F.index('best_chi')] - o[:, 4]) / \
         np.maximum(np.abs(o[:, 4]), npix_tot)
-    assert rel.max() < 1e-6, rel
+    assert rel.max() < chi_rtol, rel
     na = len(arms)
     for ia in range(na):   # continuum-only chi^2 per arm
         np.testing.assert_allclose(g[:, F.index('chisq_c%d' % ia)], o[:, 5 + ia],
@@ -101,7 +102,8 @@ def test_config1_1000_spectra_one_arm():
         # a 16-spectrum sample against the oracle
         ix = torch.as_tensor([0, 1, 63, 64, 127, 200, 255, 256, 400, 511, 512,
                               640, 777, 900, 998, 999])
-        _compare_with_oracle(bench, arms, rec, ix, 'cfg2', 'polylinear', 2001)
+        _compare_with_oracle(bench, arms, rec, ix, 'cfg2', 'polylinear', 2001,
+                             chi_rtol=1e-9)
         # position in the batch / batch size do not matter (bit for bit)
         g = torch.Generator(device='cpu')
         g.manual_seed(4)
@@ -137,7 +139,10 @@ def test_config3_nn_evaluator_10000_spectra():
             assert torch.isfinite(rec[:, F.index('best_chi')]).all()
             ix = torch.as_tensor([0, 1234, 2500, 4999, 5000, 7321, 8888, 9999])
             npix_tot = sum(a[2].shape[1] for a in arms)
-            _compare_with_oracle(bench, arms, rec, ix, 'desi', 'nn', npix_tot)
+            # (float32 MLP: the template itself agrees to 3e-6 with the numpy
+            # float32 oracle, MFMA summation order)
+            _compare_with_oracle(bench, arms, rec, ix, 'desi', 'nn', npix_tot,
+                                 chi_rtol=1e-6)
             # a subset of the batch, alone: bit for bit
             sub = torch.arange(4000, 4300, device=dev)
             assert torch.equal(pipeline.fit_batch(batch.subset(sub), cfg,

@@ -20,6 +20,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 S_FULL = 10000
+# the spectra compared with the oracle one by one, and the S/N they are given
+# (the bench generator draws 10-300; the reference's tests/test_fit_fake.py runs
+# at 1000)
+SAMPLE_IX = [0, 1999, 3333, 4242, 6001, 7000, 8765, 9999]
+SAMPLE_SNR = [30., 300., 1000., 1000., 100., 1000., 300., 1000.]
+
+
+def _truth(bench):
+    tp = bench.truth_params(S_FULL, seed=5)
+    tp['snr'][SAMPLE_IX] = SAMPLE_SNR
+    return tp
 
 
 @pytest.fixture(scope='module')
@@ -37,7 +48,7 @@ def full():
     for name, d in bench.build_library_dicts(64, gpu_convolve).items():
         spec_inter.register_library(TemplateLibrary(name, d, device=dev),
                                     bench.CONFIG['template_lib'])
-    arms = bench.make_spectra_device(bench.truth_params(S_FULL, seed=5), dev)
+    arms = bench.make_spectra_device(_truth(bench), dev)
     batch = engine.SpecBatch([engine.ArmData(n, lam, sp, es, bad, device=dev)
                               for n, lam, sp, es, bad in arms])
     rec = pipeline.fit_batch(batch, bench.CONFIG, options=bench.OPTIONS)
@@ -61,7 +72,7 @@ def test_full_size_run_is_sane(full):
     assert np.isfinite(rec[:, F.index('best_vel')]).all()
     assert np.isfinite(rec[:, F.index('best_chi')]).all()
     # the synthetic truth: velocities ~ N(0, 100) km/s recovered at S/N >= 10
-    tp = full['bench'].truth_params(S_FULL, seed=5)
+    tp = _truth(full['bench'])
     dv = rec[:, F.index('best_vel')] - tp['vel']
     assert np.median(np.abs(dv)) < 3.0
     assert (rec[:, F.index('status')] == 0).mean() > 0.99
@@ -110,23 +121,26 @@ def test_flux_scale(full):
 def test_sample_against_oracle(full):
     from rvspecfit_amd import pipeline
     F = pipeline.RECORD_FIELDS
-    # 6 spectra spread over the batch
-    ix = torch.as_tensor([0, 1999, 4242, 6001, 8765, 9999])
+    # 8 spectra spread over the batch, S/N 30 ... 1000
+    ix = torch.as_tensor(SAMPLE_IX)
     arms = [(nm, lam, sp[ix.to(sp.device)], es[ix.to(sp.device)],
              bad[ix.to(sp.device)]) for nm, lam, sp, es, bad in full['arms']]
-    args = argparse.Namespace(ccf_every=64, cpu_cores=6, workload='desi',
+    args = argparse.Namespace(ccf_every=64, cpu_cores=8, workload='desi',
                               evaluator='polylinear')
     cb = full['bench'].run_cpu_baseline(arms, len(ix), args)
     o = np.array(cb['recs'])
     g = full['rec'][ix.to(full['dev'])].cpu().numpy()
     assert np.array_equal(g[:, F.index('best_id')], o[:, 0])       # index work
     assert np.abs(g[:, F.index('vrad_ccf')] - o[:, 1]).max() < 1e-2  # km/s
-    assert np.abs(g[:, F.index('best_vel')] - o[:, 2]).max() < 1e-2
+    assert np.abs(g[:, F.index('best_vel')] - o[:, 2]).max() < 1e-3
     npix_tot = sum(a[2].shape[1] for a in full['arms'])
-    # -2 log L passes through zero: relative to max(|chi|, pixel count)
+    # -2 log L passes through zero: relative to max(|chi|, pixel count).
+    # tests/test_chisq_accuracy.py: the device's D.D - y.y form is within 4e-10
+    # of the extended-precision value at S/N 1000, the oracle within 1e-15;
+    # nearest-neighbour templates are numpy's float32 exp bit for bit
     rel = np.abs(g[:, F.index('best_chi')] - o[:, 4]) / \
         np.maximum(np.abs(o[:, 4]), npix_tot)
-    assert rel.max() < 1e-6
+    assert rel.max() < 1e-9, rel
 
 
 def _check_invariance(fit, batch, S, dev):

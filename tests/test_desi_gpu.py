@@ -17,7 +17,7 @@ CFG = dict(template_lib='golden-desi://', min_vel=-1000, max_vel=1000,
            second_minimizer=True, config_file_path='/x/config.yaml',
            lsf_sigma0_angstrom=SIG0)
 # not pinned by the real numdifftools (make_golden_desi.py header)
-UNPINNED = ('LOGG_ERR', 'TEFF_ERR', 'FEH_ERR', 'ALPHAFE_ERR')
+ERR_COLS = ('LOGG_ERR', 'TEFF_ERR', 'FEH_ERR', 'ALPHAFE_ERR')
 
 
 @pytest.fixture(scope='module')
@@ -106,8 +106,14 @@ def test_proc_desi_against_reference(dcases, desi_libs, tmp_path, tag):
                 np.array_equal(a, b, equal_nan=True), c
         elif c in ('RVS_WARN', 'SUCCESS'):
             continue
-        elif c in UNPINNED:
+        elif c in ERR_COLS:
+            # numdifftools' Hessian as restated (numdiff.py), at this run's own
+            # optimum: where that is the reference's, finite differences of a
+            # 1e-9-noisy function agree to a few per cent (at the reference's
+            # own end point: 1e-3, test_param_uncertainties_at_reference_optimum)
             assert np.array_equal(np.isnan(a), np.isnan(b)), c
+            ok = same & np.isfinite(b) & (b > 0)
+            assert np.allclose(a[ok], b[ok], rtol=5e-2), c
         elif c.startswith('CHISQ_C'):
             assert np.allclose(a, b, rtol=1e-9, atol=0, equal_nan=True), c
         elif c in ('VRAD', 'VRAD_CCF'):
@@ -121,8 +127,8 @@ def test_proc_desi_against_reference(dcases, desi_libs, tmp_path, tag):
         else:  # VSINI, LOGG, TEFF, FEH, ALPHAFE: where the optimum is the same
             scale = dict(TEFF=1.0, VSINI=0.05).get(c, 2e-3)
             assert np.nanmax(np.abs(a[same] - b[same])) <= scale, c
-    # the warning bits: identical apart from the unpinned BAD_HESSIAN bit on
-    # fibres that ended in a different optimum
+    # the warning bits: identical, BAD_HESSIAN included, where the optimiser
+    # ended in the reference's optimum; elsewhere every bit but that one
     bh = D.bitmasks['BAD_HESSIAN']
     w, w_ref = tab['RVS_WARN'], ref['RVS_WARN']
     assert np.array_equal(w[same], w_ref[same])

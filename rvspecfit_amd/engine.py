@@ -608,7 +608,9 @@ def can_fuse_objective(batch, libs, resols=None, fast_interp=False, npoly=10):
     return True
 
 
-FUSED_OBJECTIVE = _os.environ.get('RVS_FUSED_OBJECTIVE', '1') != '0'
+# False: the chain of stand-alone kernels also for regular-grid libraries
+# (tests/test_gpu_parity.py::test_objective_fused compares the two)
+FUSED_OBJECTIVE = True
 
 
 def objective_fused(batch, libs, params, vsini, vel, npoly=5, rbf=True,

@@ -152,16 +152,21 @@ class TemplateLibrary:
         return cls(name, np.load(path, allow_pickle=False), device=device)
 
     # -- A3 / A4 : template evaluation for a batch of parameter vectors ------
-    def eval_batch(self, params, details=False):
-        """params float64 [J, ndim] (device) -> templ [J, ntp], outside [J]"""
+    def eval_batch(self, params, details=False, mapped=False):
+        """params float64 [J, ndim] (device) -> templ [J, ntp], outside [J].
+        mapped=True: `params` are already what the setup's parameter mapper
+        returns (LogParamMapper.forward, read_grid.py:127-145; nn Mapper.forward,
+        nn/NNInterpolator.py:159-171) -- the contract of the reference's
+        evaluator classes (spec_inter.py:257-286), used by plugin.py."""
         L = _lib.lib()
         J = params.shape[0]
         params = params.to(torch.float64).contiguous()
+        log_mask = 0 if mapped else self.log_mask
         templ = torch.empty((J, self.ntp), dtype=torch.float64,
                             device=self.device)
         outside = torch.empty(J, dtype=torch.float64, device=self.device)
         if self.kind == 'nn':
-            return self._eval_nn(params, templ, outside)
+            return self._eval_nn(params, templ, outside, mapped)
         if self.kind == 'triangulation':
             sx = torch.empty(J, dtype=torch.int32, device=self.device)
             wts = torch.zeros((J, self.ndim + 1), dtype=torch.float64,
@@ -169,7 +174,7 @@ class TemplateLibrary:
             rc = L.rvs_template_tri(
                 _lib.ptr(self.dats), self.ntp, _lib.ptr(self.tri_simplices),
                 _lib.ptr(self.tri_transform), _lib.ptr(self.tri_extraflags),
-                self.tri_nsimplex, self.ndim, self.log_mask, self.exp_flag,
+                self.tri_nsimplex, self.ndim, log_mask, self.exp_flag,
                 _lib.ptr(params), J, _lib.ptr(templ), _lib.ptr(outside),
                 _lib.ptr(sx), _lib.ptr(wts), _lib.stream())
             _lib.check(rc, 'rvs_template_tri')
@@ -185,7 +190,7 @@ class TemplateLibrary:
         rc = L.rvs_template_polylinear(
             _lib.ptr(self.dats), self.ngrid, self.ntp, _lib.ptr(self.idgrid),
             _lib.ptr(self.uvecs), _lib.ptr(self.lens), self.ndim,
-            _lib.ptr(self.vecs_s), _lib.ptr(self.inv_ptp), self.log_mask,
+            _lib.ptr(self.vecs_s), _lib.ptr(self.inv_ptp), log_mask,
             self.exp_flag, _lib.ptr(params), J, _lib.ptr(templ),
             _lib.ptr(outside), _lib.ptr(cell), _lib.ptr(wts), _lib.stream())
         _lib.check(rc, 'rvs_template_polylinear')
@@ -218,7 +223,7 @@ class TemplateLibrary:
         else:
             raise NotImplementedError(self.kind)
 
-    def _eval_nn(self, params, templ, outside):
+    def _eval_nn(self, params, templ, outside, mapped=False):
         import ctypes
         L = _lib.lib()
         J = params.shape[0]
@@ -230,17 +235,23 @@ class TemplateLibrary:
         bp = (ctypes.c_void_p * nl)(*[b.data_ptr() for b in self.nn_b])
         from . import engine
         with engine._ktime('template_nn', J):
-            rc = L.rvs_template_nn(_lib.ptr(params), J, self.ndim, self.log_mask,
-                                   _lib.ptr(self.nn_M), _lib.ptr(self.nn_S), nl,
+            if mapped:   # Mapper.forward already applied: identity here
+                M = torch.zeros_like(self.nn_M)
+                Sc = torch.ones_like(self.nn_S)
+            else:
+                M, Sc = self.nn_M, self.nn_S
+            rc = L.rvs_template_nn(_lib.ptr(params), J, self.ndim,
+                                   0 if mapped else self.log_mask,
+                                   _lib.ptr(M), _lib.ptr(Sc), nl,
                                    ctypes.cast(Wp, ctypes.c_void_p),
                                    ctypes.cast(bp, ctypes.c_void_p),
                                    _lib.ptr(self.nn_dims), _lib.ptr(a0),
                                    _lib.ptr(a1), _lib.ptr(templ), _lib.stream())
         _lib.check(rc, 'rvs_template_nn')
-        outside.copy_(self._nn_outside(params))
+        outside.copy_(self._nn_outside(params, mapped))
         return templ, outside
 
-    def _nn_outside(self, params):
+    def _nn_outside(self, params, mapped=False):
         """OutsideInterpolator.__call__ (nn/RVSInterpolator.py:63-71) on the
         Mapper-transformed point, as SpecInterpolator.outsideFlag does
         (spec_inter.py:257-272): squared positive distance to the facets of two
@@ -249,10 +260,13 @@ class TemplateLibrary:
         if self.nn_hull is None:
             return torch.zeros(params.shape[0], dtype=torch.float64,
                                device=self.device)
-        y = params.to(torch.float32).clone()   # Mapper.forward: float32 input
-        for i in self.log_ids:
-            y[:, i] = torch.log10(y[:, i])
-        p = (y.double() - self.nn_M) / self.nn_S
+        if mapped:
+            p = params.double()
+        else:
+            y = params.to(torch.float32).clone()   # Mapper.forward: float32 input
+            for i in self.log_ids:
+                y[:, i] = torch.log10(y[:, i])
+            p = (y.double() - self.nn_M) / self.nn_S
         xe = torch.as_tensor(self.nn_hull[0], device=self.device)
         ye = torch.as_tensor(self.nn_hull[1], device=self.device)
         dx = (p[:, :2] @ xe[:, :-1].T + xe[:, -1]).max(dim=1).values

@@ -26,7 +26,6 @@ def _p(t):
 
 class ProcessObjective:
     """chisq_func for rows (list[j], X[j]) on preallocated buffers."""
-    graph_safe = True   # eval() is a fixed, allocation-free launch sequence
 
     def __init__(self, batch, libs, names, pd0, fixParam, fitVsini, config,
                  options, priors, safe_params, resols=None):
@@ -225,14 +224,14 @@ class ProcessObjective:
         self.jobs += J
 
 
-import os as _os
-# RVS_NM_NATIVE=0: the rounds driven from Python (one_round below) instead of
-# rvs_nm_run
-NATIVE_ROUNDS = _os.environ.get('RVS_NM_NATIVE', '1') != '0'
-# RVS_NM_GRAPH=1: replay each round from a HIP graph.  Measured: same wall time
-# (3.1 s per 2000 spectra either way) -- the rounds are bound by the GPU-side
-# chain of ~25 small dependent kernels, not by host launches -- so it is off.
-USE_GRAPHS = _os.environ.get('RVS_NM_GRAPH', '0') == '1'
+# False: the rounds of a fused objective are driven from Python (one_round below,
+# the loop every non-fused objective takes anyway) instead of rvs_nm_run; the
+# two give the same simplices bit for bit
+# (tests/test_gpu_parity.py::test_nm_round_drivers_agree).
+# (Replaying the rounds from HIP graphs was measured in round 1: same wall time --
+# the rounds are bound by the GPU-side chain of small dependent kernels, not by
+# host launches -- and removed.)
+NATIVE_ROUNDS = True
 
 
 class DeviceNelderMead:
@@ -261,7 +260,6 @@ class DeviceNelderMead:
         from .neldermead import _order
         L = _lib.lib()
         S, N = self.S, self.N
-        sync_every = int(_os.environ.get('RVS_NM_SYNC', sync_every))
         sim = simplex.clone().to(torch.float64).contiguous()
         allidx = torch.arange(S, dtype=torch.int32, device=self.dev)
         for k in range(N + 1):
@@ -320,13 +318,8 @@ class DeviceNelderMead:
                                  _p(self.counts), jb, st)
             _lib.check(rc, 'rvs_nm_update')
 
-        # A round is a fixed launch sequence for a given bound, so it is captured
-        # once per bound into a HIP graph and replayed: one host call per round
-        # instead of ~55.  Bounds are quantised (1/8 steps of a power of two) so
-        # that a handful of graphs serve the whole run.
-        use_graph = USE_GRAPHS and getattr(objective, 'graph_safe', False)
-        graphs = {}
-
+        # launch bounds are quantised (1/8 steps of a power of two) so that a
+        # handful of launch shapes serve the whole run
         def bucket(n):
             if n <= 64:
                 return min(S, 64)
@@ -356,21 +349,9 @@ class DeviceNelderMead:
             if live == 0:
                 break
             jb = bucket(live)
-            if use_graph:
-                if jb not in graphs:
-                    one_round(jb)       # warm-up (and a real round)
-                    rounds += 1
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        one_round(jb)
-                    graphs[jb] = g
-                for _ in range(sync_every):
-                    graphs[jb].replay()
-                rounds += sync_every
-            else:
-                for _ in range(sync_every):
-                    one_round(jb)
-                rounds += sync_every
+            for _ in range(sync_every):
+                one_round(jb)
+            rounds += sync_every
         if stats is not None:
             stats['rounds'] = stats.get('rounds', 0) + rounds
         success = (self.flags & 2) != 0

@@ -291,7 +291,10 @@ def _uncertainties_from_hessian(hessian):
 
 # vel_fit.py:653-658 second_minimizer (BFGS, bfgs.py) when the config asks for it
 RUN_SECOND_MINIMIZER = True
-BFGS_IMPL = os.environ.get('RVS_BFGS', 'native')
+# 'native': C++ coroutines (csrc/bfgs_host.cpp); 'python': the generator version
+# of the same algorithm, the one the CPU suite pins to scipy itself
+# (tests/test_gpu_parity.py::test_process_bfgs_implementations_agree)
+BFGS_IMPL = 'native'
 
 # lock-step simplices driven by the rvs_nm_* kernels (optimizer.py); False = the
 # pure-torch state machine of neldermead.py (same path, ~3x slower)
@@ -456,9 +459,9 @@ def param_uncertainties(specdata, vel, atm_params, vsini=None, options=None,
 # halves by two host threads on two HIP streams: the optimiser's rounds run in C
 # (rvs_nm_run, no interpreter lock), so while one half is in the latency-bound
 # tail of its rounds the other's kernels fill the CUs.  Results are those of the
-# unsplit run, bit for bit (no spectrum sees another).  RVS_PROCESS_STREAMS=1
-# switches it off.
-PROCESS_STREAMS = int(os.environ.get('RVS_PROCESS_STREAMS', '2'))
+# unsplit run, bit for bit (no spectrum sees another;
+# test_process_two_halves_equal_one_batch).  1 switches it off.
+PROCESS_STREAMS = 2
 PROCESS_SPLIT_MIN = 256
 
 

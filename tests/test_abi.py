@@ -108,3 +108,75 @@ def test_struct_layouts_match_the_header(tmp_path):
         for f in cls._fields_:
             assert int(got['%s.%s' % (cname, f[0])]) == \
                 getattr(cls, f[0]).offset, (cname, f[0])
+
+
+def _c_prototypes(text):
+    """{name: [parameter declarations]} of every `int rvs_*(...)` / `int64_t
+    rvs_*(...)` prototype in a C text (comments removed)"""
+    import re
+    text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(?:int|int64_t)\s+(rvs_\w+)\s*\(([^;{]*?)\)\s*;',
+                         text, flags=re.S):
+        args = [' '.join(a.split()) for a in m.group(2).split(',')]
+        out[m.group(1)] = [] if args == ['void'] else args
+    return out
+
+
+def _norm_type(decl):
+    """parameter declaration -> type without the name: 'const double *lam' ->
+    'const double*'"""
+    import re
+    decl = decl.replace('*', ' * ')
+    toks = decl.split()
+    if toks[-1] != '*' and len(toks) > 1:
+        toks = toks[:-1]          # drop the parameter name
+    return re.sub(r'\s*\*', '*', ' '.join(toks))
+
+
+def test_integration_md_prototypes_match_the_header():
+    """every C prototype and every ctypes `argtypes` list quoted in
+    INTEGRATION.md is the header's (arity and types): a maintainer binds from
+    that file"""
+    import ctypes
+    import re
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(repo, 'INTEGRATION.md')).read()
+    hdr = _c_prototypes(open(os.path.join(repo, 'include', 'rvsgpu.h')).read())
+    blocks = re.findall(r'```c\n(.*?)```', doc, flags=re.S)
+    quoted = {}
+    for b in blocks:
+        quoted.update(_c_prototypes(b))
+    assert {'rvs_spline_construct', 'rvs_spline_eval', 'rvs_chisq_grid'} <= set(quoted)
+    for name, args in quoted.items():
+        assert name in hdr, name
+        assert [_norm_type(a) for a in args] == [_norm_type(a) for a in hdr[name]], name
+    # python snippets: L.rvs_x.argtypes = [...]
+    P, I = ctypes.c_void_p, ctypes.c_int   # noqa: F841 (names used by eval)
+    kinds = {ctypes.c_void_p: 'ptr', ctypes.c_int: 'int', ctypes.c_int64: 'i64',
+             ctypes.c_double: 'f64', ctypes.c_uint32: 'u32'}
+    n = 0
+    for m in re.finditer(r'L\.(rvs_\w+)\.argtypes\s*=\s*(\[.*?\])', doc):
+        name, lst = m.group(1), eval(m.group(2))
+        want = []
+        for a in hdr[name]:
+            t = _norm_type(a)
+            want.append('ptr' if t.endswith('*') else
+                        {'int': 'int', 'int64_t': 'i64', 'double': 'f64',
+                         'uint32_t': 'u32'}[t])
+        assert [kinds[t] for t in lst] == want, name
+        n += 1
+    assert n >= 2
+    # the calls in the snippets pass as many arguments as the prototype has
+    for m in re.finditer(r'L\.(rvs_\w+)\(([^;]*?)\)\n(?:assert|ret|status|rc)',
+                         doc, flags=re.S):
+        name = m.group(1)
+        depth, nargs, cur = 0, 1, ''
+        for ch in re.sub(r'#.*', '', m.group(2)):
+            if ch in '([':
+                depth += 1
+            elif ch in ')]':
+                depth -= 1
+            elif ch == ',' and depth == 0:
+                nargs += 1
+        assert nargs == len(hdr[name]), (name, nargs, len(hdr[name]))

@@ -1065,6 +1065,74 @@ def test_fit_fake(cases, config, kind, snr, feh0):
         assert len(res['yfit'][0]) == len(lam)
 
 
+def test_nm_round_drivers_agree(cases, config):
+    """the Nelder-Mead rounds of a fused objective driven from C (rvs_nm_run,
+    the default) and from Python (optimizer.NATIVE_ROUNDS = False, the loop every
+    non-fused objective takes): same launches in the same order, so the same
+    simplices bit for bit"""
+    from rvspecfit_amd import optimizer, vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    rng = np.random.RandomState(5)
+    S = 40
+    lists = [_sds(cases, ('c1', 'c3')[i % 2]) for i in range(S)]
+    batch = SpecBatch.from_specdata(lists)
+    for a in batch.arms:
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.02 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pd0 = dict(teff=rng.uniform(5000, 6800, S), logg=rng.uniform(1.5, 4.5, S),
+               feh=rng.uniform(-1.5, -0.1, S), alpha=rng.uniform(0, 0.4, S),
+               vsini=rng.uniform(1, 60, S))
+    out = []
+    for native in (True, False):
+        optimizer.NATIVE_ROUNDS = native
+        try:
+            out.append(vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                       config=dict(config)))
+        finally:
+            optimizer.NATIVE_ROUNDS = True
+    a, b = out
+    for k in ('vel', 'chisq', 'vsini', 'nm_nit', 'nm_nfev', 'nm_vel'):
+        assert torch.equal(a[k], b[k]), k
+    for k in ('teff', 'logg', 'feh', 'alpha'):
+        assert torch.equal(a['param'][k], b['param'][k]), k
+        np.testing.assert_array_equal(a['param_err'][k], b['param_err'][k])
+
+
+def test_process_bfgs_implementations_agree(cases, config):
+    """second_minimizer through the C++ coroutines (default) and through the
+    Python generators that the CPU suite pins to scipy (vel_fit.BFGS_IMPL): the
+    real objective is noisy at the gradient step, so the two follow each other to
+    rounding, not to the bit -- same exit statistics, chi^2 and parameters well
+    inside the optimiser's tolerances"""
+    from rvspecfit_amd import vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    rng = np.random.RandomState(6)
+    S = 24
+    lists = [_sds(cases, ('c1', 'c3')[i % 2]) for i in range(S)]
+    batch = SpecBatch.from_specdata(lists)
+    for a in batch.arms:
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.02 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pd0 = dict(teff=rng.uniform(5000, 6800, S), logg=rng.uniform(1.5, 4.5, S),
+               feh=rng.uniform(-1.5, -0.1, S), alpha=rng.uniform(0, 0.4, S),
+               vsini=rng.uniform(1, 60, S))
+    cfg = dict(config, second_minimizer=True)
+    out = {}
+    for impl in ('native', 'python'):
+        vel_fit.BFGS_IMPL = impl
+        try:
+            out[impl] = vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                        config=cfg)
+        finally:
+            vel_fit.BFGS_IMPL = 'native'
+    a, b = out['native'], out['python']
+    assert a['second_minimizer_run'] and b['second_minimizer_run']
+    assert torch.equal(a['nm_nit'], b['nm_nit'])      # same simplex stage
+    assert (a['chisq'] - b['chisq']).abs().max().item() < 2e-3    # fatol level
+    assert (a['vel'] - b['vel']).abs().max().item() < 1e-2
+    assert abs(np.mean(a['bfgs']['nfev']) / np.mean(b['bfgs']['nfev']) - 1) < 0.5
+
+
 def test_process_second_minimizer(cases, pcases, config):
     """config second_minimizer=True (the reference default): BFGS from the
     simplex optimum.  The reference's own BFGS (golden p4; scipy 1.7 there,

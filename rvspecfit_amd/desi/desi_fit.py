@@ -1177,6 +1177,24 @@ def proc_desi_wrapper(*args, **kwargs):
                                        t2 - t1)
 
 
+def _select_rank_device(environ=None):
+    """One process per GPU: under torch.distributed.run every rank -- and every
+    worker process a rank spawns, which inherits its environment -- fits on the
+    GPU LOCAL_RANK names, whatever file shard it was given.  Returns the index
+    selected (None: no launcher, the current device stays)."""
+    environ = os.environ if environ is None else environ
+    lr = environ.get('LOCAL_RANK')
+    if lr is None:
+        return None
+    import torch
+    idx = int(lr)
+    n = torch.cuda.device_count()
+    if n > 0:
+        idx %= n
+    torch.cuda.set_device(idx)
+    return idx
+
+
 def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
               figure_dir=None, figure_prefix=None, config_fname=None,
               nthreads=1, fit_targetid=None, objtypes=None, minsn=-1e9,
@@ -1207,15 +1225,18 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
         shard = (int(os.environ.get('RANK', 0)),
                  int(os.environ.get('WORLD_SIZE', 1)))
     rank, world = shard
-    if world > 1 and 'LOCAL_RANK' in os.environ:
-        import torch
-        torch.cuda.set_device(int(os.environ['LOCAL_RANK']))
+    workers = nthreads is not None and nthreads > 1
+    if not workers:
+        # the process that fits selects its GPU; with worker processes the
+        # parent only waits for them and never touches a GPU, and every worker
+        # (shard (0, 1), environment inherited) comes through here itself
+        _select_rank_device()
     if process_status_file is not None:
         if world > 1:
             process_status_file = '%s.%d' % (process_status_file, rank)
         update_process_status_file(process_status_file, None, None, None, None,
                                    start=True)
-    if nthreads is not None and nthreads > 1:
+    if workers:
         import multiprocessing
         mine = list(files)[rank::world]
         ctx = multiprocessing.get_context('spawn')

@@ -75,7 +75,7 @@ def firstguess(specdata, options=None, config=None, resolParams=None,
 
 
 def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
-                           crit_ratio=5, goal_width=10, max_points=2048,
+                           crit_ratio=5, goal_width=10, grid_budget=1 << 24,
                            resolParams=None, keep_grids=False):
     """Batched _minimum_sampler (vel_fit.py:358-439): every spectrum carries
     its own (min_vel, max_vel, step) state; per round all spectra that are not
@@ -110,28 +110,46 @@ def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
         start = np.ceil((min_vel[idx] - bv_) / st_) * st_
         stop = max_vel[idx] - bv_
         nv = np.maximum(np.ceil((stop - start) / st_), 0).astype(np.int64)
-        nmax = int(nv.max())
-        if nmax > max_points:
-            raise RuntimeError('velocity grid too long')
-        ii = np.arange(nmax, dtype=np.float64)
-        vg = (start[:, None] + ii[None, :] * st_[:, None]) + bv_[:, None]
-        last = vg[np.arange(len(idx)), np.maximum(nv - 1, 0)]
-        vg = np.where(ii[None, :] < nv[:, None], vg, last[:, None])  # padding
-        if keep_grids:
-            for k, i in enumerate(idx):
-                all_grids[i].append(vg[k, :nv[k]].copy())
-        vgt = torch.as_tensor(vg).to(dev)
-        idt = torch.as_tensor(idx).to(dev)
-        p = params[idt][:, None, :].contiguous()
-        vs = None if vsini is None else vsini[idt]
-        chisq, status, _ = spec_fit.chisq_grid_jobs(
-            batch, vgt, p, vs, options, config, resol_params=resolParams,
-            spec_idx=None if len(idx) == S else idt)
-        res, _, _ = engine.grid_moments(chisq.reshape(len(idx), -1), vgt, Np=1,
-                                        nvel=torch.as_tensor(
-                                            nv.astype(np.int32)).to(dev))
-        r = res.cpu().numpy()
+        # the reference accepts any grid length ((max_vel - min_vel) / vel_step0
+        # is the user's choice): long grids are evaluated for fewer spectra at a
+        # time, so that a launch set holds at most grid_budget velocities
+        r = np.empty((len(idx), 8))
+        rows = max(1, int(grid_budget // max(int(nv.max()), 1)))
+        for a in range(0, len(idx), rows):
+            sl = slice(a, a + rows)
+            nvc = nv[sl]
+            nmax = max(int(nvc.max()), 1)
+            ii = np.arange(nmax, dtype=np.float64)
+            vg = (start[sl, None] + ii[None, :] * st_[sl, None]) + bv_[sl, None]
+            last = vg[np.arange(len(nvc)), np.maximum(nvc - 1, 0)]
+            vg = np.where(ii[None, :] < nvc[:, None], vg, last[:, None])  # padding
+            if keep_grids:
+                for k, i in enumerate(idx[sl]):
+                    all_grids[i].append(vg[k, :nvc[k]].copy())
+            vgt = torch.as_tensor(vg).to(dev)
+            idt = torch.as_tensor(idx[sl]).to(dev)
+            p = params[idt][:, None, :].contiguous()
+            vs = None if vsini is None else vsini[idt]
+            chisq, status, _ = spec_fit.chisq_grid_jobs(
+                batch, vgt, p, vs, options, config, resol_params=resolParams,
+                spec_idx=None if len(idx[sl]) == S else idt)
+            res, _, _ = engine.grid_moments(
+                chisq.reshape(len(nvc), -1), vgt, Np=1,
+                nvel=torch.as_tensor(nvc.astype(np.int32)).to(dev))
+            r[sl] = res.cpu().numpy()
         bv[idx], err[idx], kur[idx], skw[idx] = r[:, 1], r[:, 2], r[:, 3], r[:, 4]
+        # a spectrum whose grid has no finite minimum (every chi^2 non finite,
+        # an empty grid) leaves the loop with NaN results instead of steering
+        # the next grid of the whole batch with them
+        lost = ~(np.isfinite(bv[idx]) & np.isfinite(err[idx])) | (nv < 1)
+        if lost.any():
+            for arr in (bv, err, kur, skw):
+                arr[idx[lost]] = np.nan
+            active[idx[lost]] = False
+            keep = ~lost
+            idx, st_, nv = idx[keep], st_[keep], nv[keep]
+            if len(idx) == 0:
+                continue
         ngrids[idx] += 1
         ngrid_pts[idx] += nv
         e_ = err[idx]

@@ -336,6 +336,47 @@ def test_proc_many_status_file(tmp_path):
     assert len(rows) == 1 and rows[0].split()[1] == 'EXISTING'
 
 
+def test_proc_many_device_selection(tmp_path, monkeypatch):
+    """one process per GPU: the fitting process takes the GPU LOCAL_RANK names
+    whatever its file shard is -- the worker processes of `nthreads` run with
+    shard (0, 1) and must not all land on GPU 0 --, and a parent that only
+    waits for its workers never selects (touches) a GPU"""
+    import torch
+    import yaml
+    calls = []
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda i: calls.append(i))
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    assert D._select_rank_device({}) is None and calls == []
+    assert D._select_rank_device(dict(LOCAL_RANK='5')) == 5 and calls == [5]
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 4)
+    assert D._select_rank_device(dict(LOCAL_RANK='5')) == 1   # wraps
+    del calls[:]
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    cfgf = str(tmp_path / 'c.yaml')
+    with open(cfgf, 'w') as fp:
+        yaml.safe_dump(dict(template_lib='golden-desi://'), fp)
+    kw = dict(config_fname=cfgf, minsn=1e9, doplot=False, subdirs=False)
+    # a worker as proc_many spawns it: shard (0, 1), the rank's environment
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    monkeypatch.setenv('RANK', '3')
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    D.proc_many([], str(tmp_path), 'rvtab', 'rvmod', shard=(0, 1), nthreads=1,
+                **kw)
+    assert calls == [3]
+    # a rank of the launcher
+    del calls[:]
+    D.proc_many([], str(tmp_path), 'rvtab', 'rvmod', **kw)
+    assert calls == [3]
+    # the parent of worker processes: no device selected here
+    del calls[:]
+    D.proc_many([], str(tmp_path), 'rvtab', 'rvmod', nthreads=2, **kw)
+    assert calls == []
+    # no launcher: the current device stays
+    monkeypatch.delenv('LOCAL_RANK')
+    D.proc_many([], str(tmp_path), 'rvtab', 'rvmod', shard=(0, 1), **kw)
+    assert calls == []
+
+
 def test_select_expid_range_and_id_matched_redshifts(coadd, tmp_path):
     """spectra- files: the EXPID window (desi_fit.py:590-597; open ends, and no
     window at all -- where the reference trips over an unset variable -- select

@@ -196,3 +196,47 @@ def test_process_case_vs_oracle(setup, presults, name):
         assert abs(g - o['param'][p]) < max(tol, 1e-9), (name, p)
     nit = int(np.sum(o['nm_nit']))
     assert abs(int(r['nm_nit'][k]) - nit) <= 0.02 * nit, (name, 'nit')
+
+
+def test_refinement_survives_lost_rows_and_long_grids(setup):
+    """_minimum_sampler for a batch (vel_fit.py:358-439): a spectrum whose
+    velocity grid has no finite chi^2 gets NaN results and does not steer (or
+    fail) the others; a grid longer than one launch set is evaluated in row
+    chunks and gives the same numbers as the single set"""
+    from rvspecfit_amd import vel_fit
+    b = setup['bench']
+    batch, dev, F = setup['batch'], setup['dev'], setup['F']
+    rec = setup['rec']
+    n = NCLEAN
+    sub = batch.subset(torch.arange(n, device=dev))
+    par = rec[:n, F.index('p0'):F.index('p0') + 4].contiguous()
+    vs = rec[:n, F.index('vsini')]
+    vs = torch.where(torch.isfinite(vs), vs, torch.zeros_like(vs)).contiguous()
+    bv0 = rec[:n, F.index('best_vel')].cpu().numpy()
+    ref = vel_fit._minimum_sampler_batch(sub, bv0, par, vs, b.CONFIG, b.OPTIONS)
+    assert np.isfinite(ref['best_vel']).all()
+    # spectrum 3 gets non finite parameters: its template is unusable on every
+    # grid (chi^2 = 1000 * badchi everywhere is finite; NaN flux is not)
+    sick = batch.subset(torch.arange(n, device=dev))
+    for a in sick.arms:
+        a.spec = a.spec.clone()
+        a.spec[3] = float('nan')
+        a._work.clear()
+    got = vel_fit._minimum_sampler_batch(sick, bv0, par, vs, b.CONFIG, b.OPTIONS)
+    assert np.isnan(got['best_vel'][3]) and np.isnan(got['vel_err'][3])
+    ok = np.arange(n) != 3
+    for k in ('best_vel', 'vel_err', 'skewness', 'kurtosis'):
+        np.testing.assert_array_equal(got[k][ok], ref[k][ok])
+    # row chunks: at most 3 spectra' grids per launch set
+    small = vel_fit._minimum_sampler_batch(sub, bv0, par, vs, b.CONFIG, b.OPTIONS,
+                                           grid_budget=3 * 400)
+    for k in ('best_vel', 'vel_err', 'skewness', 'kurtosis', 'npoints'):
+        np.testing.assert_array_equal(small[k], ref[k])
+    # a 0.25 km/s first grid (8000 velocities per spectrum, once rejected as
+    # "too long"): same minimum as the default configuration to the contract
+    cfg = dict(b.CONFIG, vel_step0=0.25)
+    fine = vel_fit._minimum_sampler_batch(sub.subset(torch.arange(6, device=dev)),
+                                          bv0[:6], par[:6], vs[:6], cfg,
+                                          b.OPTIONS)
+    assert fine['npoints'].min() >= 8000
+    assert np.abs(fine['best_vel'] - ref['best_vel'][:6]).max() < 1e-2

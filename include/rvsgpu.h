@@ -40,6 +40,7 @@ extern "C" {
 #define RVS_ST_CCF_FAILED 0x20    /* non finite CCF minimum (fitter_ccf.py:234-236)                 */
 #define RVS_ST_ALLMASKED 0x40     /* every pixel masked in CCF preprocessing (make_ccf.py:311-315)  */
 #define RVS_ST_QUAD_ASSERT 0x80   /* parabola vertex outside its bracket (spec_fit.py:1014 assert)  */
+#define RVS_ST_ILLCOND 0x100      /* rvs_chisq_grid: normal matrix pivots span > 1e9 (long stretch of weightless pixels); re-evaluate the job with rvs_chisq_point */
 
 /* library version / build probe (host). */
 int rvs_abi_version(void);

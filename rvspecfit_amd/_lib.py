@@ -171,3 +171,4 @@ ST_OUTSIDE_NAN = 0x10
 ST_CCF_FAILED = 0x20
 ST_ALLMASKED = 0x40
 ST_QUAD_ASSERT = 0x80
+ST_ILLCOND = 0x100

@@ -266,6 +266,7 @@ __device__ __forceinline__ void
   // in-lane Cholesky of the packed normal matrix (spec_fit.py:230-247)
   bool ok = true;
   double ldet = 0;
+  double pmin = 1.79e308, pmax = 0;   // smallest / largest pivot (squared)
 #pragma unroll
   for (int i = 0; i < P; i++) {
 #pragma unroll
@@ -275,6 +276,8 @@ __device__ __forceinline__ void
       for (int k = 0; k < jj; k++) sum -= acc[TRI(i, k)] * acc[TRI(jj, k)];
       if (jj == i) {
         if (!(sum > 0)) ok = false;
+        pmin = fmin(pmin, sum);
+        pmax = fmax(pmax, sum);
         const double d = sqrt(sum);
         acc[TRI(i, i)] = d;
         ldet += log(d);
@@ -283,6 +286,15 @@ __device__ __forceinline__ void
       }
     }
   }
+  // The orthonormal basis keeps this matrix well conditioned as long as the
+  // weights t^2/e^2 are of one order over the arm.  A long stretch of pixels
+  // with (nearly) no weight -- half an arm masked with errors inflated 1e6-fold,
+  // a template that vanishes over part of the arm -- takes that away: the
+  // pivots then span > 1e9 and D.D - y.y loses the 1e-6 of the contract without
+  // any pivot turning negative.  Such jobs are flagged; the caller re-evaluates
+  // them with rvs_chisq_point (raw basis, explicit residual, Cholesky + eigen
+  // tiers: exact to 1e-13 there, tests/test_edge_cases.py).
+  if (ok && pmin < 1e-9 * pmax) st |= RVS_ST_ILLCOND;
   double yy = 0;
 #pragma unroll
   for (int i = 0; i < P; i++) {

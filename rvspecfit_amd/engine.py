@@ -417,31 +417,40 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
     shared = vels.dim() == 1
     Nv = vels.shape[-1]
     vstride = 0 if shared else Nv
-    wide = [_arm_resol(arm, ia, resols) for ia, arm in enumerate(batch.arms)]
-    if any(r is not None and r['nd'] > RES_MAXND for r in wide):
-        # resolution matrix wider than the grid kernel's band (the reference's
-        # tests/test_sdss.py uses R = 50: 371 diagonals): every (job, velocity)
-        # is a job of the point kernel, which applies a band of any width
+    def by_point_kernel(rows):
+        """every (job, velocity) of jobs `rows` (None = all) as a job of the
+        point kernel: -> chisq [len(rows), Nv], status [len(rows)]"""
         js = job_spec if job_spec is not None else _arange32(0, J, dev)
         jt = job_templ if job_templ is not None else _arange32(0, J, dev)
-        vv = (vels[None, :].expand(J, Nv) if shared else vels).reshape(-1)
-        res = torch.empty(J * Nv, dtype=torch.float64, device=dev)
-        st = torch.zeros(J * Nv, dtype=torch.int32, device=dev)
+        vv = vels[None, :].expand(J, Nv) if shared else vels
+        if rows is not None:
+            js, jt, vv = js[rows], jt[rows], vv[rows]
+        n = js.shape[0]
+        vv = vv.reshape(-1)
+        res = torch.empty(n * Nv, dtype=torch.float64, device=dev)
+        st = torch.zeros(n * Nv, dtype=torch.int32, device=dev)
         js2 = js.repeat_interleave(Nv).contiguous()
         jt2 = jt.repeat_interleave(Nv).contiguous()
         step = 1 << 18
-        for a in range(0, J * Nv, step):
-            b = min(J * Nv, a + step)
+        for a in range(0, n * Nv, step):
+            b = min(n * Nv, a + step)
             res[a:b], st[a:b] = chisq_point(
                 batch, libs, coefs, outsides, vv[a:b].contiguous(), npoly=npoly,
                 rbf=rbf, job_spec=js2[a:b], job_templ=jt2[a:b],
                 espec_sys=espec_sys, outside_penalty=outside_penalty,
                 resols=resols)
-        res = res.reshape(J, Nv)
-        stj = torch.zeros(J, dtype=torch.int32, device=dev)
-        st = st.reshape(J, Nv)
+        stj = torch.zeros(n, dtype=torch.int32, device=dev)
+        st = st.reshape(n, Nv)
         for bit in range(12):
             stj |= ((st >> bit) & 1).amax(dim=1).to(torch.int32) << bit
+        return res.reshape(n, Nv), stj
+
+    wide = [_arm_resol(arm, ia, resols) for ia, arm in enumerate(batch.arms)]
+    if any(r is not None and r['nd'] > RES_MAXND for r in wide):
+        # resolution matrix wider than the grid kernel's band (the reference's
+        # tests/test_sdss.py uses R = 50: 371 diagonals): every (job, velocity)
+        # is a job of the point kernel, which applies a band of any width
+        res, stj = by_point_kernel(None)
         if out is not None:
             out.copy_(res)
             res = out
@@ -492,6 +501,20 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
                 0.0 if ia == 0 else 1.0, CG_PACK_MIN_JOBS, _lib.ptr(out[a:b]),
                 _lib.ptr(status[a:b]), _lib.stream())
             _lib.check(rc, 'rvs_chisq_grid')
+    # Jobs whose normal matrix the velocity-grid kernel could not factor, or
+    # found spanning > 1e9 in its pivots (RVS_ST_ILLCOND: a long stretch of
+    # weightless pixels), are re-evaluated by the point kernel -- raw basis,
+    # explicit residual, the reference's Cholesky -> SVD tiers
+    # (spec_fit.py:337-354).  Rare; costs one look at the status vector.
+    redo = torch.nonzero(status & (_lib.ST_ILLCOND | _lib.ST_CHOL_FALLBACK)
+                         ).reshape(-1)
+    if redo.numel():
+        res, stj = by_point_kernel(redo)
+        out[redo] = res
+        # (ST_ILLCOND stays on as the record that the job took this path)
+        status[redo] = (status[redo] & ~(_lib.ST_NONFINITE |
+                                         _lib.ST_CHOL_FALLBACK)) | stj | \
+            _lib.ST_ILLCOND
     return out, status
 
 

@@ -180,3 +180,95 @@ def test_grid_edge_template_is_numpys_float32_exp():
                                         orc.get_poly_basis(lam, 10),
                                         es[i].cpu().numpy())
             assert abs(gp - tot) / max(abs(tot), npix) < 1e-9
+
+
+@pytest.mark.gpu
+def test_long_weightless_stretches_take_the_robust_path():
+    """The velocity-grid kernel works in a basis that is orthonormal over the
+    PIXELS: a long stretch without weight (30-70 % of an arm masked with the
+    errors inflated 1e4 ... 1e6-fold -- DESI's masked variance is
+    (1000 median)^2 --, or a template that vanishes over half the arm) makes its
+    normal matrix ill conditioned and D.D - y.y lost up to 2e-6 in round 1's
+    kernel without any flag.  The kernel now flags such jobs (RVS_ST_ILLCOND, and
+    RVS_ST_CHOL_FALLBACK when a pivot turns negative) and engine.chisq_grid
+    re-evaluates them with the point kernel -- the reference's Cholesky -> SVD
+    tiers (spec_fit.py:337-354) on the raw basis: within 5e-8 of the
+    extended-precision value in every case (1e-6 is the contract)."""
+    from conftest import gold_lib_dict, GOLD_CONFIG
+    from rvspecfit_amd import _lib, spec_fit, spec_inter
+    from rvspecfit_amd.library import TemplateLibrary
+    _lib.require_gpu()
+    d = gold_lib_dict('gold_b')
+    name = 'gold_b'
+    lam = np.arange(4400., 4720.1, 0.8)
+    p = (5100., 2.3, -0.9, 0.15)
+    vgrid = 30. + 5 * np.arange(4.)
+
+    def device_grid(gsd, cfg, npoly):
+        b, _ = spec_fit.as_batch(gsd)
+        cg, st, _ = spec_fit.chisq_grid_jobs(
+            b, torch.as_tensor(vgrid).cuda(),
+            torch.as_tensor(np.array([p]))[None].cuda(), None,
+            dict(npoly=npoly), cfg)
+        return cg.reshape(-1).cpu().numpy(), int(st[0].item())
+
+    # (1) masked stretches
+    spec_inter.register_library(TemplateLibrary(name, d), 'illcond://a')
+    cfg = dict(GOLD_CONFIG, template_lib='illcond://a')
+    olib = orc.Library(d)
+    spl = orc.Spline(d['lam'], olib.eval(p))
+    flagged = 0
+    for snr in (30., 1000.):
+        for frac, infl in ((0.5, 1e4), (0.5, 1e6), (0.7, 1e4), (0.3, 1e6)):
+            rng = np.random.RandomState(1)
+            sp0 = orc.eval_rv(spl, 30., lam)
+            es = sp0 / snr
+            sp = sp0 + es * rng.standard_normal(len(lam))
+            es = es.copy()
+            es[int(len(lam) * (1 - frac)):] *= infl
+            gsd = [spec_fit.SpecData(name, lam, sp, es)]
+            for npoly in (10, 15):
+                polys = orc.get_poly_basis(lam, npoly)
+                got, st = device_grid(gsd, cfg, npoly)
+                flagged += bool(st & _lib.ST_ILLCOND)
+                assert not st & (_lib.ST_NONFINITE | _lib.ST_CHOL_FALLBACK)
+                for v, g in zip(vgrid, got):
+                    ld = float(chisq0_longdouble(sp, orc.eval_rv(spl, v, lam),
+                                                 polys, es))
+                    # (flagged jobs: 1e-13; the rest carry cond * eps with
+                    # the pivots spanning < 1e9)
+                    assert abs(g - ld) / max(abs(ld), len(lam)) < 5e-8, \
+                        (snr, frac, infl, npoly, v)
+    assert flagged >= 4     # the 1e6-fold cases
+
+    # (2) a template that is ~e^-60 of its level over the red half of the arm
+    dd = dict(d)
+    z = np.array(d['dats'], dtype=np.float32)
+    red = d['lam'] > 4560
+    z[:, red] = -60. + 0.01 * z[:, red]
+    dd['dats'] = z
+    spec_inter.register_library(TemplateLibrary(name, dd), 'illcond://b')
+    cfg = dict(GOLD_CONFIG, template_lib='illcond://b')
+    olibs = {name: orc.Library(dd)}
+    spl = orc.Spline(dd['lam'], olibs[name].eval(p))
+    rng = np.random.RandomState(2)
+    sp = orc.eval_rv(spl, 30., lam) * (1 + 0.01 * rng.standard_normal(len(lam))) \
+        + 0.05
+    es = np.full_like(sp, 0.01 * np.median(sp))
+    gsd = [spec_fit.SpecData(name, lam, sp, es)]
+    osd = [orc.SpecData(name, lam, sp, es)]
+    for npoly in (10, 15):
+        got, st = device_grid(gsd, cfg, npoly)
+        assert st & (_lib.ST_ILLCOND | _lib.ST_CHOL_FALLBACK)
+        for v, g in zip(vgrid, got):
+            o = orc.get_chisq(osd, v, p, None, options=dict(npoly=npoly),
+                              config=cfg, libs=olibs)       # the SVD statement
+            assert abs(g - o) <= 1e-8 * max(abs(o), len(lam)), (npoly, v, g, o)
+        # find_best, the API the drivers call, goes the same way
+        fb = spec_fit.find_best(gsd, vgrid, [p], None, None,
+                                options=dict(npoly=npoly), config=cfg)
+        ob = orc.find_best(osd, vgrid, [p], None, dict(npoly=npoly), cfg, olibs,
+                           use_c=False)
+        assert abs(fb['best_vel'] - ob['best_vel']) < 1e-3
+        assert abs(fb['best_chi'] - ob['best_chi']) <= 1e-8 * max(
+            abs(ob['best_chi']), len(lam))

@@ -72,6 +72,14 @@ __global__ void __launch_bounds__(256)
 // packed lower-triangular index
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 
+// Measured negative (tools/perf/ubench_dpp.hip, round 2): gfx90a+ allows
+// `row_newbcast:n` on 64-bit VALU operations at the full v_fma_f64 rate, so the 65
+// uniform factors of a pixel (55 products P_i P_j + 10 P_j) can come from the 16
+// lanes of a row of five VGPR pairs instead of SGPRs, which drops the ten
+// `P_j * w` multiplications per pixel (74 instead of 84 fp64 instructions).  But
+// every lane then loads 5 x 8 B of table per pixel: with the spline gathers that is
+// 5 KB per pixel and wave, 69 B/clk per CU against the 64 B/clk the vector memory
+// pipe returns -- 44.2 ms against 34.9 ms per 10 000 spectra.
 // waves per SIMD the register budget is held to (168 / 256 VGPRs)
 #define CG_WAVES(P) ((P) <= 10 ? 3 : (P) <= 12 ? 2 : 1)
 

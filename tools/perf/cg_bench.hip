@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
   for (int s = 0; s < S; s++) for (int v = 0; v < Nv; v++) vels[(size_t)s * Nv + v] = -1000 + 2000.0 * v / Nv;
   double *d_lam, *d_knots, *d_coef, *d_polys, *d_spec, *d_espec, *d_vels, *d_work, *d_out; int32_t *d_st;
   hipMalloc(&d_lam, npix * 8); hipMalloc(&d_knots, ntp * 8); hipMalloc(&d_coef, 32ll * ntp * (own ? S : 1));
-  hipMalloc(&d_polys, (size_t)npix * P * 8); hipMalloc(&d_spec, spec.size() * 8); hipMalloc(&d_espec, spec.size() * 8);
+  hipMalloc(&d_polys, polysT.size() * 8); hipMalloc(&d_spec, spec.size() * 8); hipMalloc(&d_espec, spec.size() * 8);
   hipMalloc(&d_vels, vels.size() * 8); hipMalloc(&d_out, vels.size() * 8); hipMalloc(&d_st, S * 4);
   const int64_t wsz = rvs_chisq_work_size(npix, S);
   hipMalloc(&d_work, wsz * 8);

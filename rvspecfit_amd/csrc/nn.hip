@@ -7,18 +7,33 @@
 // This is the one genuinely GEMM-shaped piece of the path: Y[B,N] = act(X[B,K]
 // W[N,K]^T + b).  v_mfma_f32_32x32x2_f32 keeps exact f32 products and an f32
 // fma chain (no bf16/xf32 rounding), as needed for parity with torch float32.
-// Block = 4 waves = a 64x64 output tile (2x2 waves of 32x32), K staged through
-// LDS in 32-deep slabs with coalesced global loads; LDS rows padded to 33
-// floats so that the fragment reads (32 consecutive rows, same k) are
-// conflict-free.
+// Tiling and staging: see nn_linear_kernel.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define NN_BM 64
-#define NN_BN 64
-#define NN_BK 32
-#define NN_LDK 33
+// Block tile 128 x 128 (4 waves, each 64 x 64 = 2 x 2 MFMA tiles of 32 x 32: 64
+// accumulator registers), K in slabs of 16 through a double-buffered LDS image.
+//  * v_mfma_f32_32x32x2_f32 takes A[m][k] from lane (m, k = lane / 32): the k
+//    index is free to be permuted as long as A and B agree, so within a group of
+//    8 k's the lower half-wave takes k = g + j and the upper k = g + 4 + j in
+//    MFMA j (j < 4): ONE ds_read_b128 per operand tile feeds four MFMAs.
+//  * rows are padded to 20 floats: the 16-lane groups of a ds_read_b128 then start
+//    on 16 different multiples of four banks (conflict free), stores are 16-B
+//    aligned ds_write_b128.
+//  * the global loads of slab s + 1 are in flight (registers) while slab s is
+//    multiplied; one barrier per slab of 32 MFMAs per wave.
+// LDS 40 KB per block: four blocks per CU (the 160 KB of gfx950), 4 waves per
+// SIMD, so one block's epilogue (bias, SiLU or the float64 exp) runs on the
+// VALU under the other blocks' MFMAs.
+#define NN_BM 128
+#define NN_BN 128
+#ifndef NN_BK
+#define NN_BK 16
+#endif
+#define NN_LDK (NN_BK + 4)
 
 __global__ void __launch_bounds__(256)
     nn_map_kernel(const double *__restrict__ params, int B, int ndim,
@@ -33,53 +48,189 @@ __global__ void __launch_bounds__(256)
   x[i] = (float)(((double)y - M[d]) / S[d]);
 }
 
-// final != 0: write float64 exp(clip(y)) to yout64, else SiLU and f32 to yout32
-__global__ void __launch_bounds__(256)
+// exp(y) for |y| <= 300 in float64: y = n ln 2 + r, |r| <= 0.347, degree-12
+// Taylor polynomial of exp(r) (truncation 0.347^13 / 13! = 2e-16), scaled by 2^n
+// through the exponent field (n within +-433: never subnormal).  18 fp64
+// operations against ~35 of the library exp; within 2 ulp of it.
+__device__ __forceinline__ double exp_clip300(double y) {
+  const double n = rint(y * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, y);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 479001600.0;
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const int hi = __double2hiint(p) + ((int)n << 20);
+  return __hiloint2double(hi, __double2loint(p));
+}
+
+// Y = act(X W^T + b): X [Bn, K], W [N, K] (torch Linear.weight), row-major f32.
+// final_layer != 0: float64 exp(clip(y, +-300)) to yout64, else SiLU f32.
+// BIG = true:  block tile 128 x 128, waves 2 x 2 of 64 x 64 (the wide last layer);
+// BIG = false: block tile  32 x 128, waves 1 x 4 of 32 x 32: the 256-wide hidden
+//              layers have 2 column tiles only, and with 128-row tiles 158 blocks
+//              would occupy 158 of the 256 CUs with one wave per SIMD.
+template <bool BIG, bool KVEC, bool FINAL>
+__global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
     nn_linear_kernel(const float *__restrict__ X, const float *__restrict__ W,
                      const float *__restrict__ bias, int Bn, int K, int N,
-                     int final_layer, float *__restrict__ yout32,
+                     float *__restrict__ yout32,
                      double *__restrict__ yout64) {
-  __shared__ float Xs[NN_BM * NN_LDK];
-  __shared__ float Ws[NN_BN * NN_LDK];
+  constexpr int BM = BIG ? NN_BM : 32;
+  constexpr int TI = BIG ? 2 : 1, TJ = BIG ? 2 : 1;   // MFMA tiles per wave
+  __shared__ __attribute__((aligned(16))) float lds[2][(BM + NN_BN) * NN_LDK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int row0 = blockIdx.y * NN_BM, col0 = blockIdx.x * NN_BN;
-  f32x16 acc;
+  const int wr = BIG ? (wave >> 1) : 0, wc = BIG ? (wave & 1) : wave;
+  // Persistent blocks: a block walks over output tiles (row tiles fastest, so
+  // the blocks in flight share a few column tiles of W); the first slab of the
+  // next tile is requested before the stores of the current one.  The float64
+  // output of the last layer -- 497 MB for a 10 000-spectra DESI arm -- costs
+  // 0.12 of that layer's 0.33 ms (measured with the stores compiled out) and did
+  // not move under any arrangement tried: one tile per block, persistent blocks,
+  // next-tile prefetch ahead of the stores, staggered block starts.
+  const int ntr = (Bn + BM - 1) / BM, ntc = (N + NN_BN - 1) / NN_BN;
+  int row0 = (blockIdx.x % ntr) * BM, col0 = (blockIdx.x / ntr) * NN_BN;
+  bool first = true;
+  for (int tile = blockIdx.x; tile < ntr * ntc; tile += gridDim.x) {
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += NN_BK) {
-    __syncthreads();
-    // 64 rows x 32 k each for X and W; thread -> (row = e / 32, k = e % 32)
-    for (int e = tid; e < NN_BM * NN_BK; e += 256) {
-      const int r = e >> 5, kk = e & 31;
-      const int gr = row0 + r, gk = k0 + kk;
-      Xs[r * NN_LDK + kk] = (gr < Bn && gk < K) ? X[(int64_t)gr * K + gk] : 0.f;
-      const int gc = col0 + r;
-      Ws[r * NN_LDK + kk] = (gc < N && gk < K) ? W[(int64_t)gc * K + gk] : 0.f;
-    }
-    __syncthreads();
-    const float *xa = Xs + (wr * 32 + (lane & 31)) * NN_LDK + (lane >> 5);
-    const float *wb = Ws + (wc * 32 + (lane & 31)) * NN_LDK + (lane >> 5);
+  for (int i = 0; i < TI; i++)
 #pragma unroll
-    for (int kk = 0; kk < NN_BK; kk += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[kk], wb[kk], acc, 0, 0, 0);
-  }
-  const int col = col0 + wc * 32 + (lane & 31);
-  if (col >= N) return;
-  const float bv = bias[col];
+    for (int j = 0; j < TJ; j++)
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row >= Bn) continue;
-    const float y = acc[r] + bv;
-    if (final_layer) {
-      double v = (double)y;
-      v = fmin(fmax(v, -300.0), 300.0);
-      yout64[(int64_t)row * N + col] = exp(v);
+      for (int q = 0; q < 16; q++) acc[i][j][q] = 0.f;
+  // staging: thread -> k quad tid % (BK/4), rows tid / (BK/4) + p * RP
+  constexpr int QK = NN_BK / 4, RP = 256 / QK;        // quads per row, rows per pass
+  constexpr int PX = (BM + RP - 1) / RP, PW = NN_BN / RP;
+  const int sr = tid / QK, sq = (tid % QK) * 4;
+  // Rows beyond Bn / N are clamped to the last valid row (their products land in
+  // outputs that are never stored); only the K padding of the last slab has to
+  // be zero.  With K % 4 == 0 (every layer of the reference's architecture) a
+  // fetch is unconditional 16-B loads: no divergent control flow in the loop.
+  auto gload = [&](const float *base, int nrows, int r, int k) -> f32x4 {
+    const float *p = base + (int64_t)min(r, nrows - 1) * K;
+    f32x4 v;
+    if (KVEC) {   // K % 4 == 0: 16-B aligned rows (a launch-time property)
+      v = *reinterpret_cast<const f32x4 *>(p + ((k + 3 < K) ? k : 0));
     } else {
-      yout32[(int64_t)row * N + col] = y / (1.0f + expf(-y));
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = (k + q < K) ? p[k + q] : 0.f;
     }
+    return v;
+  };
+  f32x4 gx[PX], gw[PW];
+  bool gin = true;   // the quad fetched last lies inside K
+  auto fetch = [&](int k0) {
+    gin = !KVEC || (k0 + sq + 3 < K);
+#pragma unroll
+    for (int p = 0; p < PX; p++)
+      if (BM % RP == 0 || p * RP + sr < BM)
+        gx[p] = gload(X, Bn, row0 + p * RP + sr, k0 + sq);
+#pragma unroll
+    for (int p = 0; p < PW; p++) gw[p] = gload(W, N, col0 + p * RP + sr, k0 + sq);
+  };
+  // (the K padding is zeroed here, AFTER the multiplications of the current
+  // slab: a select right behind the loads would make the wave wait for them)
+  auto stash = [&](int buf) {
+    float *xs = lds[buf], *ws = lds[buf] + BM * NN_LDK;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < PX; p++)
+      if (BM % RP == 0 || p * RP + sr < BM)
+        *reinterpret_cast<f32x4 *>(xs + (p * RP + sr) * NN_LDK + sq) =
+            gin ? gx[p] : z;
+#pragma unroll
+    for (int p = 0; p < PW; p++)
+      *reinterpret_cast<f32x4 *>(ws + (p * RP + sr) * NN_LDK + sq) =
+          gin ? gw[p] : z;
+  };
+  const int nslab = (K + NN_BK - 1) / NN_BK;
+  if (first) fetch(0);   // (later tiles: fetched before the previous tile's stores)
+  first = false;
+  stash(0);
+  __syncthreads();
+  const int fm = lane & 31, fh = (lane >> 5) * 4;
+  constexpr int WROWS = 32 * TI, WCOLS = 32 * TJ;
+  for (int sidx = 0; sidx < nslab; sidx++) {
+    const int buf = sidx & 1;
+    if (sidx + 1 < nslab) fetch((sidx + 1) * NN_BK);
+    const float *xs = lds[buf] + (wr * WROWS + fm) * NN_LDK + fh;
+    const float *ws = lds[buf] + BM * NN_LDK + (wc * WCOLS + fm) * NN_LDK + fh;
+#pragma unroll
+    for (int g = 0; g < NN_BK; g += 8) {
+      f32x4 a[TI], b[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+        a[i] = *reinterpret_cast<const f32x4 *>(xs + i * 32 * NN_LDK + g);
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+        b[j] = *reinterpret_cast<const f32x4 *>(ws + j * 32 * NN_LDK + g);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+          for (int j = 0; j < TJ; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q],
+                                                             acc[i][j], 0, 0, 0);
+    }
+    if (sidx + 1 < nslab) stash(buf ^ 1);
+    __syncthreads();
   }
+  // The first slab of the NEXT tile is requested before this tile's stores:
+  // vmcnt counts in order, so loads issued behind the 64 stores would not be
+  // usable before every store had been acknowledged.
+  const int erow0 = row0, ecol0 = col0;
+  if (tile + (int)gridDim.x < ntr * ntc) {
+    const int nt = tile + gridDim.x;
+    row0 = (nt % ntr) * BM;
+    col0 = (nt / ntr) * NN_BN;
+    fetch(0);
+  }
+  // epilogue: bias, then SiLU (float32) or the float64 exp.  Tiles that lie
+  // inside the matrix (all but the last row / column of tiles) store without
+  // any test: straight-line code, 64 stores in flight per lane.
+  auto emit = [&](auto inside_c) {
+    constexpr bool INSIDE = decltype(inside_c)::value;
+#pragma unroll
+    for (int tj = 0; tj < TJ; tj++) {
+      const int col = ecol0 + wc * WCOLS + tj * 32 + (lane & 31);
+      const bool cok = INSIDE || col < N;
+      const float bv = bias[cok ? col : 0];
+#pragma unroll
+      for (int ti = 0; ti < TI; ti++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = erow0 + wr * WROWS + ti * 32 + (r & 3) + 8 * (r >> 2) +
+                          4 * (lane >> 5);
+          const float y = acc[ti][tj][r] + bv;
+          if (FINAL) {
+            double v = (double)y;
+            v = fmin(fmax(v, -300.0), 300.0);
+            const double e = exp_clip300(v);
+            if (INSIDE || (cok && row < Bn)) yout64[(int64_t)row * N + col] = e;
+          } else {
+            const float a = y / (1.0f + expf(-y));
+            if (INSIDE || (cok && row < Bn)) yout32[(int64_t)row * N + col] = a;
+          }
+        }
+      }
+    }
+  };
+  if (erow0 + BM <= Bn && ecol0 + NN_BN <= N)
+    emit(std::true_type{});
+  else
+    emit(std::false_type{});
+  }   // tiles
 }
 
 extern "C" int rvs_template_nn(const double *params, int B, int ndim,
@@ -99,9 +250,30 @@ extern "C" int rvs_template_nn(const double *params, int B, int ndim,
   for (int l = 0; l < nlayer; l++) {
     const int K = dims[l], N = dims[l + 1];
     const int fin = (l == nlayer - 1);
-    dim3 grid((N + NN_BN - 1) / NN_BN, (B + NN_BM - 1) / NN_BM);
-    hipLaunchKernelGGL(nn_linear_kernel, grid, dim3(256), 0, st, cur, W[l], b[l],
-                       B, K, N, fin, nxt, templ);
+    // the wide layer: 128-row tiles; narrow layers: 32-row tiles so that the
+    // launch has several blocks per CU
+    const bool big = (int64_t)((N + NN_BN - 1) / NN_BN) * ((B + NN_BM - 1) / NN_BM)
+                     >= 1024;
+    const bool kv = (K & 3) == 0;
+    const int64_t ntile = (int64_t)((N + NN_BN - 1) / NN_BN) *
+                          (big ? (B + NN_BM - 1) / NN_BM : (B + 31) / 32);
+    // four resident blocks per CU (LDS 40 KB, 120 VGPRs), 256 CUs
+    const dim3 grid((unsigned)(ntile < 1024 ? ntile : 1024));
+#define NN_LAUNCH(BG, KV, FN)                                                  \
+  hipLaunchKernelGGL((nn_linear_kernel<BG, KV, FN>), grid, dim3(256), 0, st,   \
+                     cur, W[l], b[l], B, K, N, nxt, templ)
+    if (fin) {
+      if (big && kv) NN_LAUNCH(true, true, true);
+      else if (big) NN_LAUNCH(true, false, true);
+      else if (kv) NN_LAUNCH(false, true, true);
+      else NN_LAUNCH(false, false, true);
+    } else {
+      if (big && kv) NN_LAUNCH(true, true, false);
+      else if (big) NN_LAUNCH(true, false, false);
+      else if (kv) NN_LAUNCH(false, true, false);
+      else NN_LAUNCH(false, false, false);
+    }
+#undef NN_LAUNCH
     RVS_LAUNCH_CHECK();
     float *t = cur;
     cur = nxt;

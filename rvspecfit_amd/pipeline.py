@@ -82,8 +82,9 @@ def fit_batch(batch, config, options=None, refine=False, timers=None):
 
     if refine:
         ev.start('refine')
-        r = vel_fit._minimum_sampler_batch(batch, res[:, 1].cpu().numpy(), params,
-                                           vsini, config, options)
+        r = vel_fit._minimum_sampler_batch(batch, res[:, 1].contiguous(), params,
+                                           vsini, config, options,
+                                           templates=(coefs, outs))
         rec[:, 7] = torch.as_tensor(r['best_vel']).to(dev)
         rec[:, 8] = torch.as_tensor(r['vel_err']).to(dev)
         rec[:, 9] = torch.as_tensor(r['skewness']).to(dev)

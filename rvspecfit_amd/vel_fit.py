@@ -76,92 +76,125 @@ def firstguess(specdata, options=None, config=None, resolParams=None,
 
 def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
                            crit_ratio=5, goal_width=10, grid_budget=1 << 24,
-                           resolParams=None, keep_grids=False):
+                           resolParams=None, keep_grids=False, templates=None):
     """Batched _minimum_sampler (vel_fit.py:358-439): every spectrum carries
     its own (min_vel, max_vel, step) state; per round all spectra that are not
     converged are evaluated on their own velocity grids in one launch set.
     Grid construction follows the reference formula exactly:
         arange(ceil((min_vel-best_vel)/step)*step, max_vel-best_vel, step)+best_vel
-    (host float64, per spectrum).  Returns per-spectrum numpy arrays."""
+    (host float64, per spectrum).  Returns per-spectrum numpy arrays.
+    The templates (spline records of every spectrum's parameters, all arms) are
+    built once -- or handed over by the caller as `templates` = (coefs, outs) of
+    engine.build_templates -- and every round's grids are evaluated against
+    them: the reference's get_chisq finds them in its template cache the same way
+    (spec_fit.py:902-910)."""
     S, dev = batch.S, batch.device
-    min_vel = np.full(S, float(config['min_vel']))
-    max_vel = np.full(S, float(config['max_vel']))
-    step = np.full(S, float(config['vel_step0']))
+    opts = options or {}
+    npoly = opts.get('npoly') or 5
+    rbf = opts.get('rbf_continuum', True)
+    libs = spec_inter.get_libs(batch.names, config)
+    # The per-spectrum state (window, step, current minimum) lives on the device
+    # and every formula below is the reference's, evaluated element-wise in
+    # float64 by separate (un-fused) operations -- the same roundings as numpy's:
+    #     arange(ceil((min_vel-best_vel)/step)*step, max_vel-best_vel, step)+best_vel
+    # The host looks at two numbers per round (how many spectra are still
+    # active, the longest grid); no grid ever crosses PCIe.
+    f64 = dict(dtype=torch.float64, device=dev)
+    min_vel = torch.full((S, ), float(config['min_vel']), **f64)
+    max_vel = torch.full((S, ), float(config['max_vel']), **f64)
+    step = torch.full((S, ), float(config['vel_step0']), **f64)
     min_vel_step = config['min_vel_step']
-    bv = np.clip(np.asarray(best_vel, dtype=np.float64), min_vel, max_vel)
-    err = np.zeros(S)
-    skw = np.zeros(S)
-    kur = np.zeros(S)
-    active = np.ones(S, dtype=bool)
-    ngrids = np.zeros(S, dtype=int)
-    ngrid_pts = np.zeros(S, dtype=int)
+    bv0 = best_vel if isinstance(best_vel, torch.Tensor) else \
+        torch.as_tensor(np.asarray(best_vel, dtype=np.float64))
+    bv = torch.minimum(torch.maximum(bv0.to(**f64).reshape(-1), min_vel),
+                       max_vel).clone()
+    err = torch.zeros(S, **f64)
+    skw = torch.zeros(S, **f64)
+    kur = torch.zeros(S, **f64)
+    active = torch.ones(S, dtype=torch.bool, device=dev)
+    ngrids = torch.zeros(S, dtype=torch.int64, device=dev)
+    ngrid_pts = torch.zeros(S, dtype=torch.int64, device=dev)
     params = best_param if isinstance(best_param, torch.Tensor) else \
         torch.as_tensor(np.asarray(best_param, dtype=np.float64)).to(dev)
     if params.dim() == 1:
         params = params[None].expand(S, -1)
     all_grids = [[] for _ in range(S)] if keep_grids else None
+    if templates is None:
+        coefs, outs = [], []
+        for arm in batch.arms:
+            c, o = engine.build_templates(libs[arm.name], params.contiguous(),
+                                          vsini)
+            coefs.append(c)
+            outs.append(o)
+    else:
+        coefs, outs = templates
+    resols = spec_fit._resols(batch, resolParams)
+    nanv = torch.full((1, ), float('nan'), **f64)
+    # (a tensor divisor: torch turns `x / python_scalar` into a multiplication by
+    # the reciprocal on the GPU, one ulp away from numpy's division)
+    crit = torch.full((1, ), float(crit_ratio), **f64)
     for it in range(10):
-        idx = np.nonzero(active)[0]
-        if len(idx) == 0:
+        idx = torch.nonzero(active).reshape(-1)
+        n = int(idx.numel())
+        if n == 0:
             break
-        # np.arange(start, stop, step) + bv for every active spectrum at once:
-        # values start + i*step (numpy's own formula), length ceil((stop-start)/step)
         st_, bv_ = step[idx], bv[idx]
-        start = np.ceil((min_vel[idx] - bv_) / st_) * st_
+        start = torch.ceil((min_vel[idx] - bv_) / st_) * st_
         stop = max_vel[idx] - bv_
-        nv = np.maximum(np.ceil((stop - start) / st_), 0).astype(np.int64)
+        nv = torch.clamp(torch.ceil((stop - start) / st_), min=0).to(torch.int64)
+        nvmax = int(nv.max().item())
         # the reference accepts any grid length ((max_vel - min_vel) / vel_step0
         # is the user's choice): long grids are evaluated for fewer spectra at a
         # time, so that a launch set holds at most grid_budget velocities
-        r = np.empty((len(idx), 8))
-        rows = max(1, int(grid_budget // max(int(nv.max()), 1)))
-        for a in range(0, len(idx), rows):
+        r = torch.empty((n, 8), **f64)
+        rows = max(1, int(grid_budget // max(nvmax, 1)))
+        for a in range(0, n, rows):
             sl = slice(a, a + rows)
             nvc = nv[sl]
-            nmax = max(int(nvc.max()), 1)
-            ii = np.arange(nmax, dtype=np.float64)
+            nmax = max(nvmax if rows >= n else int(nvc.max().item()), 1)
+            ii = torch.arange(nmax, **f64)
             vg = (start[sl, None] + ii[None, :] * st_[sl, None]) + bv_[sl, None]
-            last = vg[np.arange(len(nvc)), np.maximum(nvc - 1, 0)]
-            vg = np.where(ii[None, :] < nvc[:, None], vg, last[:, None])  # padding
+            last = vg.gather(1, torch.clamp(nvc - 1, min=0)[:, None])
+            vg = torch.where(ii[None, :] < nvc[:, None], vg, last).contiguous()
             if keep_grids:
-                for k, i in enumerate(idx[sl]):
-                    all_grids[i].append(vg[k, :nvc[k]].copy())
-            vgt = torch.as_tensor(vg).to(dev)
-            idt = torch.as_tensor(idx[sl]).to(dev)
-            p = params[idt][:, None, :].contiguous()
-            vs = None if vsini is None else vsini[idt]
-            chisq, status, _ = spec_fit.chisq_grid_jobs(
-                batch, vgt, p, vs, options, config, resol_params=resolParams,
-                spec_idx=None if len(idx[sl]) == S else idt)
+                vh, nh = vg.cpu().numpy(), nvc.cpu().numpy()
+                for k, i in enumerate(idx[sl].cpu().numpy()):
+                    all_grids[i].append(vh[k, :nh[k]].copy())
+            idt = None if (rows >= n and n == S) else \
+                idx[sl].to(torch.int32).contiguous()
+            chisq, status = engine.chisq_grid(
+                batch, libs, coefs, outs, vg, npoly=npoly, rbf=rbf,
+                job_spec=idt, job_templ=idt, resols=resols)
             res, _, _ = engine.grid_moments(
-                chisq.reshape(len(nvc), -1), vgt, Np=1,
-                nvel=torch.as_tensor(nvc.astype(np.int32)).to(dev))
-            r[sl] = res.cpu().numpy()
-        bv[idx], err[idx], kur[idx], skw[idx] = r[:, 1], r[:, 2], r[:, 3], r[:, 4]
+                chisq.reshape(nvc.shape[0], -1), vg, Np=1,
+                nvel=nvc.to(torch.int32).contiguous())
+            r[sl] = res
         # a spectrum whose grid has no finite minimum (every chi^2 non finite,
         # an empty grid) leaves the loop with NaN results instead of steering
         # the next grid of the whole batch with them
-        lost = ~(np.isfinite(bv[idx]) & np.isfinite(err[idx])) | (nv < 1)
-        if lost.any():
-            for arr in (bv, err, kur, skw):
-                arr[idx[lost]] = np.nan
-            active[idx[lost]] = False
-            keep = ~lost
-            idx, st_, nv = idx[keep], st_[keep], nv[keep]
-            if len(idx) == 0:
-                continue
-        ngrids[idx] += 1
-        ngrid_pts[idx] += nv
+        lost = ~(torch.isfinite(r[:, 1]) & torch.isfinite(r[:, 2])) | (nv < 1)
+        keep = ~lost
+        bv[idx] = torch.where(lost, nanv, r[:, 1])
+        err[idx] = torch.where(lost, nanv, r[:, 2])
+        kur[idx] = torch.where(lost, nanv, r[:, 3])
+        skw[idx] = torch.where(lost, nanv, r[:, 4])
+        ngrids[idx] += keep.to(torch.int64)
+        ngrid_pts[idx] += torch.where(keep, nv, torch.zeros_like(nv))
         e_ = err[idx]
-        done = (st_ < e_ / crit_ratio) | (st_ < min_vel_step)
+        done = (st_ < e_ / crit) | (st_ < min_vel_step)
         coarse = st_ > e_
-        new_step = np.where(coarse, st_ / crit_ratio, e_ / crit_ratio * 0.8)
-        width = np.where(coarse, st_ * goal_width, e_ * goal_width)
-        go = idx[~done]
-        active[idx[done]] = False
-        min_vel[go] = np.maximum(bv[go] - width[~done], min_vel[go])
-        max_vel[go] = np.minimum(bv[go] + width[~done], max_vel[go])
-        step[go] = new_step[~done]
+        new_step = torch.where(coarse, st_ / crit, e_ / crit * 0.8)
+        width = torch.where(coarse, st_ * goal_width, e_ * goal_width)
+        go = keep & ~done
+        active[idx] = go
+        bvn = bv[idx]
+        min_vel[idx] = torch.where(go, torch.maximum(bvn - width, min_vel[idx]),
+                                   min_vel[idx])
+        max_vel[idx] = torch.where(go, torch.minimum(bvn + width, max_vel[idx]),
+                                   max_vel[idx])
+        step[idx] = torch.where(go, new_step, st_)
+    bv, err, skw, kur = (_.cpu().numpy() for _ in (bv, err, skw, kur))
+    ngrids, ngrid_pts = ngrids.cpu().numpy(), ngrid_pts.cpu().numpy()
     return dict(best_vel=bv, vel_err=err, skewness=skw, kurtosis=kur,
                 ngrids=ngrids, npoints=ngrid_pts, grids=all_grids)
 

@@ -49,28 +49,69 @@ def retry_steps(x):
     return base[None] * (HESS_STEP_RATIO**(-k))[:, None, None]
 
 
-def hessian_central(func, x, h):
-    """Central second differences of func at x [S, n] with steps h [S, n]:
-    [S, n, n].  func(idx, points) -> [len(idx)] evaluates rows idx."""
+def _displacements(n, device):
+    """the evaluation points of the central rule as signed multiples of the
+    step vector: row 0 = x itself, then (+2e_i, -2e_i) per i, then
+    (++, +-, -+, --) per pair i < j.  [M, n] float64, M = 1 + 2n + 2n(n-1)."""
+    rows = [[0.0] * n]
+    for i in range(n):
+        for sg in (2.0, -2.0):
+            r = [0.0] * n
+            r[i] = sg
+            rows.append(r)
+    for i in range(n):
+        for j in range(i + 1, n):
+            for si, sj in ((1., 1.), (1., -1.), (-1., 1.), (-1., -1.)):
+                r = [0.0] * n
+                r[i], r[j] = si, sj
+                rows.append(r)
+    return torch.as_tensor(rows, dtype=torch.float64, device=device)
+
+
+def hessian_central(func, x, h, max_rows=1 << 18):
+    """Central second differences of func at x [S, n] with steps h [..., S, n]
+    (leading axes = several step sizes per point): [..., S, n, n].
+    func(idx, points) -> [len(idx)] evaluates rows idx.  All displacement
+    patterns of all points (and step sizes) go through func in as few calls as
+    max_rows allows -- one launch set instead of 1 + 2n + 2n(n-1) per step size;
+    every function value is what the one-pattern-at-a-time loop computed (the
+    objective kernels do not depend on the batch a row sits in)."""
+    lead = h.shape[:-2]
     S, n = x.shape
     dev = x.device
+    hh = h.reshape(-1, S, n)                       # [K, S, n]
+    K = hh.shape[0]
+    D = _displacements(n, dev)                     # [M, n]
+    M = D.shape[0]
+    # x + d * h with d in {0, +-1, +-2}: the products are exact, one rounding in
+    # the sum, as x + 2 * ee[i] / x + ee[i] + ee[j] up to the order of two adds --
+    # the pair patterns add h_i and h_j in two steps like numdifftools
     idx = torch.arange(S, device=dev)
-    fx = func(idx, x)
-    H = torch.empty((S, n, n), dtype=torch.float64, device=dev)
+    f = torch.empty((K, S, M), dtype=torch.float64, device=dev)
+    per = max(1, max_rows // (S * M))
+    for k0 in range(0, K, per):
+        k1 = min(K, k0 + per)
+        hk = hh[k0:k1]                             # [k, S, n]
+        pts = x[None, :, None, :].expand(k1 - k0, S, M, n).clone()
+        for c in range(n):       # (x + d_i h_i) + d_j h_j, i < j, like the loop
+            pts[..., c] = pts[..., c] + D[None, None, :, c] * hk[:, :, None, c]
+        rows = idx[None, :, None].expand(k1 - k0, S, M).reshape(-1)
+        f[k0:k1] = func(rows, pts.reshape(-1, n)).reshape(k1 - k0, S, M)
+    H = torch.empty((K, S, n, n), dtype=torch.float64, device=dev)
+    fx = f[:, :, 0]
+    m = 1
     for i in range(n):
-        ei = torch.zeros_like(x)
-        ei[:, i] = h[:, i]
-        H[:, i, i] = (func(idx, x + 2 * ei) - 2 * fx + func(idx, x - 2 * ei)) / \
-            (4. * h[:, i] * h[:, i])
+        H[:, :, i, i] = (f[:, :, m] - 2 * fx + f[:, :, m + 1]) / \
+            (4. * hh[:, :, i] * hh[:, :, i])
+        m += 2
+    for i in range(n):
         for j in range(i + 1, n):
-            ej = torch.zeros_like(x)
-            ej[:, j] = h[:, j]
-            v = (func(idx, x + ei + ej) - func(idx, x + ei - ej) -
-                 func(idx, x - ei + ej) + func(idx, x - ei - ej)) / \
-                (4. * h[:, i] * h[:, j])
-            H[:, i, j] = v
-            H[:, j, i] = v
-    return H
+            v = (f[:, :, m] - f[:, :, m + 1] - f[:, :, m + 2] + f[:, :, m + 3]) / \
+                (4. * hh[:, :, i] * hh[:, :, j])
+            H[:, :, i, j] = v
+            H[:, :, j, i] = v
+            m += 4
+    return H.reshape(lead + (S, n, n))
 
 
 # ---- extrapolation of a sequence of estimates (host, all columns at once) ----
@@ -148,7 +189,4 @@ def extrapolate(seq, step_ratio=HESS_STEP_RATIO):
 
 def hessian_retry(func, x):
     """ndf.Hessian(f)(x) with the default step generator, rows of x [S, n]"""
-    hs = retry_steps(x)
-    seq = torch.stack([hessian_central(func, x, hs[k])
-                       for k in range(hs.shape[0])]).cpu().numpy()
-    return extrapolate(seq)
+    return extrapolate(hessian_central(func, x, retry_steps(x)).cpu().numpy())

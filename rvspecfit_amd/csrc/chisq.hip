@@ -78,8 +78,14 @@ __global__ void __launch_bounds__(256)
 // lanes of a row of five VGPR pairs instead of SGPRs, which drops the ten
 // `P_j * w` multiplications per pixel (74 instead of 84 fp64 instructions).  But
 // every lane then loads 5 x 8 B of table per pixel: with the spline gathers that is
-// 5 KB per pixel and wave, 69 B/clk per CU against the 64 B/clk the vector memory
-// pipe returns -- 44.2 ms against 34.9 ms per 10 000 spectra.
+// 5 KB per pixel and wave -- 44.2 ms against 34.9 ms per 10 000 spectra.  With
+// the table AND the spline window of a 2-wave block staged through LDS by
+// global_load_lds (8-pixel chunks, double buffered, no vector-memory instruction
+// in the pixel loop, LDS reads in asm so that the compiler does not wait for the
+// copy in flight): 74 fp64 + 14 integer instructions per pixel plus the chunk
+// bookkeeping -- 35.2-36.4 ms: the ten multiplications saved are spent on LDS
+// addressing, and the VALU stays ~80 % busy (now waiting for LDS and the scalar
+// cache instead of the gathers).  tools/perf/experiments/chisq_grid_dpp_lds.patch.
 // waves per SIMD the register budget is held to (168 / 256 VGPRs)
 #define CG_WAVES(P) ((P) <= 10 ? 3 : (P) <= 12 ? 2 : 1)
 

@@ -233,6 +233,127 @@ __global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
   }   // tiles
 }
 
+// ---------------------------------------------------------------------------
+// The narrow layers in ONE launch: as separate launches the four hidden layers
+// of the reference's architecture (4 -> 256 -> 256 -> 256 -> 200) were latency
+// bound -- four dependent 10-40 us launches for 3.7 GFLOP.  Here a block owns 32
+// rows (parameter vectors) and walks through the layers with the activations in
+// LDS (two [32][260] float images, ping-pong); each of its eight waves computes 32
+// output columns (one MFMA tile) and takes its B operand
+// -- four consecutive k of one row of W per lane -- straight from global memory
+// (the weights, 256 KB per layer, live in L2 and are read by every block): no
+// staging of W, no barrier inside a layer, the loads of the next k group in
+// flight under the MFMAs of the current one.  Same k permutation as
+// nn_linear_kernel (lower half-wave k = g + j, upper k = g + 4 + j).
+// The first layer (K = ndim) is a few FMAs per output and runs on the VALU.
+// Requirements (checked by the launcher, else layer by layer): every width of
+// the fused layers <= 256 and a multiple of 32 from the second layer on.
+// ---------------------------------------------------------------------------
+#define NH_LD 260
+#define NH_MAXL 6
+struct NNHidden {
+  const float *W[NH_MAXL];
+  const float *b[NH_MAXL];
+  int dims[NH_MAXL + 1];
+  int nl;
+};
+
+__global__ void __launch_bounds__(512, 2)
+    nn_hidden_kernel(const double *__restrict__ params, int Bn, int ndim,
+                     uint32_t log_mask, const double *__restrict__ M,
+                     const double *__restrict__ S, NNHidden H,
+                     float *__restrict__ yout) {
+  __shared__ __attribute__((aligned(16))) float act[2][32 * NH_LD];
+  __shared__ float xin[32 * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * 32;
+  // Mapper.forward of the block's 32 rows
+  if (tid < 32 * 8) {
+    const int r = tid >> 3, d = tid & 7;
+    float v = 0.f;
+    if (d < ndim) {
+      const int gr = min(row0 + r, Bn - 1);
+      float y = (float)params[(int64_t)gr * ndim + d];
+      if (log_mask & (1u << d)) y = (float)log10((double)y);
+      v = (float)(((double)y - M[d]) / S[d]);
+    }
+    xin[tid] = v;
+  }
+  __syncthreads();
+  // first layer (K = ndim <= 8): a handful of FMAs per output, on the VALU;
+  // thread = output column and half of the rows
+  {
+    const int N = H.dims[1], c = tid & 255, rh = (tid >> 8) * 16;
+    float w[8], bv = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; d++)
+      w[d] = (c < N && d < ndim) ? H.W[0][c * ndim + d] : 0.f;
+    if (c < N) bv = H.b[0][c];
+    for (int r = rh; r < rh + 16; r++) {
+      float y = bv;
+#pragma unroll
+      for (int d = 0; d < 8; d++) y = fmaf(w[d], xin[r * 8 + d], y);
+      act[1][r * NH_LD + c] = c < N ? y / (1.0f + expf(-y)) : 0.f;
+    }
+  }
+  __syncthreads();
+  const int fm = lane & 31, fh = (lane >> 5) * 16;
+  for (int l = 1; l < H.nl; l++) {
+    const int K = H.dims[l], N = H.dims[l + 1];   // K % 32 == 0 (zeros to 256)
+    const float *Wl = H.W[l];
+    const float *in = act[l & 1];
+    float *outp = act[(l + 1) & 1];
+    const int col0 = wave * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    // B fragment: 16 consecutive k of one row of W per lane and 32-k chunk
+    // (lower half-wave k = G .. G+15, upper G+16 .. G+31: whole 128-byte lines)
+    const int c0 = min(col0 + fm, N - 1);
+    const float z0 = col0 + fm < N ? 1.f : 0.f;
+    const f32x4 *w0 = reinterpret_cast<const f32x4 *>(Wl + (int64_t)c0 * K + fh);
+    f32x4 nb0[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) nb0[q] = w0[q];
+    const bool wave_live = col0 < N;
+    for (int G = 0; G < K && wave_live; G += 32) {
+      f32x4 cb0[4], a[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        cb0[q] = nb0[q] * z0;
+        a[q] = *reinterpret_cast<const f32x4 *>(in + fm * NH_LD + G + fh + 4 * q);
+      }
+      if (G + 32 < K) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) nb0[q] = w0[(G + 32) / 4 + q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], cb0[q][e], acc, 0, 0, 0);
+    }
+    const bool last = (l == H.nl - 1);
+    {
+      const int col = col0 + (lane & 31);
+      const bool cok = col < N;
+      const float bv = H.b[l][cok ? col : 0];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float y = acc[r] + bv;
+        const float a = cok ? y / (1.0f + expf(-y)) : 0.f;
+        if (last) {
+          if (cok && row0 + row < Bn) yout[(int64_t)(row0 + row) * N + col] = a;
+        } else {
+          outp[row * NH_LD + col] = a;   // (zeros beyond N: the next K padding)
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int rvs_template_nn(const double *params, int B, int ndim,
                                uint32_t log_mask, const double *M,
                                const double *S, int nlayer,
@@ -243,11 +364,35 @@ extern "C" int rvs_template_nn(const double *params, int B, int ndim,
   // entries (dims[0] == ndim)
   if (B < 1 || nlayer < 1 || ndim < 1 || dims[0] != ndim) return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
-  hipLaunchKernelGGL(nn_map_kernel, dim3((B * ndim + 255) / 256), dim3(256), 0,
-                     st, params, B, ndim, log_mask, M, S, act0);
-  RVS_LAUNCH_CHECK();
+  // every layer but the last in one launch when the widths allow it
+  int lfirst = 0;
   float *cur = act0, *nxt = act1;
-  for (int l = 0; l < nlayer; l++) {
+  bool fuse = nlayer >= 3 && nlayer - 1 <= NH_MAXL && ndim <= 8;
+  for (int l = 0; fuse && l < nlayer - 1; l++)
+    if (dims[l + 1] > 256 || (l > 0 && (dims[l] & 31))) fuse = false;
+#ifdef NN_NO_FUSE  // (tools/perf/nn_bench.hip: the layer-by-layer path timed beside)
+  fuse = false;
+#endif
+  if (fuse) {
+    NNHidden H;
+    H.nl = nlayer - 1;
+    for (int l = 0; l < H.nl; l++) {
+      H.W[l] = W[l];
+      H.b[l] = b[l];
+    }
+    for (int l = 0; l <= H.nl; l++) H.dims[l] = dims[l];
+    hipLaunchKernelGGL(nn_hidden_kernel, dim3((B + 31) / 32), dim3(512), 0, st,
+                       params, B, ndim, log_mask, M, S, H, act1);
+    RVS_LAUNCH_CHECK();
+    cur = act1;
+    nxt = act0;
+    lfirst = nlayer - 1;
+  } else {
+    hipLaunchKernelGGL(nn_map_kernel, dim3((B * ndim + 255) / 256), dim3(256), 0,
+                       st, params, B, ndim, log_mask, M, S, act0);
+    RVS_LAUNCH_CHECK();
+  }
+  for (int l = lfirst; l < nlayer; l++) {
     const int K = dims[l], N = dims[l + 1];
     const int fin = (l == nlayer - 1);
     // the wide layer: 128-row tiles; narrow layers: 32-row tiles so that the

@@ -599,6 +599,46 @@ def test_nn_template_desi_size_vs_oracle(gpu):
     np.testing.assert_allclose(templ.cpu().numpy(), ref, rtol=5e-6)
 
 
+@pytest.mark.parametrize('dims', [
+    (4, 96, 128, 50, 777),        # fused narrow layers, partial column tiles
+    (4, 64, 333),                 # one hidden layer
+    (4, 100, 72, 36, 515),        # widths not multiples of 32: layer by layer
+    (4, 320, 64, 1000),           # a hidden layer wider than 256: layer by layer
+    (3, 32, 32, 32, 32, 32, 32, 32, 32, 90),   # more layers than the fused kernel holds
+])
+def test_nn_template_layer_shapes_vs_oracle(gpu, dims):
+    """rvs_template_nn picks between the one-launch hidden stack and the
+    layer-by-layer kernels by the layer widths; both against the numpy oracle,
+    with a row count that leaves partial row tiles"""
+    rng = np.random.RandomState(len(dims) * 1000 + dims[1])
+    dims = np.array(dims, dtype=np.int32)
+    nd = int(dims[0])
+    d = dict(dims=dims, M=np.array([3.7, 2.5, -1., 0.5])[:nd],
+             S=np.array([0.15, 1.4, 0.6, 0.3])[:nd])
+    nl = len(dims) - 1
+    for i in range(nl):
+        k, n = dims[i], dims[i + 1]
+        d['W%d' % i] = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+        d['b%d' % i] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    lam = np.exp(np.linspace(np.log(3500.), np.log(5900.), int(dims[-1])))
+    from rvspecfit_amd.library import TemplateLibrary
+    dd = dict(lam=lam, log_step=np.array(True), log_ids=np.array([0]),
+              parnames=np.array(['teff', 'logg', 'feh', 'alpha'][:nd]),
+              nn_dims=dims, nn_M=d['M'], nn_S=d['S'])
+    for i in range(nl):
+        dd['nn_W%d' % i] = d['W%d' % i]
+        dd['nn_b%d' % i] = d['b%d' % i]
+    lib = TemplateLibrary('nn_shapes', dd)
+    for nrow in (1, 77):
+        P = np.array([rng.uniform(3500, 9000, nrow), rng.uniform(0, 5, nrow),
+                      rng.uniform(-2, 0, nrow), rng.uniform(0, 1, nrow)]).T[:, :nd]
+        P = np.ascontiguousarray(P)
+        templ, _ = lib.eval_batch(torch.as_tensor(P).to('cuda'))
+        W = [(d['W%d' % i], d['b%d' % i]) for i in range(nl)]
+        ref = orc.nn_forward(W, P, d['M'], d['S'])
+        np.testing.assert_allclose(templ.cpu().numpy(), ref, rtol=5e-6)
+
+
 # --------------------------------------------------------------------------
 # SURVEY 8(f) rank 1: vel_fit.process (Nelder-Mead in lock-step + Hessian)
 # --------------------------------------------------------------------------

@@ -38,6 +38,29 @@ int main(int argc, char **argv) {
   std::vector<double> h((size_t)B * dims[5]); hipMemcpy(h.data(), templ, h.size() * 8, hipMemcpyDeviceToHost);
   double cs = 0; for (double v : h) cs += v;
   printf("checksum %.10e  ", cs);
+  {  // run-to-run determinism and a host f64 evaluation of a few rows
+    rvs_template_nn(dp, B, 4, 1, M, S, 5, W.data(), b.data(), dims, a0, a1, templ, nullptr);
+    std::vector<double> h2(h.size()); hipMemcpy(h2.data(), templ, h.size() * 8, hipMemcpyDeviceToHost);
+    size_t nd = 0; for (size_t i = 0; i < h.size(); i++) nd += h[i] != h2[i];
+    std::vector<std::vector<float>> hw(5), hb(5);
+    for (int l = 0; l < 5; l++) { hw[l].resize((size_t)dims[l] * dims[l + 1]); hb[l].resize(dims[l + 1]);
+      hipMemcpy(hw[l].data(), W[l], hw[l].size() * 4, hipMemcpyDeviceToHost); hipMemcpy(hb[l].data(), b[l], hb[l].size() * 4, hipMemcpyDeviceToHost); }
+    double worst = 0;
+    const int rows[4] = {0, 1, B / 2 + 7, B - 1};
+    for (int ri = 0; ri < 4; ri++) {
+      const int r = rows[ri];
+      std::vector<double> x(4), y;
+      for (int d = 0; d < 4; d++) { double v = p[4 * r + d]; if (d == 0) v = log10(v); x[d] = (v - m[d]) / s[d]; }
+      for (int l = 0; l < 5; l++) {
+        y.assign(dims[l + 1], 0.0);
+        for (int n = 0; n < dims[l + 1]; n++) { double a = hb[l][n]; for (int k = 0; k < dims[l]; k++) a += (double)hw[l][(size_t)n * dims[l] + k] * x[k];
+          y[n] = l < 4 ? a / (1 + exp(-a)) : exp(a); }
+        x = y;
+      }
+      for (int n = 0; n < dims[5]; n++) worst = fmax(worst, fabs(h[(size_t)r * dims[5] + n] / x[n] - 1));
+    }
+    printf("[rerun differs in %zu values; max rel err vs host f64 on 4 rows %.2e] ", nd, worst);
+  }
   printf("B %d N %d: %.3f ms  %.1f TFLOP/s f32 MFMA (%.3f of 157.3)  out[0..1] %.6f %.6f\n", B, dims[5], best, B * fl / (best * 1e-3) / 1e12, B * fl / (best * 1e-3) / 1e12 / 157.3, h[0], h[1]);
   return 0;
 }

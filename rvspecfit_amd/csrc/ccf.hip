@@ -84,6 +84,206 @@ __device__ __forceinline__ double sorted_median(const double *s, int n) {
   return (s[(n >> 1) - 1] + s[n >> 1]) * 0.5;
 }
 
+// ---------------------------------------------------------------------------
+// Block-wide SELECTION of order statistics (the two plain medians only need the
+// middle one or two values; as full bitonic sorts they were 78 barrier-separated
+// stages each).  Doubles are mapped to unsigned keys whose integer order is the
+// floating-point order (sign flip), the candidates are narrowed by histogram
+// rounds -- 1024 buckets over the candidates' key range, prefix sums to find the
+// bucket holding rank k: ten bits of the range per round -- until <= 64 remain,
+// which one wave ranks directly.  Every step is integer comparison and counting,
+// so the value is exactly the one a sort would put at position k.
+// ---------------------------------------------------------------------------
+#define SEL_NB 1024  // buckets == PP_NT: one per thread in the prefix sum
+struct SelShared {
+  unsigned long long kmin, kmax, result, next, cand[64];
+  int hist[SEL_NB];
+  int wtot[PP_NW];
+  int cnt, nnan, nc, bucket, kk, nle;
+};
+__device__ __forceinline__ unsigned long long sel_key(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double sel_value(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
+                                                           int o) {
+  const int lo = __shfl_xor((int)(v & 0xffffffffu), o, 64);
+  const int hi = __shfl_xor((int)(v >> 32), o, 64);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// numpy median of v[0..n) (LDS); skipnan: np.nanmedian (NaNs are left out),
+// else np.median (NaN if there is one).  Called by every thread of the block;
+// the value is returned to all of them.
+__device__ double block_median(const double *v, int n, bool skipnan,
+                               SelShared &Q) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // ---- pass 0: count, NaNs, key range ---------------------------------------
+  {
+    int cnt = 0, nn = 0;
+    unsigned long long mn = ~0ull, mx = 0ull;
+    for (int k = tid; k < n; k += PP_NT) {
+      const double x = v[k];
+      if (x != x) {
+        nn++;
+        continue;
+      }
+      const unsigned long long key = sel_key(x);
+      cnt++;
+      mn = key < mn ? key : mn;
+      mx = key > mx ? key : mx;
+    }
+    cnt = wave_sum_i(cnt);
+    nn = wave_sum_i(nn);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long a = shfl_xor_u64(mn, o), b = shfl_xor_u64(mx, o);
+      mn = a < mn ? a : mn;
+      mx = b > mx ? b : mx;
+    }
+    if (tid == 0) {
+      Q.cnt = 0;
+      Q.nnan = 0;
+      Q.kmin = ~0ull;
+      Q.kmax = 0ull;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      atomicAdd(&Q.cnt, cnt);
+      atomicAdd(&Q.nnan, nn);
+      atomicMin(&Q.kmin, mn);
+      atomicMax(&Q.kmax, mx);
+    }
+    __syncthreads();
+  }
+  const int nval = Q.cnt;
+  if (nval == 0 || (!skipnan && Q.nnan > 0)) {
+    __syncthreads();
+    return __builtin_nan("");
+  }
+  const int k_lo = (nval - 1) >> 1, k_hi = nval >> 1;
+  unsigned long long lo = Q.kmin, range = Q.kmax - Q.kmin;
+  int kk = k_lo, ncand = nval;
+  __syncthreads();  // everyone has read Q.kmin / Q.kmax / Q.cnt
+  unsigned long long found = 0;
+  bool done = false;
+  if (range == 0) {
+    found = lo;
+    done = true;
+  }
+  while (!done) {
+    // bucket = (key - lo) >> shift < SEL_NB
+    const int bits = 64 - __clzll((long long)range);  // range >= 1
+    const int shift = bits > 10 ? bits - 10 : 0;
+    if (ncand <= 64) {
+      // ---- the last candidates: ranked by one wave --------------------------
+      if (tid == 0) Q.nc = 0;
+      __syncthreads();
+      for (int k = tid; k < n; k += PP_NT) {
+        const double x = v[k];
+        if (x != x) continue;
+        const unsigned long long key = sel_key(x);
+        if (key >= lo && key - lo <= range) Q.cand[atomicAdd(&Q.nc, 1)] = key;
+      }
+      __syncthreads();
+      if (wv == 0) {
+        const int nc = Q.nc;
+        const unsigned long long my = lane < nc ? Q.cand[lane] : ~0ull;
+        int lt = 0, eq = 0;
+        for (int j = 0; j < nc; j++) {
+          const unsigned long long c = Q.cand[j];
+          lt += c < my;
+          eq += c == my;
+        }
+        if (lane < nc && lt <= kk && kk < lt + eq) Q.result = my;
+      }
+      __syncthreads();
+      found = Q.result;
+      break;
+    }
+    Q.hist[tid] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += PP_NT) {
+      const double x = v[k];
+      if (x != x) continue;
+      const unsigned long long key = sel_key(x);
+      if (key >= lo && key - lo <= range)
+        atomicAdd(&Q.hist[(int)((key - lo) >> shift)], 1);
+    }
+    __syncthreads();
+    // inclusive prefix sum over the buckets (bucket == thread)
+    const int h = Q.hist[tid];
+    int inc = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) Q.wtot[wv] = inc;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wv; w++) off += Q.wtot[w];
+    inc += off;
+    if (inc - h <= kk && kk < inc) {  // exactly one thread
+      Q.bucket = tid;
+      Q.kk = kk - (inc - h);
+      Q.nc = h;
+    }
+    __syncthreads();
+    const int bsel = Q.bucket;
+    kk = Q.kk;
+    ncand = Q.nc;
+    lo += (unsigned long long)bsel << shift;
+    if (shift == 0) {  // buckets of one key
+      found = lo;
+      break;
+    }
+    range = (1ull << shift) - 1;
+    __syncthreads();  // Q.bucket / Q.kk / Q.nc are rewritten next round
+  }
+  double med = sel_value(found);
+  if (k_hi != k_lo) {
+    // the next order statistic: `found` again if it is repeated, else the
+    // smallest key above it
+    int nle = 0;
+    unsigned long long nx = ~0ull;
+    for (int k = tid; k < n; k += PP_NT) {
+      const double x = v[k];
+      if (x != x) continue;
+      const unsigned long long key = sel_key(x);
+      if (key <= found)
+        nle++;
+      else
+        nx = key < nx ? key : nx;
+    }
+    nle = wave_sum_i(nle);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long a = shfl_xor_u64(nx, o);
+      nx = a < nx ? a : nx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      Q.nle = 0;
+      Q.next = ~0ull;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      atomicAdd(&Q.nle, nle);
+      atomicMin(&Q.next, nx);
+    }
+    __syncthreads();
+    const double hi = (Q.nle >= k_hi + 1) ? med : sel_value(Q.next);
+    med = (med + hi) * 0.5;
+  }
+  __syncthreads();
+  return med;
+}
+
 __device__ __forceinline__ double median11(double *a) {
   // insertion sort of 11 values, return the 6th
 #pragma unroll
@@ -375,6 +575,7 @@ __global__ void __launch_bounds__(PP_NT)
   short *binkey = reinterpret_cast<short *>(hw + npix);       // [np2]
   uint8_t *msk = reinterpret_cast<uint8_t *>(binkey + np2);  // [npix]
   __shared__ LMShared S;
+  __shared__ SelShared Q;
   const int b = blockIdx.x, tid = threadIdx.x;
   const double *sp0 = spec + (int64_t)b * npix;
   const double *es0 = espec + (int64_t)b * npix;
@@ -396,22 +597,8 @@ __global__ void __launch_bounds__(PP_NT)
 
   // ---- nanmedian(espec) -----------------------------------------------------
   {
-    int cnt = 0;
-    for (int k = tid; k < np2; k += PP_NT) {
-      double v = __builtin_inf();
-      if (k < npix) {
-        const double e = ce[k];
-        if (e == e) {
-          v = e;
-          cnt++;
-        }
-      }
-      sb[k] = v;
-    }
-    cnt = wave_sum_i(cnt);
-    if ((tid & 63) == 0) atomicAdd(&S.nval, cnt);
-    bitonic_sort<false>(sb, nullptr, np2);
-    if (tid == 0) S.mederr = sorted_median(sb, S.nval);
+    const double me = block_median(ce, npix, true, Q);
+    if (tid == 0) S.mederr = me;
     __syncthreads();
   }
   const double mederr = S.mederr;
@@ -490,11 +677,8 @@ __global__ void __launch_bounds__(PP_NT)
   PP_T(1);  // gap filling
   // ---- median of the filled spectrum ----------------------------------------
   {
-    for (int k = tid; k < np2; k += PP_NT)
-      sb[k] = (k < npix) ? cs[k] : __builtin_inf();
-    bitonic_sort<false>(sb, nullptr, np2);
+    const double md = block_median(cs, npix, false, Q);
     if (tid == 0) {
-      double md = sorted_median(sb, npix);
       S.medv = md;
       double ms = md;
       if (ms <= 0) {
@@ -736,12 +920,12 @@ extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
   const int np2 = next_pow2(npix);
   const size_t shm = sizeof(double) * (3 * (size_t)npix + np2) +
                      sizeof(short) * np2 + ((npix + 15) / 16) * 16;
-  if (shm + sizeof(LMShared) > 159 * 1024) return RVS_E_ARG;
+  if (shm + sizeof(LMShared) + sizeof(SelShared) > 159 * 1024) return RVS_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)ccf_preprocess_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(159 * 1024 - sizeof(LMShared)));
+                              (int)(159 * 1024 - sizeof(LMShared) - sizeof(SelShared)));
     (void)hipGetLastError();
     attr_set = true;
   }

@@ -253,15 +253,16 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
   __syncthreads();
 }
 
+// (device form of rvs_ccf_fft_pos; the radices are powers of two: masks and
+// shifts -- with `%` and `/` by the run-time radix this was ~60 integer divisions
+// per thread of ccf_rfft_kernel, most of its time)
 __device__ __forceinline__ int fft_pos(int f, int log2n) {
-  int rad[8];
-  const int np = xc_plan(log2n, rad);
-  int pos = 0, m = 1 << log2n;
-  for (int p = 0; p < np; p++) {
-    const int q = f % rad[p];
-    f /= rad[p];
-    m /= rad[p];
-    pos += q * m;
+  int pos = 0, lgm = log2n;
+  while (lgm > 0) {
+    const int lgr = lgm >= 3 ? 3 : lgm;  // plan 8,8,...,(4|2)
+    lgm -= lgr;
+    pos += (f & ((1 << lgr) - 1)) << lgm;
+    f >>= lgr;
   }
   return pos;
 }

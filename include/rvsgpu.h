@@ -223,13 +223,13 @@ int rvs_chisq_full(const double *lam, const double *polysT, const double *spec,
 /* ------------------------------------------------------------------------
  * A13  get_chisq_continuum (spec_fit.py:739-783) for a whole batch of one arm:
  * continuum-only fit (template == 1), true chi^2 over pixels with badmask == 0
- * and their count.  One lane per spectrum, one wave per pixel slice; a Cholesky failure (numerically
+ * and their count.  One wave per spectrum, lanes = pixels; a Cholesky failure (numerically
  * singular basis) is flagged and gives NaN -- rvs_chisq_full(unit_template=1)
  * is the slower entry point with the eigen (SVD) fallback.
  * polysT [npix, npoly]; spec, espec [S, npix]; badmask uint8 [S, npix] (nullable)
  * unit_templ [S, npix] (nullable): R_s @ 1 when the spectra carry a resolution
  * matrix (spec_fit.py:765-767)
- * work: scratch of rvs_chisq_continuum_work_size(npoly, S) bytes
+ * work: unused since round 2 (nullable; rvs_chisq_continuum_work_size returns 8)
  * chisq [S] (-2 log L, nullable), true_chisq [S], ngood int32 [S]
  * ---------------------------------------------------------------------- */
 int64_t rvs_chisq_continuum_work_size(int npoly, int S);

@@ -1177,44 +1177,39 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
 
 // ---------------------------------------------------------------------------
 // A13: get_chisq_continuum for a whole batch (spec_fit.py:739-783): template == 1.
-// One LANE per spectrum (the basis row is wave-uniform -> scalar cache, exactly
-// as in chisq_grid_kernel) and one WAVE per (64 spectra, run of pixel slices):
-// pass 1 writes per-slice normal-equation partials, continuum_sum_kernel folds
-// them in slice order, pass 2 factors in-lane and accumulates the model residuals
-// of its slices over the unmasked pixels, pass 3 folds those.
-// work layout: part[slice][value][S] doubles, value < NV = P(P+1)/2 + P + 2,
-// then res[slice][2][S] (true chi^2 partial, good-pixel count), then tot[NV][S].
-// ---------------------------------------------------------------------------
-// The SUMS are sliced canonically: CONT_NC pixel slices whatever the batch, each
-// accumulated from zero and folded in slice order, so a spectrum's result is the
-// same bit for bit alone or among 10 000 others (tests/test_full_size.py).  Only
-// the number of waves sharing the slices of a 64-spectrum group depends on S.
-#define CONT_NC 32
-__host__ __device__ static inline int cont_nslice(int S) {
-  int groups = (S + 63) / 64;
-  int n = 2048 / groups;
-  return n < 1 ? 1 : (n > CONT_NC ? CONT_NC : n);
+// One WAVE per spectrum, lanes = pixels (k = lane, lane + 64, ...): the spectrum
+// rows are read coalesced, every lane keeps the P(P+1)/2 + P + 2 sums of its own
+// pixels, the wave folds them with DPP (wave_sum_to63) and broadcasts lane 63, all
+// lanes factor the P x P matrix, and a second sweep over the pixels forms the model
+// residuals of the unmasked pixels.  The order of every sum depends on the pixel
+// index only, so a spectrum's result is the same bit for bit alone or among 10 000
+// others (tests/test_full_size.py).  One launch.
+// (Round 1 had one LANE per spectrum and canonical pixel slices: four launches, every
+// load instruction touched 64 cache lines, 1.8 ms per DESI arm of 10 000 spectra.)
+__device__ __forceinline__ double wave_total(double v) {
+  const double t = wave_sum_to63(v);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), 63),
+                          __builtin_amdgcn_readlane(__double2loint(t), 63));
 }
 
 template <int P>
 __global__ void __launch_bounds__(64)
-    continuum_normal_kernel(const double *__restrict__ polysT,
-                            const double *__restrict__ spec,
-                            const double *__restrict__ espec,
-                            const double *__restrict__ unit_templ, int npix,
-                            int S, int nsl, double *__restrict__ part) {
+    continuum_wave_kernel(const double *__restrict__ polysT,
+                          const double *__restrict__ spec,
+                          const double *__restrict__ espec,
+                          const double *__restrict__ unit_templ,
+                          const uint8_t *__restrict__ badmask, int npix, int S,
+                          double *__restrict__ chisq,
+                          double *__restrict__ true_chisq,
+                          int32_t *__restrict__ ngood,
+                          int32_t *__restrict__ status) {
   constexpr int NT = P * (P + 1) / 2;
-  const int s0 = blockIdx.x * 64 + threadIdx.x;
-  const bool active = s0 < S;
-  const int s = active ? s0 : S - 1;
-  const int sl = blockIdx.y;
+  const int s = blockIdx.x, lane = threadIdx.x;
   const double *sp = spec + (int64_t)s * npix;
   const double *es = espec + (int64_t)s * npix;
+  const uint8_t *bm = badmask ? badmask + (int64_t)s * npix : nullptr;
   // A9: templ = R @ 1 (spec_fit.py:765-767) instead of 1
   const double *ut = unit_templ ? unit_templ + (int64_t)s * npix : nullptr;
-  for (int c = CONT_NC * sl / nsl; c < CONT_NC * (sl + 1) / nsl; c++) {
-  const int k0 = (int)((int64_t)npix * c / CONT_NC);
-  const int k1 = (int)((int64_t)npix * (c + 1) / CONT_NC);
   double acc[NT];
   double av[P];
 #pragma unroll
@@ -1222,7 +1217,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = 0;
   double lz = 0, dd = 0;
-  for (int k = k0; k < k1; k++) {
+  for (int k = lane; k < npix; k += 64) {
     const double e = es[k], x = sp[k];
     const double ie = 1.0 / e;
     const double tv = ut ? ut[k] : 1.0;
@@ -1230,65 +1225,25 @@ __global__ void __launch_bounds__(64)
     lz += log(e);
     dd = fma(x * ie, x * ie, dd);
     const double *pr = polysT + (int64_t)k * P;
-    double pw[P];
+    double prow[P], pw[P];
 #pragma unroll
-    for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
+    for (int i = 0; i < P; i++) prow[i] = pr[i];
+#pragma unroll
+    for (int i = 0; i < P; i++) pw[i] = prow[i] * w;
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      av[i] = fma(pr[i], u, av[i]);
+      av[i] = fma(prow[i], u, av[i]);
 #pragma unroll
       for (int jj = 0; jj <= i; jj++)
-        acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
+        acc[TRI(i, jj)] = fma(prow[i], pw[jj], acc[TRI(i, jj)]);
     }
   }
-  if (active) {
-    double *o = part + (int64_t)c * (NT + P + 2) * S + s;
 #pragma unroll
-    for (int i = 0; i < NT; i++) o[(int64_t)i * S] = acc[i];
+  for (int i = 0; i < NT; i++) acc[i] = wave_total(acc[i]);
 #pragma unroll
-    for (int i = 0; i < P; i++) o[(int64_t)(NT + i) * S] = av[i];
-    o[(int64_t)(NT + P) * S] = lz;
-    o[(int64_t)(NT + P + 1) * S] = dd;
-  }
-  }
-}
-
-// folds the CONT_NC slice partials of every (value, spectrum) in slice order
-__global__ void __launch_bounds__(256)
-    continuum_sum_kernel(const double *__restrict__ part, int64_t n,
-                         double *__restrict__ tot) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double a = 0;
-#pragma unroll 8
-  for (int q = 0; q < CONT_NC; q++) a += part[(int64_t)q * n + i];
-  tot[i] = a;
-}
-
-template <int P>
-__global__ void __launch_bounds__(64)
-    continuum_resid_kernel(const double *__restrict__ polysT,
-                           const double *__restrict__ spec,
-                           const double *__restrict__ espec,
-                           const double *__restrict__ unit_templ,
-                           const uint8_t *__restrict__ badmask, int npix, int S,
-                           int nsl, const double *__restrict__ tot,
-                           double *__restrict__ res, double *__restrict__ chisq,
-                           int32_t *__restrict__ status) {
-  constexpr int NT = P * (P + 1) / 2;
-  const int s0 = blockIdx.x * 64 + threadIdx.x;
-  const bool active = s0 < S;
-  const int s = active ? s0 : S - 1;
-  const int sl = blockIdx.y;
-  double acc[NT];
-  double av[P];
-  const double *o = tot + s;   // continuum_sum_kernel's [NV][S]
-#pragma unroll
-  for (int i = 0; i < NT; i++) acc[i] = o[(int64_t)i * S];
-#pragma unroll
-  for (int i = 0; i < P; i++) av[i] = o[(int64_t)(NT + i) * S];
-  const double lz = o[(int64_t)(NT + P) * S];
-  const double dd = o[(int64_t)(NT + P + 1) * S];
+  for (int i = 0; i < P; i++) av[i] = wave_total(av[i]);
+  lz = wave_total(lz);
+  dd = wave_total(dd);
   bool ok = true;
   double ldet = 0;
 #pragma unroll
@@ -1326,62 +1281,39 @@ __global__ void __launch_bounds__(64)
     for (int q = i + 1; q < P; q++) sum -= acc[TRI(q, i)] * av[q];
     av[i] = sum / acc[TRI(i, i)];
   }
-  const double *sp = spec + (int64_t)s * npix;
-  const double *es = espec + (int64_t)s * npix;
-  const uint8_t *bm = badmask ? badmask + (int64_t)s * npix : nullptr;
-  const double *ut = unit_templ ? unit_templ + (int64_t)s * npix : nullptr;
-  for (int c = CONT_NC * sl / nsl; c < CONT_NC * (sl + 1) / nsl; c++) {
-    const int k0 = (int)((int64_t)npix * c / CONT_NC);
-    const int k1 = (int)((int64_t)npix * (c + 1) / CONT_NC);
-    double tc = 0;
-    int ng = 0;
-    for (int k = k0; k < k1; k++) {
-      const double *pr = polysT + (int64_t)k * P;
-      double m = 0;
+  double tc = 0;
+  int ng = 0;
+  for (int k = lane; k < npix; k += 64) {
+    const double *pr = polysT + (int64_t)k * P;
+    double m = 0;
 #pragma unroll
-      for (int i = 0; i < P; i++) m = fma(av[i], pr[i], m);
-      if (ut) m *= ut[k];
-      const double dev = (m - sp[k]) / es[k];
-      const bool good = bm ? (bm[k] == 0) : true;
-      if (good) {
-        tc = fma(dev, dev, tc);
-        ng++;
-      }
-    }
-    if (active) {
-      res[((int64_t)c * 2 + 0) * S + s] = ok ? tc : __builtin_nan("");
-      res[((int64_t)c * 2 + 1) * S + s] = (double)ng;
+    for (int i = 0; i < P; i++) m = fma(av[i], pr[i], m);
+    if (ut) m *= ut[k];
+    const double dev = (m - sp[k]) / es[k];
+    const bool good = bm ? (bm[k] == 0) : true;
+    if (good) {
+      tc = fma(dev, dev, tc);
+      ng++;
     }
   }
-  if (!active) return;
-  if (sl == 0) {
-    int st = 0;
-    const double chi = 2.0 * ldet + 2.0 * lz + (dd - yy);
-    if (!ok) st |= RVS_ST_CHOL_FALLBACK;
-    if (!ok || !(fabs(chi) <= 1.79e308)) st |= RVS_ST_NONFINITE;
-    if (chisq) chisq[s] = chi;
-    if (st && status) atomicOr(&status[s], st);
-  }
-}
-
-__global__ void continuum_fold_kernel(const double *__restrict__ res, int S,
-                                      int nsl, double *__restrict__ true_chisq,
-                                      int32_t *__restrict__ ngood) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
-  double tc = 0, ng = 0;
-  for (int q = 0; q < nsl; q++) {
-    tc += res[((int64_t)q * 2 + 0) * S + s];
-    ng += res[((int64_t)q * 2 + 1) * S + s];
-  }
-  true_chisq[s] = tc;
-  ngood[s] = (int32_t)ng;
+  tc = wave_total(tc);
+  ng = wave_sum_i(ng);
+  if (lane != 0) return;
+  int st = 0;
+  const double chi = 2.0 * ldet + 2.0 * lz + (dd - yy);
+  if (!ok) st |= RVS_ST_CHOL_FALLBACK;
+  if (!ok || !(fabs(chi) <= 1.79e308)) st |= RVS_ST_NONFINITE;
+  if (chisq) chisq[s] = chi;
+  true_chisq[s] = ok ? tc : __builtin_nan("");
+  ngood[s] = ng;
+  if (st && status) atomicOr(&status[s], st);
 }
 
 extern "C" int64_t rvs_chisq_continuum_work_size(int npoly, int S) {
+  // (kept in the ABI; the one-wave-per-spectrum kernel needs no scratch: 8 bytes
+  // so that callers that allocate what this returns keep working)
   if (npoly < 1 || S < 1) return 0;
-  const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly + 2;
-  return ((int64_t)CONT_NC * (nv + 2) + nv) * S * (int64_t)sizeof(double);
+  return 8;
 }
 
 extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
@@ -1391,24 +1323,14 @@ extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
                                    double *chisq, double *true_chisq,
                                    int32_t *ngood, int32_t *status,
                                    void *stream) {
-  if (S < 1 || npix < 1 || !work) return RVS_E_ARG;
+  (void)work;
+  if (S < 1 || npix < 1 || !true_chisq || !ngood) return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
-  const int nsl = cont_nslice(S);
-  const int64_t nv = (int64_t)npoly * (npoly + 1) / 2 + npoly + 2;
-  double *part = (double *)work;
-  double *res = part + (int64_t)CONT_NC * nv * S;
-  double *tot = res + (int64_t)CONT_NC * 2 * S;
-  dim3 grid((S + 63) / 64, nsl);
-  const int64_t ntot = nv * S;
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \
-    hipLaunchKernelGGL(continuum_normal_kernel<PP>, grid, dim3(64), 0, st,     \
-                       polysT, spec, espec, unit_templ, npix, S, nsl, part);   \
-    hipLaunchKernelGGL(continuum_sum_kernel, dim3((ntot + 255) / 256),         \
-                       dim3(256), 0, st, part, ntot, tot);                     \
-    hipLaunchKernelGGL(continuum_resid_kernel<PP>, grid, dim3(64), 0, st,      \
-                       polysT, spec, espec, unit_templ, badmask, npix, S, nsl, \
-                       tot, res, chisq, status);                               \
+    hipLaunchKernelGGL(continuum_wave_kernel<PP>, dim3(S), dim3(64), 0, st,    \
+                       polysT, spec, espec, unit_templ, badmask, npix, S,      \
+                       chisq, true_chisq, ngood, status);                      \
     break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
@@ -1418,8 +1340,6 @@ extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
       return RVS_E_ARG;
   }
 #undef RVS_CASE
-  hipLaunchKernelGGL(continuum_fold_kernel, dim3((S + 255) / 256), dim3(256), 0,
-                     st, res, S, CONT_NC, true_chisq, ngood);
   RVS_LAUNCH_CHECK();
   return 0;
 }

@@ -745,7 +745,7 @@ def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
 
 def chisq_continuum(batch, npoly=5, rbf=True):
     """get_chisq_continuum for a batch: per arm dict(true_chisq [S], ngood [S],
-    status [S]) (rvs_chisq_continuum, one lane per spectrum).  Spectra whose
+    status [S]) (rvs_chisq_continuum, one wave per spectrum).  Spectra whose
     normal matrix is numerically singular are redone by rvs_chisq_full, which
     carries the eigen (SVD) fallback of spec_fit.py:337-354."""
     L = _lib.lib()
@@ -758,13 +758,11 @@ def chisq_continuum(batch, npoly=5, rbf=True):
         ngood = torch.empty(S, dtype=torch.int32, device=dev)
         status = torch.zeros(S, dtype=torch.int32, device=dev)
         if npoly <= 16:
-            nb = L.rvs_chisq_continuum_work_size(npoly, S)
-            work = torch.empty(nb // 8, dtype=torch.float64, device=dev)
             ut = arm.resol['unit'] if arm.resol is not None else None
             rc = L.rvs_chisq_continuum(_lib.ptr(polysT), _lib.ptr(arm.spec),
                                        _lib.ptr(arm.espec), _lib.ptr(arm.badmask),
                                        _lib.ptr(ut), arm.npix, npoly, S,
-                                       _lib.ptr(work), None,
+                                       None, None,
                                        _lib.ptr(tchi),
                                        _lib.ptr(ngood), _lib.ptr(status),
                                        _lib.stream())

@@ -483,7 +483,7 @@ def test_batch_equals_singles(cases, config):
 
 @pytest.mark.parametrize('S,npoly', [(131, 5), (64, 10), (3, 16)])
 def test_chisq_continuum_batched(S, npoly):
-    """rvs_chisq_continuum (lane per spectrum, pixel slices) against the oracle's
+    """rvs_chisq_continuum (one wave per spectrum) against the oracle's
     get_chisq_continuum on ragged batch sizes with masked pixels"""
     from rvspecfit_amd import engine, synth
     from rvspecfit_amd.engine import ArmData, SpecBatch

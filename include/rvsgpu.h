@@ -385,8 +385,8 @@ int rvs_ccf_preprocess(const double *lam, const double *spec,
  * twid complex128 [nfft/2]   exp(+2 pi i k / nfft)
  * lag_pos int32 [nlag]  position of lag n = subind[l] in the LDS image of the
  *         half-size inverse FFT viewed as doubles: with p = rvs_ccf_fft_pos(nfft,
- *         n>>1) (digit-reversed output order of the radix-8 DIF passes) and the
- *         9/8 padding, lag_pos = 2*(p + (p>>3)) + (n&1)
+ *         n>>1) (digit-reversed output order of the radix-8 DIF passes),
+ *         lag_pos = 2*p + (n&1)   (the image is not padded since round 2)
  * lag_vel float64 [nlag] ascending lag velocities (fitter_ccf.py:136-154)
  * ilo int32 [nvel], vgrid float64 [nvel]        linear-interp tables
  * chisq [B, T, nvel]: out = beta*out + interp(-2 c0 + c1) (continuum) or

@@ -11,8 +11,7 @@
 //      so every element is read once), the Hermitian pre-processing of the
 //      half-size inverse transform is done on the fly, then one N/2-point complex
 //      FFT in LDS: radix-8 decimation-in-frequency passes, one butterfly per
-//      thread per pass, 9/8-padded LDS image (conflict free for the stride-8 and
-//      stride-1 passes).  In continuum mode the reference's two
+//      thread per pass, un-padded LDS image followed by the passes' twiddles.  In continuum mode the reference's two
 //      inverse transforms collapse into ONE by linearity:
 //      -2 c0 + c1 = irfft(-2 F S* + F2 V*).  Only the ~100 lags inside +-max_vel
 //      are gathered (digit-reversed positions come from the host through
@@ -21,7 +20,15 @@
 #include "common.h"
 
 #define XC_NT 512
-#define XC_PAD(i) ((i) + ((i) >> 3))
+// LDS image of a transform: n2 complex points, un-padded (round 1 padded the index
+// 9/8 against bank conflicts of the stride-8^k passes; measured in round 2 the
+// padding -- 1/8, 1/16 or none -- changes nothing (51.9 vs 52.2 ms per step), and its
+// 8 KB now hold the butterfly twiddles), followed by
+// XC_NTW(n2) = n2/8 twiddles  T1[i] = exp(+2 pi i (2 i) / nfft):
+// every radix-8 pass reads its first twiddle w1 = T1[r << (tws - 1)] from LDS.  As
+// a global load after each barrier it cost ~8 % of the kernel (the 64 KB table
+// does not survive in L1 beside the operand stream).
+#define XC_NTW(n2) ((n2) >> 3)
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
   return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -138,7 +145,14 @@ extern "C" int rvs_dbg_read_xc(unsigned long long *out) {
 #define XC_T(i)
 #endif
 
-// in-place DIF transform of the padded LDS image a[] (n2 points)
+// T1 of the image a[] (see XC_NTW); visible after the next barrier
+template <int NT>
+__device__ __forceinline__ void xc_fill_twiddles(double2 *a, int n2,
+                                                 const double2 *__restrict__ tw) {
+  for (int i = threadIdx.x; i < XC_NTW(n2); i += NT) a[n2 + i] = tw[2 * i];
+}
+
+// in-place DIF transform of the LDS image a[] (n2 points)
 // prune (nullable): output masks for the LAST TWO passes when both are radix 8
 // (n2 a power of 8).  Only ~100 of the n2 outputs of the inverse transform are
 // ever read (the lags inside +-max_vel), so
@@ -151,6 +165,12 @@ template <int SIGN, int NT>
 __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
                         const uint8_t *__restrict__ prune = nullptr) {
   const int n2 = 1 << log2n, nfft = n2 << 1;
+  const double2 *T1 = a + n2;  // filled by xc_fill_twiddles before the first pass
+  auto tw1 = [&](int r, int tws) -> double2 {
+    double2 w = T1[r << (tws - 1)];
+    if (SIGN < 0) w.y = -w.y;
+    return w;
+  };
   int rad[8];
   const int np = xc_plan(log2n, rad);
   const bool pr = prune && np >= 2 && rad[np - 1] == 8 && rad[np - 2] == 8;
@@ -170,13 +190,13 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
         if (mask == 0) continue;
         double2 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = a[XC_PAD(base + Mp * j)];
+        for (int j = 0; j < 8; j++) v[j] = a[base + Mp * j];
         dft8<SIGN>(v);
         // the same product tree for the twiddle powers as the full pass, so
         // the stored values are bit-identical to it
         double2 wp[8];
         wp[0] = make_double2(1.0, 0.0);
-        wp[1] = twid<SIGN>(tw, r << tws, nfft);
+        wp[1] = tw1(r, tws);
         wp[2] = cmul(wp[1], wp[1]);
         wp[3] = cmul(wp[2], wp[1]);
         wp[4] = cmul(wp[2], wp[2]);
@@ -186,7 +206,7 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
 #pragma unroll
         for (int q = 0; q < 8; q++)
           if (mask & (1u << q))
-            a[XC_PAD(base + Mp * q)] = (q == 0) ? v[0] : cmul(v[q], wp[q]);
+            a[base + Mp * q] = (q == 0) ? v[0] : cmul(v[q], wp[q]);
         continue;
       }
       if (pr && p == np - 1) {  // M = 8, Mp = 1: no twiddles
@@ -194,23 +214,23 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
         if (mask == 0) continue;
         double2 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = a[XC_PAD(base + j)];
+        for (int j = 0; j < 8; j++) v[j] = a[base + j];
         dft8<SIGN>(v);
 #pragma unroll
         for (int q = 0; q < 8; q++)
-          if (mask & (1u << q)) a[XC_PAD(base + q)] = v[q];
+          if (mask & (1u << q)) a[base + q] = v[q];
         continue;
       }
       if (R == 8) {
         double2 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = a[XC_PAD(base + Mp * j)];
+        for (int j = 0; j < 8; j++) v[j] = a[base + Mp * j];
         dft8<SIGN>(v);
         if (Mp > 1) {
           // powers of w1 generated and consumed one at a time (short live
           // ranges: 3 complex instead of 7); every power is a product of at most
           // two squarings/multiplications of table values
-          const double2 w1 = twid<SIGN>(tw, r << tws, nfft);
+          const double2 w1 = tw1(r, tws);
           v[1] = cmul(v[1], w1);
           const double2 w2 = cmul(w1, w1);
           v[2] = cmul(v[2], w2);
@@ -224,10 +244,10 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
           v[6] = cmul(v[6], cmul(w4, w2));  // w6
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++) a[XC_PAD(base + Mp * q)] = v[q];
+        for (int q = 0; q < 8; q++) a[base + Mp * q] = v[q];
       } else if (R == 4) {
-        double2 v0 = a[XC_PAD(base)], v1 = a[XC_PAD(base + Mp)],
-                v2 = a[XC_PAD(base + 2 * Mp)], v3 = a[XC_PAD(base + 3 * Mp)];
+        double2 v0 = a[base], v1 = a[base + Mp],
+                v2 = a[base + 2 * Mp], v3 = a[base + 3 * Mp];
         dft4<SIGN>(v0, v1, v2, v3);
         if (Mp > 1) {
           const double2 w1 = twid<SIGN>(tw, r << tws, nfft);
@@ -236,16 +256,16 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
           v2 = cmul(v2, w2);
           v3 = cmul(v3, w3);
         }
-        a[XC_PAD(base)] = v0;
-        a[XC_PAD(base + Mp)] = v1;
-        a[XC_PAD(base + 2 * Mp)] = v2;
-        a[XC_PAD(base + 3 * Mp)] = v3;
+        a[base] = v0;
+        a[base + Mp] = v1;
+        a[base + 2 * Mp] = v2;
+        a[base + 3 * Mp] = v3;
       } else {
-        const double2 v0 = a[XC_PAD(base)], v1 = a[XC_PAD(base + Mp)];
+        const double2 v0 = a[base], v1 = a[base + Mp];
         double2 d = csub(v0, v1);
         if (Mp > 1) d = cmul(d, twid<SIGN>(tw, r << tws, nfft));
-        a[XC_PAD(base)] = cadd(v0, v1);
-        a[XC_PAD(base + Mp)] = d;
+        a[base] = cadd(v0, v1);
+        a[base + Mp] = d;
       }
     }
     lgM = lgMp;
@@ -277,6 +297,7 @@ __global__ void __launch_bounds__(XC_NT)
   const int n2 = nfft >> 1;
   const double *ps = proc_spec + (int64_t)b * nfft;
   const double *pi = proc_ivar + (int64_t)b * nfft;
+  xc_fill_twiddles<XC_NT>(fa, n2, tw);
   for (int n = tid; n < n2; n += XC_NT) {
     double x0, x1;
     if (which == 0) {
@@ -286,7 +307,7 @@ __global__ void __launch_bounds__(XC_NT)
       x0 = pi[2 * n];
       x1 = pi[2 * n + 1];
     }
-    fa[XC_PAD(n)] = make_double2(x0, x1);
+    fa[n] = make_double2(x0, x1);
   }
   fft_lds<-1, XC_NT>(fa, log2n, tw);
   double2 *out = work + ((int64_t)b * 2 + which) * (n2 + 1);
@@ -296,8 +317,8 @@ __global__ void __launch_bounds__(XC_NT)
       const double2 z0 = fa[0];
       X = make_double2(k == 0 ? z0.x + z0.y : z0.x - z0.y, 0.0);
     } else {
-      const double2 zk = fa[XC_PAD(fft_pos(k, log2n))];
-      const double2 zm = fa[XC_PAD(fft_pos(n2 - k, log2n))];
+      const double2 zk = fa[fft_pos(k, log2n)];
+      const double2 zm = fa[fft_pos(n2 - k, log2n)];
       const double2 e = make_double2(zk.x + zm.x, zk.y - zm.y);   // zk + conj(zm)
       const double2 d = make_double2(zk.x - zm.x, zk.y + zm.y);   // zk - conj(zm)
       const double2 q = cmul(twid<-1>(tw, k, nfft), d);
@@ -329,7 +350,7 @@ __global__ void __launch_bounds__(XB_NT)
                      double *__restrict__ chisq) {
   extern __shared__ double2 fa[];
   const int n2 = nfft >> 1, npair = n2 >> 1;
-  double *c0 = reinterpret_cast<double *>(fa + XC_PAD(n2) + 1);  // [nlag]
+  double *c0 = reinterpret_cast<double *>(fa + n2 + XC_NTW(n2));  // [nlag]
   double *c1 = c0 + nlag;                                        // [nlag]
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const double2 *Sc = work + ((int64_t)b * 2) * (n2 + 1);
@@ -338,6 +359,7 @@ __global__ void __launch_bounds__(XB_NT)
   const double2 *F2 = tfft2 + (int64_t)t * (n2 + 1);
   const double inv_n = 1.0 / nfft;
   const int npass = continuum ? 1 : 2;
+  xc_fill_twiddles<XB_NT>(fa, n2, tw);
 #ifdef RVS_XC_TIMING
   unsigned long long t_prev = wall_clock64();
 #endif
@@ -421,8 +443,8 @@ __global__ void __launch_bounds__(XB_NT)
           const double2 d = make_double2(Xk.x - Xm.x, Xk.y + Xm.y);
           const double2 q = cmul(op[u][8], d);
           if (live[u]) {
-            fa[XC_PAD(k)] = make_double2(e.x - q.y, e.y + q.x);
-            if (m != k) fa[XC_PAD(m)] = make_double2(e.x + q.y, -e.y + q.x);
+            fa[k] = make_double2(e.x - q.y, e.y + q.x);
+            if (m != k) fa[m] = make_double2(e.x + q.y, -e.y + q.x);
           }
         }
       }
@@ -450,8 +472,8 @@ __global__ void __launch_bounds__(XB_NT)
         const double2 d = make_double2(Xk.x - Xm.x, Xk.y + Xm.y);  // Xk - conj Xm
         const double2 q = cmul(tw[k], d);
         // Z[k] = e + i q ; Z[m] = conj(e) + i conj(q)  (m == k: both the same)
-        fa[XC_PAD(k)] = make_double2(e.x - q.y, e.y + q.x);
-        if (m != k) fa[XC_PAD(m)] = make_double2(e.x + q.y, -e.y + q.x);
+        fa[k] = make_double2(e.x - q.y, e.y + q.x);
+        if (m != k) fa[m] = make_double2(e.x + q.y, -e.y + q.x);
       }
     }
     XC_T(0);  // operand stream + products + Hermitian fold into LDS
@@ -501,7 +523,7 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
   if ((2 << log2n) != nfft || nfft < 64 || nfft > 16384) return RVS_E_ARG;
   if (B < 1 || T < 1 || T > 65535 || nlag < 2 || nvel < 1) return RVS_E_ARG;
   const int n2 = nfft >> 1;
-  const size_t shm1 = sizeof(double2) * (size_t)(XC_PAD(n2) + 1);
+  const size_t shm1 = sizeof(double2) * (size_t)(n2 + XC_NTW(n2));
   const size_t shm2 = shm1 + sizeof(double) * 2 * (size_t)nlag;
   if (shm2 > 159 * 1024) return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);

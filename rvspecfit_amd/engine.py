@@ -231,7 +231,7 @@ class ArmData:
         pos = np.array([L.rvs_ccf_fft_pos(nfft, int(n) >> 1) for n in ind],
                        dtype=np.int64)
         T['lag_pos'] = torch.as_tensor(
-            (2 * (pos + (pos >> 3)) + (ind & 1)).astype(np.int32)).to(dev)
+            (2 * pos + (ind & 1)).astype(np.int32)).to(dev)
         # output masks of the last two radix-8 passes (rvs_ccf_xcorr `prune`):
         # only these lags are read back from the inverse transform
         n2 = nfft // 2

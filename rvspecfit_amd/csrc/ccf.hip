@@ -819,7 +819,10 @@ __global__ void __launch_bounds__(PP_NT)
           if (tid == 0) {
             for (int i = 0; i < m; i++) S.c[i] = S.cn[i];
             S.lamd = fmax(S.lamd / 8, 1e-12);
-            if (mx < 1e-11 || rel < 1e-15) S.stop = 1;
+            // converged: the accepted step moved no coefficient (log flux) by
+            // 1e-9 or lowered the cost by less than 1e-12 of itself -- four orders
+            // inside least_squares' own ftol = xtol = 1e-8 (make_ccf.py:146-150)
+            if (mx < 1e-9 || rel < 1e-12) S.stop = 1;
           }
           cost = cn;
           break;

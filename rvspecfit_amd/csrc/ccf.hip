@@ -804,14 +804,20 @@ __global__ void __launch_bounds__(PP_NT)
         __syncthreads();
         if (S.stop) break;
       }
-      // damped step; retry with larger damping until the cost does not grow
+      // damped step; retry with larger damping until the cost does not grow.
+      // The trial evaluation leaves its Gauss-Newton weights in gw / hw: they are
+      // read by the NEXT iteration's lm_normal only (a retry re-solves the banded
+      // system in S), so an accepted trial needs no second evaluation -- one
+      // pass over the pixels less per iteration, same values.
+      bool accepted = false;
       for (int tries = 0; tries < 40; tries++) {
         if (tid < 64) lm_band_solve(S, m);
         PP_T(9);  // (debug) band solve
         const double cn =
-            lm_eval(S, S.cn, Eb, El, npix, cs, ce, gw, hw, false, px);
+            lm_eval(S, S.cn, Eb, El, npix, cs, ce, gw, hw, true, px);
         PP_T(10);  // (debug) trial evaluation
         if (cn <= cost) {  // accept (block-uniform decision)
+          accepted = true;
           double mx = 0;
           for (int i = 0; i < m; i++) mx = fmax(mx, fabs(S.dl[i]));
           const double rel = (cost - cn) / fmax(cost, 1e-300);
@@ -837,8 +843,9 @@ __global__ void __launch_bounds__(PP_NT)
       }
       __syncthreads();
       if (S.stop) break;
-      cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true, px);
-      PP_T(11);  // (debug) accept + evaluation with weights
+      if (!accepted)  // (40 rejected trials: the weights of the kept point again)
+        cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true, px);
+      PP_T(11);  // (debug) accept
     }
     __syncthreads();
     if (pfit && tid < m) {

@@ -534,8 +534,9 @@ def main():
     tr_ccf, src_ccf = pmc_traffic('ccf_xcorr')
     roof = dict(bound='fp64_valu', kernel='chisq_grid_kernel',
                 timed='rvs_chisq_grid call = chisq_grid_kernel<10,false> (full '
-                      'waves) + <10,true> (packed left-over velocities), HIP '
-                      'events on the launch stream',
+                      'waves) + <10,true> (packed left-over velocities, side '
+                      'stream, joined before the call returns), HIP events '
+                      'on the launch stream around the call',
                 achieved=round(grid_tflops, 2), peak=FP64_PEAK_TF,
                 unit='TFLOP/s', frac=round(grid_tflops / FP64_PEAK_TF, 4),
                 traffic=tr_grid, traffic_source=src_grid,

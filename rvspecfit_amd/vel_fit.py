@@ -644,10 +644,11 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
 
     config['second_minimizer'] (default True in utils.read_config, as in the
     reference) adds scipy's BFGS restated in bfgs.py (host state per spectrum,
-    batched objective).  Deviation, flagged in the result:
-    * numdifftools is replaced by its central-difference rule at ONE step,
-      base_step * max(log1p|x|, 1) (numdifftools is absent from the build
-      image: parity of param_err is unpinned)."""
+    batched objective).  The Hessian is numdifftools' (vel_fit.py:713-716)
+    restated in numdiff.py: MinStepGenerator(base_step) -> one central step;
+    the step=None retry of rows with a bad Hessian -> 15 steps, Richardson +
+    Wynn extrapolation; every displacement pattern is one batched objective
+    call (param_err pinned to 1e-3: test_param_uncertainties_at_reference_optimum)."""
     from . import neldermead
     if config is None:
         raise RuntimeError('Config must be provided')

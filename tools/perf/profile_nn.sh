@@ -16,7 +16,7 @@ import csv, glob, json, collections
 f = glob.glob('/tmp/pmcnn_${tag}/**/*counter_collection.csv', recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
-    if 'nn_linear_kernel' not in r['Kernel_Name']:
+    if 'nn_linear_kernel' not in r['Kernel_Name'] and 'nn_hidden_kernel' not in r['Kernel_Name']:
         continue
     k = r['Kernel_Name'].split('(')[0]
     agg[k][r['Counter_Name']].append(float(r['Counter_Value']))

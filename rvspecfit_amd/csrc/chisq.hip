@@ -248,9 +248,11 @@ __device__ __forceinline__ void
   // way of writing it), four need 186 VGPRs,
   // this loop unrolled twice 171 (2 waves/SIMD either way).
   int k = 0;
-  // (packed waves take one pixel per trip: the per-lane spectrum terms of two
-  // pixels in flight would cost the third wave per SIMD)
-  for (; !TAIL && k + 1 < npix; k += 2) {
+  // (packed waves, P <= 10: two pixels per trip as well -- 190 VGPRs, two waves per
+  // SIMD; they run beside the full-wave launch (launch_grid), where what counts is
+  // how long they hold their slots: 34.1 -> 32.9 ms per arm of 10 000 spectra.
+  // P > 10: one pixel per trip)
+  for (; (!TAIL || P <= 10) && k + 1 < npix; k += 2) {
     double xa, xb;
     const int pa = knot_of(k, xa), pb = knot_of(k + 1, xb);
     const double ka = knots[pa], kb = knots[pb];
@@ -346,7 +348,7 @@ template <int P, bool TAIL>
 // strategy -- the scalar loads at the head of a trip are then issued and waited
 // for one by one, 36.0 against 33.2 ms per 10 000 spectra)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(
-    TAIL ? CG_WAVES(P) : (P <= 10 ? 2 : 1))))
+    TAIL ? (P <= 10 ? 2 : CG_WAVES(P)) : (P <= 10 ? 2 : 1))))
     chisq_grid_kernel(const double *__restrict__ lam,
                       const double *__restrict__ polysT,
                       const double *__restrict__ work, int npix, int S,

@@ -50,33 +50,6 @@ __device__ void bitonic_sort(double *v, short *bin, int n2) {
   __syncthreads();
 }
 
-// wave-local bitonic sort of 256 doubles (4 per lane) in a wave-private LDS
-// segment: no block barrier -- the LDS operations of one wave execute in order,
-// the fence only stops the compiler from moving them across a stage
-__device__ void wave_bitonic256(double *v) {
-  const int lane = threadIdx.x & 63;
-  for (int k = 2; k <= 256; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int t = lane + 64 * h;  // pair index 0..127
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int ixj = i | j;
-        const double a = v[i], b = v[ixj];
-        const bool up = ((i & k) == 0);
-        if (up ? (b < a) : (a < b)) {
-          v[i] = b;
-          v[ixj] = a;
-        }
-      }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // numpy median of the first n sorted values (mean of the middle two if even)
 __device__ __forceinline__ double sorted_median(const double *s, int n) {
   if (n <= 0) return __builtin_nan("");
@@ -281,6 +254,54 @@ __device__ double block_median(const double *v, int n, bool skipnan,
     med = (med + hi) * 0.5;
   }
   __syncthreads();
+  return med;
+}
+
+// numpy median of up to 256 values held four per lane (x[h] = element lane + 64 h,
+// valid while lane + 64 h < cnt) by ONE wave, no LDS: bisection on the key bits
+// -- the k-th smallest key is the largest p with #{key < p} <= k, found bit by bit
+// with four compares and four ballot counts per bit.  (As a wave-local bitonic
+// sort in LDS this was 72 dependent LDS round trips per bin.)  NaN in the bin ->
+// NaN, as np.median.
+__device__ __forceinline__ double wave_median256(const double (&x)[4], int cnt) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long key[4];
+  bool anynan = false;
+#pragma unroll
+  for (int h = 0; h < 4; h++) {
+    const bool valid = lane + 64 * h < cnt;
+    anynan |= valid && (x[h] != x[h]);
+    key[h] = valid ? sel_key(x[h]) : ~0ull;
+  }
+  if (cnt <= 0 || __ballot(anynan) != 0ull) return __builtin_nan("");
+  const int k_lo = (cnt - 1) >> 1, k_hi = cnt >> 1;
+  // (the padding keys ~0 are never below a trial value, so they never count)
+  unsigned long long p = 0;
+  for (int bit = 63; bit >= 0; bit--) {
+    const unsigned long long trial = p | (1ull << bit);
+    int c = 0;
+#pragma unroll
+    for (int h = 0; h < 4; h++) c += __popcll(__ballot(key[h] < trial));
+    if (c <= k_lo) p = trial;
+  }
+  double med = sel_value(p);
+  if (k_hi != k_lo) {
+    int cle = 0;
+    unsigned long long nx = ~0ull;
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      const bool valid = lane + 64 * h < cnt;
+      cle += __popcll(__ballot(valid && key[h] <= p));
+      if (valid && key[h] > p && key[h] < nx) nx = key[h];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long a = shfl_xor_u64(nx, o);
+      nx = a < nx ? a : nx;
+    }
+    const double hi = (cle >= k_hi + 1) ? med : sel_value(nx);
+    med = (med + hi) * 0.5;
+  }
   return med;
 }
 
@@ -701,26 +722,23 @@ __global__ void __launch_bounds__(PP_NT)
     bool small = true;
     for (int jb = 0; jb < m; jb++)
       if (bin_start[jb + 1] - bin_start[jb] > 256) small = false;
-    if (small && np2 >= PP_NW * 256) {
+    if (small) {
       const int lane = tid & 63, wv = tid >> 6;
-      double *seg = sb + wv * 256;
       for (int jb = wv; jb < m; jb += PP_NW) {
         const int b0 = bin_start[jb], cnt = bin_start[jb + 1] - b0;
+        double x[4];
 #pragma unroll
         for (int h = 0; h < 4; h++) {
           const int q = lane + 64 * h;
-          seg[q] = (q < cnt) ? cs[b0 + q] : __builtin_inf();
+          x[h] = (q < cnt) ? cs[b0 + q] : 0.0;
         }
-        wave_bitonic256(seg);
+        const double stat = wave_median256(x, cnt);
         if (lane == 0) {
-          double stat = sorted_median(seg, cnt);
           double p0 = log(fmax(stat, 1e-3 * S.medspec));
           if (!(stat == stat)) p0 = nanv;  // np.maximum propagates NaN
           if (!(fabs(p0) <= 1.79e308)) p0 = log(S.medspec);
           S.p[jb] = p0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
       }
     } else {
       for (int k = tid; k < np2; k += PP_NT) {

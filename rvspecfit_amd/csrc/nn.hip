@@ -240,11 +240,11 @@ __global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
 // rows (parameter vectors) and walks through the layers with the activations in
 // LDS (two [32][260] float images, ping-pong); each of its eight waves computes 32
 // output columns (one MFMA tile) and takes its B operand
-// -- four consecutive k of one row of W per lane -- straight from global memory
+// -- sixteen consecutive k of one row of W per lane and 32-k chunk -- straight from global memory
 // (the weights, 256 KB per layer, live in L2 and are read by every block): no
-// staging of W, no barrier inside a layer, the loads of the next k group in
-// flight under the MFMAs of the current one.  Same k permutation as
-// nn_linear_kernel (lower half-wave k = g + j, upper k = g + 4 + j).
+// staging of W, no barrier inside a layer, the loads of the next chunk in
+// flight under the MFMAs of the current one (lower half-wave k = G .. G + 15,
+// upper G + 16 .. G + 31: whole 128-byte lines per wave instruction).
 // The first layer (K = ndim) is a few FMAs per output and runs on the VALU.
 // Requirements (checked by the launcher, else layer by layer): every width of
 // the fused layers <= 256 and a multiple of 32 from the second layer on.

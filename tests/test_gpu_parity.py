@@ -312,6 +312,58 @@ def test_chisq_continuum(cases, config, tag):
                                cases[tag + '/cont/redchisq_array'], rtol=1e-8)
 
 
+@pytest.mark.parametrize('variant', ['quantised', 'plateau', 'inf_errors',
+                                     'odd_even', 'negative'])
+def test_ccf_preprocess_median_selection(cases, config, gold_libs, variant):
+    """the medians of preprocess_data come from selection (key histograms over
+    the block, bisection on the key bits per bin), not from sorts: inputs where
+    that is delicate -- long runs of equal values, +inf errors inside
+    nanmedian, odd and even counts, negative medians -- against the oracle"""
+    from rvspecfit_amd import spec_fit, spec_inter, engine
+    rng = np.random.RandomState(3)
+    sds = _sds(cases, 'c1')
+    osds = gold_specdata(cases, 'c1', orc.SpecData)
+    new, onew = [], []
+    for sd, osd in zip(sds, osds):
+        spec, espec = np.array(osd.spec), np.array(osd.espec)
+        bad = np.array(osd.badmask)
+        n = len(spec)
+        if variant == 'quantised':        # ~20 distinct flux values, 5 distinct errors
+            q = np.median(spec) / 10
+            spec = np.round(spec / q) * q
+            espec = np.round(espec / np.median(espec) * 2 + 0.5) * np.median(espec) / 2
+        elif variant == 'plateau':        # half the arm exactly constant
+            spec[n // 4:3 * n // 4] = np.median(spec)
+            espec[:] = np.median(espec)
+        elif variant == 'inf_errors':     # nanmedian keeps +inf (then masked)
+            espec[rng.choice(n, n // 3, replace=False)] = np.inf
+        elif variant == 'odd_even':       # drop one pixel: the other parity of n
+            spec, espec, bad = spec[:-1], espec[:-1], bad[:-1]
+        elif variant == 'negative':       # sky-subtracted noise: negative medians
+            spec = spec - 1.2 * np.median(spec)
+        lam = np.array(osd.lam)[:len(spec)]
+        new.append(spec_fit.SpecData(sd.name, lam, spec, espec, badmask=bad))
+        onew.append(orc.SpecData(osd.name, lam, spec, espec, badmask=bad))
+    b, _ = spec_fit.as_batch(new)
+    libs = spec_inter.get_libs(b.names, config)
+    for arm, osd in zip(b.arms, onew):
+        if variant == 'odd_even' and arm.npix != len(osd.lam):
+            pytest.skip('the CCF tables of the golden setup fix npix')
+        pre = engine.ccf_preprocess(arm, libs[arm.name], config, details=True)
+        ps, pi, info = orc.preprocess_data(osd.lam, osd.spec, osd.espec,
+                                           gold_libs[osd.name].ccf,
+                                           badmask=osd.badmask, details=True)
+        gps = pre['proc_spec'][0].cpu().numpy()
+        gpi = pre['proc_ivar'][0].cpu().numpy()
+        np.testing.assert_array_equal(gpi == 0, pi == 0)
+        np.testing.assert_array_equal(np.isfinite(gps), np.isfinite(ps))
+        ok = np.isfinite(ps)
+        np.testing.assert_allclose(pre['cont'][0].cpu().numpy(), info['cont'],
+                                   rtol=5e-6)
+        np.testing.assert_allclose(gps[ok], ps[ok], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(gpi, pi, rtol=2e-5)
+
+
 @pytest.mark.parametrize('tag', TAGS)
 def test_ccf(cases, config, gold_libs, gold_config, tag):
     from rvspecfit_amd import fitter_ccf, spec_fit, spec_inter, engine

@@ -305,6 +305,31 @@ __device__ __forceinline__ double wave_median256(const double (&x)[4], int cnt) 
   return med;
 }
 
+// the 6th smallest of 11 values without NaN: the 28 compare-exchanges of the
+// optimal 11-input sorting network (35, 8 layers) that the middle output depends
+// on (checked exhaustively with the 0-1 principle); straight-line min / max
+__device__ __forceinline__ double median11_net(const double *w) {
+  double a[11];
+#pragma unroll
+  for (int i = 0; i < 11; i++) a[i] = w[i];
+#define CE(i, j)                         \
+  {                                      \
+    const double lo_ = fmin(a[i], a[j]); \
+    a[j] = fmax(a[i], a[j]);             \
+    a[i] = lo_;                          \
+  }
+  CE(0, 9) CE(1, 6) CE(2, 4) CE(3, 7) CE(5, 8)
+  CE(0, 1) CE(3, 5) CE(4, 10) CE(6, 9) CE(7, 8)
+  CE(1, 3) CE(2, 5) CE(4, 7) CE(8, 10)
+  CE(0, 4) CE(1, 2) CE(3, 7) CE(5, 9) CE(6, 8)
+  CE(2, 6) CE(4, 5) CE(7, 8)
+  CE(2, 4) CE(3, 6) CE(5, 7)
+  CE(3, 4) CE(5, 6)
+  CE(4, 5)
+#undef CE
+  return a[5];
+}
+
 __device__ __forceinline__ double median11(double *a) {
   // insertion sort of 11 values, return the 6th
 #pragma unroll
@@ -633,7 +658,12 @@ __global__ void __launch_bounds__(PP_NT)
         const int idx = k + q - 5;
         w[q] = (idx >= 0 && idx < npix) ? cs[idx] : 0.0;  // zero padded
       }
-      const double med = median11(w);
+      // (a window that holds a NaN keeps the comparison order of the insertion
+      // sort; everywhere else the middle value does not depend on the method)
+      bool hasnan = false;
+#pragma unroll
+      for (int q = 0; q < 11; q++) hasnan |= (w[q] != w[q]);
+      const double med = hasnan ? median11(w) : median11_net(w);
       if ((ce[k] > maxerr * mederr) || (med <= 0)) msk[k] = 1;
     }
   }

@@ -23,7 +23,13 @@ for r in csv.DictReader(open(f)):
 out = {}
 for k, v in agg.items():
     busy = sum(v['SQ_VALU_MFMA_BUSY_CYCLES']); gui = sum(v['GRBM_GUI_ACTIVE'])
+    # per launch, median over the launches (one launch of a counter pass now and
+    # then shows a GRBM_GUI_ACTIVE several times the others': first touch of pages)
+    per = sorted(b / (g / 8 * 1024) for b, g in
+                 zip(v['SQ_VALU_MFMA_BUSY_CYCLES'], v['GRBM_GUI_ACTIVE']) if g)
     out[k] = dict(launches=len(v['GRBM_GUI_ACTIVE']),
+                  mfma_util_median_launch=per[len(per) // 2] if per else None,
+                  mfma_util_per_launch=[round(x, 4) for x in per],
                   mfma_busy_cycles=busy, mfma_mops_f32=sum(v['SQ_INSTS_VALU_MFMA_MOPS_F32']),
                   grbm_gui_active_sum_over_8_xcds=gui,
                   # MfmaUtil of rocprofv3's derived metrics: busy cycles over

@@ -818,7 +818,10 @@ __global__ void __launch_bounds__(PP_NT)
       S.c[tid] = s;
     }
     if (tid == 0) {
-      S.lamd = 1e-3;
+#ifndef RVS_LM_LAMBDA0
+#define RVS_LM_LAMBDA0 1e-3
+#endif
+      S.lamd = RVS_LM_LAMBDA0;
       S.stop = 0;
     }
     LMPix px[LM_PIX];

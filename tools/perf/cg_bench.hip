@@ -66,6 +66,27 @@ int main(int argc, char **argv) {
     if (r) { best = fminf(best, ms); sum += ms; }
   }
   if (rc) { printf("grid rc %d\n", rc); return 1; }
+  if (argc > 6) {   // three arms: one stream after another vs three streams, separate outputs
+    const int ns = atoi(argv[6]);
+    hipStream_t st[3]; double *o3[3]; hipEvent_t ev[3];
+    for (int a = 0; a < 3; a++) { hipStreamCreateWithFlags(&st[a], hipStreamNonBlocking); hipMalloc(&o3[a], vels.size() * 8); hipEventCreateWithFlags(&ev[a], hipEventDisableTiming); }
+    float b3 = 1e30f;
+    for (int r = 0; r < reps + 1; r++) {
+      hipDeviceSynchronize();
+      hipEventRecord(e0, st[0]);
+      for (int a = 0; a < 3; a++) {
+        hipStream_t s = st[ns == 1 ? 0 : a];
+        if (ns > 1 && a) { hipStreamWaitEvent(s, e0, 0); }
+        rvs_chisq_grid(d_lam, d_polys, d_work, npix, P, S, d_knots, d_coef, ntp, own ? S : 1, 1, nullptr, own ? nullptr : d_jt, S,
+                       d_vels, Nv, Nv, nullptr, 1e5, 0.0, pack, o3[a], d_st, s);
+        if (ns > 1 && a) { hipEventRecord(ev[a], s); hipStreamWaitEvent(st[0], ev[a], 0); }
+      }
+      hipEventRecord(e1, st[0]); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (r) b3 = fminf(b3, ms);
+    }
+    printf("three arms on %d stream(s): best %.3f ms\n", ns, b3);
+  }
   std::vector<double> out(vels.size());
   hipMemcpy(out.data(), d_out, out.size() * 8, hipMemcpyDeviceToHost);
   uint64_t h = 1469598103934665603ull; double tot = 0; int nan = 0;

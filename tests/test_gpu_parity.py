@@ -533,14 +533,16 @@ def test_batch_equals_singles(cases, config):
         np.testing.assert_array_equal(rec[i], one[0])
 
 
-@pytest.mark.parametrize('S,npoly', [(131, 5), (64, 10), (3, 16)])
-def test_chisq_continuum_batched(S, npoly):
-    """rvs_chisq_continuum (one wave per spectrum) against the oracle's
-    get_chisq_continuum on ragged batch sizes with masked pixels"""
+@pytest.mark.parametrize('S,npoly,npix', [(131, 5, 777), (64, 10, 777),
+                                          (3, 16, 777), (5, 3, 37), (2, 10, 64),
+                                          (2, 7, 129)])
+def test_chisq_continuum_batched(S, npoly, npix):
+    """rvs_chisq_continuum (one wave per spectrum, lanes over pixels) against the
+    oracle's get_chisq_continuum on ragged batch sizes with masked pixels; rows
+    shorter than a wave, exactly a wave, one pixel more than two waves"""
     from rvspecfit_amd import engine, synth
     from rvspecfit_amd.engine import ArmData, SpecBatch
     rng = np.random.RandomState(5 + S)
-    npix = 777
     lam = np.linspace(4000., 5000., npix)
     spec = 1 + 0.3 * rng.normal(size=(S, npix)) + np.linspace(0, 1, npix)
     espec = rng.uniform(0.1, 0.5, size=(S, npix))

@@ -1402,6 +1402,74 @@ def test_xcorr_pruned_passes(gpu):
     assert float((out[True][2] - out[False][2]).abs().max()) < 1e-9
 
 
+@pytest.mark.parametrize('continuum', [1, 0])
+@pytest.mark.parametrize('nfft', [64, 128, 256, 512, 1024, 2048, 4096, 8192,
+                                  16384])
+def test_xcorr_every_plan_vs_numpy(gpu, nfft, continuum):
+    """rvs_ccf_xcorr straight through the C-ABI against numpy's rfft / irfft
+    (fitter_ccf.py:126-161, 189-216) for every transform size the entry point
+    accepts: the pass plans 8,8 / 8,8,2 / 8,8,4 / 8,8,8 / ... with their radix-4
+    and radix-2 tails, the twiddle table in LDS at each size, pruned (n2 a power
+    of 8) and full last passes, both CCF modes"""
+    from rvspecfit_amd import _lib, ccf_tables
+    L = _lib.lib()
+    rng = np.random.RandomState(nfft + continuum)
+    B, T, n2 = 3, 5, nfft // 2
+    spec = 1 + 0.2 * rng.standard_normal((B, nfft))
+    ivar = rng.uniform(0.5, 2.0, (B, nfft))
+    tmod = 1 + 0.3 * rng.standard_normal((T, nfft))
+    tfft, tfft2 = np.fft.rfft(tmod, axis=1), np.fft.rfft(tmod**2, axis=1)
+    # lags and velocity grid as fitter_ccf builds them (a window of +-7 lags)
+    step = 10.0
+    maxvel = 6.5 * step
+    off = nfft // 2
+    vels = -((np.arange(nfft) + off) % nfft - off) * step
+    sel = np.abs(vels) < (maxvel + step)
+    ind = np.roll(np.nonzero(sel)[0], sel.sum() // 2)[::-1]
+    sub = np.ascontiguousarray(vels[ind])
+    assert np.all(np.diff(sub) > 0)
+    vgrid = np.linspace(-maxvel, maxvel, 41)
+    ilo = ccf_tables.interp_tables(sub, vgrid)
+    pos = np.array([L.rvs_ccf_fft_pos(nfft, int(n) >> 1) for n in ind])
+    lag_pos = (2 * pos + (ind & 1)).astype(np.int32)
+    prune = None
+    l2 = n2.bit_length() - 1
+    if l2 % 3 == 0 and l2 >= 6:
+        pm = np.zeros(n2 // 64 + n2 // 8, dtype=np.uint8)
+        for p_ in pos:
+            pm[n2 // 64 + (int(p_) >> 3)] |= 1 << (int(p_) & 7)
+            pm[int(p_) >> 6] |= 1 << ((int(p_) >> 3) & 7)
+        prune = torch.as_tensor(pm).to('cuda')
+    dev = dict(device='cuda')
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to('cuda')
+    twid = np.exp(2j * np.pi * np.arange(n2) / nfft)
+    t_spec, t_ivar, t_f, t_f2 = d(spec), d(ivar), d(tfft), d(tfft2)
+    t_tw, t_lp, t_lv, t_ilo, t_vg = d(twid), d(lag_pos), d(sub), d(ilo), d(vgrid)
+    out = torch.full((B, T, len(vgrid)), 7.0, dtype=torch.float64, **dev)
+    work = torch.empty((B, 2, n2 + 1), dtype=torch.complex128, **dev)
+    for beta in (0.0, 1.0):     # second call accumulates (the next arm)
+        rc = L.rvs_ccf_xcorr(_lib.ptr(t_spec), _lib.ptr(t_ivar), nfft, B,
+                             _lib.ptr(t_f), _lib.ptr(t_f2), T, _lib.ptr(t_tw),
+                             continuum, _lib.ptr(t_lp), _lib.ptr(t_lv), len(sub),
+                             _lib.ptr(t_ilo), _lib.ptr(t_vg), len(vgrid), beta,
+                             _lib.ptr(prune), _lib.ptr(out), _lib.ptr(work),
+                             _lib.stream())
+        assert rc == 0
+    got = out.cpu().numpy()
+    S = np.conj(np.fft.rfft(spec * ivar, axis=1))
+    V = np.conj(np.fft.rfft(ivar, axis=1))
+    for b in range(B):
+        for t in range(T):
+            c0 = np.fft.irfft(tfft[t] * S[b], nfft)[ind]
+            c1 = np.fft.irfft(tfft2[t] * V[b], nfft)[ind]
+            y = (-2 * c0 + c1) if continuum else (-c0**2 / c1)
+            lo = ilo
+            ref = (y[lo + 1] - y[lo]) / (sub[lo + 1] - sub[lo]) * \
+                (vgrid - sub[lo]) + y[lo]
+            np.testing.assert_allclose(got[b, t], 2 * ref, rtol=1e-9,
+                                       atol=1e-9 * np.abs(ref).max())
+
+
 def test_reference_test_fit_nn_sequence(gpu):
     """tests/test_fit_nn.py of the reference with the NN evaluator (the golden
     network of nn_case.npz): a flat spectrum of pure noise, process with vsini

@@ -605,6 +605,29 @@ def test_chisq_grid_wave_placement_bit_identical(cases, config):
         np.testing.assert_array_equal(grid(vg[:69], npoly, 1), ragged[:, :69])
         # more than 32 left over: never packed
         np.testing.assert_array_equal(grid(vg[-40:], npoly, 1), ragged[:, -40:])
+    # The packed launch runs on a library-owned side stream per host thread:
+    # two host threads, each on a torch stream of its own, at the same time
+    import threading
+    want = {k: grid(vg + 0.37 * k, 10, 1) for k in range(2)}
+    got, errs = {}, []
+
+    def run(k):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):
+                    got[k] = grid(vg + 0.37 * k, 10, 1)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+    keep_pack = engine.CG_PACK_MIN_JOBS
+    th = [threading.Thread(target=run, args=(k, )) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    engine.CG_PACK_MIN_JOBS = keep_pack   # (grid() saves / restores it per call)
+    assert not errs, errs
+    for k in range(2):
+        np.testing.assert_array_equal(got[k], want[k])
 
 
 def _nn_lib(d, lam):

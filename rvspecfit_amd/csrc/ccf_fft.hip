@@ -161,9 +161,33 @@ __device__ __forceinline__ void xc_fill_twiddles(double2 *a, int n2,
 //              stored: 1-2 writes and twiddles instead of 8 and 7),
 //   pass np-1: prune[n2/64 + grp]  bit q set -> output q of 8-group grp is needed
 //              (groups with an empty mask are skipped: ~64 of 512 remain).
+// a thread's share of the output masks, fetched by the caller ahead of the operand
+// stream (a load right before the passes is an exposed L2 round trip per block):
+// g = mask of 8-group threadIdx.x, b0 / b7 = masks of the first and last 8-group
+// of 64-block threadIdx.x >> 3 (every n2 that can be pruned -- 64, 512, 4096 --
+// has at most NT such groups and NT / 8 such blocks)
+struct XcMasks {
+  unsigned g, b0, b7;
+};
+template <int NT>
+__device__ __forceinline__ XcMasks xc_load_masks(const uint8_t *__restrict__ prune,
+                                                 int n2) {
+  XcMasks m = {0u, 0u, 0u};
+  if (prune && (n2 >> 3) <= NT) {
+    const int t = threadIdx.x, B = t >> 3;
+    if (t < (n2 >> 3)) m.g = prune[(n2 >> 6) + t];
+    if (B < (n2 >> 6)) {
+      m.b0 = prune[(n2 >> 6) + 8 * B];
+      m.b7 = prune[(n2 >> 6) + 8 * B + 7];
+    }
+  }
+  return m;
+}
+
 template <int SIGN, int NT>
 __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
-                        const uint8_t *__restrict__ prune = nullptr) {
+                        const uint8_t *__restrict__ prune = nullptr,
+                        const XcMasks *pm = nullptr) {
   const int n2 = 1 << log2n, nfft = n2 << 1;
   const double2 *T1 = a + n2;  // filled by xc_fill_twiddles before the first pass
   auto tw1 = [&](int r, int tws) -> double2 {
@@ -174,14 +198,67 @@ __device__ void fft_lds(double2 *a, int log2n, const double2 *__restrict__ tw,
   int rad[8];
   const int np = xc_plan(log2n, rad);
   const bool pr = prune && np >= 2 && rad[np - 1] == 8 && rad[np - 2] == 8;
+  // The lags inside +-max_vel are a few dozen outputs either side of zero: of every
+  // 64-block that enters the last two passes only frequency 0 (position 0) or 63
+  // (position 63) is read back -- X[0] = sum_n y[n], X[63] = sum_n y[n] W64^(63 n).
+  // When the masks say so (checked here, one 8-group per thread), the two pruned
+  // passes collapse into one without a barrier in between: eight lanes per block,
+  // lane s takes y[s + 8 j], j < 8, through the radix-8 butterfly (outputs 0 and
+  // 7 are what the masked pass np-2 kept), applies W64^(63 s) from the twiddle
+  // table and the eight lanes are summed with DPP -- instead of a store, a
+  // barrier, and a last pass in which one wave of eight worked.
+  bool fold = false;
+  const bool can_fold = pr && pm && (n2 >> 3) <= NT;
   int lgM = log2n;
   for (int p = 0; p < np; p++) {
+    if (can_fold && p == 0) {
+      // (the first pass's barrier doubles as the block-wide vote)
+      const int pos8 = threadIdx.x & 7;
+      const unsigned m = pm->g;
+      const bool bad =
+          m != 0 && !((pos8 == 0 && m == 0x01u) || (pos8 == 7 && m == 0x80u));
+      fold = !__syncthreads_or(bad);
+    }
+    if (fold && p == np - 2) {
+      __syncthreads();
+      const int s = threadIdx.x & 7;
+      for (int B = threadIdx.x >> 3; B < (n2 >> 6); B += NT >> 3) {
+        const unsigned m0 = pm->b0 & 1u, m63 = pm->b7 >> 7;
+        if (!(m0 | m63)) continue;   // (uniform over the eight lanes of a block)
+        double2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = a[B * 64 + s + 8 * j];
+        dft8<SIGN>(v);
+        // W64^(63 s) = conj(W64^s), W64^s = exp(SIGN 2 pi i s (nfft/64) / nfft)
+        double2 w = T1[s << (log2n - 6)];
+        if (SIGN > 0) w.y = -w.y;
+        double2 x63 = cmul(v[7], w), x0 = v[0];
+        // sum over the eight lanes: xor 1, xor 2 (quad_perm), mirror of 8
+        auto sum8 = [](double x) {
+          x += dpp_get<0xb1, 0xf, 0xf>(x);    // quad_perm [1,0,3,2]
+          x += dpp_get<0x4e, 0xf, 0xf>(x);    // quad_perm [2,3,0,1]
+          x += dpp_get<0x141, 0xf, 0xf>(x);   // row_half_mirror
+          return x;
+        };
+        if (m0) {
+          x0.x = sum8(x0.x);
+          x0.y = sum8(x0.y);
+          if (s == 0) a[B * 64] = x0;
+        }
+        if (m63) {
+          x63.x = sum8(x63.x);
+          x63.y = sum8(x63.y);
+          if (s == 0) a[B * 64 + 63] = x63;
+        }
+      }
+      break;
+    }
     // every size is a power of two: shifts, not the ~30-instruction integer
     // divisions a runtime divisor costs each thread in each pass
     const int R = rad[p], lgR = (R == 8) ? 3 : (R == 4 ? 2 : 1);
     const int lgMp = lgM - lgR, Mp = 1 << lgMp;
     const int tws = log2n + 1 - lgM;  // twiddle stride nfft / M = 1 << tws
-    __syncthreads();
+    if (!(can_fold && p == 0)) __syncthreads();
     for (int u = threadIdx.x; u < (n2 >> lgR); u += NT) {
       const int blk = u >> lgMp, r = u & (Mp - 1);
       const int base = (blk << lgM) + r;
@@ -360,6 +437,7 @@ __global__ void __launch_bounds__(XB_NT)
   const double inv_n = 1.0 / nfft;
   const int npass = continuum ? 1 : 2;
   xc_fill_twiddles<XB_NT>(fa, n2, tw);
+  const XcMasks pmask = xc_load_masks<XB_NT>(prune, n2);
 #ifdef RVS_XC_TIMING
   unsigned long long t_prev = wall_clock64();
 #endif
@@ -477,7 +555,7 @@ __global__ void __launch_bounds__(XB_NT)
       }
     }
     XC_T(0);  // operand stream + products + Hermitian fold into LDS
-    fft_lds<1, XB_NT>(fa, log2n, tw, prune);
+    fft_lds<1, XB_NT>(fa, log2n, tw, prune, &pmask);
     XC_T(1);  // the four radix-8 passes
     const double *fr = reinterpret_cast<const double *>(fa);
     double *dst = (pass == 0) ? c0 : c1;

@@ -145,11 +145,26 @@ extern "C" int rvs_dbg_read_xc(unsigned long long *out) {
 #define XC_T(i)
 #endif
 
-// T1 of the image a[] (see XC_NTW); visible after the next barrier
+// T1 of the image a[] (see XC_NTW); visible after the next barrier.
+// LDS-DMA (global_load_lds_dwordx4: no register, nothing to wait for until that
+// barrier) when a whole number of waves covers the table: as `load; wait;
+// ds_write` at the top of the kernel the fill cost every wave an L2 round trip
+// before its first operand load.  Wave w writes T1[64 w .. 64 w + 63]: the LDS
+// destination of a DMA is wave-uniform base + lane x 16 bytes.
 template <int NT>
 __device__ __forceinline__ void xc_fill_twiddles(double2 *a, int n2,
                                                  const double2 *__restrict__ tw) {
-  for (int i = threadIdx.x; i < XC_NTW(n2); i += NT) a[n2 + i] = tw[2 * i];
+  const int ntw = XC_NTW(n2);
+  if ((ntw & 63) == 0) {
+    const int lane = threadIdx.x & 63;
+    for (int i0 = (threadIdx.x >> 6) * 64; i0 < ntw; i0 += NT) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(tw + 2 * (i0 + lane)),
+          (__attribute__((address_space(3))) void *)(a + n2 + i0), 16, 0, 0);
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < ntw; i += NT) a[n2 + i] = tw[2 * i];
 }
 
 // in-place DIF transform of the LDS image a[] (n2 points)
@@ -437,7 +452,7 @@ __global__ void __launch_bounds__(XB_NT)
   const double inv_n = 1.0 / nfft;
   const int npass = continuum ? 1 : 2;
   xc_fill_twiddles<XB_NT>(fa, n2, tw);
-  const XcMasks pmask = xc_load_masks<XB_NT>(prune, n2);
+  XcMasks pmask = xc_load_masks<XB_NT>(prune, n2);
 #ifdef RVS_XC_TIMING
   unsigned long long t_prev = wall_clock64();
 #endif
@@ -450,15 +465,16 @@ __global__ void __launch_bounds__(XB_NT)
   const bool pre = (nlag <= XB_NT) && (nvel <= XB_NT);
   int pre_pos = 0, pre_lo = 0;
   double pre_x0 = 0, pre_x1 = 1, pre_xg = 0, pre_old = 0;
+  // (clamped indices, not branches: a conditional load into a register that has
+  // another definition is waited for at the join.  The second level of the
+  // interpolation table, lag_vel[pre_lo], follows after the operand loop: asked
+  // for here it made every wave wait for ilo before its first operand load)
   if (pre) {
-    if (tid < nlag) pre_pos = lag_pos[tid];
-    if (tid < nvel) {
-      pre_lo = ilo[tid];
-      pre_x0 = lag_vel[pre_lo];
-      pre_x1 = lag_vel[pre_lo + 1];
-      pre_xg = vgrid[tid];
-      if (beta != 0.0) pre_old = out[tid];
-    }
+    const int tv = min(tid, nvel - 1);
+    pre_pos = lag_pos[min(tid, nlag - 1)];
+    pre_lo = ilo[tv];
+    pre_xg = vgrid[tv];
+    pre_old = out[tv];   // (used with beta != 0 only)
   }
   for (int pass = 0; pass < npass; pass++) {
     if (continuum) {
@@ -553,6 +569,15 @@ __global__ void __launch_bounds__(XB_NT)
         fa[k] = make_double2(e.x - q.y, e.y + q.x);
         if (m != k) fa[m] = make_double2(e.x + q.y, -e.y + q.x);
       }
+    }
+    if (pass == 0 && pre) {
+      // (the fetched-ahead values are "defined" here for the compiler: left free
+      // it hoists the first trivial operation on each -- a mask bit, a sign
+      // extension -- to right behind the load and waits there)
+      asm volatile("" : "+v"(pre_pos), "+v"(pre_lo));
+      asm volatile("" : "+v"(pmask.g), "+v"(pmask.b0), "+v"(pmask.b7));
+      pre_x0 = lag_vel[pre_lo];
+      pre_x1 = lag_vel[pre_lo + 1];
     }
     XC_T(0);  // operand stream + products + Hermitian fold into LDS
     fft_lds<1, XB_NT>(fa, log2n, tw, prune, &pmask);

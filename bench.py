@@ -75,15 +75,26 @@ def nn_weights(ntp, seed):
     return d
 
 
-def build_library_dicts(ccf_every, convolve):
-    """Synthetic DESI-shape template libraries (7^4 grid, 6215/5303/6449 px,
-    N_fft 8192) in the converted-artefact dict layout."""
+def ccf_every_for(ccf_every, ngrid):
+    """--ccf-every is quoted for the 7^4 grid (64 -> T = 76, 9 -> T = 534); a
+    grid of another size keeps the same NUMBER of CCF templates"""
+    n0 = 7**4
+    nsel = -(-n0 // ccf_every)
+    return max(1, -(-ngrid // nsel)) if ngrid != n0 else ccf_every
+
+
+def build_library_dicts(ccf_every, convolve, device=None):
+    """Synthetic DESI-shape template libraries (7^4 grid unless --grid,
+    6215/5303/6449 px, N_fft 8192) in the converted-artefact dict layout.
+    `device`: synthesise the grid rows there (float32 device tensor)."""
     out = {}
     for a in ARMS:
         l0, l1, st = arm_def(a)['templ']
         lib = synth.make_interp_library_fast(arm_name(a), l0, l1, st,
-                                             grid_kw=GRID_KW, resol=RESOL)
-        ccf = synth.make_ccf_templates(lib, l0, l1, st, every=ccf_every,
+                                             grid_kw=GRID_KW, resol=RESOL,
+                                             device=device)
+        every = ccf_every_for(ccf_every, lib['dats'].shape[0])
+        ccf = synth.make_ccf_templates(lib, l0, l1, st, every=every,
                                        vsinis=(0., 300.), convolve=convolve)
         out[arm_name(a)] = synth.library_as_npz_dict(lib, ccf)
         if EVALUATOR == 'nn':
@@ -207,6 +218,8 @@ def run_cpu_baseline(arms, n, args, start=None):
            '--ccf-every', str(args.ccf_every), '--cpu-cores',
            str(args.cpu_cores), '--workload', args.workload, '--evaluator',
            args.evaluator]
+    if args.grid:
+        cmd += ['--grid', args.grid]
     if start is not None:
         cmd.append('--cpu-process')
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -355,14 +368,24 @@ def main():
     ap.add_argument('--evaluator', choices=['polylinear', 'nn'],
                     default='polylinear',
                     help='nn: BASELINE configs[3], MLP template evaluator on MFMA')
+    ap.add_argument('--grid', type=str, default='',
+                    help='template grid nodes per dimension "nteff,nlogg,nfeh,'
+                         'nalpha" (default 7,7,7,7 = 60 MB/arm, Infinity-Cache '
+                         'resident); 40,11,8,5 = 17 600 templates, 440 MB/arm: a '
+                         'library of realistic size, dimensions of different '
+                         'length, gathers served from HBM')
     ap.add_argument('--dry-launch', action='store_true',
                     help='with --gpus N: every rank prints the environment it '
                          'was started with and exits (no GPU, no torch)')
     args = ap.parse_args()
-    global ARMS, EVALUATOR
+    global ARMS, EVALUATOR, GRID_KW
     if args.workload == 'cfg2':
         ARMS = ('c', )
     EVALUATOR = args.evaluator
+    if args.grid:
+        g = [int(_) for _ in args.grid.split(',')]
+        assert len(g) == 4 and min(g) >= 2, '--grid needs four sizes >= 2'
+        GRID_KW = dict(nteff=g[0], nlogg=g[1], nfeh=g[2], nalpha=g[3])
     if args.cpu_worker:
         return cpu_worker(args)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -411,7 +434,8 @@ def main():
         return engine.convolve_vsini(lam, t, v).cpu().numpy()
 
     t_setup = time.time()
-    dicts = build_library_dicts(args.ccf_every, gpu_convolve)
+    dicts = build_library_dicts(args.ccf_every, gpu_convolve,
+                                device=dev if args.grid else None)
     for name, d in dicts.items():
         spec_inter.register_library(TemplateLibrary(name, d, device=dev),
                                     CONFIG['template_lib'])
@@ -486,6 +510,42 @@ def main():
     pipeline.fit_batch(batch, CONFIG, options=OPTIONS, timers=timers)
     torch.cuda.synchronize()
     stage = {k: v[0].elapsed_time(v[1]) for k, v in timers.items()}
+
+    # ---- the polylinear gather on its own (A3), at every spectrum's OWN
+    # parameters: the step above evaluates templates at the CCF nodes (38
+    # distinct cells, cache resident whatever the library size); the optimiser
+    # stage and a first-guess grid evaluate them anywhere in the grid, i.e.
+    # 16 rows per job scattered over the whole library
+    gather = None
+    if EVALUATOR == 'polylinear' and rank == 0:
+        ptrue = torch.as_tensor(np.stack(
+            [tp[k] for k in ('teff', 'logg', 'feh', 'alpha')], axis=1)).to(dev)
+        gb, gms = 0.0, 0.0
+        for a in ARMS:
+            lib = spec_inter.get_libs([arm_name(a)], CONFIG)[arm_name(a)]
+            lib.eval_batch(ptrue)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                lib.eval_batch(ptrue)
+            e1.record()
+            torch.cuda.synchronize()
+            gms += e0.elapsed_time(e1) / 3
+            # algorithmic bytes: 16 float32 rows in, one float64 template out
+            gb += S * lib.ntp * (16 * 4 + 8)
+        gather = dict(ms_per_batch=round(gms, 3),
+                      alg_GBps=round(gb / (gms * 1e-3) / 1e9, 1),
+                      frac_of_hbm_peak=round(gb / (gms * 1e-3) / 1e9
+                                             / HBM_PEAK_GBS, 4),
+                      library_MB_per_arm=[round(
+                          dicts[arm_name(a)]['dats'].shape[0]
+                          * len(dicts[arm_name(a)]['lam']) * 4 / 1e6, 1)
+                          for a in ARMS],
+                      note='rvs_template_polylinear at the %d spectra\'s own '
+                           '(random in-grid) parameters, all arms; bytes = 16 '
+                           'float32 rows read + one float64 template written '
+                           'per job' % S)
 
     if rank != 0:
         if world > 1:
@@ -568,6 +628,8 @@ def main():
                            alg_GBps=round(grid_gbs, 2),
                            fp64_TFLOPs=round(grid_tflops, 2)),
     }
+    if gather is not None:
+        kernels['template_polylinear'] = gather
     if 'ccf_preprocess' in kt:
         kernels['ccf_preprocess'] = dict(
             ms_per_step=round(kt['ccf_preprocess'][1] / args.steps, 2))
@@ -631,14 +693,17 @@ def main():
         warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 2),
         higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
         data='synthetic',
-        config=dict(workload='%s, %d spectra per GPU per step, %s evaluator, 7^4 '
+        config=dict(workload='%s, %d spectra per GPU per step, %s evaluator, %s '
                              'grid, T=%d CCF templates, N_fft=%d, 400-velocity '
                              'chi2 grid, npoly=10' % (
                                  'DESI b/r/z 3-arm (2751/2326/2881 px) (BASELINE '
                                  'configs[%d])' % (3 if EVALUATOR == 'nn' else 2)
                                  if args.workload == 'desi' else
                                  '1 arm 4000-5000 A 2001 px (BASELINE configs[1])',
-                                 S, EVALUATOR, Tccf, nfft),
+                                 S, EVALUATOR,
+                                 'x'.join(str(GRID_KW[k]) for k in (
+                                     'nteff', 'nlogg', 'nfeh', 'nalpha')),
+                                 Tccf, nfft),
                     spectra_per_gpu=S, ccf_templates=Tccf, nfft=nfft,
                     refine=bool(args.refine),
                     resolution_matrix=bool(args.resolution_matrix),

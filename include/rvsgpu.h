@@ -42,7 +42,15 @@ extern "C" {
 #define RVS_ST_QUAD_ASSERT 0x80   /* parabola vertex outside its bracket (spec_fit.py:1014 assert)  */
 #define RVS_ST_ILLCOND 0x100      /* rvs_chisq_grid: normal matrix pivots span > 1e9 (long stretch of weightless pixels); re-evaluate the job with rvs_chisq_point */
 
-/* library version / build probe (host). */
+/* library version / build probe (host).  RVS_ABI_VERSION changes whenever the
+ * meaning of an argument, a status bit or a work-size formula changes; a caller
+ * compares rvs_abi_version() with the header it was built against
+ * (rvspecfit_amd/_lib.py refuses a stale librvsgpu.so).
+ *   2: status bit 0x100 = RVS_ST_ILLCOND; rvs_chisq_grid's int after `beta` is
+ *      pack_min_jobs; rvs_chisq_continuum_work_size = 8 doubles per spectrum
+ *   3: rvs_template_polylinear / rvs_objective_arm take `ptp` (the query is
+ *      p / ptp as in spec_inter.py:130-132), not its reciprocal */
+#define RVS_ABI_VERSION 3
 int rvs_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -58,7 +66,7 @@ int rvs_abi_version(void);
  * uvecs     float64 [sum(lens)]   concatenated unique mapped grid values
  * lens      int32   [ndim] (host)
  * vecs_s    float64 [ngrid, ndim] grid points divided by ptp (KD-tree space)
- * inv_ptp   float64 [ndim] (host) 1/ptp per dimension
+ * ptp       float64 [ndim] (host) np.ptp(vec, axis=1): the query is p / ptp
  * log_mask  bit i set -> parameter i is mapped through log10
  * params    float64 [B, ndim]     physical parameters
  * templ     float64 [B, ntp]  out  exp'ed template
@@ -71,7 +79,7 @@ int rvs_abi_version(void);
 int rvs_template_polylinear(const float *dats, int64_t ngrid, int ntp,
                             const int64_t *idgrid, const double *uvecs,
                             const int32_t *lens, int ndim, const double *vecs_s,
-                            const double *inv_ptp, uint32_t log_mask,
+                            const double *ptp, uint32_t log_mask,
                             int exp_flag, const double *params, int B,
                             double *templ, double *outside, int32_t *cellinfo,
                             double *weights, void *stream);
@@ -300,7 +308,7 @@ typedef struct rvs_objective_arm {
   const double *uvecs, *vecs_s, *factors;
   int64_t ngrid;
   double lnstep;
-  double inv_ptp[6];
+  double ptp[6];
   int32_t lens[6];
   int32_t ntp, ndim;
   uint32_t log_mask;

@@ -69,6 +69,8 @@ SIGNATURES = {
 }
 
 _lib = None
+# RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
+ABI_VERSION = 3
 
 
 class RvsGpuError(RuntimeError):
@@ -89,6 +91,11 @@ def lib():
             fn = getattr(L_, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if L_.rvs_abi_version() != ABI_VERSION:
+            raise RvsGpuError(
+                '%s is ABI version %d, this package binds version %d: rebuild it '
+                '(make -C rvspecfit_amd/csrc)' % (LIB_PATH, L_.rvs_abi_version(),
+                                                   ABI_VERSION))
         _lib = L_
     return _lib
 
@@ -130,7 +137,7 @@ class ObjectiveArm(ctypes.Structure):
                 ('idgrid', ctypes.c_void_p), ('uvecs', ctypes.c_void_p),
                 ('vecs_s', ctypes.c_void_p), ('factors', ctypes.c_void_p),
                 ('ngrid', ctypes.c_int64), ('lnstep', ctypes.c_double),
-                ('inv_ptp', ctypes.c_double * 6), ('lens', ctypes.c_int32 * 6),
+                ('ptp', ctypes.c_double * 6), ('lens', ctypes.c_int32 * 6),
                 ('ntp', ctypes.c_int32), ('ndim', ctypes.c_int32),
                 ('log_mask', ctypes.c_uint32), ('exp_flag', ctypes.c_int32)]
 

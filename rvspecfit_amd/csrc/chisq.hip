@@ -308,8 +308,9 @@ __device__ __forceinline__ void
   // a template that vanishes over part of the arm -- takes that away: the
   // pivots then span > 1e9 and D.D - y.y loses the 1e-6 of the contract without
   // any pivot turning negative.  Such jobs are flagged; the caller re-evaluates
-  // them with rvs_chisq_point (raw basis, explicit residual, Cholesky + eigen
-  // tiers: exact to 1e-13 there, tests/test_edge_cases.py).
+  // them with rvs_chisq_point (raw basis, explicit residual, in-lane Cholesky:
+  // exact to 1e-13 there, tests/test_edge_cases.py) and, where that cannot
+  // factor either, with rvs_chisq_full (the eigen tier of spec_fit.py:337-354).
   if (ok && pmin < 1e-9 * pmax) st |= RVS_ST_ILLCOND;
   double yy = 0;
 #pragma unroll
@@ -1778,4 +1779,4 @@ extern "C" int rvs_grid_moments(const double *chisq, const double *vels,
   return 0;
 }
 
-extern "C" int rvs_abi_version(void) { return 1; }
+extern "C" int rvs_abi_version(void) { return RVS_ABI_VERSION; }

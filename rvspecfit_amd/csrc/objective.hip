@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       G.lens[d] = T.lens[d];
       G.uoff[d] = off;
       off += T.lens[d];
-      G.inv_ptp[d] = T.inv_ptp[d];
+      G.ptp[d] = T.ptp[d];
     }
     int64_t st = 1;
     for (int d = nd - 1; d >= 0; d--) {

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256)
 extern "C" int rvs_template_polylinear(
     const float *dats, int64_t ngrid, int ntp, const int64_t *idgrid,
     const double *uvecs, const int32_t *lens, int ndim, const double *vecs_s,
-    const double *inv_ptp, uint32_t log_mask, int exp_flag,
+    const double *ptp, uint32_t log_mask, int exp_flag,
     const double *params, int B, double *templ, double *outside,
     int32_t *cellinfo, double *weights, void *stream) {
   if (ndim < 1 || ndim > MAXDIM || B < 1 || ntp < 1) return RVS_E_ARG;
@@ -112,7 +112,7 @@ extern "C" int rvs_template_polylinear(
     G.lens[d] = lens[d];
     G.uoff[d] = off;
     off += lens[d];
-    G.inv_ptp[d] = inv_ptp[d];
+    G.ptp[d] = ptp[d];
   }
   int64_t st = 1;
   for (int d = ndim - 1; d >= 0; d--) {

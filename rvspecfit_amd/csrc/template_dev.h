@@ -9,7 +9,7 @@ struct GridDesc {
   int lens[MAXDIM];
   int uoff[MAXDIM];       // offset of dimension d in the concatenated uvecs
   int64_t gstride[MAXDIM];  // C-order strides of idgrid
-  double inv_ptp[MAXDIM];
+  double ptp[MAXDIM];
   uint32_t log_mask;
 };
 
@@ -108,14 +108,20 @@ __device__ void poly_locate(PolyLoc &L, const GridDesc &G,
   const int mode = L.mode;
   if (mode == 1) {
     double q[MAXDIM];
-    for (int d = 0; d < nd; d++) q[d] = L.mp[d] * G.inv_ptp[d];
+    // cKDTree.query(p / ptp) (spec_inter.py:130-132): a DIVISION, so that the
+    // distances of equidistant nodes tie (or not) exactly as the reference's do
+    for (int d = 0; d < nd; d++) q[d] = L.mp[d] / G.ptp[d];
     double bd = __builtin_inf();
     int bi = 0x7fffffff;
     for (int64_t g = tid; g < ngrid; g += NT) {
       double d2 = 0;
       for (int d = 0; d < nd; d++) {
+        // separately rounded square and sum (no fma): equidistant nodes compare
+        // equal and the first one wins
+#pragma clang fp contract(off)
         const double df = vecs_s[g * nd + d] - q[d];
-        d2 += df * df;
+        const double sq = df * df;
+        d2 = d2 + sq;
       }
       if (d2 < bd) {
         bd = d2;

@@ -1189,7 +1189,15 @@ def _select_rank_device(environ=None):
     import torch
     idx = int(lr)
     n = torch.cuda.device_count()
-    if n > 0:
+    if n > 0 and idx >= n:
+        # more ranks than visible GPUs: sharing a device silently would hide a
+        # launcher mistake; same opt-in as bench.py
+        if not environ.get('RVS_SHARE_GPU'):
+            raise RuntimeError(
+                'LOCAL_RANK=%d but only %d GPU(s) are visible; set '
+                'RVS_SHARE_GPU=1 to let ranks share a device' % (idx, n))
+        logging.warning('LOCAL_RANK=%d shares GPU %d (RVS_SHARE_GPU)', idx,
+                        idx % n)
         idx %= n
     torch.cuda.set_device(idx)
     return idx

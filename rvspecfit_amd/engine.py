@@ -439,6 +439,29 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
                 rbf=rbf, job_spec=js2[a:b], job_templ=jt2[a:b],
                 espec_sys=espec_sys, outside_penalty=outside_penalty,
                 resols=resols)
+        # third tier (spec_fit.py:337-354: Cholesky failed -> SVD): the point
+        # kernel factors in-lane by Cholesky only, so what it could not factor
+        # either goes through rvs_chisq_full, which carries the eigen branch
+        bad = torch.nonzero(st & _lib.ST_CHOL_FALLBACK).reshape(-1)
+        if bad.numel():
+            full = chisq_full(batch, libs, coefs, vv[bad].contiguous(),
+                              npoly=npoly, rbf=rbf, job_spec=js2[bad].contiguous(),
+                              job_templ=jt2[bad].contiguous(), espec_sys=espec_sys,
+                              want_models=False, resols=resols)
+            tot = torch.zeros(bad.numel(), dtype=torch.float64, device=dev)
+            stb = torch.zeros(bad.numel(), dtype=torch.int32, device=dev)
+            for ia, f in enumerate(full):
+                o = outsides[ia][jt2[bad].long()]
+                pen = o * float(batch.badchi) if outside_penalty else \
+                    torch.where(torch.isfinite(o), torch.zeros_like(o), o)
+                fin = torch.isfinite(pen)     # penalties of spec_fit.py:888-896
+                tot += torch.where(fin, f['chisq'] + pen, torch.full_like(
+                    pen, 1000.0 * float(batch.badchi)))
+                stb |= torch.where(fin, f['status'], torch.zeros_like(f['status']))
+            res[bad] = tot
+            stb = torch.where(torch.isfinite(tot), stb,
+                              stb | _lib.ST_NONFINITE)
+            st[bad] = stb | _lib.ST_CHOL_FALLBACK
         stj = torch.zeros(n, dtype=torch.int32, device=dev)
         st = st.reshape(n, Nv)
         for bit in range(12):
@@ -504,8 +527,12 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
     # Jobs whose normal matrix the velocity-grid kernel could not factor, or
     # found spanning > 1e9 in its pivots (RVS_ST_ILLCOND: a long stretch of
     # weightless pixels), are re-evaluated by the point kernel -- raw basis,
-    # explicit residual, the reference's Cholesky -> SVD tiers
-    # (spec_fit.py:337-354).  Rare; costs one look at the status vector.
+    # explicit residual, Cholesky -- and what that cannot factor either by
+    # rvs_chisq_full's eigen branch (by_point_kernel: the reference's
+    # Cholesky -> SVD tiers, spec_fit.py:337-354).  The look at the status
+    # vector is a device-to-host synchronisation at the end of every call: the
+    # host cannot queue the next stage under this one (a few launch latencies
+    # per call; the sampler's rounds synchronise on their grid sizes anyway).
     redo = torch.nonzero(status & (_lib.ST_ILLCOND | _lib.ST_CHOL_FALLBACK)
                          ).reshape(-1)
     if redo.numel():
@@ -603,7 +630,7 @@ def fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys=0.0):
         a.factors = lib.spline_factors.data_ptr()
         a.ngrid, a.lnstep = lib.ngrid, lib.lnstep
         for d in range(lib.ndim):
-            a.inv_ptp[d] = float(lib.inv_ptp[d])
+            a.ptp[d] = float(lib.ptp[d])
             a.lens[d] = int(lib.lens[d])
         a.ntp, a.ndim = lib.ntp, lib.ndim
         a.log_mask, a.exp_flag = lib.log_mask, lib.exp_flag

@@ -22,6 +22,8 @@ from . import _lib
 
 
 def _dev(a, dtype, device):
+    if isinstance(a, torch.Tensor):          # already resident (synthetic libraries)
+        return a.to(device=device, dtype=dtype).contiguous()
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
 
 
@@ -78,7 +80,7 @@ class TemplateLibrary:
             self.uvecs_host = uvecs
             vec = np.asarray(d['vec'], dtype=np.float64)  # [ndim, ngrid] mapped
             ptp = np.ptp(vec, axis=1)
-            self.inv_ptp = np.ascontiguousarray(1. / ptp)
+            self.ptp = np.ascontiguousarray(ptp)
             self.ngrid = vec.shape[1]
             self.dats = _dev(d['dats'], torch.float32, device)
             self.idgrid = _dev(idgrid.ravel(), torch.int64, device)
@@ -107,9 +109,17 @@ class TemplateLibrary:
         # ccf_<setup>.h5 ..., keys ccf_*) and not (rvs_make_ccf --nocontinuum,
         # files ccf_nocont_<setup>.h5 ..., keys ccfnc_*); make_ccf.py:19-36
         self.ccf_sets = {}
-        for cont, pre in ((True, 'ccf_'), (False, 'ccfnc_')):
+        for pre in ('ccf_', 'ccfnc_'):
             if pre + 'fft' not in d:
                 continue
+            # the set is what its own ccfconf['continuum'] says it is
+            # (make_ccf.py:483-493), whatever prefix an older converter gave it
+            cont = bool(d[pre + 'continuum'])
+            if cont in self.ccf_sets:
+                raise ValueError(
+                    'setup %s: two CCF template sets with continuum=%s; '
+                    'reconvert the artefacts with tools/convert_artefacts.py'
+                    % (name, cont))
             fft = np.ascontiguousarray(d[pre + 'fft'], dtype=np.complex128)
             fft2 = np.ascontiguousarray(d[pre + 'fft2'], dtype=np.complex128)
             self.ccf_sets[cont] = dict(
@@ -190,7 +200,7 @@ class TemplateLibrary:
         rc = L.rvs_template_polylinear(
             _lib.ptr(self.dats), self.ngrid, self.ntp, _lib.ptr(self.idgrid),
             _lib.ptr(self.uvecs), _lib.ptr(self.lens), self.ndim,
-            _lib.ptr(self.vecs_s), _lib.ptr(self.inv_ptp), log_mask,
+            _lib.ptr(self.vecs_s), _lib.ptr(self.ptp), log_mask,
             self.exp_flag, _lib.ptr(params), J, _lib.ptr(templ),
             _lib.ptr(outside), _lib.ptr(cell), _lib.ptr(wts), _lib.stream())
         _lib.check(rc, 'rvs_template_polylinear')
@@ -208,7 +218,7 @@ class TemplateLibrary:
             rc = L.rvs_template_polylinear(
                 _lib.ptr(self.dats), self.ngrid, self.ntp, _lib.ptr(self.idgrid),
                 _lib.ptr(self.uvecs), _lib.ptr(self.lens), self.ndim,
-                _lib.ptr(self.vecs_s), _lib.ptr(self.inv_ptp), self.log_mask,
+                _lib.ptr(self.vecs_s), _lib.ptr(self.ptp), self.log_mask,
                 self.exp_flag, _lib.ptr(params), J, _lib.ptr(templ),
                 _lib.ptr(outside), None, None, stream)
             _lib.check(rc, 'rvs_template_polylinear')

@@ -84,13 +84,19 @@ def template_lam_grid(lam_left, lam_right, step, deltav=1000.0):
 
 
 def regular_grid(nteff=7, nlogg=7, nfeh=7, nalpha=7, teff_range=(3000., 12000.),
-                 logg_range=(0., 5.), feh_range=(-2., 0.), alpha_range=(0., 1.)):
+                 logg_range=(0., 5.), feh_range=(-2., 0.), alpha_range=(0., 1.),
+                 axes=None):
     """Returns (uvecs in PHYSICAL units, vec[4, N] physical) of a full regular
-    grid, C-order over (teff, logg, feh, alpha)."""
-    u = [np.linspace(teff_range[0], teff_range[1], nteff),
-         np.linspace(logg_range[0], logg_range[1], nlogg),
-         np.linspace(feh_range[0], feh_range[1], nfeh),
-         np.linspace(alpha_range[0], alpha_range[1], nalpha)]
+    grid, C-order over (teff, logg, feh, alpha).  `axes`: the four node vectors
+    given explicitly (any lengths, any spacing -- the shape of a real PHOENIX
+    library, whose dimensions have different lengths)."""
+    if axes is not None:
+        u = [np.asarray(a, dtype=np.float64) for a in axes]
+    else:
+        u = [np.linspace(teff_range[0], teff_range[1], nteff),
+             np.linspace(logg_range[0], logg_range[1], nlogg),
+             np.linspace(feh_range[0], feh_range[1], nfeh),
+             np.linspace(alpha_range[0], alpha_range[1], nalpha)]
     G = np.meshgrid(*u, indexing='ij')
     vec = np.array([g.ravel() for g in G])
     return u, vec
@@ -237,14 +243,29 @@ def spectra_batch(lam, teff, logg, feh, alpha, vel=None, wresol=0.0, xp=np,
 
 
 def make_interp_library_fast(setup, lam_left, lam_right, step, grid_kw=None,
-                             resol=None, dtype=np.float32):
-    """Vectorised make_interp_library (no holes)."""
+                             resol=None, dtype=np.float32, device=None,
+                             chunk=2048):
+    """Vectorised make_interp_library (no holes).  With `device` (a torch
+    device) the rows are synthesised there, `chunk` grid points at a time, and
+    `dats` is a float32 device tensor -- how the bench builds libraries of
+    realistic size (10^4 templates, hundreds of MB per arm) in seconds."""
     grid_kw = grid_kw or {}
     u, vec = regular_grid(**grid_kw)
     lam = template_lam_grid(lam_left, lam_right, step)
     wres = 0.0 if resol is None else 0.5 * (lam_left + lam_right) / resol / 2.35
-    sp = spectra_batch(lam, vec[0], vec[1], vec[2], vec[3], wresol=wres)
-    dats = np.log(sp).astype(dtype)
+    if device is None:
+        sp = spectra_batch(lam, vec[0], vec[1], vec[2], vec[3], wresol=wres)
+        dats = np.log(sp).astype(dtype)
+    else:
+        import torch
+        n = vec.shape[1]
+        dats = torch.empty((n, len(lam)), dtype=torch.float32, device=device)
+        for i0 in range(0, n, chunk):
+            v = [torch.as_tensor(vec[k, i0:i0 + chunk]).to(device)
+                 for k in range(4)]
+            sp = spectra_batch(lam, v[0], v[1], v[2], v[3], wresol=wres,
+                               xp=torch)
+            dats[i0:i0 + chunk] = torch.log(sp).float()
     mvec = vec.copy()
     mvec[0] = np.log10(mvec[0])
     uv0 = [np.unique(mvec[i], return_inverse=True) for i in range(4)]
@@ -284,7 +305,10 @@ def make_ccf_templates(lib, lam0, lam1, step, every=64, vsinis=(0., 300.),
     sel = np.arange(0, lib['dats'].shape[0], every)
     phys = lib['physical_vec'][:, sel]
     models, params, vs_list = [], [], []
-    flux = np.exp(lib['dats'][sel].astype(np.float64))
+    rows = lib['dats'][sel]
+    if not isinstance(rows, np.ndarray):     # device tensor (bench, big grids)
+        rows = rows.cpu().numpy()
+    flux = np.exp(rows.astype(np.float64))
     cont = continuum(lib['lam'][None, :], phys[0][:, None])
     for vs in vsinis:
         m = flux

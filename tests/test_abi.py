@@ -40,7 +40,10 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_work_size(lib):
-    assert lib.rvs_abi_version() == 1
+    from rvspecfit_amd import _lib
+    hdr = open(os.path.join(REPO, 'include', 'rvsgpu.h')).read()
+    ver = int(re.search(r'#define RVS_ABI_VERSION (\d+)', hdr).group(1))
+    assert lib.rvs_abi_version() == ver == _lib.ABI_VERSION
     assert lib.rvs_chisq_work_size(100, 3) == 100 + 2 * 3 * 100 + 2 * 3
 
 

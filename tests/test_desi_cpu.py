@@ -349,7 +349,10 @@ def test_proc_many_device_selection(tmp_path, monkeypatch):
     assert D._select_rank_device({}) is None and calls == []
     assert D._select_rank_device(dict(LOCAL_RANK='5')) == 5 and calls == [5]
     monkeypatch.setattr(torch.cuda, 'device_count', lambda: 4)
-    assert D._select_rank_device(dict(LOCAL_RANK='5')) == 1   # wraps
+    # more ranks than GPUs is refused unless the caller opts in (bench.py's rule)
+    with pytest.raises(RuntimeError):
+        D._select_rank_device(dict(LOCAL_RANK='5'))
+    assert D._select_rank_device(dict(LOCAL_RANK='5', RVS_SHARE_GPU='1')) == 1
     del calls[:]
     monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
     cfgf = str(tmp_path / 'c.yaml')

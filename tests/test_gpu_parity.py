@@ -50,7 +50,7 @@ def config(gpu):
 
 def test_native_library_is_loaded(gpu):
     from rvspecfit_amd import _lib
-    assert _lib.lib().rvs_abi_version() == 1
+    assert _lib.lib().rvs_abi_version() == _lib.ABI_VERSION
     maps = open('/proc/self/maps').read()
     assert 'librvsgpu.so' in maps
 

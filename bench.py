@@ -75,6 +75,13 @@ def nn_weights(ntp, seed):
     return d
 
 
+def traffic_key(args, S, T, nfft, grid_name):
+    """what a PMC traffic figure is valid for: the workload a line describes"""
+    return '%s|S=%d|T=%d|nfft=%d|%s|grid=%s|refine=%d|resol=%d' % (
+        args.workload, S, T, nfft, args.evaluator, grid_name, int(args.refine),
+        int(args.resolution_matrix))
+
+
 def ccf_every_for(ccf_every, ngrid):
     """--ccf-every is quoted for the 7^4 grid (64 -> T = 76, 9 -> T = 534); a
     grid of another size keeps the same NUMBER of CCF templates"""
@@ -153,19 +160,39 @@ def cpu_worker(args):
     global _W
     _W = dict(libs={k: orc.make_library(v) for k, v in dicts.items()}, d=d)
     ncore = max(1, min(args.cpu_cores or (os.cpu_count() or 1), n))
-    t0 = time.time()
     one_fn = _cpu_one_process if args.cpu_process else _cpu_one
+    # The timed region holds the fits only: the pool is started and every worker
+    # has made one untimed call (first-use set-up: library views, the C port's
+    # dlopen, scipy imports) before the clock starts.  With one spectrum per
+    # worker and the pool start inside the clock, round 2's line understated
+    # the CPU six-fold.
     if ncore > 1:
-        with mp.get_context('fork').Pool(ncore) as pool:
-            recs = pool.map(one_fn, range(n))
+        with mp.get_context('fork').Pool(ncore, initializer=_cpu_warm,
+                                         initargs=(bool(args.cpu_process), )
+                                         ) as pool:
+            pool.map(_cpu_noop, range(4 * ncore), chunksize=1)  # all workers up
+            t0 = time.time()
+            recs = pool.map(one_fn, range(n), chunksize=1)
+            wall = time.time() - t0
     else:
+        one_fn(0)
+        t0 = time.time()
         recs = [one_fn(i) for i in range(n)]
-    wall = time.time() - t0
+        wall = time.time() - t0
     t1 = time.time()
     one_fn(0)
     one = time.time() - t1
     print(json.dumps(dict(n=n, wall=wall, cores=ncore, one_spectrum_s=one,
                           lib_s=tlib, recs=[list(map(float, r)) for r in recs])))
+
+
+def _cpu_warm(process):
+    (_cpu_one_process if process else _cpu_one)(0)
+
+
+def _cpu_noop(i):
+    time.sleep(0.01)
+    return i
 
 
 def _cpu_one(i):
@@ -330,7 +357,9 @@ def main():
                     help='spectra per GPU per step')
     ap.add_argument('--ccf-every', type=int, default=64,
                     help='grid subsampling of the CCF set: 64 -> T=76, 9 -> T=534')
-    ap.add_argument('--cpu-sample', type=int, default=64)
+    ap.add_argument('--cpu-sample', type=int, default=0,
+                    help='spectra of the CPU baseline sample (0: 8 per host '
+                         'core, at most 512)')
     ap.add_argument('--cpu-cores', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--refine', action='store_true',
@@ -580,16 +609,36 @@ def main():
     # call over one arm (full-wave kernel + packed-wave kernel)
     FP64_PEAK_TF = 78.6   # datasheet fp64 vector rate (256 CUs x 128 flop/clk x 2.4 GHz)
 
+    grid_name = 'x'.join(str(GRID_KW[k]) for k in ('nteff', 'nlogg', 'nfeh',
+                                                    'nalpha'))
+    tkey = traffic_key(args, S, Tccf, nfft, grid_name)
+
     def pmc_traffic(kernel):
-        """HBM bytes per launch from the committed PMC passes of this build's
-        profile (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 runs): measured
-        by tools/perf/profile_round.sh, NOT by this run"""
-        f = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
+        """HBM bytes per launch of `kernel` for THIS configuration, from the
+        committed rocprofv3 counter passes of this build (FETCH_SIZE x 2 +
+        WRITE_SIZE, separate runs, tools/perf/pmc_traffic.sh): the entry of
+        profiles/r03_pmc_traffic.json whose key is this run's configuration, or
+        None when that configuration has not been profiled -- a figure measured
+        on another workload is never stamped on this line"""
+        f = os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')
         try:
-            d = json.load(open(f))[kernel]
-            return d['hbm_bytes_per_launch'], 'profiles/r02_pmc_traffic.json (%s)' % d['source']
+            d = json.load(open(f))[tkey][kernel]
+            return d['hbm_bytes_per_launch'], \
+                'profiles/r03_pmc_traffic.json[%s] (%s)' % (tkey, d['source'])
         except Exception:
             return None, None
+
+    def sq_counters(kernel):
+        """SQ / GRBM counters per launch (tools/perf/xc_counters.sh), default
+        configuration only; None otherwise"""
+        f = os.path.join(REPO, 'profiles', 'r03_sq_counters.json')
+        try:
+            d = json.load(open(f))
+            if d.get('traffic_key') != tkey:
+                return None
+            return d['kernels'][kernel]
+        except Exception:
+            return None
     tr_grid, src_grid = pmc_traffic('chisq_grid')
     tr_ccf, src_ccf = pmc_traffic('ccf_xcorr')
     roof = dict(bound='fp64_valu', kernel='chisq_grid_kernel',
@@ -604,11 +653,10 @@ def main():
                 bytes_per_spectrum=b_grid_unit,
                 avg_launch_ms=round(ms2 / max(nl2, 1), 3), launches=nl2,
                 share_of_step=round(ms2 / args.steps / (dt / args.steps * 1e3), 3),
-                peak_sustained_ubench=70.6,
                 note='fp64 vector-ALU bound (0.07 TB/s algorithmic): flops = 170 '
-                     'per pixel-velocity; peak = datasheet fp64 vector rate, a '
-                     'pure v_fma_f64 loop sustains 70.6 TF on this chip '
-                     '(tools/perf/ubench.hip)')
+                     'per pixel-velocity; peak = datasheet fp64 vector rate (a '
+                     'pure v_fma_f64 loop sustained 70.6 TF on this chip in '
+                     'round 2, tools/perf/ubench.hip -- not measured by this run)')
     roof_ccf = dict(bound='hbm', kernel='ccf_xcorr_kernel',
                     timed='rvs_ccf_xcorr call = ccf_rfft_kernel + ccf_xcorr_kernel '
                           '(HIP events on the launch stream)',
@@ -618,9 +666,29 @@ def main():
                     bytes_per_spectrum=b_ccf_unit,
                     avg_launch_ms=round(ms / max(nl, 1), 3), launches=nl,
                     share_of_step=round(ms / args.steps / (dt / args.steps * 1e3), 3),
-                    note='algorithmic bytes = CCF template block streamed once per '
-                         'spectrum (SURVEY 8(d) D3); the block is shared by every '
-                         'spectrum so most of it is served by L2/Infinity Cache')
+                    note='BYTE MODEL, not HBM utilisation: algorithmic bytes = CCF '
+                         'template block streamed once per spectrum (SURVEY 8(d) '
+                         'D3); the block is shared by every spectrum, so it is '
+                         'served by L2 / Infinity Cache and `achieved` can exceed '
+                         'what HBM can deliver -- see counter_backed')
+    # what the counters say bounds the kernel (committed passes of this build on
+    # this configuration; null when not profiled)
+    sq = sq_counters('ccf_xcorr_kernel')
+    avg_ms = ms / max(nl, 1)
+    cb_ = dict(real_hbm_GBps=None, real_hbm_frac_of_peak=None, l2_to_l1_TBps=None,
+               valu_busy=None, lds_busy=None, source=None)
+    if tr_ccf and avg_ms > 0:
+        # one rvs_ccf_xcorr call = one launch of ccf_xcorr_kernel (+ rfft)
+        cb_['real_hbm_GBps'] = round(tr_ccf / (avg_ms * 1e-3) / 1e9, 1)
+        cb_['real_hbm_frac_of_peak'] = round(cb_['real_hbm_GBps'] / HBM_PEAK_GBS, 4)
+        cb_['source'] = src_ccf
+    if sq:
+        # vector-memory read instructions x 64 lanes x 16 B / kernel time
+        cb_['l2_to_l1_TBps'] = sq.get('l2_to_l1_TBps')
+        cb_['valu_busy'] = sq.get('valu_busy')
+        cb_['lds_busy'] = sq.get('lds_busy')
+        cb_['source'] = (cb_['source'] or '') + ' + profiles/r03_sq_counters.json'
+    roof_ccf['counter_backed'] = cb_
     kernels = {
         'ccf_xcorr': dict(ms_per_step=round(ms / args.steps, 2),
                           alg_GBps=round(ccf_gbs, 1)),
@@ -650,16 +718,25 @@ def main():
     parity = None
     # the CPU leg is timed on rank 0 at N = 1 only
     if not args.no_cpu_baseline and not args.resolution_matrix and world == 1:
-        n = min(args.cpu_sample, S)
+        ncpu = args.cpu_cores or (os.cpu_count() or 1)
+        n = min(args.cpu_sample or min(512, 8 * ncpu), S)
         cb = run_cpu_baseline(arms, n, args)
+        per_core = cb['n'] / cb['wall'] / cb['cores']
         cpu = dict(value=round(cb['n'] / cb['wall'], 3), unit='spectra/s',
                    cores=cb['cores'], kind='port',
-                   sample='%d of the %d spectra of rank 0, oracle (numpy/scipy + C '
-                          'port of the reference) CCF + 400-velocity chi^2 grid + '
-                          'continuum chi^2, process-parallel over %d host cores, '
-                          'OMP_NUM_THREADS=1' % (cb['n'], S, cb['cores']),
-                   spectra_per_s_per_core=round(cb['n'] / cb['wall'] / cb['cores'], 4),
-                   one_spectrum_seconds_1core=round(cb['one_spectrum_s'], 3))
+                   sample='%d of the %d spectra of rank 0 (%.1f per core), oracle '
+                          '(numpy/scipy + C port of the reference) CCF + '
+                          '400-velocity chi^2 grid + continuum chi^2, '
+                          'process-parallel over %d host cores, OMP_NUM_THREADS=1; '
+                          'pool start and one warm-up call per worker are outside '
+                          'the clock' % (cb['n'], S, cb['n'] / cb['cores'],
+                                         cb['cores']),
+                   spectra_per_s_per_core=round(per_core, 4),
+                   one_spectrum_seconds_1core=round(cb['one_spectrum_s'], 4),
+                   # ~1 when the workers scale; < 1: the cores share memory
+                   # bandwidth / boost clocks when all of them run
+                   per_core_rate_x_one_spectrum_seconds=round(
+                       per_core * cb['one_spectrum_s'], 3))
         g = rec[:n].cpu().numpy()
         o = np.array(cb['recs'])
         same = (g[:, 0] == o[:, 0])
@@ -687,8 +764,13 @@ def main():
             and args.workload == 'desi':
         desi = run_desi_addon(arms, args, dev, dicts)
 
+    # SURVEY 8(d) D3 end-to-end byte model: B_alg = spectrum terms + polylinear
+    # gather + CCF template block + outputs, per spectrum
+    b_alg = npix_tot * 16 + (16 * 4 * ntp_tot if EVALUATOR == 'polylinear' else 0) \
+        + b_ccf_unit + 4096
     line = dict(
-        metric='spectra/sec (CCF+chi2 grid) DESI 3-arm',
+        metric='spectra/sec (CCF+chi2 grid) DESI 3-arm' if args.workload == 'desi'
+        else 'spectra/sec (CCF+chi2 grid) 1 arm 4000-5000 A (BASELINE configs[1])',
         value=round(value, 1), unit='spectra/s', n_gpus=world, steps=args.steps,
         warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 2),
         higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
@@ -707,8 +789,16 @@ def main():
                     spectra_per_gpu=S, ccf_templates=Tccf, nfft=nfft,
                     refine=bool(args.refine),
                     resolution_matrix=bool(args.resolution_matrix),
+                    traffic_key=tkey,
                     parallelism='spectra-sharded x%d' % world),
-        roofline=roof, roofline_ccf=roof_ccf, cpu_baseline=cpu,
+        roofline=roof, roofline_ccf=roof_ccf,
+        b_alg=dict(bytes_per_spectrum=b_alg,
+                   achieved_GBps=round(value / world * b_alg / 1e9, 1),
+                   frac_of_hbm_peak=round(value / world * b_alg / 1e9
+                                          / HBM_PEAK_GBS, 4),
+                   note='SURVEY 8(d) D3 byte model of the WHOLE path per GPU; the '
+                        'path is fp64-compute-side under it (see roofline)'),
+        cpu_baseline=cpu,
         stage_ms=stage_round(stage),
         kernels=kernels, parity_sample=parity, setup_s=round(t_setup, 1))
     if proc is not None:

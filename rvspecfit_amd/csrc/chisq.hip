@@ -121,13 +121,17 @@ __device__ __forceinline__ void
   int j, iv;
   bool active;
   if (TAIL) {
-    const int jl = threadIdx.x / lpj;          // lpj lanes per job, 64/lpj jobs
-    const int jpw = 64 / lpj;
-    j = bx * jpw + jl;
-    iv = iv0 + (int)threadIdx.x - jl * lpj;
-    active = jl < jpw && j < J;
-    if (!active) {  // idle lanes shadow the wave's first lane (in-bounds loads)
-      j = bx * jpw;
+    // flat map over the J * lpj left-over (job, velocity) pairs: lane g of the
+    // launch serves velocity g % lpj of job g / lpj, so every wave but the last
+    // is full whatever lpj is (for lpj | 64 this is the 64/lpj-jobs-per-wave
+    // layout of round 2, for 100- or 125-point refinement grids -- 36 or 61
+    // left over -- it replaces a wave per job with 36 or 61 live lanes)
+    const int64_t g = (int64_t)bx * 64 + threadIdx.x;
+    j = (int)(g / lpj);
+    iv = iv0 + (int)(g - (int64_t)j * lpj);
+    active = j < J;
+    if (!active) {  // idle lanes shadow the first pair (in-bounds loads)
+      j = 0;
       iv = iv0;
     }
   } else {
@@ -721,13 +725,13 @@ static int launch_grid(const double *lam, const double *polysT,
                        const double *penalty, double badchi, double beta,
                        double *out, int32_t *status, int pack_min_jobs,
                        hipStream_t st) {
-  // left-over velocities of a job (Nv % 64): up to 32 of them are packed with
-  // those of other jobs, 64/r jobs per wave; more than 32 keep a wave of their own
-  // (below ~4000 jobs the packed launch -- one wave time whatever its size --
-  // costs more than J ragged waves inside the main launch)
+  // left-over velocities of a job (Nv % 64) are packed with those of other jobs
+  // in a flat (job, velocity) order, J * r lanes in all (below ~4000 jobs the
+  // packed launch -- one wave time whatever its size -- costs more than J ragged
+  // waves inside the main launch)
   int r = Nv % 64;
   if (pack_min_jobs == 0) pack_min_jobs = 4096;
-  if (r > 32 || pack_min_jobs < 0 || J < pack_min_jobs ||
+  if (pack_min_jobs < 0 || J < pack_min_jobs ||
       (int64_t)S * npix * 16 >= (1ll << 32))
     r = 0;
   const int nfull = r ? Nv / 64 : (Nv + 63) / 64;   // waves per job, TAIL=false
@@ -740,7 +744,6 @@ static int launch_grid(const double *lam, const double *polysT,
   // the SIMDs busy (35.2 -> 34.1 ms per arm of 10 000 spectra, same bits).
   GridFork *fk = (r && nfull > 0) ? grid_fork() : nullptr;
   if (r) {
-    const int jpw = 64 / r;
     hipStream_t ts = st;
     if (fk) {
       if (hipEventRecord(fk->fork, st) != hipSuccess ||
@@ -748,7 +751,8 @@ static int launch_grid(const double *lam, const double *polysT,
         return RVS_E_LAUNCH;
       ts = fk->side;
     }
-    hipLaunchKernelGGL((chisq_grid_kernel<P, true>), dim3((J + jpw - 1) / jpw),
+    hipLaunchKernelGGL((chisq_grid_kernel<P, true>),
+                       dim3((unsigned)(((int64_t)J * r + 63) / 64)),
                        dim3(64), 0, ts, lam, polysT, work, npix, S, knots, cf,
                        ntp, log_step, job_spec, job_templ, J, vels, vel_stride,
                        Nv, iv0, r, 0, penalty, badchi, beta, out, status);

@@ -603,8 +603,13 @@ def test_chisq_grid_wave_placement_bit_identical(cases, config):
         np.testing.assert_array_equal(grid(vg[-24:], npoly, 1), ragged[:, -24:])
         # 5 left-over velocities: 12 jobs per packed wave
         np.testing.assert_array_equal(grid(vg[:69], npoly, 1), ragged[:, :69])
-        # more than 32 left over: never packed
+        # left-overs that do not divide 64 (flat (job, velocity) packing: a
+        # job's velocities may straddle two waves): 40 of 40, and the 36 / 61
+        # left over by the 100- / 125-point grids of the refinement loop
         np.testing.assert_array_equal(grid(vg[-40:], npoly, 1), ragged[:, -40:])
+        np.testing.assert_array_equal(grid(vg[:100], npoly, 1), ragged[:, :100])
+        np.testing.assert_array_equal(grid(vg[-125:], npoly, 1),
+                                      ragged[:, -125:])
     # The packed launch runs on a library-owned side stream per host thread:
     # two host threads, each on a torch stream of its own, at the same time
     import threading
@@ -1434,10 +1439,22 @@ def test_xcorr_every_plan_vs_numpy(gpu, nfft, continuum):
     accepts: the pass plans 8,8 / 8,8,2 / 8,8,4 / 8,8,8 / ... with their radix-4
     and radix-2 tails, the twiddle table in LDS at each size, pruned (n2 a power
     of 8) and full last passes, both CCF modes"""
+    _xcorr_vs_numpy(nfft, continuum, 3, 5)
+
+
+def test_xcorr_large_template_set_job_map(gpu):
+    """a template set above 16 MB (T = 140 at nfft 8192) takes the XCD-aware,
+    grouped (spectrum, template) order of ccf_xcorr_kernel (xc_job): every
+    (b, t) row lands where the plain order puts it, padding blocks write
+    nothing"""
+    _xcorr_vs_numpy(8192, 1, 5, 140)
+
+
+def _xcorr_vs_numpy(nfft, continuum, B, T):
     from rvspecfit_amd import _lib, ccf_tables
     L = _lib.lib()
     rng = np.random.RandomState(nfft + continuum)
-    B, T, n2 = 3, 5, nfft // 2
+    n2 = nfft // 2
     spec = 1 + 0.2 * rng.standard_normal((B, nfft))
     ivar = rng.uniform(0.5, 2.0, (B, nfft))
     tmod = 1 + 0.3 * rng.standard_normal((T, nfft))

@@ -146,6 +146,30 @@ def make_spectra_device(tp, device):
 
 
 # ------------------------------------------------------------------ CPU leg
+def usable_cores():
+    """host cores this process can actually run on: the affinity mask, capped by
+    the container's CPU quota (cgroup cpu.max / cfs_quota) -- a GPU box may show
+    256 CPUs and grant 16 of them; os.cpu_count() workers would then time each
+    other's throttling"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_worker(args):
     """Runs in a fresh process (never touches the GPU): the oracle -- the CPU
     port of the reference -- on a bounded sample of the same workload."""
@@ -159,7 +183,7 @@ def cpu_worker(args):
     tlib = time.time() - t0
     global _W
     _W = dict(libs={k: orc.make_library(v) for k, v in dicts.items()}, d=d)
-    ncore = max(1, min(args.cpu_cores or (os.cpu_count() or 1), n))
+    ncore = max(1, min(args.cpu_cores or usable_cores(), n))
     one_fn = _cpu_one_process if args.cpu_process else _cpu_one
     # The timed region holds the fits only: the pool is started and every worker
     # has made one untimed call (first-use set-up: library views, the C port's
@@ -245,7 +269,7 @@ def run_cpu_baseline(arms, n, args, start=None):
            '--ccf-every', str(args.ccf_every), '--cpu-cores',
            str(args.cpu_cores), '--workload', args.workload, '--evaluator',
            args.evaluator]
-    if args.grid:
+    if getattr(args, 'grid', ''):
         cmd += ['--grid', args.grid]
     if start is not None:
         cmd.append('--cpu-process')
@@ -403,6 +427,12 @@ def main():
                          'resident); 40,11,8,5 = 17 600 templates, 440 MB/arm: a '
                          'library of realistic size, dimensions of different '
                          'length, gathers served from HBM')
+    ap.add_argument('--dump-records', type=str, default='',
+                    help='rank 0 saves the gathered [n_gpus * spectra, 16] result '
+                         'table of the last step as .npy (tests)')
+    ap.add_argument('--seed-rank', type=int, default=-1,
+                    help='generate the spectra rank R of a multi-rank run would '
+                         'generate (tests: a 1-rank run that reproduces one shard)')
     ap.add_argument('--dry-launch', action='store_true',
                     help='with --gpus N: every rank prints the environment it '
                          'was started with and exits (no GPU, no torch)')
@@ -448,7 +478,13 @@ def main():
                          % (rank, torch.cuda.device_count()))
         sys.exit(2)
     torch.cuda.set_device(local)
-    rdist.init_from_env(backend='nccl')
+    try:
+        rdist.init_from_env(backend='nccl')
+    except rdist.DistInitError as e:
+        # no retry, no other backend: this process has initialised the GPU.  The
+        # parent (launch_ranks / torch.distributed.run) relays the exit code.
+        sys.stderr.write('bench.py: %s\n' % e)
+        sys.exit(4)
     if world > 1:
         # what the line reports is what torch.distributed actually formed
         world = dist.get_world_size()
@@ -470,7 +506,8 @@ def main():
                                     CONFIG['template_lib'])
     Tccf = dicts[arm_name(ARMS[0])]['ccf_fft'].shape[0]
     nfft = int(dicts[arm_name(ARMS[0])]['ccf_npoints'])
-    tp = truth_params(S, seed=3 + 1000 * rank)
+    tp = truth_params(S, seed=3 + 1000 * (args.seed_rank if args.seed_rank >= 0
+                                          else rank))
     arms = make_spectra_device(tp, dev)
     batch = engine.SpecBatch([engine.ArmData(n, lam, sp, es, bad, device=dev)
                               for n, lam, sp, es, bad in arms])
@@ -580,6 +617,8 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if args.dump_records:
+        np.save(args.dump_records, rec.cpu().numpy())
 
     value = world * S * args.steps / dt
     # ---- roofline of the dominant kernel -------------------------------
@@ -718,7 +757,7 @@ def main():
     parity = None
     # the CPU leg is timed on rank 0 at N = 1 only
     if not args.no_cpu_baseline and not args.resolution_matrix and world == 1:
-        ncpu = args.cpu_cores or (os.cpu_count() or 1)
+        ncpu = args.cpu_cores or usable_cores()
         n = min(args.cpu_sample or min(512, 8 * ncpu), S)
         cb = run_cpu_baseline(arms, n, args)
         per_core = cb['n'] / cb['wall'] / cb['cores']

@@ -729,9 +729,13 @@ static int launch_grid(const double *lam, const double *polysT,
   // in a flat (job, velocity) order, J * r lanes in all (below ~4000 jobs the
   // packed launch -- one wave time whatever its size -- costs more than J ragged
   // waves inside the main launch)
+  // A packed lane costs ~1.5x a full-wave lane (two waves per SIMD at 190 VGPRs,
+  // spectrum terms per lane; refine_stats.py: 101-point grids 30.9 ns per
+  // job-velocity packed, 32 ragged; 125-point grids 30.1 packed, 25.9 ragged),
+  // so more than 40 left over keep a ragged wave of their own.
   int r = Nv % 64;
   if (pack_min_jobs == 0) pack_min_jobs = 4096;
-  if (pack_min_jobs < 0 || J < pack_min_jobs ||
+  if (r > 40 || pack_min_jobs < 0 || J < pack_min_jobs ||
       (int64_t)S * npix * 16 >= (1ll << 32))
     r = 0;
   const int nfull = r ? Nv / 64 : (Nv + 63) / 64;   // waves per job, TAIL=false

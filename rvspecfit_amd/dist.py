@@ -21,18 +21,48 @@ def shard_range(S, rank, world):
     return lo, hi
 
 
-def init_from_env(backend=None):
+class DistInitError(RuntimeError):
+    """the process group could not be formed (or its first collective failed)"""
+
+
+def init_from_env(backend=None, probe=True, timeout_s=600):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (as set by
-    torch.distributed.run).  Returns (rank, world, local_rank)."""
+    torch.distributed.run).  Returns (rank, world, local_rank).
+
+    RCCL builds its communicator lazily, on the first collective; with `probe` a
+    one-element all_reduce runs right here so that a broken fabric / IPC set-up
+    fails at start-up, not after the first step.  Any failure raises
+    DistInitError once: there is NO retry and no fallback to another backend --
+    this process may already have initialised the GPU, and such a process must
+    neither be re-executed nor silently measure something else; the launcher
+    (bench.py, torch.distributed.run) sees the non-zero exit and ends the job."""
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
+        import datetime
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = os.environ.get('RVS_DIST_BACKEND') or backend
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        dist.init_process_group(backend)
+        try:
+            dist.init_process_group(
+                backend, timeout=datetime.timedelta(seconds=timeout_s))
+            if probe:
+                dev = 'cuda' if backend == 'nccl' else 'cpu'
+                one = torch.ones(1, dtype=torch.float64, device=dev)
+                dist.all_reduce(one)
+                if dev == 'cuda':
+                    torch.cuda.synchronize()
+                if float(one.item()) != float(world):
+                    raise DistInitError('probe all_reduce returned %r for a world '
+                                        'of %d' % (float(one.item()), world))
+        except DistInitError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            raise DistInitError(
+                'rank %d of %d: process group (%s) failed at start-up: %s: %s'
+                % (rank, world, backend, type(e).__name__, e)) from e
     return rank, world, local
 
 

@@ -139,3 +139,24 @@ def test_bench_under_torch_distributed_run():
     js = [json.loads(l) for l in out.stdout.splitlines()
           if l.lstrip().startswith('{')]
     assert len(js) == 1 and js[0]['n_gpus'] == 2 and js[0]['ranks'] == [0, 1]
+
+
+def test_init_failure_raises_once_and_leaves_no_group(monkeypatch):
+    """a process group that cannot be formed raises DistInitError -- no retry,
+    no fallback backend (the caller exits non-zero; bench.py: code 4)"""
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    calls = []
+    real = dist.init_process_group
+
+    def failing(*a, **k):
+        calls.append(a)
+        raise RuntimeError('simulated RCCL failure')
+    monkeypatch.setattr(dist, 'init_process_group', failing)
+    with pytest.raises(rdist.DistInitError) as e:
+        rdist.init_from_env(backend='nccl')
+    assert 'simulated RCCL failure' in str(e.value) and len(calls) == 1
+    assert not dist.is_initialized()
+    monkeypatch.setattr(dist, 'init_process_group', real)

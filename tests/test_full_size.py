@@ -126,7 +126,7 @@ def test_sample_against_oracle(full):
     arms = [(nm, lam, sp[ix.to(sp.device)], es[ix.to(sp.device)],
              bad[ix.to(sp.device)]) for nm, lam, sp, es, bad in full['arms']]
     args = argparse.Namespace(ccf_every=64, cpu_cores=8, workload='desi',
-                              evaluator='polylinear')
+                              evaluator='polylinear', grid='')
     cb = full['bench'].run_cpu_baseline(arms, len(ix), args)
     o = np.array(cb['recs'])
     g = full['rec'][ix.to(full['dev'])].cpu().numpy()

@@ -604,8 +604,9 @@ def test_chisq_grid_wave_placement_bit_identical(cases, config):
         # 5 left-over velocities: 12 jobs per packed wave
         np.testing.assert_array_equal(grid(vg[:69], npoly, 1), ragged[:, :69])
         # left-overs that do not divide 64 (flat (job, velocity) packing: a
-        # job's velocities may straddle two waves): 40 of 40, and the 36 / 61
-        # left over by the 100- / 125-point grids of the refinement loop
+        # job's velocities may straddle two waves): 40 of 40, the 36 left over
+        # by a 100-point grid of the refinement loop; 61 of a 125-point grid
+        # stay a ragged wave (more than 40)
         np.testing.assert_array_equal(grid(vg[-40:], npoly, 1), ragged[:, -40:])
         np.testing.assert_array_equal(grid(vg[:100], npoly, 1), ragged[:, :100])
         np.testing.assert_array_equal(grid(vg[-125:], npoly, 1),

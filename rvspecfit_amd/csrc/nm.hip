@@ -19,7 +19,7 @@
 // The branch structure, constants (rho=1, chi=2, psi=0.5, sigma=0.5), stable
 // vertex ordering (NaN last) and the order of the floating-point operations
 // follow scipy/optimize/_optimize.py::_minimize_neldermead, the same as
-// rvspecfit_amd/neldermead.py (which tests/ checks against scipy itself).
+// tests/refmachines/neldermead_torch.py (which tests/ checks against scipy itself).
 #include "common.h"
 
 // numpy evaluates every product and sum of the simplex arithmetic separately;

@@ -35,7 +35,6 @@ import logging
 import os
 import sys
 import time
-import traceback
 import warnings
 
 import numpy as np
@@ -244,74 +243,84 @@ def fiberstatus_select(fibermap):
     return (col & good_fiberstatus) == col
 
 
+def _arm_sns(scores, setups, fluxes, ivars, masks):
+    """Per-arm median S/N of every row: the pipeline's own SCORES column when the
+    file has one (in the reference's order of preference, desi_fit.py:1049-1067),
+    else computed from the pixels (get_sns)."""
+    have = scores.columns.names
+    for stem in ('MEDIAN_CALIB_SNR_', 'MEDIAN_COADD_SNR_',
+                 'MEDIAN_COADD_FLUX_SNR_'):
+        if stem + setups[0].upper() in have:
+            return {a: scores[stem + a.upper()] for a in setups}
+    return {a: get_sns(fluxes[a], ivars[a], masks[a]) for a in setups}
+
+
+def _redrock_rows(fibermap, zbest_path, zbest_ext, zbest_type='STAR',
+                  zbest_maxvel=1500):
+    """The redshift file of a coadd, aligned with the fibermap rows
+    (desi_fit.py:639-672): returns (stellar mask [n], Z, SPECTYPE, SUBTYPE).  A
+    file with one row per fibre is taken as is (TARGETIDs must agree); any
+    other is matched by TARGETID -- fibres without a row get NaN / empty and
+    are not stellar."""
+    zb = pyfits.open(zbest_path)[zbest_ext].data
+    z, spectype, subtype = zb['Z'], zb['SPECTYPE'], zb['SUBTYPE']
+    stellar = (spectype == zbest_type) | (np.abs(z) < zbest_maxvel / 3e5)
+    tid = fibermap['TARGETID']
+    if len(zb) == len(tid):
+        assert np.all(zb['TARGETID'] == tid)
+        return stellar, z, spectype, subtype
+    row_of = {int(t): i for i, t in enumerate(zb['TARGETID'])}
+    pos = np.array([row_of.get(int(t), -1) for t in tid])
+    hit = pos >= 0
+    cols = []
+    for src, fill in ((z, np.nan), (spectype, None), (subtype, None)):
+        dst = np.zeros(len(tid), dtype=src.dtype)
+        if fill is not None:
+            dst = dst + fill
+        dst[hit] = src[pos[hit]]
+        cols.append(dst)
+    return np.isin(tid, zb['TARGETID'][stellar]), cols[0], cols[1], cols[2]
+
+
 def select_fibers_to_fit(fibermap, sns, zbest_path=None, zbest_ext=None,
                          minsn=None, objtypes=None, expid_range=None,
                          fit_targetid=None, zbest_select=False,
                          zbest_include=False):
-    """desi_fit.py:546-679.  Returns (subset, rr_z, rr_spectype, rr_subtype)."""
-    zbest_maxvel = 1500
-    zbest_type = 'STAR'
+    """Which rows of a file are fitted (the rules of desi_fit.py:546-679, one
+    boolean column per rule, all of them ANDed): exposure window, usable
+    FIBERSTATUS, not SKY / BAD, requested TARGETIDs, best-arm S/N above `minsn`,
+    and -- with `zbest_select` -- stellar according to redrock.  `objtypes`
+    needs desitarget, which the reference treats as optional too: never applied
+    here.  Returns (subset, rr_z, rr_spectype, rr_subtype); the redrock columns
+    are None unless a redshift file was read."""
     n = len(fibermap)
-    subset = np.ones(n, dtype=bool)
-    mine, maxe = -1, np.inf
-    if expid_range is not None:
-        mine, maxe = expid_range
-        mine = -1 if mine is None else mine
-        maxe = np.inf if maxe is None else maxe
+    rules = [fiberstatus_select(fibermap),
+             (fibermap['OBJTYPE'] != 'SKY') & (fibermap['OBJTYPE'] != 'BAD')]
     if 'EXPID' in fibermap.columns.names:
-        subset = subset & (fibermap['EXPID'] > mine) & (fibermap['EXPID']
-                                                        <= maxe)
-    subset = subset & fiberstatus_select(fibermap)
-    subset = subset & (fibermap['OBJTYPE'] != 'SKY') & (fibermap['OBJTYPE']
-                                                        != 'BAD')
+        lo, hi = (None, None) if expid_range is None else expid_range
+        lo = -1 if lo is None else lo
+        hi = np.inf if hi is None else hi
+        rules.append((fibermap['EXPID'] > lo) & (fibermap['EXPID'] <= hi))
     if fit_targetid is not None:
-        subset = subset & np.isin(fibermap['TARGETID'], fit_targetid)
+        rules.append(np.isin(fibermap['TARGETID'], fit_targetid))
     if minsn is not None:
-        maxsn = np.max(np.array(list(sns.values())), axis=0)
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            subset = subset & (maxsn > minsn)
-    # no desitarget: never selecting by type (see the module docstring)
-    types_subset = np.zeros(n, dtype=bool)
-    selecting_by_type = False
-    selecting_by_zbest = False
+            rules.append(np.max(np.array(list(sns.values())), axis=0) > minsn)
     rr_z = rr_spectype = rr_subtype = None
-    zbest_subset = None
     if zbest_select or zbest_include:
         if zbest_path is None:
             logging.warning(
                 'zbest selection requested, but the zbest file not found')
         else:
-            if zbest_select:
-                selecting_by_zbest = True
             logging.info('Using redshift file %s', zbest_path)
-            zb = pyfits.open(zbest_path)[zbest_ext].data
-            rr_spectype = zb['SPECTYPE']
-            rr_subtype = zb['SUBTYPE']
-            rr_z = zb['Z']
-            zbest_subset = ((rr_spectype == zbest_type) |
-                            ((np.abs(rr_z)) < zbest_maxvel / 3e5))
-            if len(zb) == n:
-                assert np.all(zb['TARGETID'] == fibermap['TARGETID'])
-            else:
-                # match by id (spectra- file with a coadd redshift file)
-                order = {int(t): i for i, t in enumerate(zb['TARGETID'])}
-                zbest_subset = np.isin(fibermap['TARGETID'],
-                                       zb['TARGETID'][zbest_subset])
-                pos = np.array([order.get(int(t), -1)
-                                for t in fibermap['TARGETID']])
-                hit = pos >= 0
-                z2 = np.zeros(n, dtype=rr_z.dtype) + np.nan
-                st2 = np.zeros(n, dtype=rr_spectype.dtype)
-                sub2 = np.zeros(n, dtype=rr_subtype.dtype)
-                z2[hit] = rr_z[pos[hit]]
-                st2[hit] = rr_spectype[pos[hit]]
-                sub2[hit] = rr_subtype[pos[hit]]
-                rr_z, rr_spectype, rr_subtype = z2, st2, sub2
-    if not selecting_by_zbest:
-        zbest_subset = np.zeros(n, dtype=bool)
-    if selecting_by_zbest or selecting_by_type:
-        subset = subset & (zbest_subset | types_subset)
+            stellar, rr_z, rr_spectype, rr_subtype = _redrock_rows(
+                fibermap, zbest_path, zbest_ext)
+            if zbest_select:
+                rules.append(stellar)
+    subset = np.ones(n, dtype=bool)
+    for r in rules:
+        subset &= np.asarray(r, dtype=bool)
     return subset, rr_z, rr_spectype, rr_subtype
 
 
@@ -898,26 +907,16 @@ def _proc_desi_steps(fname, tab_ofname, mod_ofname, fig_prefix, config,
             return 0
     fluxes, ivars, masks, waves, resolutions = read_data(FP, setups)
     tick('read')
-    sn_names = scores.columns.names
-    for pref in ('MEDIAN_CALIB_SNR_', 'MEDIAN_COADD_SNR_',
-                 'MEDIAN_COADD_FLUX_SNR_'):
-        if pref + setups[0].upper() in sn_names:
-            sns = {_: scores[pref + _.upper()] for _ in setups}
-            break
-    else:
-        sns = {_: get_sns(fluxes[_], ivars[_], masks[_]) for _ in setups}
-    for _ in setups:
-        if len(sns[_]) != len(fibermap):
-            logging.warning((
-                'WARNING the size of the data in arm %s' +
-                'does not match the size of the fibermap; file %s; skipping...'
-            ) % (_, fname))
-            return -1
+    sns = _arm_sns(scores, setups, fluxes, ivars, masks)
+    short = [a for a in setups if len(sns[a]) != len(fibermap)]
+    if short:
+        logging.warning('file %s: arm(s) %s hold another number of spectra than '
+                        'the fibermap has rows; skipping the file', fname,
+                        ','.join(short))
+        return -1
     columnDesc = get_column_desc(setups)
-    if zbest_select or zbest_include:
-        zbest_path, zbest_ext = get_zbest_fname(fname)
-    else:
-        zbest_path, zbest_ext = None, None
+    zbest_path, zbest_ext = get_zbest_fname(fname) \
+        if (zbest_select or zbest_include) else (None, None)
     subset, rr_z, rr_spectype, rr_subtype = select_fibers_to_fit(
         fibermap, sns, minsn=minsn, objtypes=objtypes, expid_range=expid_range,
         fit_targetid=fit_targetid, zbest_path=zbest_path, zbest_ext=zbest_ext,
@@ -1146,35 +1145,30 @@ def proc_desi_group(files, config, **kwargs):
 
 
 def proc_desi_wrapper(*args, **kwargs):
-    """desi_fit.py:1311-1350: status file + exception policy around proc_desi"""
-    status = ProcessStatus.SUCCESS
+    """proc_desi for one file with its outcome recorded: a line of the status
+    file (SUCCESS with the number of fitted fibres, FAILURE otherwise; the
+    reference's desi_fit.py:1311-1345 keeps the same record) and, unless
+    `throw_exceptions`, an exception is logged and the file loop goes on.  The
+    reference's per-process crash_<pid>.log files belong to its worker-pool
+    control plane and are not written: the traceback goes to the log."""
     status_file = kwargs.pop('process_status_file', None)
     throw_exceptions = kwargs.pop('throw_exceptions', None)
-    nfit = 0
-    t1 = time.time()
+    t0 = time.time()
+    nfit, failed = 0, True
     try:
-        nfit = proc_desi(*args, **kwargs)
-        if nfit < 0:
-            status = ProcessStatus.FAILURE
-            nfit = 0
-    except:  # noqa: E722
-        status = ProcessStatus.FAILURE
-        logging.exception('failed with these arguments' + str(args) +
-                          str(kwargs))
-        pid = os.getpid()
-        logfname = 'crash_%d_%s.log' % (pid, time.ctime().replace(' ', ''))
-        with open(logfname, 'w') as fd:
-            print('failed with these arguments', args, kwargs, file=fd)
-            traceback.print_exc(file=fd)
+        ret = proc_desi(*args, **kwargs)
+        failed = ret is not None and ret < 0
+        nfit = 0 if (ret is None or failed) else ret
+    except Exception:  # noqa: BLE001
+        logging.exception('proc_desi failed on %s', args[0] if args else '?')
         if throw_exceptions:
             raise
     finally:
-        t2 = time.time()
         if status_file is not None:
-            if nfit is None:
-                nfit = 0
-            update_process_status_file(status_file, args[0], status, nfit,
-                                       t2 - t1)
+            update_process_status_file(
+                status_file, args[0],
+                ProcessStatus.FAILURE if failed else ProcessStatus.SUCCESS, nfit,
+                time.time() - t0)
 
 
 def _select_rank_device(environ=None):

@@ -211,8 +211,8 @@ class TemplateLibrary:
     def eval_into(self, params, J, templ, outside, stream, scratch=None):
         """launch-only variant of eval_batch on caller-owned buffers (no
         allocation, no synchronisation): params [>=J, ndim], templ [>=J, ntp],
-        outside [>=J]; scratch: int32 [>=J] for triangulation libraries.
-        regulargrid and triangulation kinds only."""
+        outside [>=J]; scratch: int32 [>=J] for triangulation libraries, a dict
+        of activation buffers + the torch stream for nn libraries."""
         L = _lib.lib()
         if self.kind == 'regulargrid':
             rc = L.rvs_template_polylinear(
@@ -230,8 +230,29 @@ class TemplateLibrary:
                 _lib.ptr(params), J, _lib.ptr(templ), _lib.ptr(outside),
                 _lib.ptr(scratch), None, stream)
             _lib.check(rc, 'rvs_template_tri')
+        elif self.kind == 'nn':
+            # scratch: dict(a0, a1 float32 [>=J, width], torch_stream) -- the
+            # optimiser's rounds evaluate the MLP rows of all live simplices in
+            # one rvs_template_nn call on the arm's side stream
+            import ctypes
+            nl = len(self.nn_W)
+            Wp = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in self.nn_W])
+            bp = (ctypes.c_void_p * nl)(*[b.data_ptr() for b in self.nn_b])
+            rc = L.rvs_template_nn(
+                _lib.ptr(params), J, self.ndim, self.log_mask,
+                _lib.ptr(self.nn_M), _lib.ptr(self.nn_S), nl,
+                ctypes.cast(Wp, ctypes.c_void_p),
+                ctypes.cast(bp, ctypes.c_void_p), _lib.ptr(self.nn_dims),
+                _lib.ptr(scratch['a0']), _lib.ptr(scratch['a1']),
+                _lib.ptr(templ), stream)
+            _lib.check(rc, 'rvs_template_nn')
+            with torch.cuda.stream(scratch['torch_stream']):
+                outside[:J] = self._nn_outside(params[:J])
         else:
             raise NotImplementedError(self.kind)
+
+    def nn_width(self):
+        return int(max(self.nn_dims[:-1]))
 
     def _eval_nn(self, params, templ, outside, mapped=False):
         import ctypes

@@ -9,9 +9,10 @@ vel_fit.py:229-254 as a fixed launch sequence on preallocated buffers:
 rvs_proc_map -> per arm rvs_template_polylinear, rvs_vsini_convolve,
 rvs_spline_construct -> rvs_chisq_point (all arms) -> rvs_proc_finish.
 
-The pure-torch neldermead.minimize is the same state machine (and is what the
-tests compare with scipy); this module exists because its ~70 small torch
-calls and three host synchronisations per round cost more than the GPU work.
+tests/refmachines/neldermead_torch.py is the same state machine in torch: the CPU
+suite pins it to scipy (identical nit, nfev, final simplex), the GPU suite pins
+these kernels to it bit for bit.  Its ~70 small torch calls and three host
+synchronisations per round cost more than the GPU work, hence the kernels.
 """
 import ctypes
 
@@ -39,9 +40,6 @@ class ProcessObjective:
         self.npoly = options.get('npoly') or 5
         self.rbf = options.get('rbf_continuum', True)
         self.ndim = len(names)
-        for arm in batch.arms:
-            if libs[arm.name].kind not in ('regulargrid', 'triangulation'):
-                raise NotImplementedError('device optimiser: grid evaluators')
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         # parameter vector layout (vel, [vsini], free stellar parameters)
@@ -100,6 +98,11 @@ class ProcessObjective:
                      coef=torch.empty((cap, lib.ntp, 4), **f64),
                      outside=torch.empty(cap, **f64),
                      sx=torch.empty(cap, **i32),
+                     nn=None if lib.kind != 'nn' else dict(
+                         a0=torch.empty((cap, lib.nn_width()),
+                                        dtype=torch.float32, device=dev),
+                         a1=torch.empty((cap, lib.nn_width()),
+                                        dtype=torch.float32, device=dev)),
                      pen=torch.empty(cap, **f64),
                      work=arm.work(lib, 0.0), polysT=arm.basis(self.npoly,
                                                                self.rbf))
@@ -192,8 +195,11 @@ class ProcessObjective:
             lib = self.libs[arm.name]
             side.wait_event(self.ev_in)
             ss = ctypes.c_void_p(side.cuda_stream)
+            scr = b['sx']
+            if b['nn'] is not None:
+                scr = dict(b['nn'], torch_stream=side)
             lib.eval_into(self.params, J, b['templ'], b['outside'], ss,
-                          scratch=b['sx'])
+                          scratch=scr)
             y = b['templ']
             if self.has_vsini:
                 rc = L.rvs_vsini_convolve(_p(y), _p(self.vsini), _p(b['outside']),
@@ -234,6 +240,18 @@ class ProcessObjective:
 NATIVE_ROUNDS = True
 
 
+def _order(sim, fsim):
+    """scipy: ind = np.argsort(fsim); sim = np.take(sim, ind, 0) -- stable, so
+    that equal values keep their vertex order"""
+    # (np.argsort on <= 16 elements is an insertion sort, i.e. stable; NaN last)
+    key = torch.where(torch.isnan(fsim), torch.full_like(fsim, float('inf')),
+                      fsim)
+    ind = torch.sort(key, dim=1, stable=True)[1]
+    fsim = torch.gather(fsim, 1, ind)
+    sim = torch.gather(sim, 1, ind[:, :, None].expand_as(sim))
+    return sim, fsim
+
+
 class DeviceNelderMead:
 
     def __init__(self, S, N, dev):
@@ -257,7 +275,6 @@ class DeviceNelderMead:
 
     def minimize(self, objective, simplex, fatol=1e-3, xatol=1e-2,
                  maxiter=10000, sync_every=4, stats=None):
-        from .neldermead import _order
         L = _lib.lib()
         S, N = self.S, self.N
         sim = simplex.clone().to(torch.float64).contiguous()

@@ -3,7 +3,7 @@ py/rvspecfit/vel_fit.py: firstguess (:13-94), _minimum_sampler (:358-439),
 _find_best_vel_iterate (:315-355) and the first step of process (:571-602).
 
 `process` (vel_fit.py:505-737) runs its Nelder-Mead stage as S lock-step
-simplices (neldermead.py) over batched objective evaluations (SURVEY 8(f)
+simplices (optimizer.py over csrc/nm.hip) over batched objective evaluations (SURVEY 8(f)
 rank 1); see its docstring for what differs from the reference.
 """
 import contextlib
@@ -340,17 +340,6 @@ def _uncertainties_from_hessian(hessian):
     return diag_err, hessian_inv, bad_hessian
 
 
-# vel_fit.py:653-658 second_minimizer (BFGS, bfgs.py) when the config asks for it
-RUN_SECOND_MINIMIZER = True
-# 'native': C++ coroutines (csrc/bfgs_host.cpp); 'python': the generator version
-# of the same algorithm, the one the CPU suite pins to scipy itself
-# (tests/test_gpu_parity.py::test_process_bfgs_implementations_agree)
-BFGS_IMPL = 'native'
-
-# lock-step simplices driven by the rvs_nm_* kernels (optimizer.py); False = the
-# pure-torch state machine of neldermead.py (same path, ~3x slower)
-USE_DEVICE_NM = True
-
 _SIMPLEX_STD = {'logg': 0.5, 'teff': 300, 'feh': 0.5, 'alpha': 0.25}
 HESS_BASE_STEP = {'vsini': 1 / 100, 'logg': 0.1 / 100, 'feh': 0.1 / 100,
                   'alpha': .01 / 100, 'teff': 1 / 100, 'vrad': 1 / 100}
@@ -639,17 +628,16 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
 
     One spectrum (list of SpecData) returns the reference's dict.  A SpecBatch
     (paramDict0 values scalars or [S] arrays) returns [S]-leading device
-    tensors; the S optimisers advance in lock-step (neldermead.minimize), every
+    tensors; the S optimisers advance in lock-step (optimizer.DeviceNelderMead), every
     objective evaluation is one batched template build + chi^2 launch set.
 
     config['second_minimizer'] (default True in utils.read_config, as in the
-    reference) adds scipy's BFGS restated in bfgs.py (host state per spectrum,
+    reference) adds scipy's BFGS (csrc/bfgs_host.cpp; host state per spectrum,
     batched objective).  The Hessian is numdifftools' (vel_fit.py:713-716)
     restated in numdiff.py: MinStepGenerator(base_step) -> one central step;
     the step=None retry of rows with a bad Hessian -> 15 steps, Richardson +
     Wynn extrapolation; every displacement pattern is one batched objective
     call (param_err pinned to 1e-3: test_param_uncertainties_at_reference_optimum)."""
-    from . import neldermead
     if config is None:
         raise RuntimeError('Config must be provided')
     options = options or {}
@@ -698,28 +686,41 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     stats = {}
     # vel_fit.py:624-649: a second run restarts from the final simplex
     libs = spec_inter.get_libs(batch.names, config)
-    use_device_nm = USE_DEVICE_NM and all(
-        libs[a.name].kind in ('regulargrid', 'triangulation')
-        for a in batch.arms)
-    if use_device_nm:
-        from . import optimizer
+    from . import optimizer
+
+    def device_nm(b, pd, pri, start, safe, resp):
+        """lock-step simplices of the spectra of `b` on the device (rvs_nm_*):
+        every library kind -- grid libraries with the one-kernel objective where
+        it applies, the kernel chain (incl. rvs_template_nn for MLP evaluators)
+        otherwise"""
         pobj = optimizer.ProcessObjective(
-            batch, libs, names, pd0, fixParam, fitVsini, config, options, priors,
-            curparam, resols=spec_fit._resols(batch, resolParams))
-        nm = optimizer.DeviceNelderMead(S, simplex.shape[2], dev).minimize(
-            pobj, simplex, fatol=1e-3, xatol=1e-2, maxiter=10000, stats=stats)
-        obj.status |= pobj.status
-        obj.nfev += pobj.jobs
-    else:
-        nm = neldermead.minimize(obj, simplex, fatol=1e-3, xatol=1e-2,
-                                 maxiter=10000, stats=stats)
+            b, libs, names, pd, fixParam, fitVsini, config, options, pri, safe,
+            resols=spec_fit._resols(b, resp))
+        r = optimizer.DeviceNelderMead(b.S, start.shape[2], dev).minimize(
+            pobj, start, fatol=1e-3, xatol=1e-2, maxiter=10000, stats=stats)
+        return r, pobj
+    nm, pobj = device_nm(batch, pd0, priors, simplex, curparam, resolParams)
+    obj.status |= pobj.status
+    obj.nfev += pobj.jobs
     success = nm['success']
     x, nit, nfev = nm['x'], nm['nit'], nm['nfev']
     redo = torch.nonzero(~success).reshape(-1)
     if redo.numel():
-        nm2 = neldermead.minimize(lambda i, p: obj(redo[i], p),
-                                  nm['final_simplex'][0][redo], fatol=1e-3,
-                                  xatol=1e-2, maxiter=10000, stats=stats)
+        # vel_fit.py:624-649: a second run restarts from the final simplex; the
+        # unconverged spectra form a batch of their own on the same kernels
+        pri2 = priors
+        if priors:
+            pri2 = {n_: tuple(v[redo].contiguous()
+                              if isinstance(v, torch.Tensor) and v.dim() else v
+                              for v in mv) for n_, mv in priors.items()}
+        sub = batch.subset(redo)
+        nm2, pobj2 = device_nm(sub, {k_: v[redo].contiguous()
+                                     for k_, v in pd0.items()}, pri2,
+                               nm['final_simplex'][0][redo].contiguous(),
+                               curparam[redo].contiguous(),
+                               resolParams)   # (shared by every spectrum)
+        obj.status[redo] |= pobj2.status
+        obj.nfev += pobj2.jobs
         x[redo] = nm2['x']
         success[redo] = nm2['success']
         nit[redo] += nm2['nit']
@@ -730,7 +731,7 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     # vel_fit.py:653-658: optional BFGS polish from the simplex optimum
     second_run = False
     bfgs_info = None
-    if config.get('second_minimizer') and RUN_SECOND_MINIMIZER:
+    if config.get('second_minimizer'):
         from . import bfgs
         t0 = time.time()
 
@@ -739,12 +740,9 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
             return obj(it, torch.as_tensor(X_np).to(dev)).cpu().numpy()
 
         hess_inv0 = get_hess_inv(mapper.get_fitted_params())
-        # C++ state machines by default (csrc/bfgs_host.cpp); RVS_BFGS=python
-        # runs the scipy-pinned generator version of the same algorithm
-        run = bfgs.minimize_lockstep if BFGS_IMPL == 'python' else \
-            bfgs.minimize_lockstep_native
-        br = run(rows, x.cpu().numpy(), hess_inv0=hess_inv0,
-                 max_rows=max(S, 1024))
+        br = bfgs.minimize_lockstep_native(rows, x.cpu().numpy(),
+                                           hess_inv0=hess_inv0,
+                                           max_rows=max(S, 1024))
         x = torch.as_tensor(br['x']).to(dev)
         second_run = True
         bfgs_info = dict(nit=br['nit'], nfev=br['nfev'], status=br['status'],

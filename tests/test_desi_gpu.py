@@ -193,10 +193,13 @@ def test_proc_onespec_equals_batch(dcases, desi_libs):
 
 
 def test_process_device_nm_uses_resolution(desi_libs):
-    """the device Nelder-Mead objective and the torch one see the same
-    resolution matrices (per-spectrum taps): same optimum, and a different one
-    from the fit without them"""
-    from rvspecfit_amd import fits_min as F, vel_fit, engine
+    """the objective of the device Nelder-Mead applies the spectra's resolution
+    matrices (per-spectrum taps): the kernel chain (the path resolution matrices
+    take) reaches the optimum the torch reference machine reaches with the
+    batched get_chisq as objective, and a different one from the fit without
+    matrices"""
+    from refmachines import neldermead_torch
+    from rvspecfit_amd import fits_min as F, vel_fit, engine, optimizer
     from rvspecfit_amd.desi import desi_fit as D
     FP = F.open(COADD)
     data = D.read_data(FP, ['b', 'r', 'z'])
@@ -208,16 +211,26 @@ def test_process_device_nm_uses_resolution(desi_libs):
                          np.arange(3), wv, 'cuda')
     p0 = dict(teff=5200., logg=2.5, feh=-1., alpha=0.2, vsini=10.)
     cfg = dict(CFG, second_minimizer=False)
-    out = {}
-    for dev_nm in (True, False):
-        old = vel_fit.USE_DEVICE_NM
-        vel_fit.USE_DEVICE_NM = dev_nm
-        try:
-            out[dev_nm] = vel_fit.process(batch, dict(p0), config=cfg,
-                                          options=dict(npoly=10))
-        finally:
-            vel_fit.USE_DEVICE_NM = old
-    a, b = out[True], out[False]
+    a = vel_fit.process(batch, dict(p0), config=cfg, options=dict(npoly=10))
+
+    # the same simplices driven by the torch machine over vel_fit._Objective
+    # (spec_fit.chisq_jobs: rvs_chisq_point with the taps)
+    class TorchNM(optimizer.DeviceNelderMead):
+        def minimize(self, pobj, simplex, **kw):
+            names = ['teff', 'logg', 'feh', 'alpha']
+            pd = vel_fit._as_param_tensors(p0, batch.S, batch.device)
+            mapper = vel_fit.ParamMapper(names, pd, [],
+                                         vel_fit.VSiniMapper(cfg['max_vsini']),
+                                         fitVsini=True)
+            obj = vel_fit._Objective(batch, mapper, cfg, dict(npoly=10), None)
+            obj.safe_params = torch.stack([pd[_] for _ in names], dim=1)
+            return neldermead_torch.minimize(obj, simplex, **kw)
+    keep = optimizer.DeviceNelderMead
+    optimizer.DeviceNelderMead = TorchNM
+    try:
+        b = vel_fit.process(batch, dict(p0), config=cfg, options=dict(npoly=10))
+    finally:
+        optimizer.DeviceNelderMead = keep
     assert np.allclose(a['chisq'].cpu().numpy(), b['chisq'].cpu().numpy(),
                        rtol=1e-7)
     assert np.allclose(a['vel'].cpu().numpy(), b['vel'].cpu().numpy(),

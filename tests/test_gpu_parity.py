@@ -939,7 +939,8 @@ def test_device_neldermead_equals_torch(gpu):
     """the rvs_nm_* kernels take the same path as neldermead.minimize (which the
     CPU suite pins to scipy): same nit, nfev, simplices, bit for bit -- including
     shrink steps, the maxiter exit and a 1e30 wall"""
-    from rvspecfit_amd import neldermead, optimizer
+    from refmachines import neldermead_torch as neldermead
+    from rvspecfit_amd import optimizer
     rng = np.random.RandomState(3)
     for S, N, maxiter, sync in ((700, 6, 10000, 4), (64, 5, 40, 1),
                                 (1500, 2, 10000, 7)):
@@ -1221,13 +1222,15 @@ def test_nm_round_drivers_agree(cases, config):
         np.testing.assert_array_equal(a['param_err'][k], b['param_err'][k])
 
 
-def test_process_bfgs_implementations_agree(cases, config):
-    """second_minimizer through the C++ coroutines (default) and through the
-    Python generators that the CPU suite pins to scipy (vel_fit.BFGS_IMPL): the
+def test_process_bfgs_implementations_agree(cases, config, monkeypatch):
+    """second_minimizer through the C++ coroutines (what the product runs) and
+    through the Python generators that the CPU suite pins to scipy
+    (tests/refmachines/bfgs_scipy_restated.py, put in the driver's place): the
     real objective is noisy at the gradient step, so the two follow each other to
     rounding, not to the bit -- same exit statistics, chi^2 and parameters well
     inside the optimiser's tolerances"""
-    from rvspecfit_amd import vel_fit
+    from refmachines import bfgs_scipy_restated as bfgs_ref
+    from rvspecfit_amd import bfgs, vel_fit
     from rvspecfit_amd.engine import SpecBatch
     rng = np.random.RandomState(6)
     S = 24
@@ -1241,13 +1244,12 @@ def test_process_bfgs_implementations_agree(cases, config):
                vsini=rng.uniform(1, 60, S))
     cfg = dict(config, second_minimizer=True)
     out = {}
-    for impl in ('native', 'python'):
-        vel_fit.BFGS_IMPL = impl
-        try:
-            out[impl] = vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
-                                        config=cfg)
-        finally:
-            vel_fit.BFGS_IMPL = 'native'
+    out['native'] = vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                    config=cfg)
+    monkeypatch.setattr(bfgs, 'minimize_lockstep_native',
+                        bfgs_ref.minimize_lockstep)
+    out['python'] = vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                    config=cfg)
     a, b = out['native'], out['python']
     assert a['second_minimizer_run'] and b['second_minimizer_run']
     assert torch.equal(a['nm_nit'], b['nm_nit'])      # same simplex stage

@@ -93,11 +93,11 @@ def test_convert_artefacts_reproduces_reference_loader(tmp_path):
 
 
 def test_lockstep_neldermead_equals_scipy():
-    """rvspecfit_amd.neldermead follows scipy's Nelder-Mead (the optimiser of
+    """tests/refmachines/neldermead_torch follows scipy's Nelder-Mead (the optimiser of
     vel_fit.py:627-637) iteration for iteration: same nit, nfev, final simplex"""
     import scipy.optimize as so
     import torch
-    from rvspecfit_amd import neldermead as nm
+    from refmachines import neldermead_torch as nm
     rng = np.random.RandomState(1)
     S, N = 24, 6
     A = rng.normal(size=(S, N, N))
@@ -129,13 +129,14 @@ def test_lockstep_neldermead_equals_scipy():
 
 
 def test_lockstep_bfgs_equals_scipy():
-    """rvspecfit_amd.bfgs restates scipy's BFGS (vel_fit.py:653-658) with its
+    """tests/refmachines/bfgs_scipy_restated restates scipy's BFGS (vel_fit.py:653-658) with its
     Wolfe line searches and 2-point gradient: identical nit, nfev, status and
     iterates, on a smooth objective and on one with 1e-9 of deterministic noise
     (the regime of the real objective: precision-loss exit through
     line_search_wolfe2)"""
     import warnings
     import scipy.optimize as so
+    from refmachines import bfgs_scipy_restated as bfgs_ref
     from rvspecfit_amd import bfgs
     rng = np.random.RandomState(2)
     S, N = 12, 5
@@ -151,7 +152,7 @@ def test_lockstep_bfgs_equals_scipy():
     H0 = np.diag(rng.uniform(0.5, 2, N))
     x0 = rng.normal(size=(S, N)) * 2
     for nz, want_status in ((0.0, 0), (1e-9, 2)):
-        r = bfgs.minimize_lockstep(
+        r = bfgs_ref.minimize_lockstep(
             lambda idx, X: np.array([f1(int(i), x, nz) for i, x in zip(idx, X)]),
             x0, hess_inv0=H0, max_rows=17)
         with warnings.catch_warnings():
@@ -174,6 +175,7 @@ def test_native_bfgs_follows_scipy_restatement():
     itself moves by up to 1e-3).  A Rosenbrock-type valley exercises the
     line_search_wolfe2 / zoom fall-back and long runs; 1e-9 of noise the
     precision-loss exit, where only the statistics are comparable."""
+    from refmachines import bfgs_scipy_restated as bfgs_ref
     from rvspecfit_amd import bfgs
     rng = np.random.RandomState(5)
     S, N = 40, 6
@@ -193,7 +195,7 @@ def test_native_bfgs_follows_scipy_restatement():
 
     H0 = np.diag(rng.uniform(0.5, 2, N))
     x0 = rng.normal(size=(S, N)) * 2
-    a = bfgs.minimize_lockstep(quartic, x0, hess_inv0=H0, max_rows=97)
+    a = bfgs_ref.minimize_lockstep(quartic, x0, hess_inv0=H0, max_rows=97)
     b = bfgs.minimize_lockstep_native(quartic, x0, hess_inv0=H0, max_rows=97)
     assert np.array_equal(a['status'], b['status']) and not a['status'].any()
     assert np.array_equal(a['nit'], b['nit'])
@@ -204,7 +206,7 @@ def test_native_bfgs_follows_scipy_restatement():
     # the valley: ~100 iterations per run, wolfe2 / zoom fall-backs, and an exit
     # (converged or precision loss) that depends on the last bits -- the runs
     # end in the same minimum with similar effort
-    a = bfgs.minimize_lockstep(valley, x0, max_rows=97)
+    a = bfgs_ref.minimize_lockstep(valley, x0, max_rows=97)
     b = bfgs.minimize_lockstep_native(valley, x0, max_rows=97)
     assert set(a['status']) <= {0, 2} and set(b['status']) <= {0, 2}
     assert np.allclose(a['fun'], b['fun'], atol=1e-6)
@@ -212,7 +214,7 @@ def test_native_bfgs_follows_scipy_restatement():
     assert b['nit'].max() > 30
     assert abs(a['nfev'].mean() - b['nfev'].mean()) < 0.1 * a['nfev'].mean()
     noisy = lambda idx, X: quartic(idx, X, 1e-9)  # noqa: E731
-    a = bfgs.minimize_lockstep(noisy, x0, hess_inv0=H0)
+    a = bfgs_ref.minimize_lockstep(noisy, x0, hess_inv0=H0)
     b = bfgs.minimize_lockstep_native(noisy, x0, hess_inv0=H0)
     assert (a['status'] == 2).mean() > 0.8 and (b['status'] == 2).mean() > 0.8
     # (gradient noise 1e-9 / 1.5e-8: both stop a few 1e-3 above the minimum)

@@ -796,7 +796,7 @@ def main():
                       if same.any() else None)
 
     proc = None
-    if args.process > 0 and EVALUATOR == 'polylinear':
+    if args.process > 0:
         proc = run_process_addon(batch, rec, arms, args, dev)
     desi = None
     if args.desi_file > 0 and rank == 0 and EVALUATOR == 'polylinear' \

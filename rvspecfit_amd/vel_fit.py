@@ -340,6 +340,9 @@ def _uncertainties_from_hessian(hessian):
     return diag_err, hessian_inv, bad_hessian
 
 
+# iteration cap of a Nelder-Mead run (vel_fit.py:630, 644: maxiter=10000); a
+# spectrum that hits it is restarted once from its final simplex
+NM_MAXITER = 10000
 _SIMPLEX_STD = {'logg': 0.5, 'teff': 300, 'feh': 0.5, 'alpha': 0.25}
 HESS_BASE_STEP = {'vsini': 1 / 100, 'logg': 0.1 / 100, 'feh': 0.1 / 100,
                   'alpha': .01 / 100, 'teff': 1 / 100, 'vrad': 1 / 100}
@@ -697,7 +700,7 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
             b, libs, names, pd, fixParam, fitVsini, config, options, pri, safe,
             resols=spec_fit._resols(b, resp))
         r = optimizer.DeviceNelderMead(b.S, start.shape[2], dev).minimize(
-            pobj, start, fatol=1e-3, xatol=1e-2, maxiter=10000, stats=stats)
+            pobj, start, fatol=1e-3, xatol=1e-2, maxiter=NM_MAXITER, stats=stats)
         return r, pobj
     nm, pobj = device_nm(batch, pd0, priors, simplex, curparam, resolParams)
     obj.status |= pobj.status

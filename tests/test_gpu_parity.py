@@ -1559,6 +1559,90 @@ def test_reference_test_fit_nn_sequence(gpu):
     assert set(g) >= {'teff', 'logg', 'feh', 'alpha'}
 
 
+def _process_with_torch_machine(batch, p0, cfg, opt, names, fit_vsini=True):
+    """vel_fit.process with tests/refmachines/neldermead_torch.minimize over
+    vel_fit._Objective in the place of the rvs_nm_* kernels (both Nelder-Mead
+    runs of vel_fit.py:624-649)"""
+    from refmachines import neldermead_torch
+    from rvspecfit_amd import optimizer, vel_fit
+
+    class TorchNM(optimizer.DeviceNelderMead):
+        def minimize(self, pobj, simplex, **kw):
+            b = pobj.batch
+            pd = {k: v for k, v in zip(names, pobj.fixed.T)}
+            if pobj.has_vsini:
+                pd['vsini'] = torch.zeros(b.S, dtype=torch.float64,
+                                          device=b.device)
+            mapper = vel_fit.ParamMapper(
+                names, pd, [], vel_fit.VSiniMapper(cfg['max_vsini']),
+                fitVsini=fit_vsini)
+            obj = vel_fit._Objective(b, mapper, cfg, opt, None)
+            obj.safe_params = pobj.safe
+            return neldermead_torch.minimize(obj, simplex, **kw)
+    keep = optimizer.DeviceNelderMead
+    optimizer.DeviceNelderMead = TorchNM
+    try:
+        return vel_fit.process(batch, dict(p0), config=cfg, options=opt)
+    finally:
+        optimizer.DeviceNelderMead = keep
+
+
+@pytest.mark.parametrize('maxiter', [10000, 40])
+def test_process_nn_library_device_neldermead(gpu, maxiter):
+    """BASELINE configs[3]'s evaluator under the optimiser: the simplices of an NN
+    library advance on the device (rvs_nm_* state machine; rvs_template_nn for
+    the MLP rows of a round, then vsini / spline / rvs_chisq_point) exactly as
+    the torch reference machine drives them over the batched get_chisq -- same
+    iteration counts, same end points.  maxiter 40: no simplex converges, so
+    every spectrum also goes through the restart from its final simplex
+    (vel_fit.py:640-649), on the device as well."""
+    from rvspecfit_amd import spec_fit, spec_inter, vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    d = dict(np.load(os.path.join(GOLD, 'nn_case.npz')))
+    lam = np.exp(np.linspace(np.log(3950.), np.log(5060.), int(d['dims'][-1])))
+    lib = _nn_lib(d, lam)
+    lib.name = 'aat_580v'
+    spec_inter.register_library(lib, 'golden-nn://')
+    cfg = dict(template_lib='golden-nn://', min_vel=-1000, max_vel=1000,
+               min_vel_step=0.2, vel_step0=5, min_vsini=0.1, max_vsini=500,
+               second_minimizer=False)
+    S, npix = 6, 1000
+    wave = np.linspace(4000, 5000, npix)
+    rng = np.random.default_rng(41)
+    err = np.ones(npix) * 0.05
+    tsp = lib.eval_batch(torch.as_tensor([[5200., 2.5, -1., 0.2]]).to('cuda')
+                         )[0][0].cpu().numpy()
+    base = np.interp(wave, lam, tsp)
+    base = base / np.median(base)
+    lists = [[spec_fit.SpecData('aat_580v', wave,
+                                rng.normal(base, err), err)] for _ in range(S)]
+    batch = SpecBatch.from_specdata(lists)
+    p0 = dict(teff=rng.uniform(4800, 5600, S), logg=rng.uniform(2, 3, S),
+              feh=rng.uniform(-1.4, -0.6, S), alpha=rng.uniform(0.1, 0.3, S),
+              vsini=rng.uniform(5, 30, S))
+    opt = dict(npoly=5)
+    names = ['teff', 'logg', 'feh', 'alpha']
+    keep = vel_fit.NM_MAXITER
+    vel_fit.NM_MAXITER = maxiter
+    try:
+        a = vel_fit.process(batch, dict(p0), config=cfg, options=opt)
+        b = _process_with_torch_machine(batch, p0, cfg, opt, names)
+    finally:
+        vel_fit.NM_MAXITER = keep
+    if maxiter < 100:
+        assert not bool(a['minimize_success'].any())
+        assert int(a['nm_nit'].min()) == 2 * maxiter
+    else:
+        assert bool(a['minimize_success'].all())
+    assert torch.equal(a['nm_nit'], b['nm_nit'])
+    assert torch.equal(a['nm_nfev'], b['nm_nfev'])
+    assert torch.equal(a['minimize_success'], b['minimize_success'])
+    assert torch.equal(a['nm_vel'], b['nm_vel'])
+    for k in names:
+        assert torch.equal(a['param'][k], b['param'][k]), k
+    assert torch.equal(a['chisq'], b['chisq'])
+
+
 def test_ccf_readback_paths_agree(cases, config):
     """the cross-correlation kernel has two read-back paths: tables prefetched
     into registers (<= 512 lags and velocities, the normal case) and the loop

@@ -322,6 +322,22 @@ int rvs_objective_fused(const rvs_objective_arm *arms, int narm, int npoly,
                         double badchi, int outside_penalty, void *scratch,
                         double *out, int32_t *status, void *stream);
 
+/* The same objective for evaluators that are not a grid gather (the MLP of
+ * rvs_template_nn): the unbroadened template of job j on arm a is row j of
+ * templ[a] ([J, ntp] float64, device), its outside flag outside[a][j]
+ * (SpecInterpolator.outsideFlag, spec_inter.py:257-272; the MAX_VAL guard of
+ * getCurTempl, spec_fit.py:392-397, is applied here).  `templ` / `outside` are
+ * HOST arrays of narm device pointers.  Of rvs_objective_arm only pt, factors,
+ * lnstep and ntp are read.  Rotational broadening, spline solve and chi^2 are
+ * the code of rvs_objective_fused: equal arithmetic. */
+int rvs_objective_from_template(const rvs_objective_arm *arms, int narm,
+                                int npoly, const double *const *templ,
+                                const double *const *outside,
+                                const double *vsini, const int32_t *job_spec,
+                                int J, const double *vel, double badchi,
+                                int outside_penalty, void *scratch, double *out,
+                                int32_t *status, void *stream);
+
 /* ------------------------------------------------------------------------
  * Host side of the second minimiser of vel_fit.process (vel_fit.py:653-658:
  * scipy.optimize.minimize(method='BFGS', options={'hess_inv0': ...})): S

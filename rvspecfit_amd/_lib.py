@@ -58,6 +58,8 @@ SIGNATURES = {
     'rvs_objective_max_ntp': (I, [I]),
     'rvs_objective_work_size': (L, [I, I]),
     'rvs_objective_fused': (I, [P, I, I, P, P, P, I, P, D, I, P, P, P, P]),
+    'rvs_objective_from_template': (I, [P, I, I, P, P, P, P, I, P, D, I, P, P, P,
+                                        P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),

@@ -51,9 +51,18 @@ struct ObjArms {
   int n;
 };
 
-template <int P>
+// FROMT: the unbroadened template of every (job, arm) comes from HBM -- a row
+// of an evaluator that is no grid gather (the MLP of rvs_template_nn) -- with
+// its outside flag; everything behind the template (FIR, spline solve, chi^2)
+// is the same code.
+struct ObjTempl {
+  const double *templ[RVS_MAX_ARMS];    // [J, ntp] per arm
+  const double *outside[RVS_MAX_ARMS];  // [J] per arm
+};
+
+template <int P, bool FROMT>
 __global__ void __launch_bounds__(OBJ_NT)
-    objective_kernel(ObjArms A, const double *__restrict__ params,
+    objective_kernel(ObjArms A, ObjTempl TT, const double *__restrict__ params,
                      const double *__restrict__ vsini,
                      const int32_t *__restrict__ job_spec, int J,
                      const double *__restrict__ vel, double eps_ld,
@@ -95,13 +104,29 @@ __global__ void __launch_bounds__(OBJ_NT)
   unsigned long long t_prev = wall_clock64();
 #endif
   // ---- A3/A5: polylinear template into bufA -------------------------------
-  poly_locate<OBJ_NT>(PL, G, params + (int64_t)j * nd, T.idgrid, T.uvecs,
-                      T.vecs_s, T.ngrid);
-  const int mode = PL.mode;
+  int mode = 0;
+  double outside_in = 0.0;
+  if (!FROMT) {
+    poly_locate<OBJ_NT>(PL, G, params + (int64_t)j * nd, T.idgrid, T.uvecs,
+                        T.vecs_s, T.ngrid);
+    mode = PL.mode;
+  } else {
+    // outside != 0 (or not finite): the MAX_VAL guard below scans the row
+    outside_in = TT.outside[blockIdx.y][j];
+    mode = (outside_in == 0.0) ? 0 : 1;
+  }
   OBJ_T(0);
   double mx = 0;
   bool anynan = false;
-  if (mode == 0) {
+  if (FROMT) {
+    const double *row = TT.templ[blockIdx.y] + (int64_t)j * N;
+    for (int k = tid; k < N; k += OBJ_NT) {
+      const double val = row[k];
+      bufA[k] = val;
+      if (!(val == val)) anynan = true;
+      mx = fmax(mx, fabs(val));
+    }
+  } else if (mode == 0) {
     // four CONSECUTIVE pixels per thread: one 16-byte load per vertex row
     // (rows start on 4-byte boundaries only: dword-aligned x4 loads), 1 KiB per
     // wave instruction instead of 256 B
@@ -202,7 +227,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       mm = fmax(mm, red8[i]);
       nn += red8[8 + i];
     }
-    outside = PL.dist;
+    outside = FROMT ? outside_in : PL.dist;
     if (outside > 0 && (mm > 1e100 || nn > 0 || isinf(mm)))
       outside = __builtin_nan("");
   }
@@ -713,7 +738,7 @@ extern "C" int rvs_objective_max_ntp(int npoly) {
   const void *fn = nullptr;
 #define RVS_CASE(PP)                               \
   case PP:                                         \
-    fn = (const void *)objective_kernel<PP>;       \
+    fn = (const void *)objective_kernel<PP, false>;\
     break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
@@ -737,26 +762,36 @@ extern "C" int64_t rvs_objective_work_size(int J, int narm) {
   return (int64_t)narm * J * (int64_t)(2 * sizeof(double) + sizeof(int32_t));
 }
 
-extern "C" int rvs_objective_fused(const rvs_objective_arm *arms, int narm,
-                                   int npoly, const double *params,
-                                   const double *vsini, const int32_t *job_spec,
-                                   int J, const double *vel, double badchi,
-                                   int outside_penalty, void *scratch,
-                                   double *out, int32_t *status, void *stream) {
+static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
+                            const ObjTempl *tt, const double *params,
+                            const double *vsini, const int32_t *job_spec, int J,
+                            const double *vel, double badchi,
+                            int outside_penalty, void *scratch, double *out,
+                            int32_t *status, void *stream) {
   if (J < 1 || narm < 1 || narm > RVS_MAX_ARMS || !arms || !scratch)
     return RVS_E_ARG;
   ObjArms A;
   A.n = narm;
+  ObjTempl TT = {};
+  if (tt) TT = *tt;
   size_t shm = 0;
   for (int i = 0; i < narm; i++) {
     A.a[i] = arms[i];
     if (arms[i].pt.npix < 1 || arms[i].ntp < 4 || arms[i].ntp > 8192 ||
-        arms[i].ndim < 1 || arms[i].ndim > MAXDIM || arms[i].pt.taps ||
-        arms[i].pt.fast_interp || !arms[i].factors)
+        arms[i].pt.taps || arms[i].pt.fast_interp || !arms[i].factors)
       return RVS_E_ARG;
+    if (tt) {
+      if (!TT.templ[i] || !TT.outside[i]) return RVS_E_ARG;
+    } else if (arms[i].ndim < 1 || arms[i].ndim > MAXDIM) {
+      return RVS_E_ARG;
+    }
     shm = max(shm, (size_t)3 * arms[i].ntp * sizeof(double));
   }
-  for (int i = narm; i < RVS_MAX_ARMS; i++) A.a[i] = arms[0];
+  for (int i = narm; i < RVS_MAX_ARMS; i++) {
+    A.a[i] = arms[0];
+    TT.templ[i] = TT.templ[0];
+    TT.outside[i] = TT.outside[0];
+  }
   hipStream_t st = rvs_stream(stream);
   double *armchi = (double *)scratch;
   double *armout = armchi + (int64_t)narm * J;
@@ -764,20 +799,24 @@ extern "C" int rvs_objective_fused(const rvs_objective_arm *arms, int narm,
   dim3 grid(J, narm);
   if (shm > (size_t)3 * rvs_objective_max_ntp(npoly) * sizeof(double))
     return RVS_E_ARG;
-#define RVS_CASE(PP)                                                           \
-  case PP: {                                                                   \
+#define RVS_LAUNCH_OBJ(PP, FT)                                                 \
+  {                                                                            \
     static bool attr_set = false;                                              \
     if (!attr_set) {                                                           \
-      (void)hipFuncSetAttribute((const void *)objective_kernel<PP>,            \
+      (void)hipFuncSetAttribute((const void *)objective_kernel<PP, FT>,        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                 160 * 1024 - 1024);                            \
       (void)hipGetLastError();                                                 \
       attr_set = true;                                                         \
     }                                                                          \
-    hipLaunchKernelGGL(objective_kernel<PP>, grid, dim3(OBJ_NT), shm, st, A,   \
-                       params, vsini, job_spec, J, vel, 0.6, armchi, armst,    \
-                       armout);                                                \
-  } break;
+    hipLaunchKernelGGL((objective_kernel<PP, FT>), grid, dim3(OBJ_NT), shm, st, \
+                       A, TT, params, vsini, job_spec, J, vel, 0.6, armchi,    \
+                       armst, armout);                                         \
+  }
+#define RVS_CASE(PP)                                                           \
+  case PP:                                                                     \
+    if (tt) RVS_LAUNCH_OBJ(PP, true) else RVS_LAUNCH_OBJ(PP, false)            \
+    break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
     RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
@@ -786,9 +825,38 @@ extern "C" int rvs_objective_fused(const rvs_objective_arm *arms, int narm,
       return RVS_E_ARG;
   }
 #undef RVS_CASE
+#undef RVS_LAUNCH_OBJ
   hipLaunchKernelGGL(objective_sum_kernel, dim3((J + 255) / 256), dim3(256), 0,
                      st, narm, J, badchi, outside_penalty, armchi, armst, armout,
                      out, status);
   RVS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int rvs_objective_fused(const rvs_objective_arm *arms, int narm,
+                                   int npoly, const double *params,
+                                   const double *vsini, const int32_t *job_spec,
+                                   int J, const double *vel, double badchi,
+                                   int outside_penalty, void *scratch,
+                                   double *out, int32_t *status, void *stream) {
+  return objective_launch(arms, narm, npoly, nullptr, params, vsini, job_spec, J,
+                          vel, badchi, outside_penalty, scratch, out, status,
+                          stream);
+}
+
+extern "C" int rvs_objective_from_template(
+    const rvs_objective_arm *arms, int narm, int npoly,
+    const double *const *templ, const double *const *outside,
+    const double *vsini, const int32_t *job_spec, int J, const double *vel,
+    double badchi, int outside_penalty, void *scratch, double *out,
+    int32_t *status, void *stream) {
+  if (!templ || !outside || narm < 1 || narm > RVS_MAX_ARMS) return RVS_E_ARG;
+  ObjTempl tt = {};
+  for (int i = 0; i < narm; i++) {
+    tt.templ[i] = templ[i];
+    tt.outside[i] = outside[i];
+  }
+  return objective_launch(arms, narm, npoly, &tt, nullptr, vsini, job_spec, J,
+                          vel, badchi, outside_penalty, scratch, out, status,
+                          stream);
 }

@@ -625,31 +625,42 @@ def fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys=0.0):
         p.taps_stride, p.espec_sys = 0, esys[ia]
         p.npix, p.S, p.ntp = arm.npix, arm.S, lib.ntp
         p.log_step, p.nd, p.fast_interp = int(lib.log_step), 0, 0
-        a.dats, a.idgrid = lib.dats.data_ptr(), lib.idgrid.data_ptr()
-        a.uvecs, a.vecs_s = lib.uvecs.data_ptr(), lib.vecs_s.data_ptr()
         a.factors = lib.spline_factors.data_ptr()
-        a.ngrid, a.lnstep = lib.ngrid, lib.lnstep
-        for d in range(lib.ndim):
-            a.ptp[d] = float(lib.ptp[d])
-            a.lens[d] = int(lib.lens[d])
+        a.lnstep = lib.lnstep
         a.ntp, a.ndim = lib.ntp, lib.ndim
-        a.log_mask, a.exp_flag = lib.log_mask, lib.exp_flag
+        a.log_mask = lib.log_mask
+        if lib.kind == 'regulargrid':
+            a.dats, a.idgrid = lib.dats.data_ptr(), lib.idgrid.data_ptr()
+            a.uvecs, a.vecs_s = lib.uvecs.data_ptr(), lib.vecs_s.data_ptr()
+            a.ngrid = lib.ngrid
+            for d in range(lib.ndim):
+                a.ptp[d] = float(lib.ptp[d])
+                a.lens[d] = int(lib.lens[d])
+            a.exp_flag = lib.exp_flag
+        else:   # rvs_objective_from_template: the grid fields are not read
+            a.dats = a.idgrid = a.uvecs = a.vecs_s = None
+            a.ngrid, a.exp_flag = 0, 0
     return keep
 
 
 _max_ntp = {}
 
 
-def can_fuse_objective(batch, libs, resols=None, fast_interp=False, npoly=10):
-    """the single-kernel objective needs regular-grid libraries on a (log-)uniform
-    template grid that fits LDS, and neither resolution matrices nor fast_interp"""
+def can_fuse_objective(batch, libs, resols=None, fast_interp=False, npoly=10,
+                       from_template=False):
+    """the single-kernel objective needs a (log-)uniform template grid that fits
+    LDS, and neither resolution matrices nor fast_interp; with the gather inside
+    the kernel (rvs_objective_fused) regular-grid libraries, with the template
+    handed over (from_template: rvs_objective_from_template) any evaluator"""
     if fast_interp or not FUSED_OBJECTIVE:
         return False
     if npoly not in _max_ntp:
         _max_ntp[npoly] = _lib.lib().rvs_objective_max_ntp(npoly)
     for ia, arm in enumerate(batch.arms):
         lib = libs[arm.name]
-        if lib.kind != 'regulargrid' or lib.spline_factors is None:
+        if lib.spline_factors is None:
+            return False
+        if lib.kind != 'regulargrid' and not from_template:
             return False
         if lib.ntp > _max_ntp[npoly]:
             return False
@@ -691,6 +702,38 @@ def objective_fused(batch, libs, params, vsini, vel, npoly=5, rbf=True,
                                    _lib.ptr(scratch), _lib.ptr(out),
                                    _lib.ptr(status), _lib.stream())
         _lib.check(rc, 'rvs_objective_fused')
+    del keep
+    return out, status
+
+
+def objective_from_template(batch, libs, templs, outsides, vsini, vel, npoly=5,
+                            rbf=True, job_spec=None, espec_sys=0.0,
+                            outside_penalty=True):
+    """objective_fused for evaluators that are no grid gather: templs[a]
+    [J, ntp_a] (unbroadened), outsides[a] [J] (rvs_objective_from_template)."""
+    import ctypes
+    L = _lib.lib()
+    dev = batch.device
+    vel = vel.to(device=dev, dtype=torch.float64).contiguous()
+    J = vel.shape[0]
+    narm = len(batch.arms)
+    arr = (_lib.ObjectiveArm * narm)()
+    keep = fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys)
+    out = torch.empty(J, dtype=torch.float64, device=dev)
+    status = torch.zeros(J, dtype=torch.int32, device=dev)
+    nb = L.rvs_objective_work_size(J, narm)
+    scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
+    if vsini is not None:
+        vsini = vsini.to(device=dev, dtype=torch.float64).contiguous()
+    tp = (ctypes.c_void_p * narm)(*[t.data_ptr() for t in templs])
+    op = (ctypes.c_void_p * narm)(*[o.data_ptr() for o in outsides])
+    with _ktime('objective_from_template', J):
+        rc = L.rvs_objective_from_template(
+            ctypes.addressof(arr), narm, npoly, ctypes.cast(tp, ctypes.c_void_p),
+            ctypes.cast(op, ctypes.c_void_p), _lib.ptr(vsini), _lib.ptr(job_spec),
+            J, _lib.ptr(vel), float(batch.badchi), int(outside_penalty),
+            _lib.ptr(scratch), _lib.ptr(out), _lib.ptr(status), _lib.stream())
+        _lib.check(rc, 'rvs_objective_from_template')
     del keep
     return out, status
 

@@ -125,7 +125,11 @@ class ProcessObjective:
         self.scratch = torch.empty((nb + 7) // 8, **f64)
         self.fused = engine.can_fuse_objective(batch, libs, resols,
                                                npoly=self.npoly)
-        if self.fused:
+        # evaluators that are no grid gather (MLP, Delaunay): the template rows
+        # of a round from their own kernel, everything behind them in one
+        self.from_templ = (not self.fused) and engine.can_fuse_objective(
+            batch, libs, resols, npoly=self.npoly, from_template=True)
+        if self.fused or self.from_templ:
             self.oarr = (_lib.ObjectiveArm * narm)()
             self._keep = engine.fill_objective_arms(self.oarr, batch, libs,
                                                     self.npoly, self.rbf, 0.0)
@@ -179,6 +183,41 @@ class ProcessObjective:
                 _p(self.vel), self.badchi, 3, _p(self.oscratch), _p(self.chi),
                 _p(self.jstatus), st)
             _lib.check(rc, 'rvs_objective_fused')
+            rc = L.rvs_proc_finish(J, _p(counts), cidx, _p(self.chi),
+                                   _p(self.extra), _p(self.bad),
+                                   _p(self.job_spec), _p(self.jstatus), _p(F),
+                                   _p(self.status), st)
+            _lib.check(rc, 'rvs_proc_finish')
+            self.calls += 1
+            self.jobs += J
+            return
+        if self.from_templ:
+            main = torch.cuda.current_stream()
+            self.ev_in.record(main)
+            for arm, b, side, ev in zip(self.batch.arms, self.arm_buf,
+                                        self.streams, self.ev_out):
+                lib = self.libs[arm.name]
+                side.wait_event(self.ev_in)
+                scr = b['sx']
+                if b['nn'] is not None:
+                    scr = dict(b['nn'], torch_stream=side)
+                lib.eval_into(self.params, J, b['templ'], b['outside'],
+                              ctypes.c_void_p(side.cuda_stream), scratch=scr)
+                ev.record(side)
+            for ev in self.ev_out:
+                main.wait_event(ev)
+            narm = len(self.arm_buf)
+            tp = (ctypes.c_void_p * narm)(*[b['templ'].data_ptr()
+                                            for b in self.arm_buf])
+            op = (ctypes.c_void_p * narm)(*[b['outside'].data_ptr()
+                                            for b in self.arm_buf])
+            rc = L.rvs_objective_from_template(
+                ctypes.addressof(self.oarr), narm, self.npoly,
+                ctypes.cast(tp, ctypes.c_void_p),
+                ctypes.cast(op, ctypes.c_void_p), _p(self.vsini),
+                _p(self.job_spec), J, _p(self.vel), self.badchi, 3,
+                _p(self.oscratch), _p(self.chi), _p(self.jstatus), st)
+            _lib.check(rc, 'rvs_objective_from_template')
             rc = L.rvs_proc_finish(J, _p(counts), cidx, _p(self.chi),
                                    _p(self.extra), _p(self.bad),
                                    _p(self.job_spec), _p(self.jstatus), _p(F),

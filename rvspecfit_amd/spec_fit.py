@@ -386,6 +386,15 @@ def chisq_jobs(batch, idx, vel, params, vsini, options, config,
                                       npoly=npoly, rbf=rbf, job_spec=js,
                                       espec_sys=esys,
                                       outside_penalty=outside_penalty)
+    if engine.can_fuse_objective(batch, libs, resols, npoly=npoly,
+                                 from_template=True):
+        # MLP / Delaunay evaluators: template rows from their own kernel, then
+        # broadening + spline + chi^2 in one kernel
+        tt = [libs[arm.name].eval_batch(params) for arm in batch.arms]
+        return engine.objective_from_template(
+            batch, libs, [t[0] for t in tt], [t[1] for t in tt], vsini, vel,
+            npoly=npoly, rbf=rbf, job_spec=js, espec_sys=esys,
+            outside_penalty=outside_penalty)
     coefs, outs = [], []
     for arm in batch.arms:
         c, o = engine.build_templates(libs[arm.name], params, vsini)

@@ -308,6 +308,48 @@ def get_hess_inv(param_names):
     return np.diag(diag)
 
 
+def _uncertainties_from_hessians(H):
+    """_uncertainties_from_hessian for a stack [S, n, n] in one LAPACK call (the
+    per-matrix Python loop was 0.6 s per 10 000 spectra): np.linalg.inv factors
+    every matrix of a stack on its own, so each inverse is the one-matrix
+    call's, bit for bit; a singular or non-finite matrix takes the
+    diagonal-only branch of the reference.  Returns (diag_err [S, n], covar
+    [S, n, n], bad [S])."""
+    H = np.asarray(H, dtype=np.float64)
+    S, n = H.shape[0], H.shape[1]
+    dh = np.diagonal(H, axis1=1, axis2=2)
+    with np.errstate(all='ignore'):
+        inv_d = 1. / (dh + (dh == 0))
+    inv_d = np.where(dh == 0, np.inf, inv_d)
+    bad = np.zeros(S, dtype=bool)
+    Hinv = np.empty_like(H)
+    ok = np.isfinite(H).all(axis=(1, 2))
+    if ok.any():
+        try:
+            Hinv[ok] = np.linalg.inv(H[ok])
+        except np.linalg.LinAlgError:    # some matrix is exactly singular
+            for i in np.nonzero(ok)[0]:
+                try:
+                    Hinv[i] = np.linalg.inv(H[i])
+                except np.linalg.LinAlgError:
+                    ok[i] = False
+    for i in np.nonzero(~ok)[0]:
+        bad[i] = True
+        Hinv[i] = np.diag(inv_d[i])
+    e0 = np.array(np.diagonal(Hinv, axis1=1, axis2=2))
+    e1 = inv_d
+    bad0, bad1 = e0 < 0, e1 < 0
+    bad |= bad0.any(axis=1)
+    sub1, sub2 = bad0 & ~bad1, bad0 & bad1
+    e0[sub1] = e1[sub1]
+    e0[sub2] = 0
+    with np.errstate(all='ignore'):
+        err = np.sqrt(e0)
+    err[sub2] = np.nan
+    bad |= (~np.isfinite(err)).any(axis=1)
+    return err, Hinv, bad
+
+
 def _uncertainties_from_hessian(hessian):
     """vel_fit._uncertainties_from_hessian (vel_fit.py:464-502), one matrix"""
     diag_hessian = np.diag(hessian)
@@ -458,9 +500,8 @@ def _hessian_stage(obj, names, vel, params, vsini):
                                         ).cpu().numpy()
         else:
             H = numdiff.hessian_retry(fn, xx)
-        for k, i in enumerate(todo):
-            diag_err[i], covar[i], bad_hessian[i] = \
-                _uncertainties_from_hessian(H[k])
+        diag_err[todo], covar[todo], bad_hessian[todo] = \
+            _uncertainties_from_hessians(H)
         todo = todo[bad_hessian[todo]]
     return diag_err, covar, bad_hessian
 
@@ -605,6 +646,18 @@ def _process_split(batch, paramDict0, kwargs):
     return _merge_parts(parts, idxs, S)
 
 
+def _rounds_run_in_c(batch, config, resolParams):
+    """the optimiser's rounds of this batch run inside the library (rvs_nm_run:
+    regular-grid libraries, no resolution matrix); only then do two host threads
+    help -- rounds driven from Python (MLP / Delaunay evaluators, resolution
+    matrices) share the interpreter lock: 432 against 586 spectra/s for an NN
+    library split in two"""
+    libs = spec_inter.get_libs(batch.names, config)
+    return resolParams is None and all(
+        libs[a.name].kind == 'regulargrid' and a.resol is None
+        for a in batch.arms)
+
+
 def process(specdata, paramDict0, fixParam=None, options=None, config=None,
             resolParams=None, priors=None, timers=None):
     """vel_fit.process (see _process_one); a large SpecBatch is fitted as two
@@ -613,7 +666,8 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
         raise RuntimeError('Config must be provided')
     if (PROCESS_STREAMS == 2 and isinstance(specdata, SpecBatch)
             and specdata.S >= PROCESS_SPLIT_MIN and timers is None
-            and not getattr(_tls, 'single', False)):
+            and not getattr(_tls, 'single', False)
+            and _rounds_run_in_c(specdata, config, resolParams)):
         return _process_split(specdata, paramDict0, dict(
             fixParam=fixParam, options=options, config=config,
             resolParams=resolParams, priors=priors))

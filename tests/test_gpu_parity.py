@@ -1330,6 +1330,77 @@ def test_objective_fused(cases, config, tag):
                 assert abs(c1[k].item() - want) < 1e-6 * sc, (i, c1[k].item())
 
 
+@pytest.mark.parametrize('kind', ['triangulation', 'nn'])
+def test_objective_from_template(cases, gpu, kind):
+    """rvs_objective_from_template (template rows of a Delaunay / MLP evaluator
+    from their own kernel, then FIR + spline solve + chi^2 in one kernel) against
+    the chain of stand-alone kernels (rvs_vsini_convolve -> rvs_spline_construct
+    -> rvs_chisq_point) on the same rows, and -- Delaunay -- against the
+    reference's get_chisq"""
+    from rvspecfit_amd import engine, spec_fit, spec_inter
+    from rvspecfit_amd.library import TemplateLibrary
+    rng = np.random.RandomState(12)
+    if kind == 'triangulation':
+        g = dict(np.load(os.path.join(GOLD, 'tri_cases.npz')))
+        cfg = dict(GOLD_CONFIG, template_lib='golden-tri://')
+        for n in ('gold_b', 'gold_r'):
+            d = np.load(os.path.join(GOLD, 'lib_tri_%s.npz' % n))
+            spec_inter.register_library(TemplateLibrary(n, d), 'golden-tri://')
+        sds = _sds(cases, 'c1')
+        par = np.array([g['c1/t%d/param' % i] for i in range(4)])
+        vel = np.array([float(g['c1/t%d/vel' % i]) for i in range(4)])
+        vsn = np.array([float(g['c1/t%d/vsini' % i]) for i in range(4)])
+        want = np.array([float(g['c1/t%d/value' % i]) for i in range(4)])
+        npoly = 10
+    else:
+        d = dict(np.load(os.path.join(GOLD, 'nn_case.npz')))
+        lam = np.exp(np.linspace(np.log(3950.), np.log(5060.),
+                                 int(d['dims'][-1])))
+        lib = _nn_lib(d, lam)
+        lib.name = 'aat_580v'
+        spec_inter.register_library(lib, 'golden-nn://')
+        cfg = dict(GOLD_CONFIG, template_lib='golden-nn://')
+        wave = np.linspace(4000, 5000, 1000)
+        err = np.ones(1000) * 0.1
+        sds = [spec_fit.SpecData('aat_580v', wave,
+                                 rng.normal(wave * 0 + 1, err), err)]
+        par = np.stack([rng.uniform(4500, 6500, 6), rng.uniform(1, 4, 6),
+                        rng.uniform(-2, 0, 6), rng.uniform(0, 0.4, 6)], axis=1)
+        vel = rng.uniform(-300, 300, 6)
+        vsn = np.array([np.nan, np.nan, np.nan, 5., 40., 250.])
+        want = None
+        npoly = 5
+    b, _ = spec_fit.as_batch(sds)
+    libs = spec_inter.get_libs(b.names, cfg)
+    assert engine.can_fuse_objective(b, libs, None, npoly=npoly,
+                                     from_template=True)
+    assert not engine.can_fuse_objective(b, libs, None, npoly=npoly)
+    for with_rot in (False, True):
+        ii = np.nonzero(np.isfinite(vsn) == with_rot)[0]
+        if not len(ii):
+            continue
+        tv = torch.as_tensor(vel[ii]).to('cuda')
+        tp = torch.as_tensor(par[ii]).to('cuda')
+        vs = torch.as_tensor(vsn[ii]).to('cuda') if with_rot else None
+        idx = torch.zeros(len(ii), dtype=torch.long, device='cuda')
+        out = {}
+        for fused in (True, False):
+            engine.FUSED_OBJECTIVE = fused
+            try:
+                with np.errstate(all='ignore'):
+                    out[fused] = spec_fit.chisq_jobs(b, idx, tv, tp, vs,
+                                                     dict(npoly=npoly), cfg)
+            finally:
+                engine.FUSED_OBJECTIVE = True
+        (c1, s1), (c0, s0) = out[True], out[False]
+        assert torch.equal(s0, s1)
+        for k, i in enumerate(ii):
+            sc = max(abs(c0[k].item()), 1e3)
+            assert abs(c1[k].item() - c0[k].item()) < 1e-11 * sc, (kind, i)
+            if want is not None:
+                assert abs(c1[k].item() - want[i]) < 1e-6 * max(abs(want[i]), 1e3)
+
+
 def test_resolution_matrix_grid_nd11(cases, config, gold_libs, gold_config):
     """11-diagonal matrices (the DESI width) take the register-window variant of
     the grid kernel; against the oracle's get_chisq on a velocity grid"""

@@ -6,7 +6,7 @@ out=gpurun_out/configs_$tag.jsonl
 : > $out
 run() { python bench.py "$@" 2>/dev/null | tail -1 >> $out; }
 run --steps 3 --warmup 1
-run --ccf-every 9 --steps 2 --warmup 1 --cpu-sample 32
+run --ccf-every 9 --steps 2 --warmup 1 --cpu-sample 64
 run --workload cfg2 --spectra 1000 --steps 5 --warmup 1 --cpu-sample 256
 run --evaluator nn --steps 3 --warmup 1
 run --refine --steps 2 --warmup 1 --no-cpu-baseline
@@ -18,12 +18,20 @@ run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --proc
 run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --desi-nfiles 16
 run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --desi-nfiles 16 --process-bfgs
 run --spectra 62500 --steps 2 --warmup 1 --no-cpu-baseline
+# a library of realistic size (17 600 templates, dimensions of different length,
+# 440 MB per arm: gathers served from HBM), the default step and the optimiser
+run --grid 40,11,8,5 --steps 3 --warmup 1 --no-cpu-baseline
+run --grid 40,11,8,5 --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000
+# the optimiser stage at full batch size, and on the NN evaluator
+run --spectra 10000 --steps 1 --warmup 1 --no-cpu-baseline --process 10000
+run --evaluator nn --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000
 python - <<PY
 import json
 for l in open("$out"):
     d = json.loads(l)
     c = d["config"]
-    print(round(d["value"]), d["ms_per_step"], c["spectra_per_gpu"], c["ccf_templates"], c.get("refine"), c.get("resolution_matrix"),
-          d["roofline"]["frac"], d["roofline_ccf"]["frac"], (d.get("cpu_baseline") or {}).get("value"), d["kernels"].get("template_nn"), (d.get("process") or {}).get("spectra_per_s"),
+    print(round(d["value"]), d["ms_per_step"], c["traffic_key"], d["roofline"]["frac"], d["roofline"]["traffic"],
+          d["roofline_ccf"]["frac"], d["roofline_ccf"]["traffic"], (d.get("cpu_baseline") or {}).get("value"),
+          (d["kernels"].get("template_polylinear") or {}).get("alg_GBps"), (d.get("process") or {}).get("spectra_per_s"),
           (d.get("desi_file") or {}).get("fibres_per_s"))
 PY

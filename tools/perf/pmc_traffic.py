@@ -49,10 +49,10 @@ def main():
         ccf_xcorr=entry(['ccf_xcorr_kernel'], 'ccf_xcorr_kernel',
                         'ccf_xcorr_kernel (one launch = one accumulator chunk x T '
                         'templates x one arm)'),
-        chisq_grid=entry(['chisq_grid_kernel', 'chisq_grid_resol_kernel'],
+        chisq_grid=entry(['chisq_grid_kernel', 'chisq_grid_resol'],
                          'chisq_grid_kernel<10, false>'
                          if not any('chisq_grid_resol' in k for k in fe)
-                         else 'chisq_grid_resol_kernel',
+                         else 'chisq_grid_resol',
                          'every chisq_grid kernel of one rvs_chisq_grid call (full '
                          'waves + packed left-over velocities); FETCH_SIZE '
                          'doubling is calibrated for 16-B streaming reads, this '

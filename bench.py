@@ -409,6 +409,9 @@ def main():
                     help='with --desi-file: this many copies of the file are '
                          'processed as one group (desi_fit.proc_desi_group, what '
                          'proc_many does with files_per_batch)')
+    ap.add_argument('--desi-files-per-batch', type=int, default=4,
+                    help='with --desi-nfiles: files fitted together in one GPU '
+                         'batch (proc_many files_per_batch)')
     ap.add_argument('--desi-workers', type=int, default=1,
                     help='with --desi-nfiles: worker processes sharing the GPU '
                          '(proc_many nthreads); the synthetic template libraries '
@@ -1008,7 +1011,7 @@ def run_desi_addon(arms, args, dev, dicts):
         D.proc_many(links, tmp, 'rvtab', 'rvmod', config_fname=cfgf, minsn=-1e9,
                     doplot=False, subdirs=False, npoly=OPTIONS['npoly'],
                     process_status_file=st, shard=(0, 1),
-                    files_per_batch=min(4, nfiles),
+                    files_per_batch=min(max(1, args.desi_files_per_batch), nfiles),
                     nthreads=max(1, args.desi_workers))
         rows = [l.split() for l in open(st).read().strip().split('\n')]
         assert all(r[1] == 'SUCCESS' for r in rows), rows
@@ -1020,6 +1023,7 @@ def run_desi_addon(arms, args, dev, dicts):
     tab = F.open(tabf, verify_checksum=True)['RVTAB'].data
     warn = np.asarray(tab['RVS_WARN'])
     out = dict(fibres=int(nfit), files=nfiles,
+               files_per_batch=min(max(1, args.desi_files_per_batch), nfiles),
                workers=max(1, args.desi_workers) if nfiles > 1 else 1,
                fibres_per_s=round(nfit / dt, 1), seconds=round(dt, 2),
                stage_s={k: round(v, 3) for k, v in tm.items()},

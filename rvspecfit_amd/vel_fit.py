@@ -646,16 +646,17 @@ def _process_split(batch, paramDict0, kwargs):
     return _merge_parts(parts, idxs, S)
 
 
-def _rounds_run_in_c(batch, config, resolParams):
+def _rounds_run_in_c(batch, config, resolParams, options=None):
     """the optimiser's rounds of this batch run inside the library (rvs_nm_run:
     regular-grid libraries, no resolution matrix); only then do two host threads
     help -- rounds driven from Python (MLP / Delaunay evaluators, resolution
     matrices) share the interpreter lock: 432 against 586 spectra/s for an NN
     library split in two"""
     libs = spec_inter.get_libs(batch.names, config)
-    return resolParams is None and all(
-        libs[a.name].kind == 'regulargrid' and a.resol is None
-        for a in batch.arms)
+    npoly = (options or {}).get('npoly') or 5
+    return engine.can_fuse_objective(batch, libs,
+                                     spec_fit._resols(batch, resolParams),
+                                     npoly=npoly)
 
 
 def process(specdata, paramDict0, fixParam=None, options=None, config=None,
@@ -667,7 +668,7 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
     if (PROCESS_STREAMS == 2 and isinstance(specdata, SpecBatch)
             and specdata.S >= PROCESS_SPLIT_MIN and timers is None
             and not getattr(_tls, 'single', False)
-            and _rounds_run_in_c(specdata, config, resolParams)):
+            and _rounds_run_in_c(specdata, config, resolParams, options)):
         return _process_split(specdata, paramDict0, dict(
             fixParam=fixParam, options=options, config=config,
             resolParams=resolParams, priors=priors))

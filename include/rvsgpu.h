@@ -49,8 +49,10 @@ extern "C" {
  *   2: status bit 0x100 = RVS_ST_ILLCOND; rvs_chisq_grid's int after `beta` is
  *      pack_min_jobs; rvs_chisq_continuum_work_size = 8 doubles per spectrum
  *   3: rvs_template_polylinear / rvs_objective_arm take `ptp` (the query is
- *      p / ptp as in spec_inter.py:130-132), not its reciprocal */
-#define RVS_ABI_VERSION 3
+ *      p / ptp as in spec_inter.py:130-132), not its reciprocal
+ *   4: rvs_objective_work_size grew (the cell-search records of the objective's
+ *      locate pass live in the caller's scratch) */
+#define RVS_ABI_VERSION 4
 int rvs_abi_version(void);
 
 /* ------------------------------------------------------------------------

@@ -72,7 +72,7 @@ SIGNATURES = {
 
 _lib = None
 # RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class RvsGpuError(RuntimeError):

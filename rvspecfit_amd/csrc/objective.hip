@@ -60,9 +60,62 @@ struct ObjTempl {
   const double *outside[RVS_MAX_ARMS];  // [J] per arm
 };
 
+// The cell search of a (job, arm) -- log10 mapping, one binary search per
+// dimension, 2^ndim idgrid look-ups, weights; outside the grid the brute-force
+// nearest neighbour -- is a chain of dependent loads that a few threads walk while
+// the other 500 of an objective block wait: 7.7 % of the block's time on the one
+// block a CU can hold.  objective_locate_kernel runs it ahead for all (job, arm)
+// pairs of a launch with one wave each (thousands of them resident at once, their
+// latencies overlapping) and leaves a record the objective block fetches with one
+// coalesced load.  Same poly_locate code: the same ids, weights and distances.
+#define OBJ_LOC_NV 16                      // grids of up to 4 dimensions
+#define OBJ_LOC_REC (2 * OBJ_LOC_NV + 2)   // doubles: w[16], id[16], dist, {mode, nearest}
+
+__device__ __forceinline__ GridDesc obj_grid_desc(const rvs_objective_arm &T) {
+  GridDesc G;
+  const int nd = T.ndim;
+  G.ndim = nd;
+  G.log_mask = T.log_mask;
+  int off = 0;
+  for (int d = 0; d < nd; d++) {
+    G.lens[d] = T.lens[d];
+    G.uoff[d] = off;
+    off += T.lens[d];
+    G.ptp[d] = T.ptp[d];
+  }
+  int64_t st = 1;
+  for (int d = nd - 1; d >= 0; d--) {
+    G.gstride[d] = st;
+    st *= T.lens[d];
+  }
+  return G;
+}
+
+__global__ void __launch_bounds__(64)
+    objective_locate_kernel(ObjArms A, const double *__restrict__ params, int J,
+                            double *__restrict__ loc) {
+  __shared__ PolyLoc PL;
+  const rvs_objective_arm &T = A.a[blockIdx.y];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const GridDesc G = obj_grid_desc(T);
+  poly_locate<64>(PL, G, params + (int64_t)j * T.ndim, T.idgrid, T.uvecs,
+                  T.vecs_s, T.ngrid);
+  double *r = loc + ((int64_t)blockIdx.y * J + j) * OBJ_LOC_REC;
+  if (tid < OBJ_LOC_NV) {
+    r[tid] = PL.w[tid];
+    reinterpret_cast<int64_t *>(r)[OBJ_LOC_NV + tid] = PL.id[tid];
+  } else if (tid == OBJ_LOC_NV) {
+    r[2 * OBJ_LOC_NV] = PL.dist;
+    int32_t *mi = reinterpret_cast<int32_t *>(r + 2 * OBJ_LOC_NV + 1);
+    mi[0] = PL.mode;
+    mi[1] = PL.nearest;
+  }
+}
+
 template <int P, bool FROMT>
 __global__ void __launch_bounds__(OBJ_NT)
-    objective_kernel(ObjArms A, ObjTempl TT, const double *__restrict__ params,
+    objective_kernel(ObjArms A, ObjTempl TT, const double *__restrict__ locrec,
+                     const double *__restrict__ params,
                      const double *__restrict__ vsini,
                      const int32_t *__restrict__ job_spec, int J,
                      const double *__restrict__ vel, double eps_ld,
@@ -83,23 +136,6 @@ __global__ void __launch_bounds__(OBJ_NT)
   const int N = T.ntp, m = N - 2;
   double *bufA = lds, *bufB = lds + N, *bufC = lds + 2 * N;
   const int nd = T.ndim, nv = 1 << nd;
-  GridDesc G;
-  G.ndim = nd;
-  G.log_mask = T.log_mask;
-  {
-    int off = 0;
-    for (int d = 0; d < nd; d++) {
-      G.lens[d] = T.lens[d];
-      G.uoff[d] = off;
-      off += T.lens[d];
-      G.ptp[d] = T.ptp[d];
-    }
-    int64_t st = 1;
-    for (int d = nd - 1; d >= 0; d--) {
-      G.gstride[d] = st;
-      st *= T.lens[d];
-    }
-  }
 #ifdef RVS_OBJ_TIMING
   unsigned long long t_prev = wall_clock64();
 #endif
@@ -107,8 +143,24 @@ __global__ void __launch_bounds__(OBJ_NT)
   int mode = 0;
   double outside_in = 0.0;
   if (!FROMT) {
-    poly_locate<OBJ_NT>(PL, G, params + (int64_t)j * nd, T.idgrid, T.uvecs,
-                        T.vecs_s, T.ngrid);
+    if (locrec) {   // the record objective_locate_kernel left for this (job, arm)
+      const double *r = locrec + ((int64_t)blockIdx.y * J + j) * OBJ_LOC_REC;
+      if (tid < OBJ_LOC_NV) {
+        PL.w[tid] = r[tid];
+        PL.id[tid] = reinterpret_cast<const int64_t *>(r)[OBJ_LOC_NV + tid];
+      } else if (tid == 64) {
+        PL.dist = r[2 * OBJ_LOC_NV];
+        const int32_t *mi =
+            reinterpret_cast<const int32_t *>(r + 2 * OBJ_LOC_NV + 1);
+        PL.mode = mi[0];
+        PL.nearest = mi[1];
+      }
+      __syncthreads();
+    } else {     // grids of more than 4 dimensions: in the block
+      const GridDesc G = obj_grid_desc(T);
+      poly_locate<OBJ_NT>(PL, G, params + (int64_t)j * nd, T.idgrid, T.uvecs,
+                          T.vecs_s, T.ngrid);
+    }
     mode = PL.mode;
   } else {
     // outside != 0 (or not finite): the MAX_VAL guard below scans the row
@@ -257,28 +309,83 @@ __global__ void __launch_bounds__(OBJ_NT)
       }
     }
     if (!copy) {
+      // The kernel's primitives (an asin and a sqrt each, ~150 dependent fp64
+      // instructions) at the clipped points x_j = clip(j / R), j = -1 .. kmax+1,
+      // ONE per thread: tap k needs them at j = k-1, k, k+1, and evaluated
+      // inside rot_segment every tap thread walked four of them in a row while
+      // the other 450 threads of the block waited.  Same arguments, same
+      // function: the same values.  (bufB is free until the FIR writes it.)
+      double *pk0 = bufB, *pk1 = bufB + (kmax + 3);
+      for (int jj = tid; jj <= kmax + 2; jj += OBJ_NT) {
+        const double x = fmin(fmax((jj - 1) / R, -1.0), 1.0);
+        double k0, k1;
+        rot_prim(x, eps_ld, k0, k1);
+        pk0[jj] = k0;
+        pk1[jj] = k1;
+      }
+      __syncthreads();
       double psum = 0;
       for (int k = tid; k <= kmax; k += OBJ_NT) {
         double ww = 0;
+        // x_{k-1}, x_k, x_{k+1} are entries k, k+1, k+2
         double lo = fmin(fmax(k / R, -1.0), 1.0),
                hi = fmin(fmax((k + 1) / R, -1.0), 1.0);
-        if (hi > lo) ww += rot_segment(lo, hi, -R, 1.0 + k, eps_ld);
+        if (hi > lo)   // rot_segment(lo, hi, -R, 1 + k)
+          ww += -R * (pk1[k + 2] - pk1[k + 1]) +
+                (1.0 + k) * (pk0[k + 2] - pk0[k + 1]);
         lo = fmin(fmax((k - 1) / R, -1.0), 1.0);
         hi = fmin(fmax(k / R, -1.0), 1.0);
-        if (hi > lo) ww += rot_segment(lo, hi, R, 1.0 - k, eps_ld);
+        if (hi > lo)   // rot_segment(lo, hi, R, 1 - k)
+          ww += R * (pk1[k + 1] - pk1[k]) + (1.0 - k) * (pk0[k + 1] - pk0[k]);
         bufC[k] = ww;
         psum += (k == 0) ? ww : 2 * ww;
       }
       psum = block_sum<OBJ_NW>(psum, red8);
       __syncthreads();
       const double inv = 1.0 / psum;
-      for (int i = tid; i < N; i += OBJ_NT) {
-        double acc = 0;
-        for (int q = max(0, i - kmax); q <= min(N - 1, i + kmax); q++) {
-          const int mm = q - i;
-          acc = fma(bufA[q], bufC[mm < 0 ? -mm : mm] * inv, acc);
+      // normalised taps once (the product every output formed per tap)
+      for (int k = tid; k <= kmax; k += OBJ_NT) bufC[k] = bufC[k] * inv;
+      __syncthreads();
+      // Four consecutive outputs per thread and trip: at tap offset mm the four
+      // inputs are a sliding window -- one new LDS read per offset, the tap read
+      // once for four FMAs -- where one output per trip read input and tap for
+      // every FMA (the phase was LDS bound: 12 % of the block).  Each output
+      // still sums over q ascending with separately rounded tap products, so
+      // the values are the ones of the plain loop (an input outside [0, N) and a
+      // tap offset behind kmax count as exact zeros: fma(0, t, acc) = acc).  Thread t owns
+      // the outputs [t L, (t + 1) L).
+      {
+        const int Lc = (N + OBJ_NT - 1) / OBJ_NT;
+        const int c0 = tid * Lc, c1 = min(N, c0 + Lc);
+        auto in = [&](int q) { return (q >= 0 && q < N) ? bufA[q] : 0.0; };
+        auto tp = [&](int mm) { return bufC[mm < 0 ? -mm : mm]; };
+        for (int i0 = c0; i0 < c1; i0 += 4) {
+          double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+          int q = i0 - kmax;                 // input of output i0 at offset -kmax
+          double a0 = in(q), a1 = in(q + 1), a2 = in(q + 2), a3 = in(q + 3);
+          for (int mm = -kmax; mm <= kmax; mm += 4, q += 4) {
+            double t = tp(mm);
+            s0 = fma(a0, t, s0), s1 = fma(a1, t, s1);
+            s2 = fma(a2, t, s2), s3 = fma(a3, t, s3);
+            a0 = in(q + 4);
+            t = (mm + 1 <= kmax) ? tp(mm + 1) : 0.0;
+            s0 = fma(a1, t, s0), s1 = fma(a2, t, s1);
+            s2 = fma(a3, t, s2), s3 = fma(a0, t, s3);
+            a1 = in(q + 5);
+            t = (mm + 2 <= kmax) ? tp(mm + 2) : 0.0;
+            s0 = fma(a2, t, s0), s1 = fma(a3, t, s1);
+            s2 = fma(a0, t, s2), s3 = fma(a1, t, s3);
+            a2 = in(q + 6);
+            t = (mm + 3 <= kmax) ? tp(mm + 3) : 0.0;
+            s0 = fma(a3, t, s0), s1 = fma(a0, t, s1);
+            s2 = fma(a1, t, s2), s3 = fma(a2, t, s3);
+            a3 = in(q + 7);
+          }
+          bufB[i0] = s0;
+          if (i0 + 1 < c1) bufB[i0 + 1] = s1;
+          if (i0 + 2 < c1) bufB[i0 + 2] = s2;
+          if (i0 + 3 < c1) bufB[i0 + 3] = s3;
         }
-        bufB[i] = acc;
       }
       y = bufB;
       dp = bufA;
@@ -555,9 +662,40 @@ __global__ void __launch_bounds__(OBJ_NT)
       for (int i = 0; i < h; i++) {
         const bool has_hi = (i + h < cnt);
         const double lo = vals[i], hi = has_hi ? vals[i + h] : 0.0;
-        const double send = up ? lo : hi;
-        const double keep = up ? hi : lo;
-        vals[i] = keep + __shfl_xor(send, mk, 64);
+        if (mk >= 16) {
+          // v_permlane32_swap / v_permlane16_swap (gfx950): the upper half (odd
+          // rows) of `lo` trades places with the lower half (even rows) of `hi`
+          // -- exactly this step's exchange, on the VALU: afterwards the lower
+          // lanes hold both lo's, the upper lanes both hi's.  As ds_bpermute
+          // (__shfl_xor) the 50 exchanges of these two steps, from 8 waves at
+          // once, queued on the CU's one LDS crossbar: 13.8 % of the block.
+          const unsigned l0 = __double2loint(lo), l1 = __double2hiint(lo);
+          const unsigned h0 = __double2loint(hi), h1 = __double2hiint(hi);
+          if (mk == 32) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
+            vals[i] = __hiloint2double(r1[0], r0[0]) +
+                      __hiloint2double(r1[1], r0[1]);
+          } else {
+            const auto r0 = __builtin_amdgcn_permlane16_swap(l0, h0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(l1, h1, false, false);
+            vals[i] = __hiloint2double(r1[0], r0[0]) +
+                      __hiloint2double(r1[1], r0[1]);
+          }
+        } else {
+          const double send = up ? lo : hi;
+          const double keep = up ? hi : lo;
+          double recv;   // lane ^ mk inside a row of 16: DPP, no LDS
+          if (mk == 8)        // row_mirror then row_half_mirror
+            recv = dpp_get<0x141, 0xf, 0xf>(dpp_get<0x140, 0xf, 0xf>(send));
+          else if (mk == 4)   // row_half_mirror then quad_perm [3,2,1,0]
+            recv = dpp_get<0x1b, 0xf, 0xf>(dpp_get<0x141, 0xf, 0xf>(send));
+          else if (mk == 2)   // quad_perm [2,3,0,1]
+            recv = dpp_get<0x4e, 0xf, 0xf>(send);
+          else                // quad_perm [1,0,3,2]
+            recv = dpp_get<0xb1, 0xf, 0xf>(send);
+          vals[i] = keep + recv;
+        }
       }
       lim = up ? lim : min(lim, base + h);
       base += up ? h : 0;
@@ -568,6 +706,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       if (i < cnt && base + i < lim) red[w][base + i] = vals[i];
   }
   __syncthreads();
+  OBJ_T(8);   // (debug) wave reductions of the NV sums
   // fold of the waves' partial sums (wave order), one sum per thread
   if (tid < NV) {
     double v = red[0][tid];
@@ -576,6 +715,7 @@ __global__ void __launch_bounds__(OBJ_NT)
     red[0][tid] = v;
   }
   __syncthreads();
+  OBJ_T(9);   // (debug) fold over the waves
   if (w == 0) {
     // Cholesky + the two triangular solves with ROW i on lane i (i < P):
     // left-looking, sums over q ascending as in the in-lane version of the
@@ -606,8 +746,18 @@ __global__ void __launch_bounds__(OBJ_NT)
       for (int q = 0; q < jj; q++) sum -= row[q] * bcast(row[q], jj);  // L[jj][q]
       // every lane runs the same instructions; lane jj's results are the ones
       // that count
-      const double d = sqrt(sum);
-      const double rd = 1.0 / d;
+      // d = sqrt(sum) and 1 / d from ONE reciprocal square root (hardware
+      // estimate + two Newton steps: error ~1e-30 before rounding) instead of an
+      // IEEE sqrt followed by an IEEE division -- some 45 dependent instructions
+      // per column of a chain that the rest of the block waits for; d differs
+      // from the correctly rounded root by at most an ulp
+      double rd = __builtin_amdgcn_rsq(sum);
+      {
+        const double hx = 0.5 * sum;
+        rd = fma(rd, fma(-hx * rd, rd, 0.5), rd);
+        rd = fma(rd, fma(-hx * rd, rd, 0.5), rd);
+      }
+      const double d = sum * rd;
       if (lane == jj) {
         if (!(sum > 0)) ok = false;
         dg = d;
@@ -759,7 +909,10 @@ extern "C" int rvs_objective_max_ntp(int npoly) {
 
 extern "C" int64_t rvs_objective_work_size(int J, int narm) {
   if (J < 1 || narm < 1) return 0;
-  return (int64_t)narm * J * (int64_t)(2 * sizeof(double) + sizeof(int32_t));
+  // per (arm, job): chi^2, outside, status (padded to 8 bytes) + the cell-search
+  // record of objective_locate_kernel
+  return (int64_t)narm * J *
+         (int64_t)(3 * sizeof(double) + OBJ_LOC_REC * sizeof(double));
 }
 
 static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
@@ -796,9 +949,21 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
   double *armchi = (double *)scratch;
   double *armout = armchi + (int64_t)narm * J;
   int32_t *armst = (int32_t *)(armout + (int64_t)narm * J);
+  double *locbuf = armout + 2 * (int64_t)narm * J;   // (status padded to 8 B)
   dim3 grid(J, narm);
   if (shm > (size_t)3 * rvs_objective_max_ntp(npoly) * sizeof(double))
     return RVS_E_ARG;
+  const double *loc = nullptr;
+  if (!tt) {
+    bool pre = true;
+    for (int i = 0; i < narm; i++)
+      if ((1 << arms[i].ndim) > OBJ_LOC_NV) pre = false;
+    if (pre) {
+      hipLaunchKernelGGL(objective_locate_kernel, grid, dim3(64), 0, st, A,
+                         params, J, locbuf);
+      loc = locbuf;
+    }
+  }
 #define RVS_LAUNCH_OBJ(PP, FT)                                                 \
   {                                                                            \
     static bool attr_set = false;                                              \
@@ -810,8 +975,8 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
       attr_set = true;                                                         \
     }                                                                          \
     hipLaunchKernelGGL((objective_kernel<PP, FT>), grid, dim3(OBJ_NT), shm, st, \
-                       A, TT, params, vsini, job_spec, J, vel, 0.6, armchi,    \
-                       armst, armout);                                         \
+                       A, TT, loc, params, vsini, job_spec, J, vel, 0.6,       \
+                       armchi, armst, armout);                                 \
   }
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \

@@ -83,8 +83,11 @@ __device__ void poly_locate(PolyLoc &L, const GridDesc &G,
       }
       L.id[v] = idgrid[off];
     }
-    if (tid >= 64 && tid < 64 + nd) {
-      const int d = tid - 64;
+    // (beside the vertex look-ups when the block has a second wave for it)
+    constexpr int XO = (NT > 64) ? 64 : 0;
+    if (NT <= 64) __syncthreads();
+    if (tid >= XO && tid < XO + nd) {
+      const int d = tid - XO;
       const double *u = uvecs + G.uoff[d];
       const int p = L.pos[d];
       L.x[d] = (L.mp[d] - u[p]) / (u[p + 1] - u[p]);

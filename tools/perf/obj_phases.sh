@@ -14,8 +14,8 @@ L = _lib.lib()
 buf = (ctypes.c_ulonglong * 16)()
 L.rvs_dbg_read.argtypes = [ctypes.c_void_p]
 L.rvs_dbg_read(ctypes.addressof(buf))
-t = np.array(buf[:8], dtype=float)
-names = ['locate', 'gather+exp', 'vsini', 'spline', 'tv+normal', 'reduce+chol', 'resid', 'model pass']
+t = np.array(buf[:10], dtype=float)
+names = ['locate', 'gather+exp', 'vsini', 'spline', 'tv+normal', 'cholesky+solve', 'resid', 'model pass', 'wave reduce', 'fold']
 print({n: round(float(v / t.sum()), 3) for n, v in zip(names, t)}, 'total ticks', t.sum())
 PY
 cp /tmp/librvsgpu_orig.so rvspecfit_amd/librvsgpu.so

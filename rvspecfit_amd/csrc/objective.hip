@@ -170,6 +170,74 @@ __global__ void __launch_bounds__(OBJ_NT)
   OBJ_T(0);
   double mx = 0;
   bool anynan = false;
+  // The first pixel group's vertex rows are requested NOW and the rotational
+  // kernel is built while they are in flight (it depends on the job's vsini
+  // only: ~1.5 us of asin / sqrt arithmetic and two barriers that used to sit
+  // behind the gather, between its last round trip and the FIR).
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int N4 = N & ~3;
+  const bool vec_gather = !FROMT && mode == 0 && nv <= 16;
+  f4u rn[16];
+  if (vec_gather && 4 * tid < N4) {
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      rn[u] = *reinterpret_cast<const f4u *>(
+          T.dats + PL.id[min(u, nv - 1)] * N + 4 * tid);
+  }
+  int st_extra = 0;
+  bool copy = true;
+  int kmax = 0;
+  if (vsini) {
+    const double vs = vsini[j];
+    const double R = (vs / RVS_C_KMS) / T.lnstep;
+    copy = !(vs > 0) || (R < 1e-9);
+    if (!copy) {
+      kmax = (int)ceil(R + 1);
+      if (kmax >= N) {
+        st_extra = RVS_ST_NONFINITE;
+        copy = true;
+      }
+    }
+    if (!copy) {
+      // The kernel's primitives (an asin and a sqrt each, ~150 dependent fp64
+      // instructions) at the clipped points x_j = clip(j / R), j = -1 .. kmax+1,
+      // ONE per thread: tap k needs them at j = k-1, k, k+1, and evaluated
+      // inside rot_segment every tap thread walked four of them in a row while
+      // the other 450 threads of the block waited.  Same arguments, same
+      // function: the same values.  (bufB is free until the FIR writes it.)
+      double *pk0 = bufB, *pk1 = bufB + (kmax + 3);
+      for (int jj = tid; jj <= kmax + 2; jj += OBJ_NT) {
+        const double x = fmin(fmax((jj - 1) / R, -1.0), 1.0);
+        double k0, k1;
+        rot_prim(x, eps_ld, k0, k1);
+        pk0[jj] = k0;
+        pk1[jj] = k1;
+      }
+      __syncthreads();
+      double psum = 0;
+      for (int k = tid; k <= kmax; k += OBJ_NT) {
+        double ww = 0;
+        // x_{k-1}, x_k, x_{k+1} are entries k, k+1, k+2
+        double lo = fmin(fmax(k / R, -1.0), 1.0),
+               hi = fmin(fmax((k + 1) / R, -1.0), 1.0);
+        if (hi > lo)   // rot_segment(lo, hi, -R, 1 + k)
+          ww += -R * (pk1[k + 2] - pk1[k + 1]) +
+                (1.0 + k) * (pk0[k + 2] - pk0[k + 1]);
+        lo = fmin(fmax((k - 1) / R, -1.0), 1.0);
+        hi = fmin(fmax(k / R, -1.0), 1.0);
+        if (hi > lo)   // rot_segment(lo, hi, R, 1 - k)
+          ww += R * (pk1[k + 1] - pk1[k]) + (1.0 - k) * (pk0[k + 1] - pk0[k]);
+        bufC[k] = ww;
+        psum += (k == 0) ? ww : 2 * ww;
+      }
+      psum = block_sum<OBJ_NW>(psum, red8);
+      __syncthreads();
+      const double inv = 1.0 / psum;
+      // normalised taps once (the product every output formed per tap)
+      for (int k = tid; k <= kmax; k += OBJ_NT) bufC[k] = bufC[k] * inv;
+      __syncthreads();
+    }
+  }
   if (FROMT) {
     const double *row = TT.templ[blockIdx.y] + (int64_t)j * N;
     for (int k = tid; k < N; k += OBJ_NT) {
@@ -182,22 +250,15 @@ __global__ void __launch_bounds__(OBJ_NT)
     // four CONSECUTIVE pixels per thread: one 16-byte load per vertex row
     // (rows start on 4-byte boundaries only: dword-aligned x4 loads), 1 KiB per
     // wave instruction instead of 256 B
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    const int N4 = N & ~3;
     if (nv <= 16) {
       // up to 4-D grids: the 2^ndim vertex rows of a pixel group are requested
       // together, and the group after it before this one is consumed (one L2
       // round trip per group, hidden behind the conversions, FMAs and exps of
-      // the previous group); the sums run in vertex order
-      f4u rn[16];
-      int k = 4 * tid;
-      if (k < N4) {
-#pragma unroll
-        for (int u = 0; u < 16; u++)
-          rn[u] = *reinterpret_cast<const f4u *>(
-              T.dats + PL.id[min(u, nv - 1)] * N + k);
-      }
-      for (; k < N4; k += 4 * OBJ_NT) {
+      // the previous group); the sums run in vertex order.  (First group:
+      // requested above, ahead of the rotational kernel.  Two groups in flight --
+      // 243 VGPRs -- measured: 5.10 against 5.00 s of Nelder-Mead per 10 000
+      // spectra, the phase is not waiting for latency.)
+      for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
         f4u r[16];
 #pragma unroll
         for (int u = 0; u < 16; u++) r[u] = rn[u];
@@ -293,59 +354,10 @@ __global__ void __launch_bounds__(OBJ_NT)
     return;
   }
   OBJ_T(1);
-  // ---- A6: rotational broadening bufA -> bufB (taps in bufC) ---------------
+  // ---- A6: rotational broadening bufA -> bufB (taps in bufC, built above) ----
   double *y = bufA, *dp = bufB;
-  int st_extra = 0;
   if (vsini) {
-    const double vs = vsini[j];
-    const double R = (vs / RVS_C_KMS) / T.lnstep;
-    bool copy = !(vs > 0) || (R < 1e-9);
-    int kmax = 0;
     if (!copy) {
-      kmax = (int)ceil(R + 1);
-      if (kmax >= N) {
-        st_extra = RVS_ST_NONFINITE;
-        copy = true;
-      }
-    }
-    if (!copy) {
-      // The kernel's primitives (an asin and a sqrt each, ~150 dependent fp64
-      // instructions) at the clipped points x_j = clip(j / R), j = -1 .. kmax+1,
-      // ONE per thread: tap k needs them at j = k-1, k, k+1, and evaluated
-      // inside rot_segment every tap thread walked four of them in a row while
-      // the other 450 threads of the block waited.  Same arguments, same
-      // function: the same values.  (bufB is free until the FIR writes it.)
-      double *pk0 = bufB, *pk1 = bufB + (kmax + 3);
-      for (int jj = tid; jj <= kmax + 2; jj += OBJ_NT) {
-        const double x = fmin(fmax((jj - 1) / R, -1.0), 1.0);
-        double k0, k1;
-        rot_prim(x, eps_ld, k0, k1);
-        pk0[jj] = k0;
-        pk1[jj] = k1;
-      }
-      __syncthreads();
-      double psum = 0;
-      for (int k = tid; k <= kmax; k += OBJ_NT) {
-        double ww = 0;
-        // x_{k-1}, x_k, x_{k+1} are entries k, k+1, k+2
-        double lo = fmin(fmax(k / R, -1.0), 1.0),
-               hi = fmin(fmax((k + 1) / R, -1.0), 1.0);
-        if (hi > lo)   // rot_segment(lo, hi, -R, 1 + k)
-          ww += -R * (pk1[k + 2] - pk1[k + 1]) +
-                (1.0 + k) * (pk0[k + 2] - pk0[k + 1]);
-        lo = fmin(fmax((k - 1) / R, -1.0), 1.0);
-        hi = fmin(fmax(k / R, -1.0), 1.0);
-        if (hi > lo)   // rot_segment(lo, hi, R, 1 - k)
-          ww += R * (pk1[k + 1] - pk1[k]) + (1.0 - k) * (pk0[k + 1] - pk0[k]);
-        bufC[k] = ww;
-        psum += (k == 0) ? ww : 2 * ww;
-      }
-      psum = block_sum<OBJ_NW>(psum, red8);
-      __syncthreads();
-      const double inv = 1.0 / psum;
-      // normalised taps once (the product every output formed per tap)
-      for (int k = tid; k <= kmax; k += OBJ_NT) bufC[k] = bufC[k] * inv;
-      __syncthreads();
       // Four consecutive outputs per thread and trip: at tap offset mm the four
       // inputs are a sliding window -- one new LDS read per offset, the tap read
       // once for four FMAs -- where one output per trip read input and tap for

@@ -77,9 +77,11 @@ def nn_weights(ntp, seed):
 
 def traffic_key(args, S, T, nfft, grid_name):
     """what a PMC traffic figure is valid for: the workload a line describes"""
-    return '%s|S=%d|T=%d|nfft=%d|%s|grid=%s|refine=%d|resol=%d' % (
+    return '%s|S=%d|T=%d|nfft=%d|%s|grid=%s|refine=%d|resol=%d|templ=%s' % (
         args.workload, S, T, nfft, args.evaluator, grid_name, int(args.refine),
-        int(args.resolution_matrix))
+        int(args.resolution_matrix),
+        'spectrum' if (getattr(args, 'per_spectrum_templates', False) or T > S)
+        else 'node')
 
 
 def ccf_every_for(ccf_every, ngrid):
@@ -430,6 +432,10 @@ def main():
                          'resident); 40,11,8,5 = 17 600 templates, 440 MB/arm: a '
                          'library of realistic size, dimensions of different '
                          'length, gathers served from HBM')
+    ap.add_argument('--per-spectrum-templates', action='store_true',
+                    help='build one template per spectrum (rounds 1-2) instead of '
+                         'one per CCF node shared by the spectra that selected it; '
+                         'same records bit for bit')
     ap.add_argument('--dump-records', type=str, default='',
                     help='rank 0 saves the gathered [n_gpus * spectra, 16] result '
                          'table of the last step as .npy (tests)')
@@ -539,7 +545,8 @@ def main():
         for a in batch.arms:
             a._work.clear()  # per-spectrum preparation belongs to the step
         rec = pipeline.fit_batch(batch, CONFIG, options=OPTIONS,
-                                 refine=args.refine)
+                                 refine=args.refine,
+                                 share_templates=not args.per_spectrum_templates)
         # the only collective of the path: gather of the result records
         return rdist.gather_records(rec, world * S, rank, world)
 
@@ -576,7 +583,8 @@ def main():
     timers = {}
     for a in batch.arms:
         a._work.clear()
-    pipeline.fit_batch(batch, CONFIG, options=OPTIONS, timers=timers)
+    pipeline.fit_batch(batch, CONFIG, options=OPTIONS, timers=timers,
+                       share_templates=not args.per_spectrum_templates)
     torch.cuda.synchronize()
     stage = {k: v[0].elapsed_time(v[1]) for k, v in timers.items()}
 
@@ -831,6 +839,12 @@ def main():
                     spectra_per_gpu=S, ccf_templates=Tccf, nfft=nfft,
                     refine=bool(args.refine),
                     resolution_matrix=bool(args.resolution_matrix),
+                    templates='one per spectrum' if (
+                        args.per_spectrum_templates or Tccf > S) else
+                    'one per CCF node (%d per arm), built every step, shared by '
+                    'the spectra that selected the node -- what the reference\'s '
+                    'getCurTempl / spline caches do (spec_fit.py:357-407, '
+                    '902-910); records identical to per-spectrum templates' % Tccf,
                     traffic_key=tkey,
                     parallelism='spectra-sharded x%d' % world),
         roofline=roof, roofline_ccf=roof_ccf,
@@ -838,7 +852,9 @@ def main():
                    achieved_GBps=round(value / world * b_alg / 1e9, 1),
                    frac_of_hbm_peak=round(value / world * b_alg / 1e9
                                           / HBM_PEAK_GBS, 4),
-                   note='SURVEY 8(d) D3 byte model of the WHOLE path per GPU; the '
+                   note='SURVEY 8(d) D3 byte model of the WHOLE path per GPU (it '
+                        'counts a 16-row gather per spectrum; with one template '
+                        'per CCF node the gather is done once per node); the '
                         'path is fp64-compute-side under it (see roofline)'),
         cpu_baseline=cpu,
         stage_ms=stage_round(stage),

@@ -23,9 +23,12 @@ RECORD_FIELDS = ('best_id', 'vrad_ccf', 'p0', 'p1', 'p2', 'p3', 'vsini',
 NREC = len(RECORD_FIELDS)
 
 
-def fit_batch(batch, config, options=None, refine=False, timers=None):
+def fit_batch(batch, config, options=None, refine=False, timers=None,
+              share_templates=True):
     """Returns rec float64 [S, NREC] (device).  `timers`, if a dict, receives
-    per-stage (start, end) torch.cuda events."""
+    per-stage (start, end) torch.cuda events.  share_templates=False builds one
+    template per spectrum even when spectra share a CCF node (same records, bit
+    for bit; tests and the bench's --per-spectrum-templates line)."""
     options = options or {}
     npoly = options.get('npoly') or 5
     rbf = options.get('rbf_continuum', True)
@@ -41,9 +44,22 @@ def fit_batch(batch, config, options=None, refine=False, timers=None):
     vsini = ref['vsinis_dev'][ccf['best_id']].contiguous()
 
     ev.start('template')
+    # The template of a spectrum is the one of its CCF node (best_par, best_vsini):
+    # a batch larger than the CCF set meets every node many times, so each node's
+    # template (interpolation, broadening, spline records) is built ONCE and the
+    # chi^2 kernels are pointed at it per job -- what the reference's caches do
+    # for successive spectra (getCurTempl's lru_cache(100) on the parameter
+    # tuple, the spline cache on templ_tag: spec_fit.py:357-407, 902-910).  Same
+    # inputs to the same kernels: the records a spectrum sees are bit for bit
+    # those of a template built for it alone.
+    Tn = ref['T']
+    shared = share_templates and Tn <= S
+    tparams = ref['params_dev'] if shared else params
+    tvsini = ref['vsinis_dev'] if shared else vsini
+    templ_rows = ccf['best_id'].to(torch.int32).contiguous() if shared else None
     coefs, outs = [], []
     for arm in batch.arms:
-        c, o = engine.build_templates(libs[arm.name], params, vsini)
+        c, o = engine.build_templates(libs[arm.name], tparams, tvsini)
         coefs.append(c)
         outs.append(o)
     ev.stop('template')
@@ -53,7 +69,7 @@ def fit_batch(batch, config, options=None, refine=False, timers=None):
         np.arange(config['min_vel'], config['max_vel'],
                   config['vel_step0']).astype(np.float64)).to(dev)
     chisq, status = engine.chisq_grid(
-        batch, libs, coefs, outs, vg, npoly=npoly, rbf=rbf,
+        batch, libs, coefs, outs, vg, npoly=npoly, rbf=rbf, job_templ=templ_rows,
         vel_bounds=(float(config['min_vel']), float(config['max_vel'])))
     res, _, mst = engine.grid_moments(chisq, vg, Np=1)
     ev.stop('chisq_grid')
@@ -84,7 +100,8 @@ def fit_batch(batch, config, options=None, refine=False, timers=None):
         ev.start('refine')
         r = vel_fit._minimum_sampler_batch(batch, res[:, 1].contiguous(), params,
                                            vsini, config, options,
-                                           templates=(coefs, outs))
+                                           templates=(coefs, outs),
+                                           templ_rows=templ_rows)
         rec[:, 7] = torch.as_tensor(r['best_vel']).to(dev)
         rec[:, 8] = torch.as_tensor(r['vel_err']).to(dev)
         rec[:, 9] = torch.as_tensor(r['skewness']).to(dev)

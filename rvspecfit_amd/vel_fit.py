@@ -76,7 +76,8 @@ def firstguess(specdata, options=None, config=None, resolParams=None,
 
 def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
                            crit_ratio=5, goal_width=10, grid_budget=1 << 24,
-                           resolParams=None, keep_grids=False, templates=None):
+                           resolParams=None, keep_grids=False, templates=None,
+                           templ_rows=None):
     """Batched _minimum_sampler (vel_fit.py:358-439): every spectrum carries
     its own (min_vel, max_vel, step) state; per round all spectra that are not
     converged are evaluated on their own velocity grids in one launch set.
@@ -85,7 +86,8 @@ def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
     (host float64, per spectrum).  Returns per-spectrum numpy arrays.
     The templates (spline records of every spectrum's parameters, all arms) are
     built once -- or handed over by the caller as `templates` = (coefs, outs) of
-    engine.build_templates -- and every round's grids are evaluated against
+    engine.build_templates, with `templ_rows` (int32 [S]) naming the row of each
+    spectrum when spectra share templates -- and every round's grids are evaluated against
     them: the reference's get_chisq finds them in its template cache the same way
     (spec_fit.py:902-910)."""
     S, dev = batch.S, batch.device
@@ -162,9 +164,13 @@ def _minimum_sampler_batch(batch, best_vel, best_param, vsini, config, options,
                     all_grids[i].append(vh[k, :nh[k]].copy())
             idt = None if (rows >= n and n == S) else \
                 idx[sl].to(torch.int32).contiguous()
+            jt = idt
+            if templ_rows is not None:
+                jt = templ_rows if idt is None else \
+                    templ_rows[idx[sl]].contiguous()
             chisq, status = engine.chisq_grid(
                 batch, libs, coefs, outs, vg, npoly=npoly, rbf=rbf,
-                job_spec=idt, job_templ=idt, resols=resols)
+                job_spec=idt, job_templ=jt, resols=resols)
             res, _, _ = engine.grid_moments(
                 chisq.reshape(nvc.shape[0], -1), vg, Np=1,
                 nvel=nvc.to(torch.int32).contiguous())

@@ -90,6 +90,23 @@ def test_permutation_and_subset(full):
     assert torch.equal(rs, full['rec'][ix])
 
 
+def test_shared_templates_equal_per_spectrum(full):
+    """one template per CCF node shared by the spectra that selected it (the
+    default when the batch is larger than the CCF set) against one template per
+    spectrum: every record bit for bit, with and without the refinement loop"""
+    from rvspecfit_amd import pipeline
+    b = full['bench']
+    ix = torch.arange(0, 3000, device=full['dev'])
+    sub = full['batch'].subset(ix)
+    for refine in (False, True):
+        a = pipeline.fit_batch(sub, b.CONFIG, options=b.OPTIONS, refine=refine)
+        c = pipeline.fit_batch(sub, b.CONFIG, options=b.OPTIONS, refine=refine,
+                               share_templates=False)
+        assert np.array_equal(a.cpu().numpy(), c.cpu().numpy(), equal_nan=True)
+    assert torch.equal(full['rec'][ix], pipeline.fit_batch(
+        sub, b.CONFIG, options=b.OPTIONS, share_templates=False))
+
+
 def test_flux_scale(full):
     from rvspecfit_amd import pipeline
     F = pipeline.RECORD_FIELDS

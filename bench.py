@@ -75,13 +75,19 @@ def nn_weights(ntp, seed):
     return d
 
 
+def node_templates(T, S):
+    """pipeline.fit_batch's rule for sharing one template per CCF node"""
+    ntp = max(len(synth.template_lam_grid(*arm_def(a)['templ'])) for a in ARMS)
+    return T <= S and T * ntp * 32 <= (64 << 20)
+
+
 def traffic_key(args, S, T, nfft, grid_name):
     """what a PMC traffic figure is valid for: the workload a line describes"""
     return '%s|S=%d|T=%d|nfft=%d|%s|grid=%s|refine=%d|resol=%d|templ=%s' % (
         args.workload, S, T, nfft, args.evaluator, grid_name, int(args.refine),
         int(args.resolution_matrix),
-        'spectrum' if (getattr(args, 'per_spectrum_templates', False) or T > S)
-        else 'node')
+        'spectrum' if (getattr(args, 'per_spectrum_templates', False)
+                       or not node_templates(T, S)) else 'node')
 
 
 def ccf_every_for(ccf_every, ngrid):
@@ -840,7 +846,7 @@ def main():
                     refine=bool(args.refine),
                     resolution_matrix=bool(args.resolution_matrix),
                     templates='one per spectrum' if (
-                        args.per_spectrum_templates or Tccf > S) else
+                        args.per_spectrum_templates or not node_templates(Tccf, S)) else
                     'one per CCF node (%d per arm), built every step, shared by '
                     'the spectra that selected the node -- what the reference\'s '
                     'getCurTempl / spline caches do (spec_fit.py:357-407, '

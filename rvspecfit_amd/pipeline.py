@@ -53,7 +53,15 @@ def fit_batch(batch, config, options=None, refine=False, timers=None,
     # inputs to the same kernels: the records a spectrum sees are bit for bit
     # those of a template built for it alone.
     Tn = ref['T']
-    shared = share_templates and Tn <= S
+    # (while a node set's spline records stay cache resident: 76 nodes x 200 KB =
+    # 15 MB per arm; at 534 nodes -- 107 MB per arm -- the chi^2 kernel's gathers
+    # miss as often as with per-spectrum templates, whose XCD placement fetches a
+    # job's records once: 101.7 against 96.7 ms per step, a wash with the 4 ms the
+    # template stage saves.  Jobs sorted by node so that an XCD holds one node at
+    # a time were measured too: every CU then hammers the same lines, 94.5
+    # against 89 ms at 76 nodes.)
+    max_ntp = max(libs[a.name].ntp for a in batch.arms)
+    shared = share_templates and Tn <= S and Tn * max_ntp * 32 <= (64 << 20)
     tparams = ref['params_dev'] if shared else params
     tvsini = ref['vsinis_dev'] if shared else vsini
     templ_rows = ccf['best_id'].to(torch.int32).contiguous() if shared else None

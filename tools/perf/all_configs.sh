@@ -6,6 +6,7 @@ out=gpurun_out/configs_$tag.jsonl
 : > $out
 run() { python bench.py "$@" 2>/dev/null | tail -1 >> $out; }
 run --steps 3 --warmup 1
+run --steps 3 --warmup 1 --per-spectrum-templates --no-cpu-baseline
 run --ccf-every 9 --steps 2 --warmup 1 --cpu-sample 64
 run --workload cfg2 --spectra 1000 --steps 5 --warmup 1 --cpu-sample 256
 run --evaluator nn --steps 3 --warmup 1

@@ -21,6 +21,7 @@ cfg() {
     /tmp/pmc_FETCH_SIZE.log "$tag" "$*"
 }
 cfg
+cfg --per-spectrum-templates
 cfg --ccf-every 9
 cfg --workload cfg2 --spectra 1000
 cfg --evaluator nn

@@ -91,15 +91,21 @@ __device__ __forceinline__ GridDesc obj_grid_desc(const rvs_objective_arm &T) {
   return G;
 }
 
-__global__ void __launch_bounds__(64)
+// (256 threads: the cell search itself needs 20 of them, but a point outside the
+// grid -- an optimiser's simplex is there every few steps -- scans all ngrid
+// nodes for its nearest neighbour, and the launch lasts as long as its slowest
+// block: with one wave per block a 17 600-node library cost every objective
+// launch ~100 us, 1.59 against 1.41 s of Nelder-Mead per 2000 spectra)
+#define OBJ_LOC_NT 256
+__global__ void __launch_bounds__(OBJ_LOC_NT)
     objective_locate_kernel(ObjArms A, const double *__restrict__ params, int J,
                             double *__restrict__ loc) {
   __shared__ PolyLoc PL;
   const rvs_objective_arm &T = A.a[blockIdx.y];
   const int j = blockIdx.x, tid = threadIdx.x;
   const GridDesc G = obj_grid_desc(T);
-  poly_locate<64>(PL, G, params + (int64_t)j * T.ndim, T.idgrid, T.uvecs,
-                  T.vecs_s, T.ngrid);
+  poly_locate<OBJ_LOC_NT>(PL, G, params + (int64_t)j * T.ndim, T.idgrid, T.uvecs,
+                          T.vecs_s, T.ngrid);
   double *r = loc + ((int64_t)blockIdx.y * J + j) * OBJ_LOC_REC;
   if (tid < OBJ_LOC_NV) {
     r[tid] = PL.w[tid];
@@ -971,7 +977,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     for (int i = 0; i < narm; i++)
       if ((1 << arms[i].ndim) > OBJ_LOC_NV) pre = false;
     if (pre) {
-      hipLaunchKernelGGL(objective_locate_kernel, grid, dim3(64), 0, st, A,
+      hipLaunchKernelGGL(objective_locate_kernel, grid, dim3(OBJ_LOC_NT), 0, st, A,
                          params, J, locbuf);
       loc = locbuf;
     }

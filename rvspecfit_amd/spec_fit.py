@@ -407,22 +407,33 @@ def chisq_jobs(batch, idx, vel, params, vsini, options, config,
 
 def chisq_grid_jobs(batch, vel_grid, params, vsini, options, config,
                     outside_penalty=True, espec_systematic=None,
-                    resol_params=None, spec_idx=None):
+                    resol_params=None, spec_idx=None, shared_vsini=None):
     """chi^2 [S, Np, Nv] for params [S, Np, ndim] (device) on a shared or
     per-spectrum velocity grid: the double loop of find_best as one launch set.
     spec_idx (device int [S']): rows refer to these spectra of the batch (the
-    batch's per-spectrum preparation is reused, nothing is copied)."""
+    batch's per-spectrum preparation is reused, nothing is copied).
+    params [Np, ndim] (2-D): ONE parameter list for every spectrum, with
+    `shared_vsini` (float or None) the rotation of all of them -- the Np
+    templates are then built once and every spectrum's jobs point at them, as
+    the reference's template caches serve find_best's double loop
+    (spec_fit.py:1043-1060, 357-407); same values as Np templates per spectrum."""
     options = options or {}
     npoly = options.get('npoly') or 5
     rbf = options.get('rbf_continuum', True)
     dev = batch.device
     S = batch.S if spec_idx is None else int(spec_idx.shape[0])
     libs = spec_inter.get_libs(batch.names, config)
-    Np = params.shape[1]
-    flat = params.reshape(S * Np, -1).contiguous()
-    vs = None
-    if vsini is not None:
-        vs = vsini.reshape(S, -1).expand(S, Np).reshape(-1).contiguous()
+    one_list = params.dim() == 2
+    Np = params.shape[0] if one_list else params.shape[1]
+    if one_list:
+        flat = params.contiguous()
+        vs = None if shared_vsini is None else torch.full(
+            (Np, ), float(shared_vsini), dtype=torch.float64, device=dev)
+    else:
+        flat = params.reshape(S * Np, -1).contiguous()
+        vs = None
+        if vsini is not None:
+            vs = vsini.reshape(S, -1).expand(S, Np).reshape(-1).contiguous()
     coefs, outs = [], []
     for arm in batch.arms:
         c, o = engine.build_templates(libs[arm.name], flat, vs)
@@ -431,15 +442,21 @@ def chisq_grid_jobs(batch, vel_grid, params, vsini, options, config,
     rows = torch.arange(S, dtype=torch.int32, device=dev) \
         if spec_idx is None else spec_idx.to(torch.int32)
     job_spec = rows.repeat_interleave(Np).contiguous()
+    job_templ = None
+    if one_list:
+        job_templ = torch.arange(Np, dtype=torch.int32,
+                                 device=dev).repeat(S).contiguous()
     vg = vel_grid
     if vg.dim() == 2:  # per spectrum grids -> per job
         vg = vg.repeat_interleave(Np, dim=0).contiguous()
     esys = float(espec_systematic) if espec_systematic is not None else 0.0
     chisq, status = engine.chisq_grid(batch, libs, coefs, outs, vg,
                                       npoly=npoly, rbf=rbf, job_spec=job_spec,
-                                      espec_sys=esys,
+                                      job_templ=job_templ, espec_sys=esys,
                                       outside_penalty=outside_penalty,
                                       resols=_resols(batch, resol_params))
+    if one_list:   # callers index the outside flags per (spectrum, parameter)
+        outs = [o.repeat(S) for o in outs]
     return chisq.reshape(S, Np, -1), status.reshape(S, Np), outs
 
 
@@ -456,6 +473,12 @@ def find_best(specdata, vel_grid, params_list, rot_params=None,
         params = params_list.to(dev, torch.float64)
     else:
         params = torch.as_tensor(np.asarray(params_list, dtype=np.float64)).to(dev)
+    # one list for every spectrum (the reference's call) and one rotation: the
+    # templates are built once for the batch
+    one_list = params.dim() == 2 and (
+        rot_params is None or (not isinstance(rot_params, torch.Tensor)
+                               and np.size(rot_params) == 1))
+    plist = params if one_list else None
     if params.dim() == 2:
         params = params[None].expand(S, *params.shape)
     Np = params.shape[1]
@@ -467,9 +490,15 @@ def find_best(specdata, vel_grid, params_list, rot_params=None,
     _check_overlap_all(batch, libs, config, float(vg.min().item()),
                        float(vg.max().item()))
     vsini = _vsini_tensor(rot_params, S, dev)
-    chisq, status, outs = chisq_grid_jobs(batch, vg, params.contiguous(), vsini,
-                                          options, config,
-                                          resol_params=resol_params)
+    if one_list:
+        sv = None if rot_params is None else float(np.ravel(rot_params)[0])
+        chisq, status, outs = chisq_grid_jobs(batch, vg, plist, None, options,
+                                              config, resol_params=resol_params,
+                                              shared_vsini=sv)
+    else:
+        chisq, status, outs = chisq_grid_jobs(batch, vg, params.contiguous(),
+                                              vsini, options, config,
+                                              resol_params=resol_params)
     res, probs, mst = engine.grid_moments(chisq.reshape(S * Np, -1), vg, Np=Np,
                                           quadratic=quadratic)
     i2 = res[:, 6].long()

@@ -519,6 +519,33 @@ def test_firstguess(cases, config):
                                cases['c0/firstguess/vals'])
 
 
+def test_find_best_one_list_shares_templates(cases, config):
+    """find_best over one parameter list for a whole batch (the reference's
+    call; vel_fit.firstguess: 60 parameter sets x 3 rotations) builds the Np
+    templates once instead of once per spectrum: chi^2 grid, best parameters
+    and moments are those of the per-spectrum form bit for bit"""
+    from rvspecfit_amd import spec_fit
+    from rvspecfit_amd.engine import SpecBatch
+    S = 7
+    lists = [_sds(cases, 'c1') for _ in range(S)]
+    batch = SpecBatch.from_specdata(lists)
+    rng = np.random.RandomState(3)
+    for a in batch.arms:   # make the spectra differ
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.05 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pl = [tuple(_) for _ in cases['c1/g3/params_list']] + [(3400., 2., -1., 0.2)]
+    vg = cases['vel_grid'].astype(np.float64)
+    for rot in (None, (30., )):
+        a = spec_fit.find_best(batch, vg, pl, rot_params=rot,
+                               options=dict(npoly=10), config=config)
+        per = torch.as_tensor(np.array(pl))[None].expand(S, -1, -1).to('cuda')
+        b = spec_fit.find_best(batch, vg, per.contiguous(), rot_params=rot,
+                               options=dict(npoly=10), config=config)
+        for k in ('chisq', 'best_chi', 'best_vel', 'vel_err', 'best_param',
+                  'probs', 'status', 'i1', 'i2'):
+            assert torch.equal(a[k], b[k]), (rot, k)
+
+
 def test_batch_equals_singles(cases, config):
     """4 golden spectra of the 2-arm cases stacked in one batch give the same
     records as one-by-one calls (batching is arithmetic-neutral)."""

@@ -371,6 +371,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(
     // blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one):
     // the nfull waves of a job are 8 blocks apart so that the job's spline
     // records are fetched into ONE L2, once
+    // (with one template per CCF node shared by the jobs the placement still
+    // pays: cg_bench, 76 node templates: 31.2 against 32.3 ms in job-major order)
     const int per = 8 * nfull;
     const int g = bx / per, r = bx - g * per;
     by = g * 8 + (r & 7);

@@ -38,14 +38,14 @@ int main(int argc, char **argv) {
   for (size_t i = 0; i < spec.size(); i++) { spec[i] = 1 + 0.1 * (rnd() - 0.5); espec[i] = 0.02 + 0.01 * rnd(); }
   for (int s = 0; s < S; s++) for (int v = 0; v < Nv; v++) vels[(size_t)s * Nv + v] = -1000 + 2000.0 * v / Nv;
   double *d_lam, *d_knots, *d_coef, *d_polys, *d_spec, *d_espec, *d_vels, *d_work, *d_out; int32_t *d_st;
-  hipMalloc(&d_lam, npix * 8); hipMalloc(&d_knots, ntp * 8); hipMalloc(&d_coef, 32ll * ntp * (own ? S : 1));
+  hipMalloc(&d_lam, npix * 8); hipMalloc(&d_knots, ntp * 8); hipMalloc(&d_coef, 32ll * ntp * (own == 1 ? S : (own == 2 ? 76 : 1)));
   hipMalloc(&d_polys, polysT.size() * 8); hipMalloc(&d_spec, spec.size() * 8); hipMalloc(&d_espec, spec.size() * 8);
   hipMalloc(&d_vels, vels.size() * 8); hipMalloc(&d_out, vels.size() * 8); hipMalloc(&d_st, S * 4);
   const int64_t wsz = rvs_chisq_work_size(npix, S);
   hipMalloc(&d_work, wsz * 8);
   hipMemcpy(d_lam, lam.data(), npix * 8, hipMemcpyHostToDevice);
   hipMemcpy(d_knots, knots.data(), ntp * 8, hipMemcpyHostToDevice);
-  for (int t = 0; t < (own ? S : 1); t++)
+  for (int t = 0; t < (own == 1 ? S : (own == 2 ? 76 : 1)); t++)
     hipMemcpy((char *)d_coef + 32ll * ntp * t, coef.data(), 32ll * ntp, hipMemcpyHostToDevice);
   hipMemcpy(d_polys, polysT.data(), polysT.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(d_spec, spec.data(), spec.size() * 8, hipMemcpyHostToDevice);
@@ -53,13 +53,19 @@ int main(int argc, char **argv) {
   hipMemcpy(d_vels, vels.data(), vels.size() * 8, hipMemcpyHostToDevice);
   hipMemset(d_st, 0, S * 4);
   int32_t *d_jt; hipMalloc(&d_jt, S * 4); hipMemset(d_jt, 0, S * 4);  // own = 0: every job uses template 0
+  const int NT_NODE = 76;   // own = 2: 76 node templates, jobs pick one at random (the pipeline's case)
+  if (own == 2) {
+    std::vector<int32_t> jt(S);
+    for (int s = 0; s < S; s++) jt[s] = rand() % NT_NODE;
+    hipMemcpy(d_jt, jt.data(), S * 4, hipMemcpyHostToDevice);
+  }
   int rc = rvs_chisq_prepare(d_lam, d_spec, d_espec, npix, S, knots.data(), 1, 0.0, d_work, nullptr);
   if (rc) { printf("prepare rc %d\n", rc); return 1; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e30f, sum = 0;
   for (int r = 0; r < reps + 1; r++) {
     hipEventRecord(e0);
-    rc = rvs_chisq_grid(d_lam, d_polys, d_work, npix, P, S, d_knots, d_coef, ntp, own ? S : 1, 1, nullptr, own ? nullptr : d_jt, S,
+    rc = rvs_chisq_grid(d_lam, d_polys, d_work, npix, P, S, d_knots, d_coef, ntp, own == 1 ? S : (own == 2 ? 76 : 1), 1, nullptr, own == 1 ? nullptr : d_jt, S,
                         d_vels, Nv, Nv, nullptr, 1e5, 0.0, pack, d_out, d_st, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -3,59 +3,20 @@
 // Reference: py/rvspecfit/make_ccf.py:105-164, 288-414 (preprocess_data,
 // interp_masker, get_continuum, fit_resid) and py/rvspecfit/fitter_ccf.py:62-253.
 //
-//  ccf_preprocess_kernel  one 256-thread block per spectrum-arm: median filter,
-//      masks, gap filling, binned-median start, robust (soft-L1) continuum fit
-//      as a Levenberg-Marquardt on the same objective, normalisation, 2-point
-//      rebin with ivar propagation onto the log-lambda FFT grid.  All medians
-//      come from in-LDS bitonic sorts.
+//  ccf_preprocess_kernel  one 512-thread block per spectrum-arm, two blocks per
+//      CU: median filter, masks, gap filling, binned-median start, robust
+//      (soft-L1) continuum fit as a Levenberg-Marquardt on the same objective,
+//      normalisation, 2-point rebin with ivar propagation onto the log-lambda
+//      FFT grid.  The medians are exact order statistics found by selection
+//      (block-wide histogram rounds, wave-level bisection for the bins).
 //  (the FFT cross-correlation itself lives in ccf_fft.hip)
 //  ccf_select_kernel      argmin over (template, velocity) + parabola.
 #include "common.h"
 
-#define PP_NT 1024   // threads per block of the pre-processing kernel
+#define PP_NT 512    // threads per block of the pre-processing kernel (two per CU)
+#define PP_LOG2NT 9  // buckets of a selection round = threads
 #define PP_NW (PP_NT / 64)
 
-// ---------------------------------------------------------------------------
-// block-wide bitonic sort of n2 (power of two) doubles in LDS, ascending.
-// Optional companion key array (int16 "bin" major key).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ bool key_less(int ba, double va, int bb, double vb) {
-  return (ba < bb) || (ba == bb && va < vb);
-}
-
-template <bool WITH_BIN>
-__device__ void bitonic_sort(double *v, short *bin, int n2) {
-  for (int k = 2; k <= n2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
-      // thread t handles the pair whose lower index has bit j clear
-      for (int t = threadIdx.x; t < (n2 >> 1); t += PP_NT) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int ixj = i | j;
-        const double a = v[i], b = v[ixj];
-        const int ba = WITH_BIN ? bin[i] : 0, bb = WITH_BIN ? bin[ixj] : 0;
-        const bool up = ((i & k) == 0);
-        const bool sw = up ? key_less(bb, b, ba, a) : key_less(ba, a, bb, b);
-        if (sw) {
-          v[i] = b;
-          v[ixj] = a;
-          if (WITH_BIN) {
-            bin[i] = (short)bb;
-            bin[ixj] = (short)ba;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// numpy median of the first n sorted values (mean of the middle two if even)
-__device__ __forceinline__ double sorted_median(const double *s, int n) {
-  if (n <= 0) return __builtin_nan("");
-  if (n & 1) return s[n >> 1];
-  return (s[(n >> 1) - 1] + s[n >> 1]) * 0.5;
-}
 
 // ---------------------------------------------------------------------------
 // Block-wide SELECTION of order statistics (the two plain medians only need the
@@ -67,7 +28,7 @@ __device__ __forceinline__ double sorted_median(const double *s, int n) {
 // which one wave ranks directly.  Every step is integer comparison and counting,
 // so the value is exactly the one a sort would put at position k.
 // ---------------------------------------------------------------------------
-#define SEL_NB 1024  // buckets == PP_NT: one per thread in the prefix sum
+#define SEL_NB PP_NT  // buckets == threads: one per thread in the prefix sum
 struct SelShared {
   unsigned long long kmin, kmax, result, next, cand[64];
   int hist[SEL_NB];
@@ -151,7 +112,7 @@ __device__ double block_median(const double *v, int n, bool skipnan,
   while (!done) {
     // bucket = (key - lo) >> shift < SEL_NB
     const int bits = 64 - __clzll((long long)range);  // range >= 1
-    const int shift = bits > 10 ? bits - 10 : 0;
+    const int shift = bits > PP_LOG2NT ? bits - PP_LOG2NT : 0;
     if (ncand <= 64) {
       // ---- the last candidates: ranked by one wave --------------------------
       if (tid == 0) Q.nc = 0;
@@ -392,9 +353,12 @@ struct LMShared {
 // matrix in node space is H = C^-T (E^T W E) C^-1 with E^T W E pentadiagonal.
 
 // cost 0.5*sum rho(f^2), rho(z) = 2(sqrt(1+z)-1) (scipy soft_l1, f_scale=1) at
-// the B-spline coefficients cc.  If store, also the Gauss-Newton weights
-//   gw[k] = (m/e) f / sqrt(1+z),  hw[k] = (m/e)^2 (1+z)^-1.5
+// the B-spline coefficients cc.  If store, the model value m_k is left in wm[k]
+// (0 where the exponent was clipped): lm_normal forms the Gauss-Newton weights
+//   gw = (m/e) f / sqrt(1+z),  hw = (m/e)^2 (1+z)^-1.5
 // (rho' f and rho' + 2 rho'' f^2, the scaling scipy applies for robust losses)
+// from it.  Storing m instead of (gw, hw) is one LDS array less, which with the
+// sort buffer gone lets TWO blocks share a CU (see the kernel).
 // px: this thread's first LM_PIX pixels' basis rows and interval indices, read
 // once before the iteration (the objective is evaluated ~2x per iteration and
 // every evaluation started with two dependent L2 round trips for them); pixels
@@ -403,12 +367,17 @@ struct LMPix {
   double e0, e1, e2;
   int l;
 };
-#define LM_PIX 3
+// (pixels per thread whose basis rows stay in registers across the iterations:
+// at the 128 VGPRs of two blocks per CU more of them spill -- 8.99 / 9.23 /
+// 9.60 ms per step for 1 / 3 / 6, tools/perf/pp_variants.sh)
+#ifndef LM_PIX
+#define LM_PIX 1
+#endif
 
 __device__ __forceinline__ double lm_eval(
     LMShared &S, const double *cc, const double *__restrict__ Eb,
     const int32_t *__restrict__ El, int npix, const double *cs, const double *ce,
-    double *gw, double *hw, bool store, const LMPix (&px)[LM_PIX]) {
+    double *wm, bool store, const LMPix (&px)[LM_PIX]) {
   __syncthreads();  // cc (LDS) was just written
   double c = 0;
 #pragma unroll
@@ -427,11 +396,7 @@ __device__ __forceinline__ double lm_eval(
       const double z = f * f;
       const double r = sqrt(1 + z);
       c += 2 * (r - 1);
-      if (store) {
-        const double d = clipped ? 0.0 : mod / e;
-        gw[k] = d * f / r;
-        hw[k] = d * d / (r * r * r);
-      }
+      if (store) wm[k] = clipped ? 0.0 : mod;   // exp(s) > 0: 0 = clipped
     }
   }
   for (int k = threadIdx.x + LM_PIX * PP_NT; k < npix; k += PP_NT) {
@@ -447,11 +412,7 @@ __device__ __forceinline__ double lm_eval(
     const double z = f * f;
     const double r = sqrt(1 + z);
     c += 2 * (r - 1);
-    if (store) {
-      const double d = clipped ? 0.0 : mod / e;
-      gw[k] = d * f / r;
-      hw[k] = d * d / (r * r * r);
-    }
+    if (store) wm[k] = clipped ? 0.0 : mod;
   }
   return 0.5 * block_sum<PP_NW>(c, S.red);
 }
@@ -460,7 +421,7 @@ __device__ __forceinline__ double lm_eval(
 // first and second sub-diagonal) and the gradient E^T gw (S.bvec).
 __device__ void lm_normal(LMShared &S, const double *__restrict__ Eb,
                           const int32_t *__restrict__ istart, int m,
-                          const double *gw, const double *hw) {
+                          const double *wm, const double *cs, const double *ce) {
   const int nint = m - 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
@@ -485,7 +446,13 @@ __device__ void lm_normal(LMShared &S, const double *__restrict__ Eb,
         const int k = k0 + 64 * c;
         if (k < k1) {
           const double e0 = e[c][0], e1 = e[c][1], e2 = e[c][2];
-          const double h = hw[k], gg = gw[k];
+          // the weights of lm_eval's formulas, from the stored model value
+          const double mod = wm[k], e = ce[k];
+          const double f = (mod - cs[k]) / e;
+          const double z = f * f;
+          const double r = sqrt(1 + z);
+          const double d = mod / e;   // (mod = 0: clipped exponent, no weight)
+          const double h = d * d / (r * r * r), gg = d * f / r;
           a[0] = fma(h * e0, e0, a[0]);
           a[1] = fma(h * e0, e1, a[1]);
           a[2] = fma(h * e0, e2, a[2]);
@@ -598,10 +565,11 @@ __device__ void lm_band_solve(LMShared &S, int m) {
 }
 
 __global__ void __launch_bounds__(PP_NT)
+    __attribute__((amdgpu_waves_per_eu(4, 4)))  // two 8-wave blocks per CU
     ccf_preprocess_kernel(const double *__restrict__ lam,
                           const double *__restrict__ spec,
                           const double *__restrict__ espec,
-                          const uint8_t *__restrict__ badmask, int npix, int np2,
+                          const uint8_t *__restrict__ badmask, int npix,
                           int continuum, const double *__restrict__ Eb,
                           const int32_t *__restrict__ El,
                           const double *__restrict__ Cinv,
@@ -614,12 +582,17 @@ __global__ void __launch_bounds__(PP_NT)
                           double *__restrict__ cont_out,
                           double *__restrict__ pfit, int32_t *__restrict__ status) {
   extern __shared__ double sm[];
+  // Three arrays of npix doubles + the mask: 72 KB for a DESI arm, so that TWO
+  // 512-thread blocks share a CU.  The kernel is a chain of short phases that
+  // barriers and single-wave steps (the LM band solve) separate: with ONE
+  // 1024-thread block per CU (round 2: 110 KB with the (gw, hw) pair and a
+  // 4096-entry sort buffer for bins of more than 256 pixels) the VALU was 45 %
+  // busy, and halving the threads of that lone block cost 6 % -- the time is in
+  // the chain, which a second resident block covers.
   double *cs = sm;              // [npix] current spectrum
   double *ce = cs + npix;       // [npix] current error
-  double *sb = ce + npix;       // [np2]  sort buffer / gw
-  double *hw = sb + np2;        // [npix] hessian weights
-  short *binkey = reinterpret_cast<short *>(hw + npix);       // [np2]
-  uint8_t *msk = reinterpret_cast<uint8_t *>(binkey + np2);  // [npix]
+  double *wm = ce + npix;       // [npix] model values of the last evaluation
+  uint8_t *msk = reinterpret_cast<uint8_t *>(wm + npix);  // [npix]
   __shared__ LMShared S;
   __shared__ SelShared Q;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -746,9 +719,9 @@ __global__ void __launch_bounds__(PP_NT)
     const int m = nnode;
     PP_T(2);  // median sort
     // ---- binned medians -> p0 (make_ccf.py:141-143) -------------------------
-    // bins of <= 256 pixels (the usual case: ~140): every wave sorts whole bins
-    // in its own 256-double LDS segment, 16 bins at a time, no block barriers;
-    // otherwise ONE block-wide sort keyed by (bin, value)
+    // bins of <= 256 pixels (the usual case: ~140): a wave takes a whole bin, four
+    // values per lane in registers, 8 bins at a time, no block barriers;
+    // otherwise the block-wide selection, bin after bin
     bool small = true;
     for (int jb = 0; jb < m; jb++)
       if (bin_start[jb + 1] - bin_start[jb] > 256) small = false;
@@ -771,38 +744,18 @@ __global__ void __launch_bounds__(PP_NT)
         }
       }
     } else {
-      for (int k = tid; k < np2; k += PP_NT) {
-        double v = __builtin_inf();
-        short bn = (short)(m + 1);
-        if (k < npix) {
-          v = cs[k];
-          bn = (short)m;  // outside every bin
-          if (k >= bin_start[0] && k < bin_start[m]) {
-            int lo = 0, hi = m;  // last j with bin_start[j] <= k
-            while (hi - lo > 1) {
-              const int mid = (lo + hi) >> 1;
-              if (bin_start[mid] <= k)
-                lo = mid;
-              else
-                hi = mid;
-            }
-            bn = (short)lo;
-          }
+      // a bin of more than 256 pixels: np.median of each bin by the block-wide
+      // selection (block_median: exact order statistics, NaN if the bin holds
+      // one), bin after bin
+      for (int jb = 0; jb < m; jb++) {
+        const int b0 = bin_start[jb], cnt = bin_start[jb + 1] - b0;
+        const double stat = block_median(cs + b0, cnt, false, Q);
+        if (tid == 0) {
+          double p0 = log(fmax(stat, 1e-3 * S.medspec));
+          if (!(stat == stat)) p0 = nanv;  // np.maximum propagates NaN
+          if (!(fabs(p0) <= 1.79e308)) p0 = log(S.medspec);
+          S.p[jb] = p0;
         }
-        sb[k] = v;
-        binkey[k] = bn;
-      }
-      bitonic_sort<true>(sb, binkey, np2);
-      if (tid < m) {
-        // pixels of bin j sit, sorted, at [bin_start[j], bin_start[j+1]) shifted by
-        // the number of pixels in front of the first bin (they sort to the end)
-        const int s0 = bin_start[tid] - bin_start[0];
-        const int cnt = bin_start[tid + 1] - bin_start[tid];
-        double stat = sorted_median(sb + s0, cnt);
-        double p0 = log(fmax(stat, 1e-3 * S.medspec));
-        if (!(stat == stat)) p0 = nanv;  // np.maximum propagates NaN
-        if (!(fabs(p0) <= 1.79e308)) p0 = log(S.medspec);
-        S.p[tid] = p0;
       }
     }
     __syncthreads();
@@ -811,7 +764,6 @@ __global__ void __launch_bounds__(PP_NT)
     // ---- Levenberg-Marquardt on the soft-L1 objective -----------------------
     // unknowns: the B-spline coefficients c = C^-1 p of the interpolating spline
     // (a linear bijection of the reference's node values p, same minimum)
-    double *gw = sb;  // reuse
     if (tid < m) {
       double s = 0;
       for (int jj = 0; jj < m; jj++) s = fma(Cinv[tid * m + jj], S.p[jj], s);
@@ -833,10 +785,10 @@ __global__ void __launch_bounds__(PP_NT)
       px[i].e2 = Eb[3 * k + 2];
       px[i].l = El[k];
     }
-    double cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true, px);
+    double cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, wm, true, px);
     PP_T(7);  // (debug) LM set-up + first evaluation
     for (int it = 0; it < RVS_LM_MAXIT; it++) {
-      lm_normal(S, Eb, istart, m, gw, hw);
+      lm_normal(S, Eb, istart, m, wm, cs, ce);
       PP_T(8);  // (debug) normal equations
       if (it == 0) {
         // least_squares' gtol exit at the starting point (make_ccf.py:146-150,
@@ -856,7 +808,7 @@ __global__ void __launch_bounds__(PP_NT)
         if (S.stop) break;
       }
       // damped step; retry with larger damping until the cost does not grow.
-      // The trial evaluation leaves its Gauss-Newton weights in gw / hw: they are
+      // The trial evaluation leaves its model values in wm: they are
       // read by the NEXT iteration's lm_normal only (a retry re-solves the banded
       // system in S), so an accepted trial needs no second evaluation -- one
       // pass over the pixels less per iteration, same values.
@@ -865,7 +817,7 @@ __global__ void __launch_bounds__(PP_NT)
         if (tid < 64) lm_band_solve(S, m);
         PP_T(9);  // (debug) band solve
         const double cn =
-            lm_eval(S, S.cn, Eb, El, npix, cs, ce, gw, hw, true, px);
+            lm_eval(S, S.cn, Eb, El, npix, cs, ce, wm, true, px);
         PP_T(10);  // (debug) trial evaluation
         if (cn <= cost) {  // accept (block-uniform decision)
           accepted = true;
@@ -895,7 +847,7 @@ __global__ void __launch_bounds__(PP_NT)
       __syncthreads();
       if (S.stop) break;
       if (!accepted)  // (40 rejected trials: the weights of the kept point again)
-        cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, gw, hw, true, px);
+        cost = lm_eval(S, S.c, Eb, El, npix, cs, ce, wm, true, px);
       PP_T(11);  // (debug) accept
     }
     __syncthreads();
@@ -932,8 +884,8 @@ __global__ void __launch_bounds__(PP_NT)
       iv = 0;
       c = 0;
     }
-    hw[k] = c;   // normalised spectrum
-    sb[k] = iv;  // its inverse variance
+    cs[k] = c;   // normalised spectrum  (every thread rewrites only the
+    ce[k] = iv;  // its inverse variance   pixels it has just read)
   }
   __syncthreads();
   PP_T(5);  // normalise
@@ -944,8 +896,8 @@ __global__ void __launch_bounds__(PP_NT)
     double r1 = 0, r2 = 0;
     if (xi >= 0) {
       const double rwt = rw[n], lwt = 1 - rwt;
-      r1 = lwt * hw[xi] + rwt * hw[xi + 1];
-      const double a = sb[xi], c = sb[xi + 1];
+      r1 = lwt * cs[xi] + rwt * cs[xi + 1];
+      const double a = ce[xi], c = ce[xi + 1];
       r2 = a * c / (lwt * lwt * c + rwt * rwt * a + ((a * c) == 0 ? 1.0 : 0.0));
     }
     proc_spec[(int64_t)b * nfft + n] = r1;
@@ -960,12 +912,6 @@ __global__ void __launch_bounds__(PP_NT)
   PP_T(6);  // rebin
 }
 
-static inline int next_pow2(int n) {
-  int p = 1;
-  while (p < n) p <<= 1;
-  return p;
-}
-
 extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
                                   const double *espec, const uint8_t *badmask,
                                   int npix, int B, int continuum,
@@ -978,9 +924,7 @@ extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
                                   double *pfit, int32_t *status, void *stream) {
   if (npix < 12 || B < 1 || nfft < 2) return RVS_E_ARG;
   if (continuum && (nnode < 3 || nnode > CCF_MAXNODE)) return RVS_E_ARG;
-  const int np2 = next_pow2(npix);
-  const size_t shm = sizeof(double) * (3 * (size_t)npix + np2) +
-                     sizeof(short) * np2 + ((npix + 15) / 16) * 16;
+  const size_t shm = sizeof(double) * 3 * (size_t)npix + ((npix + 15) / 16) * 16;
   if (shm + sizeof(LMShared) + sizeof(SelShared) > 159 * 1024) return RVS_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
@@ -991,7 +935,7 @@ extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
     attr_set = true;
   }
   hipLaunchKernelGGL(ccf_preprocess_kernel, dim3(B), dim3(PP_NT), shm,
-                     rvs_stream(stream), lam, spec, espec, badmask, npix, np2,
+                     rvs_stream(stream), lam, spec, espec, badmask, npix,
                      continuum, Eb, El, Cinv, istart, nnode, bin_start, xind, rw,
                      nfft, maxerr, proc_spec, proc_ivar, sse, cont, pfit, status);
   RVS_LAUNCH_CHECK();

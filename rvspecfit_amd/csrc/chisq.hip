@@ -72,6 +72,69 @@ __global__ void __launch_bounds__(256)
 // packed lower-triangular index
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 
+// ---------------------------------------------------------------------------
+// Wave-uniform operands of the grid kernel's pixel loop, fetched by explicit
+// scalar loads ONE PIXEL AHEAD of their use (inline asm: the compiler neither
+// sees these loads nor moves them, and the one s_waitcnt of a trip sits behind
+// the trip's arithmetic).  A basis row of P doubles is held in SGPR tuples that
+// cover it exactly (16/8/4/2-dword loads: nothing is read past a row).
+// ---------------------------------------------------------------------------
+typedef double cg_d8 __attribute__((ext_vector_type(8)));
+typedef double cg_d4 __attribute__((ext_vector_type(4)));
+typedef double cg_d2 __attribute__((ext_vector_type(2)));
+template <int P>
+struct CgRow {
+  cg_d8 a0, a1;
+  cg_d4 b;
+  cg_d2 c;
+  double d;
+  static constexpr int N8 = P / 8, R = P % 8;
+  // request the row at p (asynchronous: valid after cg_wait)
+  __device__ __forceinline__ void load(const double *p) {
+    if constexpr (N8 >= 1)
+      asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(a0) : "s"(p));
+    if constexpr (N8 >= 2)
+      asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=&s"(a1) : "s"(p));
+    if constexpr ((R & 4) != 0)
+      asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(b) : "s"(p), "n"(64 * N8));
+    if constexpr ((R & 2) != 0)
+      asm volatile("s_load_dwordx4 %0, %1, %2"
+                   : "=&s"(c) : "s"(p), "n"(64 * N8 + 8 * (R & 4)));
+    if constexpr ((R & 1) != 0)
+      asm volatile("s_load_dwordx2 %0, %1, %2"
+                   : "=&s"(d) : "s"(p), "n"(64 * N8 + 8 * (R & 6)));
+  }
+  // every later use of the row depends on this point of the program
+  __device__ __forceinline__ void pin() {
+    if constexpr (N8 >= 1) asm volatile("" : "+s"(a0));
+    if constexpr (N8 >= 2) asm volatile("" : "+s"(a1));
+    if constexpr ((R & 4) != 0) asm volatile("" : "+s"(b));
+    if constexpr ((R & 2) != 0) asm volatile("" : "+s"(c));
+    if constexpr ((R & 1) != 0) asm volatile("" : "+s"(d));
+  }
+  // (i is a compile-time constant wherever this is called: unrolled loops)
+  __device__ __forceinline__ double get(int i) const {
+    if (N8 >= 1 && i < 8) return a0[i];
+    if (N8 >= 2 && i < 16) return a1[i - 8];
+    int j = i - 8 * N8;
+    if ((R & 4) != 0) {
+      if (j < 4) return b[j];
+      j -= 4;
+    }
+    if ((R & 2) != 0) {
+      if (j < 2) return c[j];
+      j -= 2;
+    }
+    return d;
+  }
+};
+__device__ __forceinline__ void cg_sload2(double &d, const double *p) {
+  asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(d) : "s"(p));
+}
+__device__ __forceinline__ void cg_sload4(cg_d2 &d, const double2 *p) {
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(d) : "s"(p));
+}
+
 // Measured negative (tools/perf/ubench_dpp.hip, round 2): gfx90a+ allows
 // `row_newbcast:n` on 64-bit VALU operations at the full v_fma_f64 rate, so the 65
 // uniform factors of a pixel (55 products P_i P_j + 10 P_j) can come from the 16
@@ -191,92 +254,137 @@ __device__ __forceinline__ void
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = 0;
 
-  // The per-lane gather of the spline record and knot of a pixel is waited for
-  // in the trip that requests it; the other two waves of the SIMD cover most of
-  // its latency (3 waves x ~95 issue slots per pixel), two pixels per trip (below)
-  // halve the number of exposed round trips.  Requesting pixel k+1's record
-  // before the arithmetic of pixel k (a one-deep software pipeline, same 166
-  // VGPRs) was measured: 132.8 instead of 125.0 ms per step.
+  // The pixel loop is software-pipelined by hand, one pixel per trip.  While the
+  // 75 fp64 operations of pixel k issue, everything pixel k+1 needs is already
+  // in flight: its basis row and spectrum terms (scalar loads requested at the
+  // top of the trip), its knot and spline record (per-lane gathers requested at
+  // the top of the trip, from the pixel coordinate fetched one trip earlier).
+  // Left to the compiler, a trip was: scalar loads -> wait -> positions ->
+  // gathers -> wait -> arithmetic, two dependent round trips that the other two
+  // waves of the SIMD covered only partly (VALU 87 % busy, waves inside
+  // s_waitcnt 39 % of their residency, profiles/r03_sq_counters.json); every
+  // attempt to pipeline it in the source ended with the compiler's waits in
+  // front of the arithmetic again.  The scalar loads are inline
+  // asm now (CgRow), which the compiler can neither see through nor move, the
+  // trip's single s_waitcnt lgkmcnt(0) stands behind the arithmetic, and the
+  // gathered values are pinned there as well.
   // pos = (int)((log x - log x0)/step) evaluated as pixel coordinate + velocity
   // shift; it can differ from the reference's value only when x is within
   // rounding (~1e-11 knot spacings) of a knot, where the two adjacent cubics agree
   // to O(dx^3) ~ 1e-33 -- exactly the ambiguity the reference's own libm log
   // has (rvs_spline_eval keeps the reference formula verbatim).  The cubic is
   // evaluated in powers of dl = x - x_i (records built with form 1): 3 fma.
+  // A lane's arithmetic is the same sequence of operations as in rounds 1-2
+  // (P_j * w first, then the fma chain in the order (j, i >= j)).
   auto weights = [&](int k) -> double2 {
     if (TAIL)
       return *reinterpret_cast<const double2 *>(
           reinterpret_cast<const char *>(W0 + k) + woff);
     return W[k];
   };
-  auto accumulate = [&](int k, double tv, const double2 wk) {
-    const double w = tv * tv * wk.x;   // (t/e)^2
-    const double u = tv * wk.y;        // t s / e^2
-    const double *pr = polysT + (int64_t)k * P;
-#pragma unroll
-    for (int jj = 0; jj < P; jj++) {
-      const double pwj = pr[jj] * w;
-      av[jj] = fma(pr[jj], u, av[jj]);
-#pragma unroll
-      for (int i = jj; i < P; i++)
-        acc[TRI(i, jj)] = fma(pr[i], pwj, acc[TRI(i, jj)]);
-    }
-  };
-  // The loop is instantiated per knot spacing: with `log_step` tested inside it
-  // the compiler kept the test as scalar BRANCHES per pixel, each arm with its
-  // own s_load + s_waitcnt lgkmcnt(0) -- two to four serialised scalar-cache
-  // round trips at the head of every trip, before the gathers could be issued.
+  // The loop is instantiated per knot spacing (a test inside it became scalar
+  // branches per pixel in round 2).
   auto trips = [&](auto log_c) {
-  constexpr bool LOG = decltype(log_c)::value;
-  auto knot_of = [&](int k, double &x) {
-    // rounded product, as numpy's lam * f in the reference: left to itself
-    // the compiler contracts x - knot into fma(lam, f, -knot) in the
-    // LOG instance (x has no other use there) and chi^2 moves by ~1e-10
-    {
+    constexpr bool LOG = decltype(log_c)::value;
+    // clamped knot index of the pixel with wavelength lamk / coordinate pixk
+    auto pos_of = [&](double lamk, double pixk, double &x) {
+      // rounded product, as numpy's lam * f in the reference: left to itself
+      // the compiler contracts x - knot into fma(lam, f, -knot) in the
+      // LOG instance (x has no other use there) and chi^2 moves by ~1e-10
+      {
 #pragma clang fp contract(off)
-      x = lam[k] * f;
+        x = lamk * f;
+      }
+      int pos;
+      if (LOG)
+        pos = (int)(pixk + shift);
+      else
+        pos = (int)((x - x0) * lin_inv_step);
+      int r;
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(pos), "s"(ntp - 2));
+      return r;
+    };
+    // 32-bit byte offsets from the wave-uniform bases (full waves: the record
+    // base of the job's template is uniform too)
+    auto knot_at = [&](int p) {
+      return *reinterpret_cast<const double *>(
+          reinterpret_cast<const char *>(knots) + ((uint32_t)p << 3));
+    };
+    auto rec_at = [&](int p) {
+      return *reinterpret_cast<const double4 *>(
+          reinterpret_cast<const char *>(cf) + ((uint32_t)p << 5));
+    };
+    double w, u;   // (t/e)^2 and t s/e^2 of the pixel whose sums are next
+    {
+      double x;
+      const int p0 = pos_of(lam[0], pixa[0], x);
+      const double d0 = x - knot_at(p0);
+      const double4 c0 = rec_at(p0);
+      const double2 w0 = weights(0);
+      const double t0 = fma(fma(fma(c0.w, d0, c0.z), d0, c0.y), d0, c0.x);
+      w = t0 * t0 * w0.x;
+      u = t0 * w0.y;
     }
-    int pos;
-    if (LOG)
-      pos = (int)(pixa[k] + shift);
-    else
-      pos = (int)((x - x0) * lin_inv_step);
-    return min(max(pos, 0), ntp - 2);
-  };
-  // Two pixels per trip: both pixels' knot and record gathers are requested
-  // before either is used, both template values are formed before the first
-  // 75-FMA block (the records are dead by then: same 166 VGPRs, 3 waves/SIMD).
-  // 125.8 -> 117.0 ms per step.  The shape matters more than the idea: the same
-  // trip written with arrays and loops over q (identical loads and arithmetic)
-  // gave 121-122 ms, three pixels per trip 123-127 ms (either
-  // way of writing it), four need 186 VGPRs,
-  // this loop unrolled twice 171 (2 waves/SIMD either way).
-  int k = 0;
-  // (packed waves, P <= 10: two pixels per trip as well -- 190 VGPRs, two waves per
-  // SIMD; they run beside the full-wave launch (launch_grid), where what counts is
-  // how long they hold their slots: 34.1 -> 32.9 ms per arm of 10 000 spectra.
-  // P > 10: one pixel per trip)
-  for (; (!TAIL || P <= 10) && k + 1 < npix; k += 2) {
-    double xa, xb;
-    const int pa = knot_of(k, xa), pb = knot_of(k + 1, xb);
-    const double ka = knots[pa], kb = knots[pb];
-    const double4 ca = cf[pa], cb = cf[pb];
-    const double2 wa = weights(k), wb = weights(k + 1);
-    const double da = xa - ka, db = xb - kb;
-    const double ta = fma(fma(fma(ca.w, da, ca.z), da, ca.y), da, ca.x);
-    const double tb = fma(fma(fma(cb.w, db, cb.z), db, cb.y), db, cb.x);
-    accumulate(k, ta, wa);
-    accumulate(k + 1, tb, wb);
-  }
+    const int klast = npix - 1;
+    CgRow<P> R0, R1;
+    double la0, pa0, la1, pa1;   // wavelength / knot coordinate of the NEXT pixel
+    R0.load(polysT);
+    cg_sload2(la0, lam + min(1, klast));
+    cg_sload2(pa0, pixa + min(1, klast));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(la0), "+s"(pa0));
+    R0.pin();
+    // one pixel: Rc = basis row of pixel k (ready), (lac, pac) = coordinates of
+    // pixel k+1 (ready); leaves row k+1 in Rn, coordinates of k+2 in (lan, pan)
+    // (the row / coordinate addresses are recomputed from k with scalar
+    // instructions; running pointers with an unclamped main loop were measured:
+    // no difference, the scalar unit is idle)
+    auto trip = [&](int k, CgRow<P> &Rc, CgRow<P> &Rn, double lac, double pac,
+                    double &lan, double &pan) {
+      const int k1 = min(k + 1, klast), k2 = min(k + 2, klast);
+      Rn.load(polysT + (int64_t)k1 * P);
+      cg_d2 wn_s;
+      if (!TAIL) cg_sload4(wn_s, W + k1);
+      cg_sload2(lan, lam + k2);
+      cg_sload2(pan, pixa + k2);
+      double xn;
+      const int pn = pos_of(lac, pac, xn);
+      double kn = knot_at(pn);
+      double4 cn = rec_at(pn);
+      double2 wn_v;
+      if (TAIL) wn_v = weights(k1);
+      // the sums of pixel k
+#pragma unroll
+      for (int jj = 0; jj < P; jj++) {
+        const double pj = Rc.get(jj);
+        const double pwj = pj * w;
+        av[jj] = fma(pj, u, av[jj]);
+#pragma unroll
+        for (int i = jj; i < P; i++)
+          acc[TRI(i, jj)] = fma(Rc.get(i), pwj, acc[TRI(i, jj)]);
+      }
+      // pixel k+1: its gathers had the whole trip
+      asm volatile(""
+                   : "+v"(kn), "+v"(cn.x), "+v"(cn.y), "+v"(cn.z), "+v"(cn.w));
+      const double dn = xn - kn;
+      const double tn = fma(fma(fma(cn.w, dn, cn.z), dn, cn.y), dn, cn.x);
+      if (TAIL) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lan), "+s"(pan));
+        w = tn * tn * wn_v.x;
+        u = tn * wn_v.y;
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lan), "+s"(pan), "+s"(wn_s));
+        w = tn * tn * wn_s[0];
+        u = tn * wn_s[1];
+      }
+      Rn.pin();
+    };
+    int k = 0;
 #pragma unroll 1
-  for (; k < npix; k++) {
-    double xa;
-    const int pa = knot_of(k, xa);
-    const double da = xa - knots[pa];
-    const double4 ca = cf[pa];
-    accumulate(k, fma(fma(fma(ca.w, da, ca.z), da, ca.y), da, ca.x),
-               weights(k));
-  }
+    for (; k + 1 < npix; k += 2) {
+      trip(k, R0, R1, la0, pa0, la1, pa1);
+      trip(k + 1, R1, R0, la1, pa1, la0, pa0);
+    }
+    if (k < npix) trip(k, R0, R1, la0, pa0, la1, pa1);
   };
   if (log_step)
     trips(std::true_type{});
@@ -343,6 +451,9 @@ __device__ __forceinline__ void
   }
 }
 
+#ifdef CG_CLOCK
+__device__ unsigned long long cg_clock_dbg[2];
+#endif
 // Two launches: nfull full waves per job, then the packed waves.  (One launch
 // with a block-uniform branch between the two bodies was measured: the full-wave
 // path lost 4 % to the shared register allocation, 32.5 against 31.6 ms per
@@ -353,7 +464,7 @@ template <int P, bool TAIL>
 // strategy -- the scalar loads at the head of a trip are then issued and waited
 // for one by one, 36.0 against 33.2 ms per 10 000 spectra)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(
-    TAIL ? (P <= 10 ? 2 : CG_WAVES(P)) : (P <= 10 ? 2 : 1))))
+    TAIL ? (P <= 10 ? 2 : CG_WAVES(P)) : CG_WAVES(P))))
     chisq_grid_kernel(const double *__restrict__ lam,
                       const double *__restrict__ polysT,
                       const double *__restrict__ work, int npix, int S,
@@ -367,6 +478,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(
                       double beta_out, double *__restrict__ out,
                       int32_t *__restrict__ status) {
   int bx = blockIdx.x, by = 0;
+#ifdef CG_CLOCK
+  unsigned long long c0 = 0, r0 = 0;
+  if (blockIdx.x == 4096) {
+    c0 = __builtin_readcyclecounter();
+    r0 = wall_clock64();
+  }
+#endif
   if (!TAIL) {
     // blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one):
     // the nfull waves of a job are 8 blocks apart so that the job's spline
@@ -383,6 +501,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(
                            knots, coef, ntp, log_step, job_spec, job_templ, J,
                            vels, vel_stride, Nv, iv0, lpj, penalty, badchi,
                            beta_out, out, status);
+#ifdef CG_CLOCK
+  if (blockIdx.x == 4096 && threadIdx.x == 0) {
+    cg_clock_dbg[0] = __builtin_readcyclecounter() - c0;
+    cg_clock_dbg[1] = wall_clock64() - r0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -93,6 +93,14 @@ int main(int argc, char **argv) {
     }
     printf("three arms on %d stream(s): best %.3f ms\n", ns, b3);
   }
+#ifdef CG_CLOCK
+  {
+    unsigned long long c[2];
+    hipMemcpyFromSymbol(c, HIP_SYMBOL(cg_clock_dbg), sizeof(c));
+    printf("wave lifetime: %llu shader cycles, %llu ref ticks (100 MHz) -> %.1f MHz, %.3f ms; %.1f cycles/pixel\n", c[0], c[1],
+           (double)c[0] / c[1] * 100.0, c[1] / 1e5, (double)c[0] / npix);
+  }
+#endif
   std::vector<double> out(vels.size());
   hipMemcpy(out.data(), d_out, out.size() * 8, hipMemcpyDeviceToHost);
   uint64_t h = 1469598103934665603ull; double tot = 0; int nan = 0;

@@ -174,7 +174,7 @@ int rvs_spline_eval(const double *knots, const double *coef, int ntp,
  * beta    out = beta*out + value  (0 first arm, 1 following arms)
  * pack_min_jobs  the Nv % 64 left-over velocities of a job (16 of the 400-point
  *          grid) share a wave with those of other jobs when J >= this
- *          (0 = library default 4096, 1 = always, < 0 = never); where a
+ *          (0 = library default 2000, 1 = always, < 0 = never); where a
  *          velocity is computed does not change its value.  The packed launch
  *          runs on a library-owned side stream (one per host thread and
  *          device), forked from and joined to `stream` inside the call: to the

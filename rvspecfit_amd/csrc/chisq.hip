@@ -459,12 +459,13 @@ __device__ unsigned long long cg_clock_dbg[2];
 // path lost 4 % to the shared register allocation, 32.5 against 31.6 ms per
 // 10 000 spectra.)
 template <int P, bool TAIL>
-// (the full-wave kernel is left at "at least two waves per SIMD": it lands on
-// 167 VGPRs = three by itself, while a demanded three changes the scheduler's
-// strategy -- the scalar loads at the head of a trip are then issued and waited
-// for one by one, 36.0 against 33.2 ms per 10 000 spectra)
+// (three waves per SIMD are demanded for P <= 10 in both variants: with the
+// hand-pipelined loop the compiler has nothing left to reorder, the 168-VGPR
+// budget only moves post-loop values to scratch outside the loop.  The packed
+// waves had 2 per SIMD at 190 VGPRs in round 2: 100-point grids 9.6 -> 8.9 ms,
+// 16-point grids 3.55 -> 2.76 ms per 10 000 jobs with three)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(
-    TAIL ? (P <= 10 ? 2 : CG_WAVES(P)) : CG_WAVES(P))))
+    CG_WAVES(P))))
     chisq_grid_kernel(const double *__restrict__ lam,
                       const double *__restrict__ polysT,
                       const double *__restrict__ work, int npix, int S,
@@ -852,16 +853,19 @@ static int launch_grid(const double *lam, const double *polysT,
                        double *out, int32_t *status, int pack_min_jobs,
                        hipStream_t st) {
   // left-over velocities of a job (Nv % 64) are packed with those of other jobs
-  // in a flat (job, velocity) order, J * r lanes in all (below ~4000 jobs the
-  // packed launch -- one wave time whatever its size -- costs more than J ragged
-  // waves inside the main launch)
-  // A packed lane costs ~1.5x a full-wave lane (two waves per SIMD at 190 VGPRs,
-  // spectrum terms per lane; refine_stats.py: 101-point grids 30.9 ns per
-  // job-velocity packed, 32 ragged; 125-point grids 30.1 packed, 25.9 ragged),
-  // so more than 40 left over keep a ragged wave of their own.
+  // in a flat (job, velocity) order, J * r lanes in all.  Thresholds measured
+  // with the round-3 kernels (three waves per SIMD in both variants; cg_bench,
+  // ms per launch packed / ragged): 10 000 jobs of 100 points (r = 36) 8.8 / 10.0,
+  // 112 points (r = 48) 9.8 / 10.2, 125 points (r = 61) 10.7 / 10.2 -> a ragged
+  // wave of its own from r = 50 up; 400 points: 1000 jobs 3.7 / 3.7, 2000 jobs
+  // 6.6 / 6.9, 4000 jobs 12.2 / 13.3 -> packing from 2000 jobs up (the packed
+  // launch alone is one wave time whatever its size).
+#ifndef CG_PACK_MAXR
+#define CG_PACK_MAXR 50
+#endif
   int r = Nv % 64;
-  if (pack_min_jobs == 0) pack_min_jobs = 4096;
-  if (r > 40 || pack_min_jobs < 0 || J < pack_min_jobs ||
+  if (pack_min_jobs == 0) pack_min_jobs = 2000;
+  if (r > CG_PACK_MAXR || pack_min_jobs < 0 || J < pack_min_jobs ||
       (int64_t)S * npix * 16 >= (1ll << 32))
     r = 0;
   const int nfull = r ? Nv / 64 : (Nv + 63) / 64;   // waves per job, TAIL=false

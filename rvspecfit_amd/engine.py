@@ -380,7 +380,7 @@ def convolve_vsini(lib_or_lam, templ, vsini, eps=0.6):
 XCORR_PRUNE = True     # prune the last two FFT passes to the lags that are read
 import os as _os
 # rvs_chisq_grid's pack_min_jobs: 0 = library default (pack the Nv % 64
-# left-over velocities of >= 4096 jobs), 1 = always, -1 = never (tests)
+# left-over velocities of >= 2000 jobs), 1 = always, -1 = never (tests)
 CG_PACK_MIN_JOBS = 0
 
 

@@ -595,6 +595,75 @@ def test_overlap_error(cases, config):
                            options=dict(npoly=10), config=config)
 
 
+def test_chisq_grid_every_npoly_vs_objective_kernel(cases, config):
+    """The velocity-grid kernel holds a basis row in SGPR tuples that cover its
+    P doubles exactly (16/8/4/2-dword scalar loads, csrc/chisq.hip CgRow): every
+    P from 1 to 16 is a different set of pieces.  chi^2 on a 70-point grid (one
+    full wave + 6 packed left-over lanes, i.e. both kernel variants) against the
+    optimiser's one-kernel objective (explicit residual norm, its own basis
+    handling) at the same velocities."""
+    from rvspecfit_amd import spec_fit, engine
+    sds = _sds(cases, 'c1')
+    b, _ = spec_fit.as_batch(sds)
+    p = np.array(cases['c1/truth'], dtype=np.float64)
+    vg = np.linspace(-310.0, 295.0, 70)
+    par = torch.as_tensor(p[None, None, :]).to('cuda')
+    keep = engine.CG_PACK_MIN_JOBS
+    engine.CG_PACK_MIN_JOBS = 1
+    try:
+        for npoly in range(1, 17):
+            g, st, _ = spec_fit.chisq_grid_jobs(
+                b, torch.as_tensor(vg).to('cuda'), par, None,
+                dict(npoly=npoly), config)
+            assert int(st.sum().item()) == 0, npoly
+            g = g.cpu().numpy().reshape(-1)
+            idx = torch.zeros(len(vg), dtype=torch.long, device='cuda')
+            c, st2 = spec_fit.chisq_jobs(
+                b, idx, torch.as_tensor(vg).to('cuda'),
+                torch.as_tensor(np.tile(p, (len(vg), 1))).to('cuda'), None,
+                dict(npoly=npoly), config)
+            c = c.cpu().numpy()
+            assert np.all(np.isfinite(g)) and np.all(np.isfinite(c)), npoly
+            # the grid kernel's D.D - y.y against the explicit residual: 1e-16 *
+            # sum (s/e)^2 of rounding noise (DESIGN 4.7)
+            np.testing.assert_allclose(g, c, rtol=1e-9, atol=1e-7,
+                                       err_msg='npoly %d' % npoly)
+    finally:
+        engine.CG_PACK_MIN_JOBS = keep
+
+
+@pytest.mark.parametrize('npix', [2, 3, 4, 5, 8])
+def test_chisq_grid_short_arms(cases, config, npix):
+    """The grid kernel's pixel loop runs one pixel ahead of itself (row k+1,
+    coordinates k+2, clamped to the last pixel): arms of 2..8 pixels."""
+    from rvspecfit_amd import spec_fit, engine
+    sd0 = _sds(cases, 'c1')[0]
+    i0 = len(sd0.lam) // 3
+    sds = [spec_fit.SpecData(sd0.name, sd0.lam[i0:i0 + npix].copy(),
+                             sd0.spec[i0:i0 + npix].copy(),
+                             sd0.espec[i0:i0 + npix].copy())]
+    b, _ = spec_fit.as_batch(sds)
+    p = np.array(cases['c1/truth'], dtype=np.float64)
+    vg = np.linspace(-310.0, 295.0, 70)
+    keep = engine.CG_PACK_MIN_JOBS
+    engine.CG_PACK_MIN_JOBS = 1
+    try:
+        g, st, _ = spec_fit.chisq_grid_jobs(
+            b, torch.as_tensor(vg).to('cuda'),
+            torch.as_tensor(p[None, None, :]).to('cuda'), None,
+            dict(npoly=1), config)
+    finally:
+        engine.CG_PACK_MIN_JOBS = keep
+    assert int(st.sum().item()) == 0
+    idx = torch.zeros(len(vg), dtype=torch.long, device='cuda')
+    c, _ = spec_fit.chisq_jobs(
+        b, idx, torch.as_tensor(vg).to('cuda'),
+        torch.as_tensor(np.tile(p, (len(vg), 1))).to('cuda'), None,
+        dict(npoly=1), config)
+    np.testing.assert_allclose(g.cpu().numpy().reshape(-1), c.cpu().numpy(),
+                               rtol=1e-9, atol=1e-7)
+
+
 def test_chisq_grid_wave_placement_bit_identical(cases, config):
     """A velocity's chi^2 does not depend on where the kernel computes it: in a
     wave of 64 velocities of one spectrum, or in a wave that packs the left-over

@@ -73,15 +73,25 @@ __global__ void __launch_bounds__(256)
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 
 // ---------------------------------------------------------------------------
-// Wave-uniform operands of the grid kernel's pixel loop, fetched by explicit
-// scalar loads ONE PIXEL AHEAD of their use (inline asm: the compiler neither
-// sees these loads nor moves them, and the one s_waitcnt of a trip sits behind
-// the trip's arithmetic).  A basis row of P doubles is held in SGPR tuples that
-// cover it exactly (16/8/4/2-dword loads: nothing is read past a row).
+// Wave-uniform operands of the grid kernel's pixel loop, requested ONE PIXEL
+// AHEAD of their use.  They are ordinary scalar loads (the compiler tracks what
+// is pending and places the s_waitcnt itself); what keeps them -- and the
+// per-lane gathers -- at the top of a trip and their first use behind the trip's
+// arithmetic is a pair of __builtin_amdgcn_sched_barrier(0) fences (CG_FENCE)
+// around the arithmetic and an empty asm that "uses" each value behind it
+// (CgRow::pin, cg_use).  An earlier form issued the loads from inline asm, which
+// the compiler cannot see through: it measured 2-8 % slower, and under register
+// pressure (the resolution-matrix kernel) the allocator split a live range
+// right behind such a load -- copied the not-yet-loaded register and reused it
+// as an address, which the load then overwrote: a fault.  Nothing here depends
+// on instructions the compiler does not know about.
+// A basis row of P doubles is held in SGPR tuples that cover it exactly
+// (16/8/4/2-dword loads: nothing is read past a row).
 // ---------------------------------------------------------------------------
 typedef double cg_d8 __attribute__((ext_vector_type(8)));
 typedef double cg_d4 __attribute__((ext_vector_type(4)));
 typedef double cg_d2 __attribute__((ext_vector_type(2)));
+#define CG_FENCE() __builtin_amdgcn_sched_barrier(0)
 template <int P>
 struct CgRow {
   cg_d8 a0, a1;
@@ -89,22 +99,19 @@ struct CgRow {
   cg_d2 c;
   double d;
   static constexpr int N8 = P / 8, R = P % 8;
-  // request the row at p (asynchronous: valid after cg_wait)
+  // request the row at p (rows are 8-byte aligned only)
   __device__ __forceinline__ void load(const double *p) {
-    if constexpr (N8 >= 1)
-      asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(a0) : "s"(p));
-    if constexpr (N8 >= 2)
-      asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=&s"(a1) : "s"(p));
-    if constexpr ((R & 4) != 0)
-      asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(b) : "s"(p), "n"(64 * N8));
+    typedef double d8u __attribute__((ext_vector_type(8), aligned(8)));
+    typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    if constexpr (N8 >= 1) a0 = *reinterpret_cast<const d8u *>(p);
+    if constexpr (N8 >= 2) a1 = *reinterpret_cast<const d8u *>(p + 8);
+    if constexpr ((R & 4) != 0) b = *reinterpret_cast<const d4u *>(p + 8 * N8);
     if constexpr ((R & 2) != 0)
-      asm volatile("s_load_dwordx4 %0, %1, %2"
-                   : "=&s"(c) : "s"(p), "n"(64 * N8 + 8 * (R & 4)));
-    if constexpr ((R & 1) != 0)
-      asm volatile("s_load_dwordx2 %0, %1, %2"
-                   : "=&s"(d) : "s"(p), "n"(64 * N8 + 8 * (R & 6)));
+      c = *reinterpret_cast<const d2u *>(p + 8 * N8 + (R & 4));
+    if constexpr ((R & 1) != 0) d = p[8 * N8 + (R & 6)];
   }
-  // every later use of the row depends on this point of the program
+  // first "use" of the row: the loads are waited for here, not earlier
   __device__ __forceinline__ void pin() {
     if constexpr (N8 >= 1) asm volatile("" : "+s"(a0));
     if constexpr (N8 >= 2) asm volatile("" : "+s"(a1));
@@ -128,11 +135,18 @@ struct CgRow {
     return d;
   }
 };
-__device__ __forceinline__ void cg_sload2(double &d, const double *p) {
-  asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(d) : "s"(p));
+// f(integral_constant<int, I>) for I = I0 .. N-1, unrolled at compile time
+template <int I, int N, class F>
+__device__ __forceinline__ void cg_static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    cg_static_for<I + 1, N>(f);
+  }
 }
+__device__ __forceinline__ void cg_sload2(double &d, const double *p) { d = *p; }
 __device__ __forceinline__ void cg_sload4(cg_d2 &d, const double2 *p) {
-  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(d) : "s"(p));
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  d = *reinterpret_cast<const d2u *>(p);
 }
 
 // Measured negative (tools/perf/ubench_dpp.hip, round 2): gfx90a+ allows
@@ -256,18 +270,18 @@ __device__ __forceinline__ void
 
   // The pixel loop is software-pipelined by hand, one pixel per trip.  While the
   // 75 fp64 operations of pixel k issue, everything pixel k+1 needs is already
-  // in flight: its basis row and spectrum terms (scalar loads requested at the
-  // top of the trip), its knot and spline record (per-lane gathers requested at
-  // the top of the trip, from the pixel coordinate fetched one trip earlier).
-  // Left to the compiler, a trip was: scalar loads -> wait -> positions ->
-  // gathers -> wait -> arithmetic, two dependent round trips that the other two
-  // waves of the SIMD covered only partly (VALU 87 % busy, waves inside
-  // s_waitcnt 39 % of their residency, profiles/r03_sq_counters.json); every
-  // attempt to pipeline it in the source ended with the compiler's waits in
-  // front of the arithmetic again.  The scalar loads are inline
-  // asm now (CgRow), which the compiler can neither see through nor move, the
-  // trip's single s_waitcnt lgkmcnt(0) stands behind the arithmetic, and the
-  // gathered values are pinned there as well.
+  // in flight: its basis row and spectrum terms (scalar loads at the top of the
+  // trip), its knot and spline record (per-lane gathers at the top of the trip,
+  // from the pixel coordinate fetched one trip earlier).  Left to itself the
+  // compiler built a trip as scalar loads -> wait -> positions -> gathers ->
+  // wait -> arithmetic: two dependent round trips that the other two waves of
+  // the SIMD covered only partly (VALU 87 % busy, waves inside s_waitcnt 39 % of
+  // their residency, profiles/r03_sq_counters.json), and every attempt to
+  // pipeline it in the source ended with the waits in front of the arithmetic
+  // again.  Two scheduling fences around the arithmetic and an
+  // empty asm "use" of every prefetched value behind it pin the order; measured
+  // inside the kernel (cg_bench -DCG_CLOCK) a SIMD now spends 367 cycles per
+  // pixel and wave for 88 VALU instructions x 4 cycles = 352.
   // pos = (int)((log x - log x0)/step) evaluated as pixel coordinate + velocity
   // shift; it can differ from the reference's value only when x is within
   // rounding (~1e-11 knot spacings) of a knot, where the two adjacent cubics agree
@@ -331,7 +345,7 @@ __device__ __forceinline__ void
     R0.load(polysT);
     cg_sload2(la0, lam + min(1, klast));
     cg_sload2(pa0, pixa + min(1, klast));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(la0), "+s"(pa0));
+    asm volatile("" : "+s"(la0), "+s"(pa0));
     R0.pin();
     // one pixel: Rc = basis row of pixel k (ready), (lac, pac) = coordinates of
     // pixel k+1 (ready); leaves row k+1 in Rn, coordinates of k+2 in (lan, pan)
@@ -352,6 +366,7 @@ __device__ __forceinline__ void
       double4 cn = rec_at(pn);
       double2 wn_v;
       if (TAIL) wn_v = weights(k1);
+      CG_FENCE();
       // the sums of pixel k
 #pragma unroll
       for (int jj = 0; jj < P; jj++) {
@@ -362,17 +377,18 @@ __device__ __forceinline__ void
         for (int i = jj; i < P; i++)
           acc[TRI(i, jj)] = fma(Rc.get(i), pwj, acc[TRI(i, jj)]);
       }
+      CG_FENCE();
       // pixel k+1: its gathers had the whole trip
       asm volatile(""
                    : "+v"(kn), "+v"(cn.x), "+v"(cn.y), "+v"(cn.z), "+v"(cn.w));
       const double dn = xn - kn;
       const double tn = fma(fma(fma(cn.w, dn, cn.z), dn, cn.y), dn, cn.x);
       if (TAIL) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lan), "+s"(pan));
+        asm volatile("" : "+s"(lan), "+s"(pan));
         w = tn * tn * wn_v.x;
         u = tn * wn_v.y;
       } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lan), "+s"(pan), "+s"(wn_s));
+        asm volatile("" : "+s"(lan), "+s"(pan), "+s"(wn_s));
         w = tn * tn * wn_s[0];
         u = tn * wn_s[1];
       }
@@ -658,16 +674,29 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   }
 }
 
-// ---- the same, window in registers, for a compile-time number of diagonals ----
+// ---- window in registers for a compile-time number of diagonals (11: DESI),
+// software-pipelined like chisq_grid_kernel ----
+// The window of raw values around the current pixel lives in REGISTERS: the
+// pixel loop is unrolled WIN-fold (WIN = ND + 1) so that every slot index
+// (pixel mod WIN) is a compile-time constant -- no LDS ring, no moves.
+// One wave per block; the wave-uniform operands of pixel k+1 -- basis row,
+// spectrum terms, the ND taps of the pixel's resolution row (PER SPECTRUM:
+// 88 B a pixel that only this job's seven waves ever read, i.e. a scalar-cache
+// miss per pixel) -- are requested at the top of trip k, the knot / record
+// gathers of pixel k+M+1 likewise, and their first use stands behind the 75
+// fp64 operations of pixel k (CG_FENCE / pin, see CgRow).  The arithmetic
+// of a lane is that of the round-2 register-window kernel, operation for
+// operation (266 -> 140 ms per step of 10 000 DESI spectra).
 template <int P, int ND>
-__global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
-    chisq_grid_resol_reg_kernel(const double *__restrict__ lam,
+__global__ void __launch_bounds__(64)
+    __attribute__((amdgpu_waves_per_eu(P <= 12 ? 2 : 1)))
+    chisq_grid_resol_pipe_kernel(const double *__restrict__ lam,
                             const double *__restrict__ polysT,
                             const double *__restrict__ work, int npix, int S,
                             const double *__restrict__ knots,
                             const double4 *__restrict__ coef, int ntp,
                             int log_step, const double *__restrict__ taps,
-                            int nd, int64_t taps_stride,
+                            int64_t taps_stride,
                             const int32_t *__restrict__ job_spec,
                             const int32_t *__restrict__ job_templ,
                             const double *__restrict__ vels, int64_t vel_stride,
@@ -676,10 +705,9 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
                             double *__restrict__ out,
                             int32_t *__restrict__ status) {
   const int j = blockIdx.y;
-  const int wave_v0 = blockIdx.x * 256 + (threadIdx.x & ~63);
-  if (wave_v0 >= Nv) return;
-  const int iv = blockIdx.x * 256 + threadIdx.x;
+  int iv = blockIdx.x * 64 + threadIdx.x;
   const bool active = iv < Nv;
+  if (!active) iv = blockIdx.x * 64;
   const int s = job_spec ? job_spec[j] : j;
   const int t = job_templ ? job_templ[j] : j;
   double *outp = out + (int64_t)j * Nv;
@@ -697,7 +725,7 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   const double *scal = work + npix + 2ll * S * npix + 2 * s;
   const double4 *cf = coef + (int64_t)t * ntp;
   const double *tp = taps + (int64_t)s * taps_stride;
-  const double vel = vels[(int64_t)j * vel_stride + (active ? iv : 0)];
+  const double vel = vels[(int64_t)j * vel_stride + iv];
   const double bb = vel / RVS_C_KMS;
   const double f = sqrt((1.0 - bb) / (1.0 + bb));
   const double x0 = knots[0], xlast = knots[ntp - 1];
@@ -711,68 +739,132 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   }
   double acc[P * (P + 1) / 2];
   double av[P];
-  // instantiated per knot spacing (see chisq_grid_kernel: a test of log_step
-  // inside the loop becomes scalar branches with serialised s_loads)
-  auto pixels = [&](auto log_c) {
-  constexpr bool LOG = decltype(log_c)::value;
-  auto raw_at = [&](int p) {
-    double x;
-    {  // rounded product, see chisq_grid_kernel
-#pragma clang fp contract(off)
-      x = lam[p] * f;
-    }
-    int pos = LOG ? (int)(pixa[p] + shift) : (int)((x - x0) * lin_inv_step);
-    pos = min(max(pos, 0), ntp - 2);
-    const double dl = x - knots[pos];
-    const double4 c = cf[pos];
-    return fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
-  };
-  // window of raw values around the current pixel, in REGISTERS: the pixel loop
-  // is unrolled WIN-fold so that every slot index (pixel mod WIN) is a
-  // compile-time constant -- no LDS ring, no moves.  WIN = ND + 1: the value
-  // fetched in an iteration (pixel k + M + 1) is first used in the NEXT one, so
-  // its gather latency hides behind this iteration's ~90 fp64 operations.
-  constexpr int M = (ND - 1) / 2;
-  constexpr int WIN = ND + 1;
-  double win[WIN];
-#pragma unroll
-  for (int d = 0; d < WIN; d++) win[d] = 0.0;
-#pragma unroll
-  for (int p = 0; p <= M; p++)
-    if (p < npix) win[p % WIN] = raw_at(p);
-
 #pragma unroll
   for (int i = 0; i < P * (P + 1) / 2; i++) acc[i] = 0;
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = 0;
-  for (int k0 = 0; k0 < npix; k0 += WIN) {
-#pragma unroll
-    for (int j = 0; j < WIN; j++) {
-      const int k = k0 + j;
-      if (k < npix) {  // wave-uniform
-        if (k + M + 1 < npix) win[(j + M + 1) % WIN] = raw_at(k + M + 1);
-        const double *tk = tp + (int64_t)k * ND;
-        double tv = 0;
-#pragma unroll
-        for (int d = 0; d < ND; d++)
-          tv = fma(tk[d], win[(j + WIN - M + d) % WIN], tv);
-        const double2 wk = W[k];
-        const double w = tv * tv * wk.x;
-        const double u = tv * wk.y;
-        const double *pr = polysT + (int64_t)k * P;
-        double pw[P];
-#pragma unroll
-        for (int i = 0; i < P; i++) pw[i] = pr[i] * w;
-#pragma unroll
-        for (int i = 0; i < P; i++) {
-          av[i] = fma(pr[i], u, av[i]);
-#pragma unroll
-          for (int jj = 0; jj <= i; jj++)
-            acc[TRI(i, jj)] = fma(pr[i], pw[jj], acc[TRI(i, jj)]);
-        }
+  auto pixels = [&](auto log_c) {
+    constexpr bool LOG = decltype(log_c)::value;
+    constexpr int M = (ND - 1) / 2;
+    constexpr int WIN = ND + 1;   // even: the row buffers swap once per pixel
+    auto pos_of = [&](double lamk, double pixk, double &x) {
+      {  // rounded product, see chisq_grid_kernel
+#pragma clang fp contract(off)
+        x = lamk * f;
       }
+      int pos = LOG ? (int)(pixk + shift) : (int)((x - x0) * lin_inv_step);
+      int r;
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(pos), "s"(ntp - 2));
+      return r;
+    };
+    auto knot_at = [&](int p) {
+      return *reinterpret_cast<const double *>(
+          reinterpret_cast<const char *>(knots) + ((uint32_t)p << 3));
+    };
+    auto rec_at = [&](int p) {
+      return *reinterpret_cast<const double4 *>(
+          reinterpret_cast<const char *>(cf) + ((uint32_t)p << 5));
+    };
+    const int klast = npix - 1;
+    // window of raw values around the current pixel, in registers; slot =
+    // pixel mod WIN, a compile-time constant in the WIN-fold unrolled loop
+    double win[WIN];
+#pragma unroll
+    for (int d = 0; d < WIN; d++) win[d] = 0.0;
+#pragma unroll
+    for (int p = 0; p <= M; p++)
+      if (p < npix) {
+        double x;
+        const int q = pos_of(lam[p], pixa[p], x);
+        const double dl = x - knot_at(q);
+        const double4 c = rec_at(q);
+        win[p % WIN] = fma(fma(fma(c.w, dl, c.z), dl, c.y), dl, c.x);
+      }
+    double w, u;
+    {
+      double tv = 0;
+#pragma unroll
+      for (int d = 0; d < ND; d++)
+        tv = fma(tp[d], win[(WIN - M + d) % WIN], tv);
+      const double2 w0 = W[0];
+      w = tv * tv * w0.x;
+      u = tv * w0.y;
     }
-  }
+    CgRow<P> R0, R1;
+    CgRow<ND> TP;
+    double la0, pa0, la1, pa1;   // coordinates of pixel k + M + 1 at trip k
+    R0.load(polysT);
+    cg_sload2(la0, lam + min(M + 1, klast));
+    cg_sload2(pa0, pixa + min(M + 1, klast));
+    asm volatile("" : "+s"(la0), "+s"(pa0));
+    R0.pin();
+    auto trip = [&](auto jc, int k, CgRow<P> &Rc, CgRow<P> &Rn, double lac,
+                    double pac, double &lan, double &pan) {
+      constexpr int JJ = decltype(jc)::value;   // k mod WIN
+      const int k1 = min(k + 1, klast), k2 = min(k + M + 2, klast);
+      Rn.load(polysT + (int64_t)k1 * P);
+      TP.load(tp + (int64_t)k1 * ND);
+      cg_d2 wn_s;
+      cg_sload4(wn_s, W + k1);
+      cg_sload2(lan, lam + k2);
+      cg_sload2(pan, pixa + k2);
+      const bool fresh = k + M + 1 < npix;   // wave-uniform
+      double xn;
+      const int pn = pos_of(lac, pac, xn);
+      double kn = knot_at(pn);
+      double4 cn = rec_at(pn);
+      CG_FENCE();
+#pragma unroll
+      for (int jj = 0; jj < P; jj++) {
+        const double pj = Rc.get(jj);
+        const double pwj = pj * w;
+        av[jj] = fma(pj, u, av[jj]);
+#pragma unroll
+        for (int i = jj; i < P; i++)
+          acc[TRI(i, jj)] = fma(Rc.get(i), pwj, acc[TRI(i, jj)]);
+      }
+      CG_FENCE();
+      asm volatile(""
+                   : "+v"(kn), "+v"(cn.x), "+v"(cn.y), "+v"(cn.z), "+v"(cn.w));
+      const double dn = xn - kn;
+      const double raw = fma(fma(fma(cn.w, dn, cn.z), dn, cn.y), dn, cn.x);
+      // (beyond the last pixel the matrix has no column: zero, as the sparse
+      // product of convolve_resol)
+      win[(JJ + M + 1) % WIN] = fresh ? raw : 0.0;
+      asm volatile("" : "+s"(lan), "+s"(pan), "+s"(wn_s));
+      TP.pin();
+      Rn.pin();
+      double tv = 0;
+#pragma unroll
+      for (int d = 0; d < ND; d++)
+        tv = fma(TP.get(d), win[(JJ + 1 + WIN - M + d) % WIN], tv);
+      w = tv * tv * wn_s[0];
+      u = tv * wn_s[1];
+    };
+    // whole windows without a test per pixel (with one, every trip ended in a
+    // branch whose join cost a dozen register moves), then the last < WIN pixels
+    int k0 = 0;
+#pragma unroll 1
+    for (; k0 + WIN <= npix; k0 += WIN) {
+      cg_static_for<0, WIN / 2>([&](auto hc) {
+        constexpr int J2 = 2 * decltype(hc)::value;
+        trip(std::integral_constant<int, J2>{}, k0 + J2, R0, R1, la0, pa0, la1,
+             pa1);
+        trip(std::integral_constant<int, J2 + 1>{}, k0 + J2 + 1, R1, R0, la1,
+             pa1, la0, pa0);
+      });
+    }
+    if (k0 < npix) {
+      cg_static_for<0, WIN / 2>([&](auto hc) {
+        constexpr int J2 = 2 * decltype(hc)::value;
+        if (k0 + J2 < npix)
+          trip(std::integral_constant<int, J2>{}, k0 + J2, R0, R1, la0, pa0,
+               la1, pa1);
+        if (k0 + J2 + 1 < npix)
+          trip(std::integral_constant<int, J2 + 1>{}, k0 + J2 + 1, R1, R0, la1,
+               pa1, la0, pa0);
+      });
+    }
   };
   if (log_step)
     pixels(std::true_type{});
@@ -984,10 +1076,11 @@ extern "C" int rvs_chisq_grid_resol(
       attr_set = true;                                                         \
     }                                                                          \
     if (nd == 11)                                                              \
-      hipLaunchKernelGGL((chisq_grid_resol_reg_kernel<PP, 11>), grid,          \
-                         dim3(256), 0, st, lam, polysT, work, npix, S, knots,  \
+      hipLaunchKernelGGL((chisq_grid_resol_pipe_kernel<PP, 11>),               \
+                         dim3((Nv + 63) / 64, J), dim3(64), 0, st, lam,        \
+                         polysT, work, npix, S, knots,                         \
                          reinterpret_cast<const double4 *>(coef), ntp,         \
-                         log_step, taps, nd, taps_stride, job_spec, job_templ, \
+                         log_step, taps, taps_stride, job_spec, job_templ,     \
                          vels, vel_stride, Nv, penalty, badchi, beta, out,     \
                          status);                                              \
     else                                                                       \

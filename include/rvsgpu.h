@@ -51,8 +51,10 @@ extern "C" {
  *   3: rvs_template_polylinear / rvs_objective_arm take `ptp` (the query is
  *      p / ptp as in spec_inter.py:130-132), not its reciprocal
  *   4: rvs_objective_work_size grew (the cell-search records of the objective's
- *      locate pass live in the caller's scratch) */
-#define RVS_ABI_VERSION 4
+ *      locate pass live in the caller's scratch)
+ *   5: rvs_nn_outside added; rvs_chisq_grid packs left-over velocities from
+ *      2000 jobs up by default (pack_min_jobs = 0) */
+#define RVS_ABI_VERSION 5
 int rvs_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -458,6 +460,20 @@ int rvs_template_nn(const double *params, int B, int ndim, uint32_t log_mask,
                     const float *const *W, const float *const *b,
                     const int32_t *dims, float *act0, float *act1,
                     double *templ, void *stream);
+
+/* Outside flag of an NN library; replaces OutsideInterpolator.__call__
+ * (nn/RVSInterpolator.py:63-71) as SpecInterpolator.outsideFlag calls it on the
+ * Mapper-transformed point (spec_inter.py:257-272, nn/NNInterpolator.py:159-171):
+ * outside[j] = max(max_f xeqs[f].(p0,p1,1), max_f yeqs[f].(p2..,1), 0)^2.
+ * xeqs [nfx, 3], yeqs [nfy, ndim-1]: scipy.spatial.ConvexHull(...).equations of
+ * the first two / the remaining mapped coordinates of the training points
+ * (built once by the caller); params, M, S, log_mask as rvs_template_nn;
+ * mapped != 0: params ARE the Mapper's float64 output (M, S, log_mask unused).
+ * A NaN parameter gives NaN (the arm is then skipped, spec_fit.py:888-893). */
+int rvs_nn_outside(const double *params, int B, int ndim, uint32_t log_mask,
+                   const double *M, const double *S, int mapped,
+                   const double *xeqs, int nfx, const double *yeqs, int nfy,
+                   double *outside, void *stream);
 
 /* ------------------------------------------------------------------------
  * the optimiser stage of vel_fit.process

@@ -68,11 +68,12 @@ SIGNATURES = {
                           P, P]),
     'rvs_ccf_select': (I, [P, P, I, I, I, P, I, P, P, P, P]),
     'rvs_template_nn': (I, [P, I, I, U, P, P, I, P, P, P, P, P, P, P]),
+    'rvs_nn_outside': (I, [P, I, I, U, P, P, I, P, I, P, I, P, P]),
 }
 
 _lib = None
 # RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class RvsGpuError(RuntimeError):

@@ -48,6 +48,50 @@ __global__ void __launch_bounds__(256)
   x[i] = (float)(((double)y - M[d]) / S[d]);
 }
 
+// OutsideInterpolator.__call__ (nn/RVSInterpolator.py:63-71) at the point
+// Mapper.forward (nn/NNInterpolator.py:159-171) makes of the parameters, as
+// SpecInterpolator.outsideFlag calls it (spec_inter.py:257-272): the largest
+// signed distance to the facets of two convex hulls -- the first two and the
+// remaining mapped coordinates -- clamped at zero and squared.  (The reference
+// asks two Delaunay triangulations whether the point is inside first; for a
+// convex hull that is "no facet distance is positive", which the clamp says.)
+// One thread per job; a NaN coordinate gives NaN, like numpy's max.
+__global__ void __launch_bounds__(256)
+    nn_outside_kernel(const double *__restrict__ params, int B, int ndim,
+                      uint32_t log_mask, const double *__restrict__ M,
+                      const double *__restrict__ S, int mapped,
+                      const double *__restrict__ xeqs, int nfx,
+                      const double *__restrict__ yeqs, int nfy,
+                      double *__restrict__ outside) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= B) return;
+  double p[8];
+  for (int d = 0; d < ndim; d++) {
+    if (mapped) {   // the Mapper's float64 output already
+      p[d] = params[(int64_t)j * ndim + d];
+    } else {
+      float y = (float)params[(int64_t)j * ndim + d];   // as nn_map_kernel
+      if (log_mask & (1u << d)) y = (float)log10((double)y);
+      p[d] = ((double)y - M[d]) / S[d];
+    }
+  }
+  auto hull = [&](const double *eq, int nf, const double *q, int nq) {
+    double best = -__builtin_inf();
+    for (int f = 0; f < nf; f++) {
+      const double *e = eq + (int64_t)f * (nq + 1);
+      double v = e[nq];
+      for (int d = 0; d < nq; d++) v = fma(e[d], q[d], v);
+      best = (v > best || v != v) ? v : best;   // a NaN sticks
+    }
+    return best;
+  };
+  const double dx = hull(xeqs, nfx, p, 2);
+  const double dy = hull(yeqs, nfy, p + 2, ndim - 2);
+  double m = (dx > dy || dx != dx) ? dx : dy;
+  m = (m < 0.0) ? 0.0 : m;
+  outside[j] = m * m;
+}
+
 // exp(y) for |y| <= 300 in float64: y = n ln 2 + r, |r| <= 0.347, degree-12
 // Taylor polynomial of exp(r) (truncation 0.347^13 / 13! = 2e-16), scaled by 2^n
 // through the exponent field (n within +-433: never subnormal).  18 fp64
@@ -424,5 +468,20 @@ extern "C" int rvs_template_nn(const double *params, int B, int ndim,
     cur = nxt;
     nxt = t;
   }
+  return 0;
+}
+
+extern "C" int rvs_nn_outside(const double *params, int B, int ndim,
+                              uint32_t log_mask, const double *M,
+                              const double *S, int mapped, const double *xeqs,
+                              int nfx, const double *yeqs, int nfy,
+                              double *outside, void *stream) {
+  if (B < 1 || ndim < 3 || ndim > 8 || nfx < 1 || nfy < 1 || !params ||
+      (!mapped && (!M || !S)) || !xeqs || !yeqs || !outside)
+    return RVS_E_ARG;
+  hipLaunchKernelGGL(nn_outside_kernel, dim3((B + 255) / 256), dim3(256), 0,
+                     rvs_stream(stream), params, B, ndim, log_mask, M, S, mapped,
+                     xeqs, nfx, yeqs, nfy, outside);
+  RVS_LAUNCH_CHECK();
   return 0;
 }

@@ -246,8 +246,7 @@ class TemplateLibrary:
                 _lib.ptr(scratch['a0']), _lib.ptr(scratch['a1']),
                 _lib.ptr(templ), stream)
             _lib.check(rc, 'rvs_template_nn')
-            with torch.cuda.stream(scratch['torch_stream']):
-                outside[:J] = self._nn_outside(params[:J])
+            self._nn_outside(params[:J], out=outside, stream=stream)
         else:
             raise NotImplementedError(self.kind)
 
@@ -282,24 +281,29 @@ class TemplateLibrary:
         outside.copy_(self._nn_outside(params, mapped))
         return templ, outside
 
-    def _nn_outside(self, params, mapped=False):
+    def _nn_outside(self, params, mapped=False, out=None, stream=None):
         """OutsideInterpolator.__call__ (nn/RVSInterpolator.py:63-71) on the
         Mapper-transformed point, as SpecInterpolator.outsideFlag does
         (spec_inter.py:257-272): squared positive distance to the facets of two
-        2-D convex hulls (facet equations built once on the host; evaluated
-        with torch on the device -- a [J,2]x[2,F] product, not a hot kernel)."""
+        convex hulls (facet equations built once on the host, kept on the
+        device; rvs_nn_outside, one launch).  out / stream: caller-owned result
+        rows and HIP stream (the optimiser's rounds)."""
+        J = params.shape[0]
+        if out is None:
+            out = torch.empty(J, dtype=torch.float64, device=self.device)
         if self.nn_hull is None:
-            return torch.zeros(params.shape[0], dtype=torch.float64,
-                               device=self.device)
-        if mapped:
-            p = params.double()
-        else:
-            y = params.to(torch.float32).clone()   # Mapper.forward: float32 input
-            for i in self.log_ids:
-                y[:, i] = torch.log10(y[:, i])
-            p = (y.double() - self.nn_M) / self.nn_S
-        xe = torch.as_tensor(self.nn_hull[0], device=self.device)
-        ye = torch.as_tensor(self.nn_hull[1], device=self.device)
-        dx = (p[:, :2] @ xe[:, :-1].T + xe[:, -1]).max(dim=1).values
-        dy = (p[:, 2:] @ ye[:, :-1].T + ye[:, -1]).max(dim=1).values
-        return torch.clamp(torch.maximum(dx, dy), min=0)**2
+            out[:J] = 0.0
+            return out
+        if getattr(self, '_hull_dev', None) is None:
+            self._hull_dev = tuple(
+                torch.as_tensor(np.ascontiguousarray(h, dtype=np.float64),
+                                device=self.device) for h in self.nn_hull)
+        xe, ye = self._hull_dev
+        p = params if params.dtype == torch.float64 else params.double()
+        rc = _lib.lib().rvs_nn_outside(
+            _lib.ptr(p.contiguous()), J, self.ndim, self.log_mask,
+            _lib.ptr(self.nn_M), _lib.ptr(self.nn_S), 1 if mapped else 0,
+            _lib.ptr(xe), xe.shape[0], _lib.ptr(ye), ye.shape[0], _lib.ptr(out),
+            _lib.stream() if stream is None else stream)
+        _lib.check(rc, 'rvs_nn_outside')
+        return out

@@ -756,6 +756,55 @@ def test_nn_template_vs_reference_golden(gpu):
                                atol=1e-9)
 
 
+def test_nn_outside_kernel_vs_numpy(gpu):
+    """rvs_nn_outside through the C-ABI: OutsideInterpolator.__call__
+    (nn/RVSInterpolator.py:63-71) restated in numpy on the Mapper's point, for
+    points inside, outside and with a NaN coordinate; mapped and unmapped entry."""
+    import ctypes
+    import scipy.spatial
+    from rvspecfit_amd import _lib
+    d = dict(np.load(os.path.join(GOLD, 'nn_case.npz')))
+    pts = np.asarray(d['pts'], dtype=np.float64)
+    xe = np.ascontiguousarray(scipy.spatial.ConvexHull(pts[:, :2]).equations)
+    ye = np.ascontiguousarray(scipy.spatial.ConvexHull(pts[:, 2:]).equations)
+    rng = np.random.default_rng(7)
+    B = 300
+    par = np.column_stack([rng.uniform(2500, 13000, B), rng.uniform(-1, 6, B),
+                           rng.uniform(-3, 1, B), rng.uniform(-0.5, 1.5, B)])
+    par[:len(d['params'])] = d['params']
+    par[B - 1, 2] = np.nan
+    y = par.astype(np.float32)
+    y[:, 0] = np.log10(y[:, 0].astype(np.float64)).astype(np.float32)
+    mp = (y.astype(np.float64) - d['M']) / d['S']
+    dx = (mp[:, :2] @ xe[:, :-1].T + xe[:, -1]).max(axis=1)
+    dy = (mp[:, 2:] @ ye[:, :-1].T + ye[:, -1]).max(axis=1)
+    with np.errstate(invalid='ignore'):
+        want = np.maximum(np.maximum(dx, dy), 0)**2
+    assert np.isnan(want[B - 1]) and (want == 0).sum() > 20 and (want > 0).sum() > 20
+    L = _lib.lib()
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to('cuda')  # noqa: E731
+    out = torch.empty(B, dtype=torch.float64, device='cuda')
+    tM, tS, txe, tye = dev(d['M'].astype(np.float64)), dev(
+        d['S'].astype(np.float64)), dev(xe), dev(ye)
+    for mapped, p in ((0, par), (1, mp)):
+        tp = dev(p)
+        rc = L.rvs_nn_outside(_lib.ptr(tp), B, 4, 1, _lib.ptr(tM), _lib.ptr(tS),
+                              mapped, _lib.ptr(txe), xe.shape[0], _lib.ptr(tye),
+                              ye.shape[0], _lib.ptr(out), _lib.stream())
+        assert rc == 0
+        got = out.cpu().numpy()
+        assert np.isnan(got[B - 1])
+        ok = np.isfinite(want)
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-12, atol=1e-14)
+        np.testing.assert_array_equal(got[ok] == 0, want[ok] == 0)
+    # the golden points: the reference's own values
+    np.testing.assert_allclose(got[:len(d['outside'])], d['outside'], rtol=1e-5,
+                               atol=1e-9)
+    assert L.rvs_nn_outside(_lib.ptr(tp), 0, 4, 1, _lib.ptr(tM), _lib.ptr(tS), 0,
+                            _lib.ptr(txe), xe.shape[0], _lib.ptr(tye),
+                            ye.shape[0], _lib.ptr(out), None) < 0
+
+
 def test_nn_template_desi_size_vs_oracle(gpu):
     """the production shape 4 -> 256 -> 256 -> 256 -> 200 -> 6215 on the f32
     MFMA path against the numpy float32 oracle, 300 parameter vectors (covers

@@ -19,7 +19,9 @@
 // to rounding (tests/test_gpu_parity.py::test_objective_fused).
 #include "template_dev.h"
 
+#ifndef OBJ_NT
 #define OBJ_NT 512
+#endif
 #define OBJ_NW (OBJ_NT / 64)
 #define OBJ_W 32  // warm-up rows of the windowed recurrences (see template.hip)
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   __shared__ double coefs[P + 2];
   __shared__ double Lm[P][P + 1];
   __shared__ double ldv[P];
-  __shared__ double red8[16];
+  __shared__ double red8[2 * OBJ_NW];
   const rvs_objective_arm &T = A.a[blockIdx.y];
   const int j = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -338,13 +340,13 @@ __global__ void __launch_bounds__(OBJ_NT)
     const double nanf = wave_sum(anynan ? 1.0 : 0.0);
     if (lane == 0) {
       red8[w] = mx;
-      red8[8 + w] = nanf;
+      red8[OBJ_NW + w] = nanf;
     }
     __syncthreads();
     double mm = 0, nn = 0;
     for (int i = 0; i < OBJ_NW; i++) {
       mm = fmax(mm, red8[i]);
-      nn += red8[8 + i];
+      nn += red8[OBJ_NW + i];
     }
     outside = FROMT ? outside_in : PL.dist;
     if (outside > 0 && (mm > 1e100 || nn > 0 || isinf(mm)))

@@ -53,8 +53,9 @@ extern "C" {
  *   4: rvs_objective_work_size grew (the cell-search records of the objective's
  *      locate pass live in the caller's scratch)
  *   5: rvs_nn_outside added; rvs_chisq_grid packs left-over velocities from
- *      2000 jobs up by default (pack_min_jobs = 0) */
-#define RVS_ABI_VERSION 5
+ *      2000 jobs up by default (pack_min_jobs = 0)
+ *   6: rvs_nm_objective.nn (MLP evaluators inside rvs_nm_run) */
+#define RVS_ABI_VERSION 6
 int rvs_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -547,6 +548,20 @@ typedef struct rvs_nm_state {
   int32_t *nit, *nfev, *flags, *list1, *list2, *list3, *cases, *pos2, *counts;
   int32_t S, N;
 } rvs_nm_state;
+/* One arm's MLP evaluator for rvs_nm_run: the arguments of rvs_template_nn and
+ * rvs_nn_outside (xeqs == NULL: no hull, outside = 0), and the buffers the
+ * round's template rows / outside flags go to ([>= S, ntp] / [>= S], device). */
+typedef struct rvs_nm_nn_arm {
+  const double *M, *S;
+  const float *const *W, *const *b; /* HOST arrays of nlayer device pointers */
+  const int32_t *dims;              /* HOST [nlayer + 1] */
+  float *act0, *act1;
+  double *templ, *outside;
+  const double *xeqs, *yeqs;
+  int32_t nlayer, nfx, nfy;
+  uint32_t log_mask;
+} rvs_nm_nn_arm;
+
 typedef struct rvs_nm_objective {
   const rvs_objective_arm *arms;
   const double *fixed, *vsini_fixed, *safe, *prior_mean, *prior_isig;
@@ -556,6 +571,11 @@ typedef struct rvs_nm_objective {
   double min_vel, max_vel, max_vsini, badchi;
   int32_t narm, npoly, n, ndim, vsini_col;
   int32_t src[8];
+  /* NULL: regular-grid libraries, rvs_objective_fused.  Else [narm]: MLP
+   * libraries -- a round's objective is rvs_template_nn + rvs_nn_outside per
+   * arm, then rvs_objective_from_template (vel_fit.py:505-737 with
+   * nn/RVSInterpolator.py:36-71 as the evaluator) */
+  const rvs_nm_nn_arm *nn;
 } rvs_nm_objective;
 int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o, double xatol,
                double fatol, int maxiter, int sync_every, int64_t *stats,

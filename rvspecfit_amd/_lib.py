@@ -73,7 +73,7 @@ SIGNATURES = {
 
 _lib = None
 # RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class RvsGpuError(RuntimeError):
@@ -111,6 +111,15 @@ class NmState(ctypes.Structure):
                     ('S', ctypes.c_int32), ('N', ctypes.c_int32)]
 
 
+class NmNNArm(ctypes.Structure):
+    """rvs_nm_nn_arm of include/rvsgpu.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ('M', 'S', 'W', 'b', 'dims', 'act0', 'act1', 'templ', 'outside',
+                 'xeqs', 'yeqs')] + [(k, ctypes.c_int32) for k in
+                                     ('nlayer', 'nfx', 'nfy')] + [
+                    ('log_mask', ctypes.c_uint32)]
+
+
 class NmObjective(ctypes.Structure):
     """rvs_nm_objective of include/rvsgpu.h"""
     _fields_ = [(k, ctypes.c_void_p) for k in
@@ -121,7 +130,7 @@ class NmObjective(ctypes.Structure):
                     ('min_vel', 'max_vel', 'max_vsini', 'badchi')] + [
                     (k, ctypes.c_int32) for k in
                     ('narm', 'npoly', 'n', 'ndim', 'vsini_col')] + [
-                    ('src', ctypes.c_int32 * 8)]
+                    ('src', ctypes.c_int32 * 8), ('nn', ctypes.c_void_p)]
 
 
 class PointArm(ctypes.Structure):

@@ -281,6 +281,17 @@ class TemplateLibrary:
         outside.copy_(self._nn_outside(params, mapped))
         return templ, outside
 
+    def hull_device(self):
+        """(xeqs, yeqs) facet equations of the two convex hulls on the device,
+        or None for a library without an outside check"""
+        if self.nn_hull is None:
+            return None
+        if getattr(self, '_hull_dev', None) is None:
+            self._hull_dev = tuple(
+                torch.as_tensor(np.ascontiguousarray(h, dtype=np.float64),
+                                device=self.device) for h in self.nn_hull)
+        return self._hull_dev
+
     def _nn_outside(self, params, mapped=False, out=None, stream=None):
         """OutsideInterpolator.__call__ (nn/RVSInterpolator.py:63-71) on the
         Mapper-transformed point, as SpecInterpolator.outsideFlag does
@@ -294,11 +305,7 @@ class TemplateLibrary:
         if self.nn_hull is None:
             out[:J] = 0.0
             return out
-        if getattr(self, '_hull_dev', None) is None:
-            self._hull_dev = tuple(
-                torch.as_tensor(np.ascontiguousarray(h, dtype=np.float64),
-                                device=self.device) for h in self.nn_hull)
-        xe, ye = self._hull_dev
+        xe, ye = self.hull_device()
         p = params if params.dtype == torch.float64 else params.double()
         rc = _lib.lib().rvs_nn_outside(
             _lib.ptr(p.contiguous()), J, self.ndim, self.log_mask,

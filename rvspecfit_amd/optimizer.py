@@ -135,6 +135,9 @@ class ProcessObjective:
                                                     self.npoly, self.rbf, 0.0)
             nb = L.rvs_objective_work_size(cap, narm)
             self.oscratch = torch.empty((nb + 7) // 8, **f64)
+        # MLP libraries on every arm: the rounds can run inside rvs_nm_run too
+        self.nn_native = self.from_templ and all(
+            libs[arm.name].kind == 'nn' for arm in batch.arms)
         self.streams = [torch.cuda.Stream(device=dev) for _ in batch.arms]
         self.ev_in = torch.cuda.Event()
         self.ev_out = [torch.cuda.Event() for _ in batch.arms]
@@ -160,6 +163,34 @@ class ProcessObjective:
         o.n, o.ndim, o.vsini_col = self.n, self.ndim, self.vsini_col
         for i in range(8):
             o.src[i] = self.src[i] if i < self.ndim else -1
+        o.nn = None
+        if self.nn_native:
+            narm = len(self.arm_buf)
+            self._nn_arr = (_lib.NmNNArm * narm)()
+            self._nn_keep = []
+            for ia, (arm, b) in enumerate(zip(self.batch.arms, self.arm_buf)):
+                lib = self.libs[arm.name]
+                a = self._nn_arr[ia]
+                nl = len(lib.nn_W)
+                Wp = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in lib.nn_W])
+                bp = (ctypes.c_void_p * nl)(*[x.data_ptr() for x in lib.nn_b])
+                self._nn_keep += [Wp, bp]
+                a.M, a.S = lib.nn_M.data_ptr(), lib.nn_S.data_ptr()
+                a.W = ctypes.cast(Wp, ctypes.c_void_p)
+                a.b = ctypes.cast(bp, ctypes.c_void_p)
+                a.dims = lib.nn_dims.ctypes.data
+                a.act0 = b['nn']['a0'].data_ptr()
+                a.act1 = b['nn']['a1'].data_ptr()
+                a.templ, a.outside = b['templ'].data_ptr(), b['outside'].data_ptr()
+                hull = lib.hull_device()
+                if hull is None:
+                    a.xeqs = a.yeqs = None
+                    a.nfx = a.nfy = 0
+                else:
+                    a.xeqs, a.yeqs = hull[0].data_ptr(), hull[1].data_ptr()
+                    a.nfx, a.nfy = hull[0].shape[0], hull[1].shape[0]
+                a.nlayer, a.log_mask = nl, lib.log_mask
+            o.nn = ctypes.addressof(self._nn_arr)
         return o
 
     def eval(self, list_t, X, J, counts, cidx, F):
@@ -327,7 +358,7 @@ class DeviceNelderMead:
         self.fsim.copy_(fsim)
         fs = self.fsim
         if NATIVE_ROUNDS and isinstance(objective, ProcessObjective) and \
-                objective.fused:
+                (objective.fused or objective.nn_native):
             # the rounds in C (rvs_nm_run): same launches, no interpreter
             m = _lib.NmState()
             for k, t in (('sim', sim), ('fsim', fs), ('X1', self.X1),

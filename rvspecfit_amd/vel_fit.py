@@ -654,15 +654,20 @@ def _process_split(batch, paramDict0, kwargs):
 
 def _rounds_run_in_c(batch, config, resolParams, options=None):
     """the optimiser's rounds of this batch run inside the library (rvs_nm_run:
-    regular-grid libraries, no resolution matrix); only then do two host threads
-    help -- rounds driven from Python (MLP / Delaunay evaluators, resolution
-    matrices) share the interpreter lock: 432 against 586 spectra/s for an NN
-    library split in two"""
+    regular-grid and MLP libraries, no resolution matrix); only then do two host
+    threads help -- rounds driven from Python (Delaunay evaluators, resolution
+    matrices) share the interpreter lock (round 3, NN rounds still in Python:
+    432 against 586 spectra/s split in two)"""
     libs = spec_inter.get_libs(batch.names, config)
     npoly = (options or {}).get('npoly') or 5
-    return engine.can_fuse_objective(batch, libs,
-                                     spec_fit._resols(batch, resolParams),
-                                     npoly=npoly)
+    rs = spec_fit._resols(batch, resolParams)
+    if engine.can_fuse_objective(batch, libs, rs, npoly=npoly):
+        return True
+    # MLP libraries on every arm: rvs_nm_run drives rvs_template_nn +
+    # rvs_objective_from_template itself
+    return all(libs[a.name].kind == 'nn' for a in batch.arms) and \
+        engine.can_fuse_objective(batch, libs, rs, npoly=npoly,
+                                  from_template=True)
 
 
 def process(specdata, paramDict0, fixParam=None, options=None, config=None,

@@ -90,6 +90,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     pairs = [('rvs_point_arm', _lib.PointArm),
              ('rvs_objective_arm', _lib.ObjectiveArm),
              ('rvs_nm_state', _lib.NmState),
+             ('rvs_nm_nn_arm', _lib.NmNNArm),
              ('rvs_nm_objective', _lib.NmObjective)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rvsgpu.h"',
              'int main(void) {']

@@ -54,7 +54,8 @@ extern "C" {
  *      locate pass live in the caller's scratch)
  *   5: rvs_nn_outside added; rvs_chisq_grid packs left-over velocities from
  *      2000 jobs up by default (pack_min_jobs = 0)
- *   6: rvs_nm_objective.nn (MLP evaluators inside rvs_nm_run) */
+ *   6: rvs_nm_objective.nn (MLP evaluators inside rvs_nm_run),
+ *      rvs_template_nn_arms */
 #define RVS_ABI_VERSION 6
 int rvs_abi_version(void);
 
@@ -561,6 +562,14 @@ typedef struct rvs_nm_nn_arm {
   int32_t nlayer, nfx, nfy;
   uint32_t log_mask;
 } rvs_nm_nn_arm;
+
+/* rvs_template_nn + rvs_nn_outside of narm MLPs at the same B rows of `params`
+ * (an optimiser round: a few hundred rows per arm, where three dependent launch
+ * chains cost more than their arithmetic): three launches in all when the
+ * networks have one shape up to the output width, else arm by arm.  Results in
+ * arms[a].templ / .outside; same values as the per-arm calls. */
+int rvs_template_nn_arms(const double *params, int B, int ndim, int narm,
+                         const rvs_nm_nn_arm *arms, void *stream);
 
 typedef struct rvs_nm_objective {
   const rvs_objective_arm *arms;

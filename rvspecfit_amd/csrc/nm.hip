@@ -624,25 +624,15 @@ static int nm_eval(const rvs_nm_objective *o, const int32_t *list,
     // broadening + spline + chi^2 in one kernel (optimizer.py's from_templ path)
     const double *tp[8], *op[8];
     if (o->narm > 8) return RVS_E_ARG;
-    // (the arms one after another on the caller's stream: forked onto side
-    // streams they overlap inside one optimiser instance -- Nelder-Mead 2.53 ->
-    // 2.36 s per 2000 spectra -- but two instances on two host threads, which is
-    // how vel_fit.process runs a large batch, then take 3.5 s instead of 2.4)
+    // (one grouped launch chain for the arms.  Forked onto side streams the
+    // per-arm chains overlapped inside one optimiser instance -- Nelder-Mead
+    // 2.53 -> 2.36 s per 2000 spectra -- but two instances on two host threads,
+    // which is how vel_fit.process runs a large batch, then took 3.5 s for 2.4)
+    rc = rvs_template_nn_arms(o->params, J, o->ndim, o->narm, o->nn, st);
+    if (rc) return rc;
     for (int a = 0; a < o->narm; a++) {
-      const rvs_nm_nn_arm &n = o->nn[a];
-      rc = rvs_template_nn(o->params, J, o->ndim, n.log_mask, n.M, n.S, n.nlayer,
-                           n.W, n.b, n.dims, n.act0, n.act1, n.templ, st);
-      if (rc) return rc;
-      if (n.xeqs) {
-        rc = rvs_nn_outside(o->params, J, o->ndim, n.log_mask, n.M, n.S, 0,
-                            n.xeqs, n.nfx, n.yeqs, n.nfy, n.outside, st);
-        if (rc) return rc;
-      } else if (hipMemsetAsync(n.outside, 0, sizeof(double) * (size_t)J, st) !=
-                 hipSuccess) {
-        return RVS_E_LAUNCH;
-      }
-      tp[a] = n.templ;
-      op[a] = n.outside;
+      tp[a] = o->nn[a].templ;
+      op[a] = o->nn[a].outside;
     }
     rc = rvs_objective_from_template(o->arms, o->narm, o->npoly, tp, op,
                                      o->vsini, o->job_spec, J, o->vel, o->badchi,

@@ -56,15 +56,12 @@ __global__ void __launch_bounds__(256)
 // asks two Delaunay triangulations whether the point is inside first; for a
 // convex hull that is "no facet distance is positive", which the clamp says.)
 // One thread per job; a NaN coordinate gives NaN, like numpy's max.
-__global__ void __launch_bounds__(256)
-    nn_outside_kernel(const double *__restrict__ params, int B, int ndim,
-                      uint32_t log_mask, const double *__restrict__ M,
-                      const double *__restrict__ S, int mapped,
-                      const double *__restrict__ xeqs, int nfx,
-                      const double *__restrict__ yeqs, int nfy,
-                      double *__restrict__ outside) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= B) return;
+__device__ __forceinline__ double
+    nn_outside_point(const double *__restrict__ params, int j, int ndim,
+                     uint32_t log_mask, const double *__restrict__ M,
+                     const double *__restrict__ S, int mapped,
+                     const double *__restrict__ xeqs, int nfx,
+                     const double *__restrict__ yeqs, int nfy) {
   double p[8];
   for (int d = 0; d < ndim; d++) {
     if (mapped) {   // the Mapper's float64 output already
@@ -89,7 +86,19 @@ __global__ void __launch_bounds__(256)
   const double dy = hull(yeqs, nfy, p + 2, ndim - 2);
   double m = (dx > dy || dx != dx) ? dx : dy;
   m = (m < 0.0) ? 0.0 : m;
-  outside[j] = m * m;
+  return m * m;
+}
+__global__ void __launch_bounds__(256)
+    nn_outside_kernel(const double *__restrict__ params, int B, int ndim,
+                      uint32_t log_mask, const double *__restrict__ M,
+                      const double *__restrict__ S, int mapped,
+                      const double *__restrict__ xeqs, int nfx,
+                      const double *__restrict__ yeqs, int nfy,
+                      double *__restrict__ outside) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= B) return;
+  outside[j] = nn_outside_point(params, j, ndim, log_mask, M, S, mapped, xeqs,
+                                nfx, yeqs, nfy);
 }
 
 // exp(y) for |y| <= 300 in float64: y = n ln 2 + r, |r| <= 0.347, degree-12
@@ -123,12 +132,15 @@ __device__ __forceinline__ double exp_clip300(double y) {
 // BIG = false: block tile  32 x 128, waves 1 x 4 of 32 x 32: the 256-wide hidden
 //              layers have 2 column tiles only, and with 128-row tiles 158 blocks
 //              would occupy 158 of the 256 CUs with one wave per SIMD.
+// (bx, nbx: this block's index among the nbx blocks that walk the tiles of ONE
+// matrix product: the whole grid of nn_linear_kernel, one y-slice of the grid of
+// nn_linear_group_kernel)
 template <bool BIG, bool KVEC, bool FINAL>
-__global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
-    nn_linear_kernel(const float *__restrict__ X, const float *__restrict__ W,
-                     const float *__restrict__ bias, int Bn, int K, int N,
-                     float *__restrict__ yout32,
-                     double *__restrict__ yout64) {
+__device__ __forceinline__ void
+    nn_linear_body(const float *__restrict__ X, const float *__restrict__ W,
+                   const float *__restrict__ bias, int Bn, int K, int N,
+                   float *__restrict__ yout32, double *__restrict__ yout64,
+                   const int bx, const int nbx) {
   constexpr int BM = BIG ? NN_BM : 32;
   constexpr int TI = BIG ? 2 : 1, TJ = BIG ? 2 : 1;   // MFMA tiles per wave
   __shared__ __attribute__((aligned(16))) float lds[2][(BM + NN_BN) * NN_LDK];
@@ -142,9 +154,9 @@ __global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
   // not move under any arrangement tried: one tile per block, persistent blocks,
   // next-tile prefetch ahead of the stores, staggered block starts.
   const int ntr = (Bn + BM - 1) / BM, ntc = (N + NN_BN - 1) / NN_BN;
-  int row0 = (blockIdx.x % ntr) * BM, col0 = (blockIdx.x / ntr) * NN_BN;
+  int row0 = (bx % ntr) * BM, col0 = (bx / ntr) * NN_BN;
   bool first = true;
-  for (int tile = blockIdx.x; tile < ntr * ntc; tile += gridDim.x) {
+  for (int tile = bx; tile < ntr * ntc; tile += nbx) {
   f32x16 acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; i++)
@@ -234,8 +246,8 @@ __global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
   // vmcnt counts in order, so loads issued behind the 64 stores would not be
   // usable before every store had been acknowledged.
   const int erow0 = row0, ecol0 = col0;
-  if (tile + (int)gridDim.x < ntr * ntc) {
-    const int nt = tile + gridDim.x;
+  if (tile + nbx < ntr * ntc) {
+    const int nt = tile + nbx;
     row0 = (nt % ntr) * BM;
     col0 = (nt / ntr) * NN_BN;
     fetch(0);
@@ -277,6 +289,34 @@ __global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
   }   // tiles
 }
 
+template <bool BIG, bool KVEC, bool FINAL>
+__global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
+    nn_linear_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                     const float *__restrict__ bias, int Bn, int K, int N,
+                     float *__restrict__ yout32,
+                     double *__restrict__ yout64) {
+  nn_linear_body<BIG, KVEC, FINAL>(X, W, bias, Bn, K, N, yout32, yout64,
+                                   blockIdx.x, gridDim.x);
+}
+
+// The last layers of several arms' MLPs (same input rows, same K; own weights
+// and widths) in ONE launch: grid.y = arm.  An optimiser round evaluates a few
+// hundred rows per arm -- one wave of blocks per launch -- and three dependent
+// launches per objective call were as long as the objective kernel itself.
+#define NN_MAXARM 4
+struct NNLinG {
+  const float *X[NN_MAXARM], *W[NN_MAXARM], *bias[NN_MAXARM];
+  double *y64[NN_MAXARM];
+  int N[NN_MAXARM];
+};
+template <bool BIG, bool KVEC>
+__global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
+    nn_linear_group_kernel(NNLinG G, int Bn, int K) {
+  const int a = blockIdx.y;
+  nn_linear_body<BIG, KVEC, true>(G.X[a], G.W[a], G.bias[a], Bn, K, G.N[a],
+                                  nullptr, G.y64[a], blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------
 // The narrow layers in ONE launch: as separate launches the four hidden layers
 // of the reference's architecture (4 -> 256 -> 256 -> 256 -> 200) were latency
@@ -302,13 +342,12 @@ struct NNHidden {
   int nl;
 };
 
-__global__ void __launch_bounds__(512, 2)
-    nn_hidden_kernel(const double *__restrict__ params, int Bn, int ndim,
-                     uint32_t log_mask, const double *__restrict__ M,
-                     const double *__restrict__ S, NNHidden H,
-                     float *__restrict__ yout) {
-  __shared__ __attribute__((aligned(16))) float act[2][32 * NH_LD];
-  __shared__ float xin[32 * 8];
+__device__ __forceinline__ void
+    nn_hidden_body(const double *__restrict__ params, int Bn, int ndim,
+                   uint32_t log_mask, const double *__restrict__ M,
+                   const double *__restrict__ S, const NNHidden &H,
+                   float *__restrict__ yout, float (*act)[32 * NH_LD],
+                   float *xin) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * 32;
   // Mapper.forward of the block's 32 rows
@@ -398,6 +437,33 @@ __global__ void __launch_bounds__(512, 2)
   }
 }
 
+__global__ void __launch_bounds__(512, 2)
+    nn_hidden_kernel(const double *__restrict__ params, int Bn, int ndim,
+                     uint32_t log_mask, const double *__restrict__ M,
+                     const double *__restrict__ S, NNHidden H,
+                     float *__restrict__ yout) {
+  __shared__ __attribute__((aligned(16))) float act[2][32 * NH_LD];
+  __shared__ float xin[32 * 8];
+  nn_hidden_body(params, Bn, ndim, log_mask, M, S, H, yout, act, xin);
+}
+
+// the hidden stacks of several arms in one launch (grid.y = arm)
+struct NNHiddenG {
+  NNHidden H[NN_MAXARM];
+  const double *M[NN_MAXARM], *S[NN_MAXARM];
+  float *yout[NN_MAXARM];
+  uint32_t log_mask[NN_MAXARM];
+};
+__global__ void __launch_bounds__(512, 2)
+    nn_hidden_group_kernel(const double *__restrict__ params, int Bn, int ndim,
+                           NNHiddenG G) {
+  __shared__ __attribute__((aligned(16))) float act[2][32 * NH_LD];
+  __shared__ float xin[32 * 8];
+  const int a = blockIdx.y;
+  nn_hidden_body(params, Bn, ndim, G.log_mask[a], G.M[a], G.S[a], G.H[a],
+                 G.yout[a], act, xin);
+}
+
 extern "C" int rvs_template_nn(const double *params, int B, int ndim,
                                uint32_t log_mask, const double *M,
                                const double *S, int nlayer,
@@ -483,5 +549,120 @@ extern "C" int rvs_nn_outside(const double *params, int B, int ndim,
                      rvs_stream(stream), params, B, ndim, log_mask, M, S, mapped,
                      xeqs, nfx, yeqs, nfy, outside);
   RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// rvs_template_nn + rvs_nn_outside for the MLPs of several arms at the same
+// rows (an optimiser round): three launches in all when the arms' networks have
+// one shape up to the output width (the reference's architecture per arm),
+// else arm by arm.
+// ---------------------------------------------------------------------------
+struct NNOutG {
+  const double *M[NN_MAXARM], *S[NN_MAXARM], *xeqs[NN_MAXARM], *yeqs[NN_MAXARM];
+  double *out[NN_MAXARM];
+  int nfx[NN_MAXARM], nfy[NN_MAXARM];
+  uint32_t log_mask[NN_MAXARM];
+};
+__global__ void __launch_bounds__(256)
+    nn_outside_group_kernel(const double *__restrict__ params, int B, int ndim,
+                            NNOutG G) {
+  const int a = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= B) return;
+  if (!G.xeqs[a]) {
+    G.out[a][j] = 0.0;
+    return;
+  }
+  G.out[a][j] = nn_outside_point(params, j, ndim, G.log_mask[a], G.M[a], G.S[a],
+                                 0, G.xeqs[a], G.nfx[a], G.yeqs[a], G.nfy[a]);
+}
+
+extern "C" int rvs_template_nn_arms(const double *params, int B, int ndim,
+                                    int narm, const rvs_nm_nn_arm *arms,
+                                    void *stream) {
+  if (B < 1 || narm < 1 || !arms || !params) return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  const rvs_nm_nn_arm &a0 = arms[0];
+  const int nl = a0.nlayer;
+  bool group = narm > 1 && narm <= NN_MAXARM && nl >= 3 && nl - 1 <= NH_MAXL &&
+               ndim <= 8 && a0.dims[0] == ndim;
+  for (int a = 0; group && a < narm; a++) {
+    if (arms[a].nlayer != nl) group = false;
+    for (int l = 0; group && l < nl; l++)   // every width but the output's
+      if (arms[a].dims[l] != a0.dims[l]) group = false;
+  }
+  for (int l = 0; group && l < nl - 1; l++)
+    if (a0.dims[l + 1] > 256 || (l > 0 && (a0.dims[l] & 31))) group = false;
+  if (group && (a0.dims[nl - 1] & 3)) group = false;
+  if (!group) {
+    for (int a = 0; a < narm; a++) {
+      const rvs_nm_nn_arm &n = arms[a];
+      int rc = rvs_template_nn(params, B, ndim, n.log_mask, n.M, n.S, n.nlayer,
+                               n.W, n.b, n.dims, n.act0, n.act1, n.templ, stream);
+      if (rc) return rc;
+      if (n.xeqs) {
+        rc = rvs_nn_outside(params, B, ndim, n.log_mask, n.M, n.S, 0, n.xeqs,
+                            n.nfx, n.yeqs, n.nfy, n.outside, stream);
+        if (rc) return rc;
+      } else if (hipMemsetAsync(n.outside, 0, sizeof(double) * (size_t)B, st) !=
+                 hipSuccess) {
+        return RVS_E_LAUNCH;
+      }
+    }
+    return 0;
+  }
+  NNHiddenG HG;
+  NNLinG LG;
+  NNOutG OG;
+  int nmax = 0;
+  for (int a = 0; a < narm; a++) {
+    const rvs_nm_nn_arm &n = arms[a];
+    HG.H[a].nl = nl - 1;
+    for (int l = 0; l < nl - 1; l++) {
+      HG.H[a].W[l] = n.W[l];
+      HG.H[a].b[l] = n.b[l];
+    }
+    for (int l = 0; l <= nl - 1; l++) HG.H[a].dims[l] = n.dims[l];
+    HG.M[a] = n.M;
+    HG.S[a] = n.S;
+    HG.yout[a] = n.act1;
+    HG.log_mask[a] = n.log_mask;
+    LG.X[a] = n.act1;
+    LG.W[a] = n.W[nl - 1];
+    LG.bias[a] = n.b[nl - 1];
+    LG.y64[a] = n.templ;
+    LG.N[a] = n.dims[nl];
+    if (n.dims[nl] > nmax) nmax = n.dims[nl];
+    OG.M[a] = n.M;
+    OG.S[a] = n.S;
+    OG.xeqs[a] = n.xeqs;
+    OG.yeqs[a] = n.yeqs;
+    OG.out[a] = n.outside;
+    OG.nfx[a] = n.nfx;
+    OG.nfy[a] = n.nfy;
+    OG.log_mask[a] = n.log_mask;
+  }
+  hipLaunchKernelGGL(nn_hidden_group_kernel, dim3((B + 31) / 32, narm), dim3(512),
+                     0, st, params, B, ndim, HG);
+  RVS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nn_outside_group_kernel, dim3((B + 255) / 256, narm),
+                     dim3(256), 0, st, params, B, ndim, OG);
+  RVS_LAUNCH_CHECK();
+  {
+    const int K = a0.dims[nl - 1];
+    const int ntc = (nmax + NN_BN - 1) / NN_BN;
+    const bool big = (int64_t)ntc * ((B + NN_BM - 1) / NN_BM) >= 1024;
+    const int64_t ntile = (int64_t)ntc * (big ? (B + NN_BM - 1) / NN_BM
+                                              : (B + 31) / 32);
+    const dim3 grid((unsigned)(ntile < 1024 ? ntile : 1024), narm);
+    if (big)
+      hipLaunchKernelGGL((nn_linear_group_kernel<true, true>), grid, dim3(256), 0,
+                         st, LG, B, K);
+    else
+      hipLaunchKernelGGL((nn_linear_group_kernel<false, true>), grid, dim3(256),
+                         0, st, LG, B, K);
+    RVS_LAUNCH_CHECK();
+  }
   return 0;
 }

@@ -222,7 +222,15 @@ class ProcessObjective:
             self.calls += 1
             self.jobs += J
             return
-        if self.from_templ:
+        if self.from_templ and self.nn_native:
+            # MLP libraries on every arm: one grouped launch chain
+            if getattr(self, '_nn_arr', None) is None:
+                self.native_desc()
+            rc = L.rvs_template_nn_arms(_p(self.params), J, self.ndim,
+                                        len(self.arm_buf),
+                                        ctypes.addressof(self._nn_arr), st)
+            _lib.check(rc, 'rvs_template_nn_arms')
+        elif self.from_templ:
             main = torch.cuda.current_stream()
             self.ev_in.record(main)
             for arm, b, side, ev in zip(self.batch.arms, self.arm_buf,
@@ -237,6 +245,7 @@ class ProcessObjective:
                 ev.record(side)
             for ev in self.ev_out:
                 main.wait_event(ev)
+        if self.from_templ:
             narm = len(self.arm_buf)
             tp = (ctypes.c_void_p * narm)(*[b['templ'].data_ptr()
                                             for b in self.arm_buf])

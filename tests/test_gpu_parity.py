@@ -827,6 +827,68 @@ def test_nn_template_desi_size_vs_oracle(gpu):
     np.testing.assert_allclose(templ.cpu().numpy(), ref, rtol=5e-6)
 
 
+@pytest.mark.parametrize('B', [7, 300, 700])
+@pytest.mark.parametrize('same_shape', [True, False])
+def test_nn_template_arms_equals_per_arm_calls(gpu, B, same_shape):
+    """rvs_template_nn_arms (the arms' MLPs in grouped launches, grid.y = arm)
+    gives the rows and outside flags of the per-arm rvs_template_nn /
+    rvs_nn_outside calls BIT FOR BIT; arms whose networks differ in shape fall
+    back to the per-arm calls inside the entry point."""
+    import ctypes
+    import scipy.spatial
+    from rvspecfit_amd import _lib
+    rng = np.random.RandomState(5)
+    widths = [6215, 5303, 6449]
+    libs = []
+    for a, w in enumerate(widths):
+        hid = (256, 256, 256, 200) if (same_shape or a != 1) else (256, 128, 200)
+        dims = np.array((4, ) + hid + (w, ), dtype=np.int32)
+        d = dict(dims=dims, M=np.array([3.7, 2.5, -1., 0.5]) + 0.01 * a,
+                 S=np.array([0.15, 1.4, 0.6, 0.3]))
+        for i in range(len(dims) - 1):
+            k, n = dims[i], dims[i + 1]
+            d['W%d' % i] = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(
+                np.float32)
+            d['b%d' % i] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        if a != 2:   # the third arm has no hull: outside = 0
+            d['pts'] = rng.uniform(-1.5, 1.5, (60, 4))
+        libs.append(_nn_lib(d, np.exp(np.linspace(8.2, 8.7, w))))
+    P = np.array([rng.uniform(3500, 9000, B), rng.uniform(0, 5, B),
+                  rng.uniform(-2, 0, B), rng.uniform(0, 1, B)]).T
+    tp = torch.as_tensor(np.ascontiguousarray(P)).to('cuda')
+    want = [lib.eval_batch(tp) for lib in libs]
+    arr = (_lib.NmNNArm * 3)()
+    keep, got = [], []
+    for a, lib in enumerate(libs):
+        nl = len(lib.nn_W)
+        Wp = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in lib.nn_W])
+        bp = (ctypes.c_void_p * nl)(*[x.data_ptr() for x in lib.nn_b])
+        a0 = torch.empty((B, lib.nn_width()), dtype=torch.float32, device='cuda')
+        a1 = torch.empty_like(a0)
+        t = torch.empty((B, lib.ntp), dtype=torch.float64, device='cuda')
+        o = torch.full((B, ), -1.0, dtype=torch.float64, device='cuda')
+        keep += [Wp, bp, a0, a1]
+        got.append((t, o))
+        x = arr[a]
+        x.M, x.S = lib.nn_M.data_ptr(), lib.nn_S.data_ptr()
+        x.W, x.b = ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(bp, ctypes.c_void_p)
+        x.dims = lib.nn_dims.ctypes.data
+        x.act0, x.act1 = a0.data_ptr(), a1.data_ptr()
+        x.templ, x.outside = t.data_ptr(), o.data_ptr()
+        hull = lib.hull_device()
+        if hull is not None:
+            x.xeqs, x.yeqs = hull[0].data_ptr(), hull[1].data_ptr()
+            x.nfx, x.nfy = hull[0].shape[0], hull[1].shape[0]
+        x.nlayer, x.log_mask = nl, lib.log_mask
+    rc = _lib.lib().rvs_template_nn_arms(_lib.ptr(tp), B, 4, 3,
+                                         ctypes.addressof(arr), _lib.stream())
+    assert rc == 0
+    for (t, o), (wt, wo) in zip(got, want):
+        assert torch.equal(t, wt)
+        assert torch.equal(o, wo)
+    assert float(got[2][1].abs().max()) == 0.0 and float(got[0][1].max()) > 0
+
+
 @pytest.mark.parametrize('dims', [
     (4, 96, 128, 50, 777),        # fused narrow layers, partial column tiles
     (4, 64, 333),                 # one hidden layer

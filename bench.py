@@ -816,7 +816,7 @@ def main():
     if args.process > 0:
         proc = run_process_addon(batch, rec, arms, args, dev)
     desi = None
-    if args.desi_file > 0 and rank == 0 and EVALUATOR == 'polylinear' \
+    if args.desi_file > 0 and rank == 0 \
             and args.workload == 'desi':
         desi = run_desi_addon(arms, args, dev, dicts)
 

@@ -26,6 +26,9 @@ run --grid 40,11,8,5 --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --pro
 # the optimiser stage at full batch size, and on the NN evaluator
 run --spectra 10000 --steps 1 --warmup 1 --no-cpu-baseline --process 10000
 run --evaluator nn --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000
+run --evaluator nn --spectra 10000 --steps 1 --warmup 1 --no-cpu-baseline --process 10000
+# the DESI driver on MLP libraries (random weights: the fits themselves mean nothing)
+run --evaluator nn --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --desi-nfiles 16
 python - <<PY
 import json
 for l in open("$out"):

@@ -1637,6 +1637,50 @@ def test_resolution_matrix_grid_nd11(cases, config, gold_libs, gold_config):
     assert int(st.sum().item()) == 0
 
 
+@pytest.mark.parametrize('npix,npoly', [(6, 2), (11, 3), (12, 5), (13, 5),
+                                        (25, 10), (330, 10), (330, 15)])
+def test_resolution_grid_pipe_kernel_vs_point_kernel(cases, config, npix, npoly):
+    """11-diagonal matrices: the software-pipelined register-window grid kernel
+    (whole windows of 12 pixels + a tail, rows one pixel ahead, gathers six) against
+    the point kernel, which applies a band of any width from LDS -- arms shorter
+    than / equal to / just above one window, several windows, a velocity count that
+    is no multiple of 64."""
+    from rvspecfit_amd import spec_fit, engine
+    sd0 = _sds(cases, 'c1')[0]
+    i0 = len(sd0.lam) // 4
+    i0 = min(i0, len(sd0.lam) - npix)
+    lam = sd0.lam[i0:i0 + npix].copy()
+    assert len(lam) == npix
+    import scipy.sparse
+    offs = np.arange(-5, 6)
+    rng = np.random.default_rng(npix)
+    band = np.exp(-0.5 * (offs[:, None] / 1.7)**2) * (
+        1 + 0.05 * rng.standard_normal((11, npix)))
+    R = spec_fit.ResolMatrix(scipy.sparse.dia_matrix((band, offs),
+                                                     shape=(npix, npix)))
+    taps, nd = engine.resol_taps([R.mat], len(lam))
+    assert nd == 11
+    sds = [spec_fit.SpecData(sd0.name, lam, sd0.spec[i0:i0 + npix].copy(),
+                             sd0.espec[i0:i0 + npix].copy(), resolution=R)]
+    b, _ = spec_fit.as_batch(sds)
+    p = np.array(cases['c1/truth'], dtype=np.float64)
+    vg = np.linspace(-310.0, 295.0, 70)
+    opt = dict(npoly=npoly)
+    g, st, _ = spec_fit.chisq_grid_jobs(
+        b, torch.as_tensor(vg).to('cuda'),
+        torch.as_tensor(p[None, None, :]).to('cuda'),
+        torch.as_tensor([25.], dtype=torch.float64).to('cuda'), opt, config)
+    assert int(st.sum().item()) == 0
+    idx = torch.zeros(len(vg), dtype=torch.long, device='cuda')
+    c, _ = spec_fit.chisq_jobs(
+        b, idx, torch.as_tensor(vg).to('cuda'),
+        torch.as_tensor(np.tile(p, (len(vg), 1))).to('cuda'),
+        torch.full((len(vg), ), 25., dtype=torch.float64, device='cuda'), opt,
+        config)
+    np.testing.assert_allclose(g.cpu().numpy().reshape(-1), c.cpu().numpy(),
+                               rtol=1e-9, atol=1e-7)
+
+
 def test_pipeline_process_batch(cases, config):
     """fit_batch -> process_batch (the DESI flow of desi_fit.py:288-309) on a
     2-spectrum batch: one fixed-size record per spectrum, consistent with the

@@ -632,6 +632,53 @@ def test_chisq_grid_every_npoly_vs_objective_kernel(cases, config):
         engine.CG_PACK_MIN_JOBS = keep
 
 
+def test_chisq_grid_linear_template_grid(cases, gpu):
+    """A template library on a LINEAR wavelength grid (log_step False: the knot
+    index is (int)((x - x0)/step), spliner.c:92-96): the velocity-grid kernel's
+    linear-knot loop instance, full and packed waves, against the oracle's
+    get_chisq and against the optimiser's one-kernel objective."""
+    from rvspecfit_amd import spec_fit, spec_inter, engine
+    from rvspecfit_amd.library import TemplateLibrary
+    d = gold_lib_dict('gold_b')
+    lam_log = np.asarray(d['lam'], dtype=np.float64)
+    d['lam'] = np.linspace(lam_log[0], lam_log[-1], len(lam_log))
+    d['log_step'] = np.array(False)
+    lib = TemplateLibrary('gold_b', d)
+    assert not lib.log_step
+    spec_inter.register_library(lib, 'golden-lin://')
+    cfg = dict(GOLD_CONFIG, template_lib='golden-lin://')
+    sd = [x for x in _sds(cases, 'c1') if x.name == 'gold_b'][:1]
+    assert sd
+    b, _ = spec_fit.as_batch(sd)
+    p = np.array(cases['c1/truth'], dtype=np.float64)
+    vg = np.linspace(-310.0, 295.0, 70)
+    keep = engine.CG_PACK_MIN_JOBS
+    engine.CG_PACK_MIN_JOBS = 1
+    try:
+        g, st, _ = spec_fit.chisq_grid_jobs(
+            b, torch.as_tensor(vg).to('cuda'),
+            torch.as_tensor(p[None, None, :]).to('cuda'), None, dict(npoly=10),
+            cfg)
+    finally:
+        engine.CG_PACK_MIN_JOBS = keep
+    assert int(st.sum().item()) == 0
+    g = g.cpu().numpy().reshape(-1)
+    idx = torch.zeros(len(vg), dtype=torch.long, device='cuda')
+    c, _ = spec_fit.chisq_jobs(
+        b, idx, torch.as_tensor(vg).to('cuda'),
+        torch.as_tensor(np.tile(p, (len(vg), 1))).to('cuda'), None,
+        dict(npoly=10), cfg)
+    np.testing.assert_allclose(g, c.cpu().numpy(), rtol=1e-9, atol=1e-7)
+    olib = {'gold_b': orc.Library(d)}
+    osd = [orc.SpecData(x.name, x.lam, x.spec, x.espec, badmask=x.badmask)
+           for x in sd]
+    for i in (0, 33, 69):
+        want = orc.get_chisq(osd, float(vg[i]), tuple(p), None,
+                             options=dict(npoly=10), config=dict(GOLD_CONFIG),
+                             libs=olib)
+        assert abs(g[i] - want) < 1e-8 * max(abs(want), 1e3), (i, g[i], want)
+
+
 @pytest.mark.parametrize('npix', [2, 3, 4, 5, 8])
 def test_chisq_grid_short_arms(cases, config, npix):
     """The grid kernel's pixel loop runs one pixel ahead of itself (row k+1,

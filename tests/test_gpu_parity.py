@@ -632,21 +632,33 @@ def test_chisq_grid_every_npoly_vs_objective_kernel(cases, config):
         engine.CG_PACK_MIN_JOBS = keep
 
 
+_lin_cfg = {}
+
+
+def _linear_grid_config():
+    """gold_b on a LINEAR wavelength grid, registered under its own template_lib"""
+    if not _lin_cfg:
+        from rvspecfit_amd import spec_inter
+        from rvspecfit_amd.library import TemplateLibrary
+        d = gold_lib_dict('gold_b')
+        lam_log = np.asarray(d['lam'], dtype=np.float64)
+        d['lam'] = np.linspace(lam_log[0], lam_log[-1], len(lam_log))
+        d['log_step'] = np.array(False)
+        lib = TemplateLibrary('gold_b', d)
+        assert not lib.log_step
+        spec_inter.register_library(lib, 'golden-lin://')
+        _lin_cfg['cfg'] = dict(GOLD_CONFIG, template_lib='golden-lin://')
+        _lin_cfg['d'] = d
+    return _lin_cfg['cfg'], _lin_cfg['d']
+
+
 def test_chisq_grid_linear_template_grid(cases, gpu):
     """A template library on a LINEAR wavelength grid (log_step False: the knot
     index is (int)((x - x0)/step), spliner.c:92-96): the velocity-grid kernel's
     linear-knot loop instance, full and packed waves, against the oracle's
     get_chisq and against the optimiser's one-kernel objective."""
-    from rvspecfit_amd import spec_fit, spec_inter, engine
-    from rvspecfit_amd.library import TemplateLibrary
-    d = gold_lib_dict('gold_b')
-    lam_log = np.asarray(d['lam'], dtype=np.float64)
-    d['lam'] = np.linspace(lam_log[0], lam_log[-1], len(lam_log))
-    d['log_step'] = np.array(False)
-    lib = TemplateLibrary('gold_b', d)
-    assert not lib.log_step
-    spec_inter.register_library(lib, 'golden-lin://')
-    cfg = dict(GOLD_CONFIG, template_lib='golden-lin://')
+    from rvspecfit_amd import spec_fit, engine
+    cfg, d = _linear_grid_config()
     sd = [x for x in _sds(cases, 'c1') if x.name == 'gold_b'][:1]
     assert sd
     b, _ = spec_fit.as_batch(sd)
@@ -1684,16 +1696,21 @@ def test_resolution_matrix_grid_nd11(cases, config, gold_libs, gold_config):
     assert int(st.sum().item()) == 0
 
 
+@pytest.mark.parametrize('linear', [False, True])
 @pytest.mark.parametrize('npix,npoly', [(6, 2), (11, 3), (12, 5), (13, 5),
                                         (25, 10), (330, 10), (330, 15)])
-def test_resolution_grid_pipe_kernel_vs_point_kernel(cases, config, npix, npoly):
+def test_resolution_grid_pipe_kernel_vs_point_kernel(cases, config, npix, npoly,
+                                                     linear):
     """11-diagonal matrices: the software-pipelined register-window grid kernel
     (whole windows of 12 pixels + a tail, rows one pixel ahead, gathers six) against
     the point kernel, which applies a band of any width from LDS -- arms shorter
     than / equal to / just above one window, several windows, a velocity count that
     is no multiple of 64."""
     from rvspecfit_amd import spec_fit, engine
-    sd0 = _sds(cases, 'c1')[0]
+    sd0 = [x for x in _sds(cases, 'c1') if x.name == 'gold_b'][0]
+    rot = 25.
+    if linear:   # (no rotation: convolve_vsini needs a log-spaced grid)
+        config, rot = _linear_grid_config()[0], None
     i0 = len(sd0.lam) // 4
     i0 = min(i0, len(sd0.lam) - npix)
     lam = sd0.lam[i0:i0 + npix].copy()
@@ -1716,14 +1733,15 @@ def test_resolution_grid_pipe_kernel_vs_point_kernel(cases, config, npix, npoly)
     g, st, _ = spec_fit.chisq_grid_jobs(
         b, torch.as_tensor(vg).to('cuda'),
         torch.as_tensor(p[None, None, :]).to('cuda'),
-        torch.as_tensor([25.], dtype=torch.float64).to('cuda'), opt, config)
+        None if rot is None else torch.as_tensor(
+            [rot], dtype=torch.float64).to('cuda'), opt, config)
     assert int(st.sum().item()) == 0
     idx = torch.zeros(len(vg), dtype=torch.long, device='cuda')
     c, _ = spec_fit.chisq_jobs(
         b, idx, torch.as_tensor(vg).to('cuda'),
         torch.as_tensor(np.tile(p, (len(vg), 1))).to('cuda'),
-        torch.full((len(vg), ), 25., dtype=torch.float64, device='cuda'), opt,
-        config)
+        None if rot is None else torch.full(
+            (len(vg), ), rot, dtype=torch.float64, device='cuda'), opt, config)
     np.testing.assert_allclose(g.cpu().numpy().reshape(-1), c.cpu().numpy(),
                                rtol=1e-9, atol=1e-7)
 

@@ -886,7 +886,7 @@ def test_nn_template_desi_size_vs_oracle(gpu):
     np.testing.assert_allclose(templ.cpu().numpy(), ref, rtol=5e-6)
 
 
-@pytest.mark.parametrize('B', [7, 300, 700])
+@pytest.mark.parametrize('B', [7, 300, 700, 3000])
 @pytest.mark.parametrize('same_shape', [True, False])
 def test_nn_template_arms_equals_per_arm_calls(gpu, B, same_shape):
     """rvs_template_nn_arms (the arms' MLPs in grouped launches, grid.y = arm)

@@ -135,6 +135,27 @@ struct CgRow {
     return d;
   }
 };
+// Structured buffer loads (buffer_load ... idxen): the hardware forms
+// base + index * stride from a 32-bit record index, so the per-lane gather of
+// knot `pos` (8-B records) and of spline record `pos` (32-B records) needs no
+// address arithmetic in the pixel loop.  (The intrinsics have no clang builtin
+// in ROCm 7.2; binding the LLVM name is how composable_kernel reaches them.)
+typedef int cg_v4i __attribute__((ext_vector_type(4)));
+typedef int cg_v2i __attribute__((ext_vector_type(2)));
+__device__ cg_v4i cg_sbl128(cg_v4i rsrc, int vindex, int voffset, int soffset,
+                            int aux) __asm("llvm.amdgcn.struct.buffer.load.v4i32");
+__device__ cg_v2i cg_sbl64(cg_v4i rsrc, int vindex, int voffset, int soffset,
+                           int aux) __asm("llvm.amdgcn.struct.buffer.load.v2i32");
+__device__ __forceinline__ cg_v4i cg_rsrc(const void *p, unsigned stride,
+                                          unsigned nrec) {
+  const unsigned long long a = (unsigned long long)p;
+  cg_v4i r;
+  r.x = (int)(unsigned)a;
+  r.y = (int)(((unsigned)(a >> 32) & 0xffffu) | (stride << 16));
+  r.z = (int)nrec;
+  r.w = 0x00020000;
+  return r;
+}
 // f(integral_constant<int, I>) for I = I0 .. N-1, unrolled at compile time
 template <int I, int N, class F>
 __device__ __forceinline__ void cg_static_for(F &&f) {
@@ -318,13 +339,30 @@ __device__ __forceinline__ void
       asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(pos), "s"(ntp - 2));
       return r;
     };
-    // 32-bit byte offsets from the wave-uniform bases (full waves: the record
-    // base of the job's template is uniform too)
-    auto knot_at = [&](int p) {
+    // full waves: the knot / record gathers as structured buffer loads (the
+    // record index is the knot index: no shifts; in round 3's first half, with the
+    // loop still waiting for its loads, the same change measured 2 % SLOWER --
+    // issue bound, the two instructions saved per pixel are 1.1 %: cg_bench 30.30
+    // -> 29.96 ms); packed waves (a template per lane): 32-bit byte offsets
+    const cg_v4i rk = cg_rsrc(knots, 8, (unsigned)ntp);
+    const cg_v4i rc = cg_rsrc(cf, 32, (unsigned)ntp);
+    auto knot_at = [&](int p) -> double {
+      if (!TAIL) {
+        const cg_v2i v = cg_sbl64(rk, p, 0, 0, 0);
+        return __hiloint2double(v.y, v.x);
+      }
       return *reinterpret_cast<const double *>(
           reinterpret_cast<const char *>(knots) + ((uint32_t)p << 3));
     };
-    auto rec_at = [&](int p) {
+    auto rec_at = [&](int p) -> double4 {
+      if (!TAIL) {
+        const cg_v4i lo = cg_sbl128(rc, p, 0, 0, 0);
+        const cg_v4i hi = cg_sbl128(rc, p, 16, 0, 0);
+        return make_double4(__hiloint2double(lo.y, lo.x),
+                            __hiloint2double(lo.w, lo.z),
+                            __hiloint2double(hi.y, hi.x),
+                            __hiloint2double(hi.w, hi.z));
+      }
       return *reinterpret_cast<const double4 *>(
           reinterpret_cast<const char *>(cf) + ((uint32_t)p << 5));
     };
@@ -757,6 +795,9 @@ __global__ void __launch_bounds__(64)
       asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(pos), "s"(ntp - 2));
       return r;
     };
+    // (32-bit byte offsets from the wave-uniform bases; the structured buffer
+    // loads of chisq_grid_kernel measured slower here -- two waves per SIMD:
+    // 146 against 140 ms per step)
     auto knot_at = [&](int p) {
       return *reinterpret_cast<const double *>(
           reinterpret_cast<const char *>(knots) + ((uint32_t)p << 3));

@@ -453,7 +453,10 @@ __host__ inline int64_t xc_nblocks(int T, int B, int G) {
 __host__ inline int xc_group(int T, int nfft) {
   const int64_t per_t = 2ll * ((nfft >> 1) + 1) * 16;
   if (per_t * T <= (16ll << 20)) return 0;
-  int G = (int)((2ll << 20) / per_t);
+#ifndef XC_GROUP_BYTES
+#define XC_GROUP_BYTES (2ll << 20)
+#endif
+  int G = (int)(XC_GROUP_BYTES / per_t);
   const int ntx = (T + 7) >> 3;
   if (G < 1) G = 1;
   if (G > ntx) G = ntx;

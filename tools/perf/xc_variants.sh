@@ -7,7 +7,7 @@ for v in ${XC_VARIANTS:--DXC_BASE -DXC_TW_DERIVE -DXC_BASE -DXC_TW_DERIVE}; do
   hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 $v -c rvspecfit_amd/csrc/ccf_fft.hip -o /tmp/xc_v.o 2>/dev/null
   hipcc --offload-arch=gfx950 -shared -fPIC -o rvspecfit_amd/librvsgpu.so /tmp/xc_v.o $(ls rvspecfit_amd/csrc/_build/*.o | grep -v /ccf_fft.o)
   python -m pytest tests -x -q -m gpu -k "ccf or xcorr" 2>&1 | tail -1
-  python bench.py --steps 5 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py ${XC_BENCH_ARGS:---steps 5} --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['kernels']['ccf_xcorr'])"
 done

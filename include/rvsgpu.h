@@ -471,7 +471,9 @@ int rvs_template_nn(const double *params, int B, int ndim, uint32_t log_mask,
  * the first two / the remaining mapped coordinates of the training points
  * (built once by the caller); params, M, S, log_mask as rvs_template_nn;
  * mapped != 0: params ARE the Mapper's float64 output (M, S, log_mask unused).
- * A NaN parameter gives NaN (the arm is then skipped, spec_fit.py:888-893). */
+ * A NaN parameter gives NaN (the arm is then skipped, spec_fit.py:888-893).
+ * nfx == nfy == 0: a library without hulls (no outside check) -- outside[] is
+ * zeroed on `stream`, nothing else is read. */
 int rvs_nn_outside(const double *params, int B, int ndim, uint32_t log_mask,
                    const double *M, const double *S, int mapped,
                    const double *xeqs, int nfx, const double *yeqs, int nfy,

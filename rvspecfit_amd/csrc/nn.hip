@@ -542,6 +542,13 @@ extern "C" int rvs_nn_outside(const double *params, int B, int ndim,
                               const double *S, int mapped, const double *xeqs,
                               int nfx, const double *yeqs, int nfy,
                               double *outside, void *stream) {
+  if (B >= 1 && outside && nfx == 0 && nfy == 0) {
+    // a library without hulls has no outside check: zeros, on the caller's stream
+    return hipMemsetAsync(outside, 0, sizeof(double) * (size_t)B,
+                          rvs_stream(stream)) == hipSuccess
+               ? 0
+               : RVS_E_LAUNCH;
+  }
   if (B < 1 || ndim < 3 || ndim > 8 || nfx < 1 || nfy < 1 || !params ||
       (!mapped && (!M || !S)) || !xeqs || !yeqs || !outside)
     return RVS_E_ARG;

@@ -17,14 +17,20 @@
 // No spline record ever goes to HBM.  Each phase repeats the arithmetic of the
 // stand-alone kernel it replaces (template.hip, chisq.hip), so the values agree
 // to rounding (tests/test_gpu_parity.py::test_objective_fused).
-#include "template_dev.h"
+#include "objective_dev.h"
+#include <stdlib.h>
 
 #ifndef OBJ_NT
 #define OBJ_NT 512
 #endif
 #define OBJ_NW (OBJ_NT / 64)
+#ifdef OBJ_EXP_ONEROW   // (measurement only: every vertex load hits row 0's lines)
+#define OBJ_VTX(u) 0
+#else
+#define OBJ_VTX(u) min(u, nv - 1)
+#endif
+#define OBJ_CHMAX ((8192 + OBJ_NT - 1) / OBJ_NT)  // rows of a thread's Thomas chunk
 #define OBJ_W 32  // warm-up rows of the windowed recurrences (see template.hip)
-#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 
 #ifdef RVS_OBJ_TIMING
 // debug build only (tools/perf/obj_phases.sh): clock budget of the phases
@@ -47,51 +53,6 @@ extern "C" int rvs_dbg_read(unsigned long long *out) {
 #else
 #define OBJ_T(i)
 #endif
-
-struct ObjArms {
-  rvs_objective_arm a[RVS_MAX_ARMS];
-  int n;
-};
-
-// FROMT: the unbroadened template of every (job, arm) comes from HBM -- a row
-// of an evaluator that is no grid gather (the MLP of rvs_template_nn) -- with
-// its outside flag; everything behind the template (FIR, spline solve, chi^2)
-// is the same code.
-struct ObjTempl {
-  const double *templ[RVS_MAX_ARMS];    // [J, ntp] per arm
-  const double *outside[RVS_MAX_ARMS];  // [J] per arm
-};
-
-// The cell search of a (job, arm) -- log10 mapping, one binary search per
-// dimension, 2^ndim idgrid look-ups, weights; outside the grid the brute-force
-// nearest neighbour -- is a chain of dependent loads that a few threads walk while
-// the other 500 of an objective block wait: 7.7 % of the block's time on the one
-// block a CU can hold.  objective_locate_kernel runs it ahead for all (job, arm)
-// pairs of a launch with one wave each (thousands of them resident at once, their
-// latencies overlapping) and leaves a record the objective block fetches with one
-// coalesced load.  Same poly_locate code: the same ids, weights and distances.
-#define OBJ_LOC_NV 16                      // grids of up to 4 dimensions
-#define OBJ_LOC_REC (2 * OBJ_LOC_NV + 2)   // doubles: w[16], id[16], dist, {mode, nearest}
-
-__device__ __forceinline__ GridDesc obj_grid_desc(const rvs_objective_arm &T) {
-  GridDesc G;
-  const int nd = T.ndim;
-  G.ndim = nd;
-  G.log_mask = T.log_mask;
-  int off = 0;
-  for (int d = 0; d < nd; d++) {
-    G.lens[d] = T.lens[d];
-    G.uoff[d] = off;
-    off += T.lens[d];
-    G.ptp[d] = T.ptp[d];
-  }
-  int64_t st = 1;
-  for (int d = nd - 1; d >= 0; d--) {
-    G.gstride[d] = st;
-    st *= T.lens[d];
-  }
-  return G;
-}
 
 // (256 threads: the cell search itself needs 20 of them, but a point outside the
 // grid -- an optimiser's simplex is there every few steps -- scans all ngrid
@@ -165,9 +126,11 @@ __global__ void __launch_bounds__(OBJ_NT)
       }
       __syncthreads();
     } else {     // grids of more than 4 dimensions: in the block
+#ifndef OBJ_EXP_NOLOC
       const GridDesc G = obj_grid_desc(T);
       poly_locate<OBJ_NT>(PL, G, params + (int64_t)j * nd, T.idgrid, T.uvecs,
                           T.vecs_s, T.ngrid);
+#endif
     }
     mode = PL.mode;
   } else {
@@ -190,7 +153,7 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
     for (int u = 0; u < 16; u++)
       rn[u] = *reinterpret_cast<const f4u *>(
-          T.dats + PL.id[min(u, nv - 1)] * N + 4 * tid);
+          T.dats + PL.id[OBJ_VTX(u)] * N + 4 * tid);
   }
   int st_extra = 0;
   bool copy = true;
@@ -201,7 +164,10 @@ __global__ void __launch_bounds__(OBJ_NT)
     copy = !(vs > 0) || (R < 1e-9);
     if (!copy) {
       kmax = (int)ceil(R + 1);
-      if (kmax >= N) {
+      // (the kernel's primitives are staged in bufB as two runs of kmax + 3
+      // doubles: a kernel wider than that is refused like one wider than the
+      // template)
+      if (kmax >= N || 2 * (kmax + 3) > N) {
         st_extra = RVS_ST_NONFINITE;
         copy = true;
       }
@@ -275,7 +241,7 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
           for (int u = 0; u < 16; u++)
             rn[u] = *reinterpret_cast<const f4u *>(
-                T.dats + PL.id[min(u, nv - 1)] * N + kn);
+                T.dats + PL.id[OBJ_VTX(u)] * N + kn);
         }
         double a4[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -451,9 +417,9 @@ __global__ void __launch_bounds__(OBJ_NT)
   // grid tend to 2 - sqrt 3).  Against warming every chunk up over 32 extra
   // rows this reads each row once instead of 3.5 times (the phase is bound by
   // LDS bandwidth) and takes two barriers fewer.
-  const int CH = max(12, (m + OBJ_NT - 1) / OBJ_NT);  // <= 16 (ntp <= 8192)
+  const int CH = max(12, (m + OBJ_NT - 1) / OBJ_NT);  // <= OBJ_CHMAX (ntp <= 8192)
   const int a0 = min(m, tid * CH), a1 = min(m, a0 + CH);
-  double loc[16], pr[16];
+  double loc[OBJ_CHMAX], pr[OBJ_CHMAX];
   // value entering a chunk from `dir` = -1 (lower threads) or +1 (upper): the
   // three nearest chunks' coefficients through wave shuffles, across a wave
   // boundary through red[] (static LDS, free until the reductions)
@@ -487,7 +453,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   {
     double d = 0, pb = 1;
 #pragma unroll
-    for (int q = 0; q < 16; q++)
+    for (int q = 0; q < OBJ_CHMAX; q++)
       if (a0 + q < a1) {
         const double ei = ec[a0 + q];
         d = dp[a0 + q] - ei * d;
@@ -506,13 +472,13 @@ __global__ void __launch_bounds__(OBJ_NT)
       if (i0 + c * OBJ_NT < m) ec[i0 + c * OBJ_NT] = fc[c];
   }
 #pragma unroll
-  for (int q = 0; q < 16; q++)
+  for (int q = 0; q < OBJ_CHMAX; q++)
     if (a0 + q < a1) loc[q] = loc[q] + pr[q] * d_in;  // d of the forward sweep
   __syncthreads();
   {
     double z = 0, pb = 1;
 #pragma unroll
-    for (int q = 15; q >= 0; q--)
+    for (int q = OBJ_CHMAX - 1; q >= 0; q--)
       if (a0 + q < a1) {
         const double ci = ec[a0 + q];
         z = loc[q] - ci * z;
@@ -522,7 +488,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       }
     const double z_in = chain3(z, pb, +1);
 #pragma unroll
-    for (int q = 0; q < 16; q++)
+    for (int q = 0; q < OBJ_CHMAX; q++)
       if (a0 + q < a1) dp[a0 + q] = loc[q] + pr[q] * z_in;
   }
   __syncthreads();
@@ -911,9 +877,7 @@ extern "C" int rvs_objective_max_ntp(int npoly) {
     fn = (const void *)objective_kernel<PP, false>;\
     break;
   switch (npoly) {
-    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
-    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
-    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
+    RVS_ALL_CASES
     default:
       return 0;
   }
@@ -984,6 +948,29 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
       loc = locbuf;
     }
   }
+  // the persistent producer/consumer kernel (objective_pipe.hip) where it
+  // applies; RVS_OBJ_PIPE=0 keeps the one-block-per-item kernel (a test hook:
+  // tests/test_gpu_parity.py compares the two)
+  {
+    static int use_pipe = -1;
+    if (use_pipe < 0) {
+      const char *ev = getenv("RVS_OBJ_PIPE");
+      use_pipe = (ev && ev[0] == '0') ? 0 : 1;
+    }
+    if (use_pipe && (tt || loc)) {
+      const int prc = objective_pipe_launch(A, tt ? &TT : nullptr, npoly, loc, vsini,
+                                            job_spec, J, vel, shm / (3 * sizeof(double)),
+                                            armchi, armst, armout, st);
+      if (prc == 0) {
+        hipLaunchKernelGGL(objective_sum_kernel, dim3((J + 255) / 256), dim3(256), 0,
+                           st, narm, J, badchi, outside_penalty, armchi, armst,
+                           armout, out, status);
+        RVS_LAUNCH_CHECK();
+        return 0;
+      }
+      if (prc != RVS_E_ARG) return prc;
+    }
+  }
 #define RVS_LAUNCH_OBJ(PP, FT)                                                 \
   {                                                                            \
     static bool attr_set = false;                                              \
@@ -1003,9 +990,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     if (tt) RVS_LAUNCH_OBJ(PP, true) else RVS_LAUNCH_OBJ(PP, false)            \
     break;
   switch (npoly) {
-    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
-    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
-    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
+    RVS_ALL_CASES
     default:
       return RVS_E_ARG;
   }

@@ -303,10 +303,17 @@ class TemplateLibrary:
         if out is None:
             out = torch.empty(J, dtype=torch.float64, device=self.device)
         if self.nn_hull is None:
-            out[:J] = 0.0
+            # on the caller's stream, like the launch below (the optimiser's
+            # chain reads the flags there)
+            rc = _lib.lib().rvs_nn_outside(
+                None, J, self.ndim, 0, None, None, 1, None, 0, None, 0,
+                _lib.ptr(out), _lib.stream() if stream is None else stream)
+            _lib.check(rc, 'rvs_nn_outside')
             return out
         xe, ye = self.hull_device()
-        p = params if params.dtype == torch.float64 else params.double()
+        if params.dtype != torch.float64:
+            raise TypeError('rvs_nn_outside takes float64 parameters')
+        p = params
         rc = _lib.lib().rvs_nn_outside(
             _lib.ptr(p.contiguous()), J, self.ndim, self.log_mask,
             _lib.ptr(self.nn_M), _lib.ptr(self.nn_S), 1 if mapped else 0,

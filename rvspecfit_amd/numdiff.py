@@ -173,7 +173,9 @@ def _nanpercentile_cols(a, q):
     d = y - x
     out = x + d * t
     out = np.where(t >= 0.5, y - d * (1 - t), out)
-    out = np.where(t == 0, x, out)                # numpy: lerp(a, b, 0) = a exactly
+    # numpy: lerp(a, b, 0) = a exactly -- for a finite difference only (with an
+    # infinite neighbour numpy's inf * 0 is NaN, and so is this)
+    out = np.where((t == 0) & np.isfinite(d), x, out)
     return np.where(n == 0, np.nan, out)
 
 

@@ -3,7 +3,8 @@
 # flags, one variant per word) and prints the default step's xcorr time
 cd $GRAFT_REPO_ROOT
 cp rvspecfit_amd/librvsgpu.so /tmp/librvsgpu_orig.so
-for v in ${XC_VARIANTS:--DXC_BASE -DXC_TW_DERIVE -DXC_BASE -DXC_TW_DERIVE}; do
+trap 'cp /tmp/librvsgpu_orig.so rvspecfit_amd/librvsgpu.so' EXIT
+for v in ${XC_VARIANTS:--DXC_GROUP_BYTES=1048576 -DXC_GROUP_BYTES=2097152}; do
   hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 $v -c rvspecfit_amd/csrc/ccf_fft.hip -o /tmp/xc_v.o 2>/dev/null
   hipcc --offload-arch=gfx950 -shared -fPIC -o rvspecfit_amd/librvsgpu.so /tmp/xc_v.o $(ls rvspecfit_amd/csrc/_build/*.o | grep -v /ccf_fft.o)
   python -m pytest tests -x -q -m gpu -k "ccf or xcorr" 2>&1 | tail -1
@@ -11,4 +12,3 @@ for v in ${XC_VARIANTS:--DXC_BASE -DXC_TW_DERIVE -DXC_BASE -DXC_TW_DERIVE}; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['kernels']['ccf_xcorr'])"
 done
-cp /tmp/librvsgpu_orig.so rvspecfit_amd/librvsgpu.so

@@ -24,6 +24,12 @@
 #define OBJ_NT 512
 #endif
 #define OBJ_NW (OBJ_NT / 64)
+#ifndef OBJ_PREFETCH
+#define OBJ_PREFETCH 1   // factor / pixel loads ahead of the barriers (0: at their use)
+#endif
+#ifndef OBJ_SORT_MIN_JOBS
+#define OBJ_SORT_MIN_JOBS 512   // launches below this keep the caller's job order
+#endif
 #ifdef OBJ_EXP_ONEROW   // (measurement only: every vertex load hits row 0's lines)
 #define OBJ_VTX(u) 0
 #else
@@ -81,9 +87,63 @@ __global__ void __launch_bounds__(OBJ_LOC_NT)
   }
 }
 
-template <int P, bool FROMT>
+// Jobs of a launch in the order of their grid cell: a counting sort of the lowest
+// vertex row of arm 0's cell record (the nearest node for a point outside the
+// grid) by one 1024-thread block -- histogram in LDS, block scan, scatter.  The
+// order inside a bin is whatever the atomics give; it only decides WHICH block
+// evaluates a job.
+#define OBJ_ORD_NT 1024
+#define OBJ_ORD_NB 8192
+__global__ void __launch_bounds__(OBJ_ORD_NT)
+    objective_order_kernel(const double *__restrict__ loc, int J, int shift, int nb,
+                           int32_t *__restrict__ perm) {
+  __shared__ int hist[OBJ_ORD_NB];
+  __shared__ int wsum[OBJ_ORD_NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < nb; i += OBJ_ORD_NT) hist[i] = 0;
+  __syncthreads();
+  auto key_of = [&](int j) {
+    const double *r = loc + (int64_t)j * OBJ_LOC_REC;
+    const int32_t *mi = reinterpret_cast<const int32_t *>(r + 2 * OBJ_LOC_NV + 1);
+    const int64_t id = (mi[0] == 0) ? reinterpret_cast<const int64_t *>(r)[OBJ_LOC_NV]
+                                    : (int64_t)mi[1];
+    const int64_t k = (id < 0 ? 0 : id) >> shift;
+    return (int)(k < nb ? k : nb - 1);
+  };
+  for (int j = tid; j < J; j += OBJ_ORD_NT) atomicAdd(&hist[key_of(j)], 1);
+  __syncthreads();
+  // exclusive scan: every thread owns nb / 1024 consecutive bins
+  const int per = (nb + OBJ_ORD_NT - 1) / OBJ_ORD_NT;
+  const int b0 = min(nb, tid * per), b1 = min(nb, b0 + per);
+  int loc_sum = 0;
+  for (int i = b0; i < b1; i++) loc_sum += hist[i];
+  int inc = loc_sum;   // inclusive scan over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int q = 0; q < w; q++) base += wsum[q];
+  int run = base + inc - loc_sum;
+  for (int i = b0; i < b1; i++) {
+    const int c = hist[i];
+    hist[i] = run;
+    run += c;
+  }
+  __syncthreads();
+  for (int j = tid; j < J; j += OBJ_ORD_NT) perm[atomicAdd(&hist[key_of(j)], 1)] = j;
+}
+
+// INBLK: grids of more than 4 dimensions (no cell record: the search runs in
+// the block; its dynamically indexed descriptor costs every instantiation that
+// contains it 168 B of scratch per lane, so it is a variant of its own)
+template <int P, bool FROMT, bool INBLK = false>
 __global__ void __launch_bounds__(OBJ_NT)
     objective_kernel(ObjArms A, ObjTempl TT, const double *__restrict__ locrec,
+                     const int32_t *__restrict__ perm,
                      const double *__restrict__ params,
                      const double *__restrict__ vsini,
                      const int32_t *__restrict__ job_spec, int J,
@@ -100,7 +160,21 @@ __global__ void __launch_bounds__(OBJ_NT)
   __shared__ double ldv[P];
   __shared__ double red8[2 * OBJ_NW];
   const rvs_objective_arm &T = A.a[blockIdx.y];
-  const int j = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  // Job of this block.  With `perm` (the jobs of the launch in the order of their
+  // grid cell, objective_order_kernel) block x takes position
+  //   p = f (J / 8) + min(f, J % 8) + (x >> 3),   f = x & 7:
+  // blocks are dealt to the 8 XCDs round robin, so the blocks of one f share an
+  // XCD and work through one contiguous eighth of the sorted list -- the vertex
+  // rows of a cell (shared by all jobs in it, and half of them by the next cell)
+  // are fetched into that XCD's L2 once and hit there afterwards.  Which block
+  // computes a job does not change its value.
+  int j = blockIdx.x;
+  if (perm) {
+    const int f = j & 7;
+    // (one value for the block: keep it in a scalar register)
+    j = __builtin_amdgcn_readfirstlane(perm[f * (J >> 3) + min(f, J & 7) + (j >> 3)]);
+  }
   const int lane = tid & 63, w = tid >> 6;
   const int N = T.ntp, m = N - 2;
   double *bufA = lds, *bufB = lds + N, *bufC = lds + 2 * N;
@@ -125,12 +199,10 @@ __global__ void __launch_bounds__(OBJ_NT)
         PL.nearest = mi[1];
       }
       __syncthreads();
-    } else {     // grids of more than 4 dimensions: in the block
-#ifndef OBJ_EXP_NOLOC
+    } else if (INBLK) {
       const GridDesc G = obj_grid_desc(T);
       poly_locate<OBJ_NT>(PL, G, params + (int64_t)j * nd, T.idgrid, T.uvecs,
                           T.vecs_s, T.ngrid);
-#endif
     }
     mode = PL.mode;
   } else {
@@ -328,6 +400,40 @@ __global__ void __launch_bounds__(OBJ_NT)
     return;
   }
   OBJ_T(1);
+  const rvs_point_arm &S = T.pt;
+  const int npix = S.npix;
+  const int s = job_spec ? job_spec[j] : j;
+  const double bb = vel[j] / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double espec_sys = S.espec_sys;
+  const double sys2 = espec_sys * espec_sys;
+  const double *sp = S.spec + (int64_t)s * npix;
+  const double *es = S.espec + (int64_t)s * npix;
+  const double x0 = S.knots[0], xlast = S.knots[N - 1];
+  const double shift = S.log_step ? log(f) / log(S.knots[1] / x0) : 0.0;
+  const double lin_inv_step = S.log_step ? 0.0 : 1.0 / (S.knots[1] - x0);
+  const double *g = T.factors, *e = T.factors + N, *cc = T.factors + 2 * N,
+               *hh = T.factors + 3 * N, *ih = T.factors + 4 * N;
+#if OBJ_PREFETCH
+  // The phases below are separated by barriers and the block is the only one on its
+  // CU (two waves per SIMD): a load issued where its value is needed is a fully
+  // exposed L2 round trip.  The spline factors of every row of this thread are
+  // requested HERE, ahead of the FIR (which needs few registers), the backward
+  // multipliers under the forward sweep, the model pass's pixel terms under the
+  // backward sweep.  Same loads, same arithmetic: the values are unchanged.
+  constexpr int RT = (8192 + OBJ_NT - 1) / OBJ_NT;   // rows of a thread (stride OBJ_NT)
+  double pf0[RT], pf1[RT], pfg[RT], pfe[RT];
+#pragma unroll
+  for (int r = 0; r < RT; r++) {
+    if (r * OBJ_NT < m) {
+      const int i = min(tid + r * OBJ_NT, m - 1);
+      pf0[r] = ih[i];
+      pf1[r] = ih[i + 1];
+      pfg[r] = g[i];
+      pfe[r] = e[i];
+    }
+  }
+#endif
   // ---- A6: rotational broadening bufA -> bufB (taps in bufC, built above) ----
   double *y = bufA, *dp = bufB;
   if (vsini) {
@@ -381,8 +487,22 @@ __global__ void __launch_bounds__(OBJ_NT)
   OBJ_T(2);
   // ---- A7 construct: natural spline of y, windowed Thomas (template.hip) ---
   double *ec = bufC;
-  const double *g = T.factors, *e = T.factors + N, *cc = T.factors + 2 * N,
-               *hh = T.factors + 3 * N, *ih = T.factors + 4 * N;
+#if OBJ_PREFETCH
+#pragma unroll
+  for (int r = 0; r < RT; r++) {
+    const int i = tid + r * OBJ_NT;
+    if (i < m) {
+      const double y1 = y[i + 1];
+      const double s0 = (y1 - y[i]) * pf0[r], s1 = (y[i + 2] - y1) * pf1[r];
+      dp[i] = 6 * (s1 - s0) * pfg[r];
+      ec[i] = pfe[r];
+    }
+  }
+  double pfc[RT];   // backward multipliers: in flight under the forward sweep
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+    if (r * OBJ_NT < m) pfc[r] = cc[min(tid + r * OBJ_NT, m - 1)];
+#else
   // four rows per trip with their factor loads issued together (the factors
   // come out of L2: one exposed round trip per trip instead of per row)
   for (int i0 = tid; i0 < m; i0 += 4 * OBJ_NT) {
@@ -406,6 +526,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       }
     }
   }
+#endif
   __syncthreads();
   // Chunked Thomas with chunk transfer coefficients.  Thread t owns rows
   // [a0, a1) (>= 12 of them).  Both recurrences are linear in the value that
@@ -463,6 +584,25 @@ __global__ void __launch_bounds__(OBJ_NT)
       }
     d_in = chain3(d, pb, -1);  // (barrier inside: all reads of ec are done)
   }
+#if OBJ_PREFETCH
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+    if (tid + r * OBJ_NT < m) ec[tid + r * OBJ_NT] = pfc[r];
+  // pixel terms of the model pass (first trip of its loop): under the backward sweep
+  constexpr int PU = 6;
+  double qlm[PU], qwk[PU], qe[PU], qs[PU];
+  const bool cached = 2 * npix <= N;
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+      const int k = min(tid + u * OBJ_NT, npix - 1);
+      qlm[u] = S.lam[k];
+      qwk[u] = S.log_step ? S.work[k] : 0.0;
+      qe[u] = es[k];
+      qs[u] = sp[k];
+    }
+  }
+#else
   for (int i0 = tid; i0 < m; i0 += 4 * OBJ_NT) {
     double fc[4];
 #pragma unroll
@@ -471,6 +611,7 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int c = 0; c < 4; c++)
       if (i0 + c * OBJ_NT < m) ec[i0 + c * OBJ_NT] = fc[c];
   }
+#endif
 #pragma unroll
   for (int q = 0; q < OBJ_CHMAX; q++)
     if (a0 + q < a1) loc[q] = loc[q] + pr[q] * d_in;  // d of the forward sweep
@@ -491,22 +632,29 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int q = 0; q < OBJ_CHMAX; q++)
       if (a0 + q < a1) dp[a0 + q] = loc[q] + pr[q] * z_in;
   }
+#if OBJ_PREFETCH
+  // ... and the knot terms of those pixels (their interval index needs the job's
+  // velocity and the prefetched pixel terms only): in flight across the barrier
+  double qkn[PU], qhk[PU], qik[PU];
+  int qps[PU];
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+      qlm[u] *= f;
+      int pos = S.log_step ? (int)(qwk[u] + shift)
+                           : (int)((qlm[u] - x0) * lin_inv_step);
+      pos = min(max(pos, 0), N - 2);
+      qps[u] = pos;
+      qkn[u] = S.knots[pos];
+      qhk[u] = hh[pos];
+      qik[u] = ih[pos];
+    }
+  }
+#endif
   __syncthreads();
   OBJ_T(3);
   // dp[u] = z at knot u+1; spline piece i in powers of dl = x - x_i exactly as
   // rvs_spline_construct(form 1) stores it
-  const rvs_point_arm &S = T.pt;
-  const int npix = S.npix;
-  const int s = job_spec ? job_spec[j] : j;
-  const double bb = vel[j] / RVS_C_KMS;
-  const double f = sqrt((1.0 - bb) / (1.0 + bb));
-  const double espec_sys = S.espec_sys;
-  const double sys2 = espec_sys * espec_sys;
-  const double *sp = S.spec + (int64_t)s * npix;
-  const double *es = S.espec + (int64_t)s * npix;
-  const double x0 = S.knots[0], xlast = S.knots[N - 1];
-  const double shift = S.log_step ? log(f) / log(S.knots[1] / x0) : 0.0;
-  const double lin_inv_step = S.log_step ? 0.0 : 1.0 / (S.knots[1] - x0);
   auto tv_at = [&](int k) {
     const double x = S.lam[k] * f;
     int pos = S.log_step ? (int)(S.work[k] + shift)
@@ -535,31 +683,44 @@ __global__ void __launch_bounds__(OBJ_NT)
   // of a thread with each round of loads issued together (pixel terms, then
   // the knot terms that depend on the interval index): two L2 round trips for
   // six pixels instead of two per pixel.
+#if !OBJ_PREFETCH
   const bool cached = 2 * npix <= N;
+#endif
   double *tcache = bufC;
   if (cached) {
     constexpr int U = 6;
     for (int kb = tid; kb < npix; kb += U * OBJ_NT) {
       double lm[U], wk[U], e_[U], s_[U], kn[U], hk[U], ik[U];
       int ps[U];
+#if OBJ_PREFETCH
+      if (kb == tid) {
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int k = min(kb + u * OBJ_NT, npix - 1);
-        lm[u] = S.lam[k];
-        wk[u] = S.log_step ? S.work[k] : 0.0;
-        e_[u] = es[k];
-        s_[u] = sp[k];
-      }
+        for (int u = 0; u < U; u++) {
+          lm[u] = qlm[u], e_[u] = qe[u], s_[u] = qs[u];
+          ps[u] = qps[u], kn[u] = qkn[u], hk[u] = qhk[u], ik[u] = qik[u];
+        }
+      } else
+#endif
+      {
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        lm[u] *= f;
-        int pos = S.log_step ? (int)(wk[u] + shift)
-                             : (int)((lm[u] - x0) * lin_inv_step);
-        pos = min(max(pos, 0), N - 2);
-        ps[u] = pos;
-        kn[u] = S.knots[pos];
-        hk[u] = hh[pos];
-        ik[u] = ih[pos];
+        for (int u = 0; u < U; u++) {
+          const int k = min(kb + u * OBJ_NT, npix - 1);
+          lm[u] = S.lam[k];
+          wk[u] = S.log_step ? S.work[k] : 0.0;
+          e_[u] = es[k];
+          s_[u] = sp[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          lm[u] *= f;
+          int pos = S.log_step ? (int)(wk[u] + shift)
+                               : (int)((lm[u] - x0) * lin_inv_step);
+          pos = min(max(pos, 0), N - 2);
+          ps[u] = pos;
+          kn[u] = S.knots[pos];
+          hk[u] = hh[pos];
+          ik[u] = ih[pos];
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -702,6 +863,18 @@ __global__ void __launch_bounds__(OBJ_NT)
   }
   __syncthreads();
   OBJ_T(9);   // (debug) fold over the waves
+#if OBJ_PREFETCH
+  // basis rows of the residual pass: requested before the Cholesky (one wave works
+  // there, the other seven wait) instead of behind it
+  constexpr int RPF = (P <= 10) ? 6 : (P <= 12 ? 4 : 3);
+  double qp[RPF][P];
+#pragma unroll
+  for (int u = 0; u < RPF; u++) {
+    const double *prow = S.polysT + (int64_t)min(tid + u * OBJ_NT, npix - 1) * P;
+#pragma unroll
+    for (int i = 0; i < P; i++) qp[u][i] = prow[i];
+  }
+#endif
   if (w == 0) {
     // Cholesky + the two triangular solves with ROW i on lane i (i < P):
     // left-looking, sums over q ascending as in the in-lane version of the
@@ -790,8 +963,7 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
   for (int i = 0; i < P; i++) av[i] = coefs[i];
   double rr = 0;
-  for (int k = tid; k < npix; k += OBJ_NT) {
-    double te, dk;
+  auto te_dk = [&](int k, double &te, double &dk) {
     if (cached) {
       te = tcache[k];
       dk = tcache[npix + k];
@@ -803,6 +975,27 @@ __global__ void __launch_bounds__(OBJ_NT)
       te = tv * ie;
       dk = sp[k] * ie;
     }
+  };
+  int kres = tid;
+#if OBJ_PREFETCH
+#pragma unroll
+  for (int u = 0; u < RPF; u++) {
+    const int k = tid + u * OBJ_NT;
+    if (k < npix) {
+      double te, dk;
+      te_dk(k, te, dk);
+      double mdl = 0;
+#pragma unroll
+      for (int i = 0; i < P; i++) mdl = fma(av[i], qp[u][i], mdl);
+      const double r = dk - mdl * te;
+      rr = fma(r, r, rr);
+    }
+  }
+  kres = tid + RPF * OBJ_NT;
+#endif
+  for (int k = kres; k < npix; k += OBJ_NT) {
+    double te, dk;
+    te_dk(k, te, dk);
     const double *pr = S.polysT + (int64_t)k * P;
     double mdl = 0;
 #pragma unroll
@@ -895,8 +1088,10 @@ extern "C" int64_t rvs_objective_work_size(int J, int narm) {
   if (J < 1 || narm < 1) return 0;
   // per (arm, job): chi^2, outside, status (padded to 8 bytes) + the cell-search
   // record of objective_locate_kernel
+  // ... + the jobs' order (objective_order_kernel)
   return (int64_t)narm * J *
-         (int64_t)(3 * sizeof(double) + OBJ_LOC_REC * sizeof(double));
+             (int64_t)(3 * sizeof(double) + OBJ_LOC_REC * sizeof(double)) +
+         8 * (((int64_t)J + 1) / 2);
 }
 
 static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
@@ -938,6 +1133,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
   if (shm > (size_t)3 * rvs_objective_max_ntp(npoly) * sizeof(double))
     return RVS_E_ARG;
   const double *loc = nullptr;
+  int32_t *perm = nullptr;
   if (!tt) {
     bool pre = true;
     for (int i = 0; i < narm; i++)
@@ -946,17 +1142,25 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
       hipLaunchKernelGGL(objective_locate_kernel, grid, dim3(OBJ_LOC_NT), 0, st, A,
                          params, J, locbuf);
       loc = locbuf;
+      // from a few blocks per CU up: jobs in cell order (RVS_OBJ_SORT=0: a test
+      // hook, tests/test_gpu_parity.py::test_objective_job_order)
+      const char *ev = getenv("RVS_OBJ_SORT");
+      if (J >= OBJ_SORT_MIN_JOBS && !(ev && ev[0] == '0')) {
+        int shift = 0;
+        while (((arms[0].ngrid - 1) >> shift) >= OBJ_ORD_NB) shift++;
+        const int nb = (int)((arms[0].ngrid - 1) >> shift) + 1;
+        perm = (int32_t *)(locbuf + (int64_t)narm * J * OBJ_LOC_REC);
+        hipLaunchKernelGGL(objective_order_kernel, dim3(1), dim3(OBJ_ORD_NT), 0, st,
+                           locbuf, J, shift, nb, perm);
+      }
     }
   }
-  // the persistent producer/consumer kernel (objective_pipe.hip) where it
-  // applies; RVS_OBJ_PIPE=0 keeps the one-block-per-item kernel (a test hook:
-  // tests/test_gpu_parity.py compares the two)
+#ifdef OBJ_PIPE_EXPERIMENT
+  // tools/perf/experiments/objective_pipe.hip (obj_bench only): the persistent
+  // producer/consumer kernel where it applies; RVS_OBJ_PIPE=0 keeps this file's
   {
-    static int use_pipe = -1;
-    if (use_pipe < 0) {
-      const char *ev = getenv("RVS_OBJ_PIPE");
-      use_pipe = (ev && ev[0] == '0') ? 0 : 1;
-    }
+    const char *ev = getenv("RVS_OBJ_PIPE");   // (read per call: tests flip it)
+    const bool use_pipe = !(ev && ev[0] == '0');
     if (use_pipe && (tt || loc)) {
       const int prc = objective_pipe_launch(A, tt ? &TT : nullptr, npoly, loc, vsini,
                                             job_spec, J, vel, shm / (3 * sizeof(double)),
@@ -971,23 +1175,27 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
       if (prc != RVS_E_ARG) return prc;
     }
   }
-#define RVS_LAUNCH_OBJ(PP, FT)                                                 \
+#endif
+#define RVS_LAUNCH_OBJ(PP, FT, IB)                                                 \
   {                                                                            \
     static bool attr_set = false;                                              \
     if (!attr_set) {                                                           \
-      (void)hipFuncSetAttribute((const void *)objective_kernel<PP, FT>,        \
+      (void)hipFuncSetAttribute((const void *)objective_kernel<PP, FT, IB>,    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                 160 * 1024 - 1024);                            \
       (void)hipGetLastError();                                                 \
       attr_set = true;                                                         \
     }                                                                          \
-    hipLaunchKernelGGL((objective_kernel<PP, FT>), grid, dim3(OBJ_NT), shm, st, \
-                       A, TT, loc, params, vsini, job_spec, J, vel, 0.6,       \
+    hipLaunchKernelGGL((objective_kernel<PP, FT, IB>), grid, dim3(OBJ_NT), shm,  \
+                       st,                                                     \
+                       A, TT, loc, perm, params, vsini, job_spec, J, vel, 0.6, \
                        armchi, armst, armout);                                 \
   }
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \
-    if (tt) RVS_LAUNCH_OBJ(PP, true) else RVS_LAUNCH_OBJ(PP, false)            \
+    if (tt) RVS_LAUNCH_OBJ(PP, true, false)                                    \
+    else if (loc) RVS_LAUNCH_OBJ(PP, false, false)                             \
+    else RVS_LAUNCH_OBJ(PP, false, true)                                       \
     break;
   switch (npoly) {
     RVS_ALL_CASES

@@ -46,27 +46,34 @@ __device__ __forceinline__ GridDesc obj_grid_desc(const rvs_objective_arm &T) {
   G.ndim = nd;
   G.log_mask = T.log_mask;
   int off = 0;
-  for (int d = 0; d < nd; d++) {
-    G.lens[d] = T.lens[d];
+#pragma unroll
+  for (int d = 0; d < MAXDIM; d++) {   // (static indices: the descriptor stays in registers)
+    G.lens[d] = (d < nd) ? T.lens[d] : 1;
     G.uoff[d] = off;
-    off += T.lens[d];
-    G.ptp[d] = T.ptp[d];
+    off += G.lens[d];
+    G.ptp[d] = (d < nd) ? T.ptp[d] : 1.0;
   }
   int64_t st = 1;
-  for (int d = nd - 1; d >= 0; d--) {
-    G.gstride[d] = st;
-    st *= T.lens[d];
+#pragma unroll
+  for (int d = MAXDIM - 1; d >= 0; d--) {
+    if (d < nd) {
+      G.gstride[d] = st;
+      st *= T.lens[d];
+    } else {
+      G.gstride[d] = 0;
+    }
   }
   return G;
 }
 
 
-// objective_pipe.hip: the persistent kernel behind rvs_objective_fused /
-// rvs_objective_from_template.  Returns RVS_E_ARG when the launch is outside
-// what that kernel covers (the caller then uses the per-block kernel).
+#ifdef OBJ_PIPE_EXPERIMENT
+// tools/perf/experiments/objective_pipe.hip: the persistent producer/consumer
+// kernel.  Returns RVS_E_ARG when the launch is outside what it covers.
 int objective_pipe_launch(const ObjArms &A, const ObjTempl *tt, int npoly,
                           const double *locrec, const double *vsini,
                           const int32_t *job_spec, int J, const double *vel,
                           size_t nmax, double *armchi, int32_t *armst,
                           double *armout, hipStream_t st);
 int objective_pipe_max_ntp(int npoly);
+#endif

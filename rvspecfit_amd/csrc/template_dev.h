@@ -13,6 +13,15 @@ struct GridDesc {
   uint32_t log_mask;
 };
 
+// a[d] for a thread-dependent d without putting the array into scratch
+template <class T>
+__device__ __forceinline__ T sel_dim(const T (&a)[MAXDIM], int d) {
+  T v = a[0];
+#pragma unroll
+  for (int i = 1; i < MAXDIM; i++) v = (d == i) ? a[i] : v;
+  return v;
+}
+
 // np.searchsorted(u, x, 'right') - 1  == np.digitize(x, u) - 1
 __device__ __forceinline__ int cell_index(const double *u, int n, double x) {
   if (!(x == x)) return n - 1;  // NaN sorts to the end
@@ -47,7 +56,7 @@ struct PolyLoc {
 // ptp-scaled coordinates, :127-132), 2 = non-finite parameters.  Called by ALL
 // NT threads of the block (contains barriers).
 template <int NT>
-__device__ void poly_locate(PolyLoc &L, const GridDesc &G,
+__device__ __forceinline__ void poly_locate(PolyLoc &L, const GridDesc &G,
                             const double *__restrict__ prow,
                             const int64_t *__restrict__ idgrid,
                             const double *__restrict__ uvecs,
@@ -61,10 +70,11 @@ __device__ void poly_locate(PolyLoc &L, const GridDesc &G,
     double v = prow[d];
     if (G.log_mask & (1u << d)) v = log10(v);
     L.mp[d] = v;
-    const int p = cell_index(uvecs + G.uoff[d], G.lens[d], v);
+    const int len_d = sel_dim(G.lens, d);
+    const int p = cell_index(uvecs + sel_dim(G.uoff, d), len_d, v);
     L.pos[d] = p;
     L.flag[d] = ((fabs(v) <= 1.79e308) ? 0 : 1) |
-                ((p < 0 || p >= G.lens[d] - 1) ? 2 : 0);
+                ((p < 0 || p >= len_d - 1) ? 2 : 0);
   }
   __syncthreads();
   bool finite = true, outsidebox = false;
@@ -77,9 +87,12 @@ __device__ void poly_locate(PolyLoc &L, const GridDesc &G,
       // vertices in itertools.product([0,1]^ndim) order: first dim slowest
       const int v = tid;
       int64_t off = 0;
-      for (int d = 0; d < nd; d++) {
-        const int bit = (v >> (nd - 1 - d)) & 1;
-        off += (int64_t)(L.pos[d] + bit) * G.gstride[d];
+#pragma unroll
+      for (int d = 0; d < MAXDIM; d++) {
+        if (d < nd) {
+          const int bit = (v >> (nd - 1 - d)) & 1;
+          off += (int64_t)(L.pos[d] + bit) * G.gstride[d];
+        }
       }
       L.id[v] = idgrid[off];
     }
@@ -88,7 +101,7 @@ __device__ void poly_locate(PolyLoc &L, const GridDesc &G,
     if (NT <= 64) __syncthreads();
     if (tid >= XO && tid < XO + nd) {
       const int d = tid - XO;
-      const double *u = uvecs + G.uoff[d];
+      const double *u = uvecs + sel_dim(G.uoff, d);
       const int p = L.pos[d];
       L.x[d] = (L.mp[d] - u[p]) / (u[p + 1] - u[p]);
     }
@@ -113,18 +126,22 @@ __device__ void poly_locate(PolyLoc &L, const GridDesc &G,
     double q[MAXDIM];
     // cKDTree.query(p / ptp) (spec_inter.py:130-132): a DIVISION, so that the
     // distances of equidistant nodes tie (or not) exactly as the reference's do
-    for (int d = 0; d < nd; d++) q[d] = L.mp[d] / G.ptp[d];
+#pragma unroll
+    for (int d = 0; d < MAXDIM; d++) q[d] = (d < nd) ? L.mp[d] / G.ptp[d] : 0.0;
     double bd = __builtin_inf();
     int bi = 0x7fffffff;
     for (int64_t g = tid; g < ngrid; g += NT) {
       double d2 = 0;
-      for (int d = 0; d < nd; d++) {
+#pragma unroll
+      for (int d = 0; d < MAXDIM; d++) {
         // separately rounded square and sum (no fma): equidistant nodes compare
         // equal and the first one wins
 #pragma clang fp contract(off)
-        const double df = vecs_s[g * nd + d] - q[d];
-        const double sq = df * df;
-        d2 = d2 + sq;
+        if (d < nd) {
+          const double df = vecs_s[g * nd + d] - q[d];
+          const double sq = df * df;
+          d2 = d2 + sq;
+        }
       }
       if (d2 < bd) {
         bd = d2;

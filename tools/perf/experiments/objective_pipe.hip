@@ -1,3 +1,7 @@
+// EXPERIMENT (round 4; built, verified to 4e-16 against the shipped kernel, measured
+// SLOWER: 46.7 us per (job, arm) against 40.3 -- DESIGN 4.7).  Not part of
+// librvsgpu.so; tools/perf/obj_bench.hip builds it with -DOBJ_PIPE_EXPERIMENT.
+//
 // objective_pipe.hip -- the optimiser's objective (get_chisq at one point per
 // job, spec_fit.py:797-989; chisq_func of vel_fit.py:205-254) as a PERSISTENT
 // kernel with wave specialisation.
@@ -25,14 +29,14 @@
 // threadgroup split), so the producers' requests stay in flight across it.
 // 168 VGPRs (three waves per SIMD): the P(P+3)/2 normal-equation sums are
 // accumulated in two passes over the pixels.
-#include "objective_dev.h"
+#include "../../../rvspecfit_amd/csrc/objective_dev.h"
 
 #define PIPE_NT 768
 #define PIPE_NC 512            // consumer threads (waves 0..7)
 #define PIPE_NCW 8
 #define PIPE_NP 256            // producer threads (waves 8..11)
 #define PIPE_NPW 4
-#define PIPE_NBAR 12           // barriers per item, both roles
+#define PIPE_NBAR 13           // barriers per item, both roles
 #define PIPE_GPX (4 * PIPE_NP) // template points per gather group
 #define PIPE_NG 8              // groups: ntp <= 8192
 #define PIPE_CHMAX 16          // rows of a consumer's Thomas chunk (8192 / 512)
@@ -163,13 +167,17 @@ __global__ void __launch_bounds__(PIPE_NT)
     // the item being gathered (n + 2 in the steady state)
     int g_arm = 0, g_j = 0, g_N = 0, g_mode = 0;
     bool g_valid = false;
-    auto g_setup = [&](int m) {   // uniform
-      g_valid = (m >= 0 && m < cnt);
-      if (g_valid) {
+    // ... and the one after it (its cell record is fetched ahead)
+    int n_arm = 0, n_j = 0, n_N = 0, n_mode = 0;
+    bool n_valid = false;
+    auto n_setup = [&](int m) {   // uniform
+      n_valid = (m >= 0 && m < cnt);
+      n_mode = 0;
+      if (n_valid) {
         const int q = blockIdx.x + m * gridDim.x;
-        g_arm = q / J;
-        g_j = q - g_arm * J;
-        g_N = A.a[g_arm].ntp;
+        n_arm = q / J;
+        n_j = q - n_arm * J;
+        n_N = A.a[n_arm].ntp;
       }
     };
     // request group g of the item being gathered (H[hp] holds its cell record)
@@ -245,21 +253,52 @@ __global__ void __launch_bounds__(PIPE_NT)
       const int hp = n & 1;        // H[hp]: cell record of the item being gathered
                                    //        in slots 1-7 that is item n+1: H[(n+1)&1]
       const int hq = (n + 1) & 1;
-      // ---- slots 1..7: groups 3..7 of item n+1 ---------------------------------
+      // ---- slots 1..8: groups 3..6 of item n+1 (a group is consumed two or more
+      // consumer phases after its request: ~2.5 us, the round trip under load)
       P_STEP(2, 3, hq);
       PIPE_BAR();   // 1
-      P_STEP(3, 4, hq);
       PIPE_BAR();   // 2
-      P_STEP(4, 5, hq);
+      P_STEP(3, 4, hq);
       PIPE_BAR();   // 3
+      // cell record of item n+2 -> H[hp] (the consumers read H[hp] in slot 1 only)
+      n_setup(n + 2);
+      if (n_valid) {
+        if (!FROMT) {
+          const double *r = locrec + ((int64_t)n_arm * J + n_j) * OBJ_LOC_REC;
+          if (pt < OBJ_LOC_NV) {
+            H[hp].w[pt] = r[pt];
+            H[hp].id[pt] = reinterpret_cast<const int64_t *>(r)[OBJ_LOC_NV + pt];
+          }
+          const int32_t *mi = reinterpret_cast<const int32_t *>(r + 2 * OBJ_LOC_NV + 1);
+          n_mode = mi[0];   // (every producer: its branch in issue / consume)
+          if (pt == 64) {
+            H[hp].dist = r[2 * OBJ_LOC_NV];
+            H[hp].mode = mi[0];
+            H[hp].nearest = mi[1];
+          }
+        } else {
+          const double o = TT.outside[n_arm][n_j];
+          n_mode = (o == 0.0) ? 0 : 1;
+          if (pt == 64) {
+            H[hp].dist = o;
+            H[hp].mode = n_mode;
+            H[hp].nearest = 0;
+          }
+        }
+      }
       PIPE_BAR();   // 4
-      P_STEP(5, 6, hq);
       PIPE_BAR();   // 5
+      P_STEP(4, 5, hq);
       PIPE_BAR();   // 6
-      P_STEP(6, 7, hq);
       PIPE_BAR();   // 7
-      // ---- slot 8: hand-over of item n+1 -----------------------------------------
-      P_STEP(7, -1, hq);
+      P_STEP(5, 6, hq);
+      PIPE_BAR();   // 8
+      // ---- slot 9: hand-over of item n+1 -----------------------------------------
+      P_STEP(6, -1, hq);
+      if (g_valid && g_N > 7 * PIPE_GPX) {   // (ntp > 7168: an eighth group)
+        issue(7, H[hq]);
+        consume(7, H[hq], &tr[28]);
+      }
       if (g_valid) {
         const int N = g_N;
         const int N4 = N & ~3;
@@ -357,49 +396,24 @@ __global__ void __launch_bounds__(PIPE_NT)
           }
         }
       }
-      // cell record of item n+2 -> H[hp] (the consumers read H[hp] in slot 1)
-      g_setup(n + 2);
+      // item n+2 becomes the item being gathered; its first group goes out now
+      g_valid = n_valid, g_arm = n_arm, g_j = n_j, g_N = n_N, g_mode = n_mode;
       gmx = 0;
       gnan = false;
-      g_mode = 0;
-      if (g_valid) {
-        if (!FROMT) {
-          const double *r = locrec + ((int64_t)g_arm * J + g_j) * OBJ_LOC_REC;
-          if (pt < OBJ_LOC_NV) {
-            H[hp].w[pt] = r[pt];
-            H[hp].id[pt] = reinterpret_cast<const int64_t *>(r)[OBJ_LOC_NV + pt];
-          }
-          const int32_t *mi = reinterpret_cast<const int32_t *>(r + 2 * OBJ_LOC_NV + 1);
-          g_mode = mi[0];   // (every producer: its branch in issue / consume)
-          if (pt == 64) {
-            H[hp].dist = r[2 * OBJ_LOC_NV];
-            H[hp].mode = mi[0];
-            H[hp].nearest = mi[1];
-          }
-        } else {
-          const double o = TT.outside[g_arm][g_j];
-          g_mode = (o == 0.0) ? 0 : 1;
-          if (pt == 64) {
-            H[hp].dist = o;
-            H[hp].mode = g_mode;
-            H[hp].nearest = 0;
-          }
-        }
-      }
-      PIPE_BAR();   // 8
       P_STEP(-1, 0, hp);
       PIPE_BAR();   // 9
-      P_STEP(0, 1, hp);
       PIPE_BAR();   // 10
-      P_STEP(1, 2, hp);
+      P_STEP(0, 1, hp);
       PIPE_BAR();   // 11
-      // ---- slot 12: taps of item n+1 into bufC (tcache of item n is dead) -------
+      P_STEP(1, 2, hp);
+      PIPE_BAR();   // 12
+      // ---- slot 13: taps of item n+1 into bufC (tcache of item n is dead) -------
       if (pw == 0 && n + 1 >= 0 && n + 1 < cnt && !H[hq].copy) {
         const int kmax = H[hq].kmax;
         const double *tp = bufB + 2 * (kmax + 3);
         for (int k = lane; k <= kmax; k += 64) bufC[k] = tp[k];
       }
-      PIPE_BAR();   // 12
+      PIPE_BAR();   // 13
     }
 #undef P_STEP
     return;
@@ -513,7 +527,6 @@ __global__ void __launch_bounds__(PIPE_NT)
     // ---- slots 3-6: chunked Thomas with chunk transfer coefficients -----------------
     const int CH = max(12, (m + PIPE_NC - 1) / PIPE_NC);
     const int a0 = min(m, tid * CH), a1 = min(m, a0 + CH);
-    double loc[PIPE_CHMAX], pr[PIPE_CHMAX];
     // value entering a chunk from dir = -1 (lower threads) / +1 (upper): the three
     // nearest chunks' coefficients; across a wave boundary through red[]
     auto chain_pub = [&](double al, double be, int dir) {
@@ -609,8 +622,11 @@ __global__ void __launch_bounds__(PIPE_NT)
           dp[a0 + qq] = z;
         }
     }
-    PIPE_BAR();   // 6
-    // ---- slot 7: model and data in units of sigma -> tcache (bufC) -------------------
+    PIPE_BAR();   // 7
+#ifndef PIPE_NO_FENCE7
+    __builtin_amdgcn_sched_barrier(0);   // (the model pass's loads stay below the solve)
+#endif
+    // ---- slot 8: model and data in units of sigma -> tcache (bufC) -------------------
     const rvs_point_arm &S = T.pt;
     const int npix = S.npix;
     const int s = job_spec ? job_spec[j] : j;
@@ -670,8 +686,8 @@ __global__ void __launch_bounds__(PIPE_NT)
         }
       }
     }
-    PIPE_BAR();   // 7: y, dp are dead -- the producers fill bufA with item n+1
-    // ---- slot 8: normal equations, two passes, wave totals into red[w][] -------------
+    PIPE_BAR();   // 8: y, dp are dead -- the producers fill bufA with item n+1
+    // ---- slot 9: normal equations, two passes, wave totals into red[w][] -------------
     if (!(PIPE_DBG_SKIP & 8)) {
       constexpr int PA = pipe_split(P);
       constexpr int TA = PA * (PA + 1) / 2;          // matrix sums of pass A
@@ -734,8 +750,8 @@ __global__ void __launch_bounds__(PIPE_NT)
           }
       }
     }
-    PIPE_BAR();   // 8
-    // ---- slot 9: fold of the waves' totals (wave order) ------------------------------
+    PIPE_BAR();   // 13
+    // ---- slot 10: fold of the waves' totals (wave order) ------------------------------
     if (tid < NV) {
       double v = red[0][tid];
 #pragma unroll
@@ -743,7 +759,7 @@ __global__ void __launch_bounds__(PIPE_NT)
       red[0][tid] = v;
     }
     PIPE_BAR();   // 9
-    // ---- slot 10: Cholesky + triangular solves, row i on lane i (objective.hip) ------
+    // ---- slot 11: Cholesky + triangular solves, row i on lane i (objective.hip) ------
     if (!(PIPE_DBG_SKIP & 16) && w == 0) {
       const int i = lane < P ? lane : P - 1;
       double row[P];
@@ -807,7 +823,7 @@ __global__ void __launch_bounds__(PIPE_NT)
       }
     }
     PIPE_BAR();   // 10
-    // ---- slot 11: explicit residual norm ||D - a.ST||^2 (spec_fit.py:249) ------------
+    // ---- slot 12: explicit residual norm ||D - a.ST||^2 (spec_fit.py:249) ------------
     if (!(PIPE_DBG_SKIP & 32)) {
       double av[P];
 #pragma unroll
@@ -826,7 +842,7 @@ __global__ void __launch_bounds__(PIPE_NT)
       if (lane == 0) red8[w] = rr;
     }
     PIPE_BAR();   // 11
-    // ---- slot 12: the item's outputs ---------------------------------------------------
+    // ---- slot 13: the item's outputs ---------------------------------------------------
     if (tid == 0) {
       const int64_t o = (int64_t)arm * J + j;
       if (!usable) {   // unusable template: arm skipped

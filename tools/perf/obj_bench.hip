@@ -21,6 +21,10 @@
 #define objective_sum_kernel bench_objective_sum_kernel
 #define obj_dbg bench_obj_dbg
 #include "../../rvspecfit_amd/csrc/objective.hip"
+#ifdef OBJ_PIPE_EXPERIMENT
+#define objective_pipe_kernel bench_objective_pipe_kernel
+#include "experiments/objective_pipe.hip"
+#endif
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -190,6 +194,34 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
+  // the one-block-per-item kernel first (RVS_OBJ_PIPE=0): the values the
+  // persistent kernel is compared with
+  std::vector<double> out0(J);
+  float best0 = 1e30f;
+  const bool skip_ref = getenv("OBJ_BENCH_SKIP_REF") != nullptr;   // (counter runs)
+  if (skip_ref) {
+    setenv("RVS_OBJ_SORT", getenv("OBJ_BENCH_SORT") ? getenv("OBJ_BENCH_SORT") : "1", 1);
+  } else {
+    setenv("RVS_OBJ_PIPE", "0", 1);
+    setenv("RVS_OBJ_SORT", "0", 1);   // first run: the caller's job order
+    for (int r = 0; r < reps + 1; r++) {
+      hipEventRecord(e0);
+      int rc0 = rvs_objective_fused(arms, NARM, P, d_params, vsmax > 0 ? d_vsini : nullptr,
+                                    d_jspec, J, d_vel, 1e5, 1 | RVS_OBJ_STATUS_STORE,
+                                    scratch, d_out, d_st, nullptr);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      if (r) best0 = fminf(best0, ms);
+      if (rc0) return printf("objective (per-block) rc %d\n", rc0), 1;
+    }
+    CK(hipDeviceSynchronize());
+    hipMemcpy(out0.data(), d_out, J * 8, hipMemcpyDeviceToHost);
+    hipMemset(d_out, 0, J * 8);
+    setenv("RVS_OBJ_PIPE", getenv("OBJ_BENCH_PIPE") ? getenv("OBJ_BENCH_PIPE") : "1", 1);
+    setenv("RVS_OBJ_SORT", getenv("OBJ_BENCH_SORT") ? getenv("OBJ_BENCH_SORT") : "1", 1);
+  }
   float best = 1e30f, sum = 0;
   int rc = 0;
   for (int r = 0; r < reps + 1; r++) {
@@ -224,6 +256,17 @@ int main(int argc, char **argv) {
       if (st[j] || !(out[j] == out[j])) nbad++;
     }
   }
+  double maxrel = 0;
+  int nnan = 0;
+  for (int j = 0; j < J; j++) {
+    if (skip_ref) break;
+    if (out[j] == out[j] && out0[j] == out0[j])
+      maxrel = fmax(maxrel, fabs(out[j] - out0[j]) / fabs(out0[j]));
+    else if ((out[j] == out[j]) != (out0[j] == out0[j]))
+      nnan++;
+  }
+  printf("unsorted, per-block kernel: best %.3f ms (%.2f us per block-CU); max rel diff %.3g, NaN mismatches %d\n",
+         best0, 1e3 * best0 * 256 / ((double)J * NARM), maxrel, nnan);
   const double nblk = (double)J * NARM;
   printf("J %d grid %d,%d,%d,%d sorted %d vsini<=%g: best %.3f ms mean %.3f ms  "
          "%.2f us per block-CU  checksum %016llx  flagged %d  out[0..2] %.10g %.10g %.10g\n",

@@ -83,11 +83,12 @@ def node_templates(T, S):
 
 def traffic_key(args, S, T, nfft, grid_name):
     """what a PMC traffic figure is valid for: the workload a line describes"""
-    return '%s|S=%d|T=%d|nfft=%d|%s|grid=%s|refine=%d|resol=%d|templ=%s' % (
+    key = '%s|S=%d|T=%d|nfft=%d|%s|grid=%s|refine=%d|resol=%d|templ=%s' % (
         args.workload, S, T, nfft, args.evaluator, grid_name, int(args.refine),
         int(args.resolution_matrix),
         'spectrum' if (getattr(args, 'per_spectrum_templates', False)
                        or not node_templates(T, S)) else 'node')
+    return key if OPTIONS['npoly'] == 10 else key + '|npoly=%d' % OPTIONS['npoly']
 
 
 def ccf_every_for(ccf_every, ngrid):
@@ -279,6 +280,7 @@ def run_cpu_baseline(arms, n, args, start=None):
            args.evaluator]
     if getattr(args, 'grid', ''):
         cmd += ['--grid', args.grid]
+    cmd += ['--npoly', str(OPTIONS['npoly'])]
     if start is not None:
         cmd.append('--cpu-process')
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -426,6 +428,9 @@ def main():
                          'are written to disk for them')
     ap.add_argument('--cpu-process', action='store_true',
                     help='(cpu worker) run the oracle process stage')
+    ap.add_argument('--npoly', type=int, default=10,
+                    help='continuum basis size (the reference\'s tests and the WEAVE '
+                         'driver run 15); the flop model follows it')
     ap.add_argument('--workload', choices=['desi', 'cfg2'], default='desi',
                     help='desi: BASELINE configs[2] (3 arms); cfg2: configs[1] '
                          '(1 arm, 2001 px, N_fft 4096)')
@@ -456,6 +461,8 @@ def main():
     if args.workload == 'cfg2':
         ARMS = ('c', )
     EVALUATOR = args.evaluator
+    assert 1 <= args.npoly <= 16, '--npoly: 1..16'
+    OPTIONS['npoly'] = args.npoly
     if args.grid:
         g = [int(_) for _ in args.grid.split(',')]
         assert len(g) == 4 and min(g) >= 2, '--grid needs four sizes >= 2'
@@ -656,7 +663,9 @@ def main():
     # velocities on every arm, refinement rounds add shorter grids)
     units2 = units2 / 400.0
     grid_gbs = (units2 / len(ARMS)) * b_grid_unit / (ms2 * 1e-3) / 1e9 if ms2 else 0
-    flop_grid_unit = 400 * npix_tot * (2 * 65 + 40)
+    P_ = OPTIONS['npoly']
+    nsum_ = P_ * (P_ + 1) // 2 + P_
+    flop_grid_unit = 400 * npix_tot * (2 * nsum_ + 40)
     grid_tflops = (units2 / len(ARMS)) * flop_grid_unit / (ms2 * 1e-3) / 1e12 if ms2 else 0
     # ---- roofline of the DOMINANT kernel: the fp64 chi^2 grid ----------------
     # algorithmic flops per spectrum: Nv * sum_arm npix * (2*65 + 40) at npoly 10
@@ -709,8 +718,9 @@ def main():
                 bytes_per_spectrum=b_grid_unit,
                 avg_launch_ms=round(ms2 / max(nl2, 1), 3), launches=nl2,
                 share_of_step=round(ms2 / args.steps / (dt / args.steps * 1e3), 3),
-                note='fp64 vector-ALU bound (0.07 TB/s algorithmic): flops = 170 '
-                     'per pixel-velocity; peak = datasheet fp64 vector rate (a '
+                npoly=OPTIONS['npoly'],
+                note='fp64 vector-ALU bound (0.07 TB/s algorithmic): flops = '
+                     '2 (P (P + 1) / 2 + P) + 40 per pixel-velocity (170 at npoly 10); peak = datasheet fp64 vector rate (a '
                      'pure v_fma_f64 loop sustained 70.6 TF on this chip in '
                      'round 2, tools/perf/ubench.hip -- not measured by this run)')
     roof_ccf = dict(bound='hbm', kernel='ccf_xcorr_kernel',
@@ -833,7 +843,7 @@ def main():
         data='synthetic',
         config=dict(workload='%s, %d spectra per GPU per step, %s evaluator, %s '
                              'grid, T=%d CCF templates, N_fft=%d, 400-velocity '
-                             'chi2 grid, npoly=10' % (
+                             'chi2 grid, npoly=%d' % (
                                  'DESI b/r/z 3-arm (2751/2326/2881 px) (BASELINE '
                                  'configs[%d])' % (3 if EVALUATOR == 'nn' else 2)
                                  if args.workload == 'desi' else
@@ -841,8 +851,8 @@ def main():
                                  S, EVALUATOR,
                                  'x'.join(str(GRID_KW[k]) for k in (
                                      'nteff', 'nlogg', 'nfeh', 'nalpha')),
-                                 Tccf, nfft),
-                    spectra_per_gpu=S, ccf_templates=Tccf, nfft=nfft,
+                                 Tccf, nfft, OPTIONS['npoly']),
+                    spectra_per_gpu=S, npoly=OPTIONS['npoly'], ccf_templates=Tccf, nfft=nfft,
                     refine=bool(args.refine),
                     resolution_matrix=bool(args.resolution_matrix),
                     templates='one per spectrum' if (
@@ -872,6 +882,93 @@ def main():
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def objective_model(ntp, npix, npoly, nvert, ktaps, kind='regulargrid'):
+    """Algorithmic fp64 flops and gathered bytes of ONE (job, arm) evaluation of
+    the optimiser's objective (csrc/objective.hip), per phase:
+      gather   ntp (2 nvert + 35)        nvert-row blend (one FMA per row) + exp
+      fir      ntp 2 ktaps               rotational broadening, ktaps = 2 kmax + 1
+      spline   ntp 20                    right-hand sides, two sweeps, corrections
+      model    npix 25                   spline value at the pixel, units of sigma
+      normal   npix (2 (P(P+1)/2 + P) + P + 3)   the P(P+3)/2 sums
+      resid    npix (2 P + 3)            explicit residual norm
+      solve    P^3 / 3 + 2 P^2           Cholesky + two triangular solves
+    bytes: the nvert float32 vertex rows (what comes out of the Infinity Cache /
+    HBM per evaluation; the per-arm constants -- spline factors, basis, pixel
+    grid -- and the spectrum's 3 npix doubles are L2 traffic and not counted)."""
+    P = npoly
+    fl = dict(gather=ntp * (2 * nvert + 35) if kind == 'regulargrid' else 0,
+              fir=ntp * 2 * ktaps, spline=ntp * 20, model=npix * 25,
+              normal=npix * (2 * (P * (P + 1) // 2 + P) + P + 3),
+              resid=npix * (2 * P + 3), solve=P ** 3 // 3 + 2 * P * P)
+    by = nvert * ntp * 4 if kind == 'regulargrid' else ntp * 8
+    return fl, by
+
+
+def objective_counters(grid_name):
+    """SQ / TCC counters of objective_kernel<10> from the committed counter passes
+    of this build (tools/perf/obj_counters.sh on tools/perf/obj_bench: 9000 jobs x
+    3 DESI arms at random in-grid parameters, the library of this grid) -- not
+    measured by this run; None for a grid that has not been profiled."""
+    f = os.path.join(REPO, 'profiles', 'r04_obj_counters.json')
+    try:
+        return json.load(open(f))[grid_name]
+    except Exception:
+        return None
+
+
+def process_roofline(sub, r, out, tm, dt, dt1):
+    """Efficiency of the optimiser stage: objective evaluations per second and what
+    they amount to against the fp64 vector peak and the memory system (the stage is
+    bound by objective_kernel: one block per CU)."""
+    from rvspecfit_amd import spec_inter
+    FP64_PEAK_TF = 78.6
+    evals = int(r['objective_evals'])
+    vs = r['vsini'] if 'vsini' in r else None
+    fl_tot, by_tot, per_arm = 0, 0, {}
+    for a in sub.arms:
+        lib = spec_inter.interp_cache.registered[(CONFIG['template_lib'], a.name)]
+        kind = 'regulargrid' if (EVALUATOR == 'polylinear' and
+                                 lib.kind == 'regulargrid') else 'from_template'
+        nvert = 2 ** lib.ndim if kind == 'regulargrid' else 1
+        kt = 1
+        if vs is not None:   # taps of the fitted vsini, mean over the spectra
+            import torch
+            R = (torch.nan_to_num(vs.double(), nan=0.0) / 299792.458) / lib.lnstep
+            kt = float((2 * torch.ceil(R + 1) + 1).mean())
+        fl, by = objective_model(lib.ntp, len(a.lam_host), OPTIONS['npoly'], nvert, kt,
+                                 kind)
+        per_arm[a.name] = dict(ntp=lib.ntp, npix=len(a.lam_host), nvert=nvert,
+                               taps=round(kt, 1), flops=int(sum(fl.values())),
+                               flops_by_phase={k: int(v) for k, v in fl.items()},
+                               gathered_bytes=by)
+        fl_tot += sum(fl.values())
+        by_tot += by
+    nm_s = tm.get('neldermead', 0.0)
+    tf = evals * fl_tot / dt / 1e12
+    grid_name = 'x'.join(str(GRID_KW[k]) for k in ('nteff', 'nlogg', 'nfeh', 'nalpha'))
+    return dict(
+        kernel='objective_kernel<%d,%s>' % (OPTIONS['npoly'],
+                                            'false' if EVALUATOR == 'polylinear' else 'true'),
+        bound='latency / fp64 VALU issue at two waves per SIMD (one 155-KB-LDS block '
+              'per CU); not HBM',
+        unit='TFLOP/s', achieved=round(tf, 2), peak=FP64_PEAK_TF,
+        frac=round(tf / FP64_PEAK_TF, 4),
+        evaluations=evals, arm_evaluations=evals * len(sub.arms),
+        evaluations_per_s=round(evals / dt, 0),
+        flops_per_evaluation=int(fl_tot), gathered_bytes_per_evaluation=int(by_tot),
+        gather_GBps=round(evals * by_tot / dt / 1e9, 1),
+        gather_frac_of_hbm_peak=round(evals * by_tot / dt / 1e9 / HBM_PEAK_GBS, 4),
+        us_per_arm_evaluation_per_cu=round(
+            (nm_s if nm_s else dt) * 256 / max(1, evals * len(sub.arms)) * 1e6 *
+            (dt / dt1 if nm_s else 1.0), 2),
+        per_arm=per_arm, counters=objective_counters(grid_name),
+        counters_source='profiles/r04_obj_counters.json[%s] (tools/perf/obj_counters.sh, '
+                        'stand-alone objective bench; not this run)' % grid_name,
+        note='flops / bytes: objective_model() of bench.py (phase by phase, DESIGN '
+             '4.7); evaluations counted by the optimiser; seconds = the whole '
+             'vel_fit.process call (first grid, Nelder-Mead, refinement, Hessian)')
 
 
 def run_process_addon(batch, rec, arms, args, dev):
@@ -923,6 +1020,7 @@ def run_process_addon(batch, rec, arms, args, dev):
                second_minimizer=bool(args.process_bfgs),
                note='add-on, not part of `value`; Hessian by central '
                     'differences (see DESIGN.md)')
+    out['roofline'] = process_roofline(sub, r, out, tm, dt, dt1)
     if 'bfgs' in r:
         out['bfgs'] = dict(rounds=int(r['bfgs']['rounds']),
                            nfev_mean=round(float(np.mean(r['bfgs']['nfev'])), 1),

@@ -196,7 +196,7 @@ __device__ __forceinline__ void cg_sload4(cg_d2 &d, const double2 *p) {
 // it costs is the second evaluation of the spline and of the P products P_j w
 // per pixel (215 instead of 175 fp64 operations per pixel-velocity at P = 15).
 __host__ __device__ constexpr int cg_split(int P) {
-  if (P <= 12) return P;
+  if (P <= 14) return P;
   int pa = 1;
   while (pa < P && pa * (pa + 3) < P * (P + 3) / 2) pa++;
   return pa;

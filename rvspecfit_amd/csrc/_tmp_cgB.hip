@@ -185,7 +185,7 @@ __device__ __forceinline__ void cg_sload4(cg_d2 &d, const double2 *p) {
 // addressing, and the VALU stays ~80 % busy (now waiting for LDS and the scalar
 // cache instead of the gathers).  tools/perf/experiments/chisq_grid_dpp_lds.patch.
 // waves per SIMD the register budget is held to (168 / 256 VGPRs)
-#define CG_WAVES(P) ((P) <= 10 ? 3 : 2)
+#define CG_WAVES(P) ((P) <= 10 || (P) == 13 || (P) == 14 ? 3 : 2)
 // npoly 13..16 (the reference's own tests and the WEAVE driver run 15): the
 // P (P + 3) / 2 = 104..152 sums of a lane do not fit the 256 registers of two
 // waves per SIMD (round 3: 512 VGPRs + scratch, ONE wave per SIMD).  There the

@@ -19,6 +19,7 @@
 // to rounding (tests/test_gpu_parity.py::test_objective_fused).
 #include "objective_dev.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #ifndef OBJ_NT
 #define OBJ_NT 512
@@ -671,12 +672,7 @@ __global__ void __launch_bounds__(OBJ_NT)
     return fma(fma(fma(c3, dl, c2), dl, cb), dl, yi);
   };
   // ---- A10/A11: continuum-marginalised chi^2 (as point_block_kernel) -------
-  double acc[NT];
-  double av[P];
-#pragma unroll
-  for (int i = 0; i < NT; i++) acc[i] = 0;
-#pragma unroll
-  for (int i = 0; i < P; i++) av[i] = 0;
+  double av[P];   // (the coefficients, from the Cholesky solve on)
   // model / data in units of sigma are parked in the (now free) factor buffer
   // when they fit: [npix] t_k/e_k, [npix] s_k/e_k.  They are produced by a
   // first pass that holds no accumulators, so it is unrolled over the pixels
@@ -745,16 +741,14 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
   }
   OBJ_T(7);
-  // basis rows one pixel ahead: the P loads of the next pixel are in flight
-  // while the P(P+3)/2 FMAs of the current one issue
-  double pn[P];
-  {
-    const double *pr = S.polysT + (int64_t)min(tid, npix - 1) * P;
-#pragma unroll
-    for (int i = 0; i < P; i++) pn[i] = pr[i];
-  }
-  for (int k = tid; k < npix; k += OBJ_NT) {
-    double te, dk;
+  // Normal equations: rows [I0, I1) of the packed matrix + right-hand side, summed
+  // over this thread's pixels, reduced over the wave by halving, wave totals into
+  // red[w][].  One pass over the pixels up to P = 10 (65 sums: 130 registers); from
+  // P = 11 the rows are split over two passes (objective_kernel<15> held 256 VGPRs
+  // + 536 B of scratch per lane in round 3): a pass keeps about half of the sums, the
+  // basis columns it needs are read again, every sum still receives its pixels in
+  // the same order.
+  auto te_dk_of = [&](int k, double &te, double &dk) {
     if (cached) {  // written by this same thread above
       te = tcache[k];
       dk = tcache[npix + k];
@@ -766,91 +760,61 @@ __global__ void __launch_bounds__(OBJ_NT)
       te = tv * ie;
       dk = sp[k] * ie;
     }
-    const double wt = te * te, u = te * dk;
-    double pv[P], pw[P];
+  };
+  auto normal_pass = [&](auto i0_c, auto i1_c) {
+    constexpr int I0 = decltype(i0_c)::value, I1 = decltype(i1_c)::value;
+    constexpr int T0 = I0 * (I0 + 1) / 2, CM = I1 * (I1 + 1) / 2 - T0;
+    constexpr int CNT = CM + (I1 - I0);
+    double vals[CNT];   // [CM] matrix sums TRI(i, jj) - T0, then [I1 - I0] right-hand sides
 #pragma unroll
-    for (int i = 0; i < P; i++) pv[i] = pn[i];
+    for (int i = 0; i < CNT; i++) vals[i] = 0;
+    // basis rows one pixel ahead: the loads of the next pixel are in flight while
+    // the FMAs of the current one issue
+    double pn[I1];
     {
-      const double *pr = S.polysT + (int64_t)min(k + OBJ_NT, npix - 1) * P;
+      const double *pr = S.polysT + (int64_t)min(tid, npix - 1) * P;
 #pragma unroll
-      for (int i = 0; i < P; i++) pn[i] = pr[i];
+      for (int i = 0; i < I1; i++) pn[i] = pr[i];
     }
+    for (int k = tid; k < npix; k += OBJ_NT) {
+      double te, dk;
+      te_dk_of(k, te, dk);
+      const double wt = te * te, u = te * dk;
+      double pv[I1], pw[I1];
 #pragma unroll
-    for (int i = 0; i < P; i++) pw[i] = pv[i] * wt;
+      for (int i = 0; i < I1; i++) pv[i] = pn[i];
+      {
+        const double *pr = S.polysT + (int64_t)min(k + OBJ_NT, npix - 1) * P;
 #pragma unroll
-    for (int i = 0; i < P; i++) {
-      av[i] = fma(pv[i], u, av[i]);
-#pragma unroll
-      for (int jj = 0; jj <= i; jj++)
-        acc[TRI(i, jj)] = fma(pv[i], pw[jj], acc[TRI(i, jj)]);
-    }
-  }
-  OBJ_T(4);
-  {
-    // wave reduction of the NV sums by halving: at the step with lane mask m
-    // the lanes l and l^m split the live sums between them (the lane with the
-    // bit clear keeps the lower half), so a step moves half as many values as
-    // the one before: ~NV exchanges in all instead of NV full butterflies.
-    // After the six steps every total sits in exactly one lane.
-    double vals[NV];
-#pragma unroll
-    for (int i = 0; i < NT; i++) vals[i] = acc[i];
-#pragma unroll
-    for (int i = 0; i < P; i++) vals[NT + i] = av[i];
-    // slot i of a lane stands for sum number base + i; lim = end of the
-    // range that is really this lane's (an odd count leaves the upper lanes a
-    // zero slot whose number belongs to another lane group)
-    int cnt = NV, base = 0, lim = NV;
-#pragma unroll
-    for (int mk = 32; mk >= 1; mk >>= 1) {
-      const int h = (cnt + 1) >> 1;
-      const bool up = (lane & mk) != 0;
-#pragma unroll
-      for (int i = 0; i < h; i++) {
-        const bool has_hi = (i + h < cnt);
-        const double lo = vals[i], hi = has_hi ? vals[i + h] : 0.0;
-        if (mk >= 16) {
-          // v_permlane32_swap / v_permlane16_swap (gfx950): the upper half (odd
-          // rows) of `lo` trades places with the lower half (even rows) of `hi`
-          // -- exactly this step's exchange, on the VALU: afterwards the lower
-          // lanes hold both lo's, the upper lanes both hi's.  As ds_bpermute
-          // (__shfl_xor) the 50 exchanges of these two steps, from 8 waves at
-          // once, queued on the CU's one LDS crossbar: 13.8 % of the block.
-          const unsigned l0 = __double2loint(lo), l1 = __double2hiint(lo);
-          const unsigned h0 = __double2loint(hi), h1 = __double2hiint(hi);
-          if (mk == 32) {
-            const auto r0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);
-            const auto r1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
-            vals[i] = __hiloint2double(r1[0], r0[0]) +
-                      __hiloint2double(r1[1], r0[1]);
-          } else {
-            const auto r0 = __builtin_amdgcn_permlane16_swap(l0, h0, false, false);
-            const auto r1 = __builtin_amdgcn_permlane16_swap(l1, h1, false, false);
-            vals[i] = __hiloint2double(r1[0], r0[0]) +
-                      __hiloint2double(r1[1], r0[1]);
-          }
-        } else {
-          const double send = up ? lo : hi;
-          const double keep = up ? hi : lo;
-          double recv;   // lane ^ mk inside a row of 16: DPP, no LDS
-          if (mk == 8)        // row_mirror then row_half_mirror
-            recv = dpp_get<0x141, 0xf, 0xf>(dpp_get<0x140, 0xf, 0xf>(send));
-          else if (mk == 4)   // row_half_mirror then quad_perm [3,2,1,0]
-            recv = dpp_get<0x1b, 0xf, 0xf>(dpp_get<0x141, 0xf, 0xf>(send));
-          else if (mk == 2)   // quad_perm [2,3,0,1]
-            recv = dpp_get<0x4e, 0xf, 0xf>(send);
-          else                // quad_perm [1,0,3,2]
-            recv = dpp_get<0xb1, 0xf, 0xf>(send);
-          vals[i] = keep + recv;
-        }
+        for (int i = 0; i < I1; i++) pn[i] = pr[i];
       }
-      lim = up ? lim : min(lim, base + h);
-      base += up ? h : 0;
-      cnt = h;
-    }
 #pragma unroll
-    for (int i = 0; i < (NV + 63) / 64 + 1; i++)
-      if (i < cnt && base + i < lim) red[w][base + i] = vals[i];
+      for (int i = 0; i < I1; i++) pw[i] = pv[i] * wt;
+#pragma unroll
+      for (int i = I0; i < I1; i++) {
+        vals[CM + i - I0] = fma(pv[i], u, vals[CM + i - I0]);
+#pragma unroll
+        for (int jj = 0; jj <= i; jj++)
+          vals[TRI(i, jj) - T0] = fma(pv[i], pw[jj], vals[TRI(i, jj) - T0]);
+      }
+    }
+    OBJ_T(4);
+    // slot i of a lane stands for sum number base + i of this pass; lim = end of
+    // the range that is really this lane's
+    int cnt, base, lim;
+    wave_halve<CNT>(vals, lane, cnt, base, lim);
+#pragma unroll
+    for (int i = 0; i < (CNT + 63) / 64 + 1; i++)
+      if (i < cnt && base + i < lim) {
+        const int a = base + i;
+        red[w][a < CM ? T0 + a : NT + I0 + (a - CM)] = vals[i];
+      }
+  };
+  {
+    constexpr int PA = obj_split(P);
+    normal_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, PA>{});
+    if constexpr (PA < P)
+      normal_pass(std::integral_constant<int, PA>{}, std::integral_constant<int, P>{});
   }
   __syncthreads();
   OBJ_T(8);   // (debug) wave reductions of the NV sums

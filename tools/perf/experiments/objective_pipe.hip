@@ -57,58 +57,6 @@ struct PipeHdr {
   int kmax, copy, st_extra;
 };
 
-// wave reduction of CNT per-lane sums by halving (objective.hip): at the step
-// with lane mask m the lanes l and l^m split the live sums between them.  After
-// the six steps slot i (< cnt) of a lane holds the wave total of sum number
-// base + i when that number is < lim.
-template <int CNT>
-__device__ __forceinline__ void wave_halve(double (&vals)[CNT], int lane,
-                                           int &cnt_o, int &base_o, int &lim_o) {
-  int cnt = CNT, base = 0, lim = CNT;
-#pragma unroll
-  for (int mk = 32; mk >= 1; mk >>= 1) {
-    const int h = (cnt + 1) >> 1;
-    const bool up = (lane & mk) != 0;
-#pragma unroll
-    for (int i = 0; i < h; i++) {
-      const bool has_hi = (i + h < cnt);
-      const double lo = vals[i], hi = has_hi ? vals[i + h] : 0.0;
-      if (mk >= 16) {
-        const unsigned l0 = __double2loint(lo), l1 = __double2hiint(lo);
-        const unsigned h0 = __double2loint(hi), h1 = __double2hiint(hi);
-        if (mk == 32) {
-          const auto r0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);
-          const auto r1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
-          vals[i] = __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
-        } else {
-          const auto r0 = __builtin_amdgcn_permlane16_swap(l0, h0, false, false);
-          const auto r1 = __builtin_amdgcn_permlane16_swap(l1, h1, false, false);
-          vals[i] = __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
-        }
-      } else {
-        const double send = up ? lo : hi;
-        const double keep = up ? hi : lo;
-        double recv;
-        if (mk == 8)
-          recv = dpp_get<0x141, 0xf, 0xf>(dpp_get<0x140, 0xf, 0xf>(send));
-        else if (mk == 4)
-          recv = dpp_get<0x1b, 0xf, 0xf>(dpp_get<0x141, 0xf, 0xf>(send));
-        else if (mk == 2)
-          recv = dpp_get<0x4e, 0xf, 0xf>(send);
-        else
-          recv = dpp_get<0xb1, 0xf, 0xf>(send);
-        vals[i] = keep + recv;
-      }
-    }
-    lim = up ? lim : min(lim, base + h);
-    base += up ? h : 0;
-    cnt = h;
-  }
-  cnt_o = cnt;
-  base_o = base;
-  lim_o = lim;
-}
-
 // rows [0, PA) of the normal equations go into the first accumulation pass:
 // the smallest PA with PA (PA + 3) / 2 >= half of the P (P + 3) / 2 sums
 __host__ __device__ constexpr int pipe_split(int P) {

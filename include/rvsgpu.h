@@ -55,8 +55,14 @@ extern "C" {
  *   5: rvs_nn_outside added; rvs_chisq_grid packs left-over velocities from
  *      2000 jobs up by default (pack_min_jobs = 0)
  *   6: rvs_nm_objective.nn (MLP evaluators inside rvs_nm_run),
- *      rvs_template_nn_arms */
-#define RVS_ABI_VERSION 6
+ *      rvs_template_nn_arms
+ *   7: grid sets -- spectra of one arm on different wavelength grids in one batch
+ *      (spec_fit.py:70-145 takes any `lam` per object): rvs_chisq_work_size_g,
+ *      rvs_chisq_prepare_g, rvs_chisq_grid_g, rvs_chisq_full_g,
+ *      rvs_chisq_continuum_g, rvs_ccf_preprocess_g; rvs_point_arm grew (grid_id,
+ *      polys_stride, G); rvs_objective_work_size grew (the jobs' cell order);
+ *      rvs_nn_outside accepts nfx = nfy = 0 */
+#define RVS_ABI_VERSION 7
 int rvs_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -199,6 +205,30 @@ int rvs_chisq_grid(const double *lam, const double *polysT, const double *work,
                    int pack_min_jobs, double *out, int32_t *status,
                    void *stream);
 
+/* Grid sets (ABI 7): the S spectra of an arm observed on G different wavelength
+ * grids (SDSS-style objects: every spectrum has its own `lam`, spec_fit.py:70-145,
+ * tests/test_sdss.py).  lam [G, npix]: grid g in row g, a grid with fewer than
+ * npix pixels padded by repeating its last wavelength; grid_id int32 [S]: the grid
+ * of spectrum s; on the padding the spectra carry espec = +inf (weight 0, no term
+ * in sum log e) and the basis rows are 0; polysT of grid g starts at
+ * polysT + g * polys_stride.  work: rvs_chisq_work_size_g(npix, S, G) doubles from
+ * rvs_chisq_prepare_g.  G = 1 (grid_id NULL) is the shared-grid call.  With G > 1
+ * the left-over velocities of a job are not packed with those of other jobs. */
+int64_t rvs_chisq_work_size_g(int npix, int S, int G);
+int rvs_chisq_prepare_g(const double *lam, const double *spec,
+                        const double *espec, int npix, int S, int G,
+                        const double *knots_host3, int log_step, double espec_sys,
+                        double *work, void *stream);
+int rvs_chisq_grid_g(const double *lam, const double *polysT, const double *work,
+                     int npix, int npoly, int S, const int32_t *grid_id, int G,
+                     int64_t polys_stride, const double *knots,
+                     const double *coef, int ntp, int Tn, int log_step,
+                     const int32_t *job_spec, const int32_t *job_templ, int J,
+                     const double *vels, int64_t vel_stride, int Nv,
+                     const double *penalty, double badchi, double beta,
+                     int pack_min_jobs, double *out, int32_t *status,
+                     void *stream);
+
 /* A9  the same with a banded resolution matrix applied to the resampled
  * template before the fit: replaces convolve_resol / ResolMatrix
  * (spec_fit.py:54-67, 474-492) as used by get_chisq (:920-929).
@@ -236,6 +266,19 @@ int rvs_chisq_full(const double *lam, const double *polysT, const double *spec,
                    double *chisq, double *coeffs,
                    double *model, double *raw_model, double *true_chisq,
                    int32_t *ngood, int32_t *status, void *stream);
+/* ... on grid sets (see rvs_chisq_grid_g): lam [G, npix], polysT per grid; the
+ * padding of a short grid does not count in ngood / true_chisq, model is 0 there. */
+int rvs_chisq_full_g(const double *lam, const double *polysT, const double *spec,
+                     const double *espec, const uint8_t *badmask, int npix,
+                     int npoly, int S, const double *knots, const double *coef,
+                     int ntp, int Tn, int log_step, int cform, int unit_template,
+                     const int32_t *job_spec, const int32_t *job_templ, int J,
+                     const double *vel, double espec_sys, int fast_interp,
+                     const double *taps, int nd, int64_t taps_stride,
+                     double *chisq, double *coeffs, double *model,
+                     double *raw_model, double *true_chisq, int32_t *ngood,
+                     int32_t *status, const int32_t *grid_id, int G,
+                     int64_t polys_stride, void *stream);
 
 /* ------------------------------------------------------------------------
  * A13  get_chisq_continuum (spec_fit.py:739-783) for a whole batch of one arm:
@@ -256,6 +299,13 @@ int rvs_chisq_continuum(const double *polysT, const double *spec,
                         void *work, double *chisq,
                         double *true_chisq, int32_t *ngood, int32_t *status,
                         void *stream);
+int rvs_chisq_continuum_g(const double *polysT, const double *spec,
+                          const double *espec, const uint8_t *badmask,
+                          const double *unit_templ, int npix, int npoly, int S,
+                          void *work, double *chisq, double *true_chisq,
+                          int32_t *ngood, int32_t *status,
+                          const int32_t *grid_id, int G, int64_t polys_stride,
+                          void *stream);
 
 /* ------------------------------------------------------------------------
  * A11 at one velocity per job: the objective of the optimiser stage,
@@ -281,6 +331,14 @@ typedef struct rvs_point_arm {
                            `work` must have been prepared with the same value */
   int32_t npix, S, ntp, log_step, nd;
   int32_t fast_interp;  /* nearest-knot template instead of the spline (:913-918) */
+  /* wavelength grids of the arm (ABI 7): G <= 1 -- one grid, lam [npix], polysT
+   * [npix, npoly], work from rvs_chisq_prepare; G > 1 -- spectrum s is observed on
+   * grid grid_id[s]: lam [G, npix], polysT of grid g at polysT + g*polys_stride,
+   * work from rvs_chisq_prepare_g (a grid shorter than npix is padded: lam repeats
+   * its last value, espec = +inf, basis rows 0).  No resolution matrix with G > 1. */
+  const int32_t *grid_id;
+  int64_t polys_stride;
+  int32_t G, reserved_;
 } rvs_point_arm;
 int64_t rvs_chisq_point_work_size(int J, int narm);
 int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
@@ -409,6 +467,23 @@ int rvs_ccf_preprocess(const double *lam, const double *spec,
                        double *proc_spec, double *proc_ivar, double *sse,
                        double *cont, double *pfit, int32_t *status,
                        void *stream);
+/* ... on grid sets: spectrum b is observed on grid grid_id[b] with npix_g[g]
+ * pixels and nnode_g[g] continuum nodes (make_ccf.py:123-131: the node count
+ * follows the grid's wavelength range).  Every table holds one slice per grid:
+ * lam [G, npix], Eb [G, npix, 3], El [G, npix], Cinv [G, 2, nnode, nnode] (grid g's
+ * two nnode_g x nnode_g matrices packed at the start of its slice), istart
+ * [G, nnode], bin_start [G, nnode + 1], xind / rw [G, nfft]; npix / nnode = the
+ * largest grid = the row strides of spec, espec, badmask, cont / pfit. */
+int rvs_ccf_preprocess_g(const double *lam, const double *spec, const double *espec,
+                         const uint8_t *badmask, int npix, int B, int continuum,
+                         const double *Eb, const int32_t *El, const double *Cinv,
+                         const int32_t *istart, int nnode,
+                         const int32_t *bin_start, const int32_t *xind,
+                         const double *rw, int nfft, double maxerr,
+                         double *proc_spec, double *proc_ivar, double *sse,
+                         double *cont, double *pfit, int32_t *status,
+                         const int32_t *grid_id, const int32_t *npix_g,
+                         const int32_t *nnode_g, void *stream);
 
 /* ------------------------------------------------------------------------
  * A14  FFT cross-correlation of one arm against T templates; replaces the

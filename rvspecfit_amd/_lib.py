@@ -29,6 +29,10 @@ SIGNATURES = {
     'rvs_spline_construct': (I, [P, P, I, I, I, P, P, P]),
     'rvs_spline_eval': (I, [P, P, I, I, P, I, I, P, P, P, P]),
     'rvs_chisq_work_size': (L, [I, I]),
+    'rvs_chisq_work_size_g': (L, [I, I, I]),
+    'rvs_chisq_prepare_g': (I, [P, P, P, I, I, I, P, I, D, P, P]),
+    'rvs_chisq_grid_g': (I, [P, P, P, I, I, I, P, I, L, P, P, I, I, I, P, P, I, P, L,
+                             I, P, D, D, I, P, P, P]),
     'rvs_chisq_prepare': (I, [P, P, P, I, I, P, I, D, P, P]),
     'rvs_chisq_grid': (I, [P, P, P, I, I, I, P, P, I, I, I, P, P, I, P, L, I, P,
                            D, D, I, P, P, P]),
@@ -36,7 +40,11 @@ SIGNATURES = {
                                  I, P, L, I, P, D, D, P, P, P]),
     'rvs_chisq_full': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, P, P, I,
                            P, D, I, P, I, L, P, P, P, P, P, P, P, P]),
+    'rvs_chisq_full_g': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, P, P, I,
+                             P, D, I, P, I, L, P, P, P, P, P, P, P, P, I, L, P]),
     'rvs_chisq_continuum_work_size': (L, [I, I]),
+    'rvs_chisq_continuum_g': (I, [P, P, P, P, P, I, I, I, P, P, P, P, P, P, I, L,
+                                  P]),
     'rvs_chisq_continuum': (I, [P, P, P, P, P, I, I, I, P, P, P, P, P, P]),
     'rvs_chisq_point_work_size': (L, [I, I]),
     'rvs_chisq_point': (I, [P, I, I, P, P, I, P, D, P, P, P, P]),
@@ -63,6 +71,8 @@ SIGNATURES = {
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),
+    'rvs_ccf_preprocess_g': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I,
+                                 D, P, P, P, P, P, P, P, P, P, P]),
     'rvs_ccf_fft_pos': (I, [I, I]),
     'rvs_ccf_xcorr': (I, [P, P, I, I, P, P, I, P, I, P, P, I, P, P, I, D, P, P,
                           P, P]),
@@ -74,7 +84,7 @@ SIGNATURES = {
 
 _lib = None
 # RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class RvsGpuError(RuntimeError):
@@ -141,7 +151,9 @@ class PointArm(ctypes.Structure):
                  'penalty', 'taps')] + [('taps_stride', ctypes.c_int64),
                                         ('espec_sys', ctypes.c_double)] + [
                     (k, ctypes.c_int32) for k in
-                    ('npix', 'S', 'ntp', 'log_step', 'nd', 'fast_interp')]
+                    ('npix', 'S', 'ntp', 'log_step', 'nd', 'fast_interp')] + [
+                    ('grid_id', ctypes.c_void_p), ('polys_stride', ctypes.c_int64),
+                    ('G', ctypes.c_int32), ('reserved_', ctypes.c_int32)]
 
 
 class ObjectiveArm(ctypes.Structure):

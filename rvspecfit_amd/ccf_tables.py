@@ -53,14 +53,25 @@ def interp_spline_tables(nodes, lam, k=2):
     assert n == m + k + 1
 
     def basis(xs):
-        Eb = np.zeros((len(xs), k + 1))
-        El = np.zeros(len(xs), dtype=np.int32)
-        for r, x in enumerate(xs):
-            l = np.searchsorted(t, x, 'right') - 1
-            l = min(max(l, k), n - k - 2)   # ext=0: end pieces extrapolate
-            Eb[r] = _bspl_basis(t, k, x, l)
-            El[r] = l - k
-        return Eb, El
+        # FITPACK fpbspl for k = 2, all abscissae at once (the operations of
+        # _bspl_basis in the same order: the same values)
+        xs = np.asarray(xs, dtype=np.float64)
+        l = np.searchsorted(t, xs, 'right') - 1
+        l = np.minimum(np.maximum(l, k), n - k - 2)   # ext=0: end pieces extrapolate
+        tl, tl1, tl2, tlm1 = t[l], t[l + 1], t[l + 2], t[l - 1]
+        # j = 1
+        f = 1.0 / (tl1 - tl)
+        a0 = f * (tl1 - xs)
+        a1 = f * (xs - tl)
+        # j = 2
+        f = a0 / (tl1 - tlm1)
+        h0 = f * (tl1 - xs)
+        h1 = f * (xs - tlm1)
+        f = a1 / (tl2 - tl)
+        h1 = h1 + f * (tl2 - xs)
+        h2 = f * (xs - tl)
+        Eb = np.stack([h0, h1, h2], axis=1)
+        return Eb, (l - k).astype(np.int32)
 
     Cb, Cl = basis(nodes)
     C = np.zeros((m, m))

@@ -580,8 +580,30 @@ __global__ void __launch_bounds__(PP_NT)
                           double *__restrict__ proc_spec,
                           double *__restrict__ proc_ivar, double *__restrict__ sse,
                           double *__restrict__ cont_out,
-                          double *__restrict__ pfit, int32_t *__restrict__ status) {
+                          double *__restrict__ pfit, int32_t *__restrict__ status,
+                          const int32_t *__restrict__ gid,
+                          const int32_t *__restrict__ npix_g,
+                          const int32_t *__restrict__ nnode_g) {
   extern __shared__ double sm[];
+  // Grid sets (rvs_ccf_preprocess_g): the spectrum of this block is observed on
+  // grid g = gid[b] with npix_g[g] pixels and nnode_g[g] continuum nodes; every
+  // table holds one slice per grid, npix / nnode (the kernel arguments) apart.
+  const int npix_s = npix, nnode_s = nnode;   // row strides (= the largest grid)
+  if (gid) {
+    const int g = gid[blockIdx.x];
+    npix = npix_g[g];
+    nnode = nnode_g[g];
+    lam += (int64_t)g * npix_s;
+    xind += (int64_t)g * nfft;
+    rw += (int64_t)g * nfft;
+    if (continuum) {
+      Eb += (int64_t)g * 3 * npix_s;
+      El += (int64_t)g * npix_s;
+      Cinv += (int64_t)g * 2 * nnode_s * nnode_s;
+      istart += (int64_t)g * nnode_s;
+      bin_start += (int64_t)g * (nnode_s + 1);
+    }
+  }
   // Three arrays of npix doubles + the mask: 72 KB for a DESI arm, so that TWO
   // 512-thread blocks share a CU.  The kernel is a chain of short phases that
   // barriers and single-wave steps (the LM band solve) separate: with ONE
@@ -596,8 +618,8 @@ __global__ void __launch_bounds__(PP_NT)
   __shared__ LMShared S;
   __shared__ SelShared Q;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const double *sp0 = spec + (int64_t)b * npix;
-  const double *es0 = espec + (int64_t)b * npix;
+  const double *sp0 = spec + (int64_t)b * npix_s;
+  const double *es0 = espec + (int64_t)b * npix_s;
   const double nanv = __builtin_nan("");
 #ifdef RVS_PP_TIMING
   unsigned long long t_prev = wall_clock64();
@@ -606,7 +628,7 @@ __global__ void __launch_bounds__(PP_NT)
   for (int k = tid; k < npix; k += PP_NT) {
     cs[k] = sp0[k];
     ce[k] = es0[k];
-    msk[k] = badmask ? (badmask[(int64_t)b * npix + k] != 0) : 0;
+    msk[k] = badmask ? (badmask[(int64_t)b * npix_s + k] != 0) : 0;
   }
   if (tid == 0) {
     S.flag = 0;
@@ -856,7 +878,7 @@ __global__ void __launch_bounds__(PP_NT)
       const double *Cm = Cinv + m * m;
       double s = 0;
       for (int jj = 0; jj < m; jj++) s = fma(Cm[tid * m + jj], S.c[jj], s);
-      pfit[(int64_t)b * m + tid] = s;
+      pfit[(int64_t)b * nnode_s + tid] = s;
     }
   }
 
@@ -875,7 +897,7 @@ __global__ void __launch_bounds__(PP_NT)
       cont = fmax(1e-2 * medv, cont);
     else
       cont = fmax(cont, 1.0);
-    if (cont_out) cont_out[(int64_t)b * npix + k] = cont;
+    if (cont_out) cont_out[(int64_t)b * npix_s + k] = cont;
     const double e = ce[k];
     double iv = 1.0 / (e * e);
     double c = sp0[k] / cont;
@@ -912,7 +934,7 @@ __global__ void __launch_bounds__(PP_NT)
   PP_T(6);  // rebin
 }
 
-extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
+extern "C" int rvs_ccf_preprocess_g(const double *lam, const double *spec,
                                   const double *espec, const uint8_t *badmask,
                                   int npix, int B, int continuum,
                                   const double *Eb, const int32_t *El,
@@ -921,8 +943,12 @@ extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
                                   const int32_t *xind, const double *rw, int nfft,
                                   double maxerr, double *proc_spec,
                                   double *proc_ivar, double *sse, double *cont,
-                                  double *pfit, int32_t *status, void *stream) {
+                                  double *pfit, int32_t *status,
+                                  const int32_t *grid_id,
+                                  const int32_t *npix_g, const int32_t *nnode_g,
+                                  void *stream) {
   if (npix < 12 || B < 1 || nfft < 2) return RVS_E_ARG;
+  if (grid_id && (!npix_g || (continuum && !nnode_g))) return RVS_E_ARG;
   if (continuum && (nnode < 3 || nnode > CCF_MAXNODE)) return RVS_E_ARG;
   const size_t shm = sizeof(double) * 3 * (size_t)npix + ((npix + 15) / 16) * 16;
   if (shm + sizeof(LMShared) + sizeof(SelShared) > 159 * 1024) return RVS_E_ARG;
@@ -937,9 +963,26 @@ extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
   hipLaunchKernelGGL(ccf_preprocess_kernel, dim3(B), dim3(PP_NT), shm,
                      rvs_stream(stream), lam, spec, espec, badmask, npix,
                      continuum, Eb, El, Cinv, istart, nnode, bin_start, xind, rw,
-                     nfft, maxerr, proc_spec, proc_ivar, sse, cont, pfit, status);
+                     nfft, maxerr, proc_spec, proc_ivar, sse, cont, pfit, status, grid_id,
+                     npix_g, nnode_g);
   RVS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int rvs_ccf_preprocess(const double *lam, const double *spec,
+                                  const double *espec, const uint8_t *badmask,
+                                  int npix, int B, int continuum,
+                                  const double *Eb, const int32_t *El,
+                                  const double *Cinv, const int32_t *istart,
+                                  int nnode, const int32_t *bin_start,
+                                  const int32_t *xind, const double *rw, int nfft,
+                                  double maxerr, double *proc_spec,
+                                  double *proc_ivar, double *sse, double *cont,
+                                  double *pfit, int32_t *status, void *stream) {
+  return rvs_ccf_preprocess_g(lam, spec, espec, badmask, npix, B, continuum, Eb, El,
+                              Cinv, istart, nnode, bin_start, xind, rw, nfft, maxerr,
+                              proc_spec, proc_ivar, sse, cont, pfit, status, nullptr,
+                              nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------

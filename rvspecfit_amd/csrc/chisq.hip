@@ -23,37 +23,51 @@
 #include <type_traits>
 
 // ---------------------------------------------------------------------------
-// work buffer layout (doubles): [0, npix) pixel knot coordinate
+// work buffer layout (doubles): [0, G*npix) pixel knot coordinate
 //   (log lam_k - log x0)/logstep   (or (lam_k - x0)/step for linear knots)
-// [npix, npix + 2*S*npix) {1/e^2, s/e^2} per spectrum pixel
+//   of each of the G wavelength grids of the arm (G = 1: one grid shared by all
+//   spectra; else spectrum s is observed on grid grid_id[s], spec_fit.py:70-145
+//   takes any `lam` per object)
+// [G*npix, G*npix + 2*S*npix) {1/e^2, s/e^2} per spectrum pixel
 // then [2*S] {sum log e, sum s^2/e^2}
+// A grid shorter than npix is padded: lam repeats its last value, the spectra on
+// it carry espec = +inf there -- such a pixel has weight 0 and is left out of
+// sum log e.
 // ---------------------------------------------------------------------------
+extern "C" int64_t rvs_chisq_work_size_g(int npix, int S, int G) {
+  return (int64_t)G * npix + 2ll * S * npix + 2ll * S;
+}
 extern "C" int64_t rvs_chisq_work_size(int npix, int S) {
-  return (int64_t)npix + 2ll * S * npix + 2ll * S;
+  return rvs_chisq_work_size_g(npix, S, 1);
 }
 
 __global__ void __launch_bounds__(256)
     chisq_prepare_kernel(const double *__restrict__ lam,
                          const double *__restrict__ spec,
-                         const double *__restrict__ espec, int npix, int S,
+                         const double *__restrict__ espec, int npix, int S, int G,
                          double x0, double inv_step, int log_step,
                          double espec_sys, double *__restrict__ work) {
   __shared__ double red[8];
   const int s = blockIdx.x;
-  double *pixa = work;
-  double2 *W = reinterpret_cast<double2 *>(work + npix);
-  double *scal = work + npix + 2ll * S * npix;
-  if (s == S) {  // extra block: per-arm pixel coordinates
+  double2 *W = reinterpret_cast<double2 *>(work + (int64_t)G * npix);
+  double *scal = work + (int64_t)G * npix + 2ll * S * npix;
+  if (s >= S) {  // extra blocks: pixel coordinates of grid s - S
     const double lx0 = log(x0);
+    const double *lg = lam + (int64_t)(s - S) * npix;
+    double *pixa = work + (int64_t)(s - S) * npix;
     for (int k = threadIdx.x; k < npix; k += 256)
-      pixa[k] = log_step ? (log(lam[k]) - lx0) * inv_step
-                         : (lam[k] - x0) * inv_step;
+      pixa[k] = log_step ? (log(lg[k]) - lx0) * inv_step
+                         : (lg[k] - x0) * inv_step;
     return;
   }
   double lz = 0, dd = 0;
   const double sys2 = espec_sys * espec_sys;
   for (int k = threadIdx.x; k < npix; k += 256) {
     double e = espec[(int64_t)s * npix + k];
+    if (isinf(e)) {   // padding of a short grid: no weight, no term in sum log e
+      W[(int64_t)s * npix + k] = make_double2(0.0, 0.0);
+      continue;
+    }
     if (espec_sys > 0) e = sqrt(sys2 + e * e);
     const double sp = spec[(int64_t)s * npix + k];
     const double d = sp / e;
@@ -68,6 +82,14 @@ __global__ void __launch_bounds__(256)
     scal[2 * s + 1] = dd;
   }
 }
+
+// The G wavelength grids of an arm: spectrum s is on grid gid[s] (nullptr: all on
+// grid 0); basis tables of consecutive grids are polys_stride doubles apart.
+struct GridSet {
+  const int32_t *gid;
+  int64_t polys_stride;
+  int G;
+};
 
 // packed lower-triangular index
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
@@ -186,8 +208,8 @@ __device__ __forceinline__ void cg_sload4(cg_d2 &d, const double2 *p) {
 // cache instead of the gathers).  tools/perf/experiments/chisq_grid_dpp_lds.patch.
 // waves per SIMD the register budget is held to (168 / 256 VGPRs)
 #define CG_WAVES(P) ((P) <= 10 ? 3 : 2)
-// npoly 13..16 (the reference's own tests and the WEAVE driver run 15): the
-// P (P + 3) / 2 = 104..152 sums of a lane do not fit the 256 registers of two
+// npoly 14..16 (the reference's own tests and the WEAVE driver run 15): the
+// P (P + 3) / 2 = 119..152 sums of a lane do not fit the 256 registers of two
 // waves per SIMD (round 3: 512 VGPRs + scratch, ONE wave per SIMD).  There the
 // pixel loop runs TWICE, the first time for the rows i < CG_SPLIT(P) of the
 // normal equations, the second time for the others: a pass holds about half of
@@ -196,7 +218,7 @@ __device__ __forceinline__ void cg_sload4(cg_d2 &d, const double2 *p) {
 // it costs is the second evaluation of the spline and of the P products P_j w
 // per pixel (215 instead of 175 fp64 operations per pixel-velocity at P = 15).
 __host__ __device__ constexpr int cg_split(int P) {
-  if (P <= 12) return P;
+  if (P <= 13) return P;   // (13: 104 sums, 251 VGPRs, no scratch in one pass)
   int pa = 1;
   while (pa < P && pa * (pa + 3) < P * (P + 3) / 2) pa++;
   return pa;
@@ -229,7 +251,7 @@ __device__ __forceinline__ void
                       int Nv, int iv0, int lpj,
                       const double *__restrict__ penalty, double badchi,
                       double beta_out, double *__restrict__ out,
-                      int32_t *__restrict__ status) {
+                      int32_t *__restrict__ status, const GridSet GS) {
   // lane -> (job j, velocity index iv)
   int j, iv;
   bool active;
@@ -268,13 +290,22 @@ __device__ __forceinline__ void
     return;
   }
 
-  const double *pixa = work;
-  const double2 *W0 = reinterpret_cast<const double2 *>(work + npix);
+  // the wavelength grid of the spectrum (full waves only: the launcher does not
+  // pack lanes of different jobs when the arm has more than one grid)
+  // (wave-uniform: the rows below are fetched with scalar loads)
+  int gsel = 0;
+  if (!TAIL && GS.gid) gsel = GS.gid[__builtin_amdgcn_readfirstlane(s)];
+  gsel = __builtin_amdgcn_readfirstlane(gsel);
+  lam += (int64_t)gsel * npix;
+  polysT += (int64_t)gsel * GS.polys_stride;
+  const double *pixa = work + (int64_t)gsel * npix;
+  const double2 *W0 =
+      reinterpret_cast<const double2 *>(work + (int64_t)GS.G * npix);
   // TAIL: byte offset of the lane's spectrum inside the {1/e^2, s/e^2} block
   // (the launcher checks that it fits 32 bits)
   const uint32_t woff = TAIL ? (uint32_t)s * (uint32_t)npix * 16u : 0u;
   const double2 *W = W0 + (TAIL ? 0 : (int64_t)s * npix);
-  const double *scal = work + npix + 2ll * S * npix + 2 * s;
+  const double *scal = work + (int64_t)GS.G * npix + 2ll * S * npix + 2 * s;
   const double4 *cf = coef + (int64_t)t * ntp;
 
   const double vel = vels[(int64_t)j * vel_stride + iv];
@@ -554,7 +585,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(
                       int Nv, int iv0, int lpj, int nfull,
                       const double *__restrict__ penalty, double badchi,
                       double beta_out, double *__restrict__ out,
-                      int32_t *__restrict__ status) {
+                      int32_t *__restrict__ status, const GridSet GS) {
   int bx = blockIdx.x, by = 0;
 #ifdef CG_CLOCK
   unsigned long long c0 = 0, r0 = 0;
@@ -578,7 +609,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(
   chisq_grid_body<P, TAIL>(bx, by, lam, polysT, work, npix, S,
                            knots, coef, ntp, log_step, job_spec, job_templ, J,
                            vels, vel_stride, Nv, iv0, lpj, penalty, badchi,
-                           beta_out, out, status);
+                           beta_out, out, status, GS);
 #ifdef CG_CLOCK
   if (blockIdx.x == 4096 && threadIdx.x == 0) {
     cg_clock_dbg[0] = __builtin_readcyclecounter() - c0;
@@ -1008,7 +1039,7 @@ static int launch_grid(const double *lam, const double *polysT,
                        const double *vels, int64_t vel_stride, int Nv,
                        const double *penalty, double badchi, double beta,
                        double *out, int32_t *status, int pack_min_jobs,
-                       hipStream_t st) {
+                       const GridSet GS, hipStream_t st) {
   // left-over velocities of a job (Nv % 64) are packed with those of other jobs
   // in a flat (job, velocity) order, J * r lanes in all.  Thresholds measured
   // with the round-3 kernels (three waves per SIMD in both variants; cg_bench,
@@ -1023,8 +1054,8 @@ static int launch_grid(const double *lam, const double *polysT,
   int r = Nv % 64;
   if (pack_min_jobs == 0) pack_min_jobs = 2000;
   if (r > CG_PACK_MAXR || pack_min_jobs < 0 || J < pack_min_jobs ||
-      (int64_t)S * npix * 16 >= (1ll << 32))
-    r = 0;
+      (int64_t)S * npix * 16 >= (1ll << 32) || GS.gid)
+    r = 0;   // (grid sets: a packed wave would need a basis row per lane)
   const int nfull = r ? Nv / 64 : (Nv + 63) / 64;   // waves per job, TAIL=false
   const int iv0 = r ? Nv - r : Nv;
   const double4 *cf = reinterpret_cast<const double4 *>(coef);
@@ -1046,7 +1077,7 @@ static int launch_grid(const double *lam, const double *polysT,
                        dim3((unsigned)(((int64_t)J * r + 63) / 64)),
                        dim3(64), 0, ts, lam, polysT, work, npix, S, knots, cf,
                        ntp, log_step, job_spec, job_templ, J, vels, vel_stride,
-                       Nv, iv0, r, 0, penalty, badchi, beta, out, status);
+                       Nv, iv0, r, 0, penalty, badchi, beta, out, status, GS);
     RVS_LAUNCH_CHECK();
     if (fk && hipEventRecord(fk->join, fk->side) != hipSuccess)
       return RVS_E_LAUNCH;
@@ -1057,7 +1088,8 @@ static int launch_grid(const double *lam, const double *polysT,
     hipLaunchKernelGGL((chisq_grid_kernel<P, false>), dim3((unsigned)nb),
                        dim3(64), 0, st, lam, polysT, work, npix, S, knots, cf,
                        ntp, log_step, job_spec, job_templ, J, vels, vel_stride,
-                       Nv, iv0, 64, nfull, penalty, badchi, beta, out, status);
+                       Nv, iv0, 64, nfull, penalty, badchi, beta, out, status,
+                       GS);
     RVS_LAUNCH_CHECK();
   }
   if (fk && hipStreamWaitEvent(st, fk->join, 0) != hipSuccess)
@@ -1065,13 +1097,13 @@ static int launch_grid(const double *lam, const double *polysT,
   return 0;
 }
 
-extern "C" int rvs_chisq_prepare(const double *lam, const double *spec,
-                                 const double *espec, int npix, int S,
-                                 const double *knots_host3, int log_step,
-                                 double espec_sys, double *work, void *stream) {
+extern "C" int rvs_chisq_prepare_g(const double *lam, const double *spec,
+                                   const double *espec, int npix, int S, int G,
+                                   const double *knots_host3, int log_step,
+                                   double espec_sys, double *work, void *stream) {
   // knots_host3: HOST pointer to the first three knots (uniformity test of
   // spliner.c:84-96 is done here, on the host, once per arm)
-  if (npix < 1 || S < 1 || !work) return RVS_E_ARG;
+  if (npix < 1 || S < 1 || G < 1 || !work) return RVS_E_ARG;
   const double x0 = knots_host3[0], x1 = knots_host3[1], x2 = knots_host3[2];
   double step, step2;
   if (log_step) {
@@ -1082,11 +1114,50 @@ extern "C" int rvs_chisq_prepare(const double *lam, const double *spec,
     step2 = x2 - x1;
   }
   if (fabs(step - step2) > 1e-10) return -3;  // evaler's -2
-  hipLaunchKernelGGL(chisq_prepare_kernel, dim3(S + 1), dim3(256), 0,
-                     rvs_stream(stream), lam, spec, espec, npix, S, x0,
+  hipLaunchKernelGGL(chisq_prepare_kernel, dim3(S + G), dim3(256), 0,
+                     rvs_stream(stream), lam, spec, espec, npix, S, G, x0,
                      1.0 / step, log_step, espec_sys, work);
   RVS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int rvs_chisq_prepare(const double *lam, const double *spec,
+                                 const double *espec, int npix, int S,
+                                 const double *knots_host3, int log_step,
+                                 double espec_sys, double *work, void *stream) {
+  return rvs_chisq_prepare_g(lam, spec, espec, npix, S, 1, knots_host3, log_step,
+                             espec_sys, work, stream);
+}
+
+extern "C" int rvs_chisq_grid_g(const double *lam, const double *polysT,
+                                const double *work, int npix, int npoly, int S,
+                                const int32_t *grid_id, int G,
+                                int64_t polys_stride, const double *knots,
+                                const double *coef, int ntp, int Tn, int log_step,
+                                const int32_t *job_spec, const int32_t *job_templ,
+                                int J, const double *vels, int64_t vel_stride,
+                                int Nv, const double *penalty, double badchi,
+                                double beta, int pack_min_jobs, double *out,
+                                int32_t *status, void *stream) {
+  (void)Tn;
+  if (J < 1 || Nv < 1 || npix < 1 || ntp < 3 || G < 1 || (G > 1 && !grid_id))
+    return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G};
+#define RVS_CASE(PP)                                                          \
+  case PP:                                                                    \
+    return launch_grid<PP>(lam, polysT, work, npix, S, knots, coef, ntp,      \
+                           log_step, job_spec, job_templ, J, vels, vel_stride, \
+                           Nv, penalty, badchi, beta, out, status,       \
+                           pack_min_jobs, GS, st);
+  switch (npoly) {
+    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
+    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
+    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
+    default:
+      return RVS_E_ARG;
+  }
+#undef RVS_CASE
 }
 
 extern "C" int rvs_chisq_grid(const double *lam, const double *polysT,
@@ -1098,23 +1169,10 @@ extern "C" int rvs_chisq_grid(const double *lam, const double *polysT,
                               const double *penalty, double badchi, double beta,
                               int pack_min_jobs, double *out, int32_t *status,
                               void *stream) {
-  (void)Tn;
-  if (J < 1 || Nv < 1 || npix < 1 || ntp < 3) return RVS_E_ARG;
-  hipStream_t st = rvs_stream(stream);
-#define RVS_CASE(PP)                                                          \
-  case PP:                                                                    \
-    return launch_grid<PP>(lam, polysT, work, npix, S, knots, coef, ntp,      \
-                           log_step, job_spec, job_templ, J, vels, vel_stride, \
-                           Nv, penalty, badchi, beta, out, status,       \
-                           pack_min_jobs, st);
-  switch (npoly) {
-    RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
-    RVS_CASE(7) RVS_CASE(8) RVS_CASE(9) RVS_CASE(10) RVS_CASE(11) RVS_CASE(12)
-    RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
-    default:
-      return RVS_E_ARG;
-  }
-#undef RVS_CASE
+  return rvs_chisq_grid_g(lam, polysT, work, npix, npoly, S, nullptr, 1, 0, knots,
+                          coef, ntp, Tn, log_step, job_spec, job_templ, J, vels,
+                          vel_stride, Nv, penalty, badchi, beta, pack_min_jobs,
+                          out, status, stream);
 }
 
 extern "C" int rvs_chisq_grid_resol(
@@ -1225,7 +1283,7 @@ __global__ void __launch_bounds__(256)
                       double *__restrict__ chisq, double *__restrict__ coeffs,
                       double *__restrict__ model, double *__restrict__ raw_model,
                       double *__restrict__ true_chisq, int32_t *__restrict__ ngood,
-                      int32_t *__restrict__ status) {
+                      int32_t *__restrict__ status, const GridSet GS) {
   extern __shared__ double sm[];
   double *tvs = sm;                 // [npix]   template / e
   double *Ds = sm + npix;           // [npix]   spec / e
@@ -1243,6 +1301,11 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   const double *sp = spec + (int64_t)s * npix;
   const double *es = espec + (int64_t)s * npix;
+  if (GS.gid) {   // the spectrum's own wavelength grid and basis
+    const int g = GS.gid[s];
+    lam += (int64_t)g * npix;
+    polysT += (int64_t)g * GS.polys_stride;
+  }
   const double sys2 = espec_sys * espec_sys;
   double f = 1, x0 = 0, xlast = 0, inv_step = 0, lx0 = 0;
   const double4 *cf = coef + (int64_t)t * ntp;
@@ -1308,6 +1371,11 @@ __global__ void __launch_bounds__(256)
     }
     if (raw_model) raw_model[(int64_t)j * npix + k] = tv;
     double e = es[k];
+    if (isinf(e)) {   // padding of a short grid (rvs_chisq_prepare_g)
+      tvs[k] = 0.0;
+      Ds[k] = 0.0;
+      continue;
+    }
     if (espec_sys > 0) e = sqrt(sys2 + e * e);
     lz += log(e);
     tvs[k] = tv / e;
@@ -1408,6 +1476,10 @@ __global__ void __launch_bounds__(256)
     // model in flux units: coeffs . (polys * templ); true chi^2 uses the
     // ORIGINAL error vector (spec_fit.py:952)
     double e = es[k];
+    if (isinf(e)) {
+      if (model) model[(int64_t)j * npix + k] = 0.0;
+      continue;
+    }
     double ee = e;
     if (espec_sys > 0) ee = sqrt(sys2 + e * e);
     const double mod = m * tvs[k] * ee;
@@ -1436,7 +1508,7 @@ __global__ void __launch_bounds__(256)
     for (int i = tid; i < P; i += 256) coeffs[(int64_t)j * P + i] = aa[i];
 }
 
-extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
+extern "C" int rvs_chisq_full_g(const double *lam, const double *polysT,
                               const double *spec, const double *espec,
                               const uint8_t *badmask, int npix, int npoly,
                               int S, const double *knots, const double *coef,
@@ -1447,8 +1519,12 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
                               const double *taps, int nd, int64_t taps_stride,
                               double *chisq, double *coeffs, double *model,
                               double *raw_model, double *true_chisq,
-                              int32_t *ngood, int32_t *status, void *stream) {
+                              int32_t *ngood, int32_t *status,
+                              const int32_t *grid_id, int G, int64_t polys_stride,
+                              void *stream) {
   (void)S;
+  if (G < 1 || (G > 1 && !grid_id)) return RVS_E_ARG;
+  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G};
   (void)Tn;
   if (npoly < 1 || npoly > FULL_MAXP || J < 1 || npix < 1) return RVS_E_ARG;
   if (taps && (nd < 1 || (nd & 1) == 0)) return RVS_E_ARG;
@@ -1469,9 +1545,28 @@ extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
                      npix, npoly, knots, reinterpret_cast<const double4 *>(coef),
                      ntp, log_step, cform, unit_template, job_spec, job_templ,
                      vel, espec_sys, fast_interp, taps, nd, taps_stride, chisq,
-                     coeffs, model, raw_model, true_chisq, ngood, status);
+                     coeffs, model, raw_model, true_chisq, ngood, status, GS);
   RVS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int rvs_chisq_full(const double *lam, const double *polysT,
+                              const double *spec, const double *espec,
+                              const uint8_t *badmask, int npix, int npoly,
+                              int S, const double *knots, const double *coef,
+                              int ntp, int Tn, int log_step, int cform,
+                              int unit_template, const int32_t *job_spec,
+                              const int32_t *job_templ, int J, const double *vel,
+                              double espec_sys, int fast_interp,
+                              const double *taps, int nd, int64_t taps_stride,
+                              double *chisq, double *coeffs, double *model,
+                              double *raw_model, double *true_chisq,
+                              int32_t *ngood, int32_t *status, void *stream) {
+  return rvs_chisq_full_g(lam, polysT, spec, espec, badmask, npix, npoly, S, knots,
+                          coef, ntp, Tn, log_step, cform, unit_template, job_spec,
+                          job_templ, J, vel, espec_sys, fast_interp, taps, nd,
+                          taps_stride, chisq, coeffs, model, raw_model, true_chisq,
+                          ngood, status, nullptr, 1, 0, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -1501,9 +1596,10 @@ __global__ void __launch_bounds__(64)
                           double *__restrict__ chisq,
                           double *__restrict__ true_chisq,
                           int32_t *__restrict__ ngood,
-                          int32_t *__restrict__ status) {
+                          int32_t *__restrict__ status, const GridSet GS) {
   constexpr int NT = P * (P + 1) / 2;
   const int s = blockIdx.x, lane = threadIdx.x;
+  if (GS.gid) polysT += (int64_t)GS.gid[s] * GS.polys_stride;
   const double *sp = spec + (int64_t)s * npix;
   const double *es = espec + (int64_t)s * npix;
   const uint8_t *bm = badmask ? badmask + (int64_t)s * npix : nullptr;
@@ -1518,10 +1614,10 @@ __global__ void __launch_bounds__(64)
   double lz = 0, dd = 0;
   for (int k = lane; k < npix; k += 64) {
     const double e = es[k], x = sp[k];
-    const double ie = 1.0 / e;
+    const double ie = 1.0 / e;   // (0 on the padding of a short grid)
     const double tv = ut ? ut[k] : 1.0;
     const double w = (tv * ie) * (tv * ie), u = (tv * ie) * (x * ie);
-    lz += log(e);
+    lz += isinf(e) ? 0.0 : log(e);
     dd = fma(x * ie, x * ie, dd);
     const double *pr = polysT + (int64_t)k * P;
     double prow[P], pw[P];
@@ -1615,21 +1711,24 @@ extern "C" int64_t rvs_chisq_continuum_work_size(int npoly, int S) {
   return 8;
 }
 
-extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
+extern "C" int rvs_chisq_continuum_g(const double *polysT, const double *spec,
                                    const double *espec, const uint8_t *badmask,
                                    const double *unit_templ, int npix, int npoly,
                                    int S, void *work,
                                    double *chisq, double *true_chisq,
                                    int32_t *ngood, int32_t *status,
-                                   void *stream) {
+                                   const int32_t *grid_id, int G,
+                                   int64_t polys_stride, void *stream) {
   (void)work;
+  if (G < 1 || (G > 1 && !grid_id)) return RVS_E_ARG;
+  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G};
   if (S < 1 || npix < 1 || !true_chisq || !ngood) return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
 #define RVS_CASE(PP)                                                           \
   case PP:                                                                     \
     hipLaunchKernelGGL(continuum_wave_kernel<PP>, dim3(S), dim3(64), 0, st,    \
                        polysT, spec, espec, unit_templ, badmask, npix, S,      \
-                       chisq, true_chisq, ngood, status);                      \
+                       chisq, true_chisq, ngood, status, GS);                  \
     break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
@@ -1641,6 +1740,18 @@ extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
 #undef RVS_CASE
   RVS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int rvs_chisq_continuum(const double *polysT, const double *spec,
+                                   const double *espec, const uint8_t *badmask,
+                                   const double *unit_templ, int npix, int npoly,
+                                   int S, void *work,
+                                   double *chisq, double *true_chisq,
+                                   int32_t *ngood, int32_t *status,
+                                   void *stream) {
+  return rvs_chisq_continuum_g(polysT, spec, espec, badmask, unit_templ, npix,
+                               npoly, S, work, chisq, true_chisq, ngood, status,
+                               nullptr, 1, 0, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -1661,12 +1772,28 @@ struct PointArms {
   int n;
 };
 
-__device__ __forceinline__ double point_tv(const rvs_point_arm &T,
+// the grid of spectrum s on an arm: wavelengths, pixel knot coordinates, basis,
+// and the base of the per-spectrum blocks of the rvs_chisq_prepare buffer
+struct ArmGrid {
+  const double *lam, *pix, *polysT, *wbase;
+};
+__device__ __forceinline__ ArmGrid arm_grid(const rvs_point_arm &T, int s) {
+  ArmGrid g;
+  const int G = T.G > 1 ? T.G : 1;
+  const int64_t gi = (T.G > 1 && T.grid_id) ? T.grid_id[s] : 0;
+  g.lam = T.lam + gi * T.npix;
+  g.pix = T.work + gi * T.npix;
+  g.polysT = T.polysT + gi * T.polys_stride;
+  g.wbase = T.work + (int64_t)G * T.npix;   // {1/e^2, s/e^2} [S, npix], then scal [S, 2]
+  return g;
+}
+
+__device__ __forceinline__ double point_tv(const rvs_point_arm &T, const ArmGrid &AG,
                                            const double4 *cf, int k, double f,
                                            double shift, double x0,
                                            double lin_inv_step) {
-  const double x = T.lam[k] * f;
-  int pos = T.log_step ? (int)(T.work[k] + shift)
+  const double x = AG.lam[k] * f;
+  int pos = T.log_step ? (int)(AG.pix[k] + shift)
                        : (int)((x - x0) * lin_inv_step);
   pos = min(max(pos, 0), T.ntp - 2);
   const double dl = x - T.knots[pos];
@@ -1697,6 +1824,7 @@ __global__ void __launch_bounds__(256)
   const rvs_point_arm &T = A.a[blockIdx.y];
   const int s = job_spec ? job_spec[j] : j;
   const int t = job_templ ? job_templ[j] : j;
+  const ArmGrid AG = arm_grid(T, s);
   const double bb = vel[j] / RVS_C_KMS;
   const double f = sqrt((1.0 - bb) / (1.0 + bb));
   const double espec_sys = T.espec_sys;
@@ -1714,11 +1842,11 @@ __global__ void __launch_bounds__(256)
   const int nd = T.nd, mres = (T.nd - 1) / 2;
   if (tp) {
     for (int k = threadIdx.x; k < npix; k += 256)
-      rawsh[k] = point_tv(T, cf, k, f, shift, x0, lin_inv_step);
+      rawsh[k] = point_tv(T, AG, cf, k, f, shift, x0, lin_inv_step);
     __syncthreads();
   }
   auto tv_at = [&](int k) {
-    if (!tp) return point_tv(T, cf, k, f, shift, x0, lin_inv_step);
+    if (!tp) return point_tv(T, AG, cf, k, f, shift, x0, lin_inv_step);
     double v = 0;
     for (int d = 0; d < nd; d++) {
       const int q = k - mres + d;
@@ -1739,7 +1867,7 @@ __global__ void __launch_bounds__(256)
     const double ie = 1.0 / e;
     const double te = tv * ie;
     const double wt = te * te, u = te * (sp[k] * ie);
-    const double *pr = T.polysT + (int64_t)k * P;
+    const double *pr = AG.polysT + (int64_t)k * P;
     double pv[P], pw[P];
 #pragma unroll
     for (int i = 0; i < P; i++) {
@@ -1823,7 +1951,7 @@ __global__ void __launch_bounds__(256)
     double e = es[k];
     if (espec_sys > 0) e = sqrt(sys2 + e * e);
     const double ie = 1.0 / e;
-    const double *pr = T.polysT + (int64_t)k * P;
+    const double *pr = AG.polysT + (int64_t)k * P;
     double m = 0;
 #pragma unroll
     for (int i = 0; i < P; i++) m = fma(av[i], pr[i], m);
@@ -1836,10 +1964,10 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   if (threadIdx.x == 0) {
     rr = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
-    const double lz = T.work[npix + 2ll * T.S * npix + 2 * s];
+    const double lz = AG.wbase[2ll * T.S * npix + 2 * s];
     double chi = 2.0 * coefs[P] + 2.0 * lz + rr;
     int st = 0;
-    const double xa = T.lam[0] * f, xb = T.lam[npix - 1] * f;
+    const double xa = AG.lam[0] * f, xb = AG.lam[npix - 1] * f;
     if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) {
       st |= RVS_ST_SPLINE_RANGE;
       chi = __builtin_nan("");

@@ -404,6 +404,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   const rvs_point_arm &S = T.pt;
   const int npix = S.npix;
   const int s = job_spec ? job_spec[j] : j;
+  const ObjArmGrid AG = obj_arm_grid(S, s);   // the spectrum's wavelength grid
   const double bb = vel[j] / RVS_C_KMS;
   const double f = sqrt((1.0 - bb) / (1.0 + bb));
   const double espec_sys = S.espec_sys;
@@ -597,8 +598,8 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
     for (int u = 0; u < PU; u++) {
       const int k = min(tid + u * OBJ_NT, npix - 1);
-      qlm[u] = S.lam[k];
-      qwk[u] = S.log_step ? S.work[k] : 0.0;
+      qlm[u] = AG.lam[k];
+      qwk[u] = S.log_step ? AG.pix[k] : 0.0;
       qe[u] = es[k];
       qs[u] = sp[k];
     }
@@ -657,8 +658,8 @@ __global__ void __launch_bounds__(OBJ_NT)
   // dp[u] = z at knot u+1; spline piece i in powers of dl = x - x_i exactly as
   // rvs_spline_construct(form 1) stores it
   auto tv_at = [&](int k) {
-    const double x = S.lam[k] * f;
-    int pos = S.log_step ? (int)(S.work[k] + shift)
+    const double x = AG.lam[k] * f;
+    int pos = S.log_step ? (int)(AG.pix[k] + shift)
                          : (int)((x - x0) * lin_inv_step);
     pos = min(max(pos, 0), N - 2);
     const double dl = x - S.knots[pos];
@@ -701,8 +702,8 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int k = min(kb + u * OBJ_NT, npix - 1);
-          lm[u] = S.lam[k];
-          wk[u] = S.log_step ? S.work[k] : 0.0;
+          lm[u] = AG.lam[k];
+          wk[u] = S.log_step ? AG.pix[k] : 0.0;
           e_[u] = es[k];
           s_[u] = sp[k];
         }
@@ -772,7 +773,7 @@ __global__ void __launch_bounds__(OBJ_NT)
     // the FMAs of the current one issue
     double pn[I1];
     {
-      const double *pr = S.polysT + (int64_t)min(tid, npix - 1) * P;
+      const double *pr = AG.polysT + (int64_t)min(tid, npix - 1) * P;
 #pragma unroll
       for (int i = 0; i < I1; i++) pn[i] = pr[i];
     }
@@ -784,7 +785,7 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
       for (int i = 0; i < I1; i++) pv[i] = pn[i];
       {
-        const double *pr = S.polysT + (int64_t)min(k + OBJ_NT, npix - 1) * P;
+        const double *pr = AG.polysT + (int64_t)min(k + OBJ_NT, npix - 1) * P;
 #pragma unroll
         for (int i = 0; i < I1; i++) pn[i] = pr[i];
       }
@@ -834,7 +835,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   double qp[RPF][P];
 #pragma unroll
   for (int u = 0; u < RPF; u++) {
-    const double *prow = S.polysT + (int64_t)min(tid + u * OBJ_NT, npix - 1) * P;
+    const double *prow = AG.polysT + (int64_t)min(tid + u * OBJ_NT, npix - 1) * P;
 #pragma unroll
     for (int i = 0; i < P; i++) qp[u][i] = prow[i];
   }
@@ -960,7 +961,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   for (int k = kres; k < npix; k += OBJ_NT) {
     double te, dk;
     te_dk(k, te, dk);
-    const double *pr = S.polysT + (int64_t)k * P;
+    const double *pr = AG.polysT + (int64_t)k * P;
     double mdl = 0;
 #pragma unroll
     for (int i = 0; i < P; i++) mdl = fma(av[i], pr[i], mdl);
@@ -975,10 +976,10 @@ __global__ void __launch_bounds__(OBJ_NT)
   if (tid == 0) {
     rr = red[0][0];
     for (int q = 1; q < OBJ_NW; q++) rr += red[q][0];
-    const double lz = S.work[npix + 2ll * S.S * npix + 2 * s];
+    const double lz = AG.wbase[2ll * S.S * npix + 2 * s];
     double chi = 2.0 * coefs[P] + 2.0 * lz + rr;
     int st = st_extra;
-    const double xa = S.lam[0] * f, xb = S.lam[npix - 1] * f;
+    const double xa = AG.lam[0] * f, xb = AG.lam[npix - 1] * f;
     if (xa < x0 || xb < x0 || xa >= xlast || xb >= xlast) {
       st |= RVS_ST_SPLINE_RANGE;
       chi = __builtin_nan("");

@@ -15,6 +15,23 @@
   RVS_CASE(12) RVS_CASE(13) RVS_CASE(14) RVS_CASE(15) RVS_CASE(16)
 #endif
 
+// the grid of spectrum s on an arm (rvs_point_arm.grid_id, include/rvsgpu.h):
+// wavelengths, pixel knot coordinates, basis, base of the per-spectrum blocks of
+// the rvs_chisq_prepare buffer
+struct ObjArmGrid {
+  const double *lam, *pix, *polysT, *wbase;
+};
+__device__ __forceinline__ ObjArmGrid obj_arm_grid(const rvs_point_arm &T, int s) {
+  ObjArmGrid g;
+  const int G = T.G > 1 ? T.G : 1;
+  const int64_t gi = (T.G > 1 && T.grid_id) ? T.grid_id[s] : 0;
+  g.lam = T.lam + gi * T.npix;
+  g.pix = T.work + gi * T.npix;
+  g.polysT = T.polysT + gi * T.polys_stride;
+  g.wbase = T.work + (int64_t)G * T.npix;
+  return g;
+}
+
 struct ObjArms {
   rvs_objective_arm a[RVS_MAX_ARMS];
   int n;

@@ -107,18 +107,47 @@ def resol_taps(mats, npix):
 
 
 class ArmData:
-    """One spectral arm of a batch: S spectra on a common wavelength grid.
+    """One spectral arm of a batch: S spectra on a common wavelength grid -- or,
+    with `grid_id`, on G grids of their own (the reference takes any `lam` per
+    object, spec_fit.py:70-145; SDSS-style spectra, tests/test_sdss.py): `lam` is
+    then a list of G wavelength arrays and grid_id[s] the grid of spectrum s; spec
+    / espec / badmask are [S, npix] with npix the longest grid, a spectrum on a
+    shorter grid padded behind its last pixel (any spec, espec and badmask are
+    overwritten there).  The kernels read the grid, the pixel coordinates and the
+    continuum basis of a job's own grid (include/rvsgpu.h, "grid sets").
     resolution: None, or a list of S scipy.sparse matrices (SpecData.resolution
     .mat, spec_fit.py:54-67) applied to the resampled template (A9)."""
 
     def __init__(self, name, lam, spec, espec, badmask=None, device='cuda',
-                 resolution=None):
+                 resolution=None, grid_id=None):
         _lib.require_gpu()
         self.name = name
         self.device = device
-        self.lam_host = np.ascontiguousarray(lam, dtype=np.float64)
-        self.npix = len(self.lam_host)
-        self.lam = torch.as_tensor(self.lam_host).to(device)
+        if grid_id is None:
+            self.G = 1
+            self.lam_host = np.ascontiguousarray(lam, dtype=np.float64)
+            self.npix = len(self.lam_host)
+            self.npix_g = np.array([self.npix], dtype=np.int32)
+            self.grids = [self.lam_host]
+            self.grid_id = self.grid_id_host = None
+            self.lam = torch.as_tensor(self.lam_host).to(device)
+        else:
+            self.grids = [np.ascontiguousarray(g, dtype=np.float64) for g in lam]
+            self.G = len(self.grids)
+            self.npix_g = np.array([len(g) for g in self.grids], dtype=np.int32)
+            self.npix = int(self.npix_g.max())
+            lam2 = np.empty((self.G, self.npix))
+            for i, g in enumerate(self.grids):   # padding repeats the last pixel
+                lam2[i, :len(g)] = g
+                lam2[i, len(g):] = g[-1]
+            # (lam_host: the longest grid, for code that only needs the arm's
+            # extent -- overlap checks use grid_extent())
+            self.lam_host = self.grids[int(np.argmax(self.npix_g))]
+            self.grid_id_host = np.ascontiguousarray(grid_id, dtype=np.int32)
+            assert self.grid_id_host.min() >= 0 and \
+                self.grid_id_host.max() < self.G
+            self.grid_id = torch.as_tensor(self.grid_id_host).to(device)
+            self.lam = torch.as_tensor(lam2).to(device)
         self.spec = self._as2d(spec, torch.float64)
         self.espec = self._as2d(espec, torch.float64)
         self.S = self.spec.shape[0]
@@ -129,6 +158,19 @@ class ArmData:
             self.badmask = self._as2d(badmask, torch.uint8)
         assert self.spec.shape == self.espec.shape == self.badmask.shape
         assert self.spec.shape[1] == self.npix
+        if self.G > 1:
+            assert resolution is None, \
+                'resolution matrices need one wavelength grid per arm'
+            assert len(self.grid_id_host) == self.S
+            # the padding: no weight (espec = +inf is the kernels' marker), masked
+            n_s = torch.as_tensor(self.npix_g).to(device)[self.grid_id.long()]
+            pad = torch.arange(self.npix, device=device)[None, :] >= n_s[:, None]
+            if bool(pad.any()):
+                self.spec = torch.where(pad, torch.zeros_like(self.spec), self.spec)
+                self.espec = torch.where(pad, torch.full_like(self.espec, np.inf),
+                                         self.espec)
+                self.badmask = torch.where(pad, torch.ones_like(self.badmask),
+                                           self.badmask)
         self._basis = {}
         self._work = {}
         self._ccf = {}
@@ -143,6 +185,11 @@ class ArmData:
 
     def subset(self, idx):
         """ArmData of the spectra idx (device long tensor)"""
+        if self.G > 1:
+            a = ArmData(self.name, self.grids, self.spec[idx], self.espec[idx],
+                        self.badmask[idx], device=self.device,
+                        grid_id=self.grid_id[idx].cpu().numpy())
+            return a
         a = ArmData(self.name, self.lam_host, self.spec[idx], self.espec[idx],
                     self.badmask[idx], device=self.device)
         if self.resol is not None:
@@ -165,14 +212,29 @@ class ArmData:
             t = t[None, :]
         return t.contiguous()
 
+    def grid_extent(self):
+        """(largest first wavelength, smallest last wavelength) over the grids"""
+        return max(g[0] for g in self.grids), min(g[-1] for g in self.grids)
+
+    def grid_args(self):
+        """(grid_id pointer, G) of the _g entry points"""
+        return (_lib.ptr(self.grid_id) if self.G > 1 else None), self.G
+
+    def basis_stride(self, npoly):
+        """doubles between the basis tables of consecutive grids"""
+        return (self.npix + 1) * npoly
+
     def basis(self, npoly, rbf):
-        """pixel-major continuum basis get_poly_basis(lam).T (+ one zero row)"""
+        """pixel-major continuum basis get_poly_basis(lam).T (+ one zero row) of
+        every grid: [npix + 1, npoly], or [G, npix + 1, npoly] (rows behind a
+        grid's last pixel are zero)"""
         key = (npoly, bool(rbf))
         if key not in self._basis:
-            P = get_poly_basis(self.lam_host, npoly, rbf)
-            PT = np.zeros((self.npix + 1, npoly))
-            PT[:self.npix] = P.T
-            self._basis[key] = torch.as_tensor(PT).to(self.device)
+            PT = np.zeros((self.G, self.npix + 1, npoly))
+            for i, g in enumerate(self.grids):
+                PT[i, :len(g)] = get_poly_basis(g, npoly, rbf).T
+            self._basis[key] = torch.as_tensor(
+                PT[0] if self.G == 1 else PT).to(self.device)
         return self._basis[key]
 
     def basis_ortho(self, npoly, rbf):
@@ -183,15 +245,24 @@ class ArmData:
         so the kernel works on M' (condition number ~1-10 instead of 1e4-1e5 for
         the monomial + RBF basis, which keeps the normal-equation rounding error
         of the in-register Cholesky at the 1e-10 level even at S/N 1000) and the
-        constant 2 log|det R| is added back.  Returns (Q^T pixel-major, const)."""
+        constant 2 log|det R| is added back.  Returns (Q^T pixel-major, const):
+        const is a float for one grid, a device tensor [S] (the constant of every
+        spectrum's grid) for a grid set."""
         key = ('ortho', npoly, bool(rbf))
         if key not in self._basis:
-            P = get_poly_basis(self.lam_host, npoly, rbf)
-            Q, R = np.linalg.qr(P.T)
-            QT = np.zeros((self.npix + 1, npoly))
-            QT[:self.npix] = Q
-            off = 2.0 * float(np.sum(np.log(np.abs(np.diag(R)))))
-            self._basis[key] = (torch.as_tensor(QT).to(self.device), off)
+            QT = np.zeros((self.G, self.npix + 1, npoly))
+            off = np.zeros(self.G)
+            for i, g in enumerate(self.grids):
+                P = get_poly_basis(g, npoly, rbf)
+                Q, R = np.linalg.qr(P.T)
+                QT[i, :len(g)] = Q
+                off[i] = 2.0 * float(np.sum(np.log(np.abs(np.diag(R)))))
+            if self.G == 1:
+                self._basis[key] = (torch.as_tensor(QT[0]).to(self.device),
+                                    float(off[0]))
+            else:
+                offs = torch.as_tensor(off).to(self.device)[self.grid_id.long()]
+                self._basis[key] = (torch.as_tensor(QT).to(self.device), offs)
         return self._basis[key]
 
     def work(self, lib, espec_sys=0.0):
@@ -199,13 +270,13 @@ class ArmData:
         key = (lib.name, id(lib), float(espec_sys))
         if key not in self._work:
             L = _lib.lib()
-            n = L.rvs_chisq_work_size(self.npix, self.S)
+            n = L.rvs_chisq_work_size_g(self.npix, self.S, self.G)
             w = torch.empty(n, dtype=torch.float64, device=self.device)
-            rc = L.rvs_chisq_prepare(_lib.ptr(self.lam), _lib.ptr(self.spec),
-                                     _lib.ptr(self.espec), self.npix, self.S,
-                                     _lib.ptr(lib.knots3), int(lib.log_step),
-                                     float(espec_sys), _lib.ptr(w),
-                                     _lib.stream())
+            rc = L.rvs_chisq_prepare_g(_lib.ptr(self.lam), _lib.ptr(self.spec),
+                                       _lib.ptr(self.espec), self.npix, self.S,
+                                       self.G, _lib.ptr(lib.knots3),
+                                       int(lib.log_step), float(espec_sys),
+                                       _lib.ptr(w), _lib.stream())
             if rc == -3:
                 raise AssertionError('spline knots are not uniformly spaced')
             _lib.check(rc, 'rvs_chisq_prepare')
@@ -246,29 +317,55 @@ class ArmData:
         T['lag_vel'] = torch.as_tensor(sub).to(dev)
         T['nlag'] = len(ind)
         T['ilo'] = torch.as_tensor(ccf_tables.interp_tables(sub, vgrid)).to(dev)
-        xi, rw = ccf_tables.rebin_tables(self.lam_host, cc['logl0'], cc['logl1'],
-                                         nfft)
-        T['xind'] = torch.as_tensor(xi).to(dev)
-        T['rw'] = torch.as_tensor(rw).to(dev)
+        # per wavelength grid: rebin tables, and the continuum-spline tables (the
+        # node count follows the grid's range, make_ccf.py:123-131); one slice per
+        # grid, the longest grid / largest node count apart (rvs_ccf_preprocess_g)
+        G = self.G
+        xi = np.empty((G, nfft), dtype=np.int32)
+        rw = np.empty((G, nfft))
+        per = []
+        for i, g in enumerate(self.grids):
+            xi[i], rw[i] = ccf_tables.rebin_tables(g, cc['logl0'], cc['logl1'], nfft)
+            if cc['continuum']:
+                nodes, edges = ccf_tables.continuum_nodes(g, cc['splinestep'])
+                per.append((nodes, edges) + ccf_tables.interp_spline_tables(nodes, g))
+        T['xind'] = torch.as_tensor(xi if G > 1 else xi[0]).to(dev)
+        T['rw'] = torch.as_tensor(rw if G > 1 else rw[0]).to(dev)
         tw = np.exp(2j * np.pi * np.arange(nfft // 2) / nfft)
         T['twid'] = torch.as_tensor(
             np.ascontiguousarray(tw).view(np.float64)).to(dev)
+        T['npix_g'] = T['nnode_g'] = None
         if cc['continuum']:
-            nodes, edges = ccf_tables.continuum_nodes(self.lam_host,
-                                                      cc['splinestep'])
-            Eb, El, Cinv, istart = ccf_tables.interp_spline_tables(
-                nodes, self.lam_host)
-            T['Eb'] = torch.as_tensor(np.ascontiguousarray(Eb)).to(dev)
-            T['El'] = torch.as_tensor(El).to(dev)
-            T['Cinv'] = torch.as_tensor(np.ascontiguousarray(
-                np.stack([Cinv, np.linalg.inv(Cinv)]))).to(dev)
-            T['istart'] = torch.as_tensor(istart).to(dev)
-            T['nnode'] = len(nodes)
-            T['bin_start'] = torch.as_tensor(
-                ccf_tables.bin_ranges(self.lam_host, edges)).to(dev)
+            nn = max(len(q[0]) for q in per)
+            npx = self.npix
+            Eb = np.zeros((G, npx, 3))
+            El = np.zeros((G, npx), dtype=np.int32)
+            Cinv = np.zeros((G, 2 * nn * nn))
+            istart = np.zeros((G, nn), dtype=np.int32)
+            bst = np.zeros((G, nn + 1), dtype=np.int32)
+            nng = np.zeros(G, dtype=np.int32)
+            for i, (nodes, edges, eb, el, ci, ist) in enumerate(per):
+                m, n_i = len(nodes), len(self.grids[i])
+                Eb[i, :n_i], El[i, :n_i] = eb, el
+                Cinv[i, :m * m] = ci.ravel()
+                Cinv[i, m * m:2 * m * m] = np.linalg.inv(ci).ravel()
+                istart[i, :len(ist)] = ist
+                bst[i, :m + 1] = ccf_tables.bin_ranges(self.grids[i], edges)
+                nng[i] = m
+            one = (G == 1)
+            T['Eb'] = torch.as_tensor(Eb[0] if one else Eb).to(dev)
+            T['El'] = torch.as_tensor(El[0] if one else El).to(dev)
+            T['Cinv'] = torch.as_tensor(Cinv[0] if one else Cinv).to(dev)
+            T['istart'] = torch.as_tensor(istart[0] if one else istart).to(dev)
+            T['bin_start'] = torch.as_tensor(bst[0] if one else bst).to(dev)
+            T['nnode'] = nn
+            if not one:
+                T['nnode_g'] = torch.as_tensor(nng).to(dev)
         else:
             T['Eb'] = T['El'] = T['Cinv'] = T['istart'] = None
             T['nnode'], T['bin_start'] = 0, None
+        if G > 1:
+            T['npix_g'] = torch.as_tensor(self.npix_g).to(dev)
         self._ccf[key] = T
         return T
 
@@ -298,27 +395,51 @@ class SpecBatch:
 
     @classmethod
     def from_specdata(cls, specdata_lists, device='cuda'):
-        """specdata_lists: list (spectra) of lists (arms) of SpecData sharing
-        per-arm wavelength grids."""
+        """specdata_lists: list (spectra) of lists (arms) of SpecData.  The
+        spectra of an arm may share the wavelength grid (one grid, the fast
+        path) or come on grids of their own (SDSS-style objects, spec_fit.py:
+        70-145): the distinct grids of an arm become its grid set, spectra on
+        shorter grids are padded (ArmData)."""
         first = specdata_lists[0]
         arms = []
         for ia, sd0 in enumerate(first):
+            grids, index, gid = [], {}, []
             for sl in specdata_lists:
-                if not np.array_equal(sl[ia].lam, sd0.lam):
-                    raise ValueError('spectra of one arm must share the '
-                                     'wavelength grid to be batched')
+                lam = np.ascontiguousarray(sl[ia].lam, dtype=np.float64)
+                key = (len(lam), lam.tobytes())
+                if key not in index:
+                    index[key] = len(grids)
+                    grids.append(lam)
+                gid.append(index[key])
             res = [getattr(sl[ia], 'resolution', None) for sl in specdata_lists]
             if any(r is not None for r in res) and any(r is None for r in res):
                 raise ValueError('either every spectrum of an arm carries a '
                                  'resolution matrix or none does')
-            arms.append(
-                ArmData(sd0.name, sd0.lam,
-                        np.stack([sl[ia].spec for sl in specdata_lists]),
-                        np.stack([sl[ia].espec for sl in specdata_lists]),
-                        np.stack([np.asarray(sl[ia].badmask, dtype=np.uint8)
-                                  for sl in specdata_lists]), device=device,
-                        resolution=None if res[0] is None else
-                        [r.mat for r in res]))
+            if len(grids) == 1:
+                arms.append(
+                    ArmData(sd0.name, sd0.lam,
+                            np.stack([sl[ia].spec for sl in specdata_lists]),
+                            np.stack([sl[ia].espec for sl in specdata_lists]),
+                            np.stack([np.asarray(sl[ia].badmask, dtype=np.uint8)
+                                      for sl in specdata_lists]), device=device,
+                            resolution=None if res[0] is None else
+                            [r.mat for r in res]))
+                continue
+            if res[0] is not None:
+                raise ValueError('spectra with resolution matrices must share the '
+                                 'wavelength grid of their arm to be batched')
+            npix = max(len(g) for g in grids)
+
+            def padded(attr, fill, dtype):
+                out = np.full((len(specdata_lists), npix), fill, dtype=dtype)
+                for i, sl in enumerate(specdata_lists):
+                    v = np.asarray(getattr(sl[ia], attr))
+                    out[i, :len(v)] = v
+                return out
+            arms.append(ArmData(sd0.name, grids, padded('spec', 0.0, np.float64),
+                                padded('espec', np.inf, np.float64),
+                                padded('badmask', 1, np.uint8), device=device,
+                                grid_id=np.array(gid, dtype=np.int32)))
         return cls(arms)
 
     def subset(self, idx):
@@ -494,6 +615,9 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
             torch.isfinite(o), torch.zeros_like(o), o)
         # + the constant log-determinant of the basis change (see basis_ortho);
         # a non finite penalty stays non finite (unusable template)
+        if torch.is_tensor(logdet_off):   # grid set: the constant of each job's grid
+            logdet_off = logdet_off if job_spec is None else \
+                logdet_off[job_spec.long()]
         pen = (pen + logdet_off).contiguous()
         coef = coefs[ia]
         rs = _arm_resol(arm, ia, resols)
@@ -504,6 +628,7 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
             jt = _lib.ptr(job_templ[a:b]) if job_templ is not None else \
                 (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None)
             if rs is not None:   # A9: banded resolution matrix
+                assert arm.G == 1
                 rc = L.rvs_chisq_grid_resol(
                     _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(work),
                     arm.npix, npoly, arm.S, _lib.ptr(lib.knots), _lib.ptr(coef),
@@ -515,9 +640,11 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
                     _lib.ptr(status[a:b]), _lib.stream())
                 _lib.check(rc, 'rvs_chisq_grid_resol')
                 continue
-            rc = L.rvs_chisq_grid(
+            gid, G = arm.grid_args()
+            rc = L.rvs_chisq_grid_g(
                 _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(work), arm.npix,
-                npoly, arm.S, _lib.ptr(lib.knots), _lib.ptr(coef), lib.ntp,
+                npoly, arm.S, gid, G, arm.basis_stride(npoly),
+                _lib.ptr(lib.knots), _lib.ptr(coef), lib.ntp,
                 coef.shape[0], int(lib.log_step), js, jt, b - a,
                 _lib.ptr(vels if shared else vels[a:b]), vstride, Nv,
                 _lib.ptr(pen[a:b]), float(batch.badchi),
@@ -590,6 +717,7 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
         a.work, a.knots = work.data_ptr(), lib.knots.data_ptr()
         a.coef, a.penalty = coef.data_ptr(), pen.data_ptr()
         a.npix, a.S, a.ntp = arm.npix, arm.S, lib.ntp
+        set_point_grid(a, arm, npoly)
         a.log_step = int(lib.log_step)
         a.espec_sys, a.fast_interp = esys[ia], int(bool(fast_interp))
         rs = _arm_resol(arm, ia, resols)
@@ -604,6 +732,13 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
                                _lib.ptr(status), _lib.stream())
         _lib.check(rc, 'rvs_chisq_point')
     return out, status
+
+
+def set_point_grid(p, arm, npoly):
+    """grid-set fields of an rvs_point_arm (include/rvsgpu.h)"""
+    p.G = arm.G
+    p.grid_id = arm.grid_id.data_ptr() if arm.G > 1 else None
+    p.polys_stride = arm.basis_stride(npoly)
 
 
 def fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys=0.0):
@@ -624,6 +759,7 @@ def fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys=0.0):
         p.coef = p.penalty = p.taps = None
         p.taps_stride, p.espec_sys = 0, esys[ia]
         p.npix, p.S, p.ntp = arm.npix, arm.S, lib.ntp
+        set_point_grid(p, arm, npoly)
         p.log_step, p.nd, p.fast_interp = int(lib.log_step), 0, 0
         a.factors = lib.spline_factors.data_ptr()
         a.lnstep = lib.lnstep
@@ -793,7 +929,9 @@ def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
             raw = torch.empty((J, arm.npix), dtype=torch.float64, device=dev)
         coef = None if unit_template else coefs[ia]
         rs = _arm_resol(arm, ia, resols)
-        rc = L.rvs_chisq_full(
+        gid, G = arm.grid_args()
+        assert rs is None or G == 1
+        rc = L.rvs_chisq_full_g(
             _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(arm.spec),
             _lib.ptr(arm.espec), _lib.ptr(arm.badmask), arm.npix, npoly, arm.S,
             _lib.ptr(lib.knots) if lib else None, _lib.ptr(coef),
@@ -806,7 +944,7 @@ def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
             rs['nd'] if rs else 0, rs['stride'] if rs else 0,
             _lib.ptr(chisq), _lib.ptr(coeffs),
             _lib.ptr(model), _lib.ptr(raw), _lib.ptr(tchi), _lib.ptr(ngood),
-            _lib.ptr(status), _lib.stream())
+            _lib.ptr(status), gid, G, arm.basis_stride(npoly), _lib.stream())
         _lib.check(rc, 'rvs_chisq_full')
         res.append(dict(chisq=chisq, true_chisq=tchi, coeffs=coeffs,
                         ngood=ngood, status=status, model=model, raw_model=raw))
@@ -829,13 +967,16 @@ def chisq_continuum(batch, npoly=5, rbf=True):
         status = torch.zeros(S, dtype=torch.int32, device=dev)
         if npoly <= 16:
             ut = arm.resol['unit'] if arm.resol is not None else None
-            rc = L.rvs_chisq_continuum(_lib.ptr(polysT), _lib.ptr(arm.spec),
-                                       _lib.ptr(arm.espec), _lib.ptr(arm.badmask),
-                                       _lib.ptr(ut), arm.npix, npoly, S,
-                                       None, None,
-                                       _lib.ptr(tchi),
-                                       _lib.ptr(ngood), _lib.ptr(status),
-                                       _lib.stream())
+            gid, G = arm.grid_args()
+            rc = L.rvs_chisq_continuum_g(_lib.ptr(polysT), _lib.ptr(arm.spec),
+                                         _lib.ptr(arm.espec),
+                                         _lib.ptr(arm.badmask),
+                                         _lib.ptr(ut), arm.npix, npoly, S,
+                                         None, None,
+                                         _lib.ptr(tchi),
+                                         _lib.ptr(ngood), _lib.ptr(status),
+                                         gid, G, arm.basis_stride(npoly),
+                                         _lib.stream())
             _lib.check(rc, 'rvs_chisq_continuum')
         else:
             status.fill_(_lib.ST_CHOL_FALLBACK)
@@ -877,14 +1018,15 @@ def ccf_preprocess(arm, lib, config, details=False):
         pfit = torch.zeros((arm.S, max(T['nnode'], 1)), dtype=torch.float64,
                            device=dev)
     with _ktime('ccf_preprocess', arm.S):
-      rc = L.rvs_ccf_preprocess(
+      rc = L.rvs_ccf_preprocess_g(
         _lib.ptr(arm.lam), _lib.ptr(arm.spec), _lib.ptr(arm.espec),
         _lib.ptr(arm.badmask), arm.npix, arm.S, int(cc['continuum']),
         _lib.ptr(T['Eb']), _lib.ptr(T['El']), _lib.ptr(T['Cinv']),
         _lib.ptr(T['istart']), T['nnode'], _lib.ptr(T['bin_start']),
         _lib.ptr(T['xind']), _lib.ptr(T['rw']), nfft, 10.0, _lib.ptr(ps),
         _lib.ptr(pi), _lib.ptr(sse), _lib.ptr(cont), _lib.ptr(pfit),
-        _lib.ptr(status), _lib.stream())
+        _lib.ptr(status), arm.grid_args()[0], _lib.ptr(T['npix_g']),
+        _lib.ptr(T['nnode_g']), _lib.stream())
     _lib.check(rc, 'rvs_ccf_preprocess')
     out = dict(proc_spec=ps, proc_ivar=pi, sse=sse, status=status)
     if details:

@@ -113,6 +113,7 @@ class ProcessObjective:
             a.work, a.knots = b['work'].data_ptr(), lib.knots.data_ptr()
             a.coef, a.penalty = b['coef'].data_ptr(), b['pen'].data_ptr()
             a.npix, a.S, a.ntp = arm.npix, arm.S, lib.ntp
+            engine.set_point_grid(a, arm, self.npoly)
             a.log_step = int(lib.log_step)
             # A9: the spectra's own resolution matrices or the resol_params
             # override, as engine.chisq_point wires them

@@ -202,9 +202,10 @@ def _overlap_check(templ_l0, templ_l1, spec_l0, spec_l1, min_vel, max_vel):
 def _check_overlap_all(batch, libs, config, vmin, vmax):
     for arm in batch.arms:
         lib = libs[arm.name]
-        _overlap_check(lib.lam[0], lib.lam[-1], arm.lam_host[0],
-                       arm.lam_host[-1], min(config['min_vel'], vmin),
-                       max(config['max_vel'], vmax))
+        # (a grid set: the widest extent over the spectra's own grids)
+        _overlap_check(lib.lam[0], lib.lam[-1], min(g[0] for g in arm.grids),
+                       max(g[-1] for g in arm.grids),
+                       min(config['min_vel'], vmin), max(config['max_vel'], vmax))
 
 
 def _raise_for_status(st, what):

@@ -1,0 +1,170 @@
+"""Batches of spectra on their OWN wavelength grids (the reference takes any `lam`
+per object, spec_fit.py:70-145; SDSS spectra, tests/test_sdss.py): ten spectra cut
+from the reference's data fixture on shifted / truncated pieces of its log-lambda
+grid, each fitted by the reference alone (tests/golden/make_golden_sdss_grids.py).
+Here they are ONE batch (nine distinct grids: a grid set, include/rvsgpu.h ABI 7):
+the batch must equal the spectra fitted one by one, and the reference's values."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+CFG = dict(template_lib='golden-sdss://', min_vel=-1000, max_vel=1000,
+           min_vel_step=0.2, vel_step0=5, min_vsini=0.1, max_vsini=500,
+           second_minimizer=True)
+NAMES = ('teff', 'logg', 'feh', 'alpha')
+POINTS = [(30., (5000., 3., -1., 0.2), 19.), (-85., (5600., 4.2, -0.4, 0.1), None),
+          (140., (4500., 2., -1.6, 0.3), 120.)]
+OPT = dict(npoly=10)
+
+
+@pytest.fixture(scope='module')
+def gcases():
+    return dict(np.load(os.path.join(GOLD, 'sdss_grid_cases.npz')))
+
+
+def test_golden_inputs(gcases):
+    """ten spectra, nine distinct grids, lengths 2842 .. 3842"""
+    pieces = gcases['pieces']
+    assert len(pieces) == 10
+    lams = [gcases['s%d/lam' % i] for i in range(10)]
+    assert sorted(len(_) for _ in lams)[0] == 3000 and max(len(_) for _ in lams) == 3842
+    assert len({(len(_), _.tobytes()) for _ in lams}) == 9
+    assert np.array_equal(lams[3], lams[7])
+
+
+@pytest.fixture(scope='module')
+def gbatch(gcases):
+    from rvspecfit_amd import spec_fit, spec_inter
+    from rvspecfit_amd.engine import SpecBatch
+    from rvspecfit_amd.library import TemplateLibrary
+    lib = TemplateLibrary('sdss1', np.load(os.path.join(GOLD, 'lib_sdss1.npz')))
+    spec_inter.register_library(lib, 'golden-sdss://')
+    sds = [[spec_fit.SpecData('sdss1', gcases['s%d/lam' % i], gcases['s%d/spec' % i],
+                              gcases['s%d/espec' % i],
+                              badmask=gcases['s%d/badmask' % i])]
+           for i in range(10)]
+    batch = SpecBatch.from_specdata(sds)
+    assert batch.arms[0].G == 9 and batch.arms[0].npix == 3842
+    assert batch.arms[0].grid_id_host[3] == batch.arms[0].grid_id_host[7]
+    return sds, batch
+
+
+@pytest.mark.gpu
+def test_get_chisq_batch_equals_singles_and_reference(gcases, gbatch):
+    import torch
+    from rvspecfit_amd import spec_fit
+    sds, batch = gbatch
+    S = len(sds)
+    for q, (v, par, vs) in enumerate(POINTS):
+        rot = None if vs is None else torch.full((S, ), vs, dtype=torch.float64,
+                                                 device=batch.device)
+        out = spec_fit.get_chisq(batch, np.full(S, v), par, rot_params=rot,
+                                 config=CFG, options=OPT, full_output=True)
+        chi = out['chisq'].cpu().numpy()
+        ca = out['chisq_array'].cpu().numpy()[:, 0]
+        npx = out['npix_array'].cpu().numpy()[:, 0]
+        for i in range(S):
+            one = spec_fit.get_chisq(sds[i], v, par,
+                                     rot_params=None if vs is None else (vs, ),
+                                     config=CFG, options=OPT, full_output=True)
+            # the batch IS the single spectrum: same kernels, same operands
+            assert chi[i] == one['chisq'], (q, i)
+            assert ca[i] == one['chisq_array'][0]
+            assert npx[i] == one['npix_array'][0]
+            n = len(sds[i][0].lam)
+            mod = out['models'][0][i].cpu().numpy()
+            assert np.array_equal(mod[:n], one['models'][0])
+            assert not mod[n:].any()
+            ref = float(gcases['s%d/pt%d/chisq' % (i, q)])
+            assert abs(chi[i] - ref) <= 1e-7 * abs(ref), (q, i, chi[i], ref)
+            assert np.isclose(ca[i], gcases['s%d/pt%d/chisq_array' % (i, q)][0],
+                              rtol=1e-7)
+            rm = gcases['s%d/pt%d/model' % (i, q)]
+            assert np.abs(mod[:n] - rm).max() <= 1e-6 * np.abs(rm).max()
+
+
+@pytest.mark.gpu
+def test_find_best_and_continuum(gcases, gbatch):
+    from rvspecfit_amd import spec_fit
+    sds, batch = gbatch
+    S = len(sds)
+    vel_grid = np.linspace(-500, 500, 201)
+    plist = [list(POINTS[0][1]), list(POINTS[1][1])]
+    fb = spec_fit.find_best(batch, vel_grid, plist, rot_params=None,
+                            resol_params=None, options=OPT, config=CFG)
+    cc = spec_fit.get_chisq_continuum(batch, options=OPT)['chisq_array'].cpu().numpy()
+    for i in range(S):
+        t = 's%d/find_best/' % i
+        assert abs(float(fb['best_vel'][i]) - gcases[t + 'best_vel']) < 1e-3
+        assert np.isclose(float(fb['best_chi'][i]), gcases[t + 'best_chi'], rtol=1e-7)
+        assert np.isclose(float(fb['vel_err'][i]), gcases[t + 'vel_err'], rtol=1e-4)
+        assert list(fb['best_param'][i].cpu().numpy()) == list(gcases[t + 'best_param'])
+        one = spec_fit.find_best(sds[i], vel_grid, plist, rot_params=None,
+                                 resol_params=None, options=OPT, config=CFG)
+        assert float(fb['best_chi'][i]) == one['best_chi']
+        assert float(fb['best_vel'][i]) == one['best_vel']
+        assert np.isclose(cc[i, 0], gcases['s%d/continuum' % i][0], rtol=1e-8)
+        assert cc[i, 0] == spec_fit.get_chisq_continuum(
+            sds[i], options=OPT)['chisq_array'][0]
+
+
+@pytest.mark.gpu
+def test_ccf_and_contract_step(gcases, gbatch):
+    """fitter_ccf.fit and the contract step (CCF -> chi^2 grid -> continuum) on
+    the grid set: every spectrum as alone, the CCF as the reference's"""
+    from rvspecfit_amd import fitter_ccf, pipeline
+    from rvspecfit_amd.engine import SpecBatch
+    sds, batch = gbatch
+    S = len(sds)
+    r = fitter_ccf.fit(batch, CFG)
+    bv = r['best_vel'].cpu().numpy()
+    bp = r['best_par'].cpu().numpy()
+    bc = r['best_ccf'].cpu().numpy()
+    for i in range(S):
+        t = 's%d/ccf/' % i
+        assert abs(bv[i] - gcases[t + 'best_vel']) < 1e-3, i
+        assert np.array_equal(bp[i], gcases[t + 'best_par'])
+        sc = np.abs(gcases[t + 'best_ccf']).max()
+        assert np.abs(bc[i] - gcases[t + 'best_ccf']).max() < 2e-5 * sc
+        one = fitter_ccf.fit(sds[i], CFG)
+        assert bv[i] == one['best_vel']
+        assert np.array_equal(bc[i], one['best_ccf'])
+    rec = pipeline.fit_batch(batch, CFG, options=OPT).cpu().numpy()
+    for i in range(S):
+        one = pipeline.fit_batch(SpecBatch.from_specdata([sds[i]]), CFG,
+                                 options=OPT).cpu().numpy()[0]
+        assert np.array_equal(rec[i], one, equal_nan=True), i
+
+
+@pytest.mark.gpu
+def test_process_on_grid_set(gcases, gbatch):
+    """vel_fit.process of the whole batch (device Nelder-Mead on the fused
+    objective, each job on its own grid): the three spectra the reference
+    processed end at its optimum; every spectrum ends where it ends alone"""
+    import torch
+    from rvspecfit_amd import vel_fit
+    sds, batch = gbatch
+    S = len(sds)
+    start = np.array([list(gcases['s%d/ccf/best_par' % i]) +
+                      [float(gcases['s%d/ccf/best_vsini' % i])] for i in range(S)])
+    assert np.isfinite(start).all()
+    pd = {k: torch.as_tensor(start[:, j]).to(batch.device)
+          for j, k in enumerate(NAMES + ('vsini', ))}
+    res = vel_fit.process(batch, pd, fixParam=[], config=CFG, options=OPT)
+    vel = res['vel'].cpu().numpy()
+    chi = res['chisq'].cpu().numpy()
+    for i in (0, 2, 5):
+        t = 's%d/process/' % i
+        assert abs(chi[i] - float(gcases[t + 'chisq'])) <= 2e-3, i
+        assert abs(vel[i] - float(gcases[t + 'vel'])) <= 0.01, i
+        got = np.array([float(res['param'][k][i]) for k in NAMES])
+        assert np.all(np.abs(got - gcases[t + 'param']) <=
+                      np.array([0.5, 5e-3, 2e-3, 2e-3])), i
+    for i in (1, 7):   # a spectrum of the batch against itself alone
+        one = vel_fit.process(sds[i], dict(zip(NAMES + ('vsini', ), start[i])),
+                              fixParam=[], config=CFG, options=OPT)
+        assert abs(one['vel'] - vel[i]) <= 1e-6
+        assert abs(one['chisq'] - chi[i]) <= 1e-6

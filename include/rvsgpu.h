@@ -213,7 +213,8 @@ int rvs_chisq_grid(const double *lam, const double *polysT, const double *work,
  * in sum log e) and the basis rows are 0; polysT of grid g starts at
  * polysT + g * polys_stride.  work: rvs_chisq_work_size_g(npix, S, G) doubles from
  * rvs_chisq_prepare_g.  G = 1 (grid_id NULL) is the shared-grid call.  With G > 1
- * the left-over velocities of a job are not packed with those of other jobs. */
+ * the left-over velocities of a job are not packed with those of other jobs.
+ * pen_scale [S] or NULL: per-spectrum factor on badchi (see rvs_point_arm). */
 int64_t rvs_chisq_work_size_g(int npix, int S, int G);
 int rvs_chisq_prepare_g(const double *lam, const double *spec,
                         const double *espec, int npix, int S, int G,
@@ -226,8 +227,8 @@ int rvs_chisq_grid_g(const double *lam, const double *polysT, const double *work
                      const int32_t *job_spec, const int32_t *job_templ, int J,
                      const double *vels, int64_t vel_stride, int Nv,
                      const double *penalty, double badchi, double beta,
-                     int pack_min_jobs, double *out, int32_t *status,
-                     void *stream);
+                     int pack_min_jobs, const double *pen_scale, double *out,
+                     int32_t *status, void *stream);
 
 /* A9  the same with a banded resolution matrix applied to the resampled
  * template before the fit: replaces convolve_resol / ResolMatrix
@@ -339,6 +340,11 @@ typedef struct rvs_point_arm {
   const int32_t *grid_id;
   int64_t polys_stride;
   int32_t G, reserved_;
+  /* per-spectrum factor on `badchi` [S] or NULL (read from arm 0): badchi is
+   * 10 x the pixel count of the SPECTRUM (spec_fit.py:863), which differs between
+   * the spectra of a grid set -- the scalar argument carries the largest, this the
+   * ratio */
+  const double *pen_scale;
 } rvs_point_arm;
 int64_t rvs_chisq_point_work_size(int J, int narm);
 int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,

@@ -32,7 +32,7 @@ SIGNATURES = {
     'rvs_chisq_work_size_g': (L, [I, I, I]),
     'rvs_chisq_prepare_g': (I, [P, P, P, I, I, I, P, I, D, P, P]),
     'rvs_chisq_grid_g': (I, [P, P, P, I, I, I, P, I, L, P, P, I, I, I, P, P, I, P, L,
-                             I, P, D, D, I, P, P, P]),
+                             I, P, D, D, I, P, P, P, P]),
     'rvs_chisq_prepare': (I, [P, P, P, I, I, P, I, D, P, P]),
     'rvs_chisq_grid': (I, [P, P, P, I, I, I, P, P, I, I, I, P, P, I, P, L, I, P,
                            D, D, I, P, P, P]),
@@ -153,7 +153,8 @@ class PointArm(ctypes.Structure):
                     (k, ctypes.c_int32) for k in
                     ('npix', 'S', 'ntp', 'log_step', 'nd', 'fast_interp')] + [
                     ('grid_id', ctypes.c_void_p), ('polys_stride', ctypes.c_int64),
-                    ('G', ctypes.c_int32), ('reserved_', ctypes.c_int32)]
+                    ('G', ctypes.c_int32), ('reserved_', ctypes.c_int32),
+                    ('pen_scale', ctypes.c_void_p)]
 
 
 class ObjectiveArm(ctypes.Structure):

@@ -89,6 +89,7 @@ struct GridSet {
   const int32_t *gid;
   int64_t polys_stride;
   int G;
+  const double *pen_scale;   // per-spectrum factor on badchi, or nullptr
 };
 
 // packed lower-triangular index
@@ -282,6 +283,7 @@ __device__ __forceinline__ void
   const double pen = penalty ? penalty[j] : 0.0;
   // template unusable (non finite outside flag): spec_fit.py:888-893
   const bool unusable = !(pen == pen) || isinf(pen);
+  if (GS.pen_scale) badchi *= GS.pen_scale[s];   // 10 x the spectrum's own pixels
   if (!TAIL && unusable) {   // wave-uniform: the whole wave is done
     if (active) {
       const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
@@ -1137,13 +1139,14 @@ extern "C" int rvs_chisq_grid_g(const double *lam, const double *polysT,
                                 const int32_t *job_spec, const int32_t *job_templ,
                                 int J, const double *vels, int64_t vel_stride,
                                 int Nv, const double *penalty, double badchi,
-                                double beta, int pack_min_jobs, double *out,
+                                double beta, int pack_min_jobs,
+                                const double *pen_scale, double *out,
                                 int32_t *status, void *stream) {
   (void)Tn;
   if (J < 1 || Nv < 1 || npix < 1 || ntp < 3 || G < 1 || (G > 1 && !grid_id))
     return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
-  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G};
+  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G, pen_scale};
 #define RVS_CASE(PP)                                                          \
   case PP:                                                                    \
     return launch_grid<PP>(lam, polysT, work, npix, S, knots, coef, ntp,      \
@@ -1172,7 +1175,7 @@ extern "C" int rvs_chisq_grid(const double *lam, const double *polysT,
   return rvs_chisq_grid_g(lam, polysT, work, npix, npoly, S, nullptr, 1, 0, knots,
                           coef, ntp, Tn, log_step, job_spec, job_templ, J, vels,
                           vel_stride, Nv, penalty, badchi, beta, pack_min_jobs,
-                          out, status, stream);
+                          nullptr, out, status, stream);
 }
 
 extern "C" int rvs_chisq_grid_resol(
@@ -1524,7 +1527,7 @@ extern "C" int rvs_chisq_full_g(const double *lam, const double *polysT,
                               void *stream) {
   (void)S;
   if (G < 1 || (G > 1 && !grid_id)) return RVS_E_ARG;
-  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G};
+  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G, nullptr};
   (void)Tn;
   if (npoly < 1 || npoly > FULL_MAXP || J < 1 || npix < 1) return RVS_E_ARG;
   if (taps && (nd < 1 || (nd & 1) == 0)) return RVS_E_ARG;
@@ -1721,7 +1724,7 @@ extern "C" int rvs_chisq_continuum_g(const double *polysT, const double *spec,
                                    int64_t polys_stride, void *stream) {
   (void)work;
   if (G < 1 || (G > 1 && !grid_id)) return RVS_E_ARG;
-  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G};
+  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G, nullptr};
   if (S < 1 || npix < 1 || !true_chisq || !ngood) return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
 #define RVS_CASE(PP)                                                           \
@@ -1985,12 +1988,14 @@ __global__ void __launch_bounds__(256)
 
 // arms summed in order; penalties of A11 (spec_fit.py:888-896)
 __global__ void point_sum_kernel(PointArms A, int J, double badchi,
+                                 const int32_t *__restrict__ job_spec,
                                  const double *__restrict__ armchi,
                                  const int32_t *__restrict__ armst,
                                  double *__restrict__ out,
                                  int32_t *__restrict__ status) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= J) return;
+  if (A.a[0].pen_scale) badchi *= A.a[0].pen_scale[job_spec ? job_spec[j] : j];
   double tot = 0;
   int st = 0;
   for (int ia = 0; ia < A.n; ia++) {
@@ -2051,7 +2056,7 @@ extern "C" int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
   }
 #undef RVS_CASE
   hipLaunchKernelGGL(point_sum_kernel, dim3((J + 255) / 256), dim3(256), 0, st,
-                     A, J, badchi, armchi, armst, out, status);
+                     A, J, badchi, job_spec, armchi, armst, out, status);
   RVS_LAUNCH_CHECK();
   return 0;
 }

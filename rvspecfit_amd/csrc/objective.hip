@@ -998,6 +998,8 @@ __global__ void __launch_bounds__(OBJ_NT)
 
 // arms in order; penalties of A11 (spec_fit.py:888-896)
 __global__ void objective_sum_kernel(int narm, int J, double badchi,
+                                     const double *__restrict__ pen_scale,
+                                     const int32_t *__restrict__ job_spec,
                                      int outside_penalty,
                                      const double *__restrict__ armchi,
                                      const int32_t *__restrict__ armst,
@@ -1006,6 +1008,9 @@ __global__ void objective_sum_kernel(int narm, int J, double badchi,
                                      int32_t *__restrict__ status) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= J) return;
+  // (badchi = 10 x the pixel count of the spectrum, spec_fit.py:863: the factor
+  // of a spectrum on a shorter grid of a grid set)
+  if (pen_scale) badchi *= pen_scale[job_spec ? job_spec[j] : j];
   double tot = 0;
   int st = 0;
   for (int ia = 0; ia < narm; ia++) {
@@ -1132,7 +1137,8 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
                                             armchi, armst, armout, st);
       if (prc == 0) {
         hipLaunchKernelGGL(objective_sum_kernel, dim3((J + 255) / 256), dim3(256), 0,
-                           st, narm, J, badchi, outside_penalty, armchi, armst,
+                           st, narm, J, badchi, arms[0].pt.pen_scale, job_spec,
+                           outside_penalty, armchi, armst,
                            armout, out, status);
         RVS_LAUNCH_CHECK();
         return 0;
@@ -1170,7 +1176,8 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
 #undef RVS_CASE
 #undef RVS_LAUNCH_OBJ
   hipLaunchKernelGGL(objective_sum_kernel, dim3((J + 255) / 256), dim3(256), 0,
-                     st, narm, J, badchi, outside_penalty, armchi, armst, armout,
+                     st, narm, J, badchi, arms[0].pt.pen_scale, job_spec,
+                           outside_penalty, armchi, armst, armout,
                      out, status);
   RVS_LAUNCH_CHECK();
   return 0;

@@ -171,6 +171,7 @@ class ArmData:
                                          self.espec)
                 self.badmask = torch.where(pad, torch.ones_like(self.badmask),
                                            self.badmask)
+        self.pen_scale = None   # (set by the SpecBatch that holds the arm)
         self._basis = {}
         self._work = {}
         self._ccf = {}
@@ -392,6 +393,16 @@ class SpecBatch:
         self.device = self.arms[0].device
         self.names = [a.name for a in self.arms]
         self.badchi = 10 * sum(a.npix for a in self.arms)  # spec_fit.py:863
+        # grid sets: a spectrum's own pixel count -> per-spectrum factor on badchi
+        self.pen_scale = None
+        if any(a.G > 1 for a in self.arms):
+            n = sum(torch.as_tensor(a.npix_g.astype(np.float64)).to(self.device)[
+                a.grid_id.long()] if a.G > 1 else
+                torch.full((self.S, ), float(a.npix), dtype=torch.float64,
+                           device=self.device) for a in self.arms)
+            self.pen_scale = (10.0 * n / float(self.badchi)).contiguous()
+        for a in self.arms:
+            a.pen_scale = self.pen_scale
 
     @classmethod
     def from_specdata(cls, specdata_lists, device='cuda'):
@@ -441,6 +452,14 @@ class SpecBatch:
                                 padded('badmask', 1, np.uint8), device=device,
                                 grid_id=np.array(gid, dtype=np.int32)))
         return cls(arms)
+
+    def badchi_jobs(self, job_spec=None):
+        """badchi of every job: the float of the batch, or (grid sets) a device
+        tensor with the value of each job's spectrum"""
+        if self.pen_scale is None:
+            return float(self.badchi)
+        ps = self.pen_scale if job_spec is None else self.pen_scale[job_spec.long()]
+        return ps * float(self.badchi)
 
     def subset(self, idx):
         return SpecBatch([a.subset(idx) for a in self.arms])
@@ -573,11 +592,12 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
             stb = torch.zeros(bad.numel(), dtype=torch.int32, device=dev)
             for ia, f in enumerate(full):
                 o = outsides[ia][jt2[bad].long()]
-                pen = o * float(batch.badchi) if outside_penalty else \
+                bc = batch.badchi_jobs(js2[bad])
+                pen = o * bc if outside_penalty else \
                     torch.where(torch.isfinite(o), torch.zeros_like(o), o)
                 fin = torch.isfinite(pen)     # penalties of spec_fit.py:888-896
-                tot += torch.where(fin, f['chisq'] + pen, torch.full_like(
-                    pen, 1000.0 * float(batch.badchi)))
+                tot += torch.where(fin, f['chisq'] + pen,
+                                   torch.zeros_like(pen) + 1000.0 * bc)
                 stb |= torch.where(fin, f['status'], torch.zeros_like(f['status']))
             res[bad] = tot
             stb = torch.where(torch.isfinite(tot), stb,
@@ -611,7 +631,7 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
         o = outsides[ia]
         if job_templ is not None:
             o = o[job_templ.long()]
-        pen = o * float(batch.badchi) if outside_penalty else torch.where(
+        pen = o * batch.badchi_jobs(job_spec) if outside_penalty else torch.where(
             torch.isfinite(o), torch.zeros_like(o), o)
         # + the constant log-determinant of the basis change (see basis_ortho);
         # a non finite penalty stays non finite (unusable template)
@@ -648,7 +668,8 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
                 coef.shape[0], int(lib.log_step), js, jt, b - a,
                 _lib.ptr(vels if shared else vels[a:b]), vstride, Nv,
                 _lib.ptr(pen[a:b]), float(batch.badchi),
-                0.0 if ia == 0 else 1.0, CG_PACK_MIN_JOBS, _lib.ptr(out[a:b]),
+                0.0 if ia == 0 else 1.0, CG_PACK_MIN_JOBS,
+                _lib.ptr(batch.pen_scale), _lib.ptr(out[a:b]),
                 _lib.ptr(status[a:b]), _lib.stream())
             _lib.check(rc, 'rvs_chisq_grid')
     # Jobs whose normal matrix the velocity-grid kernel could not factor, or
@@ -706,7 +727,7 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
         o = outsides[ia]
         if job_templ is not None:
             o = o[job_templ.long()]
-        pen = o * float(batch.badchi) if outside_penalty else torch.where(
+        pen = o * batch.badchi_jobs(job_spec) if outside_penalty else torch.where(
             torch.isfinite(o), torch.zeros_like(o), o)
         pen = pen.contiguous()
         coef = coefs[ia]
@@ -739,6 +760,8 @@ def set_point_grid(p, arm, npoly):
     p.G = arm.G
     p.grid_id = arm.grid_id.data_ptr() if arm.G > 1 else None
     p.polys_stride = arm.basis_stride(npoly)
+    ps = getattr(arm, 'pen_scale', None)
+    p.pen_scale = ps.data_ptr() if ps is not None else None
 
 
 def fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys=0.0):

@@ -293,6 +293,8 @@ class ProcessObjective:
             _lib.check(rc, 'rvs_spline_construct')
             with torch.cuda.stream(side):
                 torch.mul(b['outside'], self.badchi, out=b['pen'])
+                if self.batch.pen_scale is not None:   # grid sets (engine.SpecBatch)
+                    b['pen'][:J] *= self.batch.pen_scale[self.job_spec[:J].long()]
             ev.record(side)
         for ev in self.ev_out:
             main.wait_event(ev)

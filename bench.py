@@ -38,6 +38,13 @@ ARMS = ('b', 'r', 'z')
 # BASELINE configs[1] ("Cfg2"): 1 arm 4000-5000 A, 2001 px, template 3950-5050 A
 # step 0.5 (2272 px), N_fft 4096
 CFG2_ARM = dict(obs=(4000., 5000.01, 0.5), templ=(3950., 5050., 0.5))
+# --workload sdss: ONE arm on the log-lambda lattice of an SDSS spectrum
+# (log10 lam = 3.5798 + 1e-4 k, 3842 pixels, 3800-9200 A: the reference's own data
+# fixture tests/data/spec-0266-51602-0031.fits), every object on its OWN piece of
+# the lattice -- shifted start, truncated end (spec_fit.py:70-145 takes any `lam`
+# per object; tests/test_sdss.py) -- i.e. a grid set of S grids
+SDSS_ARM = dict(obs=(3.5798, 1e-4, 3842), templ=(3750., 9300., 1.0))
+SDSS_PIECES = None   # int64 [S, 2] (first pixel, pixel count) of every spectrum
 CONFIG = dict(min_vel=-1000, max_vel=1000, vel_step0=5, min_vel_step=0.2,
               min_vsini=0.1, max_vsini=500, template_lib='synthetic://desi')
 OPTIONS = dict(npoly=10)
@@ -49,12 +56,24 @@ def arm_name(a):
 
 
 def arm_def(a):
+    if a == 's':
+        return SDSS_ARM
     return CFG2_ARM if a == 'c' else synth.DESI_ARMS[a]
 
 
 def obs_lam(a):
     lo, hi, st = arm_def(a)['obs']
+    if a == 's':   # (log10 of the first pixel, step in dex, pixels)
+        return 10**(lo + hi * np.arange(st))
     return np.arange(lo, hi, st)
+
+
+def sdss_pieces(S, seed):
+    """(first pixel, pixel count) of every spectrum on the 3842-pixel lattice"""
+    rng = np.random.RandomState(4242 + seed)
+    a0 = rng.randint(0, 256, S)
+    n = 3842 - a0 - rng.randint(0, 400, S)
+    return np.stack([a0, n], axis=1).astype(np.int64)
 
 
 def nn_weights(ntp, seed):
@@ -228,12 +247,23 @@ def _cpu_noop(i):
     return i
 
 
+def _cpu_specdata(orc, d, i):
+    """spectrum i of the sample as the oracle's SpecData (--workload sdss: on
+    its own piece of the lattice)"""
+    if 'pieces' in d:
+        a0, n = (int(_) for _ in d['pieces'][i])
+        return [orc.SpecData(arm_name(a), obs_lam(a)[a0:a0 + n],
+                             d['spec_' + a][i][:n], d['espec_' + a][i][:n],
+                             badmask=d['bad_' + a][i][:n] != 0) for a in ARMS]
+    return [orc.SpecData(arm_name(a), obs_lam(a), d['spec_' + a][i],
+                         d['espec_' + a][i], badmask=d['bad_' + a][i] != 0)
+            for a in ARMS]
+
+
 def _cpu_one(i):
     from oracle import rvs_oracle as orc
     libs, d = _W['libs'], _W['d']
-    sds = [orc.SpecData(arm_name(a), obs_lam(a), d['spec_' + a][i],
-                        d['espec_' + a][i], badmask=d['bad_' + a][i] != 0)
-           for a in ARMS]
+    sds = _cpu_specdata(orc, d, i)
     o = orc.ccf_fit(sds, CONFIG, libs)
     vg = np.arange(CONFIG['min_vel'], CONFIG['max_vel'], CONFIG['vel_step0'])
     vs = o['best_vsini']
@@ -250,9 +280,7 @@ def _cpu_one_process(i):
     """oracle vel_fit.process from the (GPU) CCF parameters of spectrum i"""
     from oracle import rvs_oracle as orc
     libs, d = _W['libs'], _W['d']
-    sds = [orc.SpecData(arm_name(a), obs_lam(a), d['spec_' + a][i],
-                        d['espec_' + a][i], badmask=d['bad_' + a][i] != 0)
-           for a in ARMS]
+    sds = _cpu_specdata(orc, d, i)
     names = ['teff', 'logg', 'feh', 'alpha']
     pd0 = {k: float(d['start'][i, j]) for j, k in enumerate(names)}
     pd0['vsini'] = float(d['start'][i, 4])
@@ -273,6 +301,8 @@ def run_cpu_baseline(arms, n, args, start=None):
         sample['spec_' + a] = spec[:n].cpu().numpy()
         sample['espec_' + a] = es[:n].cpu().numpy()
         sample['bad_' + a] = bad[:n].cpu().numpy()
+    if SDSS_PIECES is not None:
+        sample['pieces'] = SDSS_PIECES[:n]
     np.savez(path, **sample)
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', path,
            '--ccf-every', str(args.ccf_every), '--cpu-cores',
@@ -431,7 +461,7 @@ def main():
     ap.add_argument('--npoly', type=int, default=10,
                     help='continuum basis size (the reference\'s tests and the WEAVE '
                          'driver run 15); the flop model follows it')
-    ap.add_argument('--workload', choices=['desi', 'cfg2'], default='desi',
+    ap.add_argument('--workload', choices=['desi', 'cfg2', 'sdss'], default='desi',
                     help='desi: BASELINE configs[2] (3 arms); cfg2: configs[1] '
                          '(1 arm, 2001 px, N_fft 4096)')
     ap.add_argument('--evaluator', choices=['polylinear', 'nn'],
@@ -460,6 +490,8 @@ def main():
     global ARMS, EVALUATOR, GRID_KW
     if args.workload == 'cfg2':
         ARMS = ('c', )
+    if args.workload == 'sdss':
+        ARMS = ('s', )
     EVALUATOR = args.evaluator
     assert 1 <= args.npoly <= 16, '--npoly: 1..16'
     OPTIONS['npoly'] = args.npoly
@@ -531,8 +563,25 @@ def main():
     tp = truth_params(S, seed=3 + 1000 * (args.seed_rank if args.seed_rank >= 0
                                           else rank))
     arms = make_spectra_device(tp, dev)
-    batch = engine.SpecBatch([engine.ArmData(n, lam, sp, es, bad, device=dev)
-                              for n, lam, sp, es, bad in arms])
+    if args.workload == 'sdss':
+        # every spectrum keeps its own piece of the lattice: its pixels move to the
+        # front of its row, the rest is padding (engine.ArmData, grid sets)
+        global SDSS_PIECES
+        SDSS_PIECES = sdss_pieces(S, int(tp['seed']))
+        name, lam, sp, es, bad = arms[0]
+        a0 = torch.as_tensor(SDSS_PIECES[:, 0]).to(dev)
+        npx = int(SDSS_PIECES[:, 1].max())
+        col = (a0[:, None] + torch.arange(npx, device=dev)[None, :]).clamp_(
+            max=sp.shape[1] - 1)
+        arms = [(name, lam, sp.gather(1, col), es.gather(1, col),
+                 bad.gather(1, col))]
+        grids = [lam[a:a + n] for a, n in SDSS_PIECES]
+        batch = engine.SpecBatch([engine.ArmData(
+            name, grids, arms[0][2], arms[0][3], arms[0][4], device=dev,
+            grid_id=np.arange(S, dtype=np.int32))])
+    else:
+        batch = engine.SpecBatch([engine.ArmData(n, lam, sp, es, bad, device=dev)
+                                  for n, lam, sp, es, bad in arms])
     if args.resolution_matrix:
         # per-spectrum Gaussian rows, sigma 0.45-0.65 px-units of 0.8 A, 11 taps,
         # rows normalised (what desi_fit.construct_resolution_sparse_matrix
@@ -655,7 +704,9 @@ def main():
     ccf_bytes = units / len(ARMS) * b_ccf_unit
     ccf_gbs = ccf_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     nl2, ms2, units2 = kt.get('chisq_grid', (0, 0.0, 0))
-    npix_tot = sum(a.npix for a in batch.arms)
+    # (a grid set: the spectra's own pixel counts, not the padded row length)
+    npix_tot = sum(float(a.npix_g[a.grid_id_host].mean()) if a.G > 1 else a.npix
+                   for a in batch.arms)
     ntp_tot = sum(len(dicts[arm_name(a)]['lam']) for a in ARMS)
     # chi^2 grid: spectrum terms (16 B/px) + spline records (32 B/knot) + out
     b_grid_unit = npix_tot * 16 + ntp_tot * 32 + 400 * 8
@@ -836,7 +887,9 @@ def main():
         + b_ccf_unit + 4096
     line = dict(
         metric='spectra/sec (CCF+chi2 grid) DESI 3-arm' if args.workload == 'desi'
-        else 'spectra/sec (CCF+chi2 grid) 1 arm 4000-5000 A (BASELINE configs[1])',
+        else ('spectra/sec (CCF+chi2 grid) 1 arm, every spectrum on its own '
+              'wavelength grid (SDSS-style)' if args.workload == 'sdss' else
+              'spectra/sec (CCF+chi2 grid) 1 arm 4000-5000 A (BASELINE configs[1])'),
         value=round(value, 1), unit='spectra/s', n_gpus=world, steps=args.steps,
         warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 2),
         higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
@@ -847,7 +900,12 @@ def main():
                                  'DESI b/r/z 3-arm (2751/2326/2881 px) (BASELINE '
                                  'configs[%d])' % (3 if EVALUATOR == 'nn' else 2)
                                  if args.workload == 'desi' else
-                                 '1 arm 4000-5000 A 2001 px (BASELINE configs[1])',
+                                 ('1 arm on the SDSS log-lambda lattice, %d grids '
+                                  'of %d-%d px (one per spectrum; add-on workload)'
+                                  % (S, int(SDSS_PIECES[:, 1].min()),
+                                     int(SDSS_PIECES[:, 1].max()))
+                                  if args.workload == 'sdss' else
+                                  '1 arm 4000-5000 A 2001 px (BASELINE configs[1])'),
                                  S, EVALUATOR,
                                  'x'.join(str(GRID_KW[k]) for k in (
                                      'nteff', 'nlogg', 'nfeh', 'nalpha')),

@@ -716,7 +716,10 @@ def main():
     grid_gbs = (units2 / len(ARMS)) * b_grid_unit / (ms2 * 1e-3) / 1e9 if ms2 else 0
     P_ = OPTIONS['npoly']
     nsum_ = P_ * (P_ + 1) // 2 + P_
-    flop_grid_unit = 400 * npix_tot * (2 * nsum_ + 40)
+    # (--resolution-matrix: + the 11-tap band on the resampled template, one FMA
+    # per tap and pixel-velocity)
+    flop_grid_unit = 400 * npix_tot * (2 * nsum_ + 40 +
+                                       (22 if args.resolution_matrix else 0))
     grid_tflops = (units2 / len(ARMS)) * flop_grid_unit / (ms2 * 1e-3) / 1e12 if ms2 else 0
     # ---- roofline of the DOMINANT kernel: the fp64 chi^2 grid ----------------
     # algorithmic flops per spectrum: Nv * sum_arm npix * (2*65 + 40) at npoly 10
@@ -771,7 +774,8 @@ def main():
                 share_of_step=round(ms2 / args.steps / (dt / args.steps * 1e3), 3),
                 npoly=OPTIONS['npoly'],
                 note='fp64 vector-ALU bound (0.07 TB/s algorithmic): flops = '
-                     '2 (P (P + 1) / 2 + P) + 40 per pixel-velocity (170 at npoly 10); peak = datasheet fp64 vector rate (a '
+                     '2 (P (P + 1) / 2 + P) + 40 per pixel-velocity (170 at npoly 10; '
+                     '+ 22 for the 11-tap band with --resolution-matrix); peak = datasheet fp64 vector rate (a '
                      'pure v_fma_f64 loop sustained 70.6 TF on this chip in '
                      'round 2, tools/perf/ubench.hip -- not measured by this run)')
     roof_ccf = dict(bound='hbm', kernel='ccf_xcorr_kernel',

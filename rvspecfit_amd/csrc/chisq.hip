@@ -797,11 +797,21 @@ __global__ void __launch_bounds__(64)
                             int Nv, const double *__restrict__ penalty,
                             double badchi, double beta_out,
                             double *__restrict__ out,
-                            int32_t *__restrict__ status) {
-  const int j = blockIdx.y;
-  int iv = blockIdx.x * 64 + threadIdx.x;
+                            int32_t *__restrict__ status, int J, int nw) {
+  // Blocks are dealt round-robin over the 8 XCDs: the nw waves of a job are 8
+  // blocks apart (as in chisq_grid_kernel), so that the job's taps (npix x 11
+  // doubles, 242 KB per DESI arm, read by every one of its waves through the
+  // scalar cache) and spline records are fetched into ONE L2, once.  With the
+  // waves of a job in consecutive blocks -- seven XCDs, seven fetches -- the
+  // launch read 44 GB from HBM for 4.8 GB of operands (profiles/r03_pmc_traffic).
+  const int per = 8 * nw;
+  const int gq = blockIdx.x / per, rq = blockIdx.x - gq * per;
+  const int j = gq * 8 + (rq & 7);
+  const int bx = rq >> 3;
+  if (j >= J) return;
+  int iv = bx * 64 + threadIdx.x;
   const bool active = iv < Nv;
-  if (!active) iv = blockIdx.x * 64;
+  if (!active) iv = bx * 64;
   const int s = job_spec ? job_spec[j] : j;
   const int t = job_templ ? job_templ[j] : j;
   double *outp = out + (int64_t)j * Nv;
@@ -1203,12 +1213,13 @@ extern "C" int rvs_chisq_grid_resol(
     }                                                                          \
     if (nd == 11)                                                              \
       hipLaunchKernelGGL((chisq_grid_resol_pipe_kernel<PP, 11>),               \
-                         dim3((Nv + 63) / 64, J), dim3(64), 0, st, lam,        \
+                         dim3((unsigned)(((J + 7) / 8) * 8 * ((Nv + 63) / 64))), \
+                         dim3(64), 0, st, lam,                                 \
                          polysT, work, npix, S, knots,                         \
                          reinterpret_cast<const double4 *>(coef), ntp,         \
                          log_step, taps, taps_stride, job_spec, job_templ,     \
                          vels, vel_stride, Nv, penalty, badchi, beta, out,     \
-                         status);                                              \
+                         status, J, (Nv + 63) / 64);                           \
     else                                                                       \
       hipLaunchKernelGGL(chisq_grid_resol_kernel<PP>, grid, dim3(256), shm,    \
                          st, lam, polysT, work, npix, S, knots,                \

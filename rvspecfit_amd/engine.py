@@ -536,7 +536,8 @@ def _arm_resol(arm, ia, resols):
 
 def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
                job_spec=None, job_templ=None, espec_sys=0.0,
-               outside_penalty=True, out=None, vel_bounds=None, resols=None):
+               outside_penalty=True, out=None, vel_bounds=None, resols=None,
+               defer_redo=False):
     """chi^2 of J jobs on a velocity grid, summed over the arms of `batch`.
 
     coefs[a]    [Tn, ntp_a, 4]   spline records of arm a
@@ -678,18 +679,27 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
     # explicit residual, Cholesky -- and what that cannot factor either by
     # rvs_chisq_full's eigen branch (by_point_kernel: the reference's
     # Cholesky -> SVD tiers, spec_fit.py:337-354).  The look at the status
-    # vector is a device-to-host synchronisation at the end of every call: the
-    # host cannot queue the next stage under this one (a few launch latencies
-    # per call; the sampler's rounds synchronise on their grid sizes anyway).
-    redo = torch.nonzero(status & (_lib.ST_ILLCOND | _lib.ST_CHOL_FALLBACK)
-                         ).reshape(-1)
-    if redo.numel():
-        res, stj = by_point_kernel(redo)
-        out[redo] = res
-        # (ST_ILLCOND stays on as the record that the job took this path)
-        status[redo] = (status[redo] & ~(_lib.ST_NONFINITE |
-                                         _lib.ST_CHOL_FALLBACK)) | stj | \
-            _lib.ST_ILLCOND
+    # vector is a device-to-host synchronisation: at the end of the call, or --
+    # defer_redo -- wherever the caller runs the returned finish().
+    def finish():
+        """the look at the status vector (host synchronisation) and the redo of
+        the flagged jobs, in place; returns how many were redone"""
+        redo = torch.nonzero(status & (_lib.ST_ILLCOND | _lib.ST_CHOL_FALLBACK)
+                             ).reshape(-1)
+        if redo.numel():
+            res, stj = by_point_kernel(redo)
+            out[redo] = res
+            # (ST_ILLCOND stays on as the record that the job took this path)
+            status[redo] = (status[redo] & ~(_lib.ST_NONFINITE |
+                                             _lib.ST_CHOL_FALLBACK)) | stj | \
+                _lib.ST_ILLCOND
+        return int(redo.numel())
+    if defer_redo:
+        # the caller queues what does not depend on the redone jobs first and
+        # calls finish() where it has to wait for the device anyway
+        # (pipeline.fit_batch: at the end of the step)
+        return out, status, finish
+    finish()
     return out, status
 
 

@@ -76,33 +76,42 @@ def fit_batch(batch, config, options=None, refine=False, timers=None,
     vg = torch.as_tensor(
         np.arange(config['min_vel'], config['max_vel'],
                   config['vel_step0']).astype(np.float64)).to(dev)
-    chisq, status = engine.chisq_grid(
+    # (the redo of ill-conditioned jobs -- a host look at the status vector -- is
+    # deferred behind everything that can be queued without it: at 5 ms per step
+    # (BASELINE configs[1]) a synchronisation in the middle of the step showed)
+    chisq, status, grid_finish = engine.chisq_grid(
         batch, libs, coefs, outs, vg, npoly=npoly, rbf=rbf, job_templ=templ_rows,
-        vel_bounds=(float(config['min_vel']), float(config['max_vel'])))
+        vel_bounds=(float(config['min_vel']), float(config['max_vel'])),
+        defer_redo=True)
     res, _, mst = engine.grid_moments(chisq, vg, Np=1)
     ev.stop('chisq_grid')
 
     ev.start('continuum')
     cont = engine.chisq_continuum(batch, npoly=npoly, rbf=rbf)
     ev.stop('continuum')
-
     rec = torch.zeros((S, NREC), dtype=torch.float64, device=dev)
     rec[:, 0] = ccf['best_id'].double()
     rec[:, 1] = ccf['best_vel']
     nd = params.shape[1]
     rec[:, 2:2 + min(nd, 4)] = params[:, :4]
     rec[:, 6] = vsini
-    rec[:, 7] = res[:, 1]
-    rec[:, 8] = res[:, 2]
-    rec[:, 9] = res[:, 4]
-    rec[:, 10] = res[:, 3]
-    rec[:, 11] = res[:, 0]
     for ia in range(min(3, len(batch.arms))):
         rec[:, 12 + ia] = cont[ia]['true_chisq']
     cst = cont[0]['status']
     for c in cont[1:]:
         cst = cst | c['status']
-    rec[:, 15] = (status | mst | ccf['status'] | cst).double()
+
+    def grid_fields(res, mst):
+        rec[:, 7] = res[:, 1]
+        rec[:, 8] = res[:, 2]
+        rec[:, 9] = res[:, 4]
+        rec[:, 10] = res[:, 3]
+        rec[:, 11] = res[:, 0]
+        rec[:, 15] = (status | mst | ccf['status'] | cst).double()
+    grid_fields(res, mst)
+    if grid_finish():   # (rare) some jobs went through the point kernel
+        res, _, mst = engine.grid_moments(chisq, vg, Np=1)
+        grid_fields(res, mst)
 
     if refine:
         ev.start('refine')

@@ -206,14 +206,12 @@ def get_rvs_warn(fit_res, outdict, config):
 # --------------------------------------------------------- fibre selection
 def get_sns(data, ivars, masks):
     """desi_fit.py:444-456: vector of per-fibre median S/N"""
+    usable = (ivars > 0) & ~(masks > 0)
     with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        xind = (ivars <= 0) | (masks > 0)
-        xsn = data * np.sqrt(ivars)
-        xsn[xind] = np.nan
-        sns = np.nanmedian(xsn, axis=1)
-        sns[~np.isfinite(sns)] = -1e9
-    return sns
+        warnings.simplefilter('ignore')   # (rows without a usable pixel)
+        sn = np.where(usable, data * np.sqrt(np.where(usable, ivars, 0.0)), np.nan)
+        med = np.nanmedian(sn, axis=1)
+    return np.where(np.isfinite(med), med, -1e9)
 
 
 def read_data(FP, setups):
@@ -462,18 +460,21 @@ MINERR_FRAC = 0.3  # errors below this times the median are clamped
 def _medspec(spec, badmask):
     """median flux of one arm with the fall-backs of desi_fit.py:833-843;
     None when the arm has to be skipped"""
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        if badmask.all():
-            return None
-        medspec = np.nanmedian(spec)
-        if medspec == 0:
-            medspec = np.nanmedian(spec[(spec > 0) & (~badmask)])
-            if not np.isfinite(medspec):
-                medspec = np.nanmedian(np.abs(spec))
-    if not np.isfinite(medspec) or medspec == 0:
+    if badmask.all():
         return None
-    return medspec
+    # first usable candidate of: all pixels, the good positive ones, |flux|
+    candidates = (lambda: spec, lambda: spec[(spec > 0) & ~badmask],
+                  lambda: np.abs(spec))
+    med = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')   # (empty selections)
+        for i, pick in enumerate(candidates):
+            med = np.nanmedian(pick())
+            if i == 0 and med != 0:
+                break            # the plain median is taken as it is ...
+            if i > 0 and np.isfinite(med):
+                break            # ... the fall-backs only when finite
+    return med if (np.isfinite(med) and med != 0) else None
 
 
 def _row_nanmedian(a):
@@ -881,30 +882,28 @@ def _proc_desi_steps(fname, tab_ofname, mod_ofname, fig_prefix, config,
         now = time.time()
         tm[k] = tm.get(k, 0.) + now - t_last[0]
         t_last[0] = now
-    logging.info('Processing %s' % fname)
+    logging.info('Processing %s', fname)
+    FP = None
     try:
         FP = pyfits.open(fname)
     except OSError:
-        logging.error('Cannot read file %s' % (fname))
+        pass
+    if FP is None or not valid_file(FP):
+        logging.error('%s file: %s', 'Cannot read' if FP is None else 'Not valid',
+                      fname)
         return -1
-    if not valid_file(FP):
-        logging.error('Not valid file: %s' % (fname))
-        return -1
-    setups = ['b', 'r', 'z']
-    if fitarm is not None:
-        setups = [_ for _ in setups if _ in fitarm]
-        assert (len(setups) > 0)
+    setups = [a for a in ('b', 'r', 'z') if fitarm is None or a in fitarm]
+    assert setups, 'fitarm selects no arm'
     spectrum_header = FP[0].header
-    fibermap = FP['FIBERMAP'].data
-    scores = FP['SCORES'].data
+    fibermap, scores = FP['FIBERMAP'].data, FP['SCORES'].data
     exp_fibermap = FP['EXP_FIBERMAP'].data if 'EXP_FIBERMAP' in FP else None
-
-    if fit_targetid is not None:
-        if not np.isin(fibermap['TARGETID'], fit_targetid).any():
-            logging.warning('No fibers selected in file %s' % (fname))
-            put_empty_file(tab_ofname)
-            put_empty_file(mod_ofname)
-            return 0
+    if fit_targetid is not None and \
+            not np.isin(fibermap['TARGETID'], fit_targetid).any():
+        # nothing asked for lives in this file: empty products mark it as done
+        logging.warning('No fibers selected in file %s', fname)
+        for ofname in (tab_ofname, mod_ofname):
+            put_empty_file(ofname)
+        return 0
     fluxes, ivars, masks, waves, resolutions = read_data(FP, setups)
     tick('read')
     sns = _arm_sns(scores, setups, fluxes, ivars, masks)
@@ -1338,29 +1337,31 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
         if len(inflight) > 1:   # group g + 1 is being prepared: fit group g
             finish_oldest()
 
+    def product_names(f):
+        """(rvtab, rvmod) paths of input f -- with `subdirs` under the input's
+        last two directories -- or None for a path too short for that"""
+        parts = f.split('/')
+        if subdirs and len(parts) < 3:
+            return None
+        folder = '/'.join([output_dir] + (parts[-3:-1] if subdirs else [])) + '/'
+        os.makedirs(folder, exist_ok=True)
+        base = parts[-1][:-3] if parts[-1].endswith('.gz') else parts[-1]
+        return tuple('%s%s_%s' % (folder, pre, base)
+                     for pre in (output_tab_prefix, output_mod_prefix))
+
     for f in list(files)[rank::world]:
-        fname = f.split('/')[-1]
-        if subdirs:
-            fdirs = f.split('/')
-            if len(fdirs) < 3:
-                logging.warning(f'Invalid file {f}, it needs two be in the '
-                                'format dir1/dir2/fname')
-                continue
-            folder_path = output_dir + '/' + fdirs[-3] + '/' + fdirs[-2] + '/'
-        else:
-            folder_path = output_dir + '/'
-        os.makedirs(folder_path, exist_ok=True)
-        fname0 = fname[:-3] if fname[-3:] == '.gz' else fname
-        tab_ofname = folder_path + output_tab_prefix + '_' + fname0
-        mod_ofname = folder_path + output_mod_prefix + '_' + fname0
-        if (skipexisting and os.path.exists(tab_ofname)
-                and os.path.exists(mod_ofname)):
-            logging.info('skipping, products already exist %s' % f)
+        names = product_names(f)
+        if names is None:
+            logging.warning('Invalid file %s: with subdirs it has to be '
+                            'dir1/dir2/fname', f)
+            continue
+        if skipexisting and all(os.path.exists(n) for n in names):
+            logging.info('skipping, products already exist %s', f)
             if process_status_file is not None:
                 update_process_status_file(process_status_file, f,
                                            ProcessStatus.EXISTING, -1, 0)
             continue
-        pending.append((f, tab_ofname, mod_ofname))
+        pending.append((f, ) + names)
         if len(pending) >= max(1, files_per_batch):
             flush()
     flush()

@@ -289,8 +289,15 @@ __device__ __forceinline__ void
   }   // tiles
 }
 
+// blocks per CU the register budget is held to: the 128 x 128 tile (BIG: 64
+// accumulator registers per lane, two operand fragments, the next slab in flight,
+// 64 stores with their addresses) needs ~190 VGPRs; at the 128 of four blocks per CU
+// it carried 192-268 B of scratch per lane (round 3)
+#ifndef NN_MINB_BIG
+#define NN_MINB_BIG 2
+#endif
 template <bool BIG, bool KVEC, bool FINAL>
-__global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
+__global__ void __launch_bounds__(256, BIG ? NN_MINB_BIG : 4)
     nn_linear_kernel(const float *__restrict__ X, const float *__restrict__ W,
                      const float *__restrict__ bias, int Bn, int K, int N,
                      float *__restrict__ yout32,
@@ -310,7 +317,7 @@ struct NNLinG {
   int N[NN_MAXARM];
 };
 template <bool BIG, bool KVEC>
-__global__ void __launch_bounds__(256, NN_BK == 16 ? 4 : 2)
+__global__ void __launch_bounds__(256, BIG ? NN_MINB_BIG : 4)
     nn_linear_group_kernel(NNLinG G, int Bn, int K) {
   const int a = blockIdx.y;
   nn_linear_body<BIG, KVEC, true>(G.X[a], G.W[a], G.bias[a], Bn, K, G.N[a],
@@ -512,8 +519,9 @@ extern "C" int rvs_template_nn(const double *params, int B, int ndim,
     const bool kv = (K & 3) == 0;
     const int64_t ntile = (int64_t)((N + NN_BN - 1) / NN_BN) *
                           (big ? (B + NN_BM - 1) / NN_BM : (B + 31) / 32);
-    // four resident blocks per CU (LDS 40 KB, 120 VGPRs), 256 CUs
-    const dim3 grid((unsigned)(ntile < 1024 ? ntile : 1024));
+    // as many persistent blocks as the CUs hold at once (256 CUs)
+    const int64_t nres = 256ll * (big ? NN_MINB_BIG : 4);
+    const dim3 grid((unsigned)(ntile < nres ? ntile : nres));
 #define NN_LAUNCH(BG, KV, FN)                                                  \
   hipLaunchKernelGGL((nn_linear_kernel<BG, KV, FN>), grid, dim3(256), 0, st,   \
                      cur, W[l], b[l], B, K, N, nxt, templ)
@@ -662,7 +670,8 @@ extern "C" int rvs_template_nn_arms(const double *params, int B, int ndim,
     const bool big = (int64_t)ntc * ((B + NN_BM - 1) / NN_BM) >= 1024;
     const int64_t ntile = (int64_t)ntc * (big ? (B + NN_BM - 1) / NN_BM
                                               : (B + 31) / 32);
-    const dim3 grid((unsigned)(ntile < 1024 ? ntile : 1024), narm);
+    const int64_t nres = 256ll * (big ? NN_MINB_BIG : 4);
+    const dim3 grid((unsigned)(ntile < nres ? ntile : nres), narm);
     if (big)
       hipLaunchKernelGGL((nn_linear_group_kernel<true, true>), grid, dim3(256), 0,
                          st, LG, B, K);

@@ -736,21 +736,21 @@ def main():
         """HBM bytes per launch of `kernel` for THIS configuration, from the
         committed rocprofv3 counter passes of this build (FETCH_SIZE x 2 +
         WRITE_SIZE, separate runs, tools/perf/pmc_traffic.sh): the entry of
-        profiles/r03_pmc_traffic.json whose key is this run's configuration, or
+        profiles/r04_pmc_traffic.json whose key is this run's configuration, or
         None when that configuration has not been profiled -- a figure measured
         on another workload is never stamped on this line"""
-        f = os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')
+        f = os.path.join(REPO, 'profiles', 'r04_pmc_traffic.json')
         try:
             d = json.load(open(f))[tkey][kernel]
             return d['hbm_bytes_per_launch'], \
-                'profiles/r03_pmc_traffic.json[%s] (%s)' % (tkey, d['source'])
+                'profiles/r04_pmc_traffic.json[%s] (%s)' % (tkey, d['source'])
         except Exception:
             return None, None
 
     def sq_counters(kernel):
         """SQ / GRBM counters per launch (tools/perf/xc_counters.sh), default
         configuration only; None otherwise"""
-        f = os.path.join(REPO, 'profiles', 'r03_sq_counters.json')
+        f = os.path.join(REPO, 'profiles', 'r04_sq_counters.json')
         try:
             d = json.load(open(f))
             if d.get('traffic_key') != tkey:
@@ -808,7 +808,7 @@ def main():
         cb_['l2_to_l1_TBps'] = sq.get('l2_to_l1_TBps')
         cb_['valu_busy'] = sq.get('valu_busy')
         cb_['lds_busy'] = sq.get('lds_busy')
-        cb_['source'] = (cb_['source'] or '') + ' + profiles/r03_sq_counters.json'
+        cb_['source'] = (cb_['source'] or '') + ' + profiles/r04_sq_counters.json'
     roof_ccf['counter_backed'] = cb_
     kernels = {
         'ccf_xcorr': dict(ms_per_step=round(ms / args.steps, 2),

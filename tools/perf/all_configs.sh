@@ -29,6 +29,13 @@ run --evaluator nn --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --proce
 run --evaluator nn --spectra 10000 --steps 1 --warmup 1 --no-cpu-baseline --process 10000
 # the DESI driver on MLP libraries (random weights: the fits themselves mean nothing)
 run --evaluator nn --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --desi-nfiles 16
+# round 4: the reference's own npoly (15), every spectrum on its own wavelength
+# grid, the optimiser on the realistic-size library at full batch size
+run --npoly 15 --steps 3 --warmup 1 --no-cpu-baseline
+run --npoly 13 --steps 3 --warmup 1 --no-cpu-baseline
+run --workload sdss --steps 3 --warmup 1 --cpu-sample 128
+run --grid 40,11,8,5 --spectra 10000 --steps 1 --warmup 1 --no-cpu-baseline --process 10000
+run --npoly 15 --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000
 python - <<PY
 import json
 for l in open("$out"):

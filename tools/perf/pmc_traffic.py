@@ -36,7 +36,7 @@ def main():
     def entry(names, count_name, what):
         f = sum(sum(v) for k, v in fe.items() if any(n in k for n in names))
         w = sum(sum(v) for k, v in wr.items() if any(n in k for n in names))
-        n = sum(len(v) for k, v in fe.items() if count_name in k)
+        n = sum(len(v) for k, v in fe.items() if all(c in k for c in count_name))
         return dict(launches=n, fetch_size_raw_kb=f, write_size_raw_kb=w,
                     hbm_bytes_per_launch=(2 * f + w) * 1024 / max(n, 1),
                     fetch_uncorrected_bytes_per_launch=f * 1024 / max(n, 1),
@@ -46,13 +46,14 @@ def main():
                            '1 --no-cpu-baseline %s, tag %s' % (bargs, tag))
     d = json.load(open(out)) if os.path.exists(out) else {}
     d[key] = dict(
-        ccf_xcorr=entry(['ccf_xcorr_kernel'], 'ccf_xcorr_kernel',
+        ccf_xcorr=entry(['ccf_xcorr_kernel'], ('ccf_xcorr_kernel', ),
                         'ccf_xcorr_kernel (one launch = one accumulator chunk x T '
                         'templates x one arm)'),
         chisq_grid=entry(['chisq_grid_kernel', 'chisq_grid_resol'],
-                         'chisq_grid_kernel<10, false>'
+                         # (one full-wave launch per rvs_chisq_grid call, any npoly)
+                         ('chisq_grid_kernel<', ', false>')
                          if not any('chisq_grid_resol' in k for k in fe)
-                         else 'chisq_grid_resol',
+                         else ('chisq_grid_resol', ),
                          'every chisq_grid kernel of one rvs_chisq_grid call (full '
                          'waves + packed left-over velocities); FETCH_SIZE '
                          'doubling is calibrated for 16-B streaming reads, this '

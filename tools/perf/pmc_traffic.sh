@@ -4,7 +4,7 @@
 # two rocprofv3 counter passes per configuration (FETCH_SIZE, WRITE_SIZE; kernel
 # trace only, the program directly after `--`), reduced by pmc_traffic.py into
 # gpurun_out/pmc_traffic_<tag>.json keyed by the line's config.traffic_key.
-# Copy the result to profiles/r03_pmc_traffic.json (bench.py reads it).
+# Copy the result to profiles/r04_pmc_traffic.json (bench.py reads it).
 tag=${1:-x}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
@@ -29,4 +29,6 @@ cfg --refine
 cfg --resolution-matrix
 cfg --spectra 62500
 cfg --grid 40,11,8,5
+cfg --npoly 15
+cfg --workload sdss
 cat $out | head -c 3000

@@ -2050,3 +2050,41 @@ def test_ccf_readback_paths_agree(cases, config):
     a = out[5][1][np.searchsorted(out[5][0], common)]
     b = out[2][1][np.searchsorted(out[2][0], common)]
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_grid_redo_third_tier_singular_matrix(cases, config):
+    """The tiers behind the velocity-grid kernel (engine.chisq_grid.by_point_kernel,
+    spec_fit.py:337-354): a job whose normal matrix NEITHER kernel can factor -- a
+    template that vanishes everywhere makes it exactly zero -- goes through
+    rvs_chisq_full's eigen branch; the job is flagged, its value is what
+    rvs_chisq_full returns for it, and the other jobs of the call are untouched."""
+    from rvspecfit_amd import _lib, engine, spec_fit, spec_inter
+    sds = _sds(cases, 'c1')
+    b, _ = spec_fit.as_batch(sds)
+    libs = spec_inter.get_libs(b.names, config)
+    vg = torch.as_tensor(np.linspace(-100., 100., 21)).to('cuda')
+    par = torch.as_tensor(np.array([cases['c1/g3/params_list'][0]] * 2)).to('cuda')
+    coefs, outs = [], []
+    for arm in b.arms:
+        c, o = engine.build_templates(libs[arm.name], par, None)
+        coefs.append(c)
+        outs.append(o)
+    js = torch.zeros(2, dtype=torch.int32, device='cuda')
+    jt = torch.arange(2, dtype=torch.int32, device='cuda')
+    ref, st0 = engine.chisq_grid(b, libs, coefs, outs, vg, npoly=10, job_spec=js,
+                                 job_templ=jt)
+    assert int(st0.sum().item()) == 0
+    dead = [c.clone() for c in coefs]
+    for c in dead:
+        c[1] = 0.0                      # template 1: zero spline records
+    got, st = engine.chisq_grid(b, libs, dead, outs, vg, npoly=10, job_spec=js,
+                                job_templ=jt)
+    st = st.cpu().numpy()
+    assert st[0] == 0 and np.array_equal(got[0].cpu().numpy(), ref[0].cpu().numpy())
+    assert st[1] & _lib.ST_CHOL_FALLBACK and st[1] & _lib.ST_NONFINITE
+    full = engine.chisq_full(b, libs, dead, vg[:1].expand(1).contiguous(), npoly=10,
+                             job_spec=js[1:], job_templ=jt[1:], want_models=False)
+    # the eigen branch on an exactly singular matrix: not a finite likelihood
+    assert all(f['status'][0].item() & _lib.ST_CHOL_FALLBACK for f in full)
+    assert not np.isfinite(got[1].cpu().numpy()).any()

@@ -155,7 +155,15 @@ __global__ void __launch_bounds__(OBJ_NT)
   constexpr int NV = NT + P;
   extern __shared__ double lds[];
   __shared__ PolyLoc PL;
-  __shared__ double red[OBJ_NW][NV + 1];
+  // wave totals of the NV sums.  Up to P = 10 a static array; beyond (P = 15: 8.7 KB,
+  // which took the DESI z arm's 6449 knots out of the kernel's reach in round 3:
+  // `--npoly 15 --process` ran the kernel chain, 452 spectra/s) they live in the
+  // template buffer, which is dead by the time they are formed -- such an
+  // instantiation needs the sigma-scaled model to fit the factor buffer (2 npix <=
+  // ntp, checked by the launcher)
+  constexpr bool RED_DYN = (P > 10);
+  __shared__ double red_static[RED_DYN ? 1 : OBJ_NW * (NV + 1)];
+  __shared__ double edge_s[OBJ_NW][6];   // chunk coefficients across wave boundaries
   __shared__ double coefs[P + 2];
   __shared__ double Lm[P][P + 1];
   __shared__ double ldv[P];
@@ -179,6 +187,8 @@ __global__ void __launch_bounds__(OBJ_NT)
   const int lane = tid & 63, w = tid >> 6;
   const int N = T.ntp, m = N - 2;
   double *bufA = lds, *bufB = lds + N, *bufC = lds + 2 * N;
+  double (*red)[NV + 1] =
+      reinterpret_cast<double (*)[NV + 1]>(RED_DYN ? bufA : red_static);
   const int nd = T.ndim, nv = 1 << nd;
 #ifdef RVS_OBJ_TIMING
   unsigned long long t_prev = wall_clock64();
@@ -545,7 +555,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   double loc[OBJ_CHMAX], pr[OBJ_CHMAX];
   // value entering a chunk from `dir` = -1 (lower threads) or +1 (upper): the
   // three nearest chunks' coefficients through wave shuffles, across a wave
-  // boundary through red[] (static LDS, free until the reductions)
+  // boundary through edge_s[] (static LDS)
   auto chain3 = [&](double al, double be, int dir) -> double {
     double av3[3], bv3[3];
 #pragma unroll
@@ -555,8 +565,8 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
     const int edge = (dir < 0) ? (63 - lane) : lane;  // 0..2: published lanes
     if (edge < 3) {
-      red[w][2 * edge] = al;
-      red[w][2 * edge + 1] = be;
+      edge_s[w][2 * edge] = al;
+      edge_s[w][2 * edge + 1] = be;
     }
     __syncthreads();
     const int mine = (dir < 0) ? lane : (63 - lane);  // distance to the boundary
@@ -566,8 +576,8 @@ __global__ void __launch_bounds__(OBJ_NT)
         const int ww = w + dir;
         const int sl = k - 1 - mine;  // its distance from that wave's boundary
         const bool have = (ww >= 0 && ww < OBJ_NW);
-        av3[k - 1] = have ? red[ww][2 * sl] : 0.0;
-        bv3[k - 1] = have ? red[ww][2 * sl + 1] : 0.0;
+        av3[k - 1] = have ? edge_s[ww][2 * sl] : 0.0;
+        bv3[k - 1] = have ? edge_s[ww][2 * sl + 1] : 0.0;
       }
     }
     return av3[0] + bv3[0] * (av3[1] + bv3[1] * av3[2]);
@@ -813,6 +823,8 @@ __global__ void __launch_bounds__(OBJ_NT)
   };
   {
     constexpr int PA = obj_split(P);
+    // (red[] in the template buffer: every thread has left the model pass)
+    if (RED_DYN) __syncthreads();
     normal_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, PA>{});
     if constexpr (PA < P)
       normal_pass(std::integral_constant<int, PA>{}, std::integral_constant<int, P>{});
@@ -1102,6 +1114,9 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
   dim3 grid(J, narm);
   if (shm > (size_t)3 * rvs_objective_max_ntp(npoly) * sizeof(double))
     return RVS_E_ARG;
+  if (npoly > 10)   // (the wave totals share the template buffer: RED_DYN)
+    for (int i = 0; i < narm; i++)
+      if (2 * arms[i].pt.npix > arms[i].ntp) return RVS_E_ARG;
   const double *loc = nullptr;
   int32_t *perm = nullptr;
   if (!tt) {

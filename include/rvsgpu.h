@@ -61,7 +61,8 @@ extern "C" {
  *      rvs_chisq_prepare_g, rvs_chisq_grid_g, rvs_chisq_full_g,
  *      rvs_chisq_continuum_g, rvs_ccf_preprocess_g; rvs_point_arm grew (grid_id,
  *      polys_stride, G); rvs_objective_work_size grew (the jobs' cell order);
- *      rvs_nn_outside accepts nfx = nfy = 0 */
+ *      rvs_nn_outside accepts nfx = nfy = 0; rvs_basis_build, rvs_ccf_tables_build
+ *      (the per-grid tables on the device) */
 #define RVS_ABI_VERSION 7
 int rvs_abi_version(void);
 
@@ -434,6 +435,38 @@ int rvs_bfgs_result(void *h, double *x, double *fun, int32_t *nit,
                     int32_t *nfev, int32_t *status, double *hess_inv,
                     int64_t *rounds);
 void rvs_bfgs_end(void *h);
+
+/* ------------------------------------------------------------------------
+ * The tables that depend only on a wavelength grid, for G grids at once (one per
+ * arm on the fast path; one per SPECTRUM for SDSS-style objects): built on the
+ * device because on the host they cost ~10 ms per grid (LAPACK QR, searches).
+ *
+ * rvs_basis_build: the continuum basis get_basis (spec_fit.py:148-176) -- rbf != 0:
+ * 1, x, x^2 and npoly-3 Gaussians at `cen` (device, np.linspace(-1, 1, npoly-3));
+ * rbf == 0: Chebyshev T_i by numpy's Clenshaw recursion -- on x = the grid's own
+ * range mapped to [-1, 1]; raw [G, npix+1, npoly] pixel-major (rows from a grid's
+ * pixel count on are 0); ortho (nullable) the same function space orthonormalised
+ * over the grid's pixels (modified Gram-Schmidt, twice) with logdet[g] =
+ * 2 sum log R_jj, what the velocity-grid kernel reads (see rvs_chisq_grid).
+ * lam [G, npix]; npix_g int32 [G] or NULL (every grid has npix pixels). */
+int rvs_basis_build(const double *lam, const int32_t *npix_g, int G, int npix,
+                    int npoly, int rbf, const double *cen, double *raw,
+                    double *ortho, double *logdet, void *stream);
+/* rvs_ccf_tables_build: the grid-dependent tables of rvs_ccf_preprocess(_g):
+ * xind / rw [G, nfft] (make_ccf.py:355-357, 394-399; ccf_lam [nfft] = the FFT grid's
+ * wavelengths, device), and with `continuum` the B-spline form of the k = 2
+ * interpolating spline through the continuum nodes (make_ccf.py:155-164; FITPACK
+ * knots and fpbspl): Eb [G, npix, 3], El [G, npix], istart [G, nnode], bin_start
+ * [G, nnode + 1] (make_ccf.py:128-143, scipy.stats.binned_statistic ranges) from
+ * nodes [G, nnode] / edges [G, nnode + 1] / nnode_g [G] (make_ccf.py:123-131,
+ * computed by the caller: a log and an exp per node).  The collocation matrix and
+ * its inverse (Cinv) stay with the caller (nnode <= 24). */
+int rvs_ccf_tables_build(const double *lam, const int32_t *npix_g, int G, int npix,
+                         const double *ccf_lam, int nfft, int continuum,
+                         const double *nodes, const double *edges,
+                         const int32_t *nnode_g, int nnode, int32_t *xind,
+                         double *rw, double *Eb, int32_t *El, int32_t *istart,
+                         int32_t *bin_start, void *stream);
 
 /* ------------------------------------------------------------------------
  * A12  grid summary; replaces the tail of spec_fit.find_best

@@ -69,6 +69,9 @@ SIGNATURES = {
     'rvs_objective_from_template': (I, [P, I, I, P, P, P, P, I, P, D, I, P, P, P,
                                         P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
+    'rvs_basis_build': (I, [P, P, I, I, I, I, P, P, P, P, P]),
+    'rvs_ccf_tables_build': (I, [P, P, I, I, P, I, I, P, P, P, I, P, P, P, P, P, P,
+                                 P]),
     'rvs_ccf_preprocess': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I, D,
                                P, P, P, P, P, P, P]),
     'rvs_ccf_preprocess_g': (I, [P, P, P, P, I, I, I, P, P, P, P, I, P, P, P, I,

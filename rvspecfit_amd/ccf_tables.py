@@ -85,6 +85,14 @@ def interp_spline_tables(nodes, lam, k=2):
     return Eb, El, np.linalg.inv(C), istart
 
 
+def collocation(nodes, k=2):
+    """(C^-1, C) of the interpolating spline through `nodes` alone: the part of
+    interp_spline_tables that does not depend on the pixels (the pixel part is
+    rvs_ccf_tables_build's)"""
+    _, _, Cinv, _ = interp_spline_tables(nodes, np.asarray(nodes)[:1], k)
+    return Cinv, np.linalg.inv(Cinv)
+
+
 def interp_spline_design(nodes, lam, k=2):
     """Dense Lmat [len(lam), len(nodes)] with
     UnivariateSpline(nodes, p, s=0, k=2)(lam) == Lmat @ p (tests)."""

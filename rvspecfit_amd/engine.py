@@ -73,6 +73,10 @@ def get_poly_basis(lam, npoly, rbf=True):
     return out
 
 
+# per-grid tables (basis, orthonormal basis, CCF rebin / spline tables) on the device
+# (csrc/tables.hip); False: numpy, grid by grid (tests/test_tables_gpu.py compares)
+DEVICE_TABLES = True
+
 RES_MAXND = 33   # widest band the velocity-grid kernel holds in its LDS ring;
                  # wider matrices run the grid through the point kernel
 
@@ -187,10 +191,19 @@ class ArmData:
     def subset(self, idx):
         """ArmData of the spectra idx (device long tensor)"""
         if self.G > 1:
-            a = ArmData(self.name, self.grids, self.spec[idx], self.espec[idx],
-                        self.badmask[idx], device=self.device,
-                        grid_id=self.grid_id[idx].cpu().numpy())
-            return a
+            # only the grids the subset uses (a half of a 10 000-grid batch does not
+            # carry the other half's tables)
+            used, gid = np.unique(self.grid_id[idx].cpu().numpy(),
+                                  return_inverse=True)
+            npx = int(self.npix_g[used].max())
+            if len(used) == 1:
+                return ArmData(self.name, self.grids[int(used[0])],
+                               self.spec[idx][:, :npx], self.espec[idx][:, :npx],
+                               self.badmask[idx][:, :npx], device=self.device)
+            return ArmData(self.name, [self.grids[int(k)] for k in used],
+                           self.spec[idx][:, :npx], self.espec[idx][:, :npx],
+                           self.badmask[idx][:, :npx], device=self.device,
+                           grid_id=gid.astype(np.int32))
         a = ArmData(self.name, self.lam_host, self.spec[idx], self.espec[idx],
                     self.badmask[idx], device=self.device)
         if self.resol is not None:
@@ -225,10 +238,39 @@ class ArmData:
         """doubles between the basis tables of consecutive grids"""
         return (self.npix + 1) * npoly
 
+    def _npix_g_dev(self):
+        if self.G == 1:
+            return None
+        if getattr(self, '_npix_g_t', None) is None:
+            self._npix_g_t = torch.as_tensor(self.npix_g).to(self.device)
+        return self._npix_g_t
+
+    def _build_basis(self, npoly, rbf):
+        """raw and orthonormal basis of every grid (rvs_basis_build), cached"""
+        key = ('dev', npoly, bool(rbf))
+        if key not in self._basis:
+            G, npx = self.G, self.npix
+            f64 = dict(dtype=torch.float64, device=self.device)
+            raw = torch.empty((G, npx + 1, npoly), **f64)
+            qt = torch.empty((G, npx + 1, npoly), **f64)
+            ld = torch.empty(G, **f64)
+            cen = torch.as_tensor(np.linspace(-1, 1, max(npoly - 3, 1), True)).to(
+                self.device)
+            rc = _lib.lib().rvs_basis_build(
+                _lib.ptr(self.lam), _lib.ptr(self._npix_g_dev()), G, npx, npoly,
+                int(bool(rbf)), _lib.ptr(cen), _lib.ptr(raw), _lib.ptr(qt),
+                _lib.ptr(ld), _lib.stream())
+            _lib.check(rc, 'rvs_basis_build')
+            self._basis[key] = (raw, qt, ld)
+        return self._basis[key]
+
     def basis(self, npoly, rbf):
         """pixel-major continuum basis get_poly_basis(lam).T (+ one zero row) of
         every grid: [npix + 1, npoly], or [G, npix + 1, npoly] (rows behind a
         grid's last pixel are zero)"""
+        if DEVICE_TABLES:
+            raw = self._build_basis(npoly, rbf)[0]
+            return raw[0] if self.G == 1 else raw
         key = (npoly, bool(rbf))
         if key not in self._basis:
             PT = np.zeros((self.G, self.npix + 1, npoly))
@@ -240,7 +282,7 @@ class ArmData:
 
     def basis_ortho(self, npoly, rbf):
         """The same function space in an orthonormal basis, for the chi^2-grid
-        kernel: P^T = Q R (QR over the pixels) -> rows of Q^T.  The marginalised
+        kernel: P^T = Q R over the pixels -> rows of Q^T.  The marginalised
         likelihood only depends on span(P): with M = R^T M' R,
             log det M = log det M' + 2 log|det R|     and  v^T M^-1 v = v'^T M'^-1 v',
         so the kernel works on M' (condition number ~1-10 instead of 1e4-1e5 for
@@ -248,22 +290,33 @@ class ArmData:
         of the in-register Cholesky at the 1e-10 level even at S/N 1000) and the
         constant 2 log|det R| is added back.  Returns (Q^T pixel-major, const):
         const is a float for one grid, a device tensor [S] (the constant of every
-        spectrum's grid) for a grid set."""
-        key = ('ortho', npoly, bool(rbf))
-        if key not in self._basis:
-            QT = np.zeros((self.G, self.npix + 1, npoly))
-            off = np.zeros(self.G)
-            for i, g in enumerate(self.grids):
-                P = get_poly_basis(g, npoly, rbf)
-                Q, R = np.linalg.qr(P.T)
-                QT[i, :len(g)] = Q
-                off[i] = 2.0 * float(np.sum(np.log(np.abs(np.diag(R)))))
+        spectrum's grid) for a grid set.  Built on the device (rvs_basis_build:
+        modified Gram-Schmidt, twice) -- on the host a QR per grid is 8 ms, 80 s
+        for a batch of SDSS-style spectra; DEVICE_TABLES = False keeps numpy's
+        Householder QR (tests compare the two)."""
+        key = ('ortho', npoly, bool(rbf), DEVICE_TABLES)
+        if key in self._basis:
+            return self._basis[key]
+        if DEVICE_TABLES:
+            _, qt, ld = self._build_basis(npoly, rbf)
             if self.G == 1:
-                self._basis[key] = (torch.as_tensor(QT[0]).to(self.device),
-                                    float(off[0]))
+                self._basis[key] = (qt[0], float(ld[0].item()))
             else:
-                offs = torch.as_tensor(off).to(self.device)[self.grid_id.long()]
-                self._basis[key] = (torch.as_tensor(QT).to(self.device), offs)
+                self._basis[key] = (qt, ld[self.grid_id.long()])
+            return self._basis[key]
+        QT = np.zeros((self.G, self.npix + 1, npoly))
+        off = np.zeros(self.G)
+        for i, g in enumerate(self.grids):
+            P = get_poly_basis(g, npoly, rbf)
+            Q, R = np.linalg.qr(P.T)
+            QT[i, :len(g)] = Q
+            off[i] = 2.0 * float(np.sum(np.log(np.abs(np.diag(R)))))
+        if self.G == 1:
+            self._basis[key] = (torch.as_tensor(QT[0]).to(self.device),
+                                float(off[0]))
+        else:
+            offs = torch.as_tensor(off).to(self.device)[self.grid_id.long()]
+            self._basis[key] = (torch.as_tensor(QT).to(self.device), offs)
         return self._basis[key]
 
     def work(self, lib, espec_sys=0.0):
@@ -318,9 +371,82 @@ class ArmData:
         T['lag_vel'] = torch.as_tensor(sub).to(dev)
         T['nlag'] = len(ind)
         T['ilo'] = torch.as_tensor(ccf_tables.interp_tables(sub, vgrid)).to(dev)
-        # per wavelength grid: rebin tables, and the continuum-spline tables (the
-        # node count follows the grid's range, make_ccf.py:123-131); one slice per
-        # grid, the longest grid / largest node count apart (rvs_ccf_preprocess_g)
+        tw = np.exp(2j * np.pi * np.arange(nfft // 2) / nfft)
+        T['twid'] = torch.as_tensor(
+            np.ascontiguousarray(tw).view(np.float64)).to(dev)
+        if DEVICE_TABLES:
+            self._ccf_grid_tables_device(T, cc, nfft)
+        else:
+            self._ccf_grid_tables_host(T, cc, nfft)
+        self._ccf[key] = T
+        return T
+
+
+    def _ccf_nodes(self, cc):
+        """continuum nodes / bin edges of every grid (make_ccf.py:123-131), padded
+        to the largest node count: nodes [G, nn], edges [G, nn + 1], count [G]"""
+        l0 = np.array([g.min() for g in self.grids])
+        l1 = np.array([g.max() for g in self.grids])
+        dl = np.log(1 + cc['splinestep'] / 3e5)
+        N = np.ceil(np.log(l1 / l0) / dl).astype(np.int64)
+        nn = int(N.max())
+        nodes = l0[:, None] * np.exp(np.arange(nn) * dl)[None, :]
+        edges = l0[:, None] * np.exp((-0.5 + np.arange(nn + 1)) * dl)[None, :]
+        return nodes, edges, N.astype(np.int32), nn
+
+    def _ccf_grid_tables_device(self, T, cc, nfft):
+        """per-grid tables by rvs_ccf_tables_build; the collocation matrices (a few
+        dozen numbers per grid) on the host"""
+        dev, G, npx = self.device, self.G, self.npix
+        ccf_lam = torch.as_tensor(np.exp(np.linspace(cc['logl0'], cc['logl1'],
+                                                     nfft))).to(dev)
+        xi = torch.empty((G, nfft), dtype=torch.int32, device=dev)
+        rw = torch.empty((G, nfft), dtype=torch.float64, device=dev)
+        cont = bool(cc['continuum'])
+        nodes_t = edges_t = nng_t = Eb = El = ist = bst = None
+        nn = 0
+        if cont:
+            nodes, edges, nng, nn = self._ccf_nodes(cc)
+            nodes_t = torch.as_tensor(nodes).to(dev)
+            edges_t = torch.as_tensor(edges).to(dev)
+            nng_t = torch.as_tensor(nng).to(dev)
+            Eb = torch.empty((G, npx, 3), dtype=torch.float64, device=dev)
+            El = torch.empty((G, npx), dtype=torch.int32, device=dev)
+            ist = torch.empty((G, nn), dtype=torch.int32, device=dev)
+            bst = torch.empty((G, nn + 1), dtype=torch.int32, device=dev)
+        rc = _lib.lib().rvs_ccf_tables_build(
+            _lib.ptr(self.lam), _lib.ptr(self._npix_g_dev()), G, npx,
+            _lib.ptr(ccf_lam), nfft, int(cont), _lib.ptr(nodes_t),
+            _lib.ptr(edges_t), _lib.ptr(nng_t), nn, _lib.ptr(xi), _lib.ptr(rw),
+            _lib.ptr(Eb), _lib.ptr(El), _lib.ptr(ist), _lib.ptr(bst), _lib.stream())
+        _lib.check(rc, 'rvs_ccf_tables_build')
+        one = (G == 1)
+        T['xind'], T['rw'] = (xi[0], rw[0]) if one else (xi, rw)
+        T['npix_g'] = T['nnode_g'] = None
+        if cont:
+            Cinv = np.zeros((G, 2 * nn * nn))
+            for i in range(G):
+                m = int(nng[i])
+                ci, c = ccf_tables.collocation(nodes[i, :m])
+                Cinv[i, :m * m] = ci.ravel()
+                Cinv[i, m * m:2 * m * m] = c.ravel()
+            T['Eb'], T['El'] = (Eb[0], El[0]) if one else (Eb, El)
+            T['istart'], T['bin_start'] = (ist[0], bst[0]) if one else (ist, bst)
+            T['Cinv'] = torch.as_tensor(Cinv[0] if one else Cinv).to(dev)
+            T['nnode'] = nn
+            if not one:
+                T['nnode_g'] = nng_t
+        else:
+            T['Eb'] = T['El'] = T['Cinv'] = T['istart'] = None
+            T['nnode'], T['bin_start'] = 0, None
+        if G > 1:
+            T['npix_g'] = self._npix_g_dev()
+
+    def _ccf_grid_tables_host(self, T, cc, nfft):
+        """the same tables with numpy, grid by grid (ccf_tables.py; DEVICE_TABLES =
+        False: what rounds 1-3 shipped, kept as the statement the device tables are
+        tested against)"""
+        dev = self.device
         G = self.G
         xi = np.empty((G, nfft), dtype=np.int32)
         rw = np.empty((G, nfft))
@@ -332,9 +458,6 @@ class ArmData:
                 per.append((nodes, edges) + ccf_tables.interp_spline_tables(nodes, g))
         T['xind'] = torch.as_tensor(xi if G > 1 else xi[0]).to(dev)
         T['rw'] = torch.as_tensor(rw if G > 1 else rw[0]).to(dev)
-        tw = np.exp(2j * np.pi * np.arange(nfft // 2) / nfft)
-        T['twid'] = torch.as_tensor(
-            np.ascontiguousarray(tw).view(np.float64)).to(dev)
         T['npix_g'] = T['nnode_g'] = None
         if cc['continuum']:
             nn = max(len(q[0]) for q in per)
@@ -367,8 +490,6 @@ class ArmData:
             T['nnode'], T['bin_start'] = 0, None
         if G > 1:
             T['npix_g'] = torch.as_tensor(self.npix_g).to(dev)
-        self._ccf[key] = T
-        return T
 
 
 def make_resol(taps, nd, S, device):

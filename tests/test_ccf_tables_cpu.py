@@ -1,0 +1,59 @@
+"""Host tables of the CCF pre-processing (rvspecfit_amd/ccf_tables.py): the
+vectorised B-spline basis (round 4: per-grid tables of a grid set are built for
+thousands of grids) against the scalar FITPACK recursion it replaced, and the design
+matrix against scipy's own interpolating spline (make_ccf.py:155-164)."""
+import numpy as np
+from scipy.interpolate import UnivariateSpline
+
+from rvspecfit_amd import ccf_tables as ct
+
+
+def _grids():
+    full = 10**(3.5798 + 1e-4 * np.arange(3842))          # an SDSS lattice
+    yield np.exp(np.linspace(np.log(3600), np.log(5800), 2751))
+    yield np.arange(7520., 9824.1, 0.8)                    # DESI z, linear
+    for a, n in ((0, 3842), (37, 3805), (255, 3200), (800, 3042)):
+        yield full[a:a + n]
+
+
+def test_vectorised_basis_is_the_scalar_recursion():
+    for lam in _grids():
+        nodes, _ = ct.continuum_nodes(lam, 1000.)
+        Eb, El, Cinv, istart = ct.interp_spline_tables(nodes, lam)
+        m, k = len(nodes), 2
+        t = np.concatenate([[nodes[0]] * 3, 0.5 * (nodes[1:m - 2] + nodes[2:m - 1]),
+                            [nodes[-1]] * 3])
+        n = len(t)
+        for r in range(0, len(lam), 29):
+            l = np.searchsorted(t, lam[r], 'right') - 1
+            l = min(max(l, k), n - k - 2)
+            assert np.array_equal(ct._bspl_basis(t, k, lam[r], l), Eb[r])
+            assert El[r] == l - k
+        assert np.all(np.diff(El) >= 0)
+        assert istart[0] == 0 and istart[-1] == len(lam)
+        assert np.all(np.diff(istart) >= 0)
+        assert np.allclose(Cinv @ np.linalg.inv(Cinv), np.eye(m), atol=1e-9)
+
+
+def test_design_matrix_is_scipys_interpolating_spline():
+    rng = np.random.RandomState(3)
+    for lam in _grids():
+        nodes, edges = ct.continuum_nodes(lam, 1000.)
+        p = rng.normal(size=len(nodes))
+        want = UnivariateSpline(nodes, p, s=0, k=2)(lam)
+        got = ct.interp_spline_design(nodes, lam) @ p
+        assert np.abs(got - want).max() < 1e-12 * max(1.0, np.abs(want).max())
+        # every pixel inside the edges belongs to exactly one bin
+        b = ct.bin_ranges(lam, edges)
+        assert b[0] >= 0 and b[-1] <= len(lam) and np.all(np.diff(b) >= 0)
+
+
+def test_rebin_tables_bracket_the_fft_grid():
+    for lam in _grids():
+        l0, l1 = np.log(lam[0] * 0.98), np.log(lam[-1] * 1.02)
+        xi, rw = ct.rebin_tables(lam, l0, l1, 4096)
+        g = np.exp(np.linspace(l0, l1, 4096))
+        ok = xi >= 0
+        assert ok.any() and (~ok).any()
+        assert np.all(lam[xi[ok]] <= g[ok]) and np.all(g[ok] <= lam[xi[ok] + 1])
+        assert np.all((rw[ok] >= 0) & (rw[ok] <= 1)) and not rw[~ok].any()

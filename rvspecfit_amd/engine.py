@@ -424,12 +424,7 @@ class ArmData:
         T['xind'], T['rw'] = (xi[0], rw[0]) if one else (xi, rw)
         T['npix_g'] = T['nnode_g'] = None
         if cont:
-            Cinv = np.zeros((G, 2 * nn * nn))
-            for i in range(G):
-                m = int(nng[i])
-                ci, c = ccf_tables.collocation(nodes[i, :m])
-                Cinv[i, :m * m] = ci.ravel()
-                Cinv[i, m * m:2 * m * m] = c.ravel()
+            Cinv = ccf_tables.collocation_batch(nodes, nng)
             T['Eb'], T['El'] = (Eb[0], El[0]) if one else (Eb, El)
             T['istart'], T['bin_start'] = (ist[0], bst[0]) if one else (ist, bst)
             T['Cinv'] = torch.as_tensor(Cinv[0] if one else Cinv).to(dev)

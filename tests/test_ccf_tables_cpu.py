@@ -57,3 +57,25 @@ def test_rebin_tables_bracket_the_fft_grid():
         assert ok.any() and (~ok).any()
         assert np.all(lam[xi[ok]] <= g[ok]) and np.all(g[ok] <= lam[xi[ok] + 1])
         assert np.all((rw[ok] >= 0) & (rw[ok] <= 1)) and not rw[~ok].any()
+
+
+def test_collocation_batch_is_grid_by_grid():
+    """the stacked collocation inverses of a grid set (engine: device tables) are
+    the per-grid ones, bit for bit, also when the grids differ in node count"""
+    grids = list(_grids())
+    sets = [ct.continuum_nodes(g, 13000.)[0] for g in grids] + \
+        [ct.continuum_nodes(g, 9000.)[0] for g in grids[:2]]
+    m = np.array([len(n) for n in sets])
+    assert len(set(m)) > 1
+    nn = m.max()
+    nodes = np.zeros((len(sets), nn))
+    for i, n in enumerate(sets):
+        nodes[i, :len(n)] = n
+        nodes[i, len(n):] = n[0] * np.exp(np.arange(len(n), nn) * 0.03)  # as engine pads
+    out = ct.collocation_batch(nodes, m)
+    for i, n in enumerate(sets):
+        ci, c = ct.collocation(n)
+        mm = len(n)
+        assert np.array_equal(out[i, :mm * mm], ci.ravel()), i
+        assert np.array_equal(out[i, mm * mm:2 * mm * mm], c.ravel()), i
+        assert not out[i, 2 * mm * mm:].any()

@@ -999,9 +999,9 @@ def process_roofline(sub, r, out, tm, dt, dt1):
             import torch
             R = (torch.nan_to_num(vs.double(), nan=0.0) / 299792.458) / lib.lnstep
             kt = float((2 * torch.ceil(R + 1) + 1).mean())
-        fl, by = objective_model(lib.ntp, len(a.lam_host), OPTIONS['npoly'], nvert, kt,
-                                 kind)
-        per_arm[a.name] = dict(ntp=lib.ntp, npix=len(a.lam_host), nvert=nvert,
+        npx = float(a.npix_g[a.grid_id_host].mean()) if a.G > 1 else a.npix
+        fl, by = objective_model(lib.ntp, npx, OPTIONS['npoly'], nvert, kt, kind)
+        per_arm[a.name] = dict(ntp=lib.ntp, npix=round(npx, 1), nvert=nvert,
                                taps=round(kt, 1), flops=int(sum(fl.values())),
                                flops_by_phase={k: int(v) for k, v in fl.items()},
                                gathered_bytes=by)
@@ -1041,9 +1041,12 @@ def run_process_addon(batch, rec, arms, args, dev):
     from rvspecfit_amd import engine, pipeline, vel_fit
     n = min(args.process, batch.S)
     idx = torch.arange(n, device=dev)
-    sub = engine.SpecBatch([engine.ArmData(a.name, a.lam_host, a.spec[idx],
-                                           a.espec[idx], a.badmask[idx],
-                                           device=dev) for a in batch.arms])
+    if any(a.G > 1 for a in batch.arms):   # (--workload sdss: a grid set)
+        sub = batch.subset(idx)
+    else:
+        sub = engine.SpecBatch([engine.ArmData(a.name, a.lam_host, a.spec[idx],
+                                               a.espec[idx], a.badmask[idx],
+                                               device=dev) for a in batch.arms])
     F = pipeline.RECORD_FIELDS
     names = ['teff', 'logg', 'feh', 'alpha']
     r0 = rec[:n]

@@ -584,6 +584,14 @@ def _merge_parts(parts, idxs, S):
         if isinstance(v, (list, tuple)):
             return [merge([x[i] for x in vals]) for i in range(len(v))]
         if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n0:
+            if v.dim() == 2 and len({x.shape[1] for x in vals}) > 1:
+                # per-pixel rows of a grid set: each part is as wide as the longest
+                # grid IT holds (ArmData.subset); zeros behind a spectrum's pixels
+                out = torch.zeros((S, max(x.shape[1] for x in vals)),
+                                  dtype=v.dtype, device=v.device)
+                for x, ix in zip(vals, idxs):
+                    out[ix, :x.shape[1]] = x
+                return out
             out = torch.empty((S, ) + tuple(v.shape[1:]), dtype=v.dtype,
                               device=v.device)
             for x, ix in zip(vals, idxs):

@@ -168,3 +168,30 @@ def test_process_on_grid_set(gcases, gbatch):
                               fixParam=[], config=CFG, options=OPT)
         assert abs(one['vel'] - vel[i]) <= 1e-6
         assert abs(one['chisq'] - chi[i]) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_process_two_halves_on_grid_set(gcases, gbatch, monkeypatch):
+    """a large batch is fitted as two concurrent halves (vel_fit._process_split);
+    on a grid set each half carries only its own grids (ArmData.subset), so the
+    per-pixel outputs of the halves differ in width: merged, the batch must equal
+    the one-piece run"""
+    import torch
+    from rvspecfit_amd import vel_fit
+    sds, batch = gbatch
+    S = len(sds)
+    start = np.array([list(gcases['s%d/ccf/best_par' % i]) +
+                      [float(gcases['s%d/ccf/best_vsini' % i])] for i in range(S)])
+    pd = {k: torch.as_tensor(start[:, j]).to(batch.device)
+          for j, k in enumerate(NAMES + ('vsini', ))}
+    one = vel_fit.process(batch, dict(pd), fixParam=[], config=CFG, options=OPT)
+    monkeypatch.setattr(vel_fit, 'PROCESS_SPLIT_MIN', 4)
+    two = vel_fit.process(batch, dict(pd), fixParam=[], config=CFG, options=OPT)
+    for k in ('vel', 'chisq', 'vsini', 'nm_nit'):
+        assert torch.equal(one[k], two[k]), k
+    ya, yb = one['yfit'][0].cpu().numpy(), two['yfit'][0].cpu().numpy()
+    assert ya.shape == yb.shape == (S, 3842)
+    assert np.array_equal(ya, yb)
+    for i in range(S):
+        n = len(sds[i][0].lam)
+        assert not ya[i, n:].any()

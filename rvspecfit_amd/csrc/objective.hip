@@ -37,6 +37,9 @@
 #define OBJ_VTX(u) min(u, nv - 1)
 #endif
 #define OBJ_CHMAX ((8192 + OBJ_NT - 1) / OBJ_NT)  // rows of a thread's Thomas chunk
+#ifndef OBJ_QP_LATE
+#define OBJ_QP_LATE 1
+#endif
 #define OBJ_W 32  // warm-up rows of the windowed recurrences (see template.hip)
 
 #ifdef RVS_OBJ_TIMING
@@ -845,12 +848,22 @@ __global__ void __launch_bounds__(OBJ_NT)
   // there, the other seven wait) instead of behind it
   constexpr int RPF = (P <= 10) ? 6 : (P <= 12 ? 4 : 3);
   double qp[RPF][P];
+  auto load_qp = [&]() {
 #pragma unroll
-  for (int u = 0; u < RPF; u++) {
-    const double *prow = AG.polysT + (int64_t)min(tid + u * OBJ_NT, npix - 1) * P;
+    for (int u = 0; u < RPF; u++) {
+      const double *prow = AG.polysT + (int64_t)min(tid + u * OBJ_NT, npix - 1) * P;
 #pragma unroll
-    for (int i = 0; i < P; i++) qp[u][i] = prow[i];
-  }
+      for (int i = 0; i < P; i++) qp[u][i] = prow[i];
+    }
+  };
+  // (wave 0 requests its rows behind the factorisation: 8 waves x 30 16-byte loads
+  // take the CU's address pipe ~1.5 us to accept, and the chain everybody waits for
+  // would start behind them)
+#if OBJ_QP_LATE
+  if (w != 0) load_qp();
+#else
+  load_qp();
+#endif
 #endif
   if (w == 0) {
     // Cholesky + the two triangular solves with ROW i on lane i (i < P):
@@ -903,6 +916,9 @@ __global__ void __launch_bounds__(OBJ_NT)
       row[jj] = (lane == jj) ? d : sum * rdj;
       Lm[i][jj] = row[jj];  // mirror for the back-substitution (column reads)
     }
+#if OBJ_PREFETCH && OBJ_QP_LATE
+    load_qp();
+#endif
     // log of the diagonal: all rows at once (not one per column of the loop)
     if (lane < P) ldv[lane] = log(dg);
     // L y = v, column by column: y_q from lane q, the rows below take their share

@@ -62,8 +62,11 @@ extern "C" {
  *      rvs_chisq_continuum_g, rvs_ccf_preprocess_g; rvs_point_arm grew (grid_id,
  *      polys_stride, G); rvs_objective_work_size grew (the jobs' cell order);
  *      rvs_nn_outside accepts nfx = nfy = 0; rvs_basis_build, rvs_ccf_tables_build
- *      (the per-grid tables on the device) */
-#define RVS_ABI_VERSION 7
+ *      (the per-grid tables on the device)
+ *   8: rvs_chisq_work_size(_g) grew by 2*S*npix doubles: rvs_chisq_prepare also
+ *      leaves {1/e, s/e} per spectrum pixel (e with espec_sys in quadrature), which
+ *      rvs_objective_fused / rvs_nm_run read instead of spec / espec */
+#define RVS_ABI_VERSION 8
 int rvs_abi_version(void);
 
 /* ------------------------------------------------------------------------

@@ -87,7 +87,7 @@ SIGNATURES = {
 
 _lib = None
 # RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class RvsGpuError(RuntimeError):

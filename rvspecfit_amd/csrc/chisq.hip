@@ -30,12 +30,15 @@
 //   takes any `lam` per object)
 // [G*npix, G*npix + 2*S*npix) {1/e^2, s/e^2} per spectrum pixel
 // then [2*S] {sum log e, sum s^2/e^2}
+// then [2*S*npix] {1/e, s/e} per spectrum pixel (ABI 8): the optimiser's objective
+//   works in units of sigma and used to form both -- a square root, a division and
+//   a product per pixel -- in every one of its ~1100 evaluations per spectrum
 // A grid shorter than npix is padded: lam repeats its last value, the spectra on
 // it carry espec = +inf there -- such a pixel has weight 0 and is left out of
 // sum log e.
 // ---------------------------------------------------------------------------
 extern "C" int64_t rvs_chisq_work_size_g(int npix, int S, int G) {
-  return (int64_t)G * npix + 2ll * S * npix + 2ll * S;
+  return (int64_t)G * npix + 4ll * S * npix + 2ll * S;
 }
 extern "C" int64_t rvs_chisq_work_size(int npix, int S) {
   return rvs_chisq_work_size_g(npix, S, 1);
@@ -51,6 +54,7 @@ __global__ void __launch_bounds__(256)
   const int s = blockIdx.x;
   double2 *W = reinterpret_cast<double2 *>(work + (int64_t)G * npix);
   double *scal = work + (int64_t)G * npix + 2ll * S * npix;
+  double2 *X = reinterpret_cast<double2 *>(scal + 2ll * S);
   if (s >= S) {  // extra blocks: pixel coordinates of grid s - S
     const double lx0 = log(x0);
     const double *lg = lam + (int64_t)(s - S) * npix;
@@ -66,6 +70,7 @@ __global__ void __launch_bounds__(256)
     double e = espec[(int64_t)s * npix + k];
     if (isinf(e)) {   // padding of a short grid: no weight, no term in sum log e
       W[(int64_t)s * npix + k] = make_double2(0.0, 0.0);
+      X[(int64_t)s * npix + k] = make_double2(0.0, 0.0);
       continue;
     }
     if (espec_sys > 0) e = sqrt(sys2 + e * e);
@@ -74,6 +79,8 @@ __global__ void __launch_bounds__(256)
     lz += log(e);
     dd += d * d;
     W[(int64_t)s * npix + k] = make_double2(1.0 / (e * e), sp / (e * e));
+    const double ie = 1.0 / e;
+    X[(int64_t)s * npix + k] = make_double2(ie, sp * ie);
   }
   lz = block_sum<4>(lz, red);
   dd = block_sum<4>(dd, red);

@@ -1079,6 +1079,7 @@ def run_process_addon(batch, rec, arms, args, dev):
                nm_iterations_mean=round(float(r['nm_nit'].float().mean()), 1),
                nm_iterations_max=int(r['nm_nit'].max()),
                objective_evals=int(r['objective_evals']),
+               nm_launched_rows=int(r.get('nm_launched_rows', 0)),
                minimize_success=round(float(
                    r['minimize_success'].float().mean()), 4),
                bad_hessian=round(float(np.mean(r['bad_hessian'])), 4),

@@ -65,7 +65,9 @@ extern "C" {
  *      (the per-grid tables on the device)
  *   8: rvs_chisq_work_size(_g) grew by 2*S*npix doubles: rvs_chisq_prepare also
  *      leaves {1/e, s/e} per spectrum pixel (e with espec_sys in quadrature), which
- *      rvs_objective_fused / rvs_nm_run read instead of spec / espec */
+ *      rvs_objective_fused / rvs_nm_run read instead of spec / espec;
+ *      rvs_objective_fused_n / rvs_objective_from_template_n (job count on the
+ *      device) */
 #define RVS_ABI_VERSION 8
 int rvs_abi_version(void);
 
@@ -411,6 +413,27 @@ int rvs_objective_from_template(const rvs_objective_arm *arms, int narm,
                                 int J, const double *vel, double badchi,
                                 int outside_penalty, void *scratch, double *out,
                                 int32_t *status, void *stream);
+
+/* Both with a job count that lives on the device (ABI 8): only the first
+ * min(J, njobs_dev[0]) jobs are evaluated, out[] / status[] of the others are left
+ * as they are; J still sizes the launch, the scratch and every array.  The
+ * lock-step optimiser (rvs_nm_run) knows on the host only an upper bound of the
+ * simplices that are still running and of those that need the second point of a
+ * round; the exact counts are its device counters.  NULL = all J. */
+int rvs_objective_fused_n(const rvs_objective_arm *arms, int narm, int npoly,
+                          const double *params, const double *vsini,
+                          const int32_t *job_spec, int J,
+                          const int32_t *njobs_dev, const double *vel,
+                          double badchi, int outside_penalty, void *scratch,
+                          double *out, int32_t *status, void *stream);
+int rvs_objective_from_template_n(const rvs_objective_arm *arms, int narm,
+                                  int npoly, const double *const *templ,
+                                  const double *const *outside,
+                                  const double *vsini, const int32_t *job_spec,
+                                  int J, const int32_t *njobs_dev,
+                                  const double *vel, double badchi,
+                                  int outside_penalty, void *scratch, double *out,
+                                  int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------
  * Host side of the second minimiser of vel_fit.process (vel_fit.py:653-658:

@@ -68,6 +68,9 @@ SIGNATURES = {
     'rvs_objective_fused': (I, [P, I, I, P, P, P, I, P, D, I, P, P, P, P]),
     'rvs_objective_from_template': (I, [P, I, I, P, P, P, P, I, P, D, I, P, P, P,
                                         P]),
+    'rvs_objective_fused_n': (I, [P, I, I, P, P, P, I, P, P, D, I, P, P, P, P]),
+    'rvs_objective_from_template_n': (I, [P, I, I, P, P, P, P, I, P, P, D, I, P,
+                                          P, P, P]),
     'rvs_grid_moments': (I, [P, P, L, P, I, I, I, I, P, P, P, P]),
     'rvs_basis_build': (I, [P, P, I, I, I, I, P, P, P, P, P]),
     'rvs_ccf_tables_build': (I, [P, P, I, I, P, I, I, P, P, P, I, P, P, P, P, P, P,

@@ -619,6 +619,12 @@ static int nm_eval(const rvs_nm_objective *o, const int32_t *list,
                         o->job_spec, o->vel, o->vsini, o->params, o->extra,
                         o->bad, st);
   if (rc) return rc;
+  // rows behind the device count (simplices that finished since the host's last look,
+  // simplices that need no second point this round) are not evaluated: a quarter of
+  // the objective blocks of a run (tools/perf/nm_waste.py).  (Sizing the second
+  // launch exactly by one more look per round: 2390-2445 against 2398 spectra/s,
+  // no difference -- a block behind the count costs next to nothing.)
+  const int32_t *live = counts ? counts + cidx : nullptr;
   if (o->nn) {
     // MLP libraries: the round's template rows and outside flags per arm, then
     // broadening + spline + chi^2 in one kernel (optimizer.py's from_templ path)
@@ -634,15 +640,15 @@ static int nm_eval(const rvs_nm_objective *o, const int32_t *list,
       tp[a] = o->nn[a].templ;
       op[a] = o->nn[a].outside;
     }
-    rc = rvs_objective_from_template(o->arms, o->narm, o->npoly, tp, op,
-                                     o->vsini, o->job_spec, J, o->vel, o->badchi,
-                                     1 | RVS_OBJ_STATUS_STORE, o->scratch, o->chi,
-                                     o->jstatus, st);
+    rc = rvs_objective_from_template_n(o->arms, o->narm, o->npoly, tp, op,
+                                       o->vsini, o->job_spec, J, live, o->vel,
+                                       o->badchi, 1 | RVS_OBJ_STATUS_STORE,
+                                       o->scratch, o->chi, o->jstatus, st);
   } else {
-    rc = rvs_objective_fused(o->arms, o->narm, o->npoly, o->params, o->vsini,
-                             o->job_spec, J, o->vel, o->badchi,
-                             1 | RVS_OBJ_STATUS_STORE, o->scratch, o->chi,
-                             o->jstatus, st);
+    rc = rvs_objective_fused_n(o->arms, o->narm, o->npoly, o->params, o->vsini,
+                               o->job_spec, J, live, o->vel, o->badchi,
+                               1 | RVS_OBJ_STATUS_STORE, o->scratch, o->chi,
+                               o->jstatus, st);
   }
   if (rc) return rc;
   return rvs_proc_finish(J, counts, cidx, o->chi, o->extra, o->bad, o->job_spec,

@@ -36,7 +36,8 @@
 #else
 #define OBJ_VTX(u) min(u, nv - 1)
 #endif
-#define OBJ_CHMAX ((8192 + OBJ_NT - 1) / OBJ_NT)  // rows of a thread's Thomas chunk
+// rows of a thread's Thomas chunk (at least the 12 the transfer coefficients need)
+#define OBJ_CHMAX ((8192 + OBJ_NT - 1) / OBJ_NT > 12 ? (8192 + OBJ_NT - 1) / OBJ_NT : 12)
 #ifndef OBJ_QP_LATE
 #define OBJ_QP_LATE 1
 #endif
@@ -75,10 +76,12 @@ extern "C" int rvs_dbg_read(unsigned long long *out) {
 #define OBJ_LOC_NT 256
 __global__ void __launch_bounds__(OBJ_LOC_NT)
     objective_locate_kernel(ObjArms A, const double *__restrict__ params, int J,
+                            const int32_t *__restrict__ live,
                             double *__restrict__ loc) {
   __shared__ PolyLoc PL;
   const rvs_objective_arm &T = A.a[blockIdx.y];
   const int j = blockIdx.x, tid = threadIdx.x;
+  if (live && j >= live[0]) return;   // (see objective_kernel)
   const GridDesc G = obj_grid_desc(T);
   poly_locate<OBJ_LOC_NT>(PL, G, params + (int64_t)j * T.ndim, T.idgrid, T.uvecs,
                           T.vecs_s, T.ngrid);
@@ -102,8 +105,10 @@ __global__ void __launch_bounds__(OBJ_LOC_NT)
 #define OBJ_ORD_NT 1024
 #define OBJ_ORD_NB 8192
 __global__ void __launch_bounds__(OBJ_ORD_NT)
-    objective_order_kernel(const double *__restrict__ loc, int J, int shift, int nb,
+    objective_order_kernel(const double *__restrict__ loc, int J,
+                           const int32_t *__restrict__ live, int shift, int nb,
                            int32_t *__restrict__ perm) {
+  if (live) J = min(J, live[0]);   // the jobs that count are the first live[0]
   __shared__ int hist[OBJ_ORD_NB];
   __shared__ int wsum[OBJ_ORD_NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -151,6 +156,7 @@ template <int P, bool FROMT, bool INBLK = false>
 __global__ void __launch_bounds__(OBJ_NT)
     objective_kernel(ObjArms A, ObjTempl TT, const double *__restrict__ locrec,
                      const int32_t *__restrict__ perm,
+                     const int32_t *__restrict__ live,
                      const double *__restrict__ params,
                      const double *__restrict__ vsini,
                      const int32_t *__restrict__ job_spec, int J,
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   // template buffer, which is dead by the time they are formed -- such an
   // instantiation needs the sigma-scaled model to fit the factor buffer (2 npix <=
   // ntp, checked by the launcher)
-  constexpr bool RED_DYN = (P > 10);
+  constexpr bool RED_DYN = (P > 10) || (OBJ_NT > 512);
   __shared__ double red_static[RED_DYN ? 1 : OBJ_NW * (NV + 1)];
   __shared__ double edge_s[OBJ_NW][6];   // chunk coefficients across wave boundaries
   __shared__ double coefs[P + 2];
@@ -185,10 +191,19 @@ __global__ void __launch_bounds__(OBJ_NT)
   // are fetched into that XCD's L2 once and hit there afterwards.  Which block
   // computes a job does not change its value.
   int j = blockIdx.x;
+  // `live` (device): only the first live[0] of the launch's J jobs are evaluations
+  // somebody waits for.  The lock-step optimiser sizes its launches by the count of
+  // running simplices at its last look (every few rounds, the only host
+  // synchronisation) and by all of them for the second point of a round, which 60-70 %
+  // need: a quarter of the blocks of a Nelder-Mead run computed values nobody read
+  // (tools/perf/nm_waste.py: 1.39 launched slots per function value scipy counts).
+  // Such a block ends here; the array strides stay those of J.
+  const int Jl = live ? min(J, live[0]) : J;
+  if (j >= Jl) return;
   if (perm) {
     const int f = j & 7;
     // (one value for the block: keep it in a scalar register)
-    j = __builtin_amdgcn_readfirstlane(perm[f * (J >> 3) + min(f, J & 7) + (j >> 3)]);
+    j = __builtin_amdgcn_readfirstlane(perm[f * (Jl >> 3) + min(f, Jl & 7) + (j >> 3)]);
   }
   const int lane = tid & 63, w = tid >> 6;
   const int N = T.ntp, m = N - 2;
@@ -238,11 +253,24 @@ __global__ void __launch_bounds__(OBJ_NT)
   const int N4 = N & ~3;
   const bool vec_gather = !FROMT && mode == 0 && nv <= 16;
   f4u rn[16];
+  // the vertex rows' base addresses are the block's, not the lane's: formed once, in
+  // scalar registers (inside the loop each of the 16 loads of a trip re-read its row
+  // number from LDS and multiplied it out in 64-bit vector arithmetic: ~9 of the
+  // ~25 vector instructions per load)
+  const float *vrow[16];
+  if (vec_gather) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int64_t id = PL.id[OBJ_VTX(u)];
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)id);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(id >> 32));
+      vrow[u] = T.dats + (int64_t)(((uint64_t)hi << 32) | lo) * N;
+    }
+  }
   if (vec_gather && 4 * tid < N4) {
 #pragma unroll
     for (int u = 0; u < 16; u++)
-      rn[u] = *reinterpret_cast<const f4u *>(
-          T.dats + PL.id[OBJ_VTX(u)] * N + 4 * tid);
+      rn[u] = *reinterpret_cast<const f4u *>(vrow[u] + 4 * tid);
   }
   int st_extra = 0;
   bool copy = true;
@@ -329,8 +357,7 @@ __global__ void __launch_bounds__(OBJ_NT)
         if (kn < N4) {
 #pragma unroll
           for (int u = 0; u < 16; u++)
-            rn[u] = *reinterpret_cast<const f4u *>(
-                T.dats + PL.id[OBJ_VTX(u)] * N + kn);
+            rn[u] = *reinterpret_cast<const f4u *>(vrow[u] + kn);
         }
         double a4[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1067,6 +1094,7 @@ __global__ void __launch_bounds__(OBJ_NT)
 __global__ void objective_sum_kernel(int narm, int J, double badchi,
                                      const double *__restrict__ pen_scale,
                                      const int32_t *__restrict__ job_spec,
+                                     const int32_t *__restrict__ live,
                                      int outside_penalty,
                                      const double *__restrict__ armchi,
                                      const int32_t *__restrict__ armst,
@@ -1074,7 +1102,7 @@ __global__ void objective_sum_kernel(int narm, int J, double badchi,
                                      double *__restrict__ out,
                                      int32_t *__restrict__ status) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= J) return;
+  if (j >= J || (live && j >= live[0])) return;
   // (badchi = 10 x the pixel count of the spectrum, spec_fit.py:863: the factor
   // of a spectrum on a shorter grid of a grid set)
   if (pen_scale) badchi *= pen_scale[job_spec ? job_spec[j] : j];
@@ -1136,7 +1164,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
                             const double *vsini, const int32_t *job_spec, int J,
                             const double *vel, double badchi,
                             int outside_penalty, void *scratch, double *out,
-                            int32_t *status, void *stream) {
+                            int32_t *status, const int32_t *live, void *stream) {
   if (J < 1 || narm < 1 || narm > RVS_MAX_ARMS || !arms || !scratch)
     return RVS_E_ARG;
   ObjArms A;
@@ -1180,7 +1208,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
       if ((1 << arms[i].ndim) > OBJ_LOC_NV) pre = false;
     if (pre) {
       hipLaunchKernelGGL(objective_locate_kernel, grid, dim3(OBJ_LOC_NT), 0, st, A,
-                         params, J, locbuf);
+                         params, J, live, locbuf);
       loc = locbuf;
       // from a few blocks per CU up: jobs in cell order (RVS_OBJ_SORT=0: a test
       // hook, tests/test_gpu_parity.py::test_objective_job_order)
@@ -1191,7 +1219,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
         const int nb = (int)((arms[0].ngrid - 1) >> shift) + 1;
         perm = (int32_t *)(locbuf + (int64_t)narm * J * OBJ_LOC_REC);
         hipLaunchKernelGGL(objective_order_kernel, dim3(1), dim3(OBJ_ORD_NT), 0, st,
-                           locbuf, J, shift, nb, perm);
+                           locbuf, J, live, shift, nb, perm);
       }
     }
   }
@@ -1207,7 +1235,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
                                             armchi, armst, armout, st);
       if (prc == 0) {
         hipLaunchKernelGGL(objective_sum_kernel, dim3((J + 255) / 256), dim3(256), 0,
-                           st, narm, J, badchi, arms[0].pt.pen_scale, job_spec,
+                           st, narm, J, badchi, arms[0].pt.pen_scale, job_spec, live,
                            outside_penalty, armchi, armst,
                            armout, out, status);
         RVS_LAUNCH_CHECK();
@@ -1229,7 +1257,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     }                                                                          \
     hipLaunchKernelGGL((objective_kernel<PP, FT, IB>), grid, dim3(OBJ_NT), shm,  \
                        st,                                                     \
-                       A, TT, loc, perm, params, vsini, job_spec, J, vel, 0.6, \
+                       A, TT, loc, perm, live, params, vsini, job_spec, J, vel, 0.6, \
                        armchi, armst, armout);                                 \
   }
 #define RVS_CASE(PP)                                                           \
@@ -1246,7 +1274,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
 #undef RVS_CASE
 #undef RVS_LAUNCH_OBJ
   hipLaunchKernelGGL(objective_sum_kernel, dim3((J + 255) / 256), dim3(256), 0,
-                     st, narm, J, badchi, arms[0].pt.pen_scale, job_spec,
+                     st, narm, J, badchi, arms[0].pt.pen_scale, job_spec, live,
                            outside_penalty, armchi, armst, armout,
                      out, status);
   RVS_LAUNCH_CHECK();
@@ -1261,7 +1289,19 @@ extern "C" int rvs_objective_fused(const rvs_objective_arm *arms, int narm,
                                    double *out, int32_t *status, void *stream) {
   return objective_launch(arms, narm, npoly, nullptr, params, vsini, job_spec, J,
                           vel, badchi, outside_penalty, scratch, out, status,
-                          stream);
+                          nullptr, stream);
+}
+
+extern "C" int rvs_objective_fused_n(const rvs_objective_arm *arms, int narm,
+                                     int npoly, const double *params,
+                                     const double *vsini, const int32_t *job_spec,
+                                     int J, const int32_t *njobs_dev,
+                                     const double *vel, double badchi,
+                                     int outside_penalty, void *scratch,
+                                     double *out, int32_t *status, void *stream) {
+  return objective_launch(arms, narm, npoly, nullptr, params, vsini, job_spec, J,
+                          vel, badchi, outside_penalty, scratch, out, status,
+                          njobs_dev, stream);
 }
 
 extern "C" int rvs_objective_from_template(
@@ -1270,6 +1310,19 @@ extern "C" int rvs_objective_from_template(
     const double *vsini, const int32_t *job_spec, int J, const double *vel,
     double badchi, int outside_penalty, void *scratch, double *out,
     int32_t *status, void *stream) {
+  return rvs_objective_from_template_n(arms, narm, npoly, templ, outside, vsini,
+                                       job_spec, J, nullptr, vel, badchi,
+                                       outside_penalty, scratch, out, status,
+                                       stream);
+}
+
+extern "C" int rvs_objective_from_template_n(
+    const rvs_objective_arm *arms, int narm, int npoly,
+    const double *const *templ, const double *const *outside,
+    const double *vsini, const int32_t *job_spec, int J,
+    const int32_t *njobs_dev, const double *vel, double badchi,
+    int outside_penalty, void *scratch, double *out, int32_t *status,
+    void *stream) {
   if (!templ || !outside || narm < 1 || narm > RVS_MAX_ARMS) return RVS_E_ARG;
   ObjTempl tt = {};
   for (int i = 0; i < narm; i++) {
@@ -1278,5 +1331,5 @@ extern "C" int rvs_objective_from_template(
   }
   return objective_launch(arms, narm, npoly, &tt, nullptr, vsini, job_spec, J,
                           vel, badchi, outside_penalty, scratch, out, status,
-                          stream);
+                          njobs_dev, stream);
 }

@@ -145,8 +145,11 @@ __device__ __forceinline__ void wave_halve(double (&vals)[CNT], int lane,
 
 // rows [0, obj_split(P)) of the normal equations are summed in the first pass over
 // the pixels: everything up to P = 10, about half of the P (P + 3) / 2 sums beyond
+#ifndef OBJ_ONEPASS_MAX
+#define OBJ_ONEPASS_MAX 10
+#endif
 __host__ __device__ constexpr int obj_split(int P) {
-  if (P <= 10) return P;
+  if (P <= OBJ_ONEPASS_MAX) return P;
   int pa = 1;
   while (pa < P && pa * (pa + 3) < P * (P + 3) / 2) pa++;
   return pa;

@@ -962,10 +962,13 @@ FUSED_OBJECTIVE = True
 
 
 def objective_fused(batch, libs, params, vsini, vel, npoly=5, rbf=True,
-                    job_spec=None, espec_sys=0.0, outside_penalty=True):
+                    job_spec=None, espec_sys=0.0, outside_penalty=True,
+                    njobs=None, out=None):
     """get_chisq for J (spectrum, parameters, vsini, velocity) jobs as ONE kernel
     per call (rvs_objective_fused): no template or spline record in HBM.
-    Returns chisq [J], status int32 [J]."""
+    Returns chisq [J], status int32 [J].  `njobs` (int32 device tensor, one
+    element): only the first njobs[0] jobs are evaluated, `out` (given by the
+    caller) keeps its values behind them (rvs_objective_fused_n)."""
     import ctypes
     L = _lib.lib()
     dev = batch.device
@@ -975,19 +978,21 @@ def objective_fused(batch, libs, params, vsini, vel, npoly=5, rbf=True,
     narm = len(batch.arms)
     arr = (_lib.ObjectiveArm * narm)()
     keep = fill_objective_arms(arr, batch, libs, npoly, rbf, espec_sys)
-    out = torch.empty(J, dtype=torch.float64, device=dev)
+    if out is None:
+        out = torch.empty(J, dtype=torch.float64, device=dev)
     status = torch.zeros(J, dtype=torch.int32, device=dev)
     nb = L.rvs_objective_work_size(J, narm)
     scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
     if vsini is not None:
         vsini = vsini.to(device=dev, dtype=torch.float64).contiguous()
     with _ktime('objective_fused', J):
-        rc = L.rvs_objective_fused(ctypes.addressof(arr), narm, npoly,
-                                   _lib.ptr(params), _lib.ptr(vsini),
-                                   _lib.ptr(job_spec), J, _lib.ptr(vel),
-                                   float(batch.badchi), int(outside_penalty),
-                                   _lib.ptr(scratch), _lib.ptr(out),
-                                   _lib.ptr(status), _lib.stream())
+        rc = L.rvs_objective_fused_n(ctypes.addressof(arr), narm, npoly,
+                                     _lib.ptr(params), _lib.ptr(vsini),
+                                     _lib.ptr(job_spec), J, _lib.ptr(njobs),
+                                     _lib.ptr(vel), float(batch.badchi),
+                                     int(outside_penalty), _lib.ptr(scratch),
+                                     _lib.ptr(out), _lib.ptr(status),
+                                     _lib.stream())
         _lib.check(rc, 'rvs_objective_fused')
     del keep
     return out, status

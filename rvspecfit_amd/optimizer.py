@@ -196,7 +196,8 @@ class ProcessObjective:
 
     def eval(self, list_t, X, J, counts, cidx, F):
         """F[:J] = chisq_func(X[j]) for spectrum list_t[j]; rows >= the device
-        count are padding (evaluated, ignored)."""
+        count counts[cidx] are padding: the fused objective skips them, F there
+        is whatever it was."""
         L = self.L
         st = _lib.stream()
         rc = L.rvs_proc_map(J, self.n, self.ndim, _p(X), _p(list_t), self.src,
@@ -209,9 +210,11 @@ class ProcessObjective:
         _lib.check(rc, 'rvs_proc_map')
         if self.fused:   # one kernel: gather, FIR, spline solve, chi^2
             # 1 | RVS_OBJ_STATUS_STORE: jstatus is overwritten, no clearing launch
-            rc = L.rvs_objective_fused(
+            live = None if counts is None else \
+                counts.data_ptr() + 4 * int(cidx)
+            rc = L.rvs_objective_fused_n(
                 ctypes.addressof(self.oarr), len(self.arm_buf), self.npoly,
-                _p(self.params), _p(self.vsini), _p(self.job_spec), J,
+                _p(self.params), _p(self.vsini), _p(self.job_spec), J, live,
                 _p(self.vel), self.badchi, 3, _p(self.oscratch), _p(self.chi),
                 _p(self.jstatus), st)
             _lib.check(rc, 'rvs_objective_fused')
@@ -252,11 +255,13 @@ class ProcessObjective:
                                             for b in self.arm_buf])
             op = (ctypes.c_void_p * narm)(*[b['outside'].data_ptr()
                                             for b in self.arm_buf])
-            rc = L.rvs_objective_from_template(
+            live = None if counts is None else \
+                counts.data_ptr() + 4 * int(cidx)
+            rc = L.rvs_objective_from_template_n(
                 ctypes.addressof(self.oarr), narm, self.npoly,
                 ctypes.cast(tp, ctypes.c_void_p),
                 ctypes.cast(op, ctypes.c_void_p), _p(self.vsini),
-                _p(self.job_spec), J, _p(self.vel), self.badchi, 3,
+                _p(self.job_spec), J, live, _p(self.vel), self.badchi, 3,
                 _p(self.oscratch), _p(self.chi), _p(self.jstatus), st)
             _lib.check(rc, 'rvs_objective_from_template')
             rc = L.rvs_proc_finish(J, _p(counts), cidx, _p(self.chi),
@@ -384,12 +389,17 @@ class DeviceNelderMead:
             m.S, m.N = S, N
             o = objective.native_desc()
             st3 = (ctypes.c_int64 * 3)()
+            nfev0 = self.nfev.sum()
             rc = L.rvs_nm_run(ctypes.addressof(m), ctypes.addressof(o),
                               float(xatol), float(fatol), int(maxiter),
                               int(sync_every), st3, _lib.stream())
             _lib.check(rc, 'rvs_nm_run')
             objective.calls += int(st3[1])
-            objective.jobs += int(st3[2])
+            # evaluations performed = the function values scipy's algorithm counts
+            # (rows of a launch behind the device count are skipped); `slots` =
+            # rows launched
+            objective.jobs += int((self.nfev.sum() - nfev0).item())
+            objective.slots = getattr(objective, 'slots', 0) + int(st3[2])
             if stats is not None:
                 stats['rounds'] = stats.get('rounds', 0) + int(st3[0])
             success = (self.flags & 2) != 0

@@ -779,6 +779,7 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     nm, pobj = device_nm(batch, pd0, priors, simplex, curparam, resolParams)
     obj.status |= pobj.status
     obj.nfev += pobj.jobs
+    slots = getattr(pobj, 'slots', 0)
     success = nm['success']
     x, nit, nfev = nm['x'], nm['nit'], nm['nfev']
     redo = torch.nonzero(~success).reshape(-1)
@@ -798,6 +799,7 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
                                resolParams)   # (shared by every spectrum)
         obj.status[redo] |= pobj2.status
         obj.nfev += pobj2.jobs
+        slots += getattr(pobj2, 'slots', 0)
         x[redo] = nm2['x']
         success[redo] = nm2['success']
         nit[redo] += nm2['nit']
@@ -899,6 +901,9 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     ret['nm_nfev'] = nfev if is_batch else int(nfev[0].item())
     ret['nm_rounds'] = stats.get('rounds', 0)
     ret['objective_evals'] = obj.nfev
+    # rows the lock-step Nelder-Mead launched (an upper bound known on the host);
+    # the rows behind the device counts are skipped by the objective kernel
+    ret['nm_launched_rows'] = slots
     ret['second_minimizer_run'] = second_run
     if bfgs_info is not None:
         ret['bfgs'] = bfgs_info

@@ -1603,6 +1603,44 @@ def test_objective_fused(cases, config, tag):
                 assert abs(c1[k].item() - want) < 1e-6 * sc, (i, c1[k].item())
 
 
+def test_objective_job_order_and_device_count(cases, config, monkeypatch):
+    """700 jobs in one rvs_objective_fused launch: (i) from 512 jobs up the blocks
+    take the jobs in the order of their grid cell (objective_order_kernel) -- which
+    block evaluates a job must not change a bit of its value (RVS_OBJ_SORT=0: the
+    plain order); (ii) with a job count on the device (rvs_objective_fused_n, what
+    the lock-step optimiser passes) the first n jobs have the values of the full
+    launch and the rows behind them are not written."""
+    from rvspecfit_amd import engine, spec_fit, spec_inter
+    sds = _sds(cases, 'c3')
+    b, _ = spec_fit.as_batch(sds)
+    libs = spec_inter.get_libs(b.names, config)
+    rng = np.random.RandomState(11)
+    J = 700
+    par = np.stack([rng.uniform(5000, 6800, J), rng.uniform(1.5, 4.5, J),
+                    rng.uniform(-1.5, -0.1, J), rng.uniform(0.0, 0.4, J)], 1)
+    par[::37, 0] = 9000.0          # a few points outside the grid
+    par = torch.as_tensor(par).to('cuda')
+    vel = torch.as_tensor(rng.uniform(-300, 300, J)).to('cuda')
+    vs = torch.as_tensor(rng.uniform(0, 120, J)).to('cuda')
+    js = torch.zeros(J, dtype=torch.int32, device='cuda')
+    kw = dict(npoly=10, rbf=True, job_spec=js)
+    with np.errstate(all='ignore'):
+        c1, s1 = engine.objective_fused(b, libs, par, vs, vel, **kw)
+        monkeypatch.setenv('RVS_OBJ_SORT', '0')
+        c0, s0 = engine.objective_fused(b, libs, par, vs, vel, **kw)
+        monkeypatch.delenv('RVS_OBJ_SORT')
+        assert torch.equal(c0, c1) and torch.equal(s0, s1)
+        assert torch.isfinite(c1).all()
+        for n in (0, 1, 299, 513, 700, 5000):
+            cnt = torch.tensor([n], dtype=torch.int32, device='cuda')
+            out = torch.full((J, ), -7.0, dtype=torch.float64, device='cuda')
+            c2, s2 = engine.objective_fused(b, libs, par, vs, vel, njobs=cnt,
+                                            out=out, **kw)
+            m = min(n, J)
+            assert torch.equal(c2[:m], c1[:m]) and torch.equal(s2[:m], s1[:m])
+            assert (c2[m:] == -7.0).all()
+
+
 @pytest.mark.parametrize('kind', ['triangulation', 'nn'])
 def test_objective_from_template(cases, gpu, kind):
     """rvs_objective_from_template (template rows of a Delaunay / MLP evaluator

@@ -712,6 +712,12 @@ typedef struct rvs_nm_nn_arm {
  * arms[a].templ / .outside; same values as the per-arm calls. */
 int rvs_template_nn_arms(const double *params, int B, int ndim, int narm,
                          const rvs_nm_nn_arm *arms, void *stream);
+/* ... of the first min(B, njobs_dev[0]) rows only (a count on the device, as in
+ * rvs_objective_fused_n; the grouped launches honour it, the arm-by-arm fallback
+ * evaluates all B rows).  NULL = all B. */
+int rvs_template_nn_arms_n(const double *params, int B, const int32_t *njobs_dev,
+                           int ndim, int narm, const rvs_nm_nn_arm *arms,
+                           void *stream);
 
 typedef struct rvs_nm_objective {
   const rvs_objective_arm *arms;

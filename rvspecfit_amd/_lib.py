@@ -85,6 +85,7 @@ SIGNATURES = {
     'rvs_ccf_select': (I, [P, P, I, I, I, P, I, P, P, P, P]),
     'rvs_template_nn': (I, [P, I, I, U, P, P, I, P, P, P, P, P, P, P]),
     'rvs_template_nn_arms': (I, [P, I, I, I, P, P]),
+    'rvs_template_nn_arms_n': (I, [P, I, P, I, I, P, P]),
     'rvs_nn_outside': (I, [P, I, I, U, P, P, I, P, I, P, I, P, P]),
 }
 

@@ -634,7 +634,7 @@ static int nm_eval(const rvs_nm_objective *o, const int32_t *list,
     // per-arm chains overlapped inside one optimiser instance -- Nelder-Mead
     // 2.53 -> 2.36 s per 2000 spectra -- but two instances on two host threads,
     // which is how vel_fit.process runs a large batch, then took 3.5 s for 2.4)
-    rc = rvs_template_nn_arms(o->params, J, o->ndim, o->narm, o->nn, st);
+    rc = rvs_template_nn_arms_n(o->params, J, live, o->ndim, o->narm, o->nn, st);
     if (rc) return rc;
     for (int a = 0; a < o->narm; a++) {
       tp[a] = o->nn[a].templ;

@@ -318,7 +318,11 @@ struct NNLinG {
 };
 template <bool BIG, bool KVEC>
 __global__ void __launch_bounds__(256, BIG ? NN_MINB_BIG : 4)
-    nn_linear_group_kernel(NNLinG G, int Bn, int K) {
+    nn_linear_group_kernel(NNLinG G, int Bn, const int32_t *__restrict__ live,
+                           int K) {
+  // (rows behind the device count are nobody's: rvs_template_nn_arms_n)
+  if (live) Bn = min(Bn, live[0]);
+  if (Bn < 1) return;
   const int a = blockIdx.y;
   nn_linear_body<BIG, KVEC, true>(G.X[a], G.W[a], G.bias[a], Bn, K, G.N[a],
                                   nullptr, G.y64[a], blockIdx.x, gridDim.x);
@@ -462,10 +466,13 @@ struct NNHiddenG {
   uint32_t log_mask[NN_MAXARM];
 };
 __global__ void __launch_bounds__(512, 2)
-    nn_hidden_group_kernel(const double *__restrict__ params, int Bn, int ndim,
+    nn_hidden_group_kernel(const double *__restrict__ params, int Bn,
+                           const int32_t *__restrict__ live, int ndim,
                            NNHiddenG G) {
   __shared__ __attribute__((aligned(16))) float act[2][32 * NH_LD];
   __shared__ float xin[32 * 8];
+  if (live) Bn = min(Bn, live[0]);
+  if ((int)blockIdx.x * 32 >= Bn) return;
   const int a = blockIdx.y;
   nn_hidden_body(params, Bn, ndim, G.log_mask[a], G.M[a], G.S[a], G.H[a],
                  G.yout[a], act, xin);
@@ -580,11 +587,12 @@ struct NNOutG {
   uint32_t log_mask[NN_MAXARM];
 };
 __global__ void __launch_bounds__(256)
-    nn_outside_group_kernel(const double *__restrict__ params, int B, int ndim,
+    nn_outside_group_kernel(const double *__restrict__ params, int B,
+                            const int32_t *__restrict__ live, int ndim,
                             NNOutG G) {
   const int a = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= B) return;
+  if (j >= B || (live && j >= live[0])) return;
   if (!G.xeqs[a]) {
     G.out[a][j] = 0.0;
     return;
@@ -596,6 +604,12 @@ __global__ void __launch_bounds__(256)
 extern "C" int rvs_template_nn_arms(const double *params, int B, int ndim,
                                     int narm, const rvs_nm_nn_arm *arms,
                                     void *stream) {
+  return rvs_template_nn_arms_n(params, B, nullptr, ndim, narm, arms, stream);
+}
+
+extern "C" int rvs_template_nn_arms_n(const double *params, int B,
+                                      const int32_t *live, int ndim, int narm,
+                                      const rvs_nm_nn_arm *arms, void *stream) {
   if (B < 1 || narm < 1 || !arms || !params) return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
   const rvs_nm_nn_arm &a0 = arms[0];
@@ -659,10 +673,10 @@ extern "C" int rvs_template_nn_arms(const double *params, int B, int ndim,
     OG.log_mask[a] = n.log_mask;
   }
   hipLaunchKernelGGL(nn_hidden_group_kernel, dim3((B + 31) / 32, narm), dim3(512),
-                     0, st, params, B, ndim, HG);
+                     0, st, params, B, live, ndim, HG);
   RVS_LAUNCH_CHECK();
   hipLaunchKernelGGL(nn_outside_group_kernel, dim3((B + 255) / 256, narm),
-                     dim3(256), 0, st, params, B, ndim, OG);
+                     dim3(256), 0, st, params, B, live, ndim, OG);
   RVS_LAUNCH_CHECK();
   {
     const int K = a0.dims[nl - 1];
@@ -674,10 +688,10 @@ extern "C" int rvs_template_nn_arms(const double *params, int B, int ndim,
     const dim3 grid((unsigned)(ntile < nres ? ntile : nres), narm);
     if (big)
       hipLaunchKernelGGL((nn_linear_group_kernel<true, true>), grid, dim3(256), 0,
-                         st, LG, B, K);
+                         st, LG, B, live, K);
     else
       hipLaunchKernelGGL((nn_linear_group_kernel<false, true>), grid, dim3(256),
-                         0, st, LG, B, K);
+                         0, st, LG, B, live, K);
     RVS_LAUNCH_CHECK();
   }
   return 0;

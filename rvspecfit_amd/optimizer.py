@@ -230,9 +230,10 @@ class ProcessObjective:
             # MLP libraries on every arm: one grouped launch chain
             if getattr(self, '_nn_arr', None) is None:
                 self.native_desc()
-            rc = L.rvs_template_nn_arms(_p(self.params), J, self.ndim,
-                                        len(self.arm_buf),
-                                        ctypes.addressof(self._nn_arr), st)
+            rc = L.rvs_template_nn_arms_n(
+                _p(self.params), J,
+                None if counts is None else counts.data_ptr() + 4 * int(cidx),
+                self.ndim, len(self.arm_buf), ctypes.addressof(self._nn_arr), st)
             _lib.check(rc, 'rvs_template_nn_arms')
         elif self.from_templ:
             main = torch.cuda.current_stream()

@@ -606,6 +606,7 @@ def _merge_parts(parts, idxs, S):
     out = {k: merge([p[k] for p in parts]) for k in first}
     out['nm_rounds'] = max(p['nm_rounds'] for p in parts)
     out['objective_evals'] = sum(p['objective_evals'] for p in parts)
+    out['nm_launched_rows'] = sum(p.get('nm_launched_rows', 0) for p in parts)
     if 'bfgs' in first:
         out['bfgs']['rounds'] = max(p['bfgs']['rounds'] for p in parts)
     return out

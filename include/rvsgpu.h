@@ -377,6 +377,10 @@ int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
  * optimiser's per-call scratch needs no clearing launch).
  * ---------------------------------------------------------------------- */
 #define RVS_OBJ_STATUS_STORE 2
+/* bit 2: the per-arm results stay in `scratch` ([narm, J] chi^2, [narm, J] outside,
+ * [narm, J] int32 status), out / status are not written: rvs_nm_run folds the sum
+ * over the arms into its own bookkeeping kernels */
+#define RVS_OBJ_NO_SUM 4
 typedef struct rvs_objective_arm {
   rvs_point_arm pt;
   const float *dats;

@@ -21,6 +21,7 @@
 // follow scipy/optimize/_optimize.py::_minimize_neldermead, the same as
 // tests/refmachines/neldermead_torch.py (which tests/ checks against scipy itself).
 #include "common.h"
+#include "objective_sum.h"
 
 // numpy evaluates every product and sum of the simplex arithmetic separately;
 // a fused multiply-add would change the last bit and, eventually, the path
@@ -496,57 +497,64 @@ struct MapSrc {
   int src[NM_MAXN];
 };
 
-__global__ void __launch_bounds__(256)
-    proc_map_kernel(int J, int n, int ndim, const double *__restrict__ X,
-                    const int32_t *__restrict__ list, MapSrc M, int vsini_col,
-                    const double *__restrict__ fixed,
-                    const double *__restrict__ vsini_fixed,
-                    const double *__restrict__ safe,
-                    const double *__restrict__ prior_mean,
-                    const double *__restrict__ prior_isig, double min_vel,
-                    double max_vel, double max_vsini,
-                    int32_t *__restrict__ job_spec, double *__restrict__ vel,
-                    double *__restrict__ vsini, double *__restrict__ params,
-                    double *__restrict__ extra, int32_t *__restrict__ bad) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= J) return;
-  const int r = list[j];
-  const double *x = X + (int64_t)j * n;
+// vel_fit.chisq_func's parameter mapping for ONE row: the optimiser's vector x of
+// simplex r -> (velocity, vsini, template parameters, prior penalty, bad flag) of job j
+struct MapP {
+  int n, ndim, vsini_col;
+  MapSrc M;
+  const double *fixed, *vsini_fixed, *safe, *prior_mean, *prior_isig;
+  double min_vel, max_vel, max_vsini;
+  int32_t *job_spec;
+  double *vel, *vsini, *params, *extra;
+  int32_t *bad;
+};
+
+__device__ __forceinline__ void map_row(const MapP &P, int j, int r,
+                                        const double *__restrict__ x) {
+  const int ndim = P.ndim;
   double v = x[0];
   double pen = 0;
-  if (vsini) {
+  if (P.vsini) {
     double vs;
-    if (vsini_col >= 0) {
-      const double v0 = x[vsini_col];
-      vs = fmin(fmax(v0, 0.0), max_vsini);  // np.clip
-      if (v0 < 0 || v0 > max_vsini) pen += (vs - v0) * (vs - v0);
+    if (P.vsini_col >= 0) {
+      const double v0 = x[P.vsini_col];
+      vs = fmin(fmax(v0, 0.0), P.max_vsini);  // np.clip
+      if (v0 < 0 || v0 > P.max_vsini) pen += (vs - v0) * (vs - v0);
       if (v0 != v0) vs = v0;
     } else {
-      vs = vsini_fixed[r];
+      vs = P.vsini_fixed[r];
     }
-    vsini[j] = vs;
+    P.vsini[j] = vs;
   }
-  bool isbad = (v > max_vel) || (v < min_vel);
+  bool isbad = (v > P.max_vel) || (v < P.min_vel);
   double p[NM_MAXN];
   for (int i = 0; i < ndim; i++) {
-    p[i] = (M.src[i] >= 0) ? x[M.src[i]] : fixed[(int64_t)r * ndim + i];
+    p[i] = (P.M.src[i] >= 0) ? x[P.M.src[i]] : P.fixed[(int64_t)r * ndim + i];
     if (!(fabs(p[i]) <= 1.79e308)) isbad = true;
   }
   if (isbad) {
     v = 0;
-    for (int i = 0; i < ndim; i++) p[i] = safe[(int64_t)r * ndim + i];
+    for (int i = 0; i < ndim; i++) p[i] = P.safe[(int64_t)r * ndim + i];
   }
-  if (prior_mean)
+  if (P.prior_mean)
     for (int i = 0; i < ndim; i++) {
-      const double d = (prior_mean[(int64_t)r * ndim + i] - p[i]) *
-                       prior_isig[(int64_t)r * ndim + i];
+      const double d = (P.prior_mean[(int64_t)r * ndim + i] - p[i]) *
+                       P.prior_isig[(int64_t)r * ndim + i];
       pen += d * d;
     }
-  job_spec[j] = r;
-  vel[j] = v;
-  for (int i = 0; i < ndim; i++) params[(int64_t)j * ndim + i] = p[i];
-  extra[j] = pen;
-  bad[j] = isbad ? 1 : 0;
+  P.job_spec[j] = r;
+  P.vel[j] = v;
+  for (int i = 0; i < ndim; i++) P.params[(int64_t)j * ndim + i] = p[i];
+  P.extra[j] = pen;
+  P.bad[j] = isbad ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+    proc_map_kernel(int J, const double *__restrict__ X,
+                    const int32_t *__restrict__ list, MapP P) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= J) return;
+  map_row(P, j, list[j], X + (int64_t)j * P.n);
 }
 
 __global__ void __launch_bounds__(256)
@@ -577,13 +585,16 @@ extern "C" int rvs_proc_map(int J, int n, int ndim, const double *X,
                             void *stream) {
   if (J < 1 || n < 1 || n > NM_MAXN || ndim < 1 || ndim > NM_MAXN)
     return RVS_E_ARG;
-  MapSrc M;
-  for (int i = 0; i < NM_MAXN; i++) M.src[i] = (i < ndim) ? src[i] : -1;
+  MapP P;
+  P.n = n, P.ndim = ndim, P.vsini_col = vsini_col;
+  for (int i = 0; i < NM_MAXN; i++) P.M.src[i] = (i < ndim) ? src[i] : -1;
+  P.fixed = fixed, P.vsini_fixed = vsini_fixed, P.safe = safe;
+  P.prior_mean = prior_mean, P.prior_isig = prior_isig;
+  P.min_vel = min_vel, P.max_vel = max_vel, P.max_vsini = max_vsini;
+  P.job_spec = job_spec, P.vel = vel, P.vsini = vsini, P.params = params;
+  P.extra = extra, P.bad = bad;
   hipLaunchKernelGGL(proc_map_kernel, dim3((J + 255) / 256), dim3(256), 0,
-                     rvs_stream(stream), J, n, ndim, X, list, M, vsini_col,
-                     fixed, vsini_fixed, safe, prior_mean, prior_isig, min_vel,
-                     max_vel, max_vsini, job_spec, vel, vsini, params, extra,
-                     bad);
+                     rvs_stream(stream), J, X, list, P);
   RVS_LAUNCH_CHECK();
   return 0;
 }
@@ -655,6 +666,225 @@ static int nm_eval(const rvs_nm_objective *o, const int32_t *list,
                          o->jstatus, F, o->status, st);
 }
 
+
+// ---------------------------------------------------------------------------
+// The round as rvs_nm_run launches it: THREE launches per function evaluation --
+// cell search, job order, objective kernel -- and one bookkeeping kernel between two
+// evaluations, where the chain above takes seven (begin | decide | update, map,
+// cell search, order, objective, sum over the arms, finish).  Between two objective
+// kernels of a stream nothing else runs, and late in a run -- a few dozen simplices
+// left, an objective launch of 40 us -- the chain WAS the round: 141 us of small
+// launches per evaluation (tools/perf/trace_rounds.py).  One block does, for all
+// rows, what the separate kernels did (same device functions, same order of the
+// arithmetic, lists in the same order):
+//   nm_glue_begin     termination test + reflection point of every running simplex,
+//                     list1 / X1, and the parameter mapping of those rows
+//   nm_glue_decide    F1 = sum over the arms + priors of the rows just evaluated;
+//                     branch per simplex; second point -> list2 / X2 + their mapping
+//   nm_glue_update    F2 likewise; accept / replace / order / park; then the next
+//                     round's termination test + reflection point of the simplices
+//                     that keep running (list1 compacted in place) + their mapping
+// The function values are formed for ALL rows before any mapped row is written (the
+// mapping of the next rows lives in the buffers the evaluated rows are read from).
+// ---------------------------------------------------------------------------
+struct NmGlue {
+  rvs_nm_state m;
+  MapP P;
+  ObjArmOut AO;           // per-arm results of the evaluation just done
+  double badchi, xatol, fatol;
+  const double *pen_scale;
+  int32_t *spec_status;
+  int maxiter;
+};
+
+// F of row j of the evaluation just done (objective_sum_kernel + proc_finish_kernel)
+__device__ __forceinline__ double glue_value(const NmGlue &G, int j) {
+  const int r = G.P.job_spec[j];
+  double bc = G.badchi;
+  if (G.pen_scale) bc *= G.pen_scale[r];
+  double tot;
+  int st;
+  obj_sum_row(G.AO, j, bc, 1, tot, st);
+  const int isbad = G.P.bad[j];
+  if (st && !isbad) atomicOr(&G.spec_status[r], st);
+  return isbad ? 1e30 : tot + G.P.extra[j];
+}
+
+// nm_begin_kernel's test of simplex r: 1 = it steps this round (xr = reflection point)
+__device__ __forceinline__ int glue_begin_row(const NmGlue &G, int r, double *xr) {
+  int32_t *flags = G.m.flags;
+  const int N = G.m.N;
+  if ((flags[r] & 5) != 1) return 0;  // not active, or a shrink pending
+  if (G.m.nit[r] >= G.maxiter) {
+    flags[r] &= ~1;  // scipy: while-condition fails -> warnflag 2
+    return 0;
+  }
+  const double *s = G.m.sim + (int64_t)r * (N + 1) * N;
+  const double *f = G.m.fsim + (int64_t)r * (N + 1);
+  int conv = 0;
+  switch (N) {
+    case 1: conv = nm_begin_row<1>(s, f, G.xatol, G.fatol, xr); break;
+    case 2: conv = nm_begin_row<2>(s, f, G.xatol, G.fatol, xr); break;
+    case 3: conv = nm_begin_row<3>(s, f, G.xatol, G.fatol, xr); break;
+    case 4: conv = nm_begin_row<4>(s, f, G.xatol, G.fatol, xr); break;
+    case 5: conv = nm_begin_row<5>(s, f, G.xatol, G.fatol, xr); break;
+    case 6: conv = nm_begin_row<6>(s, f, G.xatol, G.fatol, xr); break;
+    case 7: conv = nm_begin_row<7>(s, f, G.xatol, G.fatol, xr); break;
+    default: conv = nm_begin_row<8>(s, f, G.xatol, G.fatol, xr); break;
+  }
+  if (conv) {
+    flags[r] = (flags[r] & ~1) | 2;  // converged: success
+    return 0;
+  }
+  return 1;
+}
+
+__global__ void __launch_bounds__(NM_NT) nm_glue_begin_kernel(NmGlue G) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  const int S = G.m.S, N = G.m.N;
+  int base_out = 0;
+  for (int r0 = 0; r0 < S; r0 += NM_NT) {
+    const int r = r0 + threadIdx.x;
+    double xr[NM_MAXN];
+    const int go = (r < S) ? glue_begin_row(G, r, xr) : 0;
+    int tot;
+    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    if (go) {
+      G.m.list1[pos] = r;
+      double *x = G.m.X1 + (int64_t)pos * N;
+      for (int i = 0; i < N; i++) x[i] = xr[i];
+      map_row(G.P, pos, r, x);
+    }
+    base_out += tot;
+  }
+  if (threadIdx.x == 0) {
+    G.m.counts[0] = base_out;
+    G.m.counts[3] = base_out;
+  }
+}
+
+__global__ void __launch_bounds__(NM_NT) nm_glue_decide_kernel(NmGlue G, int jbound) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  const int N = G.m.N;
+  const int J = min(G.m.counts[0], jbound);
+  for (int j = threadIdx.x; j < J; j += NM_NT) G.m.F1[j] = glue_value(G, j);
+  __syncthreads();
+  int base_out = 0;
+  for (int j0 = 0; j0 < J; j0 += NM_NT) {
+    const int j = j0 + threadIdx.x;
+    int go = 0, r = 0;
+    double x2[NM_MAXN];
+    if (j < J) {   // (nm_decide_kernel)
+      r = G.m.list1[j];
+      const double *s = G.m.sim + (int64_t)r * (N + 1) * N;
+      const double *f = G.m.fsim + (int64_t)r * (N + 1);
+      const double fxr = G.m.F1[j];
+      int c;
+      if (fxr < f[0])
+        c = 1;
+      else if (fxr < f[N - 1])
+        c = 0;
+      else if (fxr < f[N])
+        c = 2;
+      else
+        c = 3;
+      G.m.cases[j] = c;
+      if (c != 0) {
+        go = 1;
+        for (int i = 0; i < N; i++) {
+          double xb = s[i];
+          for (int k = 1; k < N; k++) xb = xb + s[k * N + i];
+          xb = xb / N;
+          const double w = s[N * N + i];
+          if (c == 1)
+            x2[i] = (1 + 1.0 * 2.0) * xb - 1.0 * 2.0 * w;
+          else if (c == 2)
+            x2[i] = (1 + 0.5 * 1.0) * xb - 0.5 * 1.0 * w;
+          else
+            x2[i] = (1 - 0.5) * xb + 0.5 * w;
+        }
+      }
+    }
+    int tot;
+    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    if (j < J) G.m.pos2[j] = go ? pos : -1;
+    if (go) {
+      G.m.list2[pos] = r;
+      double *x = G.m.X2 + (int64_t)pos * N;
+      for (int i = 0; i < N; i++) x[i] = x2[i];
+      map_row(G.P, pos, r, x);
+    }
+    base_out += tot;
+  }
+  if (threadIdx.x == 0) G.m.counts[1] = base_out;
+}
+
+__global__ void __launch_bounds__(NM_NT) nm_glue_update_kernel(NmGlue G, int jbound) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  __shared__ int parked;
+  const int N = G.m.N;
+  const int J = min(G.m.counts[0], jbound), J2 = min(G.m.counts[1], jbound);
+  if (threadIdx.x == 0) parked = 0;
+  for (int p = threadIdx.x; p < J2; p += NM_NT) G.m.F2[p] = glue_value(G, p);
+  __syncthreads();
+  int base_out = 0;
+  for (int j0 = 0; j0 < J; j0 += NM_NT) {
+    const int j = j0 + threadIdx.x;
+    int go = 0, r = 0;
+    double xr[NM_MAXN];
+    if (j < J) {   // (nm_update_kernel)
+      r = G.m.list1[j];
+      double *s = G.m.sim + (int64_t)r * (N + 1) * N;
+      double *f = G.m.fsim + (int64_t)r * (N + 1);
+      const int c = G.m.cases[j];
+      const double fxr = G.m.F1[j];
+      const int p2 = G.m.pos2[j];
+      const double f2 = (p2 >= 0) ? G.m.F2[p2] : __builtin_inf();
+      bool take2 = false, taker = false;
+      if (c == 0)
+        taker = true;
+      else if (c == 1) {
+        if (f2 < fxr)
+          take2 = true;
+        else
+          taker = true;
+      } else if (c == 2)
+        take2 = (f2 <= fxr);
+      else
+        take2 = (f2 < f[N]);
+      G.m.nfev[r] += (c == 0) ? 1 : 2;
+      if (take2 || taker) {
+        const double *src = take2 ? (G.m.X2 + (int64_t)p2 * N)
+                                  : (G.m.X1 + (int64_t)j * N);
+        for (int i = 0; i < N; i++) s[N * N + i] = src[i];
+        f[N] = take2 ? f2 : fxr;
+        nm_order(s, f, N);
+        G.m.nit[r] += 1;
+        // ... and the next round's test of this simplex (nm_begin_kernel)
+        go = glue_begin_row(G, r, xr);
+      } else {
+        G.m.flags[r] |= 4;  // shrink: parked until the host runs the shrink
+        atomicAdd(&parked, 1);
+      }
+    }
+    int tot;
+    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    if (go) {   // pos <= j: rows of this trip were read above, later rows lie behind
+      G.m.list1[pos] = r;
+      double *x = G.m.X1 + (int64_t)pos * N;
+      for (int i = 0; i < N; i++) x[i] = xr[i];
+      map_row(G.P, pos, r, x);
+    }
+    base_out += tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    G.m.counts[0] = base_out;
+    G.m.counts[3] = base_out;
+    G.m.counts[4] += parked;  // simplices waiting to shrink
+  }
+}
+
 static int nm_bucket(int n, int S) {
   // quantised launch bound (1/8 steps of the next power of two), as optimizer.py
   if (n <= 64) return S < 64 ? S : 64;
@@ -665,11 +895,120 @@ static int nm_bucket(int n, int S) {
   return b < S ? b : S;
 }
 
+// the evaluation of the rows the last bookkeeping kernel mapped (J = launch bound,
+// `live` = their count on the device); the per-arm results stay in o->scratch
+static int nm_objective_rows(const rvs_nm_objective *o, int J, const int32_t *live,
+                             hipStream_t st) {
+  if (o->nn) {
+    const double *tp[8], *op[8];
+    if (o->narm > 8) return RVS_E_ARG;
+    int rc = rvs_template_nn_arms_n(o->params, J, live, o->ndim, o->narm, o->nn, st);
+    if (rc) return rc;
+    for (int a = 0; a < o->narm; a++) {
+      tp[a] = o->nn[a].templ;
+      op[a] = o->nn[a].outside;
+    }
+    return rvs_objective_from_template_n(o->arms, o->narm, o->npoly, tp, op,
+                                         o->vsini, o->job_spec, J, live, o->vel,
+                                         o->badchi, 1 | RVS_OBJ_NO_SUM, o->scratch,
+                                         nullptr, nullptr, st);
+  }
+  return rvs_objective_fused_n(o->arms, o->narm, o->npoly, o->params, o->vsini,
+                               o->job_spec, J, live, o->vel, o->badchi,
+                               1 | RVS_OBJ_NO_SUM, o->scratch, nullptr, nullptr, st);
+}
+
+static int nm_run_chain(const rvs_nm_state *m, const rvs_nm_objective *o,
+                        double xatol, double fatol, int maxiter, int sync_every,
+                        int64_t *stats, void *stream);
+
 extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
                           double xatol, double fatol, int maxiter,
                           int sync_every, int64_t *stats, void *stream) {
   if (!m || !o || m->S < 1 || m->N < 1 || m->N > NM_MAXN || sync_every < 1)
     return RVS_E_ARG;
+  // RVS_NM_GLUE=0: the round as a chain of the stand-alone kernels (a test hook:
+  // tests/test_gpu_parity.py::test_nm_round_kernels_equal_chain)
+  if (const char *ev = getenv("RVS_NM_GLUE"))
+    if (ev[0] == '0')
+      return nm_run_chain(m, o, xatol, fatol, maxiter, sync_every, stats, stream);
+  hipStream_t st = rvs_stream(stream);
+  const int S = m->S, N = m->N;
+  int64_t rounds = 0, calls = 0, jobs = 0;
+  int32_t c[8];
+  NmGlue G;
+  G.m = *m;
+  MapP &P = G.P;
+  P.n = o->n, P.ndim = o->ndim, P.vsini_col = o->vsini_col;
+  for (int i = 0; i < NM_MAXN; i++) P.M.src[i] = (i < o->ndim) ? o->src[i] : -1;
+  P.fixed = o->fixed, P.vsini_fixed = o->vsini_fixed, P.safe = o->safe;
+  P.prior_mean = o->prior_mean, P.prior_isig = o->prior_isig;
+  P.min_vel = o->min_vel, P.max_vel = o->max_vel, P.max_vsini = o->max_vsini;
+  P.job_spec = o->job_spec, P.vel = o->vel, P.vsini = o->vsini, P.params = o->params;
+  P.extra = o->extra, P.bad = o->bad;
+  G.badchi = o->badchi, G.xatol = xatol, G.fatol = fatol, G.maxiter = maxiter;
+  G.pen_scale = o->arms[0].pt.pen_scale;
+  G.spec_status = o->status;
+  G.AO = obj_arm_out(o->scratch, o->narm, S);
+  hipLaunchKernelGGL(nm_glue_begin_kernel, dim3(1), dim3(NM_NT), 0, st, G);
+  RVS_LAUNCH_CHECK();
+  int rc = 0;
+  while (true) {
+    if (hipMemcpyAsync(c, m->counts, sizeof(c), hipMemcpyDeviceToHost, st) !=
+            hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return RVS_E_LAUNCH;
+    const int live = c[0], parked = c[4];
+    if (parked > 0) {  // scipy's shrink step for the parked simplices
+      rc = rvs_nm_collect(S, m->flags, m->list3, m->counts, st);
+      if (rc) return rc;
+      for (int k = 1; k <= N; k++) {
+        rc = rvs_nm_shrink_point(N, k, m->sim, m->list3, m->X2, m->counts,
+                                 parked, st);
+        if (rc) return rc;
+        rc = nm_eval(o, m->list3, m->X2, parked, m->counts, 2, m->F2, st);
+        if (rc) return rc;
+        calls++;
+        jobs += parked;
+        rc = rvs_nm_shrink_store(N, k, m->sim, m->fsim, m->nit, m->nfev,
+                                 m->flags, m->list3, m->F2, m->counts, parked,
+                                 st);
+        if (rc) return rc;
+      }
+      hipLaunchKernelGGL(nm_glue_begin_kernel, dim3(1), dim3(NM_NT), 0, st, G);
+      RVS_LAUNCH_CHECK();
+      continue;
+    }
+    if (live == 0) break;
+    // the live count only falls between two looks (finished and parked
+    // simplices leave the list), so it bounds the launches of the window
+    const int jb = live;
+    G.AO = obj_arm_out(o->scratch, o->narm, jb);
+    for (int r = 0; r < sync_every; r++) {
+      rc = nm_objective_rows(o, jb, m->counts, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(nm_glue_decide_kernel, dim3(1), dim3(NM_NT), 0, st, G, jb);
+      RVS_LAUNCH_CHECK();
+      rc = nm_objective_rows(o, jb, m->counts + 1, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(nm_glue_update_kernel, dim3(1), dim3(NM_NT), 0, st, G, jb);
+      RVS_LAUNCH_CHECK();
+      calls += 2;
+      jobs += 2 * (int64_t)jb;
+    }
+    rounds += sync_every;
+  }
+  if (stats) {
+    stats[0] = rounds;
+    stats[1] = calls;
+    stats[2] = jobs;
+  }
+  return 0;
+}
+
+static int nm_run_chain(const rvs_nm_state *m, const rvs_nm_objective *o,
+                        double xatol, double fatol, int maxiter, int sync_every,
+                        int64_t *stats, void *stream) {
   hipStream_t st = rvs_stream(stream);
   const int S = m->S, N = m->N;
   int64_t rounds = 0, calls = 0, jobs = 0;

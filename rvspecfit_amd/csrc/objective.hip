@@ -1106,18 +1106,11 @@ __global__ void objective_sum_kernel(int narm, int J, double badchi,
   // (badchi = 10 x the pixel count of the spectrum, spec_fit.py:863: the factor
   // of a spectrum on a shorter grid of a grid set)
   if (pen_scale) badchi *= pen_scale[job_spec ? job_spec[j] : j];
-  double tot = 0;
-  int st = 0;
-  for (int ia = 0; ia < narm; ia++) {
-    const double o = armout[(int64_t)ia * J + j];
-    if (!(fabs(o) <= 1.79e308)) {
-      tot += 1000.0 * badchi;
-      continue;
-    }
-    tot += armchi[(int64_t)ia * J + j] +
-           ((outside_penalty & 1) ? o * badchi : 0.0);
-    st |= armst[(int64_t)ia * J + j];
-  }
+  ObjArmOut AO;
+  AO.armchi = armchi, AO.armout = armout, AO.armst = armst, AO.narm = narm, AO.J = J;
+  double tot;
+  int st;
+  obj_sum_row(AO, j, badchi, outside_penalty, tot, st);
   out[j] = tot;
   if (outside_penalty & 2)
     status[j] = st;  // RVS_OBJ_STATUS_STORE: the caller's buffer is scratch
@@ -1273,6 +1266,10 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
   }
 #undef RVS_CASE
 #undef RVS_LAUNCH_OBJ
+  if (outside_penalty & RVS_OBJ_NO_SUM) {   // the caller sums the arms (nm.hip)
+    RVS_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(objective_sum_kernel, dim3((J + 255) / 256), dim3(256), 0,
                      st, narm, J, badchi, arms[0].pt.pen_scale, job_spec, live,
                            outside_penalty, armchi, armst, armout,

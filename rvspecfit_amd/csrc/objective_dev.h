@@ -2,6 +2,7 @@
 // points) and objective_pipe.hip (the persistent producer/consumer kernel).
 #pragma once
 #include "template_dev.h"
+#include "objective_sum.h"
 
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 

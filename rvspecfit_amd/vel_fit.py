@@ -551,7 +551,7 @@ def param_uncertainties(specdata, vel, atm_params, vsini=None, options=None,
 # tail of its rounds the other's kernels fill the CUs.  Results are those of the
 # unsplit run, bit for bit (no spectrum sees another;
 # test_process_two_halves_equal_one_batch).  1 switches it off.
-PROCESS_STREAMS = 2
+PROCESS_STREAMS = int(os.environ.get('RVS_PROCESS_STREAMS', '2'))
 PROCESS_SPLIT_MIN = 256
 
 
@@ -625,13 +625,14 @@ def _split_stream(dev, k):
 
 def _process_split(batch, paramDict0, kwargs):
     S, dev = batch.S, batch.device
-    idxs = [torch.arange(k, S, 2, device=dev) for k in range(2)]
+    nparts = max(2, int(PROCESS_STREAMS))
+    idxs = [torch.arange(k, S, nparts, device=dev) for k in range(nparts)]
     pd = _as_param_tensors(paramDict0, S, dev)
     pri = kwargs.get('priors')
     # template libraries are loaded (uploaded) here, before either thread
     spec_inter.get_libs(batch.names, kwargs['config'])
     torch.cuda.current_stream().synchronize()
-    parts, errs = [None, None], [None, None]
+    parts, errs = [None] * nparts, [None] * nparts
 
     def run(k):
         try:
@@ -650,7 +651,7 @@ def _process_split(batch, paramDict0, kwargs):
             st.synchronize()
         except BaseException as e:  # noqa: BLE001 -- re-raised by the caller
             errs[k] = e
-    th = [threading.Thread(target=run, args=(k, )) for k in range(2)]
+    th = [threading.Thread(target=run, args=(k, )) for k in range(nparts)]
     for t in th:
         t.start()
     for t in th:
@@ -685,7 +686,7 @@ def process(specdata, paramDict0, fixParam=None, options=None, config=None,
     concurrent halves (PROCESS_STREAMS)."""
     if config is None:
         raise RuntimeError('Config must be provided')
-    if (PROCESS_STREAMS == 2 and isinstance(specdata, SpecBatch)
+    if (PROCESS_STREAMS >= 2 and isinstance(specdata, SpecBatch)
             and specdata.S >= PROCESS_SPLIT_MIN and timers is None
             and not getattr(_tls, 'single', False)
             and _rounds_run_in_c(specdata, config, resolParams, options)):

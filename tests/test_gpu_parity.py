@@ -1531,6 +1531,40 @@ def test_process_bfgs_implementations_agree(cases, config, monkeypatch):
     assert abs(np.mean(a['bfgs']['nfev']) / np.mean(b['bfgs']['nfev']) - 1) < 0.5
 
 
+def test_nm_round_kernels_equal_chain(cases, config, monkeypatch):
+    """rvs_nm_run's rounds -- three bookkeeping kernels that also sum the arms and
+    map the next rows, the objective skipping the rows behind the device counts --
+    against the same rounds as a chain of the stand-alone kernels (RVS_NM_GLUE=0):
+    every number of vel_fit.process bit for bit."""
+    from rvspecfit_amd import vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    rng = np.random.RandomState(8)
+    S = 40
+    lists = [_sds(cases, ('c1', 'c3')[i % 2]) for i in range(S)]
+    batch = SpecBatch.from_specdata(lists)
+    for a in batch.arms:
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.03 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pd0 = dict(teff=rng.uniform(5000, 6800, S), logg=rng.uniform(1.5, 4.5, S),
+               feh=rng.uniform(-1.5, -0.1, S), alpha=rng.uniform(0, 0.4, S),
+               vsini=rng.uniform(1, 60, S))
+    out = {}
+    for glue in ('1', '0'):
+        monkeypatch.setenv('RVS_NM_GLUE', glue)
+        out[glue] = vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                    config=config)
+    a, b = out['1'], out['0']
+    assert torch.equal(a['nm_nit'], b['nm_nit'])
+    assert torch.equal(a['nm_nfev'], b['nm_nfev'])
+    assert int(a['nm_nit'].max()) > 50
+    for k in ('vel', 'chisq', 'vel_err'):
+        assert np.array_equal(np.asarray(torch.as_tensor(a[k]).cpu()),
+                              np.asarray(torch.as_tensor(b[k]).cpu())), k
+    for k in a['param']:
+        assert np.array_equal(np.asarray(torch.as_tensor(a['param'][k]).cpu()),
+                              np.asarray(torch.as_tensor(b['param'][k]).cpu())), k
+
+
 def test_process_second_minimizer(cases, pcases, config):
     """config second_minimizer=True (the reference default): BFGS from the
     simplex optimum.  The reference's own BFGS (golden p4; scipy 1.7 there,

@@ -656,6 +656,275 @@ __global__ void __launch_bounds__(XB_NT)
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Wave-specialised form (round 4, the review's item 5): ONE persistent 1024-thread
+// block per spectrum walks the T templates.  Waves 8-15 (producers) hold the
+// spectrum's S*, V* in registers for the whole walk (4 bin pairs = 16 complex128 =
+// 64 VGPRs per lane), stream the template's F, F2, form -2 F S* + F2 V* with the
+// Hermitian fold and write LDS image (t + 1) & 1, while waves 0-7 (consumers) run
+// the radix-8 passes, the lag read-back and the interpolation of template t on
+// image t & 1.  Operands per (spectrum, template): 131 KB instead of 270 KB through
+// L2 -> L1.  gfx950 has one s_barrier per workgroup: both roles execute the same
+// NBAR barriers per template (after pass 0, pass 1, the folded pass [or passes 2, 3],
+// the read-back); a producer's four pair batches fall into the first four intervals,
+// each batch requested one interval ahead (in flight across a barrier -- the barrier
+// does not wait for loads).  Same arithmetic per bin and per butterfly as
+// ccf_xcorr_kernel: bit-identical output.  nfft = 8192, continuum mode, nlag and
+// nvel <= 512 (rvs_ccf_xcorr decides; RVS_XC_WS=1).
+// ---------------------------------------------------------------------------
+#define XW_NT 1024
+#define XW_HALF 512
+
+// radix-8 DIF pass p (M = 4096 >> 3p) of the 4096-point image a[], 512 threads
+template <int SIGN>
+__device__ __forceinline__ void xw_pass(double2 *a, const double2 *T1, int p, int t) {
+  constexpr int log2n = 12;
+  const int lgM = log2n - 3 * p, lgMp = lgM - 3, Mp = 1 << lgMp;
+  const int tws = log2n + 1 - lgM;
+  const int blk = t >> lgMp, r = t & (Mp - 1);
+  const int base = (blk << lgM) + r;
+  double2 v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = a[base + Mp * j];
+  dft8<SIGN>(v);
+  if (Mp > 1) {
+    double2 w1 = T1[r << (tws - 1)];
+    if (SIGN < 0) w1.y = -w1.y;
+    v[1] = cmul(v[1], w1);
+    const double2 w2 = cmul(w1, w1);
+    v[2] = cmul(v[2], w2);
+    double2 wc = cmul(w2, w1);  // w3
+    v[3] = cmul(v[3], wc);
+    const double2 w4 = cmul(w2, w2);
+    v[4] = cmul(v[4], w4);
+    v[7] = cmul(v[7], cmul(w4, wc));  // w7 = w4 w3
+    wc = cmul(w4, w1);                // w5
+    v[5] = cmul(v[5], wc);
+    v[6] = cmul(v[6], cmul(w4, w2));  // w6
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) a[base + Mp * q] = v[q];
+}
+
+__global__ void __launch_bounds__(XW_NT)
+    ccf_xcorr_ws_kernel(const double2 *__restrict__ work,
+                        const double2 *__restrict__ tfft,
+                        const double2 *__restrict__ tfft2, int T,
+                        const double2 *__restrict__ tw,
+                        const int32_t *__restrict__ lag_pos,
+                        const double *__restrict__ lag_vel, int nlag,
+                        const int32_t *__restrict__ ilo,
+                        const double *__restrict__ vgrid, int nvel, double beta,
+                        const uint8_t *__restrict__ prune,
+                        double *__restrict__ chisq) {
+  extern __shared__ double2 fa[];
+  constexpr int nfft = 8192, n2 = 4096, npair = 2048, log2n = 12;
+  auto img = [&](int i) -> double2 * { return fa + (i & 1) * n2; };
+  const double2 *T1 = fa + 2 * n2;                         // [n2 / 8]
+  double *c0 = reinterpret_cast<double *>(fa + 2 * n2 + XC_NTW(n2));  // [nlag]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const bool producer = tid >= XW_HALF;
+  const int pt = tid & (XW_HALF - 1);
+  const double inv_n = 1.0 / nfft;
+  xc_fill_twiddles<XW_NT>(fa + n2, n2, tw);   // -> fa[2 n2 + i]
+  // output masks of the last two passes (consumers), and the block-wide vote on the
+  // folded form of those passes (see fft_lds)
+  XcMasks pmask = {0u, 0u, 0u};
+  bool bad = false;
+  if (!producer) {
+    pmask = xc_load_masks<XW_HALF>(prune, n2);
+    const int pos8 = pt & 7;
+    const unsigned m = pmask.g;
+    bad = m != 0 && !((pos8 == 0 && m == 0x01u) || (pos8 == 7 && m == 0x80u));
+  }
+  const bool fold = !__syncthreads_or(bad);
+  const double2 *Sc = work + ((int64_t)b * 2) * (n2 + 1);
+  const double2 *Vc = Sc + (n2 + 1);
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  auto ld = [](const __amdgpu_buffer_rsrc_t &r, int off) {
+    const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_double2(__hiloint2double(v.y, v.x), __hiloint2double(v.w, v.z));
+  };
+  const int nbytes = (n2 + 1) * 16;
+  if (producer) {
+    // ---- producers -------------------------------------------------------
+    double2 Sk[4], Vk[4], Sm[4], Vm[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = 1 + pt + u * XW_HALF, m = n2 - k;
+      Sk[u] = Sc[k], Vk[u] = Vc[k], Sm[u] = Sc[m], Vm[u] = Vc[m];
+    }
+    const double2 S0 = Sc[0], V0 = Vc[0], Sn = Sc[n2], Vn = Vc[n2];
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)tw, 0, (npair + 1) * 16, 0x00020000);
+    double2 op[2][5];   // the batch in flight / the batch being consumed
+    double2 dc[4];      // F[0], F2[0], F[n2], F2[n2] of the template being formed
+    auto issue = [&](int t, int u, double2 *o) {
+      const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)(tfft + (int64_t)t * (n2 + 1)), 0, nbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rF2 = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)(tfft2 + (int64_t)t * (n2 + 1)), 0, nbytes, 0x00020000);
+      const int k = 1 + pt + u * XW_HALF;
+      const int ok = k * 16, om = (n2 - k) * 16;
+      o[0] = ld(rF, ok), o[1] = ld(rF2, ok);
+      o[2] = ld(rF, om), o[3] = ld(rF2, om);
+      o[4] = ld(rT, ok);
+      if (u == 0 && pt == 0) {
+        dc[0] = ld(rF, 0), dc[1] = ld(rF2, 0);
+        dc[2] = ld(rF, n2 * 16), dc[3] = ld(rF2, n2 * 16);
+      }
+    };
+    auto form = [&](double2 *dst, int u, const double2 *o) {
+      const int k = 1 + pt + u * XW_HALF, m = n2 - k;
+      const double2 p1 = cmul(o[0], Sk[u]), p2 = cmul(o[1], Vk[u]);
+      const double2 Xk = make_double2(p2.x - 2 * p1.x, p2.y - 2 * p1.y);
+      const double2 q1 = cmul(o[2], Sm[u]), q2 = cmul(o[3], Vm[u]);
+      const double2 Xm = make_double2(q2.x - 2 * q1.x, q2.y - 2 * q1.y);
+      const double2 e = make_double2(Xk.x + Xm.x, Xk.y - Xm.y);
+      const double2 d = make_double2(Xk.x - Xm.x, Xk.y + Xm.y);
+      const double2 q = cmul(o[4], d);
+      dst[k] = make_double2(e.x - q.y, e.y + q.x);
+      if (m != k) dst[m] = make_double2(e.x + q.y, -e.y + q.x);
+      if (u == 0 && pt == 0) {
+        const double2 a1 = cmul(dc[0], S0), a2 = cmul(dc[1], V0);
+        const double2 b1 = cmul(dc[2], Sn), b2 = cmul(dc[3], Vn);
+        const double xk = a2.x - 2 * a1.x, xm = b2.x - 2 * b1.x;
+        // numpy irfft ignores the imaginary parts of the DC and Nyquist bins
+        dst[0] = make_double2(xk + xm, xk - xm);
+      }
+    };
+    issue(0, 0, op[0]);
+    for (int it = -1; it < T; it++) {
+      const int tn = it + 1;   // the template this iteration forms
+      if (tn < T) {
+        double2 *dst = img(tn);
+        issue(tn, 1, op[1]);
+        form(dst, 0, op[0]);
+        __syncthreads();
+        issue(tn, 2, op[0]);
+        form(dst, 1, op[1]);
+        __syncthreads();
+        issue(tn, 3, op[1]);
+        form(dst, 2, op[0]);
+        __syncthreads();
+        if (tn + 1 < T) issue(tn + 1, 0, op[0]);
+        form(dst, 3, op[1]);
+        __syncthreads();
+      } else {
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+      }
+      if (!fold) __syncthreads();
+    }
+    return;
+  }
+  // ---- consumers ---------------------------------------------------------
+  const int tvx = min(pt, nvel - 1);
+  const int pre_pos = lag_pos[min(pt, nlag - 1)];
+  const int pre_lo = ilo[tvx];
+  const double pre_xg = vgrid[tvx];
+  const double pre_x0 = lag_vel[pre_lo], pre_x1 = lag_vel[pre_lo + 1];
+  for (int it = -1; it < T; it++) {
+    if (it < 0) {
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();
+      if (!fold) __syncthreads();
+      continue;
+    }
+    double2 *a = img(it);
+    double *out = chisq + ((int64_t)b * T + it) * nvel;
+    double pre_old = 0;
+    if (beta != 0.0) pre_old = out[tvx];
+    xw_pass<1>(a, T1, 0, pt);
+    __syncthreads();
+    xw_pass<1>(a, T1, 1, pt);
+    __syncthreads();
+    if (fold) {
+      // the last two passes as one (fft_lds): eight lanes per 64-block
+      const int s = pt & 7;
+      const int B = pt >> 3;   // n2 / 64 = 64 blocks: one trip
+      const unsigned m0 = pmask.b0 & 1u, m63 = pmask.b7 >> 7;
+      if (m0 | m63) {
+        double2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = a[B * 64 + s + 8 * j];
+        dft8<1>(v);
+        double2 w = T1[s << (log2n - 6)];
+        w.y = -w.y;
+        double2 x63 = cmul(v[7], w), x0 = v[0];
+        auto sum8 = [](double x) {
+          x += dpp_get<0xb1, 0xf, 0xf>(x);    // quad_perm [1,0,3,2]
+          x += dpp_get<0x4e, 0xf, 0xf>(x);    // quad_perm [2,3,0,1]
+          x += dpp_get<0x141, 0xf, 0xf>(x);   // row_half_mirror
+          return x;
+        };
+        if (m0) {
+          x0.x = sum8(x0.x);
+          x0.y = sum8(x0.y);
+          if (s == 0) a[B * 64] = x0;
+        }
+        if (m63) {
+          x63.x = sum8(x63.x);
+          x63.y = sum8(x63.y);
+          if (s == 0) a[B * 64 + 63] = x63;
+        }
+      }
+      __syncthreads();
+    } else {
+      {   // pass 2 (M = 64, Mp = 8): selected outputs only
+        const int blk = pt >> 3, r = pt & 7, base = (blk << 6) + r;
+        const unsigned mask = prune[blk];
+        if (mask != 0) {
+          double2 v[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = a[base + 8 * j];
+          dft8<1>(v);
+          double2 wp[8];
+          wp[0] = make_double2(1.0, 0.0);
+          wp[1] = T1[r << (log2n + 1 - 6 - 1)];
+          wp[2] = cmul(wp[1], wp[1]);
+          wp[3] = cmul(wp[2], wp[1]);
+          wp[4] = cmul(wp[2], wp[2]);
+          wp[7] = cmul(wp[4], wp[3]);
+          wp[5] = cmul(wp[4], wp[1]);
+          wp[6] = cmul(wp[4], wp[2]);
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if (mask & (1u << q))
+              a[base + 8 * q] = (q == 0) ? v[0] : cmul(v[q], wp[q]);
+        }
+      }
+      __syncthreads();
+      {   // pass 3 (M = 8): no twiddles
+        const unsigned mask = pmask.g;
+        if (mask != 0) {
+          const int base = pt << 3;
+          double2 v[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = a[base + j];
+          dft8<1>(v);
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if (mask & (1u << q)) a[base + q] = v[q];
+        }
+      }
+      __syncthreads();
+    }
+    if (pt < nlag) c0[pt] = reinterpret_cast<const double *>(a)[pre_pos] * inv_n;
+    __syncthreads();
+    if (pt < nvel) {
+      const double sl = (c0[pre_lo + 1] - c0[pre_lo]) / (pre_x1 - pre_x0);
+      const double val = sl * (pre_xg - pre_x0) + c0[pre_lo];
+      out[pt] = (beta != 0.0) ? beta * pre_old + val : val;
+    }
+  }
+}
+
 extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
                              int nfft, int B, const double *tfft,
                              const double *tfft2, int T, const double *twid_,
@@ -690,6 +959,30 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
                      reinterpret_cast<double2 *>(work));
   RVS_LAUNCH_CHECK();
   const int G = xc_group(T, nfft);
+  {
+    // the wave-specialised persistent form (one block per spectrum), where it applies
+    const char *ev = getenv("RVS_XC_WS");
+    if (ev && ev[0] == '1' && continuum && nfft == 8192 && G == 0 && prune &&
+        nlag <= XW_HALF && nvel <= XW_HALF && T >= 2) {
+      static bool ws_attr = false;
+      if (!ws_attr) {
+        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  159 * 1024);
+        (void)hipGetLastError();
+        ws_attr = true;
+      }
+      const size_t shmw = sizeof(double2) * (size_t)(2 * n2 + XC_NTW(n2)) +
+                          sizeof(double) * (size_t)nlag;
+      hipLaunchKernelGGL(ccf_xcorr_ws_kernel, dim3(B), dim3(XW_NT), shmw, st,
+                         reinterpret_cast<const double2 *>(work),
+                         reinterpret_cast<const double2 *>(tfft),
+                         reinterpret_cast<const double2 *>(tfft2), T, tw, lag_pos,
+                         lag_vel, nlag, ilo, vgrid, nvel, beta, prune, chisq);
+      RVS_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const int bmax = G ? (int)(0x7fffffffll / xc_nblocks(T, 1, G)) : 65535;
   for (int b0 = 0; b0 < B; b0 += bmax) {
     const int nb = (B - b0 < bmax) ? (B - b0) : bmax;

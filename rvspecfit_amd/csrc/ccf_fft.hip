@@ -749,17 +749,18 @@ __global__ void __launch_bounds__(XW_NT)
   const int nbytes = (n2 + 1) * 16;
   if (producer) {
     // ---- producers -------------------------------------------------------
+#ifdef XW_PRIO
+    __builtin_amdgcn_s_setprio(XW_PRIO);
+#endif
     double2 Sk[4], Vk[4], Sm[4], Vm[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int k = 1 + pt + u * XW_HALF, m = n2 - k;
       Sk[u] = Sc[k], Vk[u] = Vc[k], Sm[u] = Sc[m], Vm[u] = Vc[m];
     }
-    const double2 S0 = Sc[0], V0 = Vc[0], Sn = Sc[n2], Vn = Vc[n2];
     const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
         (void *)tw, 0, (npair + 1) * 16, 0x00020000);
     double2 op[2][5];   // the batch in flight / the batch being consumed
-    double2 dc[4];      // F[0], F2[0], F[n2], F2[n2] of the template being formed
     auto issue = [&](int t, int u, double2 *o) {
       const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(
           (void *)(tfft + (int64_t)t * (n2 + 1)), 0, nbytes, 0x00020000);
@@ -770,11 +771,8 @@ __global__ void __launch_bounds__(XW_NT)
       o[0] = ld(rF, ok), o[1] = ld(rF2, ok);
       o[2] = ld(rF, om), o[3] = ld(rF2, om);
       o[4] = ld(rT, ok);
-      if (u == 0 && pt == 0) {
-        dc[0] = ld(rF, 0), dc[1] = ld(rF2, 0);
-        dc[2] = ld(rF, n2 * 16), dc[3] = ld(rF2, n2 * 16);
-      }
     };
+    double2 dc[4];   // F[0], F2[0], F[n2], F2[n2] of the template being formed (scalar)
     auto form = [&](double2 *dst, int u, const double2 *o) {
       const int k = 1 + pt + u * XW_HALF, m = n2 - k;
       const double2 p1 = cmul(o[0], Sk[u]), p2 = cmul(o[1], Vk[u]);
@@ -786,9 +784,11 @@ __global__ void __launch_bounds__(XW_NT)
       const double2 q = cmul(o[4], d);
       dst[k] = make_double2(e.x - q.y, e.y + q.x);
       if (m != k) dst[m] = make_double2(e.x + q.y, -e.y + q.x);
-      if (u == 0 && pt == 0) {
-        const double2 a1 = cmul(dc[0], S0), a2 = cmul(dc[1], V0);
-        const double2 b1 = cmul(dc[2], Sn), b2 = cmul(dc[3], Vn);
+      if (u == 3 && pt == 0) {
+        // the DC / Nyquist pair: wave-uniform addresses (scalar loads, requested in the
+        // template's first interval), formed in its last by one lane
+        const double2 a1 = cmul(dc[0], Sc[0]), a2 = cmul(dc[1], Vc[0]);
+        const double2 b1 = cmul(dc[2], Sc[n2]), b2 = cmul(dc[3], Vc[n2]);
         const double xk = a2.x - 2 * a1.x, xm = b2.x - 2 * b1.x;
         // numpy irfft ignores the imaginary parts of the DC and Nyquist bins
         dst[0] = make_double2(xk + xm, xk - xm);
@@ -800,6 +800,11 @@ __global__ void __launch_bounds__(XW_NT)
       if (tn < T) {
         double2 *dst = img(tn);
         issue(tn, 1, op[1]);
+        {
+          const double2 *Fp = tfft + (int64_t)tn * (n2 + 1);
+          const double2 *F2p = tfft2 + (int64_t)tn * (n2 + 1);
+          dc[0] = Fp[0], dc[1] = F2p[0], dc[2] = Fp[n2], dc[3] = F2p[n2];
+        }
         form(dst, 0, op[0]);
         __syncthreads();
         issue(tn, 2, op[0]);
@@ -961,8 +966,8 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
   const int G = xc_group(T, nfft);
   {
     // the wave-specialised persistent form (one block per spectrum), where it applies
-    const char *ev = getenv("RVS_XC_WS");
-    if (ev && ev[0] == '1' && continuum && nfft == 8192 && G == 0 && prune &&
+    const char *ev = getenv("RVS_XC_WS");   // RVS_XC_WS=0: the per-pair kernel
+    if (!(ev && ev[0] == '0') && continuum && nfft == 8192 && prune &&
         nlag <= XW_HALF && nvel <= XW_HALF && T >= 2) {
       static bool ws_attr = false;
       if (!ws_attr) {

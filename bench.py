@@ -778,9 +778,10 @@ def main():
                      '+ 22 for the 11-tap band with --resolution-matrix); peak = datasheet fp64 vector rate (a '
                      'pure v_fma_f64 loop sustained 70.6 TF on this chip in '
                      'round 2, tools/perf/ubench.hip -- not measured by this run)')
-    roof_ccf = dict(bound='hbm', kernel='ccf_xcorr_kernel',
-                    timed='rvs_ccf_xcorr call = ccf_rfft_kernel + ccf_xcorr_kernel '
-                          '(HIP events on the launch stream)',
+    roof_ccf = dict(bound='hbm', kernel='ccf_xcorr_ws_kernel (nfft 8192: one persistent '
+                    'block per spectrum, wave-specialised) / ccf_xcorr_kernel',
+                    timed='rvs_ccf_xcorr call = ccf_rfft_kernel + the cross-correlation '
+                          'kernel (HIP events on the launch stream)',
                     achieved=round(ccf_gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=round(ccf_gbs / HBM_PEAK_GBS, 4),
                     traffic=tr_ccf, traffic_source=src_ccf,
@@ -794,7 +795,7 @@ def main():
                          'what HBM can deliver -- see counter_backed')
     # what the counters say bounds the kernel (committed passes of this build on
     # this configuration; null when not profiled)
-    sq = sq_counters('ccf_xcorr_kernel')
+    sq = sq_counters('ccf_xcorr_ws_kernel') or sq_counters('ccf_xcorr_kernel')
     avg_ms = ms / max(nl, 1)
     cb_ = dict(real_hbm_GBps=None, real_hbm_frac_of_peak=None, l2_to_l1_TBps=None,
                valu_busy=None, lds_busy=None, source=None)

@@ -1911,12 +1911,30 @@ def test_xcorr_every_plan_vs_numpy(gpu, nfft, continuum):
     _xcorr_vs_numpy(nfft, continuum, 3, 5)
 
 
-def test_xcorr_large_template_set_job_map(gpu):
+def test_xcorr_large_template_set_job_map(gpu, monkeypatch):
     """a template set above 16 MB (T = 140 at nfft 8192) takes the XCD-aware,
     grouped (spectrum, template) order of ccf_xcorr_kernel (xc_job): every
     (b, t) row lands where the plain order puts it, padding blocks write
     nothing"""
+    monkeypatch.setenv('RVS_XC_WS', '0')   # (the per-pair kernel)
     _xcorr_vs_numpy(8192, 1, 5, 140)
+
+
+@pytest.mark.parametrize('B,T', [(3, 5), (5, 140), (2, 2), (1, 77)])
+def test_xcorr_wave_specialised_equals_per_pair(gpu, monkeypatch, B, T):
+    """ccf_xcorr_ws_kernel (one persistent block per spectrum: producer waves
+    keep S*, V* in registers and stream the templates into one LDS image while
+    consumer waves transform the other) against ccf_xcorr_kernel (one block per
+    (spectrum, template); RVS_XC_WS=0) and numpy, first call and accumulating
+    call, small and large template sets.  Same formulas bin by bin and butterfly
+    by butterfly; the two kernels are compiled separately, so which product of a
+    complex multiplication the compiler fuses into an fma may differ: equal to a
+    few ulp of the largest term, not bit for bit."""
+    got_ws = _xcorr_vs_numpy(8192, 1, B, T)
+    monkeypatch.setenv('RVS_XC_WS', '0')
+    got_pp = _xcorr_vs_numpy(8192, 1, B, T)
+    np.testing.assert_allclose(got_ws, got_pp, rtol=1e-12,
+                               atol=1e-12 * np.abs(got_pp).max())
 
 
 def _xcorr_vs_numpy(nfft, continuum, B, T):
@@ -1977,6 +1995,7 @@ def _xcorr_vs_numpy(nfft, continuum, B, T):
                 (vgrid - sub[lo]) + y[lo]
             np.testing.assert_allclose(got[b, t], 2 * ref, rtol=1e-9,
                                        atol=1e-9 * np.abs(ref).max())
+    return got
 
 
 def test_reference_test_fit_nn_sequence(gpu):

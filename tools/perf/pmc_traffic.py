@@ -46,9 +46,9 @@ def main():
                            '1 --no-cpu-baseline %s, tag %s' % (bargs, tag))
     d = json.load(open(out)) if os.path.exists(out) else {}
     d[key] = dict(
-        ccf_xcorr=entry(['ccf_xcorr_kernel'], ('ccf_xcorr_kernel', ),
-                        'ccf_xcorr_kernel (one launch = one accumulator chunk x T '
-                        'templates x one arm)'),
+        ccf_xcorr=entry(['ccf_xcorr_'], ('ccf_xcorr_', ),
+                        'ccf_xcorr_ws_kernel / ccf_xcorr_kernel (one launch = one '
+                        'accumulator chunk x T templates x one arm)'),
         chisq_grid=entry(['chisq_grid_kernel', 'chisq_grid_resol'],
                          # (one full-wave launch per rvs_chisq_grid call, any npoly)
                          ('chisq_grid_kernel<', ', false>')

@@ -54,6 +54,10 @@ for k, d in out.items():
         nfft = int([x for x in key.split('|') if x.startswith('nfft=')][0][5:])
         per_block = 4 * (nfft // 2 + 1) * 16 + (nfft // 16) * 16
         d['l2_to_l1_TBps'] = round(d['SQ_WAVES'] / 8 * per_block / (t * 1e-9) / 1e12, 2)
+        if 'xcorr_ws' in k:
+            # the persistent form: a block walks T templates; every vector load is
+            # 16 B per lane (operands, fold twiddles, the spectrum once per block)
+            d['l2_to_l1_TBps'] = round(d.get('SQ_INSTS_VMEM_RD', 0) * 64 * 16 / (t * 1e-9) / 1e12, 2)
         # cross-check: vector-memory read instructions x 64 lanes x 16 B (upper
         # bound: the table / mask loads are narrower)
         d['vmem_rd_TBps_upper'] = round(d.get('SQ_INSTS_VMEM_RD', 0) * 64 * 16 / (t * 1e-9) / 1e12, 2)

@@ -680,12 +680,11 @@ __global__ void __launch_bounds__(XB_NT)
 #define XW_NT 1024
 #define XW_HALF 512
 
-// radix-8 DIF pass p (M = 4096 >> 3p) of the 4096-point image a[], 512 threads
-template <int SIGN>
+// radix-8 DIF pass p (M = n2 >> 3p) of the n2 = 2^LOG2N point image a[]: butterfly t
+template <int SIGN, int LOG2N>
 __device__ __forceinline__ void xw_pass(double2 *a, const double2 *T1, int p, int t) {
-  constexpr int log2n = 12;
-  const int lgM = log2n - 3 * p, lgMp = lgM - 3, Mp = 1 << lgMp;
-  const int tws = log2n + 1 - lgM;
+  const int lgM = LOG2N - 3 * p, lgMp = lgM - 3, Mp = 1 << lgMp;
+  const int tws = LOG2N + 1 - lgM;
   const int blk = t >> lgMp, r = t & (Mp - 1);
   const int base = (blk << lgM) + r;
   double2 v[8];
@@ -711,6 +710,9 @@ __device__ __forceinline__ void xw_pass(double2 *a, const double2 *T1, int p, in
   for (int q = 0; q < 8; q++) a[base + Mp * q] = v[q];
 }
 
+// LOG2N = 12 (nfft 8192: passes 8,8,8,8, the last two pruned / folded) or 11 (nfft
+// 4096: passes 8,8,8,4, nothing pruned).  NBAR barriers per template: 4 (12, folded) or 5.
+template <int LOG2N>
 __global__ void __launch_bounds__(XW_NT)
     ccf_xcorr_ws_kernel(const double2 *__restrict__ work,
                         const double2 *__restrict__ tfft,
@@ -723,7 +725,10 @@ __global__ void __launch_bounds__(XW_NT)
                         const uint8_t *__restrict__ prune,
                         double *__restrict__ chisq) {
   extern __shared__ double2 fa[];
-  constexpr int nfft = 8192, n2 = 4096, npair = 2048, log2n = 12;
+  constexpr int log2n = LOG2N, n2 = 1 << LOG2N, nfft = 2 * n2, npair = n2 / 2;
+  constexpr int NPP = npair / XW_HALF;   // bin pairs of a producer lane: 4 or 2
+  constexpr bool P12 = (LOG2N == 12);
+  static_assert(LOG2N == 12 || LOG2N == 11, "plans 8,8,8,8 and 8,8,8,4 only");
   auto img = [&](int i) -> double2 * { return fa + (i & 1) * n2; };
   const double2 *T1 = fa + 2 * n2;                         // [n2 / 8]
   double *c0 = reinterpret_cast<double *>(fa + 2 * n2 + XC_NTW(n2));  // [nlag]
@@ -735,8 +740,8 @@ __global__ void __launch_bounds__(XW_NT)
   // output masks of the last two passes (consumers), and the block-wide vote on the
   // folded form of those passes (see fft_lds)
   XcMasks pmask = {0u, 0u, 0u};
-  bool bad = false;
-  if (!producer) {
+  bool bad = !P12;
+  if (P12 && !producer) {
     pmask = xc_load_masks<XW_HALF>(prune, n2);
     const int pos8 = pt & 7;
     const unsigned m = pmask.g;
@@ -753,12 +758,9 @@ __global__ void __launch_bounds__(XW_NT)
   const int nbytes = (n2 + 1) * 16;
   if (producer) {
     // ---- producers -------------------------------------------------------
-#ifdef XW_PRIO
-    __builtin_amdgcn_s_setprio(XW_PRIO);
-#endif
-    double2 Sk[4], Vk[4], Sm[4], Vm[4];
+    double2 Sk[NPP], Vk[NPP], Sm[NPP], Vm[NPP];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < NPP; u++) {
       const int k = 1 + pt + u * XW_HALF, m = n2 - k;
       Sk[u] = Sc[k], Vk[u] = Vc[k], Sm[u] = Sc[m], Vm[u] = Vc[m];
     }
@@ -788,9 +790,9 @@ __global__ void __launch_bounds__(XW_NT)
       const double2 q = cmul(o[4], d);
       dst[k] = make_double2(e.x - q.y, e.y + q.x);
       if (m != k) dst[m] = make_double2(e.x + q.y, -e.y + q.x);
-      if (u == 3 && pt == 0) {
+      if (u == NPP - 1 && pt == 0) {
         // the DC / Nyquist pair: wave-uniform addresses (scalar loads, requested in the
-        // template's first interval), formed in its last by one lane
+        // template's first interval), formed with its last batch by one lane
         const double2 a1 = cmul(dc[0], Sc[0]), a2 = cmul(dc[1], Vc[0]);
         const double2 b1 = cmul(dc[2], Sc[n2]), b2 = cmul(dc[3], Vc[n2]);
         const double xk = a2.x - 2 * a1.x, xm = b2.x - 2 * b1.x;
@@ -798,35 +800,45 @@ __global__ void __launch_bounds__(XW_NT)
         dst[0] = make_double2(xk + xm, xk - xm);
       }
     };
+    const int nbar = (P12 && fold) ? 4 : 5;
     issue(0, 0, op[0]);
+    if (NPP == 2) issue(0, 1, op[1]);
     for (int it = -1; it < T; it++) {
       const int tn = it + 1;   // the template this iteration forms
       if (tn < T) {
         double2 *dst = img(tn);
-        issue(tn, 1, op[1]);
         {
           const double2 *Fp = tfft + (int64_t)tn * (n2 + 1);
           const double2 *F2p = tfft2 + (int64_t)tn * (n2 + 1);
           dc[0] = Fp[0], dc[1] = F2p[0], dc[2] = Fp[n2], dc[3] = F2p[n2];
         }
-        form(dst, 0, op[0]);
-        __syncthreads();
-        issue(tn, 2, op[0]);
-        form(dst, 1, op[1]);
-        __syncthreads();
-        issue(tn, 3, op[1]);
-        form(dst, 2, op[0]);
-        __syncthreads();
-        if (tn + 1 < T) issue(tn + 1, 0, op[0]);
-        form(dst, 3, op[1]);
-        __syncthreads();
+        if (NPP == 2) {
+          // two batches, two buffers: each buffer is refilled with the NEXT
+          // template's batch as soon as it has been consumed -- a whole template
+          // (five intervals) ahead
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            form(dst, u, op[u]);
+            if (tn + 1 < T) issue(tn + 1, u, op[u]);
+            __syncthreads();
+          }
+        } else {
+          // one pair batch per interval, the next one requested first (in flight
+          // across the barrier)
+#pragma unroll
+          for (int u = 0; u < NPP; u++) {
+            if (u + 1 < NPP)
+              issue(tn, u + 1, op[(u + 1) & 1]);
+            else if (tn + 1 < T)
+              issue(tn + 1, 0, op[(u + 1) & 1]);
+            form(dst, u, op[u & 1]);
+            __syncthreads();
+          }
+        }
+        for (int q = NPP; q < nbar; q++) __syncthreads();
       } else {
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
+        for (int q = 0; q < nbar; q++) __syncthreads();
       }
-      if (!fold) __syncthreads();
     }
     return;
   }
@@ -838,22 +850,30 @@ __global__ void __launch_bounds__(XW_NT)
   const double pre_x0 = lag_vel[pre_lo], pre_x1 = lag_vel[pre_lo + 1];
   for (int it = -1; it < T; it++) {
     if (it < 0) {
-      __syncthreads();
-      __syncthreads();
-      __syncthreads();
-      __syncthreads();
-      if (!fold) __syncthreads();
+      const int nbar = (P12 && fold) ? 4 : 5;
+      for (int q = 0; q < nbar; q++) __syncthreads();
       continue;
     }
     double2 *a = img(it);
     double *out = chisq + ((int64_t)b * T + it) * nvel;
     double pre_old = 0;
     if (beta != 0.0) pre_old = out[tvx];
-    xw_pass<1>(a, T1, 0, pt);
+    if (pt < (n2 >> 3)) xw_pass<1, LOG2N>(a, T1, 0, pt);
     __syncthreads();
-    xw_pass<1>(a, T1, 1, pt);
+    if (pt < (n2 >> 3)) xw_pass<1, LOG2N>(a, T1, 1, pt);
     __syncthreads();
-    if (fold) {
+    if (!P12) {
+      // nfft 4096: a third radix-8 pass (M = 32) and the radix-4 pass (M = 4)
+      if (pt < (n2 >> 3)) xw_pass<1, LOG2N>(a, T1, 2, pt);
+      __syncthreads();
+      {
+        const int base = pt << 2;
+        double2 v0 = a[base], v1 = a[base + 1], v2 = a[base + 2], v3 = a[base + 3];
+        dft4<1>(v0, v1, v2, v3);
+        a[base] = v0, a[base + 1] = v1, a[base + 2] = v2, a[base + 3] = v3;
+      }
+      __syncthreads();
+    } else if (fold) {
       // the last two passes as one (fft_lds): eight lanes per 64-block
       const int s = pt & 7;
       const int B = pt >> 3;   // n2 / 64 = 64 blocks: one trip
@@ -934,6 +954,166 @@ __global__ void __launch_bounds__(XW_NT)
   }
 }
 
+// nfft = 4096 (BASELINE configs[0-1]: one arm of ~2000 px): a radix-8 pass of the
+// 2048-point image has 256 butterflies -- half of the consumer lanes -- and lasts as
+// long as one of the 4096-point image (one butterfly per lane either way: the pass is
+// a latency chain).  Here an iteration takes TWO templates: consumer lane pt works on
+// image pt >> 8, the producers form both images (four pair batches, as at nfft 8192).
+// Passes 8, 8, 8, 4, nothing pruned; five barriers per iteration.
+__global__ void __launch_bounds__(XW_NT)
+    ccf_xcorr_ws2_kernel(const double2 *__restrict__ work,
+                         const double2 *__restrict__ tfft,
+                         const double2 *__restrict__ tfft2, int T,
+                         const double2 *__restrict__ tw,
+                         const int32_t *__restrict__ lag_pos,
+                         const double *__restrict__ lag_vel, int nlag,
+                         const int32_t *__restrict__ ilo,
+                         const double *__restrict__ vgrid, int nvel, double beta,
+                         double *__restrict__ chisq) {
+  extern __shared__ double2 fa[];
+  constexpr int LOG2N = 11, n2 = 1 << LOG2N, nfft = 2 * n2, npair = n2 / 2;
+  constexpr int NBAR = 5;
+  // images: iteration parity i, template j of the iteration
+  auto img = [&](int i, int j) -> double2 * { return fa + (((i & 1) << 1) + j) * n2; };
+  const double2 *T1 = fa + 4 * n2;                         // [n2 / 8]
+  double *c0 = reinterpret_cast<double *>(fa + 4 * n2 + XC_NTW(n2));  // [2][nlag]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const bool producer = tid >= XW_HALF;
+  const int pt = tid & (XW_HALF - 1);
+  const double inv_n = 1.0 / nfft;
+  xc_fill_twiddles<XW_NT>(fa + 3 * n2, n2, tw);   // -> fa[4 n2 + i]
+  const double2 *Sc = work + ((int64_t)b * 2) * (n2 + 1);
+  const double2 *Vc = Sc + (n2 + 1);
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  auto ld = [](const __amdgpu_buffer_rsrc_t &r, int off) {
+    const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_double2(__hiloint2double(v.y, v.x), __hiloint2double(v.w, v.z));
+  };
+  const int nbytes = (n2 + 1) * 16;
+  const int NIT = (T + 1) >> 1;
+  __syncthreads();
+  if (producer) {
+    double2 Sk[2], Vk[2], Sm[2], Vm[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int k = 1 + pt + u * XW_HALF, m = n2 - k;
+      Sk[u] = Sc[k], Vk[u] = Vc[k], Sm[u] = Sc[m], Vm[u] = Vc[m];
+    }
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)tw, 0, (npair + 1) * 16, 0x00020000);
+    double2 op[2][5];
+    // batch q of an iteration: template 2 i + (q >> 1), pair q & 1
+    auto issue = [&](int t, int u, double2 *o) {
+      const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)(tfft + (int64_t)t * (n2 + 1)), 0, nbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rF2 = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)(tfft2 + (int64_t)t * (n2 + 1)), 0, nbytes, 0x00020000);
+      const int k = 1 + pt + u * XW_HALF;
+      const int ok = k * 16, om = (n2 - k) * 16;
+      o[0] = ld(rF, ok), o[1] = ld(rF2, ok);
+      o[2] = ld(rF, om), o[3] = ld(rF2, om);
+      o[4] = ld(rT, ok);
+    };
+    auto form = [&](double2 *dst, int t, int u, const double2 *o) {
+      const int k = 1 + pt + u * XW_HALF, m = n2 - k;
+      const double2 p1 = cmul(o[0], Sk[u]), p2 = cmul(o[1], Vk[u]);
+      const double2 Xk = make_double2(p2.x - 2 * p1.x, p2.y - 2 * p1.y);
+      const double2 q1 = cmul(o[2], Sm[u]), q2 = cmul(o[3], Vm[u]);
+      const double2 Xm = make_double2(q2.x - 2 * q1.x, q2.y - 2 * q1.y);
+      const double2 e = make_double2(Xk.x + Xm.x, Xk.y - Xm.y);
+      const double2 d = make_double2(Xk.x - Xm.x, Xk.y + Xm.y);
+      const double2 q = cmul(o[4], d);
+      dst[k] = make_double2(e.x - q.y, e.y + q.x);
+      if (m != k) dst[m] = make_double2(e.x + q.y, -e.y + q.x);
+      if (u == 1 && pt == 0) {   // DC / Nyquist pair (scalar loads: uniform addresses)
+        const double2 *Fp = tfft + (int64_t)t * (n2 + 1);
+        const double2 *F2p = tfft2 + (int64_t)t * (n2 + 1);
+        const double2 a1 = cmul(Fp[0], Sc[0]), a2 = cmul(F2p[0], Vc[0]);
+        const double2 b1 = cmul(Fp[n2], Sc[n2]), b2 = cmul(F2p[n2], Vc[n2]);
+        const double xk = a2.x - 2 * a1.x, xm = b2.x - 2 * b1.x;
+        dst[0] = make_double2(xk + xm, xk - xm);
+      }
+    };
+    // template of batch q of iteration i, clamped (an odd T forms its last template
+    // twice: the copy is never read back)
+    auto tq = [&](int i, int q) { return min(2 * i + (q >> 1), T - 1); };
+    issue(tq(0, 0), 0, op[0]);
+    for (int it = -1; it < NIT; it++) {
+      const int in = it + 1;   // the iteration whose images are formed now
+      if (in < NIT) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (q + 1 < 4)
+            issue(tq(in, q + 1), (q + 1) & 1, op[(q + 1) & 1]);
+          else if (in + 1 < NIT)
+            issue(tq(in + 1, 0), 0, op[(q + 1) & 1]);
+          form(img(in, q >> 1), tq(in, q), q & 1, op[q & 1]);
+          __syncthreads();
+        }
+        __syncthreads();
+      } else {
+        for (int q = 0; q < NBAR; q++) __syncthreads();
+      }
+    }
+    return;
+  }
+  // ---- consumers: lane pt on image j = pt >> 8, butterfly bt = pt & 255 ----
+  const int j = pt >> 8, bt = pt & 255;
+  int pre_pos[1], dummy = 0;
+  (void)dummy;
+  pre_pos[0] = lag_pos[min(pt, nlag - 1)];
+  const int tvx = min(pt, nvel - 1);
+  const int pre_lo = ilo[tvx];
+  const double pre_xg = vgrid[tvx];
+  const double pre_x0 = lag_vel[pre_lo], pre_x1 = lag_vel[pre_lo + 1];
+  for (int it = -1; it < NIT; it++) {
+    if (it < 0) {
+      for (int q = 0; q < NBAR; q++) __syncthreads();
+      continue;
+    }
+    double2 *a = img(it, j);
+    const int t0 = 2 * it, t1 = min(2 * it + 1, T - 1);
+    const bool two = (2 * it + 1 < T);
+    double *out0 = chisq + ((int64_t)b * T + t0) * nvel;
+    double *out1 = chisq + ((int64_t)b * T + t1) * nvel;
+    double old0 = 0, old1 = 0;
+    if (beta != 0.0) {
+      old0 = out0[tvx];
+      old1 = out1[tvx];
+    }
+    xw_pass<1, LOG2N>(a, T1, 0, bt);
+    __syncthreads();
+    xw_pass<1, LOG2N>(a, T1, 1, bt);
+    __syncthreads();
+    xw_pass<1, LOG2N>(a, T1, 2, bt);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {   // radix-4 pass: 512 butterflies per image
+      const int base = (bt + 256 * h) << 2;
+      double2 v0 = a[base], v1 = a[base + 1], v2 = a[base + 2], v3 = a[base + 3];
+      dft4<1>(v0, v1, v2, v3);
+      a[base] = v0, a[base + 1] = v1, a[base + 2] = v2, a[base + 3] = v3;
+    }
+    __syncthreads();
+    if (pt < nlag) {
+      c0[pt] = reinterpret_cast<const double *>(img(it, 0))[pre_pos[0]] * inv_n;
+      c0[nlag + pt] = reinterpret_cast<const double *>(img(it, 1))[pre_pos[0]] * inv_n;
+    }
+    __syncthreads();
+    if (pt < nvel) {
+      const double dx = pre_x1 - pre_x0, xg = pre_xg - pre_x0;
+      const double sl0 = (c0[pre_lo + 1] - c0[pre_lo]) / dx;
+      const double val0 = sl0 * xg + c0[pre_lo];
+      out0[pt] = (beta != 0.0) ? beta * old0 + val0 : val0;
+      if (two) {
+        const double sl1 = (c0[nlag + pre_lo + 1] - c0[nlag + pre_lo]) / dx;
+        const double val1 = sl1 * xg + c0[nlag + pre_lo];
+        out1[pt] = (beta != 0.0) ? beta * old1 + val1 : val1;
+      }
+    }
+  }
+}
+
 extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
                              int nfft, int B, const double *tfft,
                              const double *tfft2, int T, const double *twid_,
@@ -971,11 +1151,18 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
   {
     // the wave-specialised persistent form (one block per spectrum), where it applies
     const char *ev = getenv("RVS_XC_WS");   // RVS_XC_WS=0: the per-pair kernel
-    if (!(ev && ev[0] == '0') && continuum && nfft == 8192 && prune &&
+    const bool p12 = (nfft == 8192 && prune), p11 = (nfft == 4096);
+    if (!(ev && ev[0] == '0') && continuum && (p12 || p11) &&
         nlag <= XW_HALF && nvel <= XW_HALF && T >= 2) {
       static bool ws_attr = false;
       if (!ws_attr) {
-        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel,
+        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel<12>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  159 * 1024);
+        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel<11>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  159 * 1024);
+        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws2_kernel,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   159 * 1024);
         (void)hipGetLastError();
@@ -983,11 +1170,27 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
       }
       const size_t shmw = sizeof(double2) * (size_t)(2 * n2 + XC_NTW(n2)) +
                           sizeof(double) * (size_t)nlag;
-      hipLaunchKernelGGL(ccf_xcorr_ws_kernel, dim3(B), dim3(XW_NT), shmw, st,
-                         reinterpret_cast<const double2 *>(work),
-                         reinterpret_cast<const double2 *>(tfft),
-                         reinterpret_cast<const double2 *>(tfft2), T, tw, lag_pos,
-                         lag_vel, nlag, ilo, vgrid, nvel, beta, prune, chisq);
+      if (p12)
+        hipLaunchKernelGGL(ccf_xcorr_ws_kernel<12>, dim3(B), dim3(XW_NT), shmw, st,
+                           reinterpret_cast<const double2 *>(work),
+                           reinterpret_cast<const double2 *>(tfft),
+                           reinterpret_cast<const double2 *>(tfft2), T, tw, lag_pos,
+                           lag_vel, nlag, ilo, vgrid, nvel, beta, prune, chisq);
+      else if (getenv("RVS_XC_WS1"))   // (one template per iteration: measured 1.10 ms
+                                       // per 1000 spectra against 0.84; per pair 1.34)
+        hipLaunchKernelGGL(ccf_xcorr_ws_kernel<11>, dim3(B), dim3(XW_NT), shmw, st,
+                           reinterpret_cast<const double2 *>(work),
+                           reinterpret_cast<const double2 *>(tfft),
+                           reinterpret_cast<const double2 *>(tfft2), T, tw, lag_pos,
+                           lag_vel, nlag, ilo, vgrid, nvel, beta, prune, chisq);
+      else
+        hipLaunchKernelGGL(ccf_xcorr_ws2_kernel, dim3(B), dim3(XW_NT),
+                           sizeof(double2) * (size_t)(4 * n2 + XC_NTW(n2)) +
+                               sizeof(double) * 2 * (size_t)nlag,
+                           st, reinterpret_cast<const double2 *>(work),
+                           reinterpret_cast<const double2 *>(tfft),
+                           reinterpret_cast<const double2 *>(tfft2), T, tw, lag_pos,
+                           lag_vel, nlag, ilo, vgrid, nvel, beta, chisq);
       RVS_LAUNCH_CHECK();
       return 0;
     }

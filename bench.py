@@ -755,7 +755,10 @@ def main():
             d = json.load(open(f))
             if d.get('traffic_key') != tkey:
                 return None
-            return d['kernels'][kernel]
+            for k, v in d['kernels'].items():   # ('void name<..>' for templates)
+                if kernel in k:
+                    return v
+            return None
         except Exception:
             return None
     tr_grid, src_grid = pmc_traffic('chisq_grid')

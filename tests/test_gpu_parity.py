@@ -1920,19 +1920,22 @@ def test_xcorr_large_template_set_job_map(gpu, monkeypatch):
     _xcorr_vs_numpy(8192, 1, 5, 140)
 
 
-@pytest.mark.parametrize('B,T', [(3, 5), (5, 140), (2, 2), (1, 77)])
-def test_xcorr_wave_specialised_equals_per_pair(gpu, monkeypatch, B, T):
+@pytest.mark.parametrize('nfft,B,T', [(8192, 3, 5), (8192, 5, 140), (8192, 2, 2),
+                                      (8192, 1, 77), (4096, 2, 2), (4096, 3, 76),
+                                      (4096, 1, 3), (4096, 2, 141)])
+def test_xcorr_wave_specialised_equals_per_pair(gpu, monkeypatch, nfft, B, T):
     """ccf_xcorr_ws_kernel (one persistent block per spectrum: producer waves
     keep S*, V* in registers and stream the templates into one LDS image while
     consumer waves transform the other) against ccf_xcorr_kernel (one block per
     (spectrum, template); RVS_XC_WS=0) and numpy, first call and accumulating
-    call, small and large template sets.  Same formulas bin by bin and butterfly
+    call, small and large template sets, odd and even T; at nfft 4096 the form that
+    takes two templates per iteration.  Same formulas bin by bin and butterfly
     by butterfly; the two kernels are compiled separately, so which product of a
     complex multiplication the compiler fuses into an fma may differ: equal to a
     few ulp of the largest term, not bit for bit."""
-    got_ws = _xcorr_vs_numpy(8192, 1, B, T)
+    got_ws = _xcorr_vs_numpy(nfft, 1, B, T)
     monkeypatch.setenv('RVS_XC_WS', '0')
-    got_pp = _xcorr_vs_numpy(8192, 1, B, T)
+    got_pp = _xcorr_vs_numpy(nfft, 1, B, T)
     np.testing.assert_allclose(got_ws, got_pp, rtol=1e-12,
                                atol=1e-12 * np.abs(got_pp).max())
 

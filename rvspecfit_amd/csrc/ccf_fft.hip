@@ -772,7 +772,11 @@ __global__ void __launch_bounds__(XW_NT)
           (void *)(tfft + (int64_t)t * (n2 + 1)), 0, nbytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t rF2 = __builtin_amdgcn_make_buffer_rsrc(
           (void *)(tfft2 + (int64_t)t * (n2 + 1)), 0, nbytes, 0x00020000);
-      const int k = 1 + pt + u * XW_HALF;
+      // (the lane's bin offsets are re-derived at every use: kept live across the
+      // template loop they are the registers that spill)
+      int ptv = pt;
+      asm volatile("" : "+v"(ptv));
+      const int k = 1 + ptv + u * XW_HALF;
       const int ok = k * 16, om = (n2 - k) * 16;
       o[0] = ld(rF, ok), o[1] = ld(rF2, ok);
       o[2] = ld(rF, om), o[3] = ld(rF2, om);
@@ -780,7 +784,9 @@ __global__ void __launch_bounds__(XW_NT)
     };
     double2 dc[4];   // F[0], F2[0], F[n2], F2[n2] of the template being formed (scalar)
     auto form = [&](double2 *dst, int u, const double2 *o) {
-      const int k = 1 + pt + u * XW_HALF, m = n2 - k;
+      int ptv = pt;
+      asm volatile("" : "+v"(ptv));
+      const int k = 1 + ptv + u * XW_HALF, m = n2 - k;
       const double2 p1 = cmul(o[0], Sk[u]), p2 = cmul(o[1], Vk[u]);
       const double2 Xk = make_double2(p2.x - 2 * p1.x, p2.y - 2 * p1.y);
       const double2 q1 = cmul(o[2], Sm[u]), q2 = cmul(o[3], Vm[u]);
@@ -790,7 +796,7 @@ __global__ void __launch_bounds__(XW_NT)
       const double2 q = cmul(o[4], d);
       dst[k] = make_double2(e.x - q.y, e.y + q.x);
       if (m != k) dst[m] = make_double2(e.x + q.y, -e.y + q.x);
-      if (u == NPP - 1 && pt == 0) {
+      if (u == NPP - 1 && ptv == 0) {
         // the DC / Nyquist pair: wave-uniform addresses (scalar loads, requested in the
         // template's first interval), formed with its last batch by one lane
         const double2 a1 = cmul(dc[0], Sc[0]), a2 = cmul(dc[1], Vc[0]);

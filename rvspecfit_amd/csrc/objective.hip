@@ -1199,6 +1199,15 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     bool pre = true;
     for (int i = 0; i < narm; i++)
       if ((1 << arms[i].ndim) > OBJ_LOC_NV) pre = false;
+    // a launch that fits the chip in one go (<= 256 blocks): the cell search inside
+    // the block -- the same device function, so the same values -- and one launch
+    // less per evaluation in the optimiser's latency-bound last rounds (+1 % at 2000
+    // spectra; RVS_OBJ_INBLK_MAX overrides the bound, 0 = never)
+    {
+      int inblk_max = 256;
+      if (const char *ev = getenv("RVS_OBJ_INBLK_MAX")) inblk_max = atoi(ev);
+      if ((int64_t)J * narm <= inblk_max) pre = false;
+    }
     if (pre) {
       hipLaunchKernelGGL(objective_locate_kernel, grid, dim3(OBJ_LOC_NT), 0, st, A,
                          params, J, live, locbuf);

@@ -67,9 +67,34 @@ extern "C" {
  *      leaves {1/e, s/e} per spectrum pixel (e with espec_sys in quadrature), which
  *      rvs_objective_fused / rvs_nm_run read instead of spec / espec;
  *      rvs_objective_fused_n / rvs_objective_from_template_n (job count on the
- *      device) */
-#define RVS_ABI_VERSION 8
+ *      device)
+ *   9: rvs_option_set / rvs_option_get (the behaviour switches, no longer read from
+ *      the environment at launch time); rvs_basis_build takes npoly <= 32 and
+ *      npix <= 16384; espec = +inf marks padding only when G > 1 */
+#define RVS_ABI_VERSION 9
 int rvs_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Behaviour switches.  The entry points may be driven from several host threads
+ * (vel_fit.process runs its halves on two), so no switch is read from the
+ * environment at launch time.  The table is filled once, on first use, from the
+ * environment variables RVS_<NAME in upper case>; afterwards only rvs_option_set
+ * changes it, and a change takes effect at the next call that looks.  Every
+ * setting gives the same results (to the bit, or -- xc_ws -- to a few ulp); the
+ * switches exist so that tests can hold one kernel path against another.
+ *   "xc_ws"          1  rvs_ccf_xcorr: the wave-specialised persistent kernels
+ *                       where they apply; 0 = one block per (spectrum, template)
+ *   "xc_ws1"         0  nfft 4096: 1 = one template per iteration (not two)
+ *   "nm_glue"        1  rvs_nm_run: a round as three bookkeeping kernels; 0 = the
+ *                       chain of stand-alone kernels (rvs_nm_begin / _decide / ...)
+ *   "nm_bucket"      0  rvs_nm_run: launch bounds rounded up to buckets
+ *   "obj_inblk_max" 256 objective launches of <= this many blocks search their grid
+ *                       cell inside the block (0 = never)
+ *   "obj_sort"       1  objective jobs evaluated in grid-cell order
+ * Both return 0, or RVS_E_ARG for an unknown name / NULL value pointer.
+ * ---------------------------------------------------------------------- */
+int rvs_option_set(const char *name, int value);
+int rvs_option_get(const char *name, int *value);
 
 /* ------------------------------------------------------------------------
  * A3  polylinear template evaluation on a regular n-D grid
@@ -216,7 +241,9 @@ int rvs_chisq_grid(const double *lam, const double *polysT, const double *work,
  * tests/test_sdss.py).  lam [G, npix]: grid g in row g, a grid with fewer than
  * npix pixels padded by repeating its last wavelength; grid_id int32 [S]: the grid
  * of spectrum s; on the padding the spectra carry espec = +inf (weight 0, no term
- * in sum log e) and the basis rows are 0; polysT of grid g starts at
+ * in sum log e -- read as the marker ONLY when G > 1: on a single grid an infinite
+ * error is data and gives the reference's log(inf), a non-finite likelihood the
+ * status word reports) and the basis rows are 0; polysT of grid g starts at
  * polysT + g * polys_stride.  work: rvs_chisq_work_size_g(npix, S, G) doubles from
  * rvs_chisq_prepare_g.  G = 1 (grid_id NULL) is the shared-grid call.  With G > 1
  * the left-over velocities of a job are not packed with those of other jobs.
@@ -478,7 +505,8 @@ void rvs_bfgs_end(void *h);
  * pixel count on are 0); ortho (nullable) the same function space orthonormalised
  * over the grid's pixels (modified Gram-Schmidt, twice) with logdet[g] =
  * 2 sum log R_jj, what the velocity-grid kernel reads (see rvs_chisq_grid).
- * lam [G, npix]; npix_g int32 [G] or NULL (every grid has npix pixels). */
+ * lam [G, npix]; npix_g int32 [G] or NULL (every grid has npix pixels).
+ * Limits: npoly <= 32 (what rvs_chisq_full takes), npix <= 16384; RVS_E_ARG beyond. */
 int rvs_basis_build(const double *lam, const int32_t *npix_g, int G, int npix,
                     int npoly, int rbf, const double *cen, double *raw,
                     double *ortho, double *logdet, void *stream);
@@ -580,7 +608,7 @@ int rvs_ccf_preprocess_g(const double *lam, const double *spec, const double *es
  * continuum mode at nfft 8192 (with `prune`) and 4096, nlag and nvel <= 512, T >= 2,
  * one persistent wave-specialised block per spectrum walks the T templates
  * (ccf_xcorr_ws_kernel / _ws2_kernel, csrc/ccf_fft.hip); otherwise one block per
- * (spectrum, template).  Environment RVS_XC_WS=0 forces the latter.
+ * (spectrum, template).  rvs_option_set("xc_ws", 0) forces the latter.
  * ---------------------------------------------------------------------- */
 int rvs_ccf_fft_pos(int nfft, int f);  /* host helper, see lag_pos */
 int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar, int nfft,

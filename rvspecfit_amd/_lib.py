@@ -21,6 +21,8 @@ U = ctypes.c_uint32
 # name -> (restype, argtypes); mirrors include/rvsgpu.h declaration by declaration
 SIGNATURES = {
     'rvs_abi_version': (I, []),
+    'rvs_option_set': (I, [ctypes.c_char_p, I]),
+    'rvs_option_get': (I, [ctypes.c_char_p, P]),
     'rvs_template_polylinear': (I, [P, L, I, P, P, P, I, P, P, U, I, P, I, P, P,
                                     P, P, P]),
     'rvs_template_tri': (I, [P, I, P, P, P, I, I, U, I, P, I, P, P, P, P, P]),
@@ -91,7 +93,7 @@ SIGNATURES = {
 
 _lib = None
 # RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class RvsGpuError(RuntimeError):
@@ -119,6 +121,30 @@ def lib():
                                                    ABI_VERSION))
         _lib = L_
     return _lib
+
+
+def set_option(name, value):
+    """rvs_option_set; returns the previous value"""
+    old = ctypes.c_int(0)
+    check(lib().rvs_option_get(name.encode(), ctypes.byref(old)), 'rvs_option_get')
+    check(lib().rvs_option_set(name.encode(), int(value)), 'rvs_option_set')
+    return old.value
+
+
+class option:
+    """`with _lib.option('xc_ws', 0): ...` -- a switch for the duration of a block
+    (tests holding one kernel path against another)"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 class NmState(ctypes.Structure):

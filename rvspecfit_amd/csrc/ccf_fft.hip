@@ -1156,9 +1156,9 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
   const int G = xc_group(T, nfft);
   {
     // the wave-specialised persistent form (one block per spectrum), where it applies
-    const char *ev = getenv("RVS_XC_WS");   // RVS_XC_WS=0: the per-pair kernel
+    const bool ws_on = rvs_opt(RVS_OPT_XC_WS) != 0;   // xc_ws = 0: the per-pair kernel
     const bool p12 = (nfft == 8192 && prune), p11 = (nfft == 4096);
-    if (!(ev && ev[0] == '0') && continuum && (p12 || p11) &&
+    if (ws_on && continuum && (p12 || p11) &&
         nlag <= XW_HALF && nvel <= XW_HALF && T >= 2) {
       static bool ws_attr = false;
       if (!ws_attr) {
@@ -1182,8 +1182,8 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
                            reinterpret_cast<const double2 *>(tfft),
                            reinterpret_cast<const double2 *>(tfft2), T, tw, lag_pos,
                            lag_vel, nlag, ilo, vgrid, nvel, beta, prune, chisq);
-      else if (getenv("RVS_XC_WS1"))   // (one template per iteration: measured 1.10 ms
-                                       // per 1000 spectra against 0.84; per pair 1.34)
+      else if (rvs_opt(RVS_OPT_XC_WS1))   // (one template per iteration: measured 1.10
+                                          // ms per 1000 spectra against 0.84; per pair 1.34)
         hipLaunchKernelGGL(ccf_xcorr_ws_kernel<11>, dim3(B), dim3(XW_NT), shmw, st,
                            reinterpret_cast<const double2 *>(work),
                            reinterpret_cast<const double2 *>(tfft),

@@ -68,7 +68,11 @@ __global__ void __launch_bounds__(256)
   const double sys2 = espec_sys * espec_sys;
   for (int k = threadIdx.x; k < npix; k += 256) {
     double e = espec[(int64_t)s * npix + k];
-    if (isinf(e)) {   // padding of a short grid: no weight, no term in sum log e
+    // padding of a short grid (grid sets only): no weight, no term in sum log e.
+    // On a single grid an infinite error keeps the reference's arithmetic --
+    // log(inf) in the likelihood, a non-finite value the caller is told about
+    // (spec_fit.py:963-974)
+    if (G > 1 && isinf(e)) {
       W[(int64_t)s * npix + k] = make_double2(0.0, 0.0);
       X[(int64_t)s * npix + k] = make_double2(0.0, 0.0);
       continue;
@@ -1392,7 +1396,7 @@ __global__ void __launch_bounds__(256)
     }
     if (raw_model) raw_model[(int64_t)j * npix + k] = tv;
     double e = es[k];
-    if (isinf(e)) {   // padding of a short grid (rvs_chisq_prepare_g)
+    if (GS.G > 1 && isinf(e)) {   // padding of a short grid (rvs_chisq_prepare_g)
       tvs[k] = 0.0;
       Ds[k] = 0.0;
       continue;
@@ -1497,7 +1501,7 @@ __global__ void __launch_bounds__(256)
     // model in flux units: coeffs . (polys * templ); true chi^2 uses the
     // ORIGINAL error vector (spec_fit.py:952)
     double e = es[k];
-    if (isinf(e)) {
+    if (GS.G > 1 && isinf(e)) {
       if (model) model[(int64_t)j * npix + k] = 0.0;
       continue;
     }
@@ -1638,7 +1642,7 @@ __global__ void __launch_bounds__(64)
     const double ie = 1.0 / e;   // (0 on the padding of a short grid)
     const double tv = ut ? ut[k] : 1.0;
     const double w = (tv * ie) * (tv * ie), u = (tv * ie) * (x * ie);
-    lz += isinf(e) ? 0.0 : log(e);
+    lz += (GS.G > 1 && isinf(e)) ? 0.0 : log(e);
     dd = fma(x * ie, x * ie, dd);
     const double *pr = polysT + (int64_t)k * P;
     double prow[P], pw[P];

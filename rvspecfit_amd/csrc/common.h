@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/rvsgpu.h"
+#include "options.h"
 
 #define RVS_C_KMS 299792.458  // spec_fit.py:23
 

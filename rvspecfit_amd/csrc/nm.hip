@@ -927,11 +927,10 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
                           int sync_every, int64_t *stats, void *stream) {
   if (!m || !o || m->S < 1 || m->N < 1 || m->N > NM_MAXN || sync_every < 1)
     return RVS_E_ARG;
-  // RVS_NM_GLUE=0: the round as a chain of the stand-alone kernels (a test hook:
+  // nm_glue = 0: the round as a chain of the stand-alone kernels (a test hook:
   // tests/test_gpu_parity.py::test_nm_round_kernels_equal_chain)
-  if (const char *ev = getenv("RVS_NM_GLUE"))
-    if (ev[0] == '0')
-      return nm_run_chain(m, o, xatol, fatol, maxiter, sync_every, stats, stream);
+  if (!rvs_opt(RVS_OPT_NM_GLUE))
+    return nm_run_chain(m, o, xatol, fatol, maxiter, sync_every, stats, stream);
   hipStream_t st = rvs_stream(stream);
   const int S = m->S, N = m->N;
   int64_t rounds = 0, calls = 0, jobs = 0;
@@ -1046,7 +1045,7 @@ static int nm_run_chain(const rvs_nm_state *m, const rvs_nm_objective *o,
     if (live == 0) break;
     // the live count only falls between two looks (finished and parked
     // simplices leave the list), so it bounds the launches of the window
-    const int jb = getenv("RVS_NM_BUCKET") ? nm_bucket(live, S) : live;
+    const int jb = rvs_opt(RVS_OPT_NM_BUCKET) ? nm_bucket(live, S) : live;
     for (int r = 0; r < sync_every; r++) {
       rc = rvs_nm_begin(S, N, xatol, fatol, maxiter, m->sim, m->fsim, m->nit,
                         m->flags, m->list1, m->X1, m->counts, jb, st);

@@ -1202,20 +1202,15 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     // a launch that fits the chip in one go (<= 256 blocks): the cell search inside
     // the block -- the same device function, so the same values -- and one launch
     // less per evaluation in the optimiser's latency-bound last rounds (+1 % at 2000
-    // spectra; RVS_OBJ_INBLK_MAX overrides the bound, 0 = never)
-    {
-      int inblk_max = 256;
-      if (const char *ev = getenv("RVS_OBJ_INBLK_MAX")) inblk_max = atoi(ev);
-      if ((int64_t)J * narm <= inblk_max) pre = false;
-    }
+    // spectra; option obj_inblk_max overrides the bound, 0 = never)
+    if ((int64_t)J * narm <= rvs_opt(RVS_OPT_OBJ_INBLK_MAX)) pre = false;
     if (pre) {
       hipLaunchKernelGGL(objective_locate_kernel, grid, dim3(OBJ_LOC_NT), 0, st, A,
                          params, J, live, locbuf);
       loc = locbuf;
-      // from a few blocks per CU up: jobs in cell order (RVS_OBJ_SORT=0: a test
+      // from a few blocks per CU up: jobs in cell order (obj_sort = 0: a test
       // hook, tests/test_gpu_parity.py::test_objective_job_order)
-      const char *ev = getenv("RVS_OBJ_SORT");
-      if (J >= OBJ_SORT_MIN_JOBS && !(ev && ev[0] == '0')) {
+      if (J >= OBJ_SORT_MIN_JOBS && rvs_opt(RVS_OPT_OBJ_SORT)) {
         int shift = 0;
         while (((arms[0].ngrid - 1) >> shift) >= OBJ_ORD_NB) shift++;
         const int nb = (int)((arms[0].ngrid - 1) >> shift) + 1;
@@ -1229,8 +1224,10 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
   // tools/perf/experiments/objective_pipe.hip (obj_bench only): the persistent
   // producer/consumer kernel where it applies; RVS_OBJ_PIPE=0 keeps this file's
   {
-    const char *ev = getenv("RVS_OBJ_PIPE");   // (read per call: tests flip it)
-    const bool use_pipe = !(ev && ev[0] == '0');
+    static const bool use_pipe = [] {   // (obj_bench only: read once)
+      const char *ev = getenv("RVS_OBJ_PIPE");
+      return !(ev && ev[0] == '0');
+    }();
     if (use_pipe && (tt || loc)) {
       const int prc = objective_pipe_launch(A, tt ? &TT : nullptr, npoly, loc, vsini,
                                             job_spec, J, vel, shm / (3 * sizeof(double)),

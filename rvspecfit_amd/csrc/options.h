@@ -1,0 +1,16 @@
+// The behaviour switches of librvsgpu (options.cpp; include/rvsgpu.h documents
+// them under rvs_option_set).
+#pragma once
+#include "../../include/rvsgpu.h"
+
+enum {
+  RVS_OPT_XC_WS,          // wave-specialised cross-correlation where it applies
+  RVS_OPT_XC_WS1,         // nfft 4096: one template per iteration instead of two
+  RVS_OPT_NM_GLUE,        // optimiser rounds as three bookkeeping kernels
+  RVS_OPT_NM_BUCKET,      // launch bounds rounded to buckets (measurement hook)
+  RVS_OPT_OBJ_INBLK_MAX,  // launches of <= this many blocks search their cell in-block
+  RVS_OPT_OBJ_SORT,       // objective jobs in grid-cell order
+  RVS_OPT_COUNT
+};
+// current value (the table is filled from the environment on first use)
+int rvs_opt(int id);

@@ -54,8 +54,10 @@ __device__ __forceinline__ int tb_search(const double *a, int n, double v,
 // grid), and its orthonormal form Q (P^T = Q R over the grid's own pixels) with
 // 2 sum log |R_jj|.
 // ---------------------------------------------------------------------------
-#define TB_MAXP 16
-#define TB_PPT 32   // pixels per thread: npix <= 8192
+#define TB_MAXP 32  // = FULL_MAXP of chisq.hip: the widest basis any kernel takes
+// TB_PPT pixels per thread live in registers across a column's projections:
+// 32 (npix <= 8192: every survey arm) or 64 (npix <= 16384)
+template <int TB_PPT>
 __global__ void __launch_bounds__(TB_NT)
     basis_build_kernel(const double *__restrict__ lam,
                        const int32_t *__restrict__ npix_g, int npix_s, int P,
@@ -159,11 +161,17 @@ extern "C" int rvs_basis_build(const double *lam, const int32_t *npix_g, int G,
                                int npix, int npoly, int rbf, const double *cen,
                                double *raw, double *ortho, double *logdet,
                                void *stream) {
-  if (G < 1 || npix < 2 || npix > TB_NT * TB_PPT || npoly < 1 || npoly > TB_MAXP ||
+  if (G < 1 || npix < 2 || npix > TB_NT * 64 || npoly < 1 || npoly > TB_MAXP ||
       !lam || !raw || (ortho && !logdet) || (rbf && npoly > 3 && !cen))
     return RVS_E_ARG;
-  hipLaunchKernelGGL(basis_build_kernel, dim3(G), dim3(TB_NT), 0, rvs_stream(stream),
-                     lam, npix_g, npix, npoly, rbf, cen, raw, ortho, logdet);
+  if (npix <= TB_NT * 32)
+    hipLaunchKernelGGL(basis_build_kernel<32>, dim3(G), dim3(TB_NT), 0,
+                       rvs_stream(stream), lam, npix_g, npix, npoly, rbf, cen, raw,
+                       ortho, logdet);
+  else
+    hipLaunchKernelGGL(basis_build_kernel<64>, dim3(G), dim3(TB_NT), 0,
+                       rvs_stream(stream), lam, npix_g, npix, npoly, rbf, cen, raw,
+                       ortho, logdet);
   RVS_LAUNCH_CHECK();
   return 0;
 }

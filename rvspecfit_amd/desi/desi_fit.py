@@ -1128,9 +1128,11 @@ def _group_fit(state, config, kwargs):
                          max_batch=kwargs.get('max_batch', 4096))
 
 
-def _group_write(state, res):
+def _group_write(state, res, errors=None):
     """hand every file of a fitted group its results: the generators assemble and
-    write the products (host work only)"""
+    write the products (host work only).  With `errors` (a dict) a file whose
+    generator raises does not stop the others: its exception is recorded under
+    its index and its return value stays None"""
     gens, rets = state
     for (i, g, _), r in zip(gens, res):
         try:
@@ -1138,6 +1140,10 @@ def _group_write(state, res):
             raise RuntimeError('proc_desi generator did not finish')
         except StopIteration as e:
             rets[i] = e.value
+        except Exception as e:  # noqa: BLE001 -- reported per file
+            if errors is None:
+                raise
+            errors[i] = e
     return rets
 
 
@@ -1314,25 +1320,41 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
     wpool = concurrent.futures.ThreadPoolExecutor(1)
     writing = []    # [(group, start time, future of _group_write)]
 
+    def timed_write(state, res):
+        """_group_write on the writer thread: (return values, {file index:
+        exception}, seconds spent writing -- not waiting in the queue)"""
+        t0 = time.time()
+        errors = {}
+        rets = _group_write(state, res, errors)
+        return rets, errors, time.time() - t0
+
     def collect_written(block=False):
-        """groups whose products are written: status lines; a failed group is
-        redone file by file"""
+        """groups whose products are written: status lines.  Only the files whose
+        assembly / write raised are redone (file by file); the time recorded per
+        file is the group's fit plus its write, not its wait for the writer"""
         while writing and (block or writing[0][2].done()):
-            group, t1, wf = writing.pop(0)
+            group, t_fit, wf = writing.pop(0)
             try:
-                rets = wf.result()
+                rets, errors, t_write = wf.result()
             except Exception:  # noqa: BLE001 -- retried per file
                 logging.exception('writing a group of %d files failed; retrying '
                                   'one by one' % len(group))
                 one_by_one(group)
                 continue
+            for i in sorted(errors):
+                logging.error('writing the products of %s failed (%r); redoing '
+                              'that file', group[i][0], errors[i])
             if process_status_file is not None:
-                dt = (time.time() - t1) / len(group)
-                for (f, _, _), n in zip(group, rets):
+                dt = (t_fit + t_write) / len(group)
+                for i, ((f, _, _), n) in enumerate(zip(group, rets)):
+                    if i in errors:
+                        continue
                     update_process_status_file(
                         process_status_file, f,
-                        ProcessStatus.SUCCESS if n >= 0 else ProcessStatus.FAILURE,
-                        max(n, 0), dt)
+                        ProcessStatus.SUCCESS if n is not None and n >= 0
+                        else ProcessStatus.FAILURE, max(n or 0, 0), dt)
+            if errors:
+                one_by_one([group[i] for i in sorted(errors)])
 
     def finish_oldest():
         group, fut = inflight.pop(0)
@@ -1356,7 +1378,8 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
                               % len(group))
             one_by_one(group)
             return
-        writing.append((group, t1, wpool.submit(_group_write, state, res)))
+        writing.append((group, time.time() - t1,
+                        wpool.submit(timed_write, state, res)))
         collect_written()
 
     def flush():
@@ -1386,25 +1409,34 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
         return tuple('%s%s_%s' % (folder, pre, base)
                      for pre in (output_tab_prefix, output_mod_prefix))
 
-    for f in list(files)[rank::world]:
-        names = product_names(f)
-        if names is None:
-            logging.warning('Invalid file %s: with subdirs it has to be '
-                            'dir1/dir2/fname', f)
-            continue
-        if skipexisting and all(os.path.exists(n) for n in names):
-            logging.info('skipping, products already exist %s', f)
-            if process_status_file is not None:
-                update_process_status_file(process_status_file, f,
-                                           ProcessStatus.EXISTING, -1, 0)
-            continue
-        pending.append((f, ) + names)
-        if len(pending) >= max(1, files_per_batch):
-            flush()
-    flush()
-    while inflight:
-        finish_oldest()
-    collect_written(block=True)
-    pool.shutdown()
-    wpool.shutdown()
+    try:
+        for f in list(files)[rank::world]:
+            names = product_names(f)
+            if names is None:
+                logging.warning('Invalid file %s: with subdirs it has to be '
+                                'dir1/dir2/fname', f)
+                continue
+            if skipexisting and all(os.path.exists(n) for n in names):
+                logging.info('skipping, products already exist %s', f)
+                if process_status_file is not None:
+                    update_process_status_file(process_status_file, f,
+                                               ProcessStatus.EXISTING, -1, 0)
+                continue
+            pending.append((f, ) + names)
+            if len(pending) >= max(1, files_per_batch):
+                flush()
+        flush()
+        while inflight:
+            finish_oldest()
+    finally:
+        # also on the way out of an exception (throw_exceptions): the groups already
+        # handed to the writer get their products and status lines, and both
+        # worker threads end
+        try:
+            collect_written(block=True)
+        finally:
+            for _, fut in inflight:
+                fut.cancel()
+            pool.shutdown()
+            wpool.shutdown()
     logging.info('Successfully finished processing')

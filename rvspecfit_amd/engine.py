@@ -245,31 +245,40 @@ class ArmData:
             self._npix_g_t = torch.as_tensor(self.npix_g).to(self.device)
         return self._npix_g_t
 
-    def _build_basis(self, npoly, rbf):
-        """raw and orthonormal basis of every grid (rvs_basis_build), cached"""
+    def _build_basis(self, npoly, rbf, ortho=True):
+        """raw (and, with `ortho`, orthonormal) basis of every grid
+        (rvs_basis_build), cached.  Returns (raw, Q^T, log-volume) or (raw,)."""
         key = ('dev', npoly, bool(rbf))
-        if key not in self._basis:
-            G, npx = self.G, self.npix
-            f64 = dict(dtype=torch.float64, device=self.device)
-            raw = torch.empty((G, npx + 1, npoly), **f64)
-            qt = torch.empty((G, npx + 1, npoly), **f64)
-            ld = torch.empty(G, **f64)
-            cen = torch.as_tensor(np.linspace(-1, 1, max(npoly - 3, 1), True)).to(
-                self.device)
-            rc = _lib.lib().rvs_basis_build(
-                _lib.ptr(self.lam), _lib.ptr(self._npix_g_dev()), G, npx, npoly,
-                int(bool(rbf)), _lib.ptr(cen), _lib.ptr(raw), _lib.ptr(qt),
-                _lib.ptr(ld), _lib.stream())
-            _lib.check(rc, 'rvs_basis_build')
+        if key in self._basis:
+            return self._basis[key]
+        rkey = ('devraw', npoly, bool(rbf))
+        if not ortho and rkey in self._basis:
+            return self._basis[rkey]
+        G, npx = self.G, self.npix
+        f64 = dict(dtype=torch.float64, device=self.device)
+        raw = torch.empty((G, npx + 1, npoly), **f64)
+        qt = torch.empty((G, npx + 1, npoly), **f64) if ortho else None
+        ld = torch.empty(G, **f64) if ortho else None
+        cen = torch.as_tensor(np.linspace(-1, 1, max(npoly - 3, 1), True)).to(
+            self.device)
+        rc = _lib.lib().rvs_basis_build(
+            _lib.ptr(self.lam), _lib.ptr(self._npix_g_dev()), G, npx, npoly,
+            int(bool(rbf)), _lib.ptr(cen), _lib.ptr(raw), _lib.ptr(qt),
+            _lib.ptr(ld), _lib.stream())
+        _lib.check(rc, 'rvs_basis_build')
+        if ortho:
             self._basis[key] = (raw, qt, ld)
-        return self._basis[key]
+            self._basis.pop(rkey, None)
+            return self._basis[key]
+        self._basis[rkey] = (raw, )
+        return self._basis[rkey]
 
     def basis(self, npoly, rbf):
         """pixel-major continuum basis get_poly_basis(lam).T (+ one zero row) of
         every grid: [npix + 1, npoly], or [G, npix + 1, npoly] (rows behind a
         grid's last pixel are zero)"""
         if DEVICE_TABLES:
-            raw = self._build_basis(npoly, rbf)[0]
+            raw = self._build_basis(npoly, rbf, ortho=False)[0]
             return raw[0] if self.G == 1 else raw
         key = (npoly, bool(rbf))
         if key not in self._basis:

@@ -62,6 +62,44 @@ def test_argument_validation_without_gpu(lib):
                                  k3.ctypes.data, None) == -3  # evaler's -2
 
 
+def test_option_table(lib):
+    """rvs_option_set / _get: a host-side table (no GPU needed), unknown names are
+    argument errors, `with _lib.option(...)` restores the previous value; the
+    table is filled from the environment ONCE -- a later setenv changes nothing"""
+    import ctypes
+    from rvspecfit_amd import _lib
+    v = ctypes.c_int(-1)
+    assert lib.rvs_option_get(b'obj_inblk_max', ctypes.byref(v)) == 0
+    assert v.value == int(os.environ.get('RVS_OBJ_INBLK_MAX', 256))
+    for name in ('xc_ws', 'xc_ws1', 'nm_glue', 'nm_bucket', 'obj_sort'):
+        assert lib.rvs_option_get(name.encode(), ctypes.byref(v)) == 0
+    assert lib.rvs_option_get(b'no_such_switch', ctypes.byref(v)) == -1
+    assert lib.rvs_option_set(b'no_such_switch', 1) == -1
+    assert lib.rvs_option_get(b'xc_ws', None) == -1
+    before = _lib.set_option('obj_sort', 1)
+    with _lib.option('obj_sort', 0):
+        lib.rvs_option_get(b'obj_sort', ctypes.byref(v))
+        assert v.value == 0
+        os.environ['RVS_OBJ_SORT'] = '1'      # read once: no effect any more
+        lib.rvs_option_get(b'obj_sort', ctypes.byref(v))
+        assert v.value == 0
+        del os.environ['RVS_OBJ_SORT']
+    lib.rvs_option_get(b'obj_sort', ctypes.byref(v))
+    assert v.value == 1
+    _lib.set_option('obj_sort', before)
+
+
+def test_basis_build_limits(lib):
+    """rvs_basis_build takes what rvs_chisq_full takes (npoly <= 32) and arms of up
+    to 16384 pixels; beyond that an argument error, before any launch"""
+    one = np.ones(4)
+    p = one.ctypes.data
+    assert lib.rvs_basis_build(p, None, 1, 16385, 10, 1, p, p, None, None, None) == -1
+    assert lib.rvs_basis_build(p, None, 1, 100, 33, 1, p, p, None, None, None) == -1
+    assert lib.rvs_basis_build(p, None, 1, 100, 0, 1, p, p, None, None, None) == -1
+    assert lib.rvs_basis_build(p, None, 1, 100, 10, 1, p, p, p, None, None) == -1
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

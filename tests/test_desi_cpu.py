@@ -336,6 +336,68 @@ def test_proc_many_status_file(tmp_path):
     assert len(rows) == 1 and rows[0].split()[1] == 'EXISTING'
 
 
+def test_proc_many_writer_pipeline_drains_and_redoes_only_failed_files(
+        tmp_path, monkeypatch):
+    """proc_many's prepare / fit / write pipeline with the GPU part replaced: a file
+    whose product assembly raises is redone ALONE (the others of its group keep
+    their products and status lines), and an exception that leaves the file loop
+    (throw_exceptions) still lets the groups already handed to the writer finish
+    and ends both worker threads"""
+    import threading
+    import yaml
+    cfgf = str(tmp_path / 'c.yaml')
+    with open(cfgf, 'w') as fp:
+        yaml.safe_dump(dict(template_lib='golden-desi://'), fp)
+    files = [str(tmp_path / ('f%d.fits' % i)) for i in range(7)]
+    written, redone = [], []
+
+    def steps(fname, tab, mod, fig, config, **kw):
+        res = yield ('request', fname)
+        if fname.endswith('f2.fits'):
+            raise IOError('disk full')
+        written.append((fname, res))
+        return 3
+
+    def fit(state, config, kw):
+        if any(r[1].endswith('f5.fits') for _, _, r in state[0]):
+            raise RuntimeError('fit blew up')
+        return ['fit:' + r[1] for _, _, r in state[0]]
+
+    def wrapper(f, t, m, fig, config, process_status_file=None,
+                throw_exceptions=None, **kw):
+        redone.append(f)
+        if throw_exceptions:
+            raise RuntimeError('escapes the file loop')
+
+    monkeypatch.setattr(D, '_proc_desi_steps', steps)
+    monkeypatch.setattr(D, '_group_fit', fit)
+    monkeypatch.setattr(D, 'proc_desi_wrapper', wrapper)
+    st = str(tmp_path / 'status')
+    kw = dict(config_fname=cfgf, doplot=False, subdirs=False, shard=(0, 1),
+              files_per_batch=2)
+    n0 = threading.active_count()
+    D.proc_many(files[:4], str(tmp_path), 'rvtab', 'rvmod',
+                process_status_file=st, **kw)
+    assert redone == [files[2]]                      # only the file that failed
+    assert [w[0] for w in written] == [files[0], files[1], files[3]]
+    assert all(w[1] == 'fit:' + w[0] for w in written)
+    rows = [l.split() for l in open(st).read().strip().split('\n')]
+    assert [r[0] for r in rows if r[1] == 'SUCCESS'] == [files[0], files[1],
+                                                         files[3]]
+    assert threading.active_count() == n0            # both pools shut down
+    # groups (0,1) (2,3) (4,5) (6): the fit of (4,5) raises, its one-by-one retry
+    # raises out of proc_many -- (0,1) and (2,3) were handed to the writer before
+    del written[:], redone[:]
+    with pytest.raises(RuntimeError, match='escapes'):
+        D.proc_many(files, str(tmp_path), 'rvtab', 'rvmod', throw_exceptions=True,
+                    process_status_file=st + '2', **kw)
+    assert [w[0] for w in written] == [files[0], files[1], files[3]]
+    assert threading.active_count() == n0
+    rows = [l.split() for l in open(st + '2').read().strip().split('\n')]
+    assert [r[0] for r in rows if r[1] == 'SUCCESS'] == [files[0], files[1],
+                                                         files[3]]
+
+
 def test_proc_many_device_selection(tmp_path, monkeypatch):
     """one process per GPU: the fitting process takes the GPU LOCAL_RANK names
     whatever its file shard is -- the worker processes of `nthreads` run with

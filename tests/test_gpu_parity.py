@@ -13,6 +13,7 @@ import torch
 from conftest import GOLD, GOLD_CONFIG, gold_specdata, gold_lib_dict
 from oracle import rvs_oracle as orc
 from test_numpy_expf import host_numpy_expf_is_published_algorithm
+from rvspecfit_amd import _lib
 
 pytestmark = pytest.mark.gpu
 # (False only on a host whose numpy float32 exp is not the AVX2 / AVX-512 one)
@@ -310,6 +311,50 @@ def test_chisq_continuum(cases, config, tag):
                                cases[tag + '/cont/chisq_array'], rtol=1e-8)
     np.testing.assert_allclose(r['redchisq_array'],
                                cases[tag + '/cont/redchisq_array'], rtol=1e-8)
+
+
+@pytest.mark.parametrize('npoly,rbf', [(17, True), (24, False), (32, True)])
+def test_npoly_above_16(cases, config, gold_config, gold_libs, npoly, rbf):
+    """npoly 17 ... 32: no velocity-grid kernel (16 is its widest basis), but
+    get_chisq(full_output), the point objective and get_chisq_continuum take them
+    (rvs_chisq_full, FULL_MAXP 32; the continuum through rvs_chisq_full's tiers)
+    and the basis tables for them are built on the device like any other"""
+    from rvspecfit_amd import spec_fit
+    tag = 'c1'
+    sds = _sds(cases, tag)
+    osds = gold_specdata(cases, tag, orc.SpecData)
+    opt = dict(npoly=npoly, rbf_continuum=rbf)
+    par = (5500., 3.0, -0.5, 0.2)
+    got = spec_fit.get_chisq(sds, 23.0, par, rot_params=(20., ), options=opt,
+                             config=config, full_output=True)
+    want = orc.get_chisq(osds, 23.0, par, rot_params=(20., ), options=opt,
+                         config=gold_config, libs=gold_libs, full_output=True)
+    npix = sum(len(_.lam) for _ in osds)   # (-2 log L passes near 0: scale by npix)
+    assert abs(got['chisq'] - want['chisq']) <= 1e-6 * max(abs(want['chisq']), npix)
+    np.testing.assert_allclose(got['chisq_array'], want['chisq_array'], rtol=1e-6)
+    for m, w in zip(got['models'], want['models']):
+        assert np.abs(m - w).max() <= 1e-6 * np.abs(w).max()
+    r = spec_fit.get_chisq_continuum(sds, options=opt)
+    w = orc.get_chisq_continuum(osds, options=opt)
+    np.testing.assert_allclose(r['chisq_array'], w['chisq_array'], rtol=1e-7)
+
+
+def test_infinite_error_on_a_single_grid_is_data(cases, config):
+    """espec = +inf marks the padding of a short grid in a grid set (G > 1) only.
+    On an ordinary arm it is data: the reference takes log(inf) into the
+    likelihood and raises (spec_fit.py:963-974)"""
+    from rvspecfit_amd import spec_fit
+    sds = _sds(cases, 'c1')
+    es = np.array(sds[0].espec)
+    es[100] = np.inf
+    bad = [spec_fit.SpecData(sds[0].name, sds[0].lam, sds[0].spec, es,
+                             badmask=sds[0].badmask)] + list(sds[1:])
+    par = (5500., 3.0, -0.5, 0.2)
+    with pytest.raises(RuntimeError):
+        spec_fit.get_chisq(bad, 23.0, par, options=dict(npoly=10), config=config)
+    with pytest.raises(RuntimeError):
+        spec_fit.get_chisq(bad, 23.0, par, options=dict(npoly=10), config=config,
+                           full_output=True)
 
 
 @pytest.mark.parametrize('variant', ['quantised', 'plateau', 'inf_errors',
@@ -1531,10 +1576,10 @@ def test_process_bfgs_implementations_agree(cases, config, monkeypatch):
     assert abs(np.mean(a['bfgs']['nfev']) / np.mean(b['bfgs']['nfev']) - 1) < 0.5
 
 
-def test_nm_round_kernels_equal_chain(cases, config, monkeypatch):
+def test_nm_round_kernels_equal_chain(cases, config):
     """rvs_nm_run's rounds -- three bookkeeping kernels that also sum the arms and
     map the next rows, the objective skipping the rows behind the device counts --
-    against the same rounds as a chain of the stand-alone kernels (RVS_NM_GLUE=0):
+    against the same rounds as a chain of the stand-alone kernels (option nm_glue = 0):
     every number of vel_fit.process bit for bit."""
     from rvspecfit_amd import vel_fit
     from rvspecfit_amd.engine import SpecBatch
@@ -1550,9 +1595,9 @@ def test_nm_round_kernels_equal_chain(cases, config, monkeypatch):
                vsini=rng.uniform(1, 60, S))
     out = {}
     for glue in ('1', '0'):
-        monkeypatch.setenv('RVS_NM_GLUE', glue)
-        out[glue] = vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
-                                    config=config)
+        with _lib.option('nm_glue', int(glue)):
+            out[glue] = vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                        config=config)
     a, b = out['1'], out['0']
     assert torch.equal(a['nm_nit'], b['nm_nit'])
     assert torch.equal(a['nm_nfev'], b['nm_nfev'])
@@ -1637,10 +1682,10 @@ def test_objective_fused(cases, config, tag):
                 assert abs(c1[k].item() - want) < 1e-6 * sc, (i, c1[k].item())
 
 
-def test_objective_job_order_and_device_count(cases, config, monkeypatch):
+def test_objective_job_order_and_device_count(cases, config):
     """700 jobs in one rvs_objective_fused launch: (i) from 512 jobs up the blocks
     take the jobs in the order of their grid cell (objective_order_kernel) -- which
-    block evaluates a job must not change a bit of its value (RVS_OBJ_SORT=0: the
+    block evaluates a job must not change a bit of its value (option obj_sort = 0: the
     plain order); (ii) with a job count on the device (rvs_objective_fused_n, what
     the lock-step optimiser passes) the first n jobs have the values of the full
     launch and the rows behind them are not written."""
@@ -1660,9 +1705,8 @@ def test_objective_job_order_and_device_count(cases, config, monkeypatch):
     kw = dict(npoly=10, rbf=True, job_spec=js)
     with np.errstate(all='ignore'):
         c1, s1 = engine.objective_fused(b, libs, par, vs, vel, **kw)
-        monkeypatch.setenv('RVS_OBJ_SORT', '0')
-        c0, s0 = engine.objective_fused(b, libs, par, vs, vel, **kw)
-        monkeypatch.delenv('RVS_OBJ_SORT')
+        with _lib.option('obj_sort', 0):
+            c0, s0 = engine.objective_fused(b, libs, par, vs, vel, **kw)
         assert torch.equal(c0, c1) and torch.equal(s0, s1)
         assert torch.isfinite(c1).all()
         for n in (0, 1, 299, 513, 700, 5000):
@@ -1911,31 +1955,31 @@ def test_xcorr_every_plan_vs_numpy(gpu, nfft, continuum):
     _xcorr_vs_numpy(nfft, continuum, 3, 5)
 
 
-def test_xcorr_large_template_set_job_map(gpu, monkeypatch):
+def test_xcorr_large_template_set_job_map(gpu):
     """a template set above 16 MB (T = 140 at nfft 8192) takes the XCD-aware,
     grouped (spectrum, template) order of ccf_xcorr_kernel (xc_job): every
     (b, t) row lands where the plain order puts it, padding blocks write
     nothing"""
-    monkeypatch.setenv('RVS_XC_WS', '0')   # (the per-pair kernel)
-    _xcorr_vs_numpy(8192, 1, 5, 140)
+    with _lib.option('xc_ws', 0):   # (the per-pair kernel)
+        _xcorr_vs_numpy(8192, 1, 5, 140)
 
 
 @pytest.mark.parametrize('nfft,B,T', [(8192, 3, 5), (8192, 5, 140), (8192, 2, 2),
                                       (8192, 1, 77), (4096, 2, 2), (4096, 3, 76),
                                       (4096, 1, 3), (4096, 2, 141)])
-def test_xcorr_wave_specialised_equals_per_pair(gpu, monkeypatch, nfft, B, T):
+def test_xcorr_wave_specialised_equals_per_pair(gpu, nfft, B, T):
     """ccf_xcorr_ws_kernel (one persistent block per spectrum: producer waves
     keep S*, V* in registers and stream the templates into one LDS image while
     consumer waves transform the other) against ccf_xcorr_kernel (one block per
-    (spectrum, template); RVS_XC_WS=0) and numpy, first call and accumulating
+    (spectrum, template); option xc_ws = 0) and numpy, first call and accumulating
     call, small and large template sets, odd and even T; at nfft 4096 the form that
     takes two templates per iteration.  Same formulas bin by bin and butterfly
     by butterfly; the two kernels are compiled separately, so which product of a
     complex multiplication the compiler fuses into an fma may differ: equal to a
     few ulp of the largest term, not bit for bit."""
     got_ws = _xcorr_vs_numpy(nfft, 1, B, T)
-    monkeypatch.setenv('RVS_XC_WS', '0')
-    got_pp = _xcorr_vs_numpy(nfft, 1, B, T)
+    with _lib.option('xc_ws', 0):
+        got_pp = _xcorr_vs_numpy(nfft, 1, B, T)
     np.testing.assert_allclose(got_ws, got_pp, rtol=1e-12,
                                atol=1e-12 * np.abs(got_pp).max())
 

@@ -39,12 +39,18 @@ GRIDS = {
                                          (800, 3042), (5, 3500))],
     'desi_b': lambda: [np.arange(3600., 5800.1, 0.8)],
     'short': lambda: [np.linspace(4000., 5000., 2001), np.linspace(4100., 4900., 700)],
+    # beyond the 8192 pixels one register set holds (64 pixels per thread)
+    'long': lambda: [np.linspace(3600., 9800., 9000)],
+    'long_set': lambda: [np.linspace(3600., 9800., 9300), np.linspace(3700., 9000., 8200)],
 }
 
 
 @pytest.mark.parametrize('name', list(GRIDS))
 @pytest.mark.parametrize('npoly,rbf', [(10, True), (15, True), (3, True), (2, True),
-                                       (7, False), (15, False), (1, False)])
+                                       (7, False), (15, False), (1, False),
+                                       # what rvs_chisq_full / _continuum take
+                                       # beyond the grid kernel's 16
+                                       (17, True), (24, False), (32, True)])
 def test_basis(name, npoly, rbf):
     grids = GRIDS[name]()
     rng = np.random.RandomState(2)
@@ -67,7 +73,7 @@ def test_basis(name, npoly, rbf):
         # orthonormal, the same space, the same volume
         Q, H = qd[i, :n], qh[i, :n]
         assert np.abs(Q.T @ Q - np.eye(npoly)).max() < 1e-13
-        assert np.abs(H @ (H.T @ Q) - Q).max() < 1e-10
+        assert np.abs(H @ (H.T @ Q) - Q).max() < (1e-10 if npoly <= 16 else 1e-8)
         assert abs(od[i] - oh[i]) <= 1e-10 * max(1.0, abs(oh[i]))
 
 
@@ -105,3 +111,16 @@ def test_ccf_tables(name, continuum):
         else:               # searches and IEEE arithmetic: the host's bits
             assert np.array_equal(a, b), (k, np.abs(a.astype(float) - b).max())
     assert td['nnode'] == th['nnode']
+
+
+def test_raw_basis_alone_skips_the_orthonormalisation():
+    """basis() asks rvs_basis_build for the raw table only (ortho = NULL); a later
+    basis_ortho() builds both and the raw table is the same bits"""
+    rng = np.random.RandomState(4)
+    a = _arm(GRIDS['desi_b'](), rng)
+    raw = a.basis(10, True).clone()
+    assert ('devraw', 10, True) in a._basis and ('dev', 10, True) not in a._basis
+    qt, off = a.basis_ortho(10, True)
+    assert ('dev', 10, True) in a._basis and ('devraw', 10, True) not in a._basis
+    assert torch.equal(a.basis(10, True), raw)
+    assert np.isfinite(off) and qt.shape == raw.shape

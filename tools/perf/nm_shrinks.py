@@ -9,7 +9,8 @@ sys.argv = [sys.argv[0], S]
 src = open('tools/perf/proc_time.py').read().replace('for it in range(2):', 'for it in range(1):')
 out = {}
 for glue in ('1', '0'):
-    os.environ['RVS_NM_GLUE'] = glue
+    from rvspecfit_amd import _lib
+    _lib.set_option('nm_glue', int(glue))
     g = {}
     exec(compile(src, 'p', 'exec'), g)
     out[glue] = g['r']

@@ -828,6 +828,11 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
     return out, status
 
 
+# widest basis of rvs_chisq_point / rvs_chisq_grid (one lane keeps the packed
+# normal matrix); rvs_chisq_full takes 32
+POINT_MAXP = 16
+
+
 def _per_arm(v, n):
     """scalar or per-arm sequence -> list of n floats"""
     if isinstance(v, (list, tuple)):
@@ -841,12 +846,33 @@ def chisq_point(batch, libs, coefs, outsides, vel, npoly=5, rbf=True,
                 outside_penalty=True, resols=None, fast_interp=False):
     """get_chisq for J (spectrum, template, velocity) triples, all arms in one
     launch set (rvs_chisq_point: lane per job, explicit residual norm).
-    vel [J]; returns chisq [J], status int32 [J]."""
+    vel [J]; returns chisq [J], status int32 [J].  npoly 17 ... 32 (beyond the
+    point kernel's 16 basis functions per lane): the arms' values from
+    rvs_chisq_full, summed with the same penalties (spec_fit.py:888-896)."""
     import ctypes
     L = _lib.lib()
     dev = batch.device
     vel = vel.to(device=dev, dtype=torch.float64).contiguous()
     J = vel.shape[0]
+    if npoly > POINT_MAXP:
+        full = chisq_full(batch, libs, coefs, vel, npoly=npoly, rbf=rbf,
+                          job_spec=job_spec, job_templ=job_templ,
+                          espec_sys=espec_sys, want_models=False, resols=resols,
+                          fast_interp=fast_interp)
+        badchi = batch.badchi_jobs(job_spec)
+        out = torch.zeros(J, dtype=torch.float64, device=dev)
+        status = torch.zeros(J, dtype=torch.int32, device=dev)
+        for f, o in zip(full, outsides):
+            if job_templ is not None:
+                o = o[job_templ.long()]
+            usable = torch.isfinite(o)
+            term = f['chisq'] + (o * badchi if outside_penalty else 0.0)
+            out += torch.where(usable, term, 1000.0 * badchi + torch.zeros_like(o))
+            status |= torch.where(usable, f['status'], torch.zeros_like(status))
+        bad = ~torch.isfinite(out)
+        status |= torch.where(bad, torch.full_like(status, _lib.ST_NONFINITE),
+                              torch.zeros_like(status))
+        return out, status
     narm = len(batch.arms)
     out = torch.empty(J, dtype=torch.float64, device=dev)
     status = torch.zeros(J, dtype=torch.int32, device=dev)

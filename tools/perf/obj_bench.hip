@@ -199,11 +199,13 @@ int main(int argc, char **argv) {
   std::vector<double> out0(J);
   float best0 = 1e30f;
   const bool skip_ref = getenv("OBJ_BENCH_SKIP_REF") != nullptr;   // (counter runs)
+  auto env_int = [](const char *n, int d) { return getenv(n) ? atoi(getenv(n)) : d; };
+  const int want_sort = env_int("OBJ_BENCH_SORT", 1);
   if (skip_ref) {
-    setenv("RVS_OBJ_SORT", getenv("OBJ_BENCH_SORT") ? getenv("OBJ_BENCH_SORT") : "1", 1);
+    rvs_option_set("obj_sort", want_sort);
   } else {
     setenv("RVS_OBJ_PIPE", "0", 1);
-    setenv("RVS_OBJ_SORT", "0", 1);   // first run: the caller's job order
+    rvs_option_set("obj_sort", 0);      // first run: the caller's job order
     for (int r = 0; r < reps + 1; r++) {
       hipEventRecord(e0);
       int rc0 = rvs_objective_fused(arms, NARM, P, d_params, vsmax > 0 ? d_vsini : nullptr,
@@ -220,7 +222,7 @@ int main(int argc, char **argv) {
     hipMemcpy(out0.data(), d_out, J * 8, hipMemcpyDeviceToHost);
     hipMemset(d_out, 0, J * 8);
     setenv("RVS_OBJ_PIPE", getenv("OBJ_BENCH_PIPE") ? getenv("OBJ_BENCH_PIPE") : "1", 1);
-    setenv("RVS_OBJ_SORT", getenv("OBJ_BENCH_SORT") ? getenv("OBJ_BENCH_SORT") : "1", 1);
+    rvs_option_set("obj_sort", want_sort);
   }
   float best = 1e30f, sum = 0;
   int rc = 0;
@@ -268,9 +270,10 @@ int main(int argc, char **argv) {
   printf("unsorted, per-block kernel: best %.3f ms (%.2f us per block-CU); max rel diff %.3g, NaN mismatches %d\n",
          best0, 1e3 * best0 * 256 / ((double)J * NARM), maxrel, nnan);
   const double nblk = (double)J * NARM;
-  printf("J %d grid %d,%d,%d,%d sorted %d vsini<=%g: best %.3f ms mean %.3f ms  "
+  printf("J %d grid %d,%d,%d,%d sorted %d sort %d vsini<=%g: best %.3f ms mean %.3f ms  "
          "%.2f us per block-CU  checksum %016llx  flagged %d  out[0..2] %.10g %.10g %.10g\n",
-         J, lens[0], lens[1], lens[2], lens[3], sorted, vsmax, best, sum / reps,
+         J, lens[0], lens[1], lens[2], lens[3], sorted, want_sort, vsmax,
+         best, sum / reps,
          1e3 * best * 256 / nblk, (unsigned long long)h, nbad, out[0], out[1], out[2]);
 #ifdef RVS_OBJ_TIMING
   {

@@ -91,6 +91,9 @@ int rvs_abi_version(void);
  *   "obj_inblk_max" 256 objective launches of <= this many blocks search their grid
  *                       cell inside the block (0 = never)
  *   "obj_sort"       1  objective jobs evaluated in grid-cell order
+ *   "nn_pipe"        1  rvs_template_nn(_arms): the wide last layer through the kernel
+ *                       whose epilogue runs under the next tile's products (K of 128,
+ *                       200 or 256 inputs); 0 = the generic kernel (same bits)
  * Both return 0, or RVS_E_ARG for an unknown name / NULL value pointer.
  * ---------------------------------------------------------------------- */
 int rvs_option_set(const char *name, int value);

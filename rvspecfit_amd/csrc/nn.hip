@@ -126,6 +126,44 @@ __device__ __forceinline__ double exp_clip300(double y) {
   return __hiloint2double(hi, __double2loint(p));
 }
 
+// The same for NE values side by side: every step of the 22-instruction chain is
+// issued for all of them before the next step, so that a dependent fp64 operation
+// finds its operand ready (written element by element the compiler reuses one
+// register set and the wave waits out the full latency 22 times per value: that,
+// not the stores, was two thirds of the wide layer's time, tools/perf/nn_variants.sh
+// -DNN_DBG_NOEPI).  Same operations per value: the same bits.
+template <int NE>
+__device__ __forceinline__ void exp_clip300_n(double (&y)[NE]) {
+  double n[NE], r[NE], p[NE];
+#pragma unroll
+  for (int i = 0; i < NE; i++) n[i] = rint(y[i] * 1.4426950408889634074);
+#pragma unroll
+  for (int i = 0; i < NE; i++) r[i] = fma(n[i], -6.93147180369123816490e-01, y[i]);
+#pragma unroll
+  for (int i = 0; i < NE; i++) r[i] = fma(n[i], -1.90821492927058770002e-10, r[i]);
+#pragma unroll
+  for (int i = 0; i < NE; i++) p[i] = fma(1.0 / 479001600.0, r[i], 1.0 / 39916800.0);
+#define NN_EXP_STEP(C)         \
+  _Pragma("unroll") for (int i = 0; i < NE; i++) p[i] = fma(p[i], r[i], C);
+  NN_EXP_STEP(1.0 / 3628800.0)
+  NN_EXP_STEP(1.0 / 362880.0)
+  NN_EXP_STEP(1.0 / 40320.0)
+  NN_EXP_STEP(1.0 / 5040.0)
+  NN_EXP_STEP(1.0 / 720.0)
+  NN_EXP_STEP(1.0 / 120.0)
+  NN_EXP_STEP(1.0 / 24.0)
+  NN_EXP_STEP(1.0 / 6.0)
+  NN_EXP_STEP(0.5)
+  NN_EXP_STEP(1.0)
+  NN_EXP_STEP(1.0)
+#undef NN_EXP_STEP
+#pragma unroll
+  for (int i = 0; i < NE; i++) {
+    const int hi = __double2hiint(p[i]) + ((int)n[i] << 20);
+    y[i] = __hiloint2double(hi, __double2loint(p[i]));
+  }
+}
+
 // Y = act(X W^T + b): X [Bn, K], W [N, K] (torch Linear.weight), row-major f32.
 // final_layer != 0: float64 exp(clip(y, +-300)) to yout64, else SiLU f32.
 // BIG = true:  block tile 128 x 128, waves 2 x 2 of 64 x 64 (the wide last layer);
@@ -289,6 +327,273 @@ __device__ __forceinline__ void
   }   // tiles
 }
 
+
+// ---------------------------------------------------------------------------
+// The wide last layer with its epilogue under the NEXT tile's matrix products
+// (round 5).  Same tile (128 x 128, waves 2 x 2 of 64 x 64), same staging and the
+// same MFMA order per output as nn_linear_body<true, true, true> -- the values
+// are its values bit for bit -- but a finished tile is PARKED in a second
+// accumulator set and its 64 float64 exps and 8-byte stores per lane are issued
+// four at a time at the top of the K slabs of the block's next tile.
+//   Why: gfx950 counts vector loads and stores in one counter (vmcnt) and a mix of
+// both pending is unordered for the compiler: a wave that needs the next slab's
+// operands waits for EVERY store it has issued.  With the whole epilogue behind a
+// tile's last slab that was 64 stores (131 KB per block) acknowledged by HBM
+// before the next tile could start: the waves 67 % of their cycles in s_waitcnt,
+// the matrix pipe 52 % busy (profiles/r04_d_nn_mfma_counters.json).  Now at most
+// eight stores are pending when a wave asks, issued a slab's worth of MFMAs
+// (~0.85 us) earlier.
+//   The slab loop is unrolled (NSLAB = ceil(K / 16) is a template argument: 13 for
+// the reference's 200 principal components), so which accumulator elements a slab
+// stores is known at compile time and the code of a tile is straight-line: no
+// branch between the exps and the MFMAs they hide under.  Stores are buffer stores
+// with the tile's rows as the buffer: the lane's part of the offset is one VGPR
+// for the whole kernel, the element's part a scalar, rows behind the matrix fall
+// out of the buffer's range, columns behind it get an offset that does (no bounds
+// branches, edge tiles take the same code).
+// ---------------------------------------------------------------------------
+template <int I0, int I1, class F>
+__device__ __forceinline__ void nn_static_for(F &&f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    nn_static_for<I0 + 1, I1>(f);
+  }
+}
+#ifndef NN_PIPE_EPI
+#define NN_PIPE_EPI 1   // 0: the wide last layer through nn_linear_kernel<true, ., true>
+#endif
+#ifndef NN_XCD_TILES
+#define NN_XCD_TILES 1   // wide last layer: an XCD owns every eighth row tile
+#endif
+#ifndef NN_ST_AUX
+#define NN_ST_AUX 0   // cache policy bits of the epilogue's buffer stores
+#endif
+template <int NSLAB>
+__device__ __forceinline__ void
+    nn_final_pipe_body(const float *__restrict__ X, const float *__restrict__ W,
+                       const float *__restrict__ bias, int Bn, int K, int N,
+                       double *__restrict__ yout64, const int bx, const int nbx) {
+  constexpr int BM = NN_BM, TI = 2, TJ = 2;
+  __shared__ __attribute__((aligned(16))) float lds[2][(BM + NN_BN) * NN_LDK];
+  typedef int v2i_t __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ntr = (Bn + BM - 1) / BM, ntc = (N + NN_BN - 1) / NN_BN;
+  // Which tiles this block walks.  Blocks are dealt to the 8 XCDs round robin, and an
+  // XCD's L2 (4 MB) is what serves a block's operand slabs: with the tiles walked in
+  // one global order every XCD touches all of X (8 MB at 10 000 rows) between two
+  // uses of a row tile, and the 497 MB of output stream through the same L2 -- the
+  // slabs then come from beyond it, 2-3 us away, one slab of MFMAs ahead is not
+  // enough cover and the waves wait.  XCD-aware (NN_XCD_TILES, from 16 row tiles and
+  // a grid that is a multiple of 8): XCD x owns the row tiles x, x + 8, ... (1 MB of
+  // X) and its blocks walk (column tile, own row tile) with the rows fastest, so
+  // what an XCD reads at any time is its rows of X and a few column tiles of W.
+  const bool xcd_tiles = NN_XCD_TILES && ntr >= 16 && (nbx & 7) == 0;
+  const int xq = bx & 7;
+  const int nrx = xcd_tiles ? (ntr - xq + 7) >> 3 : ntr;       // row tiles walked
+  const int tstep = xcd_tiles ? nbx >> 3 : nbx;
+  const int tend = nrx * ntc;
+  auto tile_rc = [&](int u, int &r0, int &c0) {
+    const int c = u / nrx, r = u - c * nrx;
+    r0 = (xcd_tiles ? xq + 8 * r : r) * BM;
+    c0 = c * NN_BN;
+  };
+  const int tfirst = xcd_tiles ? bx >> 3 : bx;
+  int row0, col0;
+  tile_rc(tfirst, row0, col0);
+  constexpr int QK = NN_BK / 4, RP = 256 / QK;
+  constexpr int PX = BM / RP, PW = NN_BN / RP;
+  const int sr = tid / QK, sq = (tid % QK) * 4;
+  auto gload = [&](const float *base, int nrows, int r, int k) -> f32x4 {
+    const float *p = base + (int64_t)min(r, nrows - 1) * K;
+    return *reinterpret_cast<const f32x4 *>(p + ((k + 3 < K) ? k : 0));
+  };
+  f32x4 gx[PX], gw[PW];
+  // Only a tile's LAST slab can reach behind K.  There the lanes whose quad lies
+  // behind it keep zeros and do not load (exec mask) -- a select on the loaded
+  // values, as nn_linear_body has it behind its slab's products, is hoisted by the
+  // scheduler of this straight-line code to right behind the loads, where the wave
+  // then waits out their whole latency in every slab.
+  auto fetch = [&](int k0, auto last_c) {
+    if constexpr (decltype(last_c)::value) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < PX; p++) gx[p] = z;
+#pragma unroll
+      for (int p = 0; p < PW; p++) gw[p] = z;
+      if (k0 + sq + 3 < K) {
+#pragma unroll
+        for (int p = 0; p < PX; p++) gx[p] = gload(X, Bn, row0 + p * RP + sr, k0 + sq);
+#pragma unroll
+        for (int p = 0; p < PW; p++) gw[p] = gload(W, N, col0 + p * RP + sr, k0 + sq);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PX; p++) gx[p] = gload(X, Bn, row0 + p * RP + sr, k0 + sq);
+#pragma unroll
+      for (int p = 0; p < PW; p++) gw[p] = gload(W, N, col0 + p * RP + sr, k0 + sq);
+    }
+  };
+  auto stash = [&](int buf) {
+    float *xs = lds[buf], *ws = lds[buf] + BM * NN_LDK;
+#pragma unroll
+    for (int p = 0; p < PX; p++)
+      *reinterpret_cast<f32x4 *>(xs + (p * RP + sr) * NN_LDK + sq) = gx[p];
+#pragma unroll
+    for (int p = 0; p < PW; p++)
+      *reinterpret_cast<f32x4 *>(ws + (p * RP + sr) * NN_LDK + sq) = gw[p];
+  };
+  const int fm = lane & 31, fh = (lane >> 5) * 4;
+  // the parked tile
+  f32x16 accP[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) accP[i][j][q] = 0.f;
+  float pbv[TJ] = {0.f, 0.f};
+  int pvo[TJ] = {0, 0};
+  // (an empty buffer: the stores of "the tile before the first" go nowhere)
+  __amdgpu_buffer_rsrc_t prs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)yout64, 0, 0, 0x00020000);
+  const int lane_off = (4 * (lane >> 5) * N + (lane & 31)) * 8;
+  // elements [4 p, 4 p + 4) of the parked tile, in (tj, ti, r) order
+  auto epi_portion = [&](auto p_c) {
+    constexpr int PP = decltype(p_c)::value;
+#ifdef NN_DBG_NOEPI   // (one store per tile keeps the products alive)
+    if (PP != 0) return;
+#endif
+    double ev[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      constexpr int E0 = PP * 4;
+      const int e = E0 + q;
+      const int tj = e / 32, ti = (e / 16) % 2, r = e % 16;
+      const float y = accP[ti][tj][r] + pbv[tj];
+      ev[q] = fmin(fmax((double)y, -300.0), 300.0);
+    }
+#ifndef NN_DBG_NOEXP   // (tools/perf/nn_variants.sh: what the exps cost)
+    exp_clip300_n<4>(ev);
+#endif
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      constexpr int E0 = PP * 4;
+      const int e = E0 + q;
+      const int tj = e / 32, ti = (e / 16) % 2, r = e % 16;
+      const int soff = ((wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2)) * N + wc * 64 +
+                        tj * 32) * 8;
+      v2i_t d;
+      d.x = __double2loint(ev[q]);
+      d.y = __double2hiint(ev[q]);
+#ifndef NN_DBG_NOSTORE   // (tools/perf/nn_variants.sh: what the stores cost)
+      __builtin_amdgcn_raw_buffer_store_b64(d, prs, pvo[tj], soff, NN_ST_AUX);
+#else
+      if (d.x == 0x12345 && d.y == 0x54321)
+        __builtin_amdgcn_raw_buffer_store_b64(d, prs, pvo[tj], soff, NN_ST_AUX);
+#endif
+    }
+  };
+  bool first = true;
+  for (int tile = tfirst; tile < tend; tile += tstep) {
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[i][j][q] = 0.f;
+    // (later tiles: fetched under the previous tile's last slab)
+    if (first) fetch(0, std::integral_constant<bool, NSLAB == 1>{});
+    first = false;
+    stash(0);
+    __syncthreads();
+    const int erow0 = row0, ecol0 = col0;
+    const bool more = tile + tstep < tend;
+    nn_static_for<0, NSLAB>([&](auto sidx_c) {
+      constexpr int sidx = decltype(sidx_c)::value;
+      constexpr int buf = sidx & 1;
+      // the next slab's operands first (vmcnt counts loads and stores in order: the
+      // wait for them at the slab's end must not have this slab's stores ahead of it)
+#ifdef NN_DBG_NOLOAD   // (every slab multiplies the tile's first slab again)
+      if (sidx + 1 < NSLAB) {
+      } else if (more) {
+#else
+      if (sidx + 1 < NSLAB) {
+        fetch((sidx + 1) * NN_BK, std::integral_constant<bool, sidx + 2 == NSLAB>{});
+      } else if (more) {   // the first slab of the block's next tile
+#endif
+        tile_rc(tile + tstep, row0, col0);
+        fetch(0, std::integral_constant<bool, NSLAB == 1>{});
+      }
+      // this slab's share of the parked tile's epilogue (16 portions over NSLAB
+      // slabs: the first 16 - NSLAB slabs take two)
+      if constexpr (sidx < 16) epi_portion(std::integral_constant<int, sidx>{});
+      if constexpr (sidx + NSLAB < 16)
+        epi_portion(std::integral_constant<int, sidx + NSLAB>{});
+      const float *xs = lds[buf] + (wr * 64 + fm) * NN_LDK + fh;
+      const float *ws = lds[buf] + BM * NN_LDK + (wc * 64 + fm) * NN_LDK + fh;
+#pragma unroll
+      for (int g = 0; g < NN_BK; g += 8) {
+        f32x4 a[TI], b[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+          a[i] = *reinterpret_cast<const f32x4 *>(xs + i * 32 * NN_LDK + g);
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+          b[j] = *reinterpret_cast<const f32x4 *>(ws + j * 32 * NN_LDK + g);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJ; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q],
+                                                               acc[i][j], 0, 0, 0);
+      }
+      if (sidx + 1 < NSLAB) stash(buf ^ 1);
+#ifndef NN_DBG_NOBAR
+      __syncthreads();
+#endif
+    });
+    // park the tile
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) accP[i][j] = acc[i][j];
+    prs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(yout64 + (int64_t)erow0 * N), 0,
+        min(Bn - erow0, BM) * N * (int)sizeof(double), 0x00020000);
+#pragma unroll
+    for (int tj = 0; tj < TJ; tj++) {
+      const int col = ecol0 + wc * 64 + tj * 32 + (lane & 31);
+      pbv[tj] = bias[min(col, N - 1)];
+      // (a column behind the matrix: an offset behind any buffer)
+      pvo[tj] = col < N ? lane_off + ecol0 * 8 : (int)0x80000000;
+    }
+  }
+  // the block's last tile
+  nn_static_for<0, 16>([&](auto p_c) { epi_portion(p_c); });
+}
+
+template <int NSLAB>
+__global__ void __launch_bounds__(256, 2)
+    nn_final_pipe_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                         const float *__restrict__ bias, int Bn, int K, int N,
+                         double *__restrict__ yout64) {
+  static_assert(NSLAB >= 8, "16 portions, at most two per slab");
+  nn_final_pipe_body<NSLAB>(X, W, bias, Bn, K, N, yout64, blockIdx.x, gridDim.x);
+}
+// the slab counts the pipelined kernel is built for: K = 200 (the reference's
+// default number of principal components), 128, 256
+#define NN_PIPE_SLABS(F) F(13) F(8) F(16)
+static inline bool nn_pipe_has(int K) {
+  const int ns = (K + NN_BK - 1) / NN_BK;
+  return NN_PIPE_EPI && rvs_opt(RVS_OPT_NN_PIPE) && (K & 3) == 0 &&
+         (ns == 13 || ns == 8 || ns == 16);
+}
+
 // blocks per CU the register budget is held to: the 128 x 128 tile (BIG: 64
 // accumulator registers per lane, two operand fragments, the next slab in flight,
 // 64 stores with their addresses) needs ~190 VGPRs; at the 128 of four blocks per CU
@@ -326,6 +631,17 @@ __global__ void __launch_bounds__(256, BIG ? NN_MINB_BIG : 4)
   const int a = blockIdx.y;
   nn_linear_body<BIG, KVEC, true>(G.X[a], G.W[a], G.bias[a], Bn, K, G.N[a],
                                   nullptr, G.y64[a], blockIdx.x, gridDim.x);
+}
+
+template <int NSLAB>
+__global__ void __launch_bounds__(256, 2)
+    nn_final_pipe_group_kernel(NNLinG G, int Bn, const int32_t *__restrict__ live,
+                               int K) {
+  if (live) Bn = min(Bn, live[0]);
+  if (Bn < 1) return;
+  const int a = blockIdx.y;
+  nn_final_pipe_body<NSLAB>(G.X[a], G.W[a], G.bias[a], Bn, K, G.N[a], G.y64[a],
+                            blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -532,7 +848,17 @@ extern "C" int rvs_template_nn(const double *params, int B, int ndim,
 #define NN_LAUNCH(BG, KV, FN)                                                  \
   hipLaunchKernelGGL((nn_linear_kernel<BG, KV, FN>), grid, dim3(256), 0, st,   \
                      cur, W[l], b[l], B, K, N, nxt, templ)
-    if (fin) {
+    if (fin && big && nn_pipe_has(K)) {
+      switch ((K + NN_BK - 1) / NN_BK) {
+#define NN_PIPE_CASE(NS)                                                       \
+  case NS:                                                                     \
+    hipLaunchKernelGGL((nn_final_pipe_kernel<NS>), grid, dim3(256), 0, st, cur, \
+                       W[l], b[l], B, K, N, templ);                            \
+    break;
+        NN_PIPE_SLABS(NN_PIPE_CASE)
+#undef NN_PIPE_CASE
+      }
+    } else if (fin) {
       if (big && kv) NN_LAUNCH(true, true, true);
       else if (big) NN_LAUNCH(true, false, true);
       else if (kv) NN_LAUNCH(false, true, true);
@@ -686,7 +1012,17 @@ extern "C" int rvs_template_nn_arms_n(const double *params, int B,
                                               : (B + 31) / 32);
     const int64_t nres = 256ll * (big ? NN_MINB_BIG : 4);
     const dim3 grid((unsigned)(ntile < nres ? ntile : nres), narm);
-    if (big)
+    if (big && nn_pipe_has(K)) {
+      switch ((K + NN_BK - 1) / NN_BK) {
+#define NN_PIPE_CASE(NS)                                                        \
+  case NS:                                                                      \
+    hipLaunchKernelGGL((nn_final_pipe_group_kernel<NS>), grid, dim3(256), 0, st, \
+                       LG, B, live, K);                                         \
+    break;
+        NN_PIPE_SLABS(NN_PIPE_CASE)
+#undef NN_PIPE_CASE
+      }
+    } else if (big)
       hipLaunchKernelGGL((nn_linear_group_kernel<true, true>), grid, dim3(256), 0,
                          st, LG, B, live, K);
     else
@@ -696,3 +1032,4 @@ extern "C" int rvs_template_nn_arms_n(const double *params, int B,
   }
   return 0;
 }
+

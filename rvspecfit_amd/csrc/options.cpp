@@ -30,6 +30,7 @@ const OptDef kDefs[RVS_OPT_COUNT] = {
     {"nm_bucket", "RVS_NM_BUCKET", 0, true},
     {"obj_inblk_max", "RVS_OBJ_INBLK_MAX", 256, false},
     {"obj_sort", "RVS_OBJ_SORT", 1, false},
+    {"nn_pipe", "RVS_NN_PIPE", 1, false},
 };
 std::atomic<int> g_val[RVS_OPT_COUNT];
 std::once_flag g_once;

@@ -931,6 +931,40 @@ def test_nn_template_desi_size_vs_oracle(gpu):
     np.testing.assert_allclose(templ.cpu().numpy(), ref, rtol=5e-6)
 
 
+@pytest.mark.parametrize('B,npc,npix', [(3000, 200, 6215), (2700, 200, 5303),
+                                        (10000, 200, 6449), (2800, 128, 6215),
+                                        (2700, 256, 6200), (4000, 200, 6100)])
+def test_nn_wide_layer_pipelined_equals_generic(gpu, B, npc, npix):
+    """the wide last layer through nn_final_pipe_kernel (epilogue of a tile under the
+    next tile's matrix products, XCD-owned row tiles, buffer stores that drop what
+    lies outside the matrix) against nn_linear_kernel (option nn_pipe = 0): same MFMA
+    order per output, same float64 exp -- BIT FOR BIT, on row counts that end in
+    partial tiles, output widths with and without a partial column tile, the three
+    inner widths the kernel is built for"""
+    rng = np.random.RandomState(21)
+    dims = np.array([4, 256, 256, 256, npc, npix], dtype=np.int32)
+    d = dict(dims=dims, M=np.array([3.7, 2.5, -1., 0.5]),
+             S=np.array([0.15, 1.4, 0.6, 0.3]))
+    for i in range(5):
+        k, n = dims[i], dims[i + 1]
+        d['W%d' % i] = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+        d['b%d' % i] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    lib = _nn_lib(d, np.exp(np.linspace(np.log(3500.), np.log(5900.), npix)))
+    P = torch.as_tensor(np.array([rng.uniform(3500, 9000, B), rng.uniform(0, 5, B),
+                                  rng.uniform(-2, 0, B), rng.uniform(0, 1, B)]).T
+                        ).to('cuda').contiguous()
+    # the rows behind the result are a guard band: a partial row tile's stores
+    # behind row B must go nowhere
+    big = torch.full((B + 200, npix), -7.0, dtype=torch.float64, device='cuda')
+    out = torch.empty(B, dtype=torch.float64, device='cuda')
+    got, _ = lib._eval_nn(P, big[:B], out)
+    assert bool((big[B:] == -7.0).all())
+    with _lib.option('nn_pipe', 0):
+        want, _ = lib.eval_batch(P)
+    assert torch.equal(got, want)
+    assert torch.isfinite(got).all() and float(got.min()) > 0
+
+
 @pytest.mark.parametrize('B', [7, 300, 700, 3000])
 @pytest.mark.parametrize('same_shape', [True, False])
 def test_nn_template_arms_equals_per_arm_calls(gpu, B, same_shape):

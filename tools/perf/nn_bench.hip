@@ -3,6 +3,9 @@
 // that variants can be tried with -D flags.
 #include "../../rvspecfit_amd/csrc/nn.hip"
 #include <cstdio>
+// (stand-alone build: the option table of librvsgpu.so is not linked; NN_BENCH_NOPIPE=1
+// takes the generic wide-layer kernel)
+int rvs_opt(int id) { return id == RVS_OPT_NN_PIPE ? getenv("NN_BENCH_NOPIPE") == nullptr : 1; }
 #include <vector>
 #include <cstdlib>
 int main(int argc, char **argv) {

@@ -272,6 +272,26 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int u = 0; u < 16; u++)
       rn[u] = *reinterpret_cast<const f4u *>(vrow[u] + 4 * tid);
   }
+  if (FROMT) {
+    // The block's template row -- 50 KB of float64 the evaluator's kernel left in HBM
+    // -- by LDS-DMA (global_load_lds: no registers, nothing to wait for until the
+    // next barrier), every wave's share requested here in one go, in flight under
+    // the rotational kernel's construction.  (As a loop of load -> LDS store behind
+    // that construction the compiler kept a few loads in flight at a time and the
+    // row took longer than the 16-row gather it replaces: 46 against 34 us per block
+    // in the optimiser's rounds on an MLP library.)  Rows start on 8-byte
+    // boundaries only, so the pieces are dwords: wave-uniform LDS base + lane x 4.
+    const float *rowf =
+        reinterpret_cast<const float *>(TT.templ[blockIdx.y] + (int64_t)j * N);
+    float *dstf = reinterpret_cast<float *>(bufA);
+    const int ndw = 2 * N;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int c0 = wv * 64; c0 < ndw; c0 += OBJ_NT)
+      if (c0 + (tid & 63) < ndw)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(rowf + c0 + (tid & 63)),
+            (__attribute__((address_space(3))) void *)(dstf + c0), 4, 0, 0);
+  }
   int st_extra = 0;
   bool copy = true;
   int kmax = 0;
@@ -330,12 +350,14 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
   }
   if (FROMT) {
-    const double *row = TT.templ[blockIdx.y] + (int64_t)j * N;
-    for (int k = tid; k < N; k += OBJ_NT) {
-      const double val = row[k];
-      bufA[k] = val;
-      if (!(val == val)) anynan = true;
-      mx = fmax(mx, fabs(val));
+    // (the row is on its way into bufA: LDS-DMA below, complete at the next barrier)
+    if (mode != 0) {   // MAX_VAL guard: the scan needs the values
+      __syncthreads();
+      for (int k = tid; k < N; k += OBJ_NT) {
+        const double val = bufA[k];
+        if (!(val == val)) anynan = true;
+        mx = fmax(mx, fabs(val));
+      }
     }
   } else if (mode == 0) {
     // four CONSECUTIVE pixels per thread: one 16-byte load per vertex row

@@ -362,6 +362,9 @@ __device__ __forceinline__ void nn_static_for(F &&f) {
 #ifndef NN_PIPE_EPI
 #define NN_PIPE_EPI 1   // 0: the wide last layer through nn_linear_kernel<true, ., true>
 #endif
+#ifndef NN_BIG_MIN
+#define NN_BIG_MIN 1024   // 128 x 128 tiles from this many of them up, else 32 x 128
+#endif
 #ifndef NN_XCD_TILES
 #define NN_XCD_TILES 1   // wide last layer: an XCD owns every eighth row tile
 #endif
@@ -838,7 +841,7 @@ extern "C" int rvs_template_nn(const double *params, int B, int ndim,
     // the wide layer: 128-row tiles; narrow layers: 32-row tiles so that the
     // launch has several blocks per CU
     const bool big = (int64_t)((N + NN_BN - 1) / NN_BN) * ((B + NN_BM - 1) / NN_BM)
-                     >= 1024;
+                     >= NN_BIG_MIN;
     const bool kv = (K & 3) == 0;
     const int64_t ntile = (int64_t)((N + NN_BN - 1) / NN_BN) *
                           (big ? (B + NN_BM - 1) / NN_BM : (B + 31) / 32);
@@ -1007,7 +1010,7 @@ extern "C" int rvs_template_nn_arms_n(const double *params, int B,
   {
     const int K = a0.dims[nl - 1];
     const int ntc = (nmax + NN_BN - 1) / NN_BN;
-    const bool big = (int64_t)ntc * ((B + NN_BM - 1) / NN_BM) >= 1024;
+    const bool big = (int64_t)ntc * ((B + NN_BM - 1) / NN_BM) >= NN_BIG_MIN;
     const int64_t ntile = (int64_t)ntc * (big ? (B + NN_BM - 1) / NN_BM
                                               : (B + 31) / 32);
     const int64_t nres = 256ll * (big ? NN_MINB_BIG : 4);

@@ -66,13 +66,15 @@ def init_from_env(backend=None, probe=True, timeout_s=600):
     return rank, world, local
 
 
-def gather_records(rec, S_total, rank=None, world=None):
+def gather_records(rec, S_total, rank=None, world=None, alone_too=False):
     """All-gather per-shard record tensors [n_r, NREC] into [S_total, NREC] on
     every rank (shards follow shard_range; short shards are zero padded for
-    the fixed-size collective and trimmed afterwards)."""
+    the fixed-size collective and trimmed afterwards).  A group of one returns its
+    records as they are; `alone_too` runs the collective even then (what a
+    one-GPU box can show of the RCCL path: tests/test_dist_gpu.py)."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (alone_too and dist.is_initialized()):
         return rec
     per = -(-S_total // world)
     nrec = rec.shape[1]

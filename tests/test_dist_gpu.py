@@ -55,6 +55,43 @@ def test_two_ranks_on_one_gpu_equal_two_single_rank_runs(tmp_path):
     assert not np.array_equal(two[:S], two[S:])
 
 
+def test_rccl_group_of_one_runs_the_gather(tmp_path):
+    """what ONE GPU can show of the RCCL branch: a process group of one rank on
+    backend "nccl" (= RCCL) forms, the start-up probe's all_reduce and
+    dist.gather_records' all_gather_into_tensor run on the device and return the
+    shard's records unchanged (short shard: padded, gathered, trimmed).  The
+    communicator over xGMI between GPUs is the driver's scaling run."""
+    code = r'''
+import os, sys, socket, torch
+sys.path.insert(0, %r)
+s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                  MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+import torch.distributed as td
+from rvspecfit_amd import dist
+td.init_process_group('nccl', rank=0, world_size=1)
+assert td.get_backend() == 'nccl'
+one = torch.ones(1, dtype=torch.float64, device='cuda')
+td.all_reduce(one); torch.cuda.synchronize()
+assert float(one.item()) == 1.0
+rec = torch.arange(37 * 16, dtype=torch.float64, device='cuda').reshape(37, 16)
+out = dist.gather_records(rec, 37, alone_too=True)
+torch.cuda.synchronize()
+assert out.data_ptr() != rec.data_ptr() and torch.equal(out, rec)
+td.destroy_process_group()
+print('RCCL_ONE_RANK_OK')
+''' % REPO
+    e = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR',
+                      'MASTER_PORT')}
+    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    out = subprocess.run([sys.executable, '-c', code], env=e, text=True,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=600)
+    assert out.returncode == 0 and 'RCCL_ONE_RANK_OK' in out.stdout, \
+        out.stderr[-3000:]
+
+
 def test_config4_shard_62500_spectra():
     """one GPU's share of BASELINE configs[4] (500 000 spectra over 8 GPUs): the
     record of a spectrum does not depend on the 62 499 others (subsets fitted

@@ -41,6 +41,15 @@
 #ifndef OBJ_QP_LATE
 #define OBJ_QP_LATE 1
 #endif
+#ifndef OBJ_CHOL_RIGHT
+#define OBJ_CHOL_RIGHT 1   // Cholesky on lanes: trailing updates (0: left-looking sums)
+#endif
+#ifndef OBJ_LDSGROUP
+#define OBJ_LDSGROUP 1   // LDS reads of a phase requested together (0: at their use)
+#endif
+#ifndef OBJ_WREG
+#define OBJ_WREG 1
+#endif
 #ifndef OBJ_FIR_REG
 #define OBJ_FIR_REG 1
 #endif
@@ -371,6 +380,16 @@ __global__ void __launch_bounds__(OBJ_NT)
       // requested above, ahead of the rotational kernel.  Two groups in flight --
       // 243 VGPRs -- measured: 5.10 against 5.00 s of Nelder-Mead per 10 000
       // spectra, the phase is not waiting for latency.)
+      // The vertex weights are the block's: in registers for the whole phase, zero
+      // behind the grid's 2^ndim (such a slot reads the last vertex row again and adds
+      // an exact zero).  Read from LDS at their use -- one ds_read + wait per vertex
+      // and trip, behind a scalar test of u < nv that also kept the sixteen blends
+      // of a trip from interleaving -- they were 64 serialised LDS round trips per
+      // block.
+      double wreg[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) wreg[u] = (u < nv) ? PL.w[u] : 0.0;
+
       for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
         f4u r[16];
 #pragma unroll
@@ -384,13 +403,16 @@ __global__ void __launch_bounds__(OBJ_NT)
         double a4[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-          if (u < nv) {
-            const double wv = PL.w[u];
-            a4[0] = fma(wv, (double)r[u].x, a4[0]);
-            a4[1] = fma(wv, (double)r[u].y, a4[1]);
-            a4[2] = fma(wv, (double)r[u].z, a4[2]);
-            a4[3] = fma(wv, (double)r[u].w, a4[3]);
-          }
+#if OBJ_WREG
+          const double wv = wreg[u];
+#else   // (obj_bench A/B: round 4's form -- scalar test, weight from LDS at its use)
+          if (u >= nv) continue;
+          const double wv = PL.w[u];
+#endif
+          a4[0] = fma(wv, (double)r[u].x, a4[0]);
+          a4[1] = fma(wv, (double)r[u].y, a4[1]);
+          a4[2] = fma(wv, (double)r[u].z, a4[2]);
+          a4[3] = fma(wv, (double)r[u].w, a4[3]);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -598,14 +620,31 @@ __global__ void __launch_bounds__(OBJ_NT)
   // ---- A7 construct: natural spline of y, windowed Thomas (template.hip) ---
   double *ec = bufC;
 #if OBJ_PREFETCH
+  // right-hand sides: the three template values of a row are LDS reads; eight rows'
+  // worth requested together, then the arithmetic (row by row under its own `i < m`
+  // test each read was followed by its wait: thirteen exposed LDS round trips)
+  {
+    constexpr int RG = 8;
 #pragma unroll
-  for (int r = 0; r < RT; r++) {
-    const int i = tid + r * OBJ_NT;
-    if (i < m) {
-      const double y1 = y[i + 1];
-      const double s0 = (y1 - y[i]) * pf0[r], s1 = (y[i + 2] - y1) * pf1[r];
-      dp[i] = 6 * (s1 - s0) * pfg[r];
-      ec[i] = pfe[r];
+    for (int r0 = 0; r0 < RT; r0 += RG) {
+      if (r0 * OBJ_NT < m) {
+        double ya[RG], yb[RG], yc[RG];
+#pragma unroll
+        for (int g = 0; g < RG; g++) {
+          const int i = min(tid + (r0 + g) * OBJ_NT, m - 1);
+          if (OBJ_LDSGROUP) ya[g] = y[i], yb[g] = y[i + 1], yc[g] = y[i + 2];
+        }
+#pragma unroll
+        for (int g = 0; g < RG; g++) {
+          const int r = r0 + g, i = tid + r * OBJ_NT;
+          if (i < m) {
+            if (!OBJ_LDSGROUP) ya[g] = y[i], yb[g] = y[i + 1], yc[g] = y[i + 2];
+            const double s0 = (yb[g] - ya[g]) * pf0[r], s1 = (yc[g] - yb[g]) * pf1[r];
+            dp[i] = 6 * (s1 - s0) * pfg[r];
+            ec[i] = pfe[r];
+          }
+        }
+      }
     }
   }
   double pfc[RT];   // backward multipliers: in flight under the forward sweep
@@ -682,12 +721,22 @@ __global__ void __launch_bounds__(OBJ_NT)
   };
   double d_in;
   {
+    // (the chunk's multipliers and right-hand sides requested together ahead of the
+    // recurrence -- read inside it, under each row's own test, every row of the serial
+    // chain began with an exposed LDS round trip; loc / pr hold them until the
+    // recurrence overwrites them with its own values)
+#pragma unroll
+    for (int q = 0; q < OBJ_CHMAX; q++) {
+      const int i = min(a0 + q, m - 1);
+      if (OBJ_LDSGROUP) pr[q] = ec[i], loc[q] = dp[i];
+    }
     double d = 0, pb = 1;
 #pragma unroll
     for (int q = 0; q < OBJ_CHMAX; q++)
       if (a0 + q < a1) {
-        const double ei = ec[a0 + q];
-        d = dp[a0 + q] - ei * d;
+        if (!OBJ_LDSGROUP) pr[q] = ec[a0 + q], loc[q] = dp[a0 + q];
+        const double ei = pr[q];
+        d = loc[q] - ei * d;
         pb = -ei * pb;
         loc[q] = d;
         pr[q] = pb;
@@ -727,11 +776,15 @@ __global__ void __launch_bounds__(OBJ_NT)
     if (a0 + q < a1) loc[q] = loc[q] + pr[q] * d_in;  // d of the forward sweep
   __syncthreads();
   {
+#pragma unroll
+    for (int q = 0; q < OBJ_CHMAX; q++)
+      if (OBJ_LDSGROUP) pr[q] = ec[min(a0 + q, m - 1)];
     double z = 0, pb = 1;
 #pragma unroll
     for (int q = OBJ_CHMAX - 1; q >= 0; q--)
       if (a0 + q < a1) {
-        const double ci = ec[a0 + q];
+        if (!OBJ_LDSGROUP) pr[q] = ec[a0 + q];
+        const double ci = pr[q];
         z = loc[q] - ci * z;
         pb = -ci * pb;
         loc[q] = z;
@@ -980,9 +1033,19 @@ __global__ void __launch_bounds__(OBJ_NT)
     double dg = 1.0, rdg = 1.0;
 #pragma unroll
     for (int jj = 0; jj < P; jj++) {
+#if OBJ_CHOL_RIGHT
+      // right-looking: row[jj] already carries a_i,jj - sum_{q < jj} L_iq L_jj,q -- the
+      // products of the left-looking form, subtracted in the same order (q ascending),
+      // each as soon as column q existed: the trailing updates of a column are
+      // independent of one another, and the serial chain of a column is the
+      // reciprocal square root and one multiplication instead of jj dependent FMAs
+      // behind it (45 in all at P = 10).  Same operations per entry: the same bits.
+      const double sum = row[jj];
+#else
       double sum = row[jj];
 #pragma unroll
       for (int q = 0; q < jj; q++) sum -= row[q] * bcast(row[q], jj);  // L[jj][q]
+#endif
       // every lane runs the same instructions; lane jj's results are the ones
       // that count
       // d = sqrt(sum) and 1 / d from ONE reciprocal square root (hardware
@@ -1005,6 +1068,10 @@ __global__ void __launch_bounds__(OBJ_NT)
       const double rdj = bcast(rd, jj);
       row[jj] = (lane == jj) ? d : sum * rdj;
       Lm[i][jj] = row[jj];  // mirror for the back-substitution (column reads)
+#if OBJ_CHOL_RIGHT
+#pragma unroll
+      for (int k = jj + 1; k < P; k++) row[k] -= row[jj] * bcast(row[jj], k);  // L[k][jj]
+#endif
     }
 #if OBJ_PREFETCH && OBJ_QP_LATE
     load_qp();
@@ -1059,12 +1126,18 @@ __global__ void __launch_bounds__(OBJ_NT)
   };
   int kres = tid;
 #if OBJ_PREFETCH
+  // (the model / data values of those pixels: requested together, see the right-hand
+  // sides above)
+  double tev[RPF], dkv[RPF];
+#pragma unroll
+  for (int u = 0; u < RPF; u++)
+    if (OBJ_LDSGROUP) te_dk(min(tid + u * OBJ_NT, npix - 1), tev[u], dkv[u]);
 #pragma unroll
   for (int u = 0; u < RPF; u++) {
     const int k = tid + u * OBJ_NT;
     if (k < npix) {
-      double te, dk;
-      te_dk(k, te, dk);
+      if (!OBJ_LDSGROUP) te_dk(k, tev[u], dkv[u]);
+      const double te = tev[u], dk = dkv[u];
       double mdl = 0;
 #pragma unroll
       for (int i = 0; i < P; i++) mdl = fma(av[i], qp[u][i], mdl);

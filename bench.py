@@ -736,21 +736,21 @@ def main():
         """HBM bytes per launch of `kernel` for THIS configuration, from the
         committed rocprofv3 counter passes of this build (FETCH_SIZE x 2 +
         WRITE_SIZE, separate runs, tools/perf/pmc_traffic.sh): the entry of
-        profiles/r04_pmc_traffic.json whose key is this run's configuration, or
+        profiles/rNN_pmc_traffic.json (the newest round's) whose key is this run's configuration, or
         None when that configuration has not been profiled -- a figure measured
         on another workload is never stamped on this line"""
-        f = os.path.join(REPO, 'profiles', 'r04_pmc_traffic.json')
+        f = profile_file('pmc_traffic.json')
         try:
             d = json.load(open(f))[tkey][kernel]
             return d['hbm_bytes_per_launch'], \
-                'profiles/r04_pmc_traffic.json[%s] (%s)' % (tkey, d['source'])
+                'profiles/%s[%s] (%s)' % (os.path.basename(f), tkey, d['source'])
         except Exception:
             return None, None
 
     def sq_counters(kernel):
         """SQ / GRBM counters per launch (tools/perf/xc_counters.sh), default
         configuration only; None otherwise"""
-        f = os.path.join(REPO, 'profiles', 'r04_sq_counters.json')
+        f = profile_file('sq_counters.json')
         try:
             d = json.load(open(f))
             if d.get('traffic_key') != tkey:
@@ -812,7 +812,8 @@ def main():
         cb_['l2_to_l1_TBps'] = sq.get('l2_to_l1_TBps')
         cb_['valu_busy'] = sq.get('valu_busy')
         cb_['lds_busy'] = sq.get('lds_busy')
-        cb_['source'] = (cb_['source'] or '') + ' + profiles/r04_sq_counters.json'
+        cb_['source'] = (cb_['source'] or '') + ' + profiles/' + os.path.basename(
+            profile_file('sq_counters.json'))
     roof_ccf['counter_backed'] = cb_
     kernels = {
         'ccf_xcorr': dict(ms_per_step=round(ms / args.steps, 2),
@@ -972,12 +973,19 @@ def objective_model(ntp, npix, npoly, nvert, ktaps, kind='regulargrid'):
     return fl, by
 
 
+def profile_file(suffix):
+    """the newest round's committed counter file profiles/rNN_<suffix>"""
+    import glob
+    c = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r[0-9][0-9]_' + suffix)))
+    return c[-1] if c else os.path.join(REPO, 'profiles', 'r00_' + suffix)
+
+
 def objective_counters(grid_name):
     """SQ / TCC counters of objective_kernel<10> from the committed counter passes
     of this build (tools/perf/obj_counters.sh on tools/perf/obj_bench: 9000 jobs x
     3 DESI arms at random in-grid parameters, the library of this grid) -- not
     measured by this run; None for a grid that has not been profiled."""
-    f = os.path.join(REPO, 'profiles', 'r04_obj_counters.json')
+    f = profile_file('obj_counters.json')
     try:
         return json.load(open(f))[grid_name]
     except Exception:
@@ -1030,8 +1038,10 @@ def process_roofline(sub, r, out, tm, dt, dt1):
             (nm_s if nm_s else dt) * 256 / max(1, evals * len(sub.arms)) * 1e6 *
             (dt / dt1 if nm_s else 1.0), 2),
         per_arm=per_arm, counters=objective_counters(grid_name),
-        counters_source='profiles/r04_obj_counters.json[%s] (tools/perf/obj_counters.sh, '
-                        'stand-alone objective bench; not this run)' % grid_name,
+        counters_source='profiles/%s[%s] (tools/perf/obj_counters.sh, '
+                        'stand-alone objective bench; not this run)' % (
+                            os.path.basename(profile_file('obj_counters.json')),
+                            grid_name),
         note='flops / bytes: objective_model() of bench.py (phase by phase, DESIGN '
              '4.7); evaluations counted by the optimiser; seconds = the whole '
              'vel_fit.process call (first grid, Nelder-Mead, refinement, Hessian)')

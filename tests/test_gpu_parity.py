@@ -1716,6 +1716,58 @@ def test_objective_fused(cases, config, tag):
                 assert abs(c1[k].item() - want) < 1e-6 * sc, (i, c1[k].item())
 
 
+@pytest.mark.parametrize('ndim', [3, 2])
+def test_objective_fused_on_lower_dimensional_grids(cases, ndim):
+    """grids of fewer than four dimensions under the one-kernel objective: the gather
+    keeps sixteen vertex slots in registers, the slots behind the grid's 2^ndim carry
+    weight zero and read the last vertex row again -- against the chain of stand-alone
+    kernels, in-grid points, points on the grid's edge and outside it"""
+    from rvspecfit_amd import engine, spec_fit, spec_inter
+    from rvspecfit_amd.library import TemplateLibrary
+    root = 'golden-ndim%d://' % ndim
+    for n in ('gold_b', 'gold_r'):
+        d = gold_lib_dict(n)
+        idg = np.asarray(d['idgrid'])
+        sl = (Ellipsis, ) + (1, ) * (4 - ndim)        # fix the last dimensions
+        sub = idg[sl]
+        rows = sub.ravel()
+        keep = rows[rows >= 0]
+        new = np.full(rows.shape, -1, dtype=np.int64)
+        new[rows >= 0] = np.arange(len(keep))
+        dd = {k: v for k, v in d.items() if not k.startswith('uvec')}
+        dd.update(dats=np.asarray(d['dats'])[keep], vec=np.asarray(d['vec'])[:ndim, keep],
+                  idgrid=new.reshape(sub.shape), parnames=np.asarray(d['parnames'])[:ndim])
+        for i in range(ndim):
+            dd['uvec%d' % i] = d['uvec%d' % i]
+        spec_inter.register_library(TemplateLibrary(n, dd), root)
+    cfg = dict(GOLD_CONFIG)
+    cfg['template_lib'] = root
+    b, _ = spec_fit.as_batch(_sds(cases, 'c1'))
+    rng = np.random.RandomState(ndim)
+    J = 40
+    lo, hi = [3500., 0.5, -2.0][:ndim], [9000., 4.5, 0.0][:ndim]
+    par = np.stack([rng.uniform(l, h, J) for l, h in zip(lo, hi)], 1)
+    par[::9, 0] = 20000.0                             # outside: nearest neighbour
+    par = torch.as_tensor(par).to('cuda')
+    vel = torch.as_tensor(rng.uniform(-200, 200, J)).to('cuda')
+    vs = torch.as_tensor(rng.uniform(0, 80, J)).to('cuda')
+    idx = torch.zeros(J, dtype=torch.long, device='cuda')
+    out = {}
+    for fused in (True, False):
+        engine.FUSED_OBJECTIVE = fused
+        try:
+            with np.errstate(all='ignore'):
+                out[fused] = spec_fit.chisq_jobs(b, idx, vel, par, vs,
+                                                 dict(npoly=10), cfg)
+        finally:
+            engine.FUSED_OBJECTIVE = True
+    (c1, s1), (c0, s0) = out[True], out[False]
+    assert torch.equal(s0, s1)
+    assert torch.isfinite(c1).all()
+    sc = torch.clamp(c0.abs(), min=1e3)
+    assert float(((c1 - c0).abs() / sc).max()) < 1e-11
+
+
 def test_objective_job_order_and_device_count(cases, config):
     """700 jobs in one rvs_objective_fused launch: (i) from 512 jobs up the blocks
     take the jobs in the order of their grid cell (objective_order_kernel) -- which

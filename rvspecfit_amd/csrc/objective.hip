@@ -41,6 +41,12 @@
 #ifndef OBJ_QP_LATE
 #define OBJ_QP_LATE 1
 #endif
+#ifndef OBJ_FIR_KMAX
+#define OBJ_FIR_KMAX 8   // widest rotational kernel (half width) of the register-window FIR
+#endif
+#ifndef OBJ_FIR_W8
+#define OBJ_FIR_W8 1   // wide rotational kernels: eight outputs per trip (0: four)
+#endif
 #ifndef OBJ_CHOL_RIGHT
 #define OBJ_CHOL_RIGHT 1   // Cholesky on lanes: trailing updates (0: left-looking sums)
 #endif
@@ -559,12 +565,14 @@ __global__ void __launch_bounds__(OBJ_NT)
         }
       }
     };
-    const bool fir_reg = OBJ_FIR_REG && !copy && kmax <= 8;
+    const bool fir_reg = OBJ_FIR_REG && !copy && kmax <= OBJ_FIR_KMAX;
     if (fir_reg) {
       if (kmax <= 4)
         fir_small(std::integral_constant<int, 4>{});
-      else
+      else if (kmax <= 8)
         fir_small(std::integral_constant<int, 8>{});
+      else
+        fir_small(std::integral_constant<int, OBJ_FIR_KMAX>{});
       y = bufB;
       dp = bufA;
       __syncthreads();
@@ -583,33 +591,39 @@ __global__ void __launch_bounds__(OBJ_NT)
         const int c0 = tid * Lc, c1 = min(N, c0 + Lc);
         auto in = [&](int q) { return (q >= 0 && q < N) ? bufA[q] : 0.0; };
         auto tp = [&](int mm) { return bufC[mm < 0 ? -mm : mm]; };
-        for (int i0 = c0; i0 < c1; i0 += 4) {
-          double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        // W consecutive outputs per trip (8 while that many are left, then 4): per
+        // tap offset one new input and one tap are read for W FMAs -- at W = 8 half
+        // the LDS reads per FMA of W = 4 (wide kernels: v sin i beyond ~180 km/s on
+        // the DESI lattice; the phase is LDS bound there)
+        auto fir_trip = [&](auto w_c, int i0) {
+          constexpr int W = decltype(w_c)::value;
+          double sacc[W], a[W];
+#pragma unroll
+          for (int o = 0; o < W; o++) sacc[o] = 0;
           int q = i0 - kmax;                 // input of output i0 at offset -kmax
-          double a0 = in(q), a1 = in(q + 1), a2 = in(q + 2), a3 = in(q + 3);
-          for (int mm = -kmax; mm <= kmax; mm += 4, q += 4) {
-            double t = tp(mm);
-            s0 = fma(a0, t, s0), s1 = fma(a1, t, s1);
-            s2 = fma(a2, t, s2), s3 = fma(a3, t, s3);
-            a0 = in(q + 4);
-            t = (mm + 1 <= kmax) ? tp(mm + 1) : 0.0;
-            s0 = fma(a1, t, s0), s1 = fma(a2, t, s1);
-            s2 = fma(a3, t, s2), s3 = fma(a0, t, s3);
-            a1 = in(q + 5);
-            t = (mm + 2 <= kmax) ? tp(mm + 2) : 0.0;
-            s0 = fma(a2, t, s0), s1 = fma(a3, t, s1);
-            s2 = fma(a0, t, s2), s3 = fma(a1, t, s3);
-            a2 = in(q + 6);
-            t = (mm + 3 <= kmax) ? tp(mm + 3) : 0.0;
-            s0 = fma(a3, t, s0), s1 = fma(a0, t, s1);
-            s2 = fma(a1, t, s2), s3 = fma(a2, t, s3);
-            a3 = in(q + 7);
+#pragma unroll
+          for (int o = 0; o < W; o++) a[o] = in(q + o);
+          // W tap offsets per turn of the loop: the window's slots are back in
+          // order after W of them (offsets behind kmax carry exact zero taps)
+          for (int mm = -kmax; mm <= kmax; mm += W, q += W) {
+#pragma unroll
+            for (int g = 0; g < W; g++) {
+              const double t = (g == 0 || mm + g <= kmax) ? tp(mm + g) : 0.0;
+              // offset mm + g: output o takes the window's slot (o + g) mod W
+#pragma unroll
+              for (int o = 0; o < W; o++) sacc[o] = fma(a[(o + g) % W], t, sacc[o]);
+              a[g] = in(q + W + g);   // slot g is free: the next input
+            }
           }
-          bufB[i0] = s0;
-          if (i0 + 1 < c1) bufB[i0 + 1] = s1;
-          if (i0 + 2 < c1) bufB[i0 + 2] = s2;
-          if (i0 + 3 < c1) bufB[i0 + 3] = s3;
-        }
+#pragma unroll
+          for (int o = 0; o < W; o++)
+            if (o == 0 || i0 + o < c1) bufB[i0 + o] = sacc[o];
+        };
+        int i0 = c0;
+#if OBJ_FIR_W8
+        for (; i0 + 8 <= c1; i0 += 8) fir_trip(std::integral_constant<int, 8>{}, i0);
+#endif
+        for (; i0 < c1; i0 += 4) fir_trip(std::integral_constant<int, 4>{}, i0);
       }
       y = bufB;
       dp = bufA;

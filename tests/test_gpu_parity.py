@@ -1025,6 +1025,22 @@ def test_nn_template_arms_equals_per_arm_calls(gpu, B, same_shape):
         assert torch.equal(t, wt)
         assert torch.equal(o, wo)
     assert float(got[2][1].abs().max()) == 0.0 and float(got[0][1].max()) > 0
+    if not same_shape:
+        return
+    # with a row count on the device (what the lock-step optimiser passes): the rows
+    # before it as above, the rows behind it untouched -- in the hidden stack, the
+    # outside flags and the wide layer (pipelined kernel at 3000 rows)
+    for n in sorted({0, 1, B // 3, B - 1, B}):
+        for t, o in got:
+            t.fill_(-5.0)
+            o.fill_(-5.0)
+        cnt = torch.tensor([n], dtype=torch.int32, device='cuda')
+        rc = _lib.lib().rvs_template_nn_arms_n(_lib.ptr(tp), B, _lib.ptr(cnt), 4, 3,
+                                               ctypes.addressof(arr), _lib.stream())
+        assert rc == 0
+        for (t, o), (wt, wo) in zip(got, want):
+            assert torch.equal(t[:n], wt[:n]) and torch.equal(o[:n], wo[:n])
+            assert bool((t[n:] == -5.0).all()) and bool((o[n:] == -5.0).all())
 
 
 @pytest.mark.parametrize('dims', [

@@ -337,6 +337,32 @@ def test_npoly_above_16(cases, config, gold_config, gold_libs, npoly, rbf):
     r = spec_fit.get_chisq_continuum(sds, options=opt)
     w = orc.get_chisq_continuum(osds, options=opt)
     np.testing.assert_allclose(r['chisq_array'], w['chisq_array'], rtol=1e-7)
+    # ... and against the reference's own values (npoly_wide_cases.npz)
+    g = np.load(os.path.join(GOLD, 'npoly_wide_cases.npz'))
+    for tg in ('c0', 'c1'):
+        sdg = _sds(cases, tg)
+        k0 = '%s/p%d/' % (tg, npoly)
+        assert bool(g[k0 + 'rbf']) == rbf
+        rc = spec_fit.get_chisq_continuum(sdg, options=opt)
+        np.testing.assert_allclose(rc['chisq_array'], g[k0 + 'cont/chisq_array'],
+                                   rtol=1e-7)
+        npg = sum(len(_.lam) for _ in sdg)
+        for ip in range(2):
+            k = k0 + 't%d/' % ip
+            vs = float(g[k + 'vsini'])
+            rot = None if np.isnan(vs) else (vs, )
+            args = (sdg, float(g[k + 'vel']), tuple(g[k + 'param']))
+            val = spec_fit.get_chisq(*args, rot_params=rot, options=opt, config=config)
+            ref = float(g[k + 'value'])
+            assert abs(val - ref) <= 1e-6 * max(abs(ref), npg), (tg, ip, val, ref)
+            full = spec_fit.get_chisq(*args, rot_params=rot, options=opt,
+                                      config=config, full_output=True)
+            np.testing.assert_allclose(full['chisq_array'], g[k + 'chisq_array'],
+                                       rtol=1e-6)
+            np.testing.assert_array_equal(full['npix_array'], g[k + 'npix_array'])
+            for n, m in zip(cases[tg + '/names'], full['models']):
+                w_ = g[k + 'model_%s' % n]
+                assert np.abs(m - w_).max() <= 1e-6 * np.abs(w_).max()
 
 
 def test_infinite_error_on_a_single_grid_is_data(cases, config):

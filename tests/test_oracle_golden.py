@@ -448,3 +448,32 @@ def test_ccf_nocontinuum_oracle_vs_reference(cases, nocont, gold_libs,
     assert gold_libs[sds[0].name].ccf_set(gold_config)['continuum']
     assert gold_libs[sds[0].name].ccf_set(
         dict(gold_config, ccf_continuum_normalize=None))['continuum']
+
+
+@pytest.mark.parametrize('tag', ['c0', 'c1'])
+@pytest.mark.parametrize('npoly', [17, 24, 32])
+def test_npoly_above_16_vs_reference(gold_libs, gold_config, tag, npoly):
+    """continuum bases of more than 16 functions (monomials + Gaussians at 17 and 32,
+    Chebyshev at 24): the oracle's get_chisq / get_chisq_continuum against the
+    reference's own values (npoly_wide_cases.npz, make_golden_npoly_wide.py)"""
+    g = np.load(os.path.join(GOLD, 'npoly_wide_cases.npz'))
+    cases = np.load(os.path.join(GOLD, 'cases.npz'))
+    sds = gold_specdata(cases, tag, orc.SpecData)
+    k0 = '%s/p%d/' % (tag, npoly)
+    opt = dict(npoly=npoly, rbf_continuum=bool(g[k0 + 'rbf']))
+    c = orc.get_chisq_continuum(sds, options=opt)
+    np.testing.assert_allclose(c['chisq_array'], g[k0 + 'cont/chisq_array'], rtol=1e-8)
+    npix = sum(len(_.lam) for _ in sds)
+    for ip in range(2):
+        k = k0 + 't%d/' % ip
+        vs = float(g[k + 'vsini'])
+        rot = None if np.isnan(vs) else (vs, )
+        full = orc.get_chisq(sds, float(g[k + 'vel']), tuple(g[k + 'param']),
+                             rot_params=rot, options=opt, config=gold_config,
+                             libs=gold_libs, full_output=True)
+        # (-2 log L passes near zero: scaled by the pixel count)
+        assert abs(full['chisq'] - float(g[k + 'value'])) <= 1e-7 * max(
+            abs(float(g[k + 'value'])), npix)
+        np.testing.assert_allclose(full['chisq_array'], g[k + 'chisq_array'],
+                                   rtol=1e-7)
+        np.testing.assert_array_equal(full['npix_array'], g[k + 'npix_array'])

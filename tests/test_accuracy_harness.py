@@ -55,3 +55,36 @@ def test_batch_of_the_harness_equals_the_oracle_one_by_one():
                         dict(npoly=10), cfg, libs)
         assert abs(r['vel'] - out['vel'][i]) < 1e-2, (i, r['vel'], out['vel'][i])
         assert abs(r['vel_err'] - out['vel_err'][i]) < 2e-2 * r['vel_err']
+
+
+def test_batch_of_the_harness_equals_the_reference_one_by_one():
+    """ten of the harness's spectra (S/N 100) through the REFERENCE's vel_fit.process
+    one at a time (accuracy_cases.npz, make_golden_accuracy.py) against the same
+    spectra fitted as one GPU batch of 48: velocity and chi^2 at the contract's
+    tolerances, parameters well inside their uncertainties (Nelder-Mead turns the
+    rounding differences of the objective into different, equally valid paths)"""
+    import accuracy_suite
+    from conftest import GOLD
+    g = np.load(os.path.join(GOLD, 'accuracy_cases.npz'))
+    n = int(g['n'])
+    out = accuracy_suite.run(sn=float(g['sn']), n=n)
+    idx = [int(_) for _ in g['idx']]
+    assert np.array_equal(out['v0'][idx], g['v0'])
+    res = out['res']
+    chisq = res['chisq'].cpu().numpy()
+    names = ('teff', 'logg', 'feh', 'alpha')
+    par = np.stack([res['param'][k].cpu().numpy() for k in names], 1)
+    perr = np.stack([np.asarray(res['param_err'][k], dtype=float) for k in names], 1)
+    for j, i in enumerate(idx):
+        assert abs(out['vel'][i] - g['vel'][j]) < 0.01, (i, out['vel'][i], g['vel'][j])
+        assert abs(out['vel_err'][i] / g['vel_err'][j] - 1) < 2e-2
+        # same optimum: chi^2 at fatol level and 1e-6 of its scale
+        sc = max(abs(g['chisq'][j]), len(out['v0']) and 401.0)
+        assert abs(chisq[i] - g['chisq'][j]) < max(2e-3, 1e-6 * sc), \
+            (i, chisq[i], g['chisq'][j])
+        e = g['param_err'][j]
+        ok = np.isfinite(e) & (e > 0)
+        assert np.all(np.abs(par[i] - g['param'][j])[ok] < 0.05 * e[ok] + 1e-9), \
+            (i, par[i], g['param'][j], e)
+        if not bool(g['bad_hessian'][j]):
+            np.testing.assert_allclose(perr[i][ok], e[ok], rtol=5e-2)

@@ -1810,6 +1810,34 @@ def test_objective_fused_on_lower_dimensional_grids(cases, ndim):
     assert float(((c1 - c0).abs() / sc).max()) < 1e-11
 
 
+def test_objective_fused_wide_rotational_kernels(cases, config):
+    """v sin i of 150-480 km/s: rotational kernels of 6-20 template pixels half width,
+    beyond the register-window FIR (8) -- the general FIR (eight outputs per trip, then
+    four) of the one-kernel objective against vsini_kernel + the kernel chain"""
+    from rvspecfit_amd import engine, spec_fit
+    b, _ = spec_fit.as_batch(_sds(cases, 'c1'))
+    rng = np.random.RandomState(8)
+    J = 64
+    par = torch.as_tensor(np.stack([rng.uniform(4600, 7000, J), rng.uniform(1., 4., J),
+                                    rng.uniform(-1.8, -0.1, J),
+                                    rng.uniform(0.0, 0.4, J)], 1)).to('cuda')
+    vel = torch.as_tensor(rng.uniform(-300, 300, J)).to('cuda')
+    vs = torch.as_tensor(np.linspace(150., 480., J)).to('cuda')
+    idx = torch.zeros(J, dtype=torch.long, device='cuda')
+    out = {}
+    for fused in (True, False):
+        engine.FUSED_OBJECTIVE = fused
+        try:
+            out[fused] = spec_fit.chisq_jobs(b, idx, vel, par, vs, dict(npoly=10),
+                                             config)
+        finally:
+            engine.FUSED_OBJECTIVE = True
+    (c1, s1), (c0, s0) = out[True], out[False]
+    assert torch.equal(s0, s1) and int(s1.abs().sum()) == 0
+    sc = torch.clamp(c0.abs(), min=1e3)
+    assert float(((c1 - c0).abs() / sc).max()) < 1e-11
+
+
 def test_objective_job_order_and_device_count(cases, config):
     """700 jobs in one rvs_objective_fused launch: (i) from 512 jobs up the blocks
     take the jobs in the order of their grid cell (objective_order_kernel) -- which

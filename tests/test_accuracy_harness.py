@@ -88,3 +88,26 @@ def test_batch_of_the_harness_equals_the_reference_one_by_one():
             (i, par[i], g['param'][j], e)
         if not bool(g['bad_hessian'][j]):
             np.testing.assert_allclose(perr[i][ok], e[ok], rtol=5e-2)
+
+
+def test_harness_statistics_equal_the_reference():
+    """all 200 spectra of a harness run (S/N 100) through the reference one by one
+    (eight worker processes, 95 CPU-seconds: accuracy_cases.npz, all/) against the
+    same 200 as one GPU batch: every velocity within the contract's 0.01 km/s, and
+    the two summary lines runall_accuracy.py prints -- median and scatter of v - v0,
+    width of the pull -- the same to three digits"""
+    import accuracy_suite
+    from conftest import GOLD
+    g = np.load(os.path.join(GOLD, 'accuracy_cases.npz'))
+    n = int(g['all/n'])
+    out = accuracy_suite.run(sn=float(g['sn']), n=n)
+    dv = np.abs(out['vel'] - g['all/vel'])
+    assert dv.max() < 0.01, (int(np.argmax(dv)), dv.max())
+    np.testing.assert_allclose(out['vel_err'], g['all/vel_err'], rtol=2e-2)
+    chisq = out['res']['chisq'].cpu().numpy()
+    assert np.all(np.abs(chisq - g['all/chisq']) <
+                  np.maximum(2e-3, 1e-6 * np.abs(g['all/chisq'])))
+    dx, dxr = out['vel'] - out['v0'], g['all/vel'] - out['v0']
+    assert abs(np.median(dx) - np.median(dxr)) < 2e-3
+    assert abs(np.std(dx) / np.std(dxr) - 1) < 1e-3
+    assert abs(np.std(dx / out['vel_err']) / np.std(dxr / g['all/vel_err']) - 1) < 5e-3

@@ -661,6 +661,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       }
     }
   }
+  OBJ_T(10);   // (debug) right-hand sides
   double pfc[RT];   // backward multipliers: in flight under the forward sweep
 #pragma unroll
   for (int r = 0; r < RT; r++)
@@ -755,7 +756,9 @@ __global__ void __launch_bounds__(OBJ_NT)
         loc[q] = d;
         pr[q] = pb;
       }
+    OBJ_T(11);   // (debug) forward recurrence
     d_in = chain3(d, pb, -1);  // (barrier inside: all reads of ec are done)
+    OBJ_T(12);   // (debug) chunk hand-over
   }
 #if OBJ_PREFETCH
 #pragma unroll
@@ -804,7 +807,9 @@ __global__ void __launch_bounds__(OBJ_NT)
         loc[q] = z;
         pr[q] = pb;
       }
+    OBJ_T(13);   // (debug) multipliers to LDS, apply, backward recurrence
     const double z_in = chain3(z, pb, +1);
+    OBJ_T(14);   // (debug) chunk hand-over
 #pragma unroll
     for (int q = 0; q < OBJ_CHMAX; q++)
       if (a0 + q < a1) dp[a0 + q] = loc[q] + pr[q] * z_in;

@@ -57,7 +57,10 @@ int main(int argc, char **argv) {
   const int sorted = argc > 4 ? atoi(argv[4]) : 0;
   const double vsmax = argc > 5 ? atof(argv[5]) : 60.0;
   const int P = 10, S = std::min(J, 2000), NARM = 3;
-  const int npixs[3] = {2751, 2326, 2881}, ntps[3] = {6215, 5303, 6449};
+  const int npixs[3] = {2751, 2326, 2881};
+  int ntps[3] = {6215, 5303, 6449};
+  if (getenv("OBJ_BENCH_NTP"))   // (e.g. 6216,5304,6452: rows that start on 16-byte boundaries)
+    sscanf(getenv("OBJ_BENCH_NTP"), "%d,%d,%d", &ntps[0], &ntps[1], &ntps[2]);
   const double lam0[3] = {3600, 5760, 7520}, tl0[3] = {3500, 5660, 7420},
                tl1[3] = {5900, 7720, 9924};
   const int64_t ngrid = (int64_t)lens[0] * lens[1] * lens[2] * lens[3];

@@ -1306,7 +1306,11 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     return RVS_E_ARG;
   if (npoly > 10)   // (the wave totals share the template buffer: RED_DYN)
     for (int i = 0; i < narm; i++)
-      if (2 * arms[i].pt.npix > arms[i].ntp) return RVS_E_ARG;
+      // (... which the model pass has left: template and second derivatives, two
+      // buffers of ntp doubles, for OBJ_NW rows of NV + 1 sums)
+      if (2 * arms[i].pt.npix > arms[i].ntp ||
+          2 * arms[i].ntp < OBJ_NW * (npoly * (npoly + 1) / 2 + npoly + 1))
+        return RVS_E_ARG;
   const double *loc = nullptr;
   int32_t *perm = nullptr;
   if (!tt) {

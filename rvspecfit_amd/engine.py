@@ -984,7 +984,8 @@ def can_fuse_objective(batch, libs, resols=None, fast_interp=False, npoly=10,
             return False
         if lib.ntp > _max_ntp[npoly]:
             return False
-        if npoly > 10 and 2 * arm.npix > lib.ntp:
+        if npoly > 10 and (2 * arm.npix > lib.ntp or
+                           2 * lib.ntp < 8 * (npoly * (npoly + 3) // 2 + 1)):
             return False   # (objective_kernel<P > 10>: csrc/objective.hip, RED_DYN)
         if _arm_resol(arm, ia, resols) is not None:
             return False

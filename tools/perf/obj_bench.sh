@@ -13,6 +13,6 @@ for v in ${OBJ_VARIANTS:-base}; do
     -Lrvspecfit_amd -l:librvsgpu.so -Wl,-rpath,$GRAFT_REPO_ROOT/rvspecfit_amd 2>/dev/null || { echo "$v: build failed"; continue; }
   IFS=';' read -ra sets <<< "${OBJ_ARGS:-3000 5}"
   for a in "${sets[@]}"; do
-    echo "[$v] $(timeout 90 tools/perf/_bin/obj_bench_v $a 2>&1 | tail -12)" | tee -a gpurun_out/obj_bench.log
+    echo "[$v] $(timeout 90 tools/perf/_bin/obj_bench_v $a 2>&1 | tail -${OBJ_TAIL:-12})" | tee -a gpurun_out/obj_bench.log
   done
 done

@@ -70,8 +70,11 @@ extern "C" {
  *      device)
  *   9: rvs_option_set / rvs_option_get (the behaviour switches, no longer read from
  *      the environment at launch time); rvs_basis_build takes npoly <= 32 and
- *      npix <= 16384; espec = +inf marks padding only when G > 1 */
-#define RVS_ABI_VERSION 9
+ *      npix <= 16384; espec = +inf marks padding only when G > 1
+ *  10: rvs_chisq_full(_g) takes unit_template = 2 (the template given on the
+ *      pixels: get_chisq0 itself); rvs_objective_fused refuses npoly > 10 on a
+ *      template of 2 ntp < 8 (npoly (npoly + 3) / 2 + 1) knots */
+#define RVS_ABI_VERSION 10
 int rvs_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -285,7 +288,10 @@ int rvs_chisq_grid_resol(const double *lam, const double *polysT,
 /* ------------------------------------------------------------------------
  * get_chisq(full_output=True) for one velocity per job and one arm
  * (spec_fit.py:941-961), and get_chisq_continuum (spec_fit.py:739-783) when
- * unit_template != 0 (template == 1, knots/coef ignored).  cform = the form of
+ * unit_template == 1 (template == 1, knots/coef ignored); unit_template == 2:
+ * get_chisq0 itself (spec_fit.py:306-354) -- the template is given ON THE PIXELS,
+ * row job_templ[j] of `coef` read as [Tn, npix] doubles (knots, ntp, vel, cform
+ * ignored; espec of ones = "already divided by the uncertainty").  cform = the form of
  * the spline records (see rvs_spline_construct).  fast_interp: the template
  * value is the nearest knot at or above x instead of the spline
  * (spec_fit.py:913-918; needs cform = 1).  taps (nullable): resolution

@@ -172,9 +172,12 @@ def get_poly_basis(lam, npoly, rbf=True):
 def get_chisq0(spec, templ, polys, get_coeffs=False, espec=None):
     """numpy form following _get_chisq0_svd (spec_fit.py:255-303); the C form
     orc_chisq0 is the Cholesky statement of the same quantity."""
-    D = spec / espec
-    nt = templ / espec
-    logz = np.log(espec).sum()
+    if espec is None:   # already divided by the uncertainty (spec_fit.py:260-263)
+        D, nt, logz = spec, templ, 0.
+    else:
+        D = spec / espec
+        nt = templ / espec
+        logz = np.log(espec).sum()
     ST = nt[None, :] * polys
     v = ST @ D
     Minv = ST @ ST.T

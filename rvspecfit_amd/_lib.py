@@ -93,7 +93,7 @@ SIGNATURES = {
 
 _lib = None
 # RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class RvsGpuError(RuntimeError):

@@ -1334,6 +1334,9 @@ __global__ void __launch_bounds__(256)
   const double sys2 = espec_sys * espec_sys;
   double f = 1, x0 = 0, xlast = 0, inv_step = 0, lx0 = 0;
   const double4 *cf = coef + (int64_t)t * ntp;
+  // unit_template == 2: the template ON THE PIXELS, row t of `coef` read as [Tn, npix]
+  // doubles (get_chisq0's own argument, spec_fit.py:306-354); no spline, no velocity
+  const double *direct = reinterpret_cast<const double *>(coef) + (int64_t)t * npix;
   if (!unit_template) {
     const double bb = vel[j] / RVS_C_KMS;
     f = sqrt((1.0 - bb) / (1.0 + bb));
@@ -1362,6 +1365,8 @@ __global__ void __launch_bounds__(256)
                    : c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
         if (fast_interp)  // nearest knot at or above x (spec_fit.py:913-918)
           tv = cf[min(pos + (dl > 0 ? 1 : 0), ntp - 1)].x;
+      } else if (unit_template == 2) {
+        tv = direct[k];
       }
       Ds[k] = tv;
     }
@@ -1393,6 +1398,8 @@ __global__ void __launch_bounds__(256)
                  : c.x * dl * dl * dl + c.y * dr * dr * dr + c.z * dl + c.w * dr;
       if (fast_interp)  // nearest knot at or above x (spec_fit.py:913-918)
         tv = cf[min(pos + (dl > 0 ? 1 : 0), ntp - 1)].x;
+    } else if (unit_template == 2) {
+      tv = direct[k];
     }
     if (raw_model) raw_model[(int64_t)j * npix + k] = tv;
     double e = es[k];

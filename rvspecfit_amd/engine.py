@@ -1194,7 +1194,7 @@ def chisq_continuum_fix(batch, res, npoly=5, rbf=True):
 # --------------------------------------------------------------------------
 # CCF: A15 + A14
 # --------------------------------------------------------------------------
-def ccf_preprocess(arm, lib, config, details=False):
+def ccf_preprocess(arm, lib, config, details=False, maxerr=10.0):
     L = _lib.lib()
     T = arm.ccf_tables(lib, config)
     cc = lib.ccf_set(config)
@@ -1215,7 +1215,7 @@ def ccf_preprocess(arm, lib, config, details=False):
         _lib.ptr(arm.badmask), arm.npix, arm.S, int(cc['continuum']),
         _lib.ptr(T['Eb']), _lib.ptr(T['El']), _lib.ptr(T['Cinv']),
         _lib.ptr(T['istart']), T['nnode'], _lib.ptr(T['bin_start']),
-        _lib.ptr(T['xind']), _lib.ptr(T['rw']), nfft, 10.0, _lib.ptr(ps),
+        _lib.ptr(T['xind']), _lib.ptr(T['rw']), nfft, float(maxerr), _lib.ptr(ps),
         _lib.ptr(pi), _lib.ptr(sse), _lib.ptr(cont), _lib.ptr(pfit),
         _lib.ptr(status), arm.grid_args()[0], _lib.ptr(T['npix_g']),
         _lib.ptr(T['nnode_g']), _lib.stream())

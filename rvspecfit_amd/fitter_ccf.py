@@ -10,6 +10,44 @@ from . import spec_inter
 from .spec_fit import SpecData, as_batch
 
 
+class CCFCache:
+    """fitter_ccf.CCFCache (fitter_ccf.py:13-18): what get_ccf_info has handed out,
+    by setup.  (The arrays the kernels read live with the TemplateLibrary in HBM;
+    these are the host views of the same set.)"""
+    ccf_info = {}
+    ccfs = {}
+    ccf2s = {}
+    ccf_models = {}
+
+
+def get_ccf_info(spec_setup, config):
+    """fitter_ccf.get_ccf_info (fitter_ccf.py:21-59): (fft, fft2, models, info) of
+    the CCF template set of a setup -- complex128 [T, N/2 + 1] transforms of the
+    prepared templates and of their squares, the prepared templates themselves
+    [T, N] (None if the library was converted without them), and the dictionary
+    make_ccf saved: params [T, ndim], vsinis [T], parnames, ccfconf."""
+    if spec_setup not in CCFCache.ccfs:
+        lib = spec_inter.get_libs([spec_setup], config)[spec_setup]
+        cc = lib.ccf_set(config)
+        T = cc['params'].shape[0]
+        nr = cc['npoints'] // 2 + 1
+
+        def cplx(t):
+            return t.cpu().numpy().reshape(-1).view(np.complex128).reshape(T, nr)
+        conf = dict(logl0=cc['logl0'], logl1=cc['logl1'], npoints=cc['npoints'],
+                    continuum=cc['continuum'], maxcontpts=cc['maxcontpts'])
+        if cc['splinestep'] is not None:
+            conf['splinestep'] = cc['splinestep']
+        CCFCache.ccfs[spec_setup] = cplx(cc['fft'])
+        CCFCache.ccf2s[spec_setup] = cplx(cc['fft2'])
+        CCFCache.ccf_models[spec_setup] = cc['mod']
+        CCFCache.ccf_info[spec_setup] = dict(
+            params=cc['params'], vsinis=cc['vsinis'],
+            parnames=tuple(lib.parnames), ccfconf=conf)
+    return (CCFCache.ccfs[spec_setup], CCFCache.ccf2s[spec_setup],
+            CCFCache.ccf_models[spec_setup], CCFCache.ccf_info[spec_setup])
+
+
 def fit(specdata, config):
     """fitter_ccf.fit (fitter_ccf.py:62-253).
 

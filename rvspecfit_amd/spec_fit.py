@@ -17,7 +17,8 @@ import torch
 from . import _lib
 from . import engine
 from . import spec_inter
-from .engine import SpecBatch, get_poly_basis, SPEED_OF_LIGHT  # noqa: F401
+from .engine import SpecBatch, SPEED_OF_LIGHT  # noqa: F401
+import functools
 
 
 class ResolMatrix:
@@ -81,19 +82,131 @@ class SpecData:
 
     def __init__(self, name, lam, spec, espec, badmask=None, resolution=None,
                  dtype=np.float64):
-        self.name = name
-        self.lam = np.ascontiguousarray(lam, dtype=dtype)
-        self.spec = np.ascontiguousarray(spec, dtype=dtype)
-        self.espec = np.ascontiguousarray(espec, dtype=dtype)
-        self.resolution = resolution
-        self.spec_error_ratio = self.spec / self.espec
+        fd = {}
+        fd['name'] = name
+        fd['lam'] = np.ascontiguousarray(lam, dtype=dtype)
+        fd['spec'] = np.ascontiguousarray(spec, dtype=dtype)
+        fd['espec'] = np.ascontiguousarray(espec, dtype=dtype)
+        fd['resolution'] = resolution
+        fd['spec_error_ratio'] = np.ascontiguousarray(fd['spec'] / fd['espec'],
+                                                      dtype=dtype)
         if badmask is None:
-            badmask = np.zeros(len(self.spec), dtype=bool)
-        self.badmask = np.asarray(badmask, dtype=bool)
+            badmask = np.zeros(len(fd['spec']), dtype=bool)
+        fd['badmask'] = np.asarray(badmask, dtype=bool)
+        # (the reference freezes the record, utils.freezeDict: the fields have no
+        # setters -- the device copy of a batch is cached under objid)
+        self.fd = fd
         self.objid = random.getrandbits(128)
+
+    name = property(lambda self: self.fd['name'])
+    lam = property(lambda self: self.fd['lam'])
+    spec = property(lambda self: self.fd['spec'])
+    espec = property(lambda self: self.fd['espec'])
+    spec_error_ratio = property(lambda self: self.fd['spec_error_ratio'])
+    badmask = property(lambda self: self.fd['badmask'])
+    resolution = property(lambda self: self.fd['resolution'])
 
     def __hash__(self):
         return self.objid
+
+
+def get_poly_basis(lam, npoly, rbf=True):
+    """spec_fit.get_poly_basis (spec_fit.py:148-176): the continuum basis on the
+    wavelength grid `lam`, [npoly, len(lam)] float64 -- three monomials and npoly - 3
+    Gaussians on the grid's range mapped to [-1, 1] (rbf), or Chebyshev polynomials.
+    Built by the kernel the likelihood's own tables come from (rvs_basis_build,
+    csrc/tables.hip); numpy in, numpy out."""
+    _lib.require_gpu()
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    n = len(lam)
+    dl = torch.as_tensor(lam[None, :]).to('cuda')
+    raw = torch.empty((1, n + 1, npoly), dtype=torch.float64, device='cuda')
+    cen = torch.as_tensor(np.linspace(-1, 1, max(npoly - 3, 1), True)).to('cuda')
+    rc = _lib.lib().rvs_basis_build(_lib.ptr(dl), None, 1, n, npoly,
+                                    int(bool(rbf)), _lib.ptr(cen), _lib.ptr(raw),
+                                    None, None, _lib.stream())
+    _lib.check(rc, 'rvs_basis_build')
+    return np.ascontiguousarray(raw[0, :n].T.cpu().numpy())
+
+
+@functools.lru_cache(100)
+def get_basis(specdata, npoly, rbf=True):
+    """spec_fit.get_basis (spec_fit.py:179-200): get_poly_basis of a SpecData's
+    wavelengths, cached per dataset"""
+    return get_poly_basis(specdata.lam, npoly, rbf=rbf)
+
+
+def get_chisq0(spec, templ, polys, get_coeffs=False, espec=None):
+    """spec_fit.get_chisq0 (spec_fit.py:306-354): -2 log L of `spec` given the
+    template `templ` ON THE SAME PIXELS, marginalised over the linear continuum
+    coefficients of the basis `polys` [npoly, npix]:
+        log det(ST ST^T) + 2 sum log e + |D - a ST|^2,  ST = polys templ / e, D = spec / e
+    (espec None: spec and templ are taken as already divided by the uncertainty).
+    Cholesky, the eigen decomposition for a matrix that does not factor (the
+    reference's SVD tier) -- rvs_chisq_full(unit_template=2), one block per row.
+
+    One spectrum: 1-D numpy arrays in, a float (and the coefficients [npoly] with
+    get_coeffs) out, as the reference.  Batched: spec / templ / espec [S, npix]
+    (numpy or device tensors; templ may be [npix] = one template for all) give
+    device tensors chisq [S] (and coeffs [S, npoly])."""
+    _lib.require_gpu()
+    single = np.ndim(spec) == 1
+
+    def dev(x):
+        if torch.is_tensor(x):
+            return x.to('cuda', torch.float64)
+        return torch.as_tensor(np.asarray(x, dtype=np.float64)).to('cuda')
+    sp = dev(spec).reshape(-1, np.shape(spec)[-1]).contiguous()
+    S, npix = sp.shape
+    tp = dev(templ).reshape(-1, npix).contiguous()
+    assert tp.shape[0] in (1, S)
+    es = (torch.ones_like(sp) if espec is None
+          else dev(espec).reshape(-1, npix).expand(S, npix).contiguous())
+    pT = dev(polys).T.contiguous()
+    npoly = pT.shape[1]
+    assert pT.shape[0] == npix
+    f64 = dict(dtype=torch.float64, device='cuda')
+    i32 = dict(dtype=torch.int32, device='cuda')
+    chisq = torch.empty(S, **f64)
+    coeffs = torch.empty((S, npoly), **f64)
+    tchi = torch.empty(S, **f64)
+    ngood = torch.empty(S, **i32)
+    status = torch.zeros(S, **i32)
+    jt = (torch.zeros(S, **i32) if tp.shape[0] == 1
+          else torch.arange(S, **i32))
+    rc = _lib.lib().rvs_chisq_full(
+        None, _lib.ptr(pT), _lib.ptr(sp), _lib.ptr(es), None, npix, npoly, S,
+        None, _lib.ptr(tp), 0, tp.shape[0], 1, 1, 2, None, _lib.ptr(jt), S, None,
+        0.0, 0, None, 0, 0, _lib.ptr(chisq), _lib.ptr(coeffs), None, None,
+        _lib.ptr(tchi), _lib.ptr(ngood), _lib.ptr(status), _lib.stream())
+    _lib.check(rc, 'rvs_chisq_full')
+    if single:
+        c = float(chisq[0].item())
+        return (c, coeffs[0].cpu().numpy()) if get_coeffs else c
+    return (chisq, coeffs) if get_coeffs else chisq
+
+
+def compute_vsini_kernel(R, eps=0.6):
+    """spec_fit.compute_vsini_kernel (spec_fit.py:565-625): the 2 ceil(R + 1) + 1
+    weights of the rotational kernel of half width R pixels (linear limb darkening
+    eps, integrated against a piecewise-linear signal), normalised -- the response
+    of rvs_vsini_convolve to a unit pulse: every output is a sum of exact zeros and
+    one weight times 1.0."""
+    _lib.require_gpu()
+    assert R > 0
+    kmax = int(np.ceil(R + 1))
+    n = 4 * kmax + 8   # (the kernel must fit the row: csrc/template.hip)
+    c = n // 2
+    x = torch.zeros((1, n), dtype=torch.float64, device='cuda')
+    x[0, c] = 1.0
+    out = torch.empty_like(x)
+    lnstep = 1e-4
+    vs = torch.as_tensor([R * lnstep * SPEED_OF_LIGHT], dtype=torch.float64).to('cuda')
+    rc = _lib.lib().rvs_vsini_convolve(_lib.ptr(x), _lib.ptr(vs), None, lnstep,
+                                       float(eps), n, 1, _lib.ptr(out),
+                                       _lib.stream())
+    _lib.check(rc, 'rvs_vsini_convolve')
+    return out[0, c - kmax:c + kmax + 1].cpu().numpy()
 
 
 class LRUDict:

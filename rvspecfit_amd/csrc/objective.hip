@@ -63,7 +63,7 @@
 
 #ifdef RVS_OBJ_TIMING
 // debug build only (tools/perf/obj_phases.sh): clock budget of the phases
-__device__ unsigned long long obj_dbg[16];
+__device__ unsigned long long obj_dbg[24];
 #define OBJ_T(i)                                                         \
   do {                                                                   \
     __syncthreads();                                                     \
@@ -287,6 +287,7 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int u = 0; u < 16; u++)
       rn[u] = *reinterpret_cast<const f4u *>(vrow[u] + 4 * tid);
   }
+  OBJ_T(15);   // (debug) row bases, first group requested
   if (FROMT) {
     // The block's template row -- 50 KB of float64 the evaluator's kernel left in HBM
     // -- by LDS-DMA (global_load_lds: no registers, nothing to wait for until the
@@ -364,6 +365,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       __syncthreads();
     }
   }
+  OBJ_T(16);   // (debug) rotational kernel built
   if (FROMT) {
     // (the row is on its way into bufA: LDS-DMA below, complete at the next barrier)
     if (mode != 0) {   // MAX_VAL guard: the scan needs the values
@@ -466,6 +468,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       mx = fmax(mx, fabs(val));
     }
   }
+  OBJ_T(17);   // (debug) gather loop
   double outside = 0.0;
   if (mode != 0) {  // MAX_VAL guard of getCurTempl (spec_fit.py:392-397)
     mx = wave_max(mx);

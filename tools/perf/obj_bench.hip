@@ -280,18 +280,19 @@ int main(int argc, char **argv) {
          1e3 * best * 256 / nblk, (unsigned long long)h, nbad, out[0], out[1], out[2]);
 #ifdef RVS_OBJ_TIMING
   {
-    unsigned long long t[16];
+    unsigned long long t[24];
     const int drc = bench_dbg_read(t);
     if (drc) printf("dbg_read rc %d (%s)\n", drc, hipGetErrorString(hipGetLastError()));
     double tot = 0;
-    for (int i = 0; i < 15; i++) tot += (double)t[i];
-    const char *nm[15] = {"locate", "gather+exp", "vsini", "spline (rest)", "tv+normal",
+    for (int i = 0; i < 18; i++) tot += (double)t[i];
+    const char *nm[18] = {"locate", "gather: tail", "vsini", "spline (rest)", "tv+normal",
                           "cholesky", "resid", "model pass", "wave reduce", "fold",
                           "spl: rhs", "spl: forward", "spl: hand-over 1",
-                          "spl: backward", "spl: hand-over 2"};
+                          "spl: backward", "spl: hand-over 2", "gather: row bases",
+                          "gather: rot kernel", "gather: loop"};
     // (wall_clock64 ticks of 10 ns, summed by thread 0 of every block of every launch)
     const double nl = (skip_ref ? 1.0 : 2.0) * (reps + 1);
-    for (int i = 0; i < 15; i++)
+    for (int i = 0; i < 18; i++)
       printf("  %-18s %.3f  %7.2f us per block\n", nm[i], t[i] / tot,
              t[i] * 0.01 / (nl * J * NARM));
     printf("  total %.2f us per block between the first and the last stamp\n",

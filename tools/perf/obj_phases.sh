@@ -11,7 +11,7 @@ sys.argv = ['x', '1000']
 src = open('tools/perf/proc_time.py').read().replace('for it in range(2):', 'for it in range(1):')
 exec(compile(src, 'p', 'exec'))
 L = _lib.lib()
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 24)()
 L.rvs_dbg_read.argtypes = [ctypes.c_void_p]
 L.rvs_dbg_read(ctypes.addressof(buf))
 t = np.array(buf[:10], dtype=float)

@@ -44,6 +44,11 @@
 #ifndef OBJ_FIR_KMAX
 #define OBJ_FIR_KMAX 8   // widest rotational kernel (half width) of the register-window FIR
 #endif
+#ifndef OBJ_FIR_PAD
+// doubles of zeros kept on both sides of the template buffer: the register-window FIR
+// reads its inputs without range tests (0: tests, round 5's first form)
+#define OBJ_FIR_PAD OBJ_FIR_KMAX
+#endif
 #ifndef OBJ_FIR_W8
 #define OBJ_FIR_W8 1   // wide rotational kernels: eight outputs per trip (0: four)
 #endif
@@ -92,6 +97,7 @@ extern "C" int rvs_dbg_read(unsigned long long *out) {
 __global__ void __launch_bounds__(OBJ_LOC_NT)
     objective_locate_kernel(ObjArms A, const double *__restrict__ params, int J,
                             const int32_t *__restrict__ live,
+                            const double *__restrict__ vel,
                             double *__restrict__ loc) {
   __shared__ PolyLoc PL;
   const rvs_objective_arm &T = A.a[blockIdx.y];
@@ -109,6 +115,8 @@ __global__ void __launch_bounds__(OBJ_LOC_NT)
     int32_t *mi = reinterpret_cast<int32_t *>(r + 2 * OBJ_LOC_NV + 1);
     mi[0] = PL.mode;
     mi[1] = PL.nearest;
+  } else if (tid == 64) {   // (another wave, beside the record's stores)
+    obj_job_scalars(T.pt, vel[j], r + 2 * OBJ_LOC_NV + 2);
   }
 }
 
@@ -195,6 +203,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   __shared__ double Lm[P][P + 1];
   __shared__ double ldv[P];
   __shared__ double red8[2 * OBJ_NW];
+  __shared__ double jobsc[3];   // the job's Doppler scalars (obj_job_scalars)
   const rvs_objective_arm &T = A.a[blockIdx.y];
   const int tid = threadIdx.x;
   // Job of this block.  With `perm` (the jobs of the launch in the order of their
@@ -222,7 +231,10 @@ __global__ void __launch_bounds__(OBJ_NT)
   }
   const int lane = tid & 63, w = tid >> 6;
   const int N = T.ntp, m = N - 2;
-  double *bufA = lds, *bufB = lds + N, *bufC = lds + 2 * N;
+  // [pad][bufA: N][pad][bufB: N][bufC: N]
+  double *bufA = lds + OBJ_FIR_PAD, *bufB = bufA + N + OBJ_FIR_PAD, *bufC = bufB + N;
+  if (OBJ_FIR_PAD && tid < 2 * OBJ_FIR_PAD)   // (barriers follow before the FIR reads)
+    (tid < OBJ_FIR_PAD ? lds : bufA + N - OBJ_FIR_PAD)[tid] = 0.0;
   double (*red)[NV + 1] =
       reinterpret_cast<double (*)[NV + 1]>(RED_DYN ? bufA : red_static);
   const int nd = T.ndim, nv = 1 << nd;
@@ -244,6 +256,8 @@ __global__ void __launch_bounds__(OBJ_NT)
             reinterpret_cast<const int32_t *>(r + 2 * OBJ_LOC_NV + 1);
         PL.mode = mi[0];
         PL.nearest = mi[1];
+      } else if (tid >= 128 && tid < 131) {
+        jobsc[tid - 128] = r[2 * OBJ_LOC_NV + 2 + tid - 128];
       }
       __syncthreads();
     } else if (INBLK) {
@@ -287,6 +301,7 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int u = 0; u < 16; u++)
       rn[u] = *reinterpret_cast<const f4u *>(vrow[u] + 4 * tid);
   }
+  if ((FROMT || !locrec) && tid == 64) obj_job_scalars(T.pt, vel[j], jobsc);
   OBJ_T(15);   // (debug) row bases, first group requested
   if (FROMT) {
     // The block's template row -- 50 KB of float64 the evaluator's kernel left in HBM
@@ -501,8 +516,6 @@ __global__ void __launch_bounds__(OBJ_NT)
   const int npix = S.npix;
   const int s = job_spec ? job_spec[j] : j;
   const ObjArmGrid AG = obj_arm_grid(S, s);   // the spectrum's wavelength grid
-  const double bb = vel[j] / RVS_C_KMS;
-  const double f = sqrt((1.0 - bb) / (1.0 + bb));
   // {1/e, s/e} of the spectrum's pixels (rvs_chisq_prepare's second table: e with the
   // systematic floor of `espec_sys` in quadrature, 0 / 0 on the padding of a short
   // grid): one 16-byte load where every evaluation used to take a square root, a
@@ -510,8 +523,6 @@ __global__ void __launch_bounds__(OBJ_NT)
   const double2 *sig = reinterpret_cast<const double2 *>(
                            AG.wbase + 2ll * S.S * npix + 2ll * S.S) + (int64_t)s * npix;
   const double x0 = S.knots[0], xlast = S.knots[N - 1];
-  const double shift = S.log_step ? log(f) / log(S.knots[1] / x0) : 0.0;
-  const double lin_inv_step = S.log_step ? 0.0 : 1.0 / (S.knots[1] - x0);
   const double *g = T.factors, *e = T.factors + N, *cc = T.factors + 2 * N,
                *hh = T.factors + 3 * N, *ih = T.factors + 4 * N;
 #if OBJ_PREFETCH
@@ -548,10 +559,41 @@ __global__ void __launch_bounds__(OBJ_NT)
       constexpr int KM = decltype(km_c)::value;
       constexpr int LCM = (8192 + OBJ_NT - 1) / OBJ_NT;
       const int Lc = (N + OBJ_NT - 1) / OBJ_NT;
-      const int c0 = tid * Lc, c1 = min(N, c0 + Lc);
       double tp[KM + 1], win[LCM + 2 * KM];
 #pragma unroll
       for (int mm = 0; mm <= KM; mm++) tp[mm] = (mm <= kmax) ? bufC[mm] : 0.0;
+#if OBJ_FIR_PAD
+      // The inputs behind both ends of the template are zeros IN LDS (the pads): a
+      // thread's window is LCM + 2 KM reads off one base address with nothing to test
+      // (what lies behind the thread's own Lc + 2 KM is read and not used: the
+      // template's three buffers are there for any N >= LCM + KM), and its Lc outputs
+      // are computed under the block's own `o < Lc` -- per element under the lane's
+      // `0 <= q < N` every read took ~15 instructions of compares and exec masks, 580
+      // instructions per thread for 117 FMAs (a phase of 4-5 us with 0.3 us of
+      // arithmetic).  A zero that is loaded multiplies like the literal: same values.
+      static_assert(KM <= OBJ_FIR_PAD, "pad");
+      const int c0 = min(N, tid * Lc);
+      const double *wb = bufA + c0 - KM;
+      if (N >= LCM + KM) {
+#pragma unroll
+        for (int i = 0; i < LCM + 2 * KM; i++) win[i] = wb[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < LCM + 2 * KM; i++)
+          win[i] = (i < Lc + 2 * KM) ? wb[i] : 0.0;
+      }
+#pragma unroll
+      for (int o = 0; o < LCM; o++) {
+        if (o < Lc) {
+          double sacc = 0;
+#pragma unroll
+          for (int mm = -KM; mm <= KM; mm++)
+            sacc = fma(win[o + mm + KM], tp[mm < 0 ? -mm : mm], sacc);
+          if (c0 + o < N) bufB[c0 + o] = sacc;
+        }
+      }
+#else
+      const int c0 = tid * Lc, c1 = min(N, c0 + Lc);
 #pragma unroll
       for (int i = 0; i < LCM + 2 * KM; i++) {
         const int q = c0 - KM + i;
@@ -567,6 +609,7 @@ __global__ void __launch_bounds__(OBJ_NT)
           bufB[c0 + o] = sacc;
         }
       }
+#endif
     };
     const bool fir_reg = OBJ_FIR_REG && !copy && kmax <= OBJ_FIR_KMAX;
     if (fir_reg) {
@@ -695,6 +738,8 @@ __global__ void __launch_bounds__(OBJ_NT)
   }
 #endif
   __syncthreads();
+  // (the job's Doppler scalars, written barriers ago by one lane)
+  const double f = jobsc[0], shift = jobsc[1], lin_inv_step = jobsc[2];
   // Chunked Thomas with chunk transfer coefficients.  Thread t owns rows
   // [a0, a1) (>= 12 of them).  Both recurrences are linear in the value that
   // enters the chunk: d_i = d0_i + P_i d_in with d0 the run from zero and P_i
@@ -1254,7 +1299,8 @@ extern "C" int rvs_objective_max_ntp(int npoly) {
     (void)hipGetLastError();
     return 0;
   }
-  const int64_t room = 160 * 1024 - (int64_t)at.sharedSizeBytes;
+  const int64_t room = 160 * 1024 - (int64_t)at.sharedSizeBytes -
+                       2 * OBJ_FIR_PAD * (int64_t)sizeof(double);
   int n = (int)(room / (3 * (int64_t)sizeof(double)));
   return n > 8192 ? 8192 : (n < 0 ? 0 : n);
 }
@@ -1292,7 +1338,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     } else if (arms[i].ndim < 1 || arms[i].ndim > MAXDIM) {
       return RVS_E_ARG;
     }
-    shm = max(shm, (size_t)3 * arms[i].ntp * sizeof(double));
+    shm = max(shm, (size_t)(3 * arms[i].ntp + 2 * OBJ_FIR_PAD) * sizeof(double));
   }
   for (int i = narm; i < RVS_MAX_ARMS; i++) {
     A.a[i] = arms[0];
@@ -1305,7 +1351,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
   int32_t *armst = (int32_t *)(armout + (int64_t)narm * J);
   double *locbuf = armout + 2 * (int64_t)narm * J;   // (status padded to 8 B)
   dim3 grid(J, narm);
-  if (shm > (size_t)3 * rvs_objective_max_ntp(npoly) * sizeof(double))
+  if (shm > (size_t)(3 * rvs_objective_max_ntp(npoly) + 2 * OBJ_FIR_PAD) * sizeof(double))
     return RVS_E_ARG;
   if (npoly > 10)   // (the wave totals share the template buffer: RED_DYN)
     for (int i = 0; i < narm; i++)
@@ -1327,7 +1373,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     if ((int64_t)J * narm <= rvs_opt(RVS_OPT_OBJ_INBLK_MAX)) pre = false;
     if (pre) {
       hipLaunchKernelGGL(objective_locate_kernel, grid, dim3(OBJ_LOC_NT), 0, st, A,
-                         params, J, live, locbuf);
+                         params, J, live, vel, locbuf);
       loc = locbuf;
       // from a few blocks per CU up: jobs in cell order (obj_sort = 0: a test
       // hook, tests/test_gpu_parity.py::test_objective_job_order)
@@ -1351,7 +1397,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     }();
     if (use_pipe && (tt || loc)) {
       const int prc = objective_pipe_launch(A, tt ? &TT : nullptr, npoly, loc, vsini,
-                                            job_spec, J, vel, shm / (3 * sizeof(double)),
+                                            job_spec, J, vel, (shm - 2 * OBJ_FIR_PAD * sizeof(double)) / (3 * sizeof(double)),
                                             armchi, armst, armout, st);
       if (prc == 0) {
         hipLaunchKernelGGL(objective_sum_kernel, dim3((J + 255) / 256), dim3(256), 0,

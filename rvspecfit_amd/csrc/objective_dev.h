@@ -56,7 +56,27 @@ struct ObjTempl {
 // latencies overlapping) and leaves a record the objective block fetches with one
 // coalesced load.  Same poly_locate code: the same ids, weights and distances.
 #define OBJ_LOC_NV 16                      // grids of up to 4 dimensions
-#define OBJ_LOC_REC (2 * OBJ_LOC_NV + 2)   // doubles: w[16], id[16], dist, {mode, nearest}
+// doubles: w[16], id[16], dist, {mode, nearest}, the job's Doppler scalars {f, shift,
+// 1 / linear step} (obj_job_scalars)
+#define OBJ_LOC_REC (2 * OBJ_LOC_NV + 5)
+
+// What a job's velocity turns into, the same for every pixel of the (job, arm): the
+// Doppler factor f = sqrt((1 - b) / (1 + b)) (spec_fit.py:707-727), the pixels' shift in
+// knot coordinates on a log-uniform grid, ln f / ln(knot ratio), or the inverse step of a
+// linear one.  Two divisions, a square root and two logarithms -- ~330 instructions that
+// all 512 threads of an objective block used to execute for themselves (1.3 us of the
+// block's VALU issue): now ONE lane, of the cell-search kernel where it runs ahead
+// (with the cell record), else of a wave that idles under the rotational kernel's
+// construction.  Same expressions: same values.
+__device__ __forceinline__ void obj_job_scalars(const rvs_point_arm &S, double velj,
+                                                double *out) {
+  const double bb = velj / RVS_C_KMS;
+  const double f = sqrt((1.0 - bb) / (1.0 + bb));
+  const double x0 = S.knots[0];
+  out[0] = f;
+  out[1] = S.log_step ? log(f) / log(S.knots[1] / x0) : 0.0;
+  out[2] = S.log_step ? 0.0 : 1.0 / (S.knots[1] - x0);
+}
 
 __device__ __forceinline__ GridDesc obj_grid_desc(const rvs_objective_arm &T) {
   GridDesc G;

@@ -49,6 +49,12 @@
 // reads its inputs without range tests (0: tests, round 5's first form)
 #define OBJ_FIR_PAD OBJ_FIR_KMAX
 #endif
+#ifndef OBJ_GATHER_SWAP
+// gather: two register sets take turns (0: one copied into the other per trip).
+// 31.85 against 32.05 us per block on launches in cell order, 33.5 against 33.1 on
+// unordered ones (the optimiser's smaller launches); `--process 10000` equal
+#define OBJ_GATHER_SWAP 0
+#endif
 #ifndef OBJ_FIR_W8
 #define OBJ_FIR_W8 1   // wide rotational kernels: eight outputs per trip (0: four)
 #endif
@@ -413,16 +419,19 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
       for (int u = 0; u < 16; u++) wreg[u] = (u < nv) ? PL.w[u] : 0.0;
 
-      for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
-        f4u r[16];
+      // Two register sets take turns (a trip loads into one and blends the other): as
+      // one set copied into a second at the head of every trip the compiler moved 64
+      // dwords per trip.  The rows' base addresses are scalars and the offset a 32-bit
+      // byte count, which is the addressing a global load has (no 64-bit address
+      // arithmetic per load).
+      auto issue = [&](f4u *dst, int k) {
+        const uint32_t boff = (uint32_t)k * 4u;
 #pragma unroll
-        for (int u = 0; u < 16; u++) r[u] = rn[u];
-        const int kn = k + 4 * OBJ_NT;
-        if (kn < N4) {
-#pragma unroll
-          for (int u = 0; u < 16; u++)
-            rn[u] = *reinterpret_cast<const f4u *>(vrow[u] + kn);
-        }
+        for (int u = 0; u < 16; u++)
+          dst[u] = *reinterpret_cast<const f4u *>(
+              reinterpret_cast<const char *>(vrow[u]) + boff);
+      };
+      auto blend = [&](const f4u *r, int k) {
         double a4[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 16; u++) {
@@ -440,7 +449,28 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
         for (int q = 0; q < 4; q++)
           bufA[k + q] = T.exp_flag ? exp(a4[q]) : a4[q];
+      };
+#if OBJ_GATHER_SWAP
+      f4u rm[16];
+      for (int k = 4 * tid; k < N4;) {
+        const int k1 = k + 4 * OBJ_NT;
+        if (k1 < N4) issue(rm, k1);
+        blend(rn, k);
+        if (k1 >= N4) break;
+        k = k1 + 4 * OBJ_NT;
+        if (k < N4) issue(rn, k);
+        blend(rm, k1);
       }
+#else
+      for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
+        f4u r[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) r[u] = rn[u];
+        const int kn = k + 4 * OBJ_NT;
+        if (kn < N4) issue(rn, kn);
+        blend(r, k);
+      }
+#endif
     } else {
       for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
         double a4[4] = {0, 0, 0, 0};
@@ -994,32 +1024,68 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int i = 0; i < CNT; i++) vals[i] = 0;
     // basis rows one pixel ahead: the loads of the next pixel are in flight while
     // the FMAs of the current one issue
-    double pn[I1];
-    {
-      const double *pr = AG.polysT + (int64_t)min(tid, npix - 1) * P;
+    if constexpr (P <= 14) {
+      // (two row buffers taking turns: copied from one into the other at the head of
+      // every pixel the row cost I1 register moves per pixel)
+      double pn[I1], pm[I1];
+      auto row = [&](double *dst, int k) {
+        const double *pr = AG.polysT + (int64_t)min(k, npix - 1) * P;
 #pragma unroll
-      for (int i = 0; i < I1; i++) pn[i] = pr[i];
-    }
-    for (int k = tid; k < npix; k += OBJ_NT) {
-      double te, dk;
-      te_dk_of(k, te, dk);
-      const double wt = te * te, u = te * dk;
-      double pv[I1], pw[I1];
+        for (int i = 0; i < I1; i++) dst[i] = pr[i];
+      };
+      auto pixel = [&](const double *pv, int k) {
+        double te, dk;
+        te_dk_of(k, te, dk);
+        const double wt = te * te, u = te * dk;
+        double pw[I1];
 #pragma unroll
-      for (int i = 0; i < I1; i++) pv[i] = pn[i];
+        for (int i = 0; i < I1; i++) pw[i] = pv[i] * wt;
+#pragma unroll
+        for (int i = I0; i < I1; i++) {
+          vals[CM + i - I0] = fma(pv[i], u, vals[CM + i - I0]);
+#pragma unroll
+          for (int jj = 0; jj <= i; jj++)
+            vals[TRI(i, jj) - T0] = fma(pv[i], pw[jj], vals[TRI(i, jj) - T0]);
+        }
+      };
+      row(pn, tid);
+      for (int k = tid; k < npix;) {
+        row(pm, k + OBJ_NT);
+        pixel(pn, k);
+        k += OBJ_NT;
+        if (k >= npix) break;
+        row(pn, k + OBJ_NT);
+        pixel(pm, k);
+        k += OBJ_NT;
+      }
+    } else {   // (15, 16 terms: no registers for a second row buffer)
+      double pn[I1];
       {
-        const double *pr = AG.polysT + (int64_t)min(k + OBJ_NT, npix - 1) * P;
+        const double *pr = AG.polysT + (int64_t)min(tid, npix - 1) * P;
 #pragma unroll
         for (int i = 0; i < I1; i++) pn[i] = pr[i];
       }
+      for (int k = tid; k < npix; k += OBJ_NT) {
+        double te, dk;
+        te_dk_of(k, te, dk);
+        const double wt = te * te, u = te * dk;
+        double pv[I1], pw[I1];
 #pragma unroll
-      for (int i = 0; i < I1; i++) pw[i] = pv[i] * wt;
+        for (int i = 0; i < I1; i++) pv[i] = pn[i];
+        {
+          const double *pr = AG.polysT + (int64_t)min(k + OBJ_NT, npix - 1) * P;
 #pragma unroll
-      for (int i = I0; i < I1; i++) {
-        vals[CM + i - I0] = fma(pv[i], u, vals[CM + i - I0]);
+          for (int i = 0; i < I1; i++) pn[i] = pr[i];
+        }
 #pragma unroll
-        for (int jj = 0; jj <= i; jj++)
-          vals[TRI(i, jj) - T0] = fma(pv[i], pw[jj], vals[TRI(i, jj) - T0]);
+        for (int i = 0; i < I1; i++) pw[i] = pv[i] * wt;
+#pragma unroll
+        for (int i = I0; i < I1; i++) {
+          vals[CM + i - I0] = fma(pv[i], u, vals[CM + i - I0]);
+#pragma unroll
+          for (int jj = 0; jj <= i; jj++)
+            vals[TRI(i, jj) - T0] = fma(pv[i], pw[jj], vals[TRI(i, jj) - T0]);
+        }
       }
     }
     OBJ_T(4);

@@ -73,8 +73,11 @@ extern "C" {
  *      npix <= 16384; espec = +inf marks padding only when G > 1
  *  10: rvs_chisq_full(_g) takes unit_template = 2 (the template given on the
  *      pixels: get_chisq0 itself); rvs_objective_fused refuses npoly > 10 on a
- *      template of 2 ntp < 8 (npoly (npoly + 3) / 2 + 1) knots */
-#define RVS_ABI_VERSION 10
+ *      template of 2 ntp < 8 (npoly (npoly + 3) / 2 + 1) knots
+ *  11: rvs_spline_factors writes rvs_spline_factors_len(ntp) doubles (the five arrays
+ *      of ntp, then the same factors in the objective kernel's chunk order); the cell
+ *      record of rvs_objective_work_size grew by three doubles per (job, arm) */
+#define RVS_ABI_VERSION 11
 int rvs_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -176,9 +179,13 @@ int rvs_vsini_convolve(const double *templ, const double *vsini,
  *     grids, what `evaler` requires anyway): both Thomas recurrences then
  *     contract by ~0.27 per row and are evaluated in independent 32-row-overlap
  *     windows (error < 1e-18 relative) instead of by exact chunk carries; this
- *     needs `factors` [5*ntp] from rvs_spline_factors (pivots, h, 1/h of the
- *     knot grid, computed once per template grid); NULL otherwise.
+ *     needs `factors` from rvs_spline_factors (pivots, h, 1/h of the knot grid,
+ *     computed once per template grid: 5 arrays of ntp doubles, followed -- for ntp <=
+ *     8192 -- by 1/h_u, 1/h_{u+1}, g_u, e_u, c_u once more in the order the fused
+ *     objective kernel's 512 threads own their rows, 5 x 8192 doubles;
+ *     rvs_spline_factors_len(ntp) in all); NULL otherwise.
  * ---------------------------------------------------------------------- */
+int64_t rvs_spline_factors_len(int ntp);   /* doubles `factors` must hold */
 int rvs_spline_factors(const double *knots, int ntp, double *factors,
                        void *stream);
 int rvs_spline_construct(const double *knots, const double *ys, int ntp, int B,

@@ -28,6 +28,7 @@ SIGNATURES = {
     'rvs_template_tri': (I, [P, I, P, P, P, I, I, U, I, P, I, P, P, P, P, P]),
     'rvs_vsini_convolve': (I, [P, P, P, D, D, I, I, P, P]),
     'rvs_spline_factors': (I, [P, I, P, P]),
+    'rvs_spline_factors_len': (ctypes.c_int64, [I]),
     'rvs_spline_construct': (I, [P, P, I, I, I, P, P, P]),
     'rvs_spline_eval': (I, [P, P, I, I, P, I, I, P, P, P, P]),
     'rvs_chisq_work_size': (L, [I, I]),
@@ -93,7 +94,7 @@ SIGNATURES = {
 
 _lib = None
 # RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class RvsGpuError(RuntimeError):

@@ -100,3 +100,21 @@ __device__ __forceinline__ float np_expf(float x) {
   den = __fmaf_rn(den, r, 1.0f);
   return ldexpf(__fdiv_rn(num, den), (int)q);
 }
+
+// Chunk geometry of the objective kernel's spline sweeps (objective.hip): its 512
+// threads own CH consecutive rows each.  rvs_spline_factors lays the grid's factors out
+// a second time in that order (chunk-transposed: entry [q][t] = row t CH + q), so that
+// the kernel's loads of "row a0 + q of thread t" are coalesced and land in the registers
+// the sweeps use.  CH is ODD where it can be: lane t's rows start at t CH doubles, and
+// 64-bit LDS reads at a lane stride of 2 CH banks reach all 64 banks once per half wave
+// only for odd CH.
+#define RVS_OBJ_NT 512
+#define RVS_OBJ_CHMAX 16
+#define RVS_OBJ_FT_MAX_NTP (RVS_OBJ_NT * RVS_OBJ_CHMAX)   // 8192
+#define RVS_OBJ_FT_LEN (5 * RVS_OBJ_NT * RVS_OBJ_CHMAX)    // doubles behind the 5 ntp
+__host__ __device__ inline int rvs_obj_chunk_len(int m) {
+  int ch = (m + RVS_OBJ_NT - 1) / RVS_OBJ_NT;
+  if (ch < 12) ch = 12;
+  if ((ch | 1) <= RVS_OBJ_CHMAX) ch |= 1;
+  return ch;
+}

@@ -25,6 +25,7 @@
 #define OBJ_NT 512
 #endif
 #define OBJ_NW (OBJ_NT / 64)
+static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
 #ifndef OBJ_PREFETCH
 #define OBJ_PREFETCH 1   // factor / pixel loads ahead of the barriers (0: at their use)
 #endif
@@ -54,6 +55,12 @@
 // 31.85 against 32.05 us per block on launches in cell order, 33.5 against 33.1 on
 // unordered ones (the optimiser's smaller launches); `--process 10000` equal
 #define OBJ_GATHER_SWAP 0
+#endif
+#ifndef OBJ_SPLINE_T
+// spline solve off the chunk-transposed factor arrays (common.h): right-hand sides and
+// both sweeps in the chunk owner's registers (0: round 5's first form -- right-hand
+// sides by strided rows through LDS)
+#define OBJ_SPLINE_T 1
 #endif
 #ifndef OBJ_FIR_W8
 #define OBJ_FIR_W8 1   // wide rotational kernels: eight outputs per trip (0: four)
@@ -204,7 +211,11 @@ __global__ void __launch_bounds__(OBJ_NT)
   // ntp, checked by the launcher)
   constexpr bool RED_DYN = (P > 10) || (OBJ_NT > 512);
   __shared__ double red_static[RED_DYN ? 1 : OBJ_NW * (NV + 1)];
+#if OBJ_SPLINE_T
+  __shared__ double edge_s[2][OBJ_NW][6];   // chunk coefficients across wave boundaries
+#else
   __shared__ double edge_s[OBJ_NW][6];   // chunk coefficients across wave boundaries
+#endif
   __shared__ double coefs[P + 2];
   __shared__ double Lm[P][P + 1];
   __shared__ double ldv[P];
@@ -555,7 +566,32 @@ __global__ void __launch_bounds__(OBJ_NT)
   const double x0 = S.knots[0], xlast = S.knots[N - 1];
   const double *g = T.factors, *e = T.factors + N, *cc = T.factors + 2 * N,
                *hh = T.factors + 3 * N, *ih = T.factors + 4 * N;
-#if OBJ_PREFETCH
+#if OBJ_SPLINE_T
+  // The phases below are separated by barriers and the block is the only one on its
+  // CU (two waves per SIMD): a load issued where its value is needed is a fully
+  // exposed L2 round trip.  The spline factors of this thread's CHUNK of rows (row
+  // a0 + q at [q][tid] of the chunk-transposed arrays: coalesced) are requested HERE,
+  // ahead of the FIR (which needs few registers), the backward multipliers under the
+  // forward sweep, the model pass's pixel terms under the backward sweep.
+  static_assert(OBJ_NT == RVS_OBJ_NT && OBJ_CHMAX == RVS_OBJ_CHMAX, "chunk geometry");
+  const int CH = __builtin_amdgcn_readfirstlane(rvs_obj_chunk_len(m));
+  const double *FT = T.factors + 5 * (int64_t)N;
+  auto ft_row = [&](int a, int q) {   // array a, row a0 + q of this thread
+    return *reinterpret_cast<const double *>(
+        reinterpret_cast<const char *>(FT + (int64_t)a * (OBJ_NT * OBJ_CHMAX)) +
+        (uint32_t)((q * OBJ_NT + tid) * 8));
+  };
+  double tf0[OBJ_CHMAX], tf1[OBJ_CHMAX], tfg[OBJ_CHMAX], tfe[OBJ_CHMAX];
+#pragma unroll
+  for (int q = 0; q < OBJ_CHMAX; q++) {
+    if (q < CH) {
+      tf0[q] = ft_row(0, q);
+      tf1[q] = ft_row(1, q);
+      tfg[q] = ft_row(2, q);
+      tfe[q] = ft_row(3, q);
+    }
+  }
+#elif OBJ_PREFETCH
   // The phases below are separated by barriers and the block is the only one on its
   // CU (two waves per SIMD): a load issued where its value is needed is a fully
   // exposed L2 round trip.  The spline factors of every row of this thread are
@@ -707,6 +743,116 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
   }
   OBJ_T(2);
+#if OBJ_SPLINE_T
+  // ---- A7 construct: natural spline of y ---------------------------------------
+  // Thread t owns the rows [a0, a1) (CH of them): their right-hand sides
+  //   6 ((y_{i+2} - y_{i+1}) / h_{i+1} - (y_{i+1} - y_i) / h_i) g_i
+  // from CH + 2 template values read off ONE LDS address (what lies behind a1 is read
+  // and not used: the template's buffers are there) and the factors already in its
+  // registers, straight into the forward recurrence.  (By strided rows the right-hand
+  // sides and multipliers went to LDS and came back in chunk order behind a barrier,
+  // the backward multipliers likewise: 130 LDS operations per thread where these are
+  // 28, and two barriers.)  Both recurrences are linear in the value that enters the
+  // chunk: d_i = d0_i + P_i d_in with d0 the run from zero and P_i the running product
+  // of the multipliers, so one pass over the chunk yields (alpha, beta) = (d0, P) at its
+  // last row, and
+  //   d_in(t) = alpha(t-1) + beta(t-1) (alpha(t-2) + beta(t-2) alpha(t-3))
+  // to |beta|^3 <= (0.268^12)^3 = 3e-21 (the multipliers of a (log-)uniform grid tend to
+  // 2 - sqrt 3).  Same operations per row as the strided form: the same bits.
+  const int a0 = min(m, tid * CH), a1 = min(m, a0 + CH);
+  double loc[OBJ_CHMAX], pr[OBJ_CHMAX];
+  // value entering a chunk from `dir` = -1 (lower threads) or +1 (upper): the three
+  // nearest chunks' coefficients through wave shuffles, across a wave boundary through
+  // edge_s[] (static LDS; one array per direction: no barrier between the two uses)
+  auto chain3 = [&](double al, double be, int dir) -> double {
+    double (*eds)[6] = edge_s[dir < 0 ? 0 : 1];
+    double av3[3], bv3[3];
+#pragma unroll
+    for (int k = 1; k <= 3; k++) {
+      av3[k - 1] = (dir < 0) ? __shfl_up(al, k, 64) : __shfl_down(al, k, 64);
+      bv3[k - 1] = (dir < 0) ? __shfl_up(be, k, 64) : __shfl_down(be, k, 64);
+    }
+    const int edge = (dir < 0) ? (63 - lane) : lane;  // 0..2: published lanes
+    if (edge < 3) {
+      eds[w * 1][2 * edge] = al;
+      eds[w * 1][2 * edge + 1] = be;
+    }
+    __syncthreads();
+    const int mine = (dir < 0) ? lane : (63 - lane);  // distance to the boundary
+#pragma unroll
+    for (int k = 1; k <= 3; k++) {
+      if (mine < k) {  // neighbour k lives in the adjacent wave
+        const int ww = w + dir;
+        const int sl = k - 1 - mine;  // its distance from that wave's boundary
+        const bool have = (ww >= 0 && ww < OBJ_NW);
+        av3[k - 1] = have ? eds[ww][2 * sl] : 0.0;
+        bv3[k - 1] = have ? eds[ww][2 * sl + 1] : 0.0;
+      }
+    }
+    return av3[0] + bv3[0] * (av3[1] + bv3[1] * av3[2]);
+  };
+  double tfc[OBJ_CHMAX];   // backward multipliers: in flight under the forward sweep
+#pragma unroll
+  for (int q = 0; q < OBJ_CHMAX; q++)
+    if (q < CH) tfc[q] = ft_row(4, q);
+  double d_in;
+  {
+    const double *yb = y + a0;
+    double yv[OBJ_CHMAX + 2];
+#pragma unroll
+    for (int q = 0; q < OBJ_CHMAX + 2; q++)
+      if (q < CH + 2) yv[q] = yb[q];
+    double d = 0, pb = 1;
+#pragma unroll
+    for (int q = 0; q < OBJ_CHMAX; q++)
+      if (q < CH && a0 + q < a1) {
+        const double s0 = (yv[q + 1] - yv[q]) * tf0[q],
+                     s1 = (yv[q + 2] - yv[q + 1]) * tf1[q];
+        const double ei = tfe[q];
+        d = 6 * (s1 - s0) * tfg[q] - ei * d;
+        pb = -ei * pb;
+        loc[q] = d;
+        pr[q] = pb;
+      }
+    OBJ_T(11);   // (debug) right-hand sides + forward recurrence
+    d_in = chain3(d, pb, -1);
+    OBJ_T(12);   // (debug) chunk hand-over
+  }
+  // (the job's Doppler scalars, written barriers ago by one lane)
+  const double f = jobsc[0], shift = jobsc[1], lin_inv_step = jobsc[2];
+  // pixel terms of the model pass (first trip of its loop): under the backward sweep
+  constexpr int PU = 6;
+  double qlm[PU], qwk[PU];
+  double2 qsg[PU];
+  const bool cached = 2 * npix <= N;
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+      const int k = min(tid + u * OBJ_NT, npix - 1);
+      qlm[u] = AG.lam[k];
+      qwk[u] = S.log_step ? AG.pix[k] : 0.0;
+      qsg[u] = sig[k];
+    }
+  }
+  {
+    double z = 0, pb = 1;
+#pragma unroll
+    for (int q = OBJ_CHMAX - 1; q >= 0; q--)
+      if (q < CH && a0 + q < a1) {
+        const double ci = tfc[q];
+        z = (loc[q] + pr[q] * d_in) - ci * z;   // d of the forward sweep, then z
+        pb = -ci * pb;
+        loc[q] = z;
+        pr[q] = pb;
+      }
+    OBJ_T(13);   // (debug) backward recurrence
+    const double z_in = chain3(z, pb, +1);
+    OBJ_T(14);   // (debug) chunk hand-over
+#pragma unroll
+    for (int q = 0; q < OBJ_CHMAX; q++)
+      if (q < CH && a0 + q < a1) dp[a0 + q] = loc[q] + pr[q] * z_in;
+  }
+#else
   // ---- A7 construct: natural spline of y, windowed Thomas (template.hip) ---
   double *ec = bufC;
 #if OBJ_PREFETCH
@@ -892,6 +1038,7 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int q = 0; q < OBJ_CHMAX; q++)
       if (a0 + q < a1) dp[a0 + q] = loc[q] + pr[q] * z_in;
   }
+#endif
 #if OBJ_PREFETCH
   // ... and the knot terms of those pixels (their interval index needs the job's
   // velocity and the prefetched pixel terms only): in flight across the barrier

@@ -534,11 +534,36 @@ __global__ void spline_factors_kernel(const double *__restrict__ knots, int ntp,
   hh[ntp - 1] = ih[ntp - 1] = 0;
 }
 
+// the same factors in the objective kernel's chunk order (common.h): five arrays of
+// RVS_OBJ_CHMAX x RVS_OBJ_NT doubles behind the 5 ntp -- 1/h_u, 1/h_{u+1}, g_u, e_u, c_u
+// of row u = t CH + q at [q][t], zero where there is no such row
+__global__ void spline_factors_chunk_kernel(int ntp, double *__restrict__ fac) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= RVS_OBJ_FT_LEN) return;
+  const int m = ntp - 2, CH = rvs_obj_chunk_len(m);
+  const int a = idx / (RVS_OBJ_NT * RVS_OBJ_CHMAX), rem = idx % (RVS_OBJ_NT * RVS_OBJ_CHMAX);
+  const int q = rem / RVS_OBJ_NT, t = rem % RVS_OBJ_NT;
+  const int u = t * CH + q;
+  double v = 0.0;
+  if (q < CH && u < m) {
+    const double *g = fac, *e = fac + ntp, *cc = fac + 2 * ntp, *ih = fac + 4 * ntp;
+    v = a == 0 ? ih[u] : a == 1 ? ih[u + 1] : a == 2 ? g[u] : a == 3 ? e[u] : cc[u];
+  }
+  fac[5 * (int64_t)ntp + idx] = v;
+}
+
+extern "C" int64_t rvs_spline_factors_len(int ntp) {
+  return ntp < 4 ? 0 : 5 * (int64_t)ntp + RVS_OBJ_FT_LEN;
+}
+
 extern "C" int rvs_spline_factors(const double *knots, int ntp, double *factors,
                                   void *stream) {
   if (ntp < 4) return RVS_E_ARG;
   hipLaunchKernelGGL(spline_factors_kernel, dim3(1), dim3(64), 0,
                      rvs_stream(stream), knots, ntp, factors);
+  if (ntp <= RVS_OBJ_FT_MAX_NTP)
+    hipLaunchKernelGGL(spline_factors_chunk_kernel, dim3((RVS_OBJ_FT_LEN + 255) / 256),
+                       dim3(256), 0, rvs_stream(stream), ntp, factors);
   RVS_LAUNCH_CHECK();
   return 0;
 }

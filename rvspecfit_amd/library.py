@@ -54,7 +54,8 @@ class TemplateLibrary:
         self.spline_form = 3 if near_uniform else 1
         self.spline_factors = None
         if near_uniform and str(device) != 'cpu':
-            self.spline_factors = torch.empty(5 * self.ntp, dtype=torch.float64,
+            self.spline_factors = torch.empty(
+                _lib.lib().rvs_spline_factors_len(self.ntp), dtype=torch.float64,
                                               device=device)
             rc = _lib.lib().rvs_spline_factors(
                 _lib.ptr(self.knots), self.ntp, _lib.ptr(self.spline_factors),

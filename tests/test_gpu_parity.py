@@ -104,7 +104,8 @@ def test_spline_construct_forms(gpu, ntp):
         kn = torch.as_tensor(xs).to('cuda')
         yt = torch.as_tensor(ys).to('cuda')
         out = {}
-        fac = torch.empty(5 * ntp, dtype=torch.float64, device='cuda')
+        fac = torch.empty(_lib.lib().rvs_spline_factors_len(ntp),
+                          dtype=torch.float64, device='cuda')
         assert _lib.lib().rvs_spline_factors(_lib.ptr(kn), ntp, _lib.ptr(fac),
                                              _lib.stream()) == 0
         for form in (0, 1, 2, 3):

@@ -160,7 +160,7 @@ int main(int argc, char **argv) {
     A.pt.knots = to_dev(knots);
     double *work, *fac;
     CK(hipMalloc(&work, rvs_chisq_work_size(npix, S) * 8));
-    CK(hipMalloc(&fac, 5ll * ntp * 8));
+    CK(hipMalloc(&fac, rvs_spline_factors_len(ntp) * 8));
     int rc = rvs_chisq_prepare(A.pt.lam, A.pt.spec, A.pt.espec, npix, S, knots.data(),
                                1, 0.0, work, nullptr);
     if (rc) return printf("prepare rc %d\n", rc), 1;

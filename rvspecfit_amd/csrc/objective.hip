@@ -62,6 +62,9 @@ static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
 // sides by strided rows through LDS)
 #define OBJ_SPLINE_T 1
 #endif
+#ifndef OBJ_FT_IN_FIR
+#define OBJ_FT_IN_FIR 1   // spline factor requests between the FIR's outputs (0: ahead)
+#endif
 #ifndef OBJ_FIR_W8
 #define OBJ_FIR_W8 1   // wide rotational kernels: eight outputs per trip (0: four)
 #endif
@@ -582,14 +585,22 @@ __global__ void __launch_bounds__(OBJ_NT)
         (uint32_t)((q * OBJ_NT + tid) * 8));
   };
   double tf0[OBJ_CHMAX], tf1[OBJ_CHMAX], tfg[OBJ_CHMAX], tfe[OBJ_CHMAX];
-#pragma unroll
-  for (int q = 0; q < OBJ_CHMAX; q++) {
+  auto ft_fetch = [&](int q) {   // (q < OBJ_CHMAX: a compile-time slot)
     if (q < CH) {
       tf0[q] = ft_row(0, q);
       tf1[q] = ft_row(1, q);
       tfg[q] = ft_row(2, q);
       tfe[q] = ft_row(3, q);
     }
+  };
+  // With the register-window FIR ahead the requests go out BETWEEN its outputs, a
+  // row's four after each (fir_small below): issued in one go, the eight waves' 416
+  // loads fill the CU's address pipe and every wave sits in its load issue for the
+  // 1.4 us the pipe needs before its FIR starts.
+  const bool ft_in_fir = OBJ_FT_IN_FIR && vsini && OBJ_FIR_REG && !copy && kmax <= 4;
+  if (!ft_in_fir) {
+#pragma unroll
+    for (int q = 0; q < OBJ_CHMAX; q++) ft_fetch(q);
   }
 #elif OBJ_PREFETCH
   // The phases below are separated by barriers and the block is the only one on its
@@ -657,6 +668,10 @@ __global__ void __launch_bounds__(OBJ_NT)
             sacc = fma(win[o + mm + KM], tp[mm < 0 ? -mm : mm], sacc);
           if (c0 + o < N) bufB[c0 + o] = sacc;
         }
+#if OBJ_SPLINE_T
+        if constexpr (KM == 4)   // (kmax <= 4: the narrow window leaves the registers)
+          if (ft_in_fir) ft_fetch(o);
+#endif
       }
 #else
       const int c0 = tid * Lc, c1 = min(N, c0 + Lc);

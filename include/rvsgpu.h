@@ -418,7 +418,7 @@ int rvs_chisq_point(const rvs_point_arm *arms, int narm, int npoly,
  * outside_penalty: bit 0 = add the outside*badchi penalty; bit 1
  * (RVS_OBJ_STATUS_STORE) = status[j] is overwritten instead of OR-ed into (the
  * optimiser's per-call scratch needs no clearing launch).
- * RVS_E_ARG: ntp < 4 or > rvs_objective_max_ntp(npoly); and, from npoly = 11 on
+ * RVS_E_ARG: ntp < 32 or > rvs_objective_max_ntp(npoly); and, from npoly = 11 on
  * (the waves' partial sums live in the template's LDS), an arm with
  * 2*npix > ntp or 2*ntp < 8*(npoly*(npoly+3)/2 + 1) -- use the chain of
  * stand-alone kernels there.

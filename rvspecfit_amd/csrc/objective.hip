@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       // The inputs behind both ends of the template are zeros IN LDS (the pads): a
       // thread's window is LCM + 2 KM reads off one base address with nothing to test
       // (what lies behind the thread's own Lc + 2 KM is read and not used: the
-      // template's three buffers are there for any N >= LCM + KM), and its Lc outputs
+      // template's three buffers are there: N >= 32 > LCM + KM), and its Lc outputs
       // are computed under the block's own `o < Lc` -- per element under the lane's
       // `0 <= q < N` every read took ~15 instructions of compares and exec masks, 580
       // instructions per thread for 117 FMAs (a phase of 4-5 us with 0.3 us of
@@ -651,14 +651,8 @@ __global__ void __launch_bounds__(OBJ_NT)
       static_assert(KM <= OBJ_FIR_PAD, "pad");
       const int c0 = min(N, tid * Lc);
       const double *wb = bufA + c0 - KM;
-      if (N >= LCM + KM) {
 #pragma unroll
-        for (int i = 0; i < LCM + 2 * KM; i++) win[i] = wb[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < LCM + 2 * KM; i++)
-          win[i] = (i < Lc + 2 * KM) ? wb[i] : 0.0;
-      }
+      for (int i = 0; i < LCM + 2 * KM; i++) win[i] = wb[i];   // (N >= 32: the launcher)
 #pragma unroll
       for (int o = 0; o < LCM; o++) {
         if (o < Lc) {
@@ -1558,7 +1552,9 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
   size_t shm = 0;
   for (int i = 0; i < narm; i++) {
     A.a[i] = arms[i];
-    if (arms[i].pt.npix < 1 || arms[i].ntp < 4 || arms[i].ntp > 8192 ||
+    // (ntp >= 32: the FIR window and the spline chunks read up to 24 doubles behind a
+    // thread's own rows without testing, inside the block's three template buffers)
+    if (arms[i].pt.npix < 1 || arms[i].ntp < 32 || arms[i].ntp > 8192 ||
         arms[i].pt.taps || arms[i].pt.fast_interp || !arms[i].factors)
       return RVS_E_ARG;
     if (tt) {

@@ -982,7 +982,7 @@ def can_fuse_objective(batch, libs, resols=None, fast_interp=False, npoly=10,
             return False
         if lib.kind != 'regulargrid' and not from_template:
             return False
-        if lib.ntp > _max_ntp[npoly]:
+        if lib.ntp > _max_ntp[npoly] or lib.ntp < 32:
             return False
         if npoly > 10 and (2 * arm.npix > lib.ntp or
                            2 * lib.ntp < 8 * (npoly * (npoly + 3) // 2 + 1)):

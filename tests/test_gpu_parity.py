@@ -1811,6 +1811,56 @@ def test_objective_fused_on_lower_dimensional_grids(cases, ndim):
     assert float(((c1 - c0).abs() / sc).max()) < 1e-11
 
 
+@pytest.mark.parametrize('ntp', [31, 33, 64, 262, 263, 700])
+def test_objective_fused_short_templates(ntp):
+    """template grids of a few dozen to a few hundred knots under the one-kernel
+    objective: the FIR window and the spline chunks read a fixed number of doubles
+    behind a thread's own rows (the launcher asks for 32 knots; 31 goes the kernel
+    chain's way), chunks of 13 rows leave most of the 512 threads without rows, 262 /
+    263 knots end on a full chunk / start one more -- against the chain of stand-alone
+    kernels"""
+    from rvspecfit_amd import engine, spec_fit, spec_inter
+    from rvspecfit_amd.library import TemplateLibrary
+    root = 'golden-short%d://' % ntp
+    d = gold_lib_dict('gold_b')
+    lam = np.asarray(d['lam'])[100:100 + ntp]
+    dd = dict(d)
+    dd.update(lam=lam, dats=np.ascontiguousarray(np.asarray(d['dats'])[:, 100:100 + ntp]))
+    dd = {k: v for k, v in dd.items() if not k.startswith('ccf')}
+    lib = TemplateLibrary('gold_b', dd)
+    spec_inter.register_library(lib, root)
+    cfg = dict(GOLD_CONFIG, template_lib=root)
+    rng = np.random.RandomState(ntp)
+    npix = max(8, ntp // 3)
+    wl = np.linspace(lam[3] * 1.002, lam[-4] * 0.998, npix)
+    sd = [spec_fit.SpecData('gold_b', wl, 1 + 0.1 * rng.standard_normal(npix),
+                            np.full(npix, 0.1))]
+    b, _ = spec_fit.as_batch(sd)
+    libs = spec_inter.get_libs(b.names, cfg)
+    assert engine.can_fuse_objective(b, libs, None, npoly=5) == (ntp >= 32)
+    J = 24
+    par = torch.as_tensor(np.stack([rng.uniform(4600, 7000, J), rng.uniform(1., 4., J),
+                                    rng.uniform(-1.8, -0.1, J),
+                                    rng.uniform(0.0, 0.4, J)], 1)).to('cuda')
+    vel = torch.as_tensor(rng.uniform(-150, 150, J)).to('cuda')
+    vsn = rng.uniform(0, 120, J)
+    vsn[::5] = 0.0
+    vs = torch.as_tensor(vsn).to('cuda')
+    idx = torch.zeros(J, dtype=torch.long, device='cuda')
+    out = {}
+    for fused in (True, False):
+        engine.FUSED_OBJECTIVE = fused
+        try:
+            out[fused] = spec_fit.chisq_jobs(b, idx, vel, par, vs, dict(npoly=5), cfg)
+        finally:
+            engine.FUSED_OBJECTIVE = True
+    (c1, s1), (c0, s0) = out[True], out[False]
+    assert torch.equal(s0, s1)
+    assert torch.isfinite(c1).all()
+    sc = torch.clamp(c0.abs(), min=1e3)
+    assert float(((c1 - c0).abs() / sc).max()) < 1e-11
+
+
 def test_objective_fused_wide_rotational_kernels(cases, config):
     """v sin i of 150-480 km/s: rotational kernels of 6-20 template pixels half width,
     beyond the register-window FIR (8) -- the general FIR (eight outputs per trip, then

@@ -1832,7 +1832,7 @@ def test_objective_fused_short_templates(ntp):
     cfg = dict(GOLD_CONFIG, template_lib=root)
     rng = np.random.RandomState(ntp)
     npix = max(8, ntp // 3)
-    wl = np.linspace(lam[3] * 1.002, lam[-4] * 0.998, npix)
+    wl = np.linspace(lam[6] * 1.001, lam[-7] * 0.999, npix)
     sd = [spec_fit.SpecData('gold_b', wl, 1 + 0.1 * rng.standard_normal(npix),
                             np.full(npix, 0.1))]
     b, _ = spec_fit.as_batch(sd)
@@ -1842,7 +1842,7 @@ def test_objective_fused_short_templates(ntp):
     par = torch.as_tensor(np.stack([rng.uniform(4600, 7000, J), rng.uniform(1., 4., J),
                                     rng.uniform(-1.8, -0.1, J),
                                     rng.uniform(0.0, 0.4, J)], 1)).to('cuda')
-    vel = torch.as_tensor(rng.uniform(-150, 150, J)).to('cuda')
+    vel = torch.as_tensor(rng.uniform(-100, 100, J)).to('cuda')
     vsn = rng.uniform(0, 120, J)
     vsn[::5] = 0.0
     vs = torch.as_tensor(vsn).to('cuda')

@@ -181,8 +181,9 @@ int rvs_vsini_convolve(const double *templ, const double *vsini,
  *     windows (error < 1e-18 relative) instead of by exact chunk carries; this
  *     needs `factors` from rvs_spline_factors (pivots, h, 1/h of the knot grid,
  *     computed once per template grid: 5 arrays of ntp doubles, followed -- for ntp <=
- *     8192 -- by 1/h_u, 1/h_{u+1}, g_u, e_u, c_u once more in the order the fused
- *     objective kernel's 512 threads own their rows, 5 x 8192 doubles;
+ *     8192 -- by 1/h_u, 1/h_{u+1}, g_u, e_u (records of four) and c_u (pairs) once
+ *     more in the order the fused objective kernel's 512 threads own their rows,
+ *     5 x 8192 doubles;
  *     rvs_spline_factors_len(ntp) in all); NULL otherwise.
  * ---------------------------------------------------------------------- */
 int64_t rvs_spline_factors_len(int ntp);   /* doubles `factors` must hold */

@@ -578,19 +578,25 @@ __global__ void __launch_bounds__(OBJ_NT)
   // forward sweep, the model pass's pixel terms under the backward sweep.
   static_assert(OBJ_NT == RVS_OBJ_NT && OBJ_CHMAX == RVS_OBJ_CHMAX, "chunk geometry");
   const int CH = __builtin_amdgcn_readfirstlane(rvs_obj_chunk_len(m));
+  // ({1/h_u, 1/h_{u+1}, g_u, e_u} is one 32-byte record per row, the backward
+  // multipliers come in pairs of rows: 33 requests of 16 bytes per thread where five
+  // arrays of doubles took 65 -- at this occupancy a request costs what it costs
+  // whatever its width, ~45 ns of the block each)
   const double *FT = T.factors + 5 * (int64_t)N;
-  auto ft_row = [&](int a, int q) {   // array a, row a0 + q of this thread
-    return *reinterpret_cast<const double *>(
-        reinterpret_cast<const char *>(FT + (int64_t)a * (OBJ_NT * OBJ_CHMAX)) +
-        (uint32_t)((q * OBJ_NT + tid) * 8));
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  auto ft16 = [&](int64_t base, uint32_t piece) {   // 16-byte piece of a [..][tid] table
+    return *reinterpret_cast<const d2v *>(
+        reinterpret_cast<const char *>(FT + base) + piece * 16u);
   };
   double tf0[OBJ_CHMAX], tf1[OBJ_CHMAX], tfg[OBJ_CHMAX], tfe[OBJ_CHMAX];
   auto ft_fetch = [&](int q) {   // (q < OBJ_CHMAX: a compile-time slot)
     if (q < CH) {
-      tf0[q] = ft_row(0, q);
-      tf1[q] = ft_row(1, q);
-      tfg[q] = ft_row(2, q);
-      tfe[q] = ft_row(3, q);
+      const d2v a = ft16(0, (uint32_t)(q * OBJ_NT + tid) * 2u);
+      const d2v b = ft16(0, (uint32_t)(q * OBJ_NT + tid) * 2u + 1u);
+      tf0[q] = a.x;
+      tf1[q] = a.y;
+      tfg[q] = b.x;
+      tfe[q] = b.y;
     }
   };
   // With the register-window FIR ahead the requests go out BETWEEN its outputs, a
@@ -802,8 +808,12 @@ __global__ void __launch_bounds__(OBJ_NT)
   };
   double tfc[OBJ_CHMAX];   // backward multipliers: in flight under the forward sweep
 #pragma unroll
-  for (int q = 0; q < OBJ_CHMAX; q++)
-    if (q < CH) tfc[q] = ft_row(4, q);
+  for (int q2 = 0; q2 < OBJ_CHMAX / 2; q2++)
+    if (2 * q2 < CH) {
+      const d2v c = ft16(4 * OBJ_NT * OBJ_CHMAX, (uint32_t)(q2 * OBJ_NT + tid));
+      tfc[2 * q2] = c.x;
+      tfc[2 * q2 + 1] = c.y;
+    }
   double d_in;
   {
     const double *yb = y + a0;

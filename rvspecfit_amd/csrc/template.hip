@@ -534,21 +534,32 @@ __global__ void spline_factors_kernel(const double *__restrict__ knots, int ntp,
   hh[ntp - 1] = ih[ntp - 1] = 0;
 }
 
-// the same factors in the objective kernel's chunk order (common.h): five arrays of
-// RVS_OBJ_CHMAX x RVS_OBJ_NT doubles behind the 5 ntp -- 1/h_u, 1/h_{u+1}, g_u, e_u, c_u
-// of row u = t CH + q at [q][t], zero where there is no such row
+// the same factors in the objective kernel's chunk order (common.h), behind the 5 ntp:
+// records {1/h_u, 1/h_{u+1}, g_u, e_u} of row u = t CH + q at [q][t] (RVS_OBJ_CHMAX x
+// RVS_OBJ_NT records of 32 bytes: a thread's row is two 16-byte requests, a wave's
+// contiguous), then the backward multipliers in pairs {c_u(2 j), c_u(2 j + 1)} at
+// [j][t]; zero where there is no such row
 __global__ void spline_factors_chunk_kernel(int ntp, double *__restrict__ fac) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= RVS_OBJ_FT_LEN) return;
   const int m = ntp - 2, CH = rvs_obj_chunk_len(m);
-  const int a = idx / (RVS_OBJ_NT * RVS_OBJ_CHMAX), rem = idx % (RVS_OBJ_NT * RVS_OBJ_CHMAX);
-  const int q = rem / RVS_OBJ_NT, t = rem % RVS_OBJ_NT;
+  constexpr int NREC = RVS_OBJ_NT * RVS_OBJ_CHMAX;
+  const double *g = fac, *e = fac + ntp, *cc = fac + 2 * ntp, *ih = fac + 4 * ntp;
+  int q, t, a;
+  if (idx < 4 * NREC) {
+    a = idx & 3;
+    q = (idx >> 2) / RVS_OBJ_NT;
+    t = (idx >> 2) % RVS_OBJ_NT;
+  } else {
+    const int r = idx - 4 * NREC;
+    a = 4;
+    t = (r >> 1) % RVS_OBJ_NT;
+    q = 2 * ((r >> 1) / RVS_OBJ_NT) + (r & 1);
+  }
   const int u = t * CH + q;
   double v = 0.0;
-  if (q < CH && u < m) {
-    const double *g = fac, *e = fac + ntp, *cc = fac + 2 * ntp, *ih = fac + 4 * ntp;
+  if (q < CH && u < m)
     v = a == 0 ? ih[u] : a == 1 ? ih[u + 1] : a == 2 ? g[u] : a == 3 ? e[u] : cc[u];
-  }
   fac[5 * (int64_t)ntp + idx] = v;
 }
 

@@ -76,7 +76,8 @@ extern "C" {
  *      template of 2 ntp < 8 (npoly (npoly + 3) / 2 + 1) knots
  *  11: rvs_spline_factors writes rvs_spline_factors_len(ntp) doubles (the five arrays
  *      of ntp, then the same factors in the objective kernel's chunk order); the cell
- *      record of rvs_objective_work_size grew by three doubles per (job, arm) */
+ *      record of rvs_objective_work_size grew by three doubles per (job, arm);
+ *      rvs_chisq_work_size(_g) grew by 2*G*npix doubles ({lam, pix} pairs) */
 #define RVS_ABI_VERSION 11
 int rvs_abi_version(void);
 

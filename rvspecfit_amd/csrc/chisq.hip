@@ -38,7 +38,9 @@
 // sum log e.
 // ---------------------------------------------------------------------------
 extern "C" int64_t rvs_chisq_work_size_g(int npix, int S, int G) {
-  return (int64_t)G * npix + 4ll * S * npix + 2ll * S;
+  // pix [G, npix]; {1/e^2, s/e^2} [S, npix]; {sum log e, D.D} [S]; {1/e, s/e} [S, npix];
+  // {lam, pix} [G, npix] (the fused objective reads a pixel's two in one request)
+  return (int64_t)G * npix + 4ll * S * npix + 2ll * S + 2ll * G * npix;
 }
 extern "C" int64_t rvs_chisq_work_size(int npix, int S) {
   return rvs_chisq_work_size_g(npix, S, 1);
@@ -59,9 +61,13 @@ __global__ void __launch_bounds__(256)
     const double lx0 = log(x0);
     const double *lg = lam + (int64_t)(s - S) * npix;
     double *pixa = work + (int64_t)(s - S) * npix;
-    for (int k = threadIdx.x; k < npix; k += 256)
-      pixa[k] = log_step ? (log(lg[k]) - lx0) * inv_step
-                         : (lg[k] - x0) * inv_step;
+    double2 *lp = X + (int64_t)S * npix + (int64_t)(s - S) * npix;
+    for (int k = threadIdx.x; k < npix; k += 256) {
+      const double pv = log_step ? (log(lg[k]) - lx0) * inv_step
+                                 : (lg[k] - x0) * inv_step;
+      pixa[k] = pv;
+      lp[k] = make_double2(lg[k], pv);
+    }
     return;
   }
   double lz = 0, dd = 0;

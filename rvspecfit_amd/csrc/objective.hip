@@ -569,6 +569,11 @@ __global__ void __launch_bounds__(OBJ_NT)
   const double x0 = S.knots[0], xlast = S.knots[N - 1];
   const double *g = T.factors, *e = T.factors + N, *cc = T.factors + 2 * N,
                *hh = T.factors + 3 * N, *ih = T.factors + 4 * N;
+  auto knot_pair = [&](int pos) {   // knots pos, pos + 1 (rows start on 8 bytes)
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    const d2u v = *reinterpret_cast<const d2u *>(S.knots + pos);
+    return make_double2(v.x, v.y);
+  };
 #if OBJ_SPLINE_T
   // The phases below are separated by barriers and the block is the only one on its
   // CU (two waves per SIMD): a load issued where its value is needed is a fully
@@ -848,8 +853,9 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
     for (int u = 0; u < PU; u++) {
       const int k = min(tid + u * OBJ_NT, npix - 1);
-      qlm[u] = AG.lam[k];
-      qwk[u] = S.log_step ? AG.pix[k] : 0.0;
+      const double2 lp = AG.lp[k];   // (wavelength and knot coordinate: one request)
+      qlm[u] = lp.x;
+      qwk[u] = lp.y;
       qsg[u] = sig[k];
     }
   }
@@ -1016,8 +1022,9 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
     for (int u = 0; u < PU; u++) {
       const int k = min(tid + u * OBJ_NT, npix - 1);
-      qlm[u] = AG.lam[k];
-      qwk[u] = S.log_step ? AG.pix[k] : 0.0;
+      const double2 lp = AG.lp[k];   // (wavelength and knot coordinate: one request)
+      qlm[u] = lp.x;
+      qwk[u] = lp.y;
       qsg[u] = sig[k];
     }
   }
@@ -1071,8 +1078,11 @@ __global__ void __launch_bounds__(OBJ_NT)
                            : (int)((qlm[u] - x0) * lin_inv_step);
       pos = min(max(pos, 0), N - 2);
       qps[u] = pos;
-      qkn[u] = S.knots[pos];
-      qhk[u] = hh[pos];
+      // (knot i and i + 1 in one 16-byte request; h = their difference, the
+      // subtraction the factors' own h came from: one request less per pixel)
+      const double2 kk = knot_pair(pos);
+      qkn[u] = kk.x;
+      qhk[u] = kk.y - kk.x;
       qik[u] = ih[pos];
     }
   }
@@ -1127,8 +1137,9 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int k = min(kb + u * OBJ_NT, npix - 1);
-          lm[u] = AG.lam[k];
-          wk[u] = S.log_step ? AG.pix[k] : 0.0;
+          const double2 lp = AG.lp[k];
+          lm[u] = lp.x;
+          wk[u] = lp.y;
           sg[u] = sig[k];
         }
 #pragma unroll
@@ -1138,8 +1149,9 @@ __global__ void __launch_bounds__(OBJ_NT)
                                : (int)((lm[u] - x0) * lin_inv_step);
           pos = min(max(pos, 0), N - 2);
           ps[u] = pos;
-          kn[u] = S.knots[pos];
-          hk[u] = hh[pos];
+          const double2 kk = knot_pair(pos);
+          kn[u] = kk.x;
+          hk[u] = kk.y - kk.x;
           ik[u] = ih[pos];
         }
       }

@@ -21,6 +21,7 @@
 // the rvs_chisq_prepare buffer
 struct ObjArmGrid {
   const double *lam, *pix, *polysT, *wbase;
+  const double2 *lp;   // {lam, pix} of the grid's pixels (rvs_chisq_prepare)
 };
 __device__ __forceinline__ ObjArmGrid obj_arm_grid(const rvs_point_arm &T, int s) {
   ObjArmGrid g;
@@ -30,6 +31,8 @@ __device__ __forceinline__ ObjArmGrid obj_arm_grid(const rvs_point_arm &T, int s
   g.pix = T.work + gi * T.npix;
   g.polysT = T.polysT + gi * T.polys_stride;
   g.wbase = T.work + (int64_t)G * T.npix;
+  g.lp = reinterpret_cast<const double2 *>(g.wbase + 4ll * T.S * T.npix + 2ll * T.S) +
+         gi * T.npix;
   return g;
 }
 

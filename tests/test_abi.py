@@ -44,7 +44,7 @@ def test_abi_version_and_work_size(lib):
     hdr = open(os.path.join(REPO, 'include', 'rvsgpu.h')).read()
     ver = int(re.search(r'#define RVS_ABI_VERSION (\d+)', hdr).group(1))
     assert lib.rvs_abi_version() == ver == _lib.ABI_VERSION
-    assert lib.rvs_chisq_work_size(100, 3) == 100 + 4 * 3 * 100 + 2 * 3
+    assert lib.rvs_chisq_work_size(100, 3) == 100 + 4 * 3 * 100 + 2 * 3 + 2 * 100
 
 
 def test_argument_validation_without_gpu(lib):

@@ -1300,7 +1300,10 @@ __global__ void __launch_bounds__(OBJ_NT)
 #if OBJ_PREFETCH
   // basis rows of the residual pass: requested before the Cholesky (one wave works
   // there, the other seven wait) instead of behind it
-  constexpr int RPF = (P <= 10) ? 6 : (P <= 12 ? 4 : 3);
+#ifndef OBJ_RPF10
+#define OBJ_RPF10 6
+#endif
+  constexpr int RPF = (P <= 10) ? OBJ_RPF10 : (P <= 12 ? 4 : 3);
   double qp[RPF][P];
   auto load_qp = [&]() {
 #pragma unroll

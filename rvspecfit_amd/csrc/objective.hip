@@ -26,9 +26,6 @@
 #endif
 #define OBJ_NW (OBJ_NT / 64)
 static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
-#ifndef OBJ_PREFETCH
-#define OBJ_PREFETCH 1   // factor / pixel loads ahead of the barriers (0: at their use)
-#endif
 #ifndef OBJ_SORT_MIN_JOBS
 #define OBJ_SORT_MIN_JOBS 512   // launches below this keep the caller's job order
 #endif
@@ -39,9 +36,6 @@ static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
 #endif
 // rows of a thread's Thomas chunk (at least the 12 the transfer coefficients need)
 #define OBJ_CHMAX ((8192 + OBJ_NT - 1) / OBJ_NT > 12 ? (8192 + OBJ_NT - 1) / OBJ_NT : 12)
-#ifndef OBJ_QP_LATE
-#define OBJ_QP_LATE 1
-#endif
 #ifndef OBJ_FIR_KMAX
 #define OBJ_FIR_KMAX 8   // widest rotational kernel (half width) of the register-window FIR
 #endif
@@ -50,32 +44,8 @@ static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
 // reads its inputs without range tests (0: tests, round 5's first form)
 #define OBJ_FIR_PAD OBJ_FIR_KMAX
 #endif
-#ifndef OBJ_GATHER_SWAP
-// gather: two register sets take turns (0: one copied into the other per trip).
-// 31.85 against 32.05 us per block on launches in cell order, 33.5 against 33.1 on
-// unordered ones (the optimiser's smaller launches); `--process 10000` equal
-#define OBJ_GATHER_SWAP 0
-#endif
-#ifndef OBJ_SPLINE_T
-// spline solve off the chunk-transposed factor arrays (common.h): right-hand sides and
-// both sweeps in the chunk owner's registers (0: round 5's first form -- right-hand
-// sides by strided rows through LDS)
-#define OBJ_SPLINE_T 1
-#endif
 #ifndef OBJ_FT_IN_FIR
 #define OBJ_FT_IN_FIR 1   // spline factor requests between the FIR's outputs (0: ahead)
-#endif
-#ifndef OBJ_FIR_W8
-#define OBJ_FIR_W8 1   // wide rotational kernels: eight outputs per trip (0: four)
-#endif
-#ifndef OBJ_CHOL_RIGHT
-#define OBJ_CHOL_RIGHT 1   // Cholesky on lanes: trailing updates (0: left-looking sums)
-#endif
-#ifndef OBJ_LDSGROUP
-#define OBJ_LDSGROUP 1   // LDS reads of a phase requested together (0: at their use)
-#endif
-#ifndef OBJ_WREG
-#define OBJ_WREG 1
 #endif
 #ifndef OBJ_FIR_REG
 #define OBJ_FIR_REG 1
@@ -214,11 +184,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   // ntp, checked by the launcher)
   constexpr bool RED_DYN = (P > 10) || (OBJ_NT > 512);
   __shared__ double red_static[RED_DYN ? 1 : OBJ_NW * (NV + 1)];
-#if OBJ_SPLINE_T
   __shared__ double edge_s[2][OBJ_NW][6];   // chunk coefficients across wave boundaries
-#else
-  __shared__ double edge_s[OBJ_NW][6];   // chunk coefficients across wave boundaries
-#endif
   __shared__ double coefs[P + 2];
   __shared__ double Lm[P][P + 1];
   __shared__ double ldv[P];
@@ -449,12 +415,7 @@ __global__ void __launch_bounds__(OBJ_NT)
         double a4[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-#if OBJ_WREG
           const double wv = wreg[u];
-#else   // (obj_bench A/B: round 4's form -- scalar test, weight from LDS at its use)
-          if (u >= nv) continue;
-          const double wv = PL.w[u];
-#endif
           a4[0] = fma(wv, (double)r[u].x, a4[0]);
           a4[1] = fma(wv, (double)r[u].y, a4[1]);
           a4[2] = fma(wv, (double)r[u].z, a4[2]);
@@ -464,18 +425,6 @@ __global__ void __launch_bounds__(OBJ_NT)
         for (int q = 0; q < 4; q++)
           bufA[k + q] = T.exp_flag ? exp(a4[q]) : a4[q];
       };
-#if OBJ_GATHER_SWAP
-      f4u rm[16];
-      for (int k = 4 * tid; k < N4;) {
-        const int k1 = k + 4 * OBJ_NT;
-        if (k1 < N4) issue(rm, k1);
-        blend(rn, k);
-        if (k1 >= N4) break;
-        k = k1 + 4 * OBJ_NT;
-        if (k < N4) issue(rn, k);
-        blend(rm, k1);
-      }
-#else
       for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
         f4u r[16];
 #pragma unroll
@@ -484,7 +433,6 @@ __global__ void __launch_bounds__(OBJ_NT)
         if (kn < N4) issue(rn, kn);
         blend(r, k);
       }
-#endif
     } else {
       for (int k = 4 * tid; k < N4; k += 4 * OBJ_NT) {
         double a4[4] = {0, 0, 0, 0};
@@ -574,7 +522,6 @@ __global__ void __launch_bounds__(OBJ_NT)
     const d2u v = *reinterpret_cast<const d2u *>(S.knots + pos);
     return make_double2(v.x, v.y);
   };
-#if OBJ_SPLINE_T
   // The phases below are separated by barriers and the block is the only one on its
   // CU (two waves per SIMD): a load issued where its value is needed is a fully
   // exposed L2 round trip.  The spline factors of this thread's CHUNK of rows (row
@@ -613,26 +560,6 @@ __global__ void __launch_bounds__(OBJ_NT)
 #pragma unroll
     for (int q = 0; q < OBJ_CHMAX; q++) ft_fetch(q);
   }
-#elif OBJ_PREFETCH
-  // The phases below are separated by barriers and the block is the only one on its
-  // CU (two waves per SIMD): a load issued where its value is needed is a fully
-  // exposed L2 round trip.  The spline factors of every row of this thread are
-  // requested HERE, ahead of the FIR (which needs few registers), the backward
-  // multipliers under the forward sweep, the model pass's pixel terms under the
-  // backward sweep.  Same loads, same arithmetic: the values are unchanged.
-  constexpr int RT = (8192 + OBJ_NT - 1) / OBJ_NT;   // rows of a thread (stride OBJ_NT)
-  double pf0[RT], pf1[RT], pfg[RT], pfe[RT];
-#pragma unroll
-  for (int r = 0; r < RT; r++) {
-    if (r * OBJ_NT < m) {
-      const int i = min(tid + r * OBJ_NT, m - 1);
-      pf0[r] = ih[i];
-      pf1[r] = ih[i + 1];
-      pfg[r] = g[i];
-      pfe[r] = e[i];
-    }
-  }
-#endif
   // ---- A6: rotational broadening bufA -> bufB (taps in bufC, built above) ----
   double *y = bufA, *dp = bufB;
   if (vsini) {
@@ -650,7 +577,6 @@ __global__ void __launch_bounds__(OBJ_NT)
       double tp[KM + 1], win[LCM + 2 * KM];
 #pragma unroll
       for (int mm = 0; mm <= KM; mm++) tp[mm] = (mm <= kmax) ? bufC[mm] : 0.0;
-#if OBJ_FIR_PAD
       // The inputs behind both ends of the template are zeros IN LDS (the pads): a
       // thread's window is LCM + 2 KM reads off one base address with nothing to test
       // (what lies behind the thread's own Lc + 2 KM is read and not used: the
@@ -673,29 +599,9 @@ __global__ void __launch_bounds__(OBJ_NT)
             sacc = fma(win[o + mm + KM], tp[mm < 0 ? -mm : mm], sacc);
           if (c0 + o < N) bufB[c0 + o] = sacc;
         }
-#if OBJ_SPLINE_T
         if constexpr (KM == 4)   // (kmax <= 4: the narrow window leaves the registers)
           if (ft_in_fir) ft_fetch(o);
-#endif
       }
-#else
-      const int c0 = tid * Lc, c1 = min(N, c0 + Lc);
-#pragma unroll
-      for (int i = 0; i < LCM + 2 * KM; i++) {
-        const int q = c0 - KM + i;
-        win[i] = (i < Lc + 2 * KM && q >= 0 && q < N) ? bufA[q] : 0.0;
-      }
-#pragma unroll
-      for (int o = 0; o < LCM; o++) {
-        if (c0 + o < c1) {
-          double sacc = 0;
-#pragma unroll
-          for (int mm = -KM; mm <= KM; mm++)
-            sacc = fma(win[o + mm + KM], tp[mm < 0 ? -mm : mm], sacc);
-          bufB[c0 + o] = sacc;
-        }
-      }
-#endif
     };
     const bool fir_reg = OBJ_FIR_REG && !copy && kmax <= OBJ_FIR_KMAX;
     if (fir_reg) {
@@ -752,9 +658,7 @@ __global__ void __launch_bounds__(OBJ_NT)
             if (o == 0 || i0 + o < c1) bufB[i0 + o] = sacc[o];
         };
         int i0 = c0;
-#if OBJ_FIR_W8
         for (; i0 + 8 <= c1; i0 += 8) fir_trip(std::integral_constant<int, 8>{}, i0);
-#endif
         for (; i0 < c1; i0 += 4) fir_trip(std::integral_constant<int, 4>{}, i0);
       }
       y = bufB;
@@ -763,7 +667,6 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
   }
   OBJ_T(2);
-#if OBJ_SPLINE_T
   // ---- A7 construct: natural spline of y ---------------------------------------
   // Thread t owns the rows [a0, a1) (CH of them): their right-hand sides
   //   6 ((y_{i+2} - y_{i+1}) / h_{i+1} - (y_{i+1} - y_i) / h_i) g_i
@@ -877,195 +780,6 @@ __global__ void __launch_bounds__(OBJ_NT)
     for (int q = 0; q < OBJ_CHMAX; q++)
       if (q < CH && a0 + q < a1) dp[a0 + q] = loc[q] + pr[q] * z_in;
   }
-#else
-  // ---- A7 construct: natural spline of y, windowed Thomas (template.hip) ---
-  double *ec = bufC;
-#if OBJ_PREFETCH
-  // right-hand sides: the three template values of a row are LDS reads; eight rows'
-  // worth requested together, then the arithmetic (row by row under its own `i < m`
-  // test each read was followed by its wait: thirteen exposed LDS round trips)
-  {
-    constexpr int RG = 8;
-#pragma unroll
-    for (int r0 = 0; r0 < RT; r0 += RG) {
-      if (r0 * OBJ_NT < m) {
-        double ya[RG], yb[RG], yc[RG];
-#pragma unroll
-        for (int g = 0; g < RG; g++) {
-          const int i = min(tid + (r0 + g) * OBJ_NT, m - 1);
-          if (OBJ_LDSGROUP) ya[g] = y[i], yb[g] = y[i + 1], yc[g] = y[i + 2];
-        }
-#pragma unroll
-        for (int g = 0; g < RG; g++) {
-          const int r = r0 + g, i = tid + r * OBJ_NT;
-          if (i < m) {
-            if (!OBJ_LDSGROUP) ya[g] = y[i], yb[g] = y[i + 1], yc[g] = y[i + 2];
-            const double s0 = (yb[g] - ya[g]) * pf0[r], s1 = (yc[g] - yb[g]) * pf1[r];
-            dp[i] = 6 * (s1 - s0) * pfg[r];
-            ec[i] = pfe[r];
-          }
-        }
-      }
-    }
-  }
-  OBJ_T(10);   // (debug) right-hand sides
-  double pfc[RT];   // backward multipliers: in flight under the forward sweep
-#pragma unroll
-  for (int r = 0; r < RT; r++)
-    if (r * OBJ_NT < m) pfc[r] = cc[min(tid + r * OBJ_NT, m - 1)];
-#else
-  // four rows per trip with their factor loads issued together (the factors
-  // come out of L2: one exposed round trip per trip instead of per row)
-  for (int i0 = tid; i0 < m; i0 += 4 * OBJ_NT) {
-    double f0[4], f1[4], fg[4], fe[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int i = min(i0 + c * OBJ_NT, m - 1);
-      f0[c] = ih[i];
-      f1[c] = ih[i + 1];
-      fg[c] = g[i];
-      fe[c] = e[i];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int i = i0 + c * OBJ_NT;
-      if (i < m) {
-        const double y1 = y[i + 1];
-        const double s0 = (y1 - y[i]) * f0[c], s1 = (y[i + 2] - y1) * f1[c];
-        dp[i] = 6 * (s1 - s0) * fg[c];
-        ec[i] = fe[c];
-      }
-    }
-  }
-#endif
-  __syncthreads();
-  // (the job's Doppler scalars, written barriers ago by one lane)
-  const double f = jobsc[0], shift = jobsc[1], lin_inv_step = jobsc[2];
-  // Chunked Thomas with chunk transfer coefficients.  Thread t owns rows
-  // [a0, a1) (>= 12 of them).  Both recurrences are linear in the value that
-  // enters the chunk: d_i = d0_i + P_i d_in with d0 the run from zero and P_i
-  // the running product of the multipliers, so one pass over the chunk yields
-  // (alpha, beta) = (d0, P) at its last row, and
-  //   d_in(t) = alpha(t-1) + beta(t-1) (alpha(t-2) + beta(t-2) alpha(t-3))
-  // to |beta|^3 <= (0.268^12)^3 = 3e-21 (the multipliers of a (log-)uniform
-  // grid tend to 2 - sqrt 3).  Against warming every chunk up over 32 extra
-  // rows this reads each row once instead of 3.5 times (the phase is bound by
-  // LDS bandwidth) and takes two barriers fewer.
-  const int CH = max(12, (m + OBJ_NT - 1) / OBJ_NT);  // <= OBJ_CHMAX (ntp <= 8192)
-  const int a0 = min(m, tid * CH), a1 = min(m, a0 + CH);
-  double loc[OBJ_CHMAX], pr[OBJ_CHMAX];
-  // value entering a chunk from `dir` = -1 (lower threads) or +1 (upper): the
-  // three nearest chunks' coefficients through wave shuffles, across a wave
-  // boundary through edge_s[] (static LDS)
-  auto chain3 = [&](double al, double be, int dir) -> double {
-    double av3[3], bv3[3];
-#pragma unroll
-    for (int k = 1; k <= 3; k++) {
-      av3[k - 1] = (dir < 0) ? __shfl_up(al, k, 64) : __shfl_down(al, k, 64);
-      bv3[k - 1] = (dir < 0) ? __shfl_up(be, k, 64) : __shfl_down(be, k, 64);
-    }
-    const int edge = (dir < 0) ? (63 - lane) : lane;  // 0..2: published lanes
-    if (edge < 3) {
-      edge_s[w][2 * edge] = al;
-      edge_s[w][2 * edge + 1] = be;
-    }
-    __syncthreads();
-    const int mine = (dir < 0) ? lane : (63 - lane);  // distance to the boundary
-#pragma unroll
-    for (int k = 1; k <= 3; k++) {
-      if (mine < k) {  // neighbour k lives in the adjacent wave
-        const int ww = w + dir;
-        const int sl = k - 1 - mine;  // its distance from that wave's boundary
-        const bool have = (ww >= 0 && ww < OBJ_NW);
-        av3[k - 1] = have ? edge_s[ww][2 * sl] : 0.0;
-        bv3[k - 1] = have ? edge_s[ww][2 * sl + 1] : 0.0;
-      }
-    }
-    return av3[0] + bv3[0] * (av3[1] + bv3[1] * av3[2]);
-  };
-  double d_in;
-  {
-    // (the chunk's multipliers and right-hand sides requested together ahead of the
-    // recurrence -- read inside it, under each row's own test, every row of the serial
-    // chain began with an exposed LDS round trip; loc / pr hold them until the
-    // recurrence overwrites them with its own values)
-#pragma unroll
-    for (int q = 0; q < OBJ_CHMAX; q++) {
-      const int i = min(a0 + q, m - 1);
-      if (OBJ_LDSGROUP) pr[q] = ec[i], loc[q] = dp[i];
-    }
-    double d = 0, pb = 1;
-#pragma unroll
-    for (int q = 0; q < OBJ_CHMAX; q++)
-      if (a0 + q < a1) {
-        if (!OBJ_LDSGROUP) pr[q] = ec[a0 + q], loc[q] = dp[a0 + q];
-        const double ei = pr[q];
-        d = loc[q] - ei * d;
-        pb = -ei * pb;
-        loc[q] = d;
-        pr[q] = pb;
-      }
-    OBJ_T(11);   // (debug) forward recurrence
-    d_in = chain3(d, pb, -1);  // (barrier inside: all reads of ec are done)
-    OBJ_T(12);   // (debug) chunk hand-over
-  }
-#if OBJ_PREFETCH
-#pragma unroll
-  for (int r = 0; r < RT; r++)
-    if (tid + r * OBJ_NT < m) ec[tid + r * OBJ_NT] = pfc[r];
-  // pixel terms of the model pass (first trip of its loop): under the backward sweep
-  constexpr int PU = 6;
-  double qlm[PU], qwk[PU];
-  double2 qsg[PU];
-  const bool cached = 2 * npix <= N;
-  if (cached) {
-#pragma unroll
-    for (int u = 0; u < PU; u++) {
-      const int k = min(tid + u * OBJ_NT, npix - 1);
-      const double2 lp = AG.lp[k];   // (wavelength and knot coordinate: one request)
-      qlm[u] = lp.x;
-      qwk[u] = lp.y;
-      qsg[u] = sig[k];
-    }
-  }
-#else
-  for (int i0 = tid; i0 < m; i0 += 4 * OBJ_NT) {
-    double fc[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) fc[c] = cc[min(i0 + c * OBJ_NT, m - 1)];
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-      if (i0 + c * OBJ_NT < m) ec[i0 + c * OBJ_NT] = fc[c];
-  }
-#endif
-#pragma unroll
-  for (int q = 0; q < OBJ_CHMAX; q++)
-    if (a0 + q < a1) loc[q] = loc[q] + pr[q] * d_in;  // d of the forward sweep
-  __syncthreads();
-  {
-#pragma unroll
-    for (int q = 0; q < OBJ_CHMAX; q++)
-      if (OBJ_LDSGROUP) pr[q] = ec[min(a0 + q, m - 1)];
-    double z = 0, pb = 1;
-#pragma unroll
-    for (int q = OBJ_CHMAX - 1; q >= 0; q--)
-      if (a0 + q < a1) {
-        if (!OBJ_LDSGROUP) pr[q] = ec[a0 + q];
-        const double ci = pr[q];
-        z = loc[q] - ci * z;
-        pb = -ci * pb;
-        loc[q] = z;
-        pr[q] = pb;
-      }
-    OBJ_T(13);   // (debug) multipliers to LDS, apply, backward recurrence
-    const double z_in = chain3(z, pb, +1);
-    OBJ_T(14);   // (debug) chunk hand-over
-#pragma unroll
-    for (int q = 0; q < OBJ_CHMAX; q++)
-      if (a0 + q < a1) dp[a0 + q] = loc[q] + pr[q] * z_in;
-  }
-#endif
-#if OBJ_PREFETCH
   // ... and the knot terms of those pixels (their interval index needs the job's
   // velocity and the prefetched pixel terms only): in flight across the barrier
   double qkn[PU], qhk[PU], qik[PU];
@@ -1086,7 +800,6 @@ __global__ void __launch_bounds__(OBJ_NT)
       qik[u] = ih[pos];
     }
   }
-#endif
   __syncthreads();
   OBJ_T(3);
   // dp[u] = z at knot u+1; spline piece i in powers of dl = x - x_i exactly as
@@ -1114,9 +827,6 @@ __global__ void __launch_bounds__(OBJ_NT)
   // of a thread with each round of loads issued together (pixel terms, then
   // the knot terms that depend on the interval index): two L2 round trips for
   // six pixels instead of two per pixel.
-#if !OBJ_PREFETCH
-  const bool cached = 2 * npix <= N;
-#endif
   double *tcache = bufC;
   if (cached) {
     constexpr int U = 6;
@@ -1124,7 +834,6 @@ __global__ void __launch_bounds__(OBJ_NT)
       double lm[U], wk[U], kn[U], hk[U], ik[U];
       double2 sg[U];
       int ps[U];
-#if OBJ_PREFETCH
       if (kb == tid) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -1132,7 +841,6 @@ __global__ void __launch_bounds__(OBJ_NT)
           ps[u] = qps[u], kn[u] = qkn[u], hk[u] = qhk[u], ik[u] = qik[u];
         }
       } else
-#endif
       {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -1297,13 +1005,10 @@ __global__ void __launch_bounds__(OBJ_NT)
   }
   __syncthreads();
   OBJ_T(9);   // (debug) fold over the waves
-#if OBJ_PREFETCH
   // basis rows of the residual pass: requested before the Cholesky (one wave works
   // there, the other seven wait) instead of behind it
-#ifndef OBJ_RPF10
-#define OBJ_RPF10 6
-#endif
-  constexpr int RPF = (P <= 10) ? OBJ_RPF10 : (P <= 12 ? 4 : 3);
+  // (6, 4, 3 or 2 pixels ahead at P = 10: no measurable difference)
+  constexpr int RPF = (P <= 10) ? 6 : (P <= 12 ? 4 : 3);
   double qp[RPF][P];
   auto load_qp = [&]() {
 #pragma unroll
@@ -1316,12 +1021,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   // (wave 0 requests its rows behind the factorisation: 8 waves x 30 16-byte loads
   // take the CU's address pipe ~1.5 us to accept, and the chain everybody waits for
   // would start behind them)
-#if OBJ_QP_LATE
   if (w != 0) load_qp();
-#else
-  load_qp();
-#endif
-#endif
   if (w == 0) {
     // Cholesky + the two triangular solves with ROW i on lane i (i < P):
     // left-looking, sums over q ascending as in the in-lane version of the
@@ -1347,7 +1047,6 @@ __global__ void __launch_bounds__(OBJ_NT)
     double dg = 1.0, rdg = 1.0;
 #pragma unroll
     for (int jj = 0; jj < P; jj++) {
-#if OBJ_CHOL_RIGHT
       // right-looking: row[jj] already carries a_i,jj - sum_{q < jj} L_iq L_jj,q -- the
       // products of the left-looking form, subtracted in the same order (q ascending),
       // each as soon as column q existed: the trailing updates of a column are
@@ -1355,11 +1054,6 @@ __global__ void __launch_bounds__(OBJ_NT)
       // reciprocal square root and one multiplication instead of jj dependent FMAs
       // behind it (45 in all at P = 10).  Same operations per entry: the same bits.
       const double sum = row[jj];
-#else
-      double sum = row[jj];
-#pragma unroll
-      for (int q = 0; q < jj; q++) sum -= row[q] * bcast(row[q], jj);  // L[jj][q]
-#endif
       // every lane runs the same instructions; lane jj's results are the ones
       // that count
       // d = sqrt(sum) and 1 / d from ONE reciprocal square root (hardware
@@ -1382,14 +1076,10 @@ __global__ void __launch_bounds__(OBJ_NT)
       const double rdj = bcast(rd, jj);
       row[jj] = (lane == jj) ? d : sum * rdj;
       Lm[i][jj] = row[jj];  // mirror for the back-substitution (column reads)
-#if OBJ_CHOL_RIGHT
 #pragma unroll
       for (int k = jj + 1; k < P; k++) row[k] -= row[jj] * bcast(row[jj], k);  // L[k][jj]
-#endif
     }
-#if OBJ_PREFETCH && OBJ_QP_LATE
     load_qp();
-#endif
     // log of the diagonal: all rows at once (not one per column of the loop)
     if (lane < P) ldv[lane] = log(dg);
     // L y = v, column by column: y_q from lane q, the rows below take their share
@@ -1439,18 +1129,16 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
   };
   int kres = tid;
-#if OBJ_PREFETCH
   // (the model / data values of those pixels: requested together, see the right-hand
   // sides above)
   double tev[RPF], dkv[RPF];
 #pragma unroll
   for (int u = 0; u < RPF; u++)
-    if (OBJ_LDSGROUP) te_dk(min(tid + u * OBJ_NT, npix - 1), tev[u], dkv[u]);
+    te_dk(min(tid + u * OBJ_NT, npix - 1), tev[u], dkv[u]);
 #pragma unroll
   for (int u = 0; u < RPF; u++) {
     const int k = tid + u * OBJ_NT;
     if (k < npix) {
-      if (!OBJ_LDSGROUP) te_dk(k, tev[u], dkv[u]);
       const double te = tev[u], dk = dkv[u];
       double mdl = 0;
 #pragma unroll
@@ -1460,7 +1148,6 @@ __global__ void __launch_bounds__(OBJ_NT)
     }
   }
   kres = tid + RPF * OBJ_NT;
-#endif
   for (int k = kres; k < npix; k += OBJ_NT) {
     double te, dk;
     te_dk(k, te, dk);

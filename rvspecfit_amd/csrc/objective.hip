@@ -10,10 +10,16 @@
 // arm, which is why this only exists on a 160-KB-LDS part):
 //   A  <- polylinear gather of the 2^ndim float32 rows + exp     (A3, A5)
 //   B  <- rotational-broadening FIR of A, taps built in C        (A6)
-//   dp,ec <- windowed Thomas solve of the natural spline of y    (A7 construct)
+//   dp <- natural spline of y: every thread solves a chunk of rows in registers
+//         (factors from rvs_spline_factors' chunk-ordered copy), chunks joined by
+//         their transfer coefficients                            (A7 construct)
 //   chi^2 <- threads = pixels: spline value from (y, z) on the fly, normal
 //         equations per lane, wave butterflies + fixed-order fold, Cholesky,
 //         explicit residual norm                                  (A7 eval, A10, A11)
+// At two waves per SIMD every vector instruction costs the block the same ~2 ns and
+// every vector-memory request of a burst ~45 ns whatever it carries: the
+// kernel is written to the COUNT of both -- no per-element range tests (zero pads in
+// LDS), scalars of the job computed by one lane, factors as 32-byte records.
 // No spline record ever goes to HBM.  Each phase repeats the arithmetic of the
 // stand-alone kernel it replaces (template.hip, chisq.hip), so the values agree
 // to rounding (tests/test_gpu_parity.py::test_objective_fused).
@@ -41,7 +47,7 @@ static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
 #endif
 #ifndef OBJ_FIR_PAD
 // doubles of zeros kept on both sides of the template buffer: the register-window FIR
-// reads its inputs without range tests (0: tests, round 5's first form)
+// reads its inputs without range tests
 #define OBJ_FIR_PAD OBJ_FIR_KMAX
 #endif
 #ifndef OBJ_FT_IN_FIR
@@ -50,7 +56,6 @@ static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
 #ifndef OBJ_FIR_REG
 #define OBJ_FIR_REG 1
 #endif
-#define OBJ_W 32  // warm-up rows of the windowed recurrences (see template.hip)
 
 #ifdef RVS_OBJ_TIMING
 // debug build only (tools/perf/obj_phases.sh): clock budget of the phases

@@ -42,9 +42,6 @@ static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
 #endif
 // rows of a thread's Thomas chunk (at least the 12 the transfer coefficients need)
 #define OBJ_CHMAX ((8192 + OBJ_NT - 1) / OBJ_NT > 12 ? (8192 + OBJ_NT - 1) / OBJ_NT : 12)
-#ifndef OBJ_FIR_KMAX
-#define OBJ_FIR_KMAX 8   // widest rotational kernel (half width) of the register-window FIR
-#endif
 #ifndef OBJ_FIR_PAD
 // doubles of zeros kept on both sides of the template buffer: the register-window FIR
 // reads its inputs without range tests
@@ -89,6 +86,7 @@ __global__ void __launch_bounds__(OBJ_LOC_NT)
     objective_locate_kernel(ObjArms A, const double *__restrict__ params, int J,
                             const int32_t *__restrict__ live,
                             const double *__restrict__ vel,
+                            const double *__restrict__ vsini, double eps_ld,
                             double *__restrict__ loc) {
   __shared__ PolyLoc PL;
   const rvs_objective_arm &T = A.a[blockIdx.y];
@@ -108,6 +106,34 @@ __global__ void __launch_bounds__(OBJ_LOC_NT)
     mi[1] = PL.nearest;
   } else if (tid == 64) {   // (another wave, beside the record's stores)
     obj_job_scalars(T.pt, vel[j], r + 2 * OBJ_LOC_NV + 2);
+  }
+  // The taps of a narrow rotational kernel (half width <= OBJ_FIR_KMAX: what the
+  // optimiser's jobs have on the DESI lattice up to ~150 km/s): in the objective
+  // block their construction -- an asin and a sqrt per primitive, ~400 dependent
+  // instructions on a dozen lanes behind three barriers -- sat between the first
+  // vertex rows' request and the gather, longer than those rows take to arrive.
+  // Same functions, same order of the sum (one wave's butterfly; the block's other
+  // waves add zeros): the same taps.
+  __shared__ double tpk[2][OBJ_FIR_KMAX + 3];
+  double R = 0;
+  bool refused = false;
+  const int kmax = vsini ? obj_rot_kmax(T, vsini[j], R, refused) : 0;
+  if (kmax >= 1 && kmax <= OBJ_FIR_KMAX) {   // (the block's: no divergence)
+    const int l = tid - 128;
+    if (l >= 0 && l <= kmax + 2) {
+      const double x = fmin(fmax((l - 1) / R, -1.0), 1.0);
+      double k0, k1;
+      rot_prim(x, eps_ld, k0, k1);
+      tpk[0][l] = k0;
+      tpk[1][l] = k1;
+    }
+    __syncthreads();
+    if (l >= 0 && l < 64) {
+      const double ww = (l <= kmax) ? obj_rot_tap_raw(l, R, tpk[0], tpk[1]) : 0.0;
+      const double psum = wave_sum((l == 0) ? ww : 2 * ww);
+      const double inv = 1.0 / psum;
+      if (l <= kmax) r[OBJ_LOC_TAPS + l] = ww * inv;
+    }
   }
 }
 
@@ -318,20 +344,17 @@ __global__ void __launch_bounds__(OBJ_NT)
   bool copy = true;
   int kmax = 0;
   if (vsini) {
-    const double vs = vsini[j];
-    const double R = (vs / RVS_C_KMS) / T.lnstep;
-    copy = !(vs > 0) || (R < 1e-9);
-    if (!copy) {
-      kmax = (int)ceil(R + 1);
-      // (the kernel's primitives are staged in bufB as two runs of kmax + 3
-      // doubles: a kernel wider than that is refused like one wider than the
-      // template)
-      if (kmax >= N || 2 * (kmax + 3) > N) {
-        st_extra = RVS_ST_NONFINITE;
-        copy = true;
-      }
-    }
-    if (!copy) {
+    double R;
+    bool refused;
+    kmax = obj_rot_kmax(T, vsini[j], R, refused);
+    copy = kmax == 0;
+    if (refused) st_extra = RVS_ST_NONFINITE;
+    if (!copy && !FROMT && !INBLK && locrec && kmax <= OBJ_FIR_KMAX) {
+      // (the cell-search kernel built them: objective_locate_kernel; the FIR reads
+      // them behind the gather's barriers)
+      if (tid <= kmax)
+        bufC[tid] = (locrec + ((int64_t)blockIdx.y * J + j) * OBJ_LOC_REC)[OBJ_LOC_TAPS + tid];
+    } else if (!copy) {
       // The kernel's primitives (an asin and a sqrt each, ~150 dependent fp64
       // instructions) at the clipped points x_j = clip(j / R), j = -1 .. kmax+1,
       // ONE per thread: tap k needs them at j = k-1, k, k+1, and evaluated
@@ -349,17 +372,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       __syncthreads();
       double psum = 0;
       for (int k = tid; k <= kmax; k += OBJ_NT) {
-        double ww = 0;
-        // x_{k-1}, x_k, x_{k+1} are entries k, k+1, k+2
-        double lo = fmin(fmax(k / R, -1.0), 1.0),
-               hi = fmin(fmax((k + 1) / R, -1.0), 1.0);
-        if (hi > lo)   // rot_segment(lo, hi, -R, 1 + k)
-          ww += -R * (pk1[k + 2] - pk1[k + 1]) +
-                (1.0 + k) * (pk0[k + 2] - pk0[k + 1]);
-        lo = fmin(fmax((k - 1) / R, -1.0), 1.0);
-        hi = fmin(fmax(k / R, -1.0), 1.0);
-        if (hi > lo)   // rot_segment(lo, hi, R, 1 - k)
-          ww += R * (pk1[k + 1] - pk1[k]) + (1.0 - k) * (pk0[k + 1] - pk0[k]);
+        const double ww = obj_rot_tap_raw(k, R, pk0, pk1);
         bufC[k] = ww;
         psum += (k == 0) ? ww : 2 * ww;
       }
@@ -1314,7 +1327,7 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     if ((int64_t)J * narm <= rvs_opt(RVS_OPT_OBJ_INBLK_MAX)) pre = false;
     if (pre) {
       hipLaunchKernelGGL(objective_locate_kernel, grid, dim3(OBJ_LOC_NT), 0, st, A,
-                         params, J, live, vel, locbuf);
+                         params, J, live, vel, vsini, 0.6, locbuf);
       loc = locbuf;
       // from a few blocks per CU up: jobs in cell order (obj_sort = 0: a test
       // hook, tests/test_gpu_parity.py::test_objective_job_order)

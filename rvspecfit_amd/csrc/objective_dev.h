@@ -60,8 +60,46 @@ struct ObjTempl {
 // coalesced load.  Same poly_locate code: the same ids, weights and distances.
 #define OBJ_LOC_NV 16                      // grids of up to 4 dimensions
 // doubles: w[16], id[16], dist, {mode, nearest}, the job's Doppler scalars {f, shift,
-// 1 / linear step} (obj_job_scalars)
-#define OBJ_LOC_REC (2 * OBJ_LOC_NV + 5)
+// 1 / linear step} (obj_job_scalars), the normalised taps 0 .. kmax of a rotational
+// kernel of half width kmax <= OBJ_FIR_KMAX (obj_rot_taps)
+#ifndef OBJ_FIR_KMAX
+#define OBJ_FIR_KMAX 8   // widest rotational kernel (half width) of the register-window FIR
+#endif
+#define OBJ_LOC_TAPS (2 * OBJ_LOC_NV + 5)
+#define OBJ_LOC_REC (OBJ_LOC_TAPS + OBJ_FIR_KMAX + 1)
+
+// half width of a job's rotational kernel on the arm's template grid: 0 = none (no
+// rotation, or refused: `refused`), R = v sin i / c in template pixels
+__device__ __forceinline__ int obj_rot_kmax(const rvs_objective_arm &T, double vs,
+                                            double &R, bool &refused) {
+  R = (vs / RVS_C_KMS) / T.lnstep;
+  refused = false;
+  if (!(vs > 0) || (R < 1e-9)) return 0;
+  const int kmax = (int)ceil(R + 1);
+  // (the kernel's primitives are staged in a buffer of the template's length as two
+  // runs of kmax + 3 doubles: a kernel wider than that is refused like one wider than
+  // the template)
+  if (kmax >= T.ntp || 2 * (kmax + 3) > T.ntp) {
+    refused = true;
+    return 0;
+  }
+  return kmax;
+}
+// tap k (not yet normalised) from the primitives at the clipped points x_j = clip(j /
+// R), j = -1 .. kmax + 1, staged as entries j + 1 of pk0 / pk1 (rot_prim)
+__device__ __forceinline__ double obj_rot_tap_raw(int k, double R, const double *pk0,
+                                                  const double *pk1) {
+  double ww = 0;
+  // x_{k-1}, x_k, x_{k+1} are entries k, k+1, k+2
+  double lo = fmin(fmax(k / R, -1.0), 1.0), hi = fmin(fmax((k + 1) / R, -1.0), 1.0);
+  if (hi > lo)   // rot_segment(lo, hi, -R, 1 + k)
+    ww += -R * (pk1[k + 2] - pk1[k + 1]) + (1.0 + k) * (pk0[k + 2] - pk0[k + 1]);
+  lo = fmin(fmax((k - 1) / R, -1.0), 1.0);
+  hi = fmin(fmax(k / R, -1.0), 1.0);
+  if (hi > lo)   // rot_segment(lo, hi, R, 1 - k)
+    ww += R * (pk1[k + 1] - pk1[k]) + (1.0 - k) * (pk0[k + 1] - pk0[k]);
+  return ww;
+}
 
 // What a job's velocity turns into, the same for every pixel of the (job, arm): the
 // Doppler factor f = sqrt((1 - b) / (1 + b)) (spec_fit.py:707-727), the pixels' shift in

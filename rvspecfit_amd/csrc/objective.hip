@@ -118,6 +118,11 @@ __global__ void __launch_bounds__(OBJ_LOC_NT)
   double R = 0;
   bool refused = false;
   const int kmax = vsini ? obj_rot_kmax(T, vsini[j], R, refused) : 0;
+  if (tid == 192) {
+    int32_t *ri = reinterpret_cast<int32_t *>(r + OBJ_LOC_ROT);
+    ri[0] = kmax;
+    ri[1] = refused ? 1 : 0;
+  }
   if (kmax >= 1 && kmax <= OBJ_FIR_KMAX) {   // (the block's: no divergence)
     const int l = tid - 128;
     if (l >= 0 && l <= kmax + 2) {
@@ -221,6 +226,7 @@ __global__ void __launch_bounds__(OBJ_NT)
   __shared__ double ldv[P];
   __shared__ double red8[2 * OBJ_NW];
   __shared__ double jobsc[3];   // the job's Doppler scalars (obj_job_scalars)
+  __shared__ int rot_s[2];      // {kmax, refused} of its rotational kernel (the record's)
   const rvs_objective_arm &T = A.a[blockIdx.y];
   const int tid = threadIdx.x;
   // Job of this block.  With `perm` (the jobs of the launch in the order of their
@@ -275,6 +281,10 @@ __global__ void __launch_bounds__(OBJ_NT)
         PL.nearest = mi[1];
       } else if (tid >= 128 && tid < 131) {
         jobsc[tid - 128] = r[2 * OBJ_LOC_NV + 2 + tid - 128];
+      } else if (tid == 192) {
+        const int32_t *ri = reinterpret_cast<const int32_t *>(r + OBJ_LOC_ROT);
+        rot_s[0] = ri[0];
+        rot_s[1] = ri[1];
       }
       __syncthreads();
     } else if (INBLK) {
@@ -344,12 +354,19 @@ __global__ void __launch_bounds__(OBJ_NT)
   bool copy = true;
   int kmax = 0;
   if (vsini) {
-    double R;
+    double R = 0;
     bool refused;
-    kmax = obj_rot_kmax(T, vsini[j], R, refused);
+    const bool rec = !FROMT && !INBLK && locrec;
+    if (rec) {   // (two divisions per thread less: the cell-search kernel's values)
+      kmax = __builtin_amdgcn_readfirstlane(rot_s[0]);
+      refused = rot_s[1] != 0;
+      if (kmax > OBJ_FIR_KMAX) kmax = obj_rot_kmax(T, vsini[j], R, refused);   // (R)
+    } else {
+      kmax = obj_rot_kmax(T, vsini[j], R, refused);
+    }
     copy = kmax == 0;
     if (refused) st_extra = RVS_ST_NONFINITE;
-    if (!copy && !FROMT && !INBLK && locrec && kmax <= OBJ_FIR_KMAX) {
+    if (!copy && rec && kmax <= OBJ_FIR_KMAX) {
       // (the cell-search kernel built them: objective_locate_kernel; the FIR reads
       // them behind the gather's barriers)
       if (tid <= kmax)

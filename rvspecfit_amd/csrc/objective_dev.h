@@ -65,7 +65,8 @@ struct ObjTempl {
 #ifndef OBJ_FIR_KMAX
 #define OBJ_FIR_KMAX 8   // widest rotational kernel (half width) of the register-window FIR
 #endif
-#define OBJ_LOC_TAPS (2 * OBJ_LOC_NV + 5)
+#define OBJ_LOC_ROT (2 * OBJ_LOC_NV + 5)    // {kmax, refused} of the rotational kernel
+#define OBJ_LOC_TAPS (2 * OBJ_LOC_NV + 6)
 #define OBJ_LOC_REC (OBJ_LOC_TAPS + OBJ_FIR_KMAX + 1)
 
 // half width of a job's rotational kernel on the arm's template grid: 0 = none (no

@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(OBJ_ORD_NT)
     objective_order_kernel(const double *__restrict__ loc, int J,
                            const int32_t *__restrict__ live, int shift, int nb,
                            int32_t *__restrict__ perm) {
+  const int Jbound = J;
   if (live) J = min(J, live[0]);   // the jobs that count are the first live[0]
   __shared__ int hist[OBJ_ORD_NB];
   __shared__ int wsum[OBJ_ORD_NT / 64];
@@ -191,7 +192,27 @@ __global__ void __launch_bounds__(OBJ_ORD_NT)
     run += c;
   }
   __syncthreads();
-  for (int j = tid; j < J; j += OBJ_ORD_NT) perm[atomicAdd(&hist[key_of(j)], 1)] = j;
+  // Position `pos` of the sorted list goes to block x = 8 i + f, the i-th block of XCD f
+  // (blocks are dealt to the 8 XCDs round robin; XCD f works through the f-th
+  // contiguous eighth of the list, objective_kernel): the table is written by BLOCK
+  // NUMBER, so that a block finds its job with one load of an address it knows when it
+  // starts -- not live[0], then the list's entry at a position that depends on it.
+  // Blocks behind the live jobs read -1.
+  const int base8 = J >> 3, rem8 = J & 7;
+  for (int j = tid; j < J; j += OBJ_ORD_NT) {
+    const int pos = atomicAdd(&hist[key_of(j)], 1);
+    int f, i;
+    if (pos < rem8 * (base8 + 1)) {
+      f = pos / (base8 + 1);
+      i = pos % (base8 + 1);
+    } else {
+      const int q = pos - rem8 * (base8 + 1);
+      f = rem8 + q / base8;
+      i = q % base8;
+    }
+    perm[8 * i + f] = j;
+  }
+  for (int x = J + tid; x < Jbound; x += OBJ_ORD_NT) perm[x] = -1;
 }
 
 // INBLK: grids of more than 4 dimensions (no cell record: the search runs in
@@ -245,12 +266,14 @@ __global__ void __launch_bounds__(OBJ_NT)
   // need: a quarter of the blocks of a Nelder-Mead run computed values nobody read
   // (tools/perf/nm_waste.py: 1.39 launched slots per function value scipy counts).
   // Such a block ends here; the array strides stay those of J.
-  const int Jl = live ? min(J, live[0]) : J;
-  if (j >= Jl) return;
   if (perm) {
-    const int f = j & 7;
-    // (one value for the block: keep it in a scalar register)
-    j = __builtin_amdgcn_readfirstlane(perm[f * (Jl >> 3) + min(f, Jl & 7) + (j >> 3)]);
+    // (the order kernel's table by block number: -1 behind the live jobs; one value
+    // for the block, kept in a scalar register)
+    j = __builtin_amdgcn_readfirstlane(perm[j]);
+    if (j < 0) return;
+  } else {
+    const int Jl = live ? min(J, live[0]) : J;
+    if (j >= Jl) return;
   }
   const int lane = tid & 63, w = tid >> 6;
   const int N = T.ntp, m = N - 2;

@@ -47,6 +47,9 @@ static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
 // reads its inputs without range tests
 #define OBJ_FIR_PAD OBJ_FIR_KMAX
 #endif
+#ifndef OBJ_VROW_LANES
+#define OBJ_VROW_LANES 1   // row bases: one LDS read + v_readlane (0: a read per vertex)
+#endif
 #ifndef OBJ_FT_IN_FIR
 #define OBJ_FT_IN_FIR 1   // spline factor requests between the FIR's outputs (0: ahead)
 #endif
@@ -338,6 +341,19 @@ __global__ void __launch_bounds__(OBJ_NT)
   // ~25 vector instructions per load)
   const float *vrow[16];
   if (vec_gather) {
+#if OBJ_VROW_LANES
+    // (ONE LDS read: lane u of every wave takes vertex u's row number and forms the
+    // row's element offset; sixteen pairs of v_readlane with a constant lane hand them
+    // to the scalar side.  One read per vertex, each followed by its wait and two
+    // v_readfirstlane, was sixteen LDS round trips in a row ahead of the first request.)
+    const int64_t myrow = PL.id[OBJ_VTX(tid & 15)] * (int64_t)N;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)myrow, u);
+      const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(myrow >> 32), u);
+      vrow[u] = T.dats + (int64_t)(((uint64_t)hi << 32) | lo);
+    }
+#else
 #pragma unroll
     for (int u = 0; u < 16; u++) {
       const int64_t id = PL.id[OBJ_VTX(u)];
@@ -345,6 +361,7 @@ __global__ void __launch_bounds__(OBJ_NT)
       const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(id >> 32));
       vrow[u] = T.dats + (int64_t)(((uint64_t)hi << 32) | lo) * N;
     }
+#endif
   }
   if (vec_gather && 4 * tid < N4) {
 #pragma unroll

@@ -50,6 +50,11 @@ static_assert(OBJ_NT != 512 || (OBJ_NT == RVS_OBJ_NT), "chunk geometry");
 #ifndef OBJ_VROW_LANES
 #define OBJ_VROW_LANES 1   // row bases: one LDS read + v_readlane (0: a read per vertex)
 #endif
+#ifndef OBJ_FIR_CHUNKS
+// the register-window FIR works in the spline's chunks and hands its outputs over in
+// registers (0: its own chunks, a barrier and LDS reads in between)
+#define OBJ_FIR_CHUNKS 1
+#endif
 #ifndef OBJ_FT_IN_FIR
 #define OBJ_FT_IN_FIR 1   // spline factor requests between the FIR's outputs (0: ahead)
 #endif
@@ -637,6 +642,8 @@ __global__ void __launch_bounds__(OBJ_NT)
   }
   // ---- A6: rotational broadening bufA -> bufB (taps in bufC, built above) ----
   double *y = bufA, *dp = bufB;
+  bool fir_reg = false, fir_chunks = false;
+  double fy[OBJ_CHMAX + 2];   // (the FIR's outputs of this thread's spline chunk)
   if (vsini) {
     // Narrow kernels (kmax <= 8: v sin i up to ~150 km/s on the DESI template lattice)
     // keep the taps and the thread's input window [c0 - KM, c1 + KM) in registers: every
@@ -645,11 +652,20 @@ __global__ void __launch_bounds__(OBJ_NT)
     // ascending offsets; the offsets beyond kmax carry exact zero taps at both ends of
     // the chain, which leave the partial sum as it is -- the values are those of the
     // loop below (36.6 -> 35.1 us per block, same checksum).
+    fir_reg = OBJ_FIR_REG && !copy && kmax <= OBJ_FIR_KMAX;
+    // (the FIR's chunks are the spline's when 512 CH covers the template)
+    fir_chunks = OBJ_FIR_CHUNKS && fir_reg && OBJ_NT * CH >= N;
     auto fir_small = [&](auto km_c) {
       constexpr int KM = decltype(km_c)::value;
       constexpr int LCM = (8192 + OBJ_NT - 1) / OBJ_NT;
-      const int Lc = (N + OBJ_NT - 1) / OBJ_NT;
-      double tp[KM + 1], win[LCM + 2 * KM];
+      // A thread's outputs are the rows of its spline chunk (CH of them from t CH)
+      // and the two behind them: the chunk's right-hand sides then come out of THIS
+      // thread's registers (fy), and neither the barrier behind the FIR nor CH + 2 LDS
+      // reads stand between the last tap and the forward recurrence.  (The two extra
+      // outputs are the next thread's first two, computed twice and stored once.)
+      const int Lc = fir_chunks ? CH : (N + OBJ_NT - 1) / OBJ_NT;
+      constexpr int LX = OBJ_FIR_CHUNKS ? 2 : 0;
+      double tp[KM + 1], win[LCM + LX + 2 * KM];
 #pragma unroll
       for (int mm = 0; mm <= KM; mm++) tp[mm] = (mm <= kmax) ? bufC[mm] : 0.0;
       // The inputs behind both ends of the template are zeros IN LDS (the pads): a
@@ -664,21 +680,21 @@ __global__ void __launch_bounds__(OBJ_NT)
       const int c0 = min(N, tid * Lc);
       const double *wb = bufA + c0 - KM;
 #pragma unroll
-      for (int i = 0; i < LCM + 2 * KM; i++) win[i] = wb[i];   // (N >= 32: the launcher)
+      for (int i = 0; i < LCM + LX + 2 * KM; i++) win[i] = wb[i];   // (N >= 32: the launcher)
 #pragma unroll
-      for (int o = 0; o < LCM; o++) {
-        if (o < Lc) {
+      for (int o = 0; o < LCM + LX; o++) {
+        if (o < Lc + (fir_chunks ? 2 : 0)) {
           double sacc = 0;
 #pragma unroll
           for (int mm = -KM; mm <= KM; mm++)
             sacc = fma(win[o + mm + KM], tp[mm < 0 ? -mm : mm], sacc);
-          if (c0 + o < N) bufB[c0 + o] = sacc;
+          if (o < Lc && c0 + o < N) bufB[c0 + o] = sacc;
+          if (OBJ_FIR_CHUNKS) fy[o] = sacc;
         }
         if constexpr (KM == 4)   // (kmax <= 4: the narrow window leaves the registers)
-          if (ft_in_fir) ft_fetch(o);
+          if (o < LCM && ft_in_fir) ft_fetch(o);
       }
     };
-    const bool fir_reg = OBJ_FIR_REG && !copy && kmax <= OBJ_FIR_KMAX;
     if (fir_reg) {
       if (kmax <= 4)
         fir_small(std::integral_constant<int, 4>{});
@@ -688,7 +704,7 @@ __global__ void __launch_bounds__(OBJ_NT)
         fir_small(std::integral_constant<int, OBJ_FIR_KMAX>{});
       y = bufB;
       dp = bufA;
-      __syncthreads();
+      if (!fir_chunks) __syncthreads();
     }
     if (!copy && !fir_reg) {
       // Four consecutive outputs per thread and trip: at tap offset mm the four
@@ -801,9 +817,14 @@ __global__ void __launch_bounds__(OBJ_NT)
   {
     const double *yb = y + a0;
     double yv[OBJ_CHMAX + 2];
+    if (fir_chunks) {
 #pragma unroll
-    for (int q = 0; q < OBJ_CHMAX + 2; q++)
-      if (q < CH + 2) yv[q] = yb[q];
+      for (int q = 0; q < OBJ_CHMAX + 2; q++) yv[q] = fy[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < OBJ_CHMAX + 2; q++)
+        if (q < CH + 2) yv[q] = yb[q];
+    }
     double d = 0, pb = 1;
 #pragma unroll
     for (int q = 0; q < OBJ_CHMAX; q++)

@@ -1811,6 +1811,40 @@ def test_objective_fused_on_lower_dimensional_grids(cases, ndim):
     assert float(((c1 - c0).abs() / sc).max()) < 1e-11
 
 
+@pytest.mark.parametrize('ntp', [33, 262, 6215, 6658, 8192])
+def test_spline_factors_chunk_order(gpu, ntp):
+    """rvs_spline_factors lays the factors out a second time in the order the fused
+    objective kernel's 512 threads own their rows (csrc/common.h: CH rows per thread,
+    odd where it can be): records {1/h_u, 1/h_{u+1}, g_u, e_u} at [q][t] for row u =
+    t CH + q, then the backward multipliers in pairs of rows -- bit for bit the five
+    arrays in front of them, zero where there is no such row"""
+    lam = np.exp(np.linspace(np.log(3600.), np.log(5800.), ntp))
+    kn = torch.as_tensor(lam).to('cuda')
+    n = _lib.lib().rvs_spline_factors_len(ntp)
+    assert n == 5 * ntp + 5 * 8192
+    fac = torch.full((n, ), np.nan, dtype=torch.float64, device='cuda')
+    assert _lib.lib().rvs_spline_factors(_lib.ptr(kn), ntp, _lib.ptr(fac),
+                                         _lib.stream()) == 0
+    f = fac.cpu().numpy()
+    g, e, cc, hh, ih = (f[i * ntp:(i + 1) * ntp] for i in range(5))
+    np.testing.assert_array_equal(hh[:-1], np.diff(lam))
+    m = ntp - 2
+    ch = max(12, -(-m // 512))
+    if (ch | 1) <= 16:
+        ch |= 1
+    assert ch % 2 == 1 or ch == 16
+    rec = f[5 * ntp:5 * ntp + 4 * 8192].reshape(16, 512, 4)
+    ccp = f[5 * ntp + 4 * 8192:].reshape(8, 512, 2)
+    u = np.arange(512)[None, :] * ch + np.arange(16)[:, None]      # [q, t]
+    ok = (np.arange(16)[:, None] < ch) & (u < m)
+    uc = np.where(ok, u, 0)
+    for a, src in enumerate((ih[uc], ih[uc + 1], g[uc], e[uc])):
+        np.testing.assert_array_equal(rec[:, :, a], np.where(ok, src, 0.0))
+    want_c = np.where(ok, cc[uc], 0.0)                              # [q, t]
+    np.testing.assert_array_equal(ccp[:, :, 0], want_c[0::2])
+    np.testing.assert_array_equal(ccp[:, :, 1], want_c[1::2])
+
+
 @pytest.mark.parametrize('ntp', [31, 33, 64, 262, 263, 700])
 def test_objective_fused_short_templates(ntp):
     """template grids of a few dozen to a few hundred knots under the one-kernel

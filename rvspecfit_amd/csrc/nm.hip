@@ -885,6 +885,161 @@ __global__ void __launch_bounds__(NM_NT) nm_glue_update_kernel(NmGlue G, int jbo
   }
 }
 
+// ---------------------------------------------------------------------------
+// The two bookkeeping kernels above as TWO kernels each, for rounds of thousands of
+// rows: everything a row does for itself -- the value of its evaluation, its case,
+// the simplex update and ordering, the next round's test and point -- on as many
+// blocks as there are rows (`rows`), and the ordered compaction (lists in simplex
+// order, in place, as the one-block kernels leave them) behind it on one block that
+// only moves rows (`pack`).  At 5000 rows the one-block kernels take 160 and 75 us --
+// a fifth of a half's timeline, hidden only while the other half's objective kernel
+// runs.  Same operations per row, same order of the lists: the same state.  A row's
+// point waits in ITS OWN row of X1 / X2 (no other row reads that one) and its flag in
+// cases[]; the pack kernel reads a trip's rows into registers, waits for them, and
+// only then writes the packed positions (which lie at or before the rows read).
+// ---------------------------------------------------------------------------
+#define NM_ROWS_NT 256
+__global__ void __launch_bounds__(NM_ROWS_NT)
+    nm_glue_decide_rows_kernel(NmGlue G, int jbound) {
+  const int N = G.m.N;
+  const int J = min(G.m.counts[0], jbound);
+  const int j = blockIdx.x * NM_ROWS_NT + threadIdx.x;
+  if (j >= J) return;
+  const double fxr = glue_value(G, j);
+  G.m.F1[j] = fxr;
+  const int r = G.m.list1[j];
+  const double *s = G.m.sim + (int64_t)r * (N + 1) * N;
+  const double *f = G.m.fsim + (int64_t)r * (N + 1);
+  int c;
+  if (fxr < f[0])
+    c = 1;
+  else if (fxr < f[N - 1])
+    c = 0;
+  else if (fxr < f[N])
+    c = 2;
+  else
+    c = 3;
+  G.m.cases[j] = c;
+  if (c != 0) {
+    double *x2 = G.m.X2 + (int64_t)j * N;
+    for (int i = 0; i < N; i++) {
+      double xb = s[i];
+      for (int k = 1; k < N; k++) xb = xb + s[k * N + i];
+      xb = xb / N;
+      const double w = s[N * N + i];
+      if (c == 1)
+        x2[i] = (1 + 1.0 * 2.0) * xb - 1.0 * 2.0 * w;
+      else if (c == 2)
+        x2[i] = (1 + 0.5 * 1.0) * xb - 0.5 * 1.0 * w;
+      else
+        x2[i] = (1 - 0.5) * xb + 0.5 * w;
+    }
+  }
+}
+
+// rows [0, J) with flag(j) set move, in order, to the front of (list, X): X row j -> row
+// pos, list[pos] = list_in[j]; pos_out[j] = pos or -1 (nullable); returns the count
+template <typename FLAG>
+__device__ int nm_pack_rows(const NmGlue &G, int J, FLAG flag, const int32_t *list_in,
+                            int32_t *list_out, double *X, int32_t *pos_out, int *sh) {
+  const int N = G.m.N;
+  int base_out = 0;
+  for (int j0 = 0; j0 < J; j0 += NM_NT) {
+    const int j = j0 + threadIdx.x;
+    int go = 0, r = 0;
+    double xr[NM_MAXN];
+    if (j < J) {
+      go = flag(j);
+      r = list_in[j];
+      if (go)
+        for (int i = 0; i < N; i++) xr[i] = X[(int64_t)j * N + i];
+    }
+    // (the rows are in registers before any thread writes a packed position)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int tot;
+    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    if (pos_out && j < J) pos_out[j] = go ? pos : -1;
+    if (go) {
+      list_out[pos] = r;
+      double *x = X + (int64_t)pos * N;
+      for (int i = 0; i < N; i++) x[i] = xr[i];
+      map_row(G.P, pos, r, x);
+    }
+    base_out += tot;
+  }
+  return base_out;
+}
+
+__global__ void __launch_bounds__(NM_NT) nm_glue_decide_pack_kernel(NmGlue G, int jbound) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  const int J = min(G.m.counts[0], jbound);
+  const int32_t *cases = G.m.cases;
+  const int n = nm_pack_rows(G, J, [=](int j) { return cases[j] != 0 ? 1 : 0; },
+                             G.m.list1, G.m.list2, G.m.X2, G.m.pos2, sh);
+  if (threadIdx.x == 0) G.m.counts[1] = n;
+}
+
+__global__ void __launch_bounds__(NM_ROWS_NT)
+    nm_glue_update_rows_kernel(NmGlue G, int jbound) {
+  const int N = G.m.N;
+  const int J = min(G.m.counts[0], jbound);
+  const int j = blockIdx.x * NM_ROWS_NT + threadIdx.x;
+  if (j >= J) return;
+  const int r = G.m.list1[j];
+  double *s = G.m.sim + (int64_t)r * (N + 1) * N;
+  double *f = G.m.fsim + (int64_t)r * (N + 1);
+  const int c = G.m.cases[j];
+  const double fxr = G.m.F1[j];
+  const int p2 = G.m.pos2[j];
+  double f2 = __builtin_inf();
+  if (p2 >= 0) {   // (this row's second point: nobody else's)
+    f2 = glue_value(G, p2);
+    G.m.F2[p2] = f2;
+  }
+  bool take2 = false, taker = false;
+  if (c == 0)
+    taker = true;
+  else if (c == 1) {
+    if (f2 < fxr)
+      take2 = true;
+    else
+      taker = true;
+  } else if (c == 2)
+    take2 = (f2 <= fxr);
+  else
+    take2 = (f2 < f[N]);
+  G.m.nfev[r] += (c == 0) ? 1 : 2;
+  int go = 0;
+  double xr[NM_MAXN];
+  if (take2 || taker) {
+    const double *src = take2 ? (G.m.X2 + (int64_t)p2 * N) : (G.m.X1 + (int64_t)j * N);
+    for (int i = 0; i < N; i++) s[N * N + i] = src[i];
+    f[N] = take2 ? f2 : fxr;
+    nm_order(s, f, N);
+    G.m.nit[r] += 1;
+    go = glue_begin_row(G, r, xr);
+  } else {
+    G.m.flags[r] |= 4;  // shrink: parked until the host runs the shrink
+    atomicAdd(&G.m.counts[4], 1);
+  }
+  G.m.cases[j] = go;   // (the case is used up: the flag of the pack kernel)
+  if (go)
+    for (int i = 0; i < N; i++) G.m.X1[(int64_t)j * N + i] = xr[i];
+}
+
+__global__ void __launch_bounds__(NM_NT) nm_glue_update_pack_kernel(NmGlue G, int jbound) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  const int J = min(G.m.counts[0], jbound);
+  const int32_t *cases = G.m.cases;
+  const int n = nm_pack_rows(G, J, [=](int j) { return cases[j]; }, G.m.list1,
+                             G.m.list1, G.m.X1, nullptr, sh);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    G.m.counts[0] = n;
+    G.m.counts[3] = n;
+  }
+}
+
 static int nm_bucket(int n, int S) {
   // quantised launch bound (1/8 steps of the next power of two), as optimizer.py
   if (n <= 64) return S < 64 ? S : 64;
@@ -984,13 +1139,30 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
     const int jb = live;
     G.AO = obj_arm_out(o->scratch, o->narm, jb);
     for (int r = 0; r < sync_every; r++) {
+      // (from a few thousand rows up the bookkeeping is row-parallel + pack)
+      const bool split = jb >= rvs_opt(RVS_OPT_NM_SPLIT_MIN);
+      const dim3 rgrid((jb + NM_ROWS_NT - 1) / NM_ROWS_NT);
       rc = nm_objective_rows(o, jb, m->counts, st);
       if (rc) return rc;
-      hipLaunchKernelGGL(nm_glue_decide_kernel, dim3(1), dim3(NM_NT), 0, st, G, jb);
+      if (split) {
+        hipLaunchKernelGGL(nm_glue_decide_rows_kernel, rgrid, dim3(NM_ROWS_NT), 0, st,
+                           G, jb);
+        hipLaunchKernelGGL(nm_glue_decide_pack_kernel, dim3(1), dim3(NM_NT), 0, st, G,
+                           jb);
+      } else {
+        hipLaunchKernelGGL(nm_glue_decide_kernel, dim3(1), dim3(NM_NT), 0, st, G, jb);
+      }
       RVS_LAUNCH_CHECK();
       rc = nm_objective_rows(o, jb, m->counts + 1, st);
       if (rc) return rc;
-      hipLaunchKernelGGL(nm_glue_update_kernel, dim3(1), dim3(NM_NT), 0, st, G, jb);
+      if (split) {
+        hipLaunchKernelGGL(nm_glue_update_rows_kernel, rgrid, dim3(NM_ROWS_NT), 0, st,
+                           G, jb);
+        hipLaunchKernelGGL(nm_glue_update_pack_kernel, dim3(1), dim3(NM_NT), 0, st, G,
+                           jb);
+      } else {
+        hipLaunchKernelGGL(nm_glue_update_kernel, dim3(1), dim3(NM_NT), 0, st, G, jb);
+      }
       RVS_LAUNCH_CHECK();
       calls += 2;
       jobs += 2 * (int64_t)jb;

@@ -11,6 +11,7 @@ enum {
   RVS_OPT_OBJ_INBLK_MAX,  // launches of <= this many blocks search their cell in-block
   RVS_OPT_OBJ_SORT,       // objective jobs in grid-cell order
   RVS_OPT_NN_PIPE,        // MLP wide last layer: the kernel with the pipelined epilogue
+  RVS_OPT_NM_SPLIT_MIN,   // rounds of >= this many rows: row-parallel bookkeeping + pack
   RVS_OPT_COUNT
 };
 // current value (the table is filled from the environment on first use)

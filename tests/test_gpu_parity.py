@@ -1271,6 +1271,39 @@ def test_process_batch_equals_singles(cases, pcases, config):
             [rb['param_err'][k][i] for k in ('teff', 'logg', 'feh', 'alpha')])
 
 
+def test_nm_bookkeeping_rows_and_pack_equal_one_block(cases, pcases, config):
+    """rounds of thousands of rows run their bookkeeping as a row-parallel kernel and a
+    one-block pack (option nm_split_min, default 1024 rows); forced onto every round of
+    a small batch -- priors and shrinks included -- the optimiser's state is the
+    one-block kernels' to the bit: iterations, evaluations, end points"""
+    from rvspecfit_amd import vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    S = 70
+    rng = np.random.RandomState(5)
+    base = [_sds(cases, t) for t in ('c1', 'c3')]
+    batch = SpecBatch.from_specdata([base[i % 2] for i in range(S)])
+    for a in batch.arms:
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.03 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pd0 = dict(teff=rng.uniform(5000, 6800, S), logg=rng.uniform(1.5, 4.5, S),
+               feh=rng.uniform(-1.5, -0.1, S), alpha=rng.uniform(0, 0.4, S),
+               vsini=rng.uniform(1, 60, S))
+    out = []
+    for split_min in (1 << 30, 1):
+        with _lib.option('nm_split_min', split_min), vel_fit.single_stream():
+            out.append(vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                       config=dict(config)))
+    a, b = out
+    assert int(a['nm_nit'].max()) > 100
+    for k in ('vel', 'vel_err', 'chisq', 'vsini', 'nm_nit', 'nm_nfev', 'chisq_array',
+              'minimize_success'):
+        assert torch.equal(a[k], b[k]), k
+    for k in ('teff', 'logg', 'feh', 'alpha'):
+        assert torch.equal(a['param'][k], b['param'][k]), k
+        np.testing.assert_array_equal(a['param_err'][k], b['param_err'][k])
+    assert a['nm_rounds'] == b['nm_rounds']
+
+
 def test_process_two_halves_equal_one_batch(cases, pcases, config):
     """vel_fit.process fits a large SpecBatch as two interleaved halves on two
     streams (two host threads over the native round driver): every result is that

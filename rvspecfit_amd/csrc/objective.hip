@@ -84,12 +84,15 @@ extern "C" int rvs_dbg_read(unsigned long long *out) {
 #define OBJ_T(i)
 #endif
 
-// (256 threads: the cell search itself needs 20 of them, but a point outside the
-// grid -- an optimiser's simplex is there every few steps -- scans all ngrid
-// nodes for its nearest neighbour, and the launch lasts as long as its slowest
-// block: with one wave per block a 17 600-node library cost every objective
-// launch ~100 us, 1.59 against 1.41 s of Nelder-Mead per 2000 spectra)
-#define OBJ_LOC_NT 256
+// (Two waves: the cell search itself needs 20 threads, but a point outside the grid --
+// an optimiser's simplex is there every few steps -- scans all ngrid nodes for its
+// nearest neighbour, and the launch lasts as long as its slowest block: with one wave
+// per block a 17 600-node library cost every objective launch ~100 us.  Four waves, of
+// which two had nothing to do, halved the blocks a CU holds: `--process 10000` 3035
+// against 3120 spectra/s with two, the 17 600-node library equal.)
+#ifndef OBJ_LOC_NT
+#define OBJ_LOC_NT 128   // (two waves: the cell search, and the job's scalars and taps)
+#endif
 __global__ void __launch_bounds__(OBJ_LOC_NT)
     objective_locate_kernel(ObjArms A, const double *__restrict__ params, int J,
                             const int32_t *__restrict__ live,
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(OBJ_LOC_NT)
     int32_t *mi = reinterpret_cast<int32_t *>(r + 2 * OBJ_LOC_NV + 1);
     mi[0] = PL.mode;
     mi[1] = PL.nearest;
-  } else if (tid == 64) {   // (another wave, beside the record's stores)
+  } else if (tid == 64 + 32) {   // (the other wave, beside the record's stores)
     obj_job_scalars(T.pt, vel[j], r + 2 * OBJ_LOC_NV + 2);
   }
   // The taps of a narrow rotational kernel (half width <= OBJ_FIR_KMAX: what the
@@ -126,13 +129,13 @@ __global__ void __launch_bounds__(OBJ_LOC_NT)
   double R = 0;
   bool refused = false;
   const int kmax = vsini ? obj_rot_kmax(T, vsini[j], R, refused) : 0;
-  if (tid == 192) {
+  if (tid == 64 + 33) {
     int32_t *ri = reinterpret_cast<int32_t *>(r + OBJ_LOC_ROT);
     ri[0] = kmax;
     ri[1] = refused ? 1 : 0;
   }
   if (kmax >= 1 && kmax <= OBJ_FIR_KMAX) {   // (the block's: no divergence)
-    const int l = tid - 128;
+    const int l = tid - 64;   // (lanes of the second wave; 32 and 33 have other work)
     if (l >= 0 && l <= kmax + 2) {
       const double x = fmin(fmax((l - 1) / R, -1.0), 1.0);
       double k0, k1;

@@ -179,7 +179,17 @@ __global__ void __launch_bounds__(OBJ_ORD_NT)
     const int64_t k = (id < 0 ? 0 : id) >> shift;
     return (int)(k < nb ? k : nb - 1);
   };
-  for (int j = tid; j < J; j += OBJ_ORD_NT) atomicAdd(&hist[key_of(j)], 1);
+  // (a thread's keys stay in registers for the scatter pass -- up to 8 x 1024 jobs;
+  // read again behind that: two dependent loads per job)
+  constexpr int KPT = 8;
+  int keys[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; i++) {
+    const int j = tid + i * OBJ_ORD_NT;
+    keys[i] = (j < J) ? key_of(j) : 0;
+    if (j < J) atomicAdd(&hist[keys[i]], 1);
+  }
+  for (int j = tid + KPT * OBJ_ORD_NT; j < J; j += OBJ_ORD_NT) atomicAdd(&hist[key_of(j)], 1);
   __syncthreads();
   // exclusive scan: every thread owns nb / 1024 consecutive bins
   const int per = (nb + OBJ_ORD_NT - 1) / OBJ_ORD_NT;
@@ -210,8 +220,16 @@ __global__ void __launch_bounds__(OBJ_ORD_NT)
   // starts -- not live[0], then the list's entry at a position that depends on it.
   // Blocks behind the live jobs read -1.
   const int base8 = J >> 3, rem8 = J & 7;
-  for (int j = tid; j < J; j += OBJ_ORD_NT) {
-    const int pos = atomicAdd(&hist[key_of(j)], 1);
+  for (int jj = 0; jj * OBJ_ORD_NT < J; jj++) {
+    const int j = tid + jj * OBJ_ORD_NT;
+    if (j >= J) break;
+    int key = 0;
+    bool have = false;
+#pragma unroll
+    for (int i = 0; i < KPT; i++)
+      if (i == jj) key = keys[i], have = true;
+    if (!have) key = key_of(j);
+    const int pos = atomicAdd(&hist[key], 1);
     int f, i;
     if (pos < rem8 * (base8 + 1)) {
       f = pos / (base8 + 1);

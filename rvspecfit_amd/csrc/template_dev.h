@@ -16,9 +16,18 @@ struct GridDesc {
 // a[d] for a thread-dependent d without putting the array into scratch
 template <class T>
 __device__ __forceinline__ T sel_dim(const T (&a)[MAXDIM], int d) {
+  // (every element through a register first: as selects of loads the compiler turns the
+  // chain into ONE load at a selected offset -- which puts the whole descriptor into
+  // scratch memory, 168 bytes stored per lane of every block that carries one: 320 MB
+  // per launch of the optimiser's cell-search kernel, its whole duration)
   T v = a[0];
+  asm volatile("" : "+v"(v));
 #pragma unroll
-  for (int i = 1; i < MAXDIM; i++) v = (d == i) ? a[i] : v;
+  for (int i = 1; i < MAXDIM; i++) {
+    T ai = a[i];
+    asm volatile("" : "+v"(ai));
+    v = (d == i) ? ai : v;
+  }
   return v;
 }
 

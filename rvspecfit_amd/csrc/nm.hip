@@ -29,19 +29,25 @@
 
 #define NM_MAXN 8
 #define NM_NT 1024
+// the one-block kernels that hold a whole simplex in registers ((N + 1) N + N + 1
+// doubles: 98 VGPRs at N = 6, 162 at N = 8): eight waves, so that a wave has 256
+#ifndef NM_UNT
+#define NM_UNT 512
+#endif
 
 // counts layout (int32[8]): [0] jobs of list1, [1] jobs of list2, [2] length
 // of list3, [3] simplices stepping this round, [4] simplices parked for a shrink
 // flags: bit 0 active, bit 1 converged (success), bit 2 shrink pending
+template <int NT = NM_NT>
 __device__ __forceinline__ int block_excl_scan(int flag, int *total,
-                                               int *sh /*[NM_NT/64 + 1]*/) {
+                                               int *sh /*[NT/64 + 1]*/) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned long long m = __ballot(flag);
   const int pre = __popcll(m & ((1ull << lane) - 1ull));
   if (lane == 0) sh[w] = __popcll(m);
   __syncthreads();
   int off = 0, tot = 0;
-  for (int i = 0; i < NM_NT / 64; i++) {
+  for (int i = 0; i < NT / 64; i++) {
     const int c = sh[i];
     if (i < w) off += c;
     tot += c;
@@ -56,14 +62,31 @@ __device__ __forceinline__ int block_excl_scan(int flag, int *total,
 // loops unroll): sorting it in place in global memory is a chain of ~50
 // dependent loads/stores, which made the bookkeeping kernels latency-bound.
 template <int N>
-__device__ void nm_order_t(double *gsim, double *gf) {
-  double s[N + 1][N], f[N + 1];
+__device__ __forceinline__ void nm_load_regs(const double *__restrict__ gs,
+                                             const double *__restrict__ gf,
+                                             double (&s)[N + 1][N], double (&f)[N + 1]) {
 #pragma unroll
   for (int a = 0; a <= N; a++) {
     f[a] = gf[a];
 #pragma unroll
-    for (int i = 0; i < N; i++) s[a][i] = gsim[a * N + i];
+    for (int i = 0; i < N; i++) s[a][i] = gs[a * N + i];
   }
+}
+
+template <int N>
+__device__ __forceinline__ void nm_store_regs(double *gs, double *gf,
+                                              const double (&s)[N + 1][N],
+                                              const double (&f)[N + 1]) {
+#pragma unroll
+  for (int a = 0; a <= N; a++) {
+    gf[a] = f[a];
+#pragma unroll
+    for (int i = 0; i < N; i++) gs[a * N + i] = s[a][i];
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void nm_sort_regs(double (&s)[N + 1][N], double (&f)[N + 1]) {
 #pragma unroll
   for (int a = 1; a <= N; a++) {
     const double fa = f[a];
@@ -96,12 +119,14 @@ __device__ void nm_order_t(double *gsim, double *gf) {
       }
     }
   }
-#pragma unroll
-  for (int a = 0; a <= N; a++) {
-    gf[a] = f[a];
-#pragma unroll
-    for (int i = 0; i < N; i++) gsim[a * N + i] = s[a][i];
-  }
+}
+
+template <int N>
+__device__ void nm_order_t(double *gsim, double *gf) {
+  double s[N + 1][N], f[N + 1];
+  nm_load_regs<N>(gsim, gf, s, f);
+  nm_sort_regs<N>(s, f);
+  nm_store_regs<N>(gsim, gf, s, f);
 }
 
 __device__ void nm_order(double *sim, double *f, int N) {
@@ -120,17 +145,9 @@ __device__ void nm_order(double *sim, double *f, int N) {
 // termination test and reflection point of one simplex, all loads up front
 // (N compile-time); returns 1 when converged
 template <int N>
-__device__ __forceinline__ int nm_begin_row(const double *__restrict__ gs,
-                                            const double *__restrict__ gf,
-                                            double xatol, double fatol,
-                                            double *xr) {
-  double s[N + 1][N], f[N + 1];
-#pragma unroll
-  for (int k = 0; k <= N; k++) {
-    f[k] = gf[k];
-#pragma unroll
-    for (int i = 0; i < N; i++) s[k][i] = gs[k * N + i];
-  }
+__device__ __forceinline__ int nm_test_regs(const double (&s)[N + 1][N],
+                                            const double (&f)[N + 1], double xatol,
+                                            double fatol, double *xr) {
   double dx = 0, df = 0;
   bool anynan = (f[0] != f[0]);
 #pragma unroll
@@ -154,6 +171,16 @@ __device__ __forceinline__ int nm_begin_row(const double *__restrict__ gs,
     xr[i] = (1 + 1.0) * xb - 1.0 * s[N][i];
   }
   return 0;
+}
+
+template <int N>
+__device__ __forceinline__ int nm_begin_row(const double *__restrict__ gs,
+                                            const double *__restrict__ gf,
+                                            double xatol, double fatol,
+                                            double *xr) {
+  double s[N + 1][N], f[N + 1];
+  nm_load_regs<N>(gs, gf, s, f);
+  return nm_test_regs<N>(s, f, xatol, fatol, xr);
 }
 
 __global__ void __launch_bounds__(NM_NT)
@@ -528,23 +555,31 @@ __device__ __forceinline__ void map_row(const MapP &P, int j, int r,
   }
   bool isbad = (v > P.max_vel) || (v < P.min_vel);
   double p[NM_MAXN];
-  for (int i = 0; i < ndim; i++) {
+#pragma unroll
+  for (int i = 0; i < NM_MAXN; i++) {   // (p[] in registers: static indices)
+    if (i >= ndim) break;
     p[i] = (P.M.src[i] >= 0) ? x[P.M.src[i]] : P.fixed[(int64_t)r * ndim + i];
     if (!(fabs(p[i]) <= 1.79e308)) isbad = true;
   }
   if (isbad) {
     v = 0;
-    for (int i = 0; i < ndim; i++) p[i] = P.safe[(int64_t)r * ndim + i];
+#pragma unroll
+    for (int i = 0; i < NM_MAXN; i++)
+      if (i < ndim) p[i] = P.safe[(int64_t)r * ndim + i];
   }
   if (P.prior_mean)
-    for (int i = 0; i < ndim; i++) {
+#pragma unroll
+    for (int i = 0; i < NM_MAXN; i++) {
+      if (i >= ndim) break;
       const double d = (P.prior_mean[(int64_t)r * ndim + i] - p[i]) *
                        P.prior_isig[(int64_t)r * ndim + i];
       pen += d * d;
     }
   P.job_spec[j] = r;
   P.vel[j] = v;
-  for (int i = 0; i < ndim; i++) P.params[(int64_t)j * ndim + i] = p[i];
+#pragma unroll
+  for (int i = 0; i < NM_MAXN; i++)
+    if (i < ndim) P.params[(int64_t)j * ndim + i] = p[i];
   P.extra[j] = pen;
   P.bad[j] = isbad ? 1 : 0;
 }
@@ -739,20 +774,81 @@ __device__ __forceinline__ int glue_begin_row(const NmGlue &G, int r, double *xr
   return 1;
 }
 
-__global__ void __launch_bounds__(NM_NT) nm_glue_begin_kernel(NmGlue G) {
-  __shared__ int sh[NM_NT / 64 + 1];
+// nm_update_kernel's accepted point + nm_order + nm_begin_kernel's test of simplex r on
+// ONE copy of the simplex in registers: the point becomes row N, the rows are ordered
+// and stored, and the next round's test and reflection point come off the same
+// registers -- the same operations on the same values as the three steps through
+// memory (store row N; load, sort, store; load, test), two round trips shorter.
+template <int N>
+__device__ __forceinline__ int glue_accept_row_t(const NmGlue &G, int r, double *gs,
+                                                 double *gf,
+                                                 const double *__restrict__ src,
+                                                 double fnew, double *xr) {
+  double s[N + 1][N], f[N + 1];
+#pragma unroll
+  for (int a = 0; a < N; a++) {
+    f[a] = gf[a];
+#pragma unroll
+    for (int i = 0; i < N; i++) s[a][i] = gs[a * N + i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) s[N][i] = src[i];
+  f[N] = fnew;
+  nm_sort_regs<N>(s, f);
+  nm_store_regs<N>(gs, gf, s, f);
+  const int nit = G.m.nit[r] + 1;
+  G.m.nit[r] = nit;
+  // (glue_begin_row's tests, in its order)
+  int32_t *flags = G.m.flags;
+  const int fl = flags[r];
+  if ((fl & 5) != 1) return 0;
+  if (nit >= G.maxiter) {
+    flags[r] = fl & ~1;
+    return 0;
+  }
+  if (nm_test_regs<N>(s, f, G.xatol, G.fatol, xr)) {
+    flags[r] = (fl & ~1) | 2;
+    return 0;
+  }
+  return 1;
+}
+
+__device__ __forceinline__ int glue_accept_row(const NmGlue &G, int r, double *s,
+                                               double *f, const double *src,
+                                               double fnew, double *xr) {
+  switch (G.m.N) {
+    case 1: return glue_accept_row_t<1>(G, r, s, f, src, fnew, xr);
+    case 2: return glue_accept_row_t<2>(G, r, s, f, src, fnew, xr);
+    case 3: return glue_accept_row_t<3>(G, r, s, f, src, fnew, xr);
+    case 4: return glue_accept_row_t<4>(G, r, s, f, src, fnew, xr);
+    case 5: return glue_accept_row_t<5>(G, r, s, f, src, fnew, xr);
+    case 6: return glue_accept_row_t<6>(G, r, s, f, src, fnew, xr);
+    case 7: return glue_accept_row_t<7>(G, r, s, f, src, fnew, xr);
+    default: return glue_accept_row_t<8>(G, r, s, f, src, fnew, xr);
+  }
+}
+
+// row i < N of xr -> x (xr lives in registers: no indexing by a loop variable)
+__device__ __forceinline__ void nm_put_row(double *x, const double *xr, int N) {
+#pragma unroll
+  for (int i = 0; i < NM_MAXN; i++)
+    if (i < N) x[i] = xr[i];
+}
+
+__global__ void __launch_bounds__(NM_UNT) nm_glue_begin_kernel(NmGlue G) {
+  __shared__ int sh[NM_UNT / 64 + 1];
   const int S = G.m.S, N = G.m.N;
   int base_out = 0;
-  for (int r0 = 0; r0 < S; r0 += NM_NT) {
+  for (int r0 = 0; r0 < S; r0 += NM_UNT) {
     const int r = r0 + threadIdx.x;
     double xr[NM_MAXN];
     const int go = (r < S) ? glue_begin_row(G, r, xr) : 0;
     int tot;
-    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    const int pos = base_out + block_excl_scan<NM_UNT>(go, &tot, sh);
     if (go) {
       G.m.list1[pos] = r;
       double *x = G.m.X1 + (int64_t)pos * N;
-      for (int i = 0; i < N; i++) x[i] = xr[i];
+      nm_put_row(x, xr, N);
       map_row(G.P, pos, r, x);
     }
     base_out += tot;
@@ -819,16 +915,16 @@ __global__ void __launch_bounds__(NM_NT) nm_glue_decide_kernel(NmGlue G, int jbo
   if (threadIdx.x == 0) G.m.counts[1] = base_out;
 }
 
-__global__ void __launch_bounds__(NM_NT) nm_glue_update_kernel(NmGlue G, int jbound) {
-  __shared__ int sh[NM_NT / 64 + 1];
+__global__ void __launch_bounds__(NM_UNT) nm_glue_update_kernel(NmGlue G, int jbound) {
+  __shared__ int sh[NM_UNT / 64 + 1];
   __shared__ int parked;
   const int N = G.m.N;
   const int J = min(G.m.counts[0], jbound), J2 = min(G.m.counts[1], jbound);
   if (threadIdx.x == 0) parked = 0;
-  for (int p = threadIdx.x; p < J2; p += NM_NT) G.m.F2[p] = glue_value(G, p);
+  for (int p = threadIdx.x; p < J2; p += NM_UNT) G.m.F2[p] = glue_value(G, p);
   __syncthreads();
   int base_out = 0;
-  for (int j0 = 0; j0 < J; j0 += NM_NT) {
+  for (int j0 = 0; j0 < J; j0 += NM_UNT) {
     const int j = j0 + threadIdx.x;
     int go = 0, r = 0;
     double xr[NM_MAXN];
@@ -856,23 +952,19 @@ __global__ void __launch_bounds__(NM_NT) nm_glue_update_kernel(NmGlue G, int jbo
       if (take2 || taker) {
         const double *src = take2 ? (G.m.X2 + (int64_t)p2 * N)
                                   : (G.m.X1 + (int64_t)j * N);
-        for (int i = 0; i < N; i++) s[N * N + i] = src[i];
-        f[N] = take2 ? f2 : fxr;
-        nm_order(s, f, N);
-        G.m.nit[r] += 1;
         // ... and the next round's test of this simplex (nm_begin_kernel)
-        go = glue_begin_row(G, r, xr);
+        go = glue_accept_row(G, r, s, f, src, take2 ? f2 : fxr, xr);
       } else {
         G.m.flags[r] |= 4;  // shrink: parked until the host runs the shrink
         atomicAdd(&parked, 1);
       }
     }
     int tot;
-    const int pos = base_out + block_excl_scan(go, &tot, sh);
+    const int pos = base_out + block_excl_scan<NM_UNT>(go, &tot, sh);
     if (go) {   // pos <= j: rows of this trip were read above, later rows lie behind
       G.m.list1[pos] = r;
       double *x = G.m.X1 + (int64_t)pos * N;
-      for (int i = 0; i < N; i++) x[i] = xr[i];
+      nm_put_row(x, xr, N);
       map_row(G.P, pos, r, x);
     }
     base_out += tot;
@@ -1013,18 +1105,13 @@ __global__ void __launch_bounds__(NM_ROWS_NT)
   double xr[NM_MAXN];
   if (take2 || taker) {
     const double *src = take2 ? (G.m.X2 + (int64_t)p2 * N) : (G.m.X1 + (int64_t)j * N);
-    for (int i = 0; i < N; i++) s[N * N + i] = src[i];
-    f[N] = take2 ? f2 : fxr;
-    nm_order(s, f, N);
-    G.m.nit[r] += 1;
-    go = glue_begin_row(G, r, xr);
+    go = glue_accept_row(G, r, s, f, src, take2 ? f2 : fxr, xr);
   } else {
     G.m.flags[r] |= 4;  // shrink: parked until the host runs the shrink
     atomicAdd(&G.m.counts[4], 1);
   }
   G.m.cases[j] = go;   // (the case is used up: the flag of the pack kernel)
-  if (go)
-    for (int i = 0; i < N; i++) G.m.X1[(int64_t)j * N + i] = xr[i];
+  if (go) nm_put_row(G.m.X1 + (int64_t)j * N, xr, N);
 }
 
 __global__ void __launch_bounds__(NM_NT) nm_glue_update_pack_kernel(NmGlue G, int jbound) {
@@ -1104,7 +1191,7 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
   G.pen_scale = o->arms[0].pt.pen_scale;
   G.spec_status = o->status;
   G.AO = obj_arm_out(o->scratch, o->narm, S);
-  hipLaunchKernelGGL(nm_glue_begin_kernel, dim3(1), dim3(NM_NT), 0, st, G);
+  hipLaunchKernelGGL(nm_glue_begin_kernel, dim3(1), dim3(NM_UNT), 0, st, G);
   RVS_LAUNCH_CHECK();
   int rc = 0;
   while (true) {
@@ -1129,7 +1216,7 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
                                  st);
         if (rc) return rc;
       }
-      hipLaunchKernelGGL(nm_glue_begin_kernel, dim3(1), dim3(NM_NT), 0, st, G);
+      hipLaunchKernelGGL(nm_glue_begin_kernel, dim3(1), dim3(NM_UNT), 0, st, G);
       RVS_LAUNCH_CHECK();
       continue;
     }
@@ -1161,7 +1248,7 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
         hipLaunchKernelGGL(nm_glue_update_pack_kernel, dim3(1), dim3(NM_NT), 0, st, G,
                            jb);
       } else {
-        hipLaunchKernelGGL(nm_glue_update_kernel, dim3(1), dim3(NM_NT), 0, st, G, jb);
+        hipLaunchKernelGGL(nm_glue_update_kernel, dim3(1), dim3(NM_UNT), 0, st, G, jb);
       }
       RVS_LAUNCH_CHECK();
       calls += 2;

@@ -536,15 +536,30 @@ struct MapP {
   int32_t *bad;
 };
 
-__device__ __forceinline__ void map_row(const MapP &P, int j, int r,
-                                        const double *__restrict__ x) {
+// entry idx of a vector that lives in registers (a chain of selects; each entry
+// through a register first, or the compiler turns the chain into a load at a selected
+// offset and the vector into scratch memory: template_dev.h sel_dim)
+__device__ __forceinline__ double nm_pick(const double *x, int idx) {
+  double v = x[0];
+#pragma unroll
+  for (int i = 1; i < NM_MAXN; i++) {
+    double xi = x[i];
+    asm volatile("" : "+v"(xi));
+    v = (idx == i) ? xi : v;
+  }
+  return v;
+}
+
+// (x: the row in the caller's registers, NM_MAXN entries of which P.n count)
+__device__ __forceinline__ void map_row_regs(const MapP &P, int j, int r,
+                                             const double *x) {
   const int ndim = P.ndim;
   double v = x[0];
   double pen = 0;
   if (P.vsini) {
     double vs;
     if (P.vsini_col >= 0) {
-      const double v0 = x[P.vsini_col];
+      const double v0 = nm_pick(x, P.vsini_col);
       vs = fmin(fmax(v0, 0.0), P.max_vsini);  // np.clip
       if (v0 < 0 || v0 > P.max_vsini) pen += (vs - v0) * (vs - v0);
       if (v0 != v0) vs = v0;
@@ -558,7 +573,7 @@ __device__ __forceinline__ void map_row(const MapP &P, int j, int r,
 #pragma unroll
   for (int i = 0; i < NM_MAXN; i++) {   // (p[] in registers: static indices)
     if (i >= ndim) break;
-    p[i] = (P.M.src[i] >= 0) ? x[P.M.src[i]] : P.fixed[(int64_t)r * ndim + i];
+    p[i] = (P.M.src[i] >= 0) ? nm_pick(x, P.M.src[i]) : P.fixed[(int64_t)r * ndim + i];
     if (!(fabs(p[i]) <= 1.79e308)) isbad = true;
   }
   if (isbad) {
@@ -582,6 +597,24 @@ __device__ __forceinline__ void map_row(const MapP &P, int j, int r,
     if (i < ndim) P.params[(int64_t)j * ndim + i] = p[i];
   P.extra[j] = pen;
   P.bad[j] = isbad ? 1 : 0;
+}
+
+// row i < N of x (memory) <-> xr (registers: no indexing by a loop variable)
+__device__ __forceinline__ void nm_get_row(double *xr, const double *x, int N) {
+#pragma unroll
+  for (int i = 0; i < NM_MAXN; i++) xr[i] = (i < N) ? x[i] : 0.0;
+}
+__device__ __forceinline__ void nm_put_row(double *x, const double *xr, int N) {
+#pragma unroll
+  for (int i = 0; i < NM_MAXN; i++)
+    if (i < N) x[i] = xr[i];
+}
+
+__device__ __forceinline__ void map_row(const MapP &P, int j, int r,
+                                        const double *__restrict__ x) {
+  double xr[NM_MAXN];
+  nm_get_row(xr, x, P.n);
+  map_row_regs(P, j, r, xr);
 }
 
 __global__ void __launch_bounds__(256)
@@ -828,20 +861,13 @@ __device__ __forceinline__ int glue_accept_row(const NmGlue &G, int r, double *s
   }
 }
 
-// row i < N of xr -> x (xr lives in registers: no indexing by a loop variable)
-__device__ __forceinline__ void nm_put_row(double *x, const double *xr, int N) {
-#pragma unroll
-  for (int i = 0; i < NM_MAXN; i++)
-    if (i < N) x[i] = xr[i];
-}
-
 __global__ void __launch_bounds__(NM_UNT) nm_glue_begin_kernel(NmGlue G) {
   __shared__ int sh[NM_UNT / 64 + 1];
   const int S = G.m.S, N = G.m.N;
   int base_out = 0;
   for (int r0 = 0; r0 < S; r0 += NM_UNT) {
     const int r = r0 + threadIdx.x;
-    double xr[NM_MAXN];
+    double xr[NM_MAXN] = {};
     const int go = (r < S) ? glue_begin_row(G, r, xr) : 0;
     int tot;
     const int pos = base_out + block_excl_scan<NM_UNT>(go, &tot, sh);
@@ -849,7 +875,7 @@ __global__ void __launch_bounds__(NM_UNT) nm_glue_begin_kernel(NmGlue G) {
       G.m.list1[pos] = r;
       double *x = G.m.X1 + (int64_t)pos * N;
       nm_put_row(x, xr, N);
-      map_row(G.P, pos, r, x);
+      map_row_regs(G.P, pos, r, xr);
     }
     base_out += tot;
   }
@@ -863,18 +889,19 @@ __global__ void __launch_bounds__(NM_NT) nm_glue_decide_kernel(NmGlue G, int jbo
   __shared__ int sh[NM_NT / 64 + 1];
   const int N = G.m.N;
   const int J = min(G.m.counts[0], jbound);
-  for (int j = threadIdx.x; j < J; j += NM_NT) G.m.F1[j] = glue_value(G, j);
-  __syncthreads();
   int base_out = 0;
   for (int j0 = 0; j0 < J; j0 += NM_NT) {
     const int j = j0 + threadIdx.x;
     int go = 0, r = 0;
-    double x2[NM_MAXN];
+    double x2[NM_MAXN] = {};
     if (j < J) {   // (nm_decide_kernel)
       r = G.m.list1[j];
       const double *s = G.m.sim + (int64_t)r * (N + 1) * N;
       const double *f = G.m.fsim + (int64_t)r * (N + 1);
-      const double fxr = G.m.F1[j];
+      // (the row's own evaluation, read from job slot j: the slots this kernel
+      // rewrites for the second evaluation lie at or before the rows already read)
+      const double fxr = glue_value(G, j);
+      G.m.F1[j] = fxr;
       int c;
       if (fxr < f[0])
         c = 1;
@@ -887,7 +914,9 @@ __global__ void __launch_bounds__(NM_NT) nm_glue_decide_kernel(NmGlue G, int jbo
       G.m.cases[j] = c;
       if (c != 0) {
         go = 1;
-        for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int i = 0; i < NM_MAXN; i++) {   // (x2[] in registers: static indices)
+          if (i >= N) break;
           double xb = s[i];
           for (int k = 1; k < N; k++) xb = xb + s[k * N + i];
           xb = xb / N;
@@ -906,9 +935,8 @@ __global__ void __launch_bounds__(NM_NT) nm_glue_decide_kernel(NmGlue G, int jbo
     if (j < J) G.m.pos2[j] = go ? pos : -1;
     if (go) {
       G.m.list2[pos] = r;
-      double *x = G.m.X2 + (int64_t)pos * N;
-      for (int i = 0; i < N; i++) x[i] = x2[i];
-      map_row(G.P, pos, r, x);
+      nm_put_row(G.m.X2 + (int64_t)pos * N, x2, N);
+      map_row_regs(G.P, pos, r, x2);
     }
     base_out += tot;
   }
@@ -921,13 +949,16 @@ __global__ void __launch_bounds__(NM_UNT) nm_glue_update_kernel(NmGlue G, int jb
   const int N = G.m.N;
   const int J = min(G.m.counts[0], jbound), J2 = min(G.m.counts[1], jbound);
   if (threadIdx.x == 0) parked = 0;
+  // (all values of the second evaluation first: the rows' new slots below overwrite
+  // the job tables glue_value reads -- a later trip's p2 can lie under an earlier
+  // trip's packed positions)
   for (int p = threadIdx.x; p < J2; p += NM_UNT) G.m.F2[p] = glue_value(G, p);
   __syncthreads();
   int base_out = 0;
   for (int j0 = 0; j0 < J; j0 += NM_UNT) {
     const int j = j0 + threadIdx.x;
     int go = 0, r = 0;
-    double xr[NM_MAXN];
+    double xr[NM_MAXN] = {};
     if (j < J) {   // (nm_update_kernel)
       r = G.m.list1[j];
       double *s = G.m.sim + (int64_t)r * (N + 1) * N;
@@ -965,7 +996,7 @@ __global__ void __launch_bounds__(NM_UNT) nm_glue_update_kernel(NmGlue G, int jb
       G.m.list1[pos] = r;
       double *x = G.m.X1 + (int64_t)pos * N;
       nm_put_row(x, xr, N);
-      map_row(G.P, pos, r, x);
+      map_row_regs(G.P, pos, r, xr);
     }
     base_out += tot;
   }
@@ -1039,12 +1070,11 @@ __device__ int nm_pack_rows(const NmGlue &G, int J, FLAG flag, const int32_t *li
   for (int j0 = 0; j0 < J; j0 += NM_NT) {
     const int j = j0 + threadIdx.x;
     int go = 0, r = 0;
-    double xr[NM_MAXN];
+    double xr[NM_MAXN] = {};
     if (j < J) {
       go = flag(j);
       r = list_in[j];
-      if (go)
-        for (int i = 0; i < N; i++) xr[i] = X[(int64_t)j * N + i];
+      if (go) nm_get_row(xr, X + (int64_t)j * N, N);
     }
     // (the rows are in registers before any thread writes a packed position)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1053,9 +1083,8 @@ __device__ int nm_pack_rows(const NmGlue &G, int J, FLAG flag, const int32_t *li
     if (pos_out && j < J) pos_out[j] = go ? pos : -1;
     if (go) {
       list_out[pos] = r;
-      double *x = X + (int64_t)pos * N;
-      for (int i = 0; i < N; i++) x[i] = xr[i];
-      map_row(G.P, pos, r, x);
+      nm_put_row(X + (int64_t)pos * N, xr, N);
+      map_row_regs(G.P, pos, r, xr);
     }
     base_out += tot;
   }

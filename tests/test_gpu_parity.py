@@ -1686,15 +1686,18 @@ def test_process_bfgs_implementations_agree(cases, config, monkeypatch):
     assert abs(np.mean(a['bfgs']['nfev']) / np.mean(b['bfgs']['nfev']) - 1) < 0.5
 
 
-def test_nm_round_kernels_equal_chain(cases, config):
+@pytest.mark.parametrize('S', [40, 1300])
+def test_nm_round_kernels_equal_chain(cases, config, S):
     """rvs_nm_run's rounds -- three bookkeeping kernels that also sum the arms and
     map the next rows, the objective skipping the rows behind the device counts --
     against the same rounds as a chain of the stand-alone kernels (option nm_glue = 0):
-    every number of vel_fit.process bit for bit."""
+    every number of vel_fit.process bit for bit.  1300 spectra: a half of the batch is
+    650 rows, which the one-block kernels that hold a simplex in registers (512
+    threads) take in two trips -- the second trip reads job tables of the evaluation
+    just done while the first trip's rows are already mapped for the next one."""
     from rvspecfit_amd import vel_fit
     from rvspecfit_amd.engine import SpecBatch
     rng = np.random.RandomState(8)
-    S = 40
     lists = [_sds(cases, ('c1', 'c3')[i % 2]) for i in range(S)]
     batch = SpecBatch.from_specdata(lists)
     for a in batch.arms:

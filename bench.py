@@ -1226,7 +1226,8 @@ def run_desi_addon(arms, args, dev, dicts):
                files_per_batch=min(max(1, args.desi_files_per_batch), nfiles),
                workers=max(1, args.desi_workers) if nfiles > 1 else 1,
                fibres_per_s=round(nfit / dt, 1), seconds=round(dt, 2),
-               stage_s={k: round(v, 3) for k, v in tm.items()},
+               stage_s={k: round(v, 3) for k, v in tm.items()} if nfiles == 1
+               else {k: round(v, 3) for k, v in D.GROUP_TIMES.items()},
                input_MB=round(os.path.getsize(fname) / 1e6, 1),
                output_MB=round((os.path.getsize(tabf)
                                 + os.path.getsize(modf)) / 1e6, 1),

@@ -95,8 +95,10 @@ int rvs_abi_version(void);
  *   "nm_glue"        1  rvs_nm_run: a round as three bookkeeping kernels; 0 = the
  *                       chain of stand-alone kernels (rvs_nm_begin / _decide / ...)
  *   "nm_bucket"      0  rvs_nm_run: launch bounds rounded up to buckets
- *   "nm_split_min" 1024 rvs_nm_run: rounds of at least this many rows run their
- *                       bookkeeping as a row-parallel kernel + a one-block pack
+ *   "nm_split_min" 1024 rvs_nm_run: rounds of at least this many rows (and the test
+ *                       of all simplices at the start and after a shrink, for at
+ *                       least this many simplices) run their bookkeeping as a
+ *                       row-parallel kernel + a one-block pack
  *   "obj_inblk_max" 256 objective launches of <= this many blocks search their grid
  *                       cell inside the block (0 = never)
  *   "obj_sort"       1  objective jobs evaluated in grid-cell order

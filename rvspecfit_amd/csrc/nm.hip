@@ -898,16 +898,18 @@ __global__ void __launch_bounds__(NM_NT) nm_glue_decide_kernel(NmGlue G, int jbo
       r = G.m.list1[j];
       const double *s = G.m.sim + (int64_t)r * (N + 1) * N;
       const double *f = G.m.fsim + (int64_t)r * (N + 1);
+      // (the simplex values requested ahead of the evaluation's chain of loads)
+      const double f0 = f[0], fn1 = f[N - 1], fn = f[N];
       // (the row's own evaluation, read from job slot j: the slots this kernel
       // rewrites for the second evaluation lie at or before the rows already read)
       const double fxr = glue_value(G, j);
       G.m.F1[j] = fxr;
       int c;
-      if (fxr < f[0])
+      if (fxr < f0)
         c = 1;
-      else if (fxr < f[N - 1])
+      else if (fxr < fn1)
         c = 0;
-      else if (fxr < f[N])
+      else if (fxr < fn)
         c = 2;
       else
         c = 3;
@@ -1028,17 +1030,19 @@ __global__ void __launch_bounds__(NM_ROWS_NT)
   const int J = min(G.m.counts[0], jbound);
   const int j = blockIdx.x * NM_ROWS_NT + threadIdx.x;
   if (j >= J) return;
-  const double fxr = glue_value(G, j);
-  G.m.F1[j] = fxr;
   const int r = G.m.list1[j];
   const double *s = G.m.sim + (int64_t)r * (N + 1) * N;
   const double *f = G.m.fsim + (int64_t)r * (N + 1);
+  // (the simplex values requested ahead of the evaluation's chain of loads)
+  const double f0 = f[0], fn1 = f[N - 1], fn = f[N];
+  const double fxr = glue_value(G, j);
+  G.m.F1[j] = fxr;
   int c;
-  if (fxr < f[0])
+  if (fxr < f0)
     c = 1;
-  else if (fxr < f[N - 1])
+  else if (fxr < fn1)
     c = 0;
-  else if (fxr < f[N])
+  else if (fxr < fn)
     c = 2;
   else
     c = 3;
@@ -1061,7 +1065,8 @@ __global__ void __launch_bounds__(NM_ROWS_NT)
 }
 
 // rows [0, J) with flag(j) set move, in order, to the front of (list, X): X row j -> row
-// pos, list[pos] = list_in[j]; pos_out[j] = pos or -1 (nullable); returns the count
+// pos, list[pos] = list_in[j] (j itself without a list); pos_out[j] = pos or -1
+// (nullable); returns the count
 template <typename FLAG>
 __device__ int nm_pack_rows(const NmGlue &G, int J, FLAG flag, const int32_t *list_in,
                             int32_t *list_out, double *X, int32_t *pos_out, int *sh) {
@@ -1073,7 +1078,7 @@ __device__ int nm_pack_rows(const NmGlue &G, int J, FLAG flag, const int32_t *li
     double xr[NM_MAXN] = {};
     if (j < J) {
       go = flag(j);
-      r = list_in[j];
+      r = list_in ? list_in[j] : j;
       if (go) nm_get_row(xr, X + (int64_t)j * N, N);
     }
     // (the rows are in registers before any thread writes a packed position)
@@ -1089,6 +1094,30 @@ __device__ int nm_pack_rows(const NmGlue &G, int J, FLAG flag, const int32_t *li
     base_out += tot;
   }
   return base_out;
+}
+
+// nm_glue_begin_kernel the same way (the start of a run and every return from a shrink
+// test all S simplices: ten trips of one block at 5000)
+__global__ void __launch_bounds__(NM_ROWS_NT) nm_glue_begin_rows_kernel(NmGlue G) {
+  const int S = G.m.S, N = G.m.N;
+  const int r = blockIdx.x * NM_ROWS_NT + threadIdx.x;
+  if (r >= S) return;
+  double xr[NM_MAXN] = {};
+  const int go = glue_begin_row(G, r, xr);
+  G.m.cases[r] = go;   // (no round is in flight: the array is free)
+  if (go) nm_put_row(G.m.X1 + (int64_t)r * N, xr, N);
+}
+
+__global__ void __launch_bounds__(NM_NT) nm_glue_begin_pack_kernel(NmGlue G) {
+  __shared__ int sh[NM_NT / 64 + 1];
+  const int32_t *cases = G.m.cases;
+  const int n = nm_pack_rows(G, G.m.S, [=](int j) { return cases[j]; }, nullptr,
+                             G.m.list1, G.m.X1, nullptr, sh);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    G.m.counts[0] = n;
+    G.m.counts[3] = n;
+  }
 }
 
 __global__ void __launch_bounds__(NM_NT) nm_glue_decide_pack_kernel(NmGlue G, int jbound) {
@@ -1112,6 +1141,7 @@ __global__ void __launch_bounds__(NM_ROWS_NT)
   const int c = G.m.cases[j];
   const double fxr = G.m.F1[j];
   const int p2 = G.m.pos2[j];
+  const double fn = f[N];   // (requested ahead of the evaluation's chain of loads)
   double f2 = __builtin_inf();
   if (p2 >= 0) {   // (this row's second point: nobody else's)
     f2 = glue_value(G, p2);
@@ -1128,7 +1158,7 @@ __global__ void __launch_bounds__(NM_ROWS_NT)
   } else if (c == 2)
     take2 = (f2 <= fxr);
   else
-    take2 = (f2 < f[N]);
+    take2 = (f2 < fn);
   G.m.nfev[r] += (c == 0) ? 1 : 2;
   int go = 0;
   double xr[NM_MAXN];
@@ -1220,7 +1250,17 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
   G.pen_scale = o->arms[0].pt.pen_scale;
   G.spec_status = o->status;
   G.AO = obj_arm_out(o->scratch, o->narm, S);
-  hipLaunchKernelGGL(nm_glue_begin_kernel, dim3(1), dim3(NM_UNT), 0, st, G);
+  auto begin = [&]() {   // every simplex tested, the live ones listed and mapped
+    if (S >= rvs_opt(RVS_OPT_NM_SPLIT_MIN)) {
+      hipLaunchKernelGGL(nm_glue_begin_rows_kernel,
+                         dim3((S + NM_ROWS_NT - 1) / NM_ROWS_NT), dim3(NM_ROWS_NT), 0, st,
+                         G);
+      hipLaunchKernelGGL(nm_glue_begin_pack_kernel, dim3(1), dim3(NM_NT), 0, st, G);
+    } else {
+      hipLaunchKernelGGL(nm_glue_begin_kernel, dim3(1), dim3(NM_UNT), 0, st, G);
+    }
+  };
+  begin();
   RVS_LAUNCH_CHECK();
   int rc = 0;
   while (true) {
@@ -1245,7 +1285,7 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
                                  st);
         if (rc) return rc;
       }
-      hipLaunchKernelGGL(nm_glue_begin_kernel, dim3(1), dim3(NM_UNT), 0, st, G);
+      begin();
       RVS_LAUNCH_CHECK();
       continue;
     }

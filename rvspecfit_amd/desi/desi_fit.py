@@ -1213,6 +1213,11 @@ def _select_rank_device(environ=None):
     return idx
 
 
+# seconds of the last proc_many call's file groups, by where the calling thread (or the
+# writer thread: 'write') spent them -- what bench.py reports beside the fibre rate
+GROUP_TIMES = dict(wait_prepare=0., fit=0., write=0., drain=0., groups=0)
+
+
 def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
               figure_dir=None, figure_prefix=None, config_fname=None,
               nthreads=1, fit_targetid=None, objtypes=None, minsn=-1e9,
@@ -1307,6 +1312,7 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
     # thread reads and conditions group g + 1 (numpy and file I/O release the
     # GIL; the fit thread spends its time inside the library).
     import concurrent.futures
+    GROUP_TIMES.update(wait_prepare=0., fit=0., write=0., drain=0., groups=0)
     pool = concurrent.futures.ThreadPoolExecutor(1)
     pending = []
     inflight = []   # [(group, future of _group_prepare)]
@@ -1326,6 +1332,7 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
         t0 = time.time()
         errors = {}
         rets = _group_write(state, res, errors)
+        GROUP_TIMES['write'] += time.time() - t0
         return rets, errors, time.time() - t0
 
     def collect_written(block=False):
@@ -1362,6 +1369,8 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
         try:
             from .. import vel_fit
             state = fut.result()
+            GROUP_TIMES['wait_prepare'] += time.time() - t1
+            t1 = time.time()
             # One worker thread is conditioning the next group meanwhile, another
             # writes the products of the group before; the fit itself runs as
             # vel_fit.process's two halves on two streams (RVS_DESI_SINGLE_STREAM=1:
@@ -1378,6 +1387,8 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
                               % len(group))
             one_by_one(group)
             return
+        GROUP_TIMES['fit'] += time.time() - t1
+        GROUP_TIMES['groups'] += 1
         writing.append((group, time.time() - t1,
                         wpool.submit(timed_write, state, res)))
         collect_written()
@@ -1433,7 +1444,9 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
         # handed to the writer get their products and status lines, and both
         # worker threads end
         try:
+            t1 = time.time()
             collect_written(block=True)
+            GROUP_TIMES['drain'] += time.time() - t1
         finally:
             for _, fut in inflight:
                 fut.cancel()

@@ -1039,18 +1039,14 @@ def _proc_desi_steps(fname, tab_ofname, mod_ofname, fig_prefix, config,
     return nsel
 
 
-def _fit_requests(reqs, config, options, ccf_init=True, device='cuda',
-                  max_batch=4096):
-    """Fit the conditioned fibres of one or several files (the requests that
-    _proc_desi_steps yields).  Files that share arms and wavelength grids are
-    fitted TOGETHER -- one batch per pattern of usable arms -- because the
-    lock-step optimiser is bound by round latency at a few hundred fibres
-    (a 500-fibre coadd) and by throughput from a few thousand on.  Every fibre's
-    result is independent of what else is in its batch.
-    Returns, per request, (outdicts, curmodels, arms_of): lists over its fibres
-    (None for fibres without a usable arm)."""
-    out = [([None] * r['nsel'], [None] * r['nsel'], [None] * r['nsel'])
-           for r in reqs]
+def _stage_requests(reqs, device='cuda', max_batch=4096):
+    """The host half of _fit_requests: files that share arms and wavelength grids
+    concatenated, one SpecBatch per pattern of usable arms (in chunks of
+    `max_batch`), uploaded.  Needs nothing from the GPU, so proc_many's worker
+    thread does it for group g + 1 while group g is fitted (on a stream of its
+    own: the copies do not queue behind the fit's kernels).  Returns
+    [(batch, rows, names_p, owner, local)]."""
+    staged = []
     groups = {}
     for ir, r in enumerate(reqs):
         key = (tuple(r['setups']),
@@ -1080,14 +1076,34 @@ def _fit_requests(reqs, config, options, ccf_init=True, device='cuda',
             names_p = ['desi_%s' % s for s, u in zip(setups, pattern) if u]
             for c0 in range(0, len(rows_p), max_batch):
                 rows = rows_p[c0:c0 + max_batch]
-                batch = _arm_batch(cond, setups, pattern, rows, waves, device)
-                fr = fit_batch(batch, config, options, ccf_init=ccf_init)
-                for k, (i, d) in enumerate(zip(rows, _outdicts(
-                        fr, names_p, config, ccf_init))):
-                    o = out[owner[i]]
-                    o[0][local[i]] = d
-                    o[1][local[i]] = [y[k] for y in fr['yfit']]
-                    o[2][local[i]] = names_p
+                staged.append((_arm_batch(cond, setups, pattern, rows, waves, device),
+                               rows, names_p, owner, local))
+    return staged
+
+
+def _fit_requests(reqs, config, options, ccf_init=True, device='cuda',
+                  max_batch=4096, staged=None):
+    """Fit the conditioned fibres of one or several files (the requests that
+    _proc_desi_steps yields).  Files that share arms and wavelength grids are
+    fitted TOGETHER -- one batch per pattern of usable arms -- because the
+    lock-step optimiser is bound by round latency at a few hundred fibres
+    (a 500-fibre coadd) and by throughput from a few thousand on.  Every fibre's
+    result is independent of what else is in its batch.  `staged`: the batches,
+    if _stage_requests has already built them.
+    Returns, per request, (outdicts, curmodels, arms_of): lists over its fibres
+    (None for fibres without a usable arm)."""
+    out = [([None] * r['nsel'], [None] * r['nsel'], [None] * r['nsel'])
+           for r in reqs]
+    if staged is None:
+        staged = _stage_requests(reqs, device=device, max_batch=max_batch)
+    for batch, rows, names_p, owner, local in staged:
+        fr = fit_batch(batch, config, options, ccf_init=ccf_init)
+        for k, (i, d) in enumerate(zip(rows, _outdicts(
+                fr, names_p, config, ccf_init))):
+            o = out[owner[i]]
+            o[0][local[i]] = d
+            o[1][local[i]] = [y[k] for y in fr['yfit']]
+            o[2][local[i]] = names_p
     return out
 
 
@@ -1108,24 +1124,37 @@ def _group_prepare(files, config, kwargs):
     generators parked at their fit request, and the return values of the files
     that needed no fit"""
     gens, rets = [], [None] * len(files)
+    kw = {k: v for k, v in kwargs.items() if k != 'stage_ahead'}
     for i, f in enumerate(files):
-        g = _proc_desi_steps(*f, config, **kwargs)
+        g = _proc_desi_steps(*f, config, **kw)
         try:
             gens.append((i, g, next(g)))
         except StopIteration as e:
             rets[i] = e.value
+    if kwargs.get('stage_ahead') and gens:
+        # (proc_many's worker thread: the group's batches built and uploaded while
+        # the group before is fitted)
+        import torch
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            staged = _stage_requests([r for _, _, r in gens],
+                                     device=kwargs.get('device', 'cuda'),
+                                     max_batch=kwargs.get('max_batch', 4096))
+        side.synchronize()
+        return gens, rets, staged
     return gens, rets
 
 
 def _group_fit(state, config, kwargs):
     """fit the parked requests of a prepared group together (the GPU part)"""
-    gens, _ = state
+    gens = state[0]
     npoly = kwargs.get('npoly')
     options = {'npoly': 10 if npoly is None else npoly}
     return _fit_requests([r for _, _, r in gens], config, options,
                          ccf_init=kwargs.get('ccf_init', True),
                          device=kwargs.get('device', 'cuda'),
-                         max_batch=kwargs.get('max_batch', 4096))
+                         max_batch=kwargs.get('max_batch', 4096),
+                         staged=state[2] if len(state) > 2 else None)
 
 
 def _group_write(state, res, errors=None):
@@ -1133,7 +1162,7 @@ def _group_write(state, res, errors=None):
     write the products (host work only).  With `errors` (a dict) a file whose
     generator raises does not stop the others: its exception is recorded under
     its index and its return value stays None"""
-    gens, rets = state
+    gens, rets = state[0], state[1]
     for (i, g, _), r in zip(gens, res):
         try:
             g.send(r)
@@ -1312,6 +1341,10 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
     # thread reads and conditions group g + 1 (numpy and file I/O release the
     # GIL; the fit thread spends its time inside the library).
     import concurrent.futures
+    import torch
+    # (the worker thread also builds and uploads the group's batches -- where there
+    # is a device to upload to)
+    kw_prepare = dict(kw, stage_ahead=bool(torch.cuda.is_available()))
     GROUP_TIMES.update(wait_prepare=0., fit=0., write=0., drain=0., groups=0)
     pool = concurrent.futures.ThreadPoolExecutor(1)
     pending = []
@@ -1404,7 +1437,8 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
             one_by_one(group)
             return
         inflight.append((group, pool.submit(
-            _group_prepare, [(f, t, m, None) for f, t, m in group], config, kw)))
+            _group_prepare, [(f, t, m, None) for f, t, m in group], config,
+            kw_prepare)))
         if len(inflight) > 1:   # group g + 1 is being prepared: fit group g
             finish_oldest()
 

@@ -1244,7 +1244,7 @@ def _select_rank_device(environ=None):
 
 # seconds of the last proc_many call's file groups, by where the calling thread (or the
 # writer thread: 'write') spent them -- what bench.py reports beside the fibre rate
-GROUP_TIMES = dict(wait_prepare=0., fit=0., write=0., drain=0., groups=0)
+GROUP_TIMES = dict(wait_prepare=0., fit=0., write=0., drain=0., groups=0, flushed=0)
 
 
 def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
@@ -1266,7 +1266,8 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
     other and FITTED TOGETHER (proc_desi_group: a single 500-fibre coadd leaves
     the lock-step optimiser latency-bound); should the group fail, its files
     are retried one by one so that the failure lands on the file that caused
-    it.  `shard=(rank, world)` -- or the RANK/WORLD_SIZE environment of
+    it.  The first group is half a batch (from 4 files per batch up): its
+    preparation is the one stretch of host work that no fit runs beside.  `shard=(rank, world)` -- or the RANK/WORLD_SIZE environment of
     torch.distributed.run -- gives every GPU process its own stride of the file
     list; files are independent, there is no collective."""
     override = dict(ccf_continuum_normalize=ccf_continuum_normalize)
@@ -1345,7 +1346,7 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
     # (the worker thread also builds and uploads the group's batches -- where there
     # is a device to upload to)
     kw_prepare = dict(kw, stage_ahead=bool(torch.cuda.is_available()))
-    GROUP_TIMES.update(wait_prepare=0., fit=0., write=0., drain=0., groups=0)
+    GROUP_TIMES.update(wait_prepare=0., fit=0., write=0., drain=0., groups=0, flushed=0)
     pool = concurrent.futures.ThreadPoolExecutor(1)
     pending = []
     inflight = []   # [(group, future of _group_prepare)]
@@ -1468,7 +1469,14 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
                                                ProcessStatus.EXISTING, -1, 0)
                 continue
             pending.append((f, ) + names)
-            if len(pending) >= max(1, files_per_batch):
+            # (nothing overlaps the preparation of the first group: half a batch)
+            limit = files_per_batch // 2 if (files_per_batch >= 4 and
+                                             GROUP_TIMES['flushed'] == 0 and
+                                             not os.environ.get(
+                                                 'RVS_DESI_FULL_FIRST_GROUP')) \
+                else max(1, files_per_batch)
+            if len(pending) >= limit:
+                GROUP_TIMES['flushed'] += 1
                 flush()
         flush()
         while inflight:

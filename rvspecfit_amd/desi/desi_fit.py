@@ -1397,7 +1397,52 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
             if errors:
                 one_by_one([group[i] for i in sorted(errors)])
 
+    # RVS_DESI_FIT_THREADS=2: two groups are fitted side by side (each by its own
+    # thread, on its own pair of streams): the latency-bound last rounds of one
+    # group's optimiser run under the other's full-size launches
+    fit_threads = max(1, int(os.environ.get('RVS_DESI_FIT_THREADS', '1')))
+    fpool = concurrent.futures.ThreadPoolExecutor(fit_threads) \
+        if fit_threads > 1 else None
+    fitting = []    # [(group, future of fit_job)] (fit_threads > 1)
+    lanes = list(range(fit_threads))
+
+    def fit_job(fut):
+        """a fit thread: wait for the group's preparation, fit it"""
+        from .. import vel_fit
+        state = fut.result()
+        t1 = time.time()
+        lane = lanes.pop()
+        try:
+            with vel_fit.stream_lane(lane):
+                res = _group_fit(state, config, kw)
+        finally:
+            lanes.append(lane)
+        return state, res, time.time() - t1
+
+    def finish_oldest_fit():
+        group, ff = fitting.pop(0)
+        t1 = time.time()
+        try:
+            state, res, t_fit = ff.result()
+        except Exception:  # noqa: BLE001 -- retried per file
+            logging.exception('group of %d files failed; retrying one by one'
+                              % len(group))
+            one_by_one(group)
+            return
+        GROUP_TIMES['fit'] += time.time() - t1   # (the calling thread's wait)
+        GROUP_TIMES['groups'] += 1
+        writing.append((group, t_fit, wpool.submit(timed_write, state, res)))
+        collect_written()
+
     def finish_oldest():
+        if fpool is not None:
+            # hand the oldest prepared group to a fit thread; collect a fit only when
+            # more groups are in flight than fit threads
+            group, fut = inflight.pop(0)
+            fitting.append((group, fpool.submit(fit_job, fut)))
+            while len(fitting) > fit_threads:
+                finish_oldest_fit()
+            return
         group, fut = inflight.pop(0)
         t1 = time.time()
         try:
@@ -1481,6 +1526,8 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
         flush()
         while inflight:
             finish_oldest()
+        while fitting:
+            finish_oldest_fit()
     finally:
         # also on the way out of an exception (throw_exceptions): the groups already
         # handed to the writer get their products and status lines, and both
@@ -1490,8 +1537,10 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
             collect_written(block=True)
             GROUP_TIMES['drain'] += time.time() - t1
         finally:
-            for _, fut in inflight:
+            for _, fut in inflight + fitting:
                 fut.cancel()
             pool.shutdown()
+            if fpool is not None:
+                fpool.shutdown()
             wpool.shutdown()
     logging.info('Successfully finished processing')

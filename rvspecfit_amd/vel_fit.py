@@ -615,9 +615,22 @@ def _merge_parts(parts, idxs, S):
 _SPLIT_STREAMS = {}
 
 
-def _split_stream(dev, k):
+@contextlib.contextmanager
+def stream_lane(lane):
+    """process() calls of this thread inside the block run their halves on the
+    streams of `lane` (desi_fit.proc_many with two fit threads: a pair of streams
+    per thread, so that two groups' rounds do not queue behind one another)"""
+    old = getattr(_tls, 'lane', 0)
+    _tls.lane = int(lane)
+    try:
+        yield
+    finally:
+        _tls.lane = old
+
+
+def _split_stream(dev, k, lane=0):
     # kept: the caching allocator's pools are per stream
-    key = (dev.index, k)
+    key = (dev.index, k, lane)
     if key not in _SPLIT_STREAMS:
         _SPLIT_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SPLIT_STREAMS[key]
@@ -633,10 +646,11 @@ def _process_split(batch, paramDict0, kwargs):
     spec_inter.get_libs(batch.names, kwargs['config'])
     torch.cuda.current_stream().synchronize()
     parts, errs = [None] * nparts, [None] * nparts
+    lane = getattr(_tls, 'lane', 0)
 
     def run(k):
         try:
-            st = _split_stream(dev, k)
+            st = _split_stream(dev, k, lane)
             with torch.cuda.stream(st):
                 sub = batch.subset(idxs[k])
                 pdk = {n: v[idxs[k]].contiguous() for n, v in pd.items()}

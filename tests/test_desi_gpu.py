@@ -300,6 +300,43 @@ def test_grouped_files_equal_single(dcases, desi_libs, tmp_path):
     assert np.array_equal(tm['VRAD'], ts['VRAD'])
 
 
+def test_proc_many_two_fit_threads(dcases, desi_libs, tmp_path, monkeypatch):
+    """RVS_DESI_FIT_THREADS=2: two groups of files fitted side by side by two threads
+    -- every product is the one of the file processed alone, bit for bit, and every
+    file has its status line"""
+    import yaml
+    from rvspecfit_amd import fits_min as F
+    from rvspecfit_amd.desi import desi_fit as D
+    kw = dict(doplot=False, minsn=2, zbest_include=True)
+    single = (str(tmp_path / 's_tab.fits'), str(tmp_path / 's_mod.fits'))
+    n1 = D.proc_desi(COADD, single[0], single[1], None, CFG, **kw)
+    ts = F.open(single[0])['RVTAB'].data
+    cfgf = str(tmp_path / 'c.yaml')
+    with open(cfgf, 'w') as fp:
+        yaml.safe_dump({k: v for k, v in CFG.items()
+                        if k != 'config_file_path'}, fp)
+    links = []
+    for i in range(7):
+        links.append(str(tmp_path / ('coadd-c%d.fits' % i)))
+        os.symlink(COADD, links[-1])
+        os.symlink(os.path.join(GOLD, 'redrock-golden.fits'),
+                   str(tmp_path / ('redrock-c%d.fits' % i)))
+    st = str(tmp_path / 'status')
+    monkeypatch.setenv('RVS_DESI_FIT_THREADS', '2')
+    D.proc_many(links, str(tmp_path / 'out'), 'rvtab', 'rvmod', config_fname=cfgf,
+                minsn=2, zbest_include=True, doplot=False, subdirs=False,
+                process_status_file=st, shard=(0, 1), files_per_batch=2)
+    rows = [l.split() for l in open(st).read().strip().split('\n')]
+    assert sorted(r[0] for r in rows) == sorted(links)
+    assert all(r[1] == 'SUCCESS' and int(r[2]) == n1 for r in rows), rows
+    for i in range(7):
+        tg = F.open(str(tmp_path / 'out' / ('rvtab_coadd-c%d.fits' % i)))['RVTAB'].data
+        for c in ts.columns.names:
+            a, b = ts[c], tg[c]
+            assert np.array_equal(a, b) if a.dtype.kind in 'SUb' else \
+                np.array_equal(a, b, equal_nan=True), (i, c)
+
+
 def test_proc_many_worker_processes(dcases, tmp_path):
     """nthreads = 2: two worker processes share the GPU, each with its stride
     of the file list (the library comes from disk: converted-artefact files in

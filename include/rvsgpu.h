@@ -99,6 +99,10 @@ int rvs_abi_version(void);
  *                       of all simplices at the start and after a shrink, for at
  *                       least this many simplices) run their bookkeeping as a
  *                       row-parallel kernel + a one-block pack
+ *   "nm_spec_max"   21  rvs_nm_run: rounds of at most this many rows (<= 64, and a
+ *                       quarter of the simplices) evaluate all four candidate points
+ *                       of a step in one launch, with one bookkeeping kernel per
+ *                       round (same state, bit for bit); 0 = never
  *   "obj_inblk_max" 256 objective launches of <= this many blocks search their grid
  *                       cell inside the block (0 = never)
  *   "obj_sort"       1  objective jobs evaluated in grid-cell order

@@ -1011,6 +1011,187 @@ __global__ void __launch_bounds__(NM_UNT) nm_glue_update_kernel(NmGlue G, int jb
 }
 
 // ---------------------------------------------------------------------------
+// The optimiser's LAST rounds -- a few stragglers stepping, every kernel of a round a
+// latency, the chip idle -- as ONE evaluation launch and ONE bookkeeping kernel per
+// round: all four points a step can ask for (reflection, expansion, outside and inside
+// contraction: functions of the simplex alone) are evaluated together, rows q J + j for
+// candidate q of list row j, and this kernel does what decide and update do, reading
+// the one second value scipy would have computed.  Same points, same values, same
+// updates, nfev counted as scipy counts: the state is the two-launch round's to the
+// bit; the status bits of candidates scipy would not have evaluated are not taken.
+// One wave (512 VGPRs: a simplex, its next point and the three other candidates in
+// registers at any N): the host sends rounds of at most NM_SNT rows here (option
+// nm_spec_max).
+// ---------------------------------------------------------------------------
+#define NM_SNT 64
+template <int N>
+__device__ __forceinline__ void nm_other_points(const double (&s)[N + 1][N],
+                                                double (*xc)[NM_MAXN]) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {   // (nm_decide_kernel's expressions)
+    double xb = s[0][i];
+#pragma unroll
+    for (int k = 1; k < N; k++) xb = xb + s[k][i];
+    xb = xb / N;
+    const double w = s[N][i];
+    xc[0][i] = (1 + 1.0 * 2.0) * xb - 1.0 * 2.0 * w;
+    xc[1][i] = (1 + 0.5 * 1.0) * xb - 0.5 * 1.0 * w;
+    xc[2][i] = (1 - 0.5) * xb + 0.5 * w;
+  }
+}
+
+// rows (q + 1) * J + pos of X1 and of the job tables <- candidate q of simplex r
+__device__ __forceinline__ void nm_put_candidates(const NmGlue &G, int J, int pos, int r,
+                                                  const double (*xc)[NM_MAXN]) {
+  const int N = G.m.N;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int row = (q + 1) * J + pos;
+    nm_put_row(G.m.X1 + (int64_t)row * N, xc[q], N);
+    map_row_regs(G.P, row, r, xc[q]);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void glue_spec_prep_body(const NmGlue &G, int jbound) {
+  const int J = min(G.m.counts[0], jbound);
+  const int j = threadIdx.x;
+  if (j < J) {
+    const int r = G.m.list1[j];
+    double s[N + 1][N], f[N + 1];
+    nm_load_regs<N>(G.m.sim + (int64_t)r * (N + 1) * N, G.m.fsim + (int64_t)r * (N + 1),
+                    s, f);
+    double xc[3][NM_MAXN] = {};
+    nm_other_points<N>(s, xc);
+    nm_put_candidates(G, J, j, r, xc);
+  }
+  if (threadIdx.x == 0) G.m.counts[5] = 4 * J;
+}
+
+__global__ void __launch_bounds__(NM_SNT) nm_glue_spec_prep_kernel(NmGlue G, int jbound) {
+  switch (G.m.N) {
+    case 1: glue_spec_prep_body<1>(G, jbound); break;
+    case 2: glue_spec_prep_body<2>(G, jbound); break;
+    case 3: glue_spec_prep_body<3>(G, jbound); break;
+    case 4: glue_spec_prep_body<4>(G, jbound); break;
+    case 5: glue_spec_prep_body<5>(G, jbound); break;
+    case 6: glue_spec_prep_body<6>(G, jbound); break;
+    case 7: glue_spec_prep_body<7>(G, jbound); break;
+    default: glue_spec_prep_body<8>(G, jbound); break;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void glue_spec_body(const NmGlue &G, int jbound, int *sh,
+                                               int *parked) {
+  const int J = min(G.m.counts[0], jbound);
+  const int j = threadIdx.x;
+  int go = 0, r = 0;
+  double xr[NM_MAXN] = {};
+  double xc[3][NM_MAXN] = {};
+  if (j < J) {
+    r = G.m.list1[j];
+    double *gs = G.m.sim + (int64_t)r * (N + 1) * N;
+    double *gf = G.m.fsim + (int64_t)r * (N + 1);
+    const double f0 = gf[0], fn1 = gf[N - 1], fn = gf[N];
+    const double fxr = glue_value(G, j);   // (nm_decide_kernel)
+    G.m.F1[j] = fxr;
+    int c;
+    if (fxr < f0)
+      c = 1;
+    else if (fxr < fn1)
+      c = 0;
+    else if (fxr < fn)
+      c = 2;
+    else
+      c = 3;
+    // the step's second point: candidate c of this row, or none
+    const int p2 = (c == 0) ? -1 : c * J + j;
+    double f2 = __builtin_inf();
+    if (p2 >= 0) f2 = glue_value(G, p2);
+    bool take2 = false, taker = false;   // (nm_update_kernel)
+    if (c == 0)
+      taker = true;
+    else if (c == 1) {
+      if (f2 < fxr)
+        take2 = true;
+      else
+        taker = true;
+    } else if (c == 2)
+      take2 = (f2 <= fxr);
+    else
+      take2 = (f2 < fn);
+    G.m.nfev[r] += (c == 0) ? 1 : 2;
+    if (take2 || taker) {
+      const double *src = G.m.X1 + (int64_t)(take2 ? p2 : j) * N;
+      double s[N + 1][N], f[N + 1];
+#pragma unroll
+      for (int a = 0; a < N; a++) {
+        f[a] = gf[a];
+#pragma unroll
+        for (int i = 0; i < N; i++) s[a][i] = gs[a * N + i];
+      }
+#pragma unroll
+      for (int i = 0; i < N; i++) s[N][i] = src[i];
+      f[N] = take2 ? f2 : fxr;
+      nm_sort_regs<N>(s, f);
+      nm_store_regs<N>(gs, gf, s, f);
+      const int nit = G.m.nit[r] + 1;
+      G.m.nit[r] = nit;
+      // (glue_begin_row's tests, in its order)
+      int32_t *flags = G.m.flags;
+      const int fl = flags[r];
+      if ((fl & 5) == 1) {
+        if (nit >= G.maxiter) {
+          flags[r] = fl & ~1;
+        } else if (nm_test_regs<N>(s, f, G.xatol, G.fatol, xr)) {
+          flags[r] = (fl & ~1) | 2;
+        } else {
+          go = 1;
+          nm_other_points<N>(s, xc);
+        }
+      }
+    } else {
+      G.m.flags[r] |= 4;  // shrink: parked until the host runs the shrink
+      atomicAdd(parked, 1);
+    }
+  }
+  // (every row and value of this round has been read: the barriers of the scan)
+  int tot;
+  const int pos = block_excl_scan<NM_SNT>(go, &tot, sh);
+  if (go) {
+    G.m.list1[pos] = r;
+    nm_put_row(G.m.X1 + (int64_t)pos * N, xr, N);
+    map_row_regs(G.P, pos, r, xr);
+    nm_put_candidates(G, tot, pos, r, xc);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    G.m.counts[0] = tot;
+    G.m.counts[3] = tot;
+    G.m.counts[5] = 4 * tot;
+    G.m.counts[4] += *parked;  // simplices waiting to shrink
+  }
+}
+
+__global__ void __launch_bounds__(NM_SNT) nm_glue_spec_kernel(NmGlue G, int jbound) {
+  __shared__ int sh[NM_SNT / 64 + 1];
+  __shared__ int parked;
+  if (threadIdx.x == 0) parked = 0;
+  __syncthreads();
+  switch (G.m.N) {
+    case 1: glue_spec_body<1>(G, jbound, sh, &parked); break;
+    case 2: glue_spec_body<2>(G, jbound, sh, &parked); break;
+    case 3: glue_spec_body<3>(G, jbound, sh, &parked); break;
+    case 4: glue_spec_body<4>(G, jbound, sh, &parked); break;
+    case 5: glue_spec_body<5>(G, jbound, sh, &parked); break;
+    case 6: glue_spec_body<6>(G, jbound, sh, &parked); break;
+    case 7: glue_spec_body<7>(G, jbound, sh, &parked); break;
+    default: glue_spec_body<8>(G, jbound, sh, &parked); break;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The two bookkeeping kernels above as TWO kernels each, for rounds of thousands of
 // rows: everything a row does for itself -- the value of its evaluation, its case,
 // the simplex update and ordering, the next round's test and point -- on as many
@@ -1293,6 +1474,23 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
     // the live count only falls between two looks (finished and parked
     // simplices leave the list), so it bounds the launches of the window
     const int jb = live;
+    // a handful of stragglers: the step's four candidate points in one launch and one
+    // bookkeeping kernel per round (nm_glue_spec_kernel)
+    if (jb <= rvs_opt(RVS_OPT_NM_SPEC_MAX) && jb <= NM_SNT && 4 * (int64_t)jb <= S) {
+      G.AO = obj_arm_out(o->scratch, o->narm, 4 * jb);
+      hipLaunchKernelGGL(nm_glue_spec_prep_kernel, dim3(1), dim3(NM_SNT), 0, st, G, jb);
+      RVS_LAUNCH_CHECK();
+      for (int r = 0; r < sync_every; r++) {
+        rc = nm_objective_rows(o, 4 * jb, m->counts + 5, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nm_glue_spec_kernel, dim3(1), dim3(NM_SNT), 0, st, G, jb);
+        RVS_LAUNCH_CHECK();
+        calls += 1;
+        jobs += 4 * (int64_t)jb;
+      }
+      rounds += sync_every;
+      continue;
+    }
     G.AO = obj_arm_out(o->scratch, o->narm, jb);
     for (int r = 0; r < sync_every; r++) {
       // (from a few thousand rows up the bookkeeping is row-parallel + pack)

@@ -1304,6 +1304,38 @@ def test_nm_bookkeeping_rows_and_pack_equal_one_block(cases, pcases, config):
     assert a['nm_rounds'] == b['nm_rounds']
 
 
+@pytest.mark.parametrize('S,spec_max', [(70, 21), (300, 64)])
+def test_nm_last_rounds_in_one_launch_equal_two(cases, pcases, config, S, spec_max):
+    """the optimiser's last rounds (at most nm_spec_max live simplices, and a quarter of
+    the batch) evaluate all four candidate points of a step in one launch and do the
+    round's bookkeeping in one kernel: iterations, evaluations (counted as scipy counts
+    them), end points, status -- the two-launch rounds' to the bit"""
+    from rvspecfit_amd import vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    rng = np.random.RandomState(17)
+    base = [_sds(cases, t) for t in ('c1', 'c3')]
+    batch = SpecBatch.from_specdata([base[i % 2] for i in range(S)])
+    for a in batch.arms:
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.03 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pd0 = dict(teff=rng.uniform(5000, 6800, S), logg=rng.uniform(1.5, 4.5, S),
+               feh=rng.uniform(-1.5, -0.1, S), alpha=rng.uniform(0, 0.4, S),
+               vsini=rng.uniform(1, 60, S))
+    out = []
+    for m in (0, spec_max):
+        with _lib.option('nm_spec_max', m), vel_fit.single_stream():
+            out.append(vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                       config=dict(config)))
+    a, b = out
+    assert int(a['nm_nit'].max()) > 100
+    for k in ('vel', 'vel_err', 'chisq', 'vsini', 'nm_nit', 'nm_nfev', 'chisq_array',
+              'minimize_success', 'status'):
+        if k in a:
+            assert torch.equal(torch.as_tensor(a[k]), torch.as_tensor(b[k])), k
+    for k in ('teff', 'logg', 'feh', 'alpha'):
+        assert torch.equal(a['param'][k], b['param'][k]), k
+        np.testing.assert_array_equal(a['param_err'][k], b['param_err'][k])
+
 def test_process_two_halves_equal_one_batch(cases, pcases, config):
     """vel_fit.process fits a large SpecBatch as two interleaved halves on two
     streams (two host threads over the native round driver): every result is that

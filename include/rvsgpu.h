@@ -77,7 +77,9 @@ extern "C" {
  *  11: rvs_spline_factors writes rvs_spline_factors_len(ntp) doubles (the five arrays
  *      of ntp, then the same factors in the objective kernel's chunk order); the cell
  *      record of rvs_objective_work_size grew by three doubles per (job, arm);
- *      rvs_chisq_work_size(_g) grew by 2*G*npix doubles ({lam, pix} pairs) */
+ *      rvs_chisq_work_size(_g) grew by 2*G*npix doubles ({lam, pix} pairs);
+ *      options nm_split_min and nm_spec_max (additions: no signature changed);
+ *      rvs_nm_run uses counts[5] (rows of a round that evaluates all candidates) */
 #define RVS_ABI_VERSION 11
 int rvs_abi_version(void);
 
@@ -696,7 +698,8 @@ int rvs_nn_outside(const double *params, int B, int ndim, uint32_t log_mask,
  *   sim [S, N+1, N], fsim [S, N+1] ordered ascending on entry; nit, nfev [S];
  *   flags [S]: bit0 active, bit1 converged, bit2 shrink pending;
  *   counts int32[8] (device): [0] |list1|, [1] |list2|, [2] |list3|,
- *   [3] simplices stepping this round, [4] simplices parked for a shrink.
+ *   [3] simplices stepping this round, [4] simplices parked for a shrink,
+ *   [5] rvs_nm_run: rows of a round that evaluates all four candidate points.
  * Every call takes `jbound`, a host-side upper bound of the job count (the
  * live count is read from `counts` on the device), so no host synchronisation
  * is needed inside a round; list/X entries in [count, jbound) are padded with

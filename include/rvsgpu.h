@@ -78,7 +78,8 @@ extern "C" {
  *      of ntp, then the same factors in the objective kernel's chunk order); the cell
  *      record of rvs_objective_work_size grew by three doubles per (job, arm);
  *      rvs_chisq_work_size(_g) grew by 2*G*npix doubles ({lam, pix} pairs);
- *      options nm_split_min and nm_spec_max (additions: no signature changed);
+ *      options nm_split_min, nm_spec_max, nm_tail_window (additions: no signature
+ *      changed);
  *      rvs_nm_run uses counts[5] (rows of a round that evaluates all candidates) */
 #define RVS_ABI_VERSION 11
 int rvs_abi_version(void);
@@ -105,6 +106,9 @@ int rvs_abi_version(void);
  *                       quarter of the simplices) evaluate all four candidate points
  *                       of a step in one launch, with one bookkeeping kernel per
  *                       round (same state, bit for bit); 0 = never
+ *   "nm_tail_window" 16 rvs_nm_run: rounds between two looks of the host (counter
+ *                       copy + stream synchronisation) once <= 256 rows are live,
+ *                       if larger than sync_every
  *   "obj_inblk_max" 256 objective launches of <= this many blocks search their grid
  *                       cell inside the block (0 = never)
  *   "obj_sort"       1  objective jobs evaluated in grid-cell order

@@ -1474,13 +1474,20 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
     // the live count only falls between two looks (finished and parked
     // simplices leave the list), so it bounds the launches of the window
     const int jb = live;
+    // (the host looks -- a copy of the counters and a stream synchronisation, then the
+    // next launches: ~25 us with nothing queued -- every sync_every rounds while the
+    // launch bound matters, and less often in the latency-bound last rounds, where a
+    // block behind the live count costs nothing.  A simplex's path does not depend on
+    // when the host looks)
+    const int window = (jb <= 256) ? max(sync_every, rvs_opt(RVS_OPT_NM_TAIL_WINDOW))
+                                   : sync_every;
     // a handful of stragglers: the step's four candidate points in one launch and one
     // bookkeeping kernel per round (nm_glue_spec_kernel)
     if (jb <= rvs_opt(RVS_OPT_NM_SPEC_MAX) && jb <= NM_SNT && 4 * (int64_t)jb <= S) {
       G.AO = obj_arm_out(o->scratch, o->narm, 4 * jb);
       hipLaunchKernelGGL(nm_glue_spec_prep_kernel, dim3(1), dim3(NM_SNT), 0, st, G, jb);
       RVS_LAUNCH_CHECK();
-      for (int r = 0; r < sync_every; r++) {
+      for (int r = 0; r < window; r++) {
         rc = nm_objective_rows(o, 4 * jb, m->counts + 5, st);
         if (rc) return rc;
         hipLaunchKernelGGL(nm_glue_spec_kernel, dim3(1), dim3(NM_SNT), 0, st, G, jb);
@@ -1488,11 +1495,11 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
         calls += 1;
         jobs += 4 * (int64_t)jb;
       }
-      rounds += sync_every;
+      rounds += window;
       continue;
     }
     G.AO = obj_arm_out(o->scratch, o->narm, jb);
-    for (int r = 0; r < sync_every; r++) {
+    for (int r = 0; r < window; r++) {
       // (from a few thousand rows up the bookkeeping is row-parallel + pack)
       const bool split = jb >= rvs_opt(RVS_OPT_NM_SPLIT_MIN);
       const dim3 rgrid((jb + NM_ROWS_NT - 1) / NM_ROWS_NT);
@@ -1521,7 +1528,7 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
       calls += 2;
       jobs += 2 * (int64_t)jb;
     }
-    rounds += sync_every;
+    rounds += window;
   }
   if (stats) {
     stats[0] = rounds;

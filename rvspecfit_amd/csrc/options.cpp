@@ -33,6 +33,7 @@ const OptDef kDefs[RVS_OPT_COUNT] = {
     {"nn_pipe", "RVS_NN_PIPE", 1, false},
     {"nm_split_min", "RVS_NM_SPLIT_MIN", 1024, false},
     {"nm_spec_max", "RVS_NM_SPEC_MAX", 21, false},
+    {"nm_tail_window", "RVS_NM_TAIL_WINDOW", 16, false},
 };
 std::atomic<int> g_val[RVS_OPT_COUNT];
 std::once_flag g_once;

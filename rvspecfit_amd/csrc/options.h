@@ -13,6 +13,7 @@ enum {
   RVS_OPT_NN_PIPE,        // MLP wide last layer: the kernel with the pipelined epilogue
   RVS_OPT_NM_SPLIT_MIN,   // rounds of >= this many rows: row-parallel bookkeeping + pack
   RVS_OPT_NM_SPEC_MAX,    // rounds of <= this many rows: all candidates in one launch
+  RVS_OPT_NM_TAIL_WINDOW, // rounds between two looks of the host once <= 256 rows are live
   RVS_OPT_COUNT
 };
 // current value (the table is filled from the environment on first use)

@@ -433,15 +433,20 @@ def _interp_bad_rows(spec, mask):
     (np.interp works in float64 and the result is stored back)."""
     n, npix = spec.shape
     out = spec * 1
-    idx = np.arange(npix, dtype=np.int32)[None, :]
     good = ~mask
-    prev = np.maximum.accumulate(np.where(good, idx, np.int32(-1)), axis=1)
-    nxt = np.minimum.accumulate(np.where(good, idx, np.int32(npix))[:, ::-1],
-                                axis=1)[:, ::-1]
     rr, cc = np.nonzero(mask & good.any(axis=1)[:, None])
     if len(rr) == 0:
         return out
-    L, R = prev[rr, cc], nxt[rr, cc]
+    # nearest good pixel to the left / right of every masked one, in its own row (-1 /
+    # npix where there is none): a search of the masked positions in the sorted list of
+    # good ones -- the masked pixels are a few per cent of the array
+    gflat = np.flatnonzero(good)
+    row0 = rr.astype(np.int64) * npix
+    i = np.searchsorted(gflat, row0 + cc)
+    p = gflat[np.maximum(i - 1, 0)]
+    q = gflat[np.minimum(i, len(gflat) - 1)]
+    L = np.where((i > 0) & (p >= row0), p - row0, -1)
+    R = np.where((i < len(gflat)) & (q < row0 + npix), q - row0, npix)
     Lc, Rc = np.maximum(L, 0), np.minimum(R, npix - 1)
     yl = spec[rr, Lc].astype(np.float64)
     yr = spec[rr, Rc].astype(np.float64)
@@ -495,17 +500,20 @@ def _row_nanmedian(a):
 
 def get_specdata_batch(waves, fluxes, ivars, masks, resolutions, seqids, setups,
                        use_resolution_matrix=False, mask_dicroic=True,
-                       lsf_sigma0_angstrom=None):
+                       lsf_sigma0_angstrom=None, as_float64=True):
     """get_specdata (desi_fit.py:781-888) for the fibres `seqids` at once.
 
     Returns {setup: dict(spec, espec float64 [n, npix]; badmask bool [n, npix];
     ok bool [n] -- False where the reference skips the arm (all masked, or an
-    insane median); taps float64 [n, npix, w] or None)}."""
+    insane median); taps float64 [n, npix, w] or None)}.  `as_float64=False`
+    leaves spec / espec in the file's own type (float32 in DESI coadds): the
+    values the reference converts to float64 are exactly these, and the batch
+    path converts on the device (half the bytes to select, join and upload)."""
     seqids = np.asarray(seqids, dtype=np.int64)
     out = {}
     for s in setups:
-        spec = np.array(fluxes[s][seqids])
-        curivars = np.array(ivars[s][seqids])
+        spec = fluxes[s][seqids]       # (fancy indexing: already copies)
+        curivars = ivars[s][seqids]
         badmask = masks[s][seqids] > 0
         n, npix = spec.shape
         med = np.ones(n, dtype=np.float64)
@@ -540,7 +548,7 @@ def get_specdata_batch(waves, fluxes, ivars, masks, resolutions, seqids, setups,
         curivars = np.where(badall, fill[:, None], curivars)
         spec = _interp_bad_rows(spec, badall_interp)
         with np.errstate(all='ignore'):
-            espec = (1. / np.sqrt(curivars)).astype(curivars.dtype)
+            espec = (1. / np.sqrt(curivars)).astype(curivars.dtype, copy=False)
         # sigma floor: 0.3 x the median error of the good pixels of the row
         ngood = (~badall).sum(axis=1)
         for i in np.nonzero(ok & (ngood == 0))[0]:
@@ -557,8 +565,9 @@ def get_specdata_batch(waves, fluxes, ivars, masks, resolutions, seqids, setups,
             logging.warning(
                 'More than 1% of spectra had the uncertainty clamped')
         espec = np.where(replace, thresh.astype(espec.dtype)[:, None], espec)
-        out[s] = dict(spec=spec.astype(np.float64), espec=espec.astype(np.float64),
-                      badmask=badall, ok=ok, taps=taps)
+        if as_float64:
+            spec, espec = spec.astype(np.float64), espec.astype(np.float64)
+        out[s] = dict(spec=spec, espec=espec, badmask=badall, ok=ok, taps=taps)
     return out
 
 
@@ -991,7 +1000,7 @@ def _proc_desi_steps(fname, tab_ofname, mod_ofname, fig_prefix, config,
     cond = get_specdata_batch(waves, fluxes, ivars, masks, resolutions,
                               seqid_to_fit, setups,
                               use_resolution_matrix=use_resolution_matrix,
-                              lsf_sigma0_angstrom=sig0s)
+                              lsf_sigma0_angstrom=sig0s, as_float64=False)
     okmat = np.stack([cond[s]['ok'] for s in setups], axis=1)
     tick('condition')
     for i in np.nonzero(~okmat.any(axis=1))[0]:

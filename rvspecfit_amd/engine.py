@@ -220,8 +220,11 @@ class ArmData:
         if isinstance(a, torch.Tensor):
             t = a.to(device=self.device, dtype=dtype)
         else:
-            t = torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device,
-                                                             dtype=dtype)
+            # (uploaded in its own type, converted on the device: float32 survey
+            # arrays cross the bus at half the bytes, the values are the same)
+            t = torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device)
+            if t.dtype != dtype:
+                t = t.to(dtype)
         if t.dim() == 1:
             t = t[None, :]
         return t.contiguous()

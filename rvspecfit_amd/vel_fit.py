@@ -552,7 +552,9 @@ def param_uncertainties(specdata, vel, atm_params, vsini=None, options=None,
 # unsplit run, bit for bit (no spectrum sees another;
 # test_process_two_halves_equal_one_batch).  1 switches it off.
 PROCESS_STREAMS = int(os.environ.get('RVS_PROCESS_STREAMS', '2'))
-PROCESS_SPLIT_MIN = 256
+# (64: the stellar targets of one DESI petal are 100-200 spectra -- split, 100 spectra
+# 832 -> 879 per second, 200: 1207 -> 1272; it was 256 until the end of round 5)
+PROCESS_SPLIT_MIN = int(os.environ.get('RVS_PROCESS_SPLIT_MIN', '64'))
 
 
 _tls = threading.local()

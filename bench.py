@@ -438,8 +438,14 @@ def main():
                          'starting from the CCF parameters; reported under '
                          '"process", never part of `value`')
     ap.add_argument('--process-cpu-sample', type=int, default=8)
+    ap.add_argument('--process-no-bfgs', action='store_true',
+                    help='--process / --desi-file run the reference\'s default '
+                         '(utils.py:26 second_minimizer = True: BFGS after '
+                         'Nelder-Mead); this switches the second minimiser off '
+                         '(the add-on figure)')
     ap.add_argument('--process-bfgs', action='store_true',
-                    help='run the second_minimizer (BFGS) polish in --process')
+                    help='(the default since round 6; kept so that older command '
+                         'lines still parse)')
     ap.add_argument('--desi-file', type=int, default=0,
                     help='add-on: write the first N spectra as a DESI coadd FITS '
                          'file and run the driver (desi_fit.proc_desi) on it: '
@@ -1070,7 +1076,7 @@ def run_process_addon(batch, rec, arms, args, dev):
                                torch.zeros_like(vs)).contiguous()
     cfg = dict(CONFIG)
     cfg.setdefault('max_vsini', 500)
-    cfg['second_minimizer'] = bool(args.process_bfgs)
+    cfg['second_minimizer'] = (not args.process_no_bfgs)
     vel_fit.process(sub, pd0, options=OPTIONS, config=cfg)   # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -1097,7 +1103,7 @@ def run_process_addon(batch, rec, arms, args, dev):
                minimize_success=round(float(
                    r['minimize_success'].float().mean()), 4),
                bad_hessian=round(float(np.mean(r['bad_hessian'])), 4),
-               second_minimizer=bool(args.process_bfgs),
+               second_minimizer=(not args.process_no_bfgs),
                note='add-on, not part of `value`; Hessian by central '
                     'differences (see DESIGN.md)')
     out['roofline'] = process_roofline(sub, r, out, tm, dt, dt1)
@@ -1172,7 +1178,7 @@ def run_desi_addon(arms, args, dev, dicts):
         nbytes += flux.nbytes + ivar.nbytes + mask.nbytes
     hdus.append(F.BinTableHDU(sc, name='SCORES'))
     F.HDUList(hdus).writeto(fname)
-    cfg = dict(CONFIG, second_minimizer=bool(args.process_bfgs),
+    cfg = dict(CONFIG, second_minimizer=(not args.process_no_bfgs),
                config_file_path='synthetic')
     tabf, modf = os.path.join(tmp, 'rvtab.fits'), os.path.join(tmp, 'rvmod.fits')
     logging_off()
@@ -1232,7 +1238,7 @@ def run_desi_addon(arms, args, dev, dicts):
                output_MB=round((os.path.getsize(tabf)
                                 + os.path.getsize(modf)) / 1e6, 1),
                success_frac=round(float((warn == 0).mean()), 4),
-               second_minimizer=bool(args.process_bfgs),
+               second_minimizer=(not args.process_no_bfgs),
                note='add-on, not part of `value`: desi_fit.proc_desi on one '
                     'synthetic coadd file, FITS in -> RVTAB/RVMOD out')
     import shutil

@@ -80,8 +80,10 @@ extern "C" {
  *      rvs_chisq_work_size(_g) grew by 2*G*npix doubles ({lam, pix} pairs);
  *      options nm_split_min, nm_spec_max, nm_tail_window (additions: no signature
  *      changed);
- *      rvs_nm_run uses counts[5] (rows of a round that evaluates all candidates) */
-#define RVS_ABI_VERSION 11
+ *      rvs_nm_run uses counts[5] (rows of a round that evaluates all candidates)
+ *  12: rvs_bfgs_run / rvs_bfgs_run_bytes (the second minimiser's rounds on the
+ *      device; additions: no signature changed) */
+#define RVS_ABI_VERSION 12
 int rvs_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -811,6 +813,36 @@ typedef struct rvs_nm_objective {
 int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o, double xatol,
                double fatol, int maxiter, int sync_every, int64_t *stats,
                void *stream);
+
+/* The second minimiser of vel_fit.process (vel_fit.py:653-658: scipy's BFGS from the
+ * simplex optimum, `second_minimizer`, the default of utils.py:26) with its rounds
+ * on the device: the S runs are the state machines of rvs_bfgs_begin / _pending /
+ * _feed (one source, csrc/bfgs_machine.h), one thread per spectrum; the rows they
+ * ask for -- a value, the n forward-difference points of a gradient, or both -- are
+ * gathered into one list per round and evaluated by the objective of rvs_nm_run in
+ * chunks of `cap` rows (the row capacity of o's buffers), the row counts staying on
+ * the device.  Blocks the calling host thread until every run has ended.
+ *   runs      S * rvs_bfgs_run_bytes() bytes of device memory (8-byte aligned)
+ *   x0 [S, n] start points, hess_inv0 [n, n] (device; NULL = identity)
+ *   x [S, n], fun [S], hess_inv [S, n, n] (nullable), nit / nfev / status [S]
+ *             (scipy's warnflag): results
+ *   nreq, off [S]; list [S (n + 1)]; X [S (n + 1), n]; F [S (n + 1)]; counts [32]:
+ *             work arrays (list zero-filled by the caller)
+ *   n = o->n <= 8; S (n + 1) <= 24 cap; maxiter <= 0: 200 n
+ * stats (nullable) int64[3] = rounds, objective calls, rows launched. */
+typedef struct rvs_bfgs_state {
+  void *runs;
+  const double *x0, *hess_inv0;
+  double *x, *fun, *hess_inv;
+  int32_t *nit, *nfev, *status;
+  int32_t *nreq, *off, *list, *counts;
+  double *X, *F;
+  double gtol, c1, c2, xrtol;
+  int32_t S, n, cap, maxiter;
+} rvs_bfgs_state;
+int64_t rvs_bfgs_run_bytes(void);
+int rvs_bfgs_run(const rvs_bfgs_state *b, const rvs_nm_objective *o,
+                 int sync_every, int64_t *stats, void *stream);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,8 @@ SIGNATURES = {
     'rvs_bfgs_feed': (I, [P, P, L]),
     'rvs_bfgs_result': (I, [P, P, P, P, P, P, P, P]),
     'rvs_bfgs_end': (None, [P]),
+    'rvs_bfgs_run_bytes': (L, []),
+    'rvs_bfgs_run': (I, [P, P, I, P, P]),
     'rvs_objective_max_ntp': (I, [I]),
     'rvs_objective_work_size': (L, [I, I]),
     'rvs_objective_fused': (I, [P, I, I, P, P, P, I, P, D, I, P, P, P, P]),
@@ -94,7 +96,7 @@ SIGNATURES = {
 
 _lib = None
 # RVS_ABI_VERSION of the include/rvsgpu.h these signatures mirror
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class RvsGpuError(RuntimeError):
@@ -176,6 +178,16 @@ class NmObjective(ctypes.Structure):
                     (k, ctypes.c_int32) for k in
                     ('narm', 'npoly', 'n', 'ndim', 'vsini_col')] + [
                     ('src', ctypes.c_int32 * 8), ('nn', ctypes.c_void_p)]
+
+
+class BfgsState(ctypes.Structure):
+    """rvs_bfgs_state of include/rvsgpu.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ('runs', 'x0', 'hess_inv0', 'x', 'fun', 'hess_inv', 'nit', 'nfev',
+                 'status', 'nreq', 'off', 'list', 'counts', 'X', 'F')] + [
+                    (k, ctypes.c_double) for k in
+                    ('gtol', 'c1', 'c2', 'xrtol')] + [
+                    (k, ctypes.c_int32) for k in ('S', 'n', 'cap', 'maxiter')]
 
 
 class PointArm(ctypes.Structure):

@@ -1,10 +1,16 @@
 """second_minimizer of vel_fit.process (vel_fit.py:653-658): scipy's BFGS for S
-spectra in lock-step.  The per-spectrum state machines are C++20 coroutines
-(csrc/bfgs_host.cpp, rvs_bfgs_*): scipy's `_minimize_bfgs` with its Wolfe line
-searches (MINPACK-2 dcsrch / dcstep, the `line_search_wolfe2` fallback),
-ScalarFunction's value caching and the 2-point gradient, each run suspended
-where it needs function values; this driver gathers the requests of all runs
-into one objective batch per round.
+spectra in lock-step.  The per-spectrum state machine (csrc/bfgs_machine.h) is
+scipy's `_minimize_bfgs` with its Wolfe line searches (MINPACK-2 dcsrch / dcstep,
+the `line_search_wolfe2` fallback), ScalarFunction's value caching and the
+2-point gradient, each run suspended where it needs function values.  Two
+drivers around the one machine:
+  minimize_lockstep_device  the rounds on the GPU (rvs_bfgs_run: one thread per
+                            run, the requests of all runs gathered into one
+                            objective batch per round by kernels) -- what
+                            vel_fit.process takes wherever the library launches
+                            the objective itself (regular-grid and MLP libraries)
+  minimize_lockstep_native  the machines on the host (rvs_bfgs_begin / _pending /
+                            _feed) around any Python objective
 
 The Python statement of the same algorithm that the CPU suite pins to scipy
 itself (identical nit / nfev / iterates) lives with the tests:
@@ -71,3 +77,52 @@ def minimize_lockstep_native(func, x0, hess_inv0=None, max_rows=None, gtol=1e-5,
     return dict(x=x, fun=fun, nit=nit.astype(np.int64),
                 nfev=nfev.astype(np.int64), status=status.astype(np.int64),
                 hess_inv=list(Hk), rounds=int(rounds.value))
+
+
+def minimize_lockstep_device(pobj, x0, hess_inv0=None, gtol=1e-5, c1=1e-4, c2=0.9,
+                             xrtol=0, maxiter=None, sync_every=4):
+    """The runs on the device (csrc/bfgs_dev.hip, rvs_bfgs_run) around an
+    optimizer.ProcessObjective whose rounds the library drives (pobj.fused or
+    pobj.nn_native): x0 [S, n] device tensor, hess_inv0 [n, n] array.  Returns
+    device tensors x [S, n], fun, nit, nfev, status [S] and the statistics of the
+    run (rounds, objective calls, rows launched)."""
+    import ctypes
+    import torch
+    from . import _lib
+    L = _lib.lib()
+    dev = x0.device
+    S, n = x0.shape
+    if n != pobj.n or S != pobj.S:
+        raise ValueError('minimize_lockstep_device: x0 does not fit the objective')
+    f64 = dict(dtype=torch.float64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    rows = S * (n + 1)
+    x0 = x0.to(torch.float64).contiguous()
+    H0 = None if hess_inv0 is None else torch.as_tensor(
+        np.ascontiguousarray(hess_inv0, dtype=np.float64)).to(dev).contiguous()
+    keep = dict(
+        runs=torch.empty(S * int(L.rvs_bfgs_run_bytes()) // 8 + 1, **f64),
+        x0=x0, hess_inv0=H0, x=torch.empty((S, n), **f64),
+        fun=torch.empty(S, **f64), hess_inv=None,
+        nit=torch.empty(S, **i32), nfev=torch.empty(S, **i32),
+        status=torch.empty(S, **i32), nreq=torch.zeros(S, **i32),
+        off=torch.zeros(S, **i32), list=torch.zeros(rows, **i32),
+        counts=torch.zeros(32, **i32), X=torch.zeros((rows, n), **f64),
+        F=torch.zeros(rows, **f64))
+    b = _lib.BfgsState()
+    for k, t in keep.items():
+        setattr(b, k, None if t is None else t.data_ptr())
+    b.gtol, b.c1, b.c2, b.xrtol = float(gtol), float(c1), float(c2), float(xrtol)
+    b.S, b.n, b.cap, b.maxiter = S, n, int(pobj.cap), int(maxiter or 0)
+    o = pobj.native_desc()
+    st3 = (ctypes.c_int64 * 3)()
+    _lib.check(L.rvs_bfgs_run(ctypes.addressof(b), ctypes.addressof(o),
+                              int(sync_every), st3, _lib.stream()),
+               'rvs_bfgs_run')
+    pobj.calls += int(st3[1])
+    nfev = keep['nfev'].long()
+    pobj.jobs += int(nfev.sum().item())
+    pobj.slots = getattr(pobj, 'slots', 0) + int(st3[2])
+    return dict(x=keep['x'], fun=keep['fun'], nit=keep['nit'].long(), nfev=nfev,
+                status=keep['status'].long(), rounds=int(st3[0]),
+                calls=int(st3[1]), rows_launched=int(st3[2]))

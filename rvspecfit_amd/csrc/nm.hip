@@ -22,6 +22,7 @@
 // tests/refmachines/neldermead_torch.py (which tests/ checks against scipy itself).
 #include "common.h"
 #include "objective_sum.h"
+#include "nm_internal.h"
 
 // numpy evaluates every product and sum of the simplex arithmetic separately;
 // a fused multiply-add would change the last bit and, eventually, the path
@@ -689,9 +690,9 @@ extern "C" int rvs_proc_finish(int J, const int32_t *counts, int cidx,
 // its host thread but not the interpreter (ctypes releases the GIL), so two
 // optimiser instances on two streams can be driven by two Python threads.
 // ---------------------------------------------------------------------------
-static int nm_eval(const rvs_nm_objective *o, const int32_t *list,
-                   const double *X, int J, const int32_t *counts, int cidx,
-                   double *F, hipStream_t st) {
+int rvs_internal_nm_eval(const rvs_nm_objective *o, const int32_t *list,
+                         const double *X, int J, const int32_t *counts, int cidx,
+                         double *F, hipStream_t st) {
   int rc = rvs_proc_map(J, o->n, o->ndim, X, list, o->src, o->vsini_col,
                         o->fixed, o->vsini_fixed, o->safe, o->prior_mean,
                         o->prior_isig, o->min_vel, o->max_vel, o->max_vsini,
@@ -1457,7 +1458,7 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
         rc = rvs_nm_shrink_point(N, k, m->sim, m->list3, m->X2, m->counts,
                                  parked, st);
         if (rc) return rc;
-        rc = nm_eval(o, m->list3, m->X2, parked, m->counts, 2, m->F2, st);
+        rc = rvs_internal_nm_eval(o, m->list3, m->X2, parked, m->counts, 2, m->F2, st);
         if (rc) return rc;
         calls++;
         jobs += parked;
@@ -1561,7 +1562,7 @@ static int nm_run_chain(const rvs_nm_state *m, const rvs_nm_objective *o,
         rc = rvs_nm_shrink_point(N, k, m->sim, m->list3, m->X2, m->counts,
                                  parked, st);
         if (rc) return rc;
-        rc = nm_eval(o, m->list3, m->X2, parked, m->counts, 2, m->F2, st);
+        rc = rvs_internal_nm_eval(o, m->list3, m->X2, parked, m->counts, 2, m->F2, st);
         if (rc) return rc;
         calls++;
         jobs += parked;
@@ -1583,12 +1584,12 @@ static int nm_run_chain(const rvs_nm_state *m, const rvs_nm_objective *o,
       rc = rvs_nm_begin(S, N, xatol, fatol, maxiter, m->sim, m->fsim, m->nit,
                         m->flags, m->list1, m->X1, m->counts, jb, st);
       if (rc) return rc;
-      rc = nm_eval(o, m->list1, m->X1, jb, m->counts, 0, m->F1, st);
+      rc = rvs_internal_nm_eval(o, m->list1, m->X1, jb, m->counts, 0, m->F1, st);
       if (rc) return rc;
       rc = rvs_nm_decide(N, m->sim, m->fsim, m->list1, m->F1, m->cases,
                          m->pos2, m->list2, m->X2, m->counts, jb, st);
       if (rc) return rc;
-      rc = nm_eval(o, m->list2, m->X2, jb, m->counts, 1, m->F2, st);
+      rc = rvs_internal_nm_eval(o, m->list2, m->X2, jb, m->counts, 1, m->F2, st);
       if (rc) return rc;
       rc = rvs_nm_update(N, m->sim, m->fsim, m->nit, m->nfev, m->list1, m->X1,
                          m->F1, m->cases, m->pos2, m->X2, m->F2, m->flags,

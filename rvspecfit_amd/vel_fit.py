@@ -552,6 +552,11 @@ def param_uncertainties(specdata, vel, atm_params, vsini=None, options=None,
 # unsplit run, bit for bit (no spectrum sees another;
 # test_process_two_halves_equal_one_batch).  1 switches it off.
 PROCESS_STREAMS = int(os.environ.get('RVS_PROCESS_STREAMS', '2'))
+# the second minimiser's rounds on the device (rvs_bfgs_run) wherever the library
+# launches the objective itself; False: the host machines around the Python objective
+# (what Delaunay evaluators and resolution matrices take anyway) -- the two run the
+# same state machine (test_process_bfgs_device_equals_host)
+BFGS_ON_DEVICE = os.environ.get('RVS_BFGS_ON_DEVICE', '1') != '0'
 # (64: the stellar targets of one DESI petal are 100-200 spectra -- split, 100 spectra
 # 832 -> 879 per second, 200: 1207 -> 1272; it was 256 until the end of round 5)
 PROCESS_SPLIT_MIN = int(os.environ.get('RVS_PROCESS_SPLIT_MIN', '64'))
@@ -831,19 +836,33 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     if config.get('second_minimizer'):
         from . import bfgs
         t0 = time.time()
-
-        def rows(idx_np, X_np):
-            it = torch.as_tensor(idx_np).to(dev)
-            return obj(it, torch.as_tensor(X_np).to(dev)).cpu().numpy()
-
         hess_inv0 = get_hess_inv(mapper.get_fitted_params())
-        br = bfgs.minimize_lockstep_native(rows, x.cpu().numpy(),
-                                           hess_inv0=hess_inv0,
-                                           max_rows=max(S, 1024))
-        x = torch.as_tensor(br['x']).to(dev)
+        if BFGS_ON_DEVICE and optimizer.NATIVE_ROUNDS and (
+                pobj.fused or pobj.nn_native):
+            # the rounds inside the library (rvs_bfgs_run), on the objective the
+            # simplex stage ran on
+            jobs_before = pobj.jobs
+            br = bfgs.minimize_lockstep_device(pobj, x, hess_inv0=hess_inv0)
+            obj.status |= pobj.status
+            obj.nfev += pobj.jobs - jobs_before
+            slots = getattr(pobj, 'slots', slots)
+            x = br['x']
+            bfgs_info = dict(nit=br['nit'].cpu().numpy(),
+                             nfev=br['nfev'].cpu().numpy(),
+                             status=br['status'].cpu().numpy(),
+                             rounds=br['rounds'], device=True)
+        else:
+            def rows(idx_np, X_np):
+                it = torch.as_tensor(idx_np).to(dev)
+                return obj(it, torch.as_tensor(X_np).to(dev)).cpu().numpy()
+
+            br = bfgs.minimize_lockstep_native(rows, x.cpu().numpy(),
+                                               hess_inv0=hess_inv0,
+                                               max_rows=max(S, 1024))
+            x = torch.as_tensor(br['x']).to(dev)
+            bfgs_info = dict(nit=br['nit'], nfev=br['nfev'], status=br['status'],
+                             rounds=br['rounds'], device=False)
         second_run = True
-        bfgs_info = dict(nit=br['nit'], nfev=br['nfev'], status=br['status'],
-                         rounds=br['rounds'])
         _tick('bfgs', t0)
     best = mapper.forward(x, allidx)
     nm_vel = best['vel'].contiguous()

@@ -1718,6 +1718,53 @@ def test_process_bfgs_implementations_agree(cases, config, monkeypatch):
     assert abs(np.mean(a['bfgs']['nfev']) / np.mean(b['bfgs']['nfev']) - 1) < 0.5
 
 
+@pytest.mark.parametrize('S', [24, 700])
+def test_process_bfgs_device_equals_host(cases, config, monkeypatch, S):
+    """second_minimizer with its rounds on the device (rvs_bfgs_run: one thread per
+    run of csrc/bfgs_machine.h, the requests gathered by kernels, the objective of
+    rvs_nm_run in chunks of S rows) against the same machines on the host around the
+    Python objective (rvs_bfgs_begin / _pending / _feed, the pair the CPU suite pins
+    to scipy): one source for both, the same objective kernel behind both -- the
+    runs take the same path (nit, nfev, status) and end in the same point.  700
+    spectra: a half of the batch is 350 runs = 6 waves of the advance kernel, a
+    first round of 7 chunks."""
+    from rvspecfit_amd import vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    rng = np.random.RandomState(16)
+    lists = [_sds(cases, ('c1', 'c3')[i % 2]) for i in range(S)]
+    batch = SpecBatch.from_specdata(lists)
+    for a in batch.arms:
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.02 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pd0 = dict(teff=rng.uniform(5000, 6800, S), logg=rng.uniform(1.5, 4.5, S),
+               feh=rng.uniform(-1.5, -0.1, S), alpha=rng.uniform(0, 0.4, S),
+               vsini=rng.uniform(1, 60, S))
+    cfg = dict(config, second_minimizer=True)
+    out = {}
+    for name, flag in (('device', True), ('host', False)):
+        monkeypatch.setattr(vel_fit, 'BFGS_ON_DEVICE', flag)
+        out[name] = vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                    config=cfg)
+    a, b = out['device'], out['host']
+    assert a['bfgs']['device'] and not b['bfgs']['device']
+    assert torch.equal(a['nm_nit'], b['nm_nit'])      # same simplex stage
+    same = (a['bfgs']['nit'] == b['bfgs']['nit']) & \
+        (a['bfgs']['nfev'] == b['bfgs']['nfev']) & \
+        (a['bfgs']['status'] == b['bfgs']['status'])
+    # (the machines differ in pow() of _cubicmin and in the order in which the
+    # prior / vsini penalties join the sum: a run whose zoom step or tie falls on
+    # that last bit may part ways)
+    assert same.mean() > 0.9, (same.mean(), a['bfgs']['nfev'][~same],
+                               b['bfgs']['nfev'][~same])
+    assert a['bfgs']['nfev'].max() > 20
+    sm = torch.as_tensor(same).to(a['vel'].device)
+    for k in ('vel', 'chisq'):
+        assert torch.equal(a[k][sm], b[k][sm]), k
+    for k in ('teff', 'logg', 'feh', 'alpha'):
+        assert torch.equal(a['param'][k][sm], b['param'][k][sm]), k
+    assert (a['chisq'] - b['chisq']).abs().max().item() < 2e-3    # fatol level
+
+
 @pytest.mark.parametrize('S', [40, 1300])
 def test_nm_round_kernels_equal_chain(cases, config, S):
     """rvs_nm_run's rounds -- three bookkeeping kernels that also sum the arms and

@@ -12,12 +12,14 @@ run --workload cfg2 --spectra 1000 --steps 5 --warmup 1 --cpu-sample 256
 run --evaluator nn --steps 3 --warmup 1
 run --refine --steps 2 --warmup 1 --no-cpu-baseline
 run --resolution-matrix --steps 2 --warmup 1 --no-cpu-baseline
+# (--process / --desi-file run the reference's default, second_minimizer = True;
+# --process-no-bfgs is the Nelder-Mead-only add-on)
 run --spectra 2000 --steps 1 --warmup 1 --cpu-sample 8 --process 2000 --process-cpu-sample 8
-run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000 --process-bfgs
+run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000 --process-no-bfgs
 run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500
-run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --process-bfgs
+run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --process-no-bfgs
 run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --desi-nfiles 16
-run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --desi-nfiles 16 --process-bfgs
+run --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --desi-file 500 --desi-nfiles 16 --process-no-bfgs
 run --spectra 62500 --steps 2 --warmup 1 --no-cpu-baseline
 # a library of realistic size (17 600 templates, dimensions of different length,
 # 440 MB per arm: gathers served from HBM), the default step and the optimiser
@@ -25,6 +27,8 @@ run --grid 40,11,8,5 --steps 3 --warmup 1 --no-cpu-baseline
 run --grid 40,11,8,5 --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000
 # the optimiser stage at full batch size, and on the NN evaluator
 run --spectra 10000 --steps 1 --warmup 1 --no-cpu-baseline --process 10000
+run --spectra 10000 --steps 1 --warmup 1 --no-cpu-baseline --process 10000 --process-no-bfgs
+run --spectra 500 --steps 1 --warmup 1 --no-cpu-baseline --process 500
 run --evaluator nn --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000
 run --evaluator nn --spectra 10000 --steps 1 --warmup 1 --no-cpu-baseline --process 10000
 # the DESI driver on MLP libraries (random weights: the fits themselves mean nothing)

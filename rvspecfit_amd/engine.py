@@ -739,10 +739,14 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
         return res.reshape(n, Nv), stj
 
     wide = [_arm_resol(arm, ia, resols) for ia, arm in enumerate(batch.arms)]
-    if any(r is not None and r['nd'] > RES_MAXND for r in wide):
+    if npoly > POINT_MAXP or \
+            any(r is not None and r['nd'] > RES_MAXND for r in wide):
         # resolution matrix wider than the grid kernel's band (the reference's
         # tests/test_sdss.py uses R = 50: 371 diagonals): every (job, velocity)
-        # is a job of the point kernel, which applies a band of any width
+        # is a job of the point kernel, which applies a band of any width.
+        # Likewise a continuum basis of 17 ... 32 functions (the reference has no
+        # cap: spec_fit.py:860, :1018-1092; the grid kernel keeps at most 16 per
+        # lane): chisq_point hands such jobs to rvs_chisq_full, a block per job
         res, stj = by_point_kernel(None)
         if out is not None:
             out.copy_(res)

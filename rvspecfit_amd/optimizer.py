@@ -39,6 +39,7 @@ class ProcessObjective:
         self.S, self.dev = S, dev
         self.npoly = options.get('npoly') or 5
         self.rbf = options.get('rbf_continuum', True)
+        self.resols = resols
         self.ndim = len(names)
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -304,12 +305,24 @@ class ProcessObjective:
             ev.record(side)
         for ev in self.ev_out:
             main.wait_event(ev)
-        self.jstatus.zero_()
-        rc = L.rvs_chisq_point(ctypes.addressof(self.arr), len(self.arm_buf),
-                               self.npoly, _p(self.job_spec), None, J,
-                               _p(self.vel), self.badchi, _p(self.scratch),
-                               _p(self.chi), _p(self.jstatus), st)
-        _lib.check(rc, 'rvs_chisq_point')
+        from . import engine
+        if self.npoly > engine.POINT_MAXP:
+            # 17 ... 32 basis functions: beyond the point kernel's 16 per lane, the
+            # arms' values come from rvs_chisq_full (engine.chisq_point)
+            c, stj = engine.chisq_point(
+                self.batch, self.libs, [b['coef'] for b in self.arm_buf],
+                [b['outside'][:J] for b in self.arm_buf], self.vel[:J],
+                npoly=self.npoly, rbf=self.rbf, job_spec=self.job_spec[:J],
+                resols=self.resols)
+            self.chi[:J] = c
+            self.jstatus[:J] = stj
+        else:
+            self.jstatus.zero_()
+            rc = L.rvs_chisq_point(ctypes.addressof(self.arr), len(self.arm_buf),
+                                   self.npoly, _p(self.job_spec), None, J,
+                                   _p(self.vel), self.badchi, _p(self.scratch),
+                                   _p(self.chi), _p(self.jstatus), st)
+            _lib.check(rc, 'rvs_chisq_point')
         rc = L.rvs_proc_finish(J, _p(counts), cidx, _p(self.chi), _p(self.extra),
                                _p(self.bad), _p(self.job_spec), _p(self.jstatus),
                                _p(F), _p(self.status), st)

@@ -477,3 +477,23 @@ def test_npoly_above_16_vs_reference(gold_libs, gold_config, tag, npoly):
         np.testing.assert_allclose(full['chisq_array'], g[k + 'chisq_array'],
                                    rtol=1e-7)
         np.testing.assert_array_equal(full['npix_array'], g[k + 'npix_array'])
+
+
+@pytest.mark.parametrize('tag,npoly', [('c0', 17), ('c1', 24)])
+def test_find_best_above_16_vs_reference(gold_libs, gold_config, tag, npoly):
+    """the oracle's find_best at 17 / 24 continuum functions against the reference's
+    own (npoly_wide_grid_cases.npz, make_golden_npoly_wide.py grid_callers)"""
+    g = np.load(os.path.join(GOLD, 'npoly_wide_grid_cases.npz'))
+    cases = np.load(os.path.join(GOLD, 'cases.npz'))
+    sds = gold_specdata(cases, tag, orc.SpecData)
+    k0 = '%s/p%d/' % (tag, npoly)
+    opt = dict(npoly=npoly, rbf_continuum=bool(g[k0 + 'rbf']))
+    vg = g[k0 + 'vel_grid'][20:41]      # (a third of the grid: CPU seconds)
+    pl = [tuple(_) for _ in g[k0 + 'params']][:2]
+    npix = sum(len(_.lam) for _ in sds)
+    k = k0 + 'rot/'
+    chi = np.array([[float(orc.get_chisq(sds, v, par, rot_params=(20., ), options=opt,
+                                         config=gold_config, libs=gold_libs))
+                     for par in pl] for v in vg])
+    want = g[k + 'chisq'][20:41, :2]
+    assert np.abs(chi - want).max() <= 1e-7 * max(np.abs(want).max(), npix)

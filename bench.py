@@ -94,6 +94,28 @@ def nn_weights(ntp, seed):
     return d
 
 
+def nn_node_rows(w, physical_vec, chunk=4096):
+    """log-flux rows (float32, what GridInterp keeps as `dats`) of the MLP `w` at
+    the grid nodes physical_vec [4, n]: nn/NNInterpolator.py:14-91 with the
+    Mapper's log10 of teff (:159-171) in float32 numpy -- the CCF template set of an
+    MLP library is built from the MLP's own templates, as make_ccf.py builds it
+    from whatever evaluator the setup has"""
+    dims = [int(_) for _ in w['nn_dims']]
+    M, Sd = w['nn_M'], w['nn_S']
+    out = np.empty((physical_vec.shape[1], dims[-1]), dtype=np.float32)
+    for a in range(0, out.shape[0], chunk):
+        p = physical_vec[:, a:a + chunk].T.astype(np.float32)
+        y = p.copy()
+        y[:, 0] = np.log10(p[:, 0])
+        h = ((y - M) / Sd).astype(np.float32)
+        for i in range(len(dims) - 1):
+            h = (h @ w['nn_W%d' % i].T + w['nn_b%d' % i]).astype(np.float32)
+            if i < len(dims) - 2:
+                h = (h / (np.float32(1) + np.exp(-h))).astype(np.float32)
+        out[a:a + chunk] = h
+    return out
+
+
 def node_templates(T, S):
     """pipeline.fit_batch's rule for sharing one template per CCF node"""
     ntp = max(len(synth.template_lam_grid(*arm_def(a)['templ'])) for a in ARMS)
@@ -129,15 +151,24 @@ def build_library_dicts(ccf_every, convolve, device=None):
                                              grid_kw=GRID_KW, resol=RESOL,
                                              device=device)
         every = ccf_every_for(ccf_every, lib['dats'].shape[0])
-        ccf = synth.make_ccf_templates(lib, l0, l1, st, every=every,
-                                       vsinis=(0., 300.), convolve=convolve)
-        out[arm_name(a)] = synth.library_as_npz_dict(lib, ccf)
+        w = None
         if EVALUATOR == 'nn':
-            # the NN replaces the polylinear evaluator of the template build
+            # the MLP replaces the polylinear evaluator of the template build: its
+            # own templates at the grid nodes feed the CCF set (and, in main(), the
+            # observed spectra are drawn from it: make_spectra_from_library), so
+            # that the fits of this configuration mean something although the
+            # weights are random
+            w = nn_weights(len(lib['lam']), seed=11 + ord(a))
+            lib['dats'] = nn_node_rows(w, lib['physical_vec'])
+        ccf = synth.make_ccf_templates(lib, l0, l1, st, every=every,
+                                       vsinis=(0., 300.), convolve=convolve,
+                                       cont=None if w is None else 1.0)
+        out[arm_name(a)] = synth.library_as_npz_dict(lib, ccf)
+        if w is not None:
             d = out[arm_name(a)]
             for k in ('dats', 'idgrid', 'vec', 'uvec0', 'uvec1', 'uvec2', 'uvec3'):
                 d.pop(k)
-            d.update(nn_weights(len(lib['lam']), seed=11 + ord(a)))
+            d.update(w)
     return out
 
 
@@ -170,6 +201,43 @@ def make_spectra_device(tp, device):
         bad = torch.rand(sp0.shape, device=device, generator=g) < 0.05
         es = torch.where(bad, es * 1e4, es)  # masked: sigma inflated
         arms.append((arm_name(a), lam, spec, es, bad.to(torch.uint8)))
+    return arms
+
+
+def make_spectra_from_library(tp, device, config):
+    """Observed spectra drawn from the REGISTERED libraries themselves (float64, in
+    HBM): the library's template at the truth parameters, at the truth velocity on
+    the arm's pixels -- the `raw_models` of spec_fit.get_chisq(full_output), i.e.
+    the library's own evaluator, spline and Doppler factor -- plus noise at the
+    truth S/N and 5 % masked pixels.  For evaluators whose templates are not the
+    synthetic family's (--evaluator nn: an MLP with random weights): spectra from
+    synth.spectra_batch would have nothing to do with such a library and every fit
+    would end with a chi^2 warning (round 5: success_frac 0.0 on MLP libraries)."""
+    import torch
+    from rvspecfit_amd import engine, spec_fit
+    g = torch.Generator(device=device)
+    g.manual_seed(int(tp['seed']) + 77)
+    t = {k: torch.as_tensor(np.asarray(v, dtype=np.float64)).to(device)
+         for k, v in tp.items() if k != 'seed'}
+    S = t['vel'].shape[0]
+    one = [engine.ArmData(arm_name(a), obs_lam(a),
+                          torch.ones((S, len(obs_lam(a))), dtype=torch.float64,
+                                     device=device),
+                          torch.ones((S, len(obs_lam(a))), dtype=torch.float64,
+                                     device=device), device=device) for a in ARMS]
+    par = torch.stack([t['teff'], t['logg'], t['feh'], t['alpha']], dim=1)
+    outp = spec_fit.get_chisq(engine.SpecBatch(one), t['vel'].contiguous(),
+                              par.contiguous(), None, None, options=OPTIONS,
+                              config=config, full_output=True)
+    arms = []
+    for a, sp0 in zip(ARMS, outp['raw_models']):
+        es = sp0 / t['snr'][:, None]
+        noise = torch.randn(sp0.shape, dtype=torch.float64, device=device,
+                            generator=g)
+        spec = sp0 + es * noise
+        bad = torch.rand(sp0.shape, device=device, generator=g) < 0.05
+        es = torch.where(bad, es * 1e4, es)
+        arms.append((arm_name(a), obs_lam(a), spec, es, bad.to(torch.uint8)))
     return arms
 
 
@@ -286,7 +354,13 @@ def _cpu_one_process(i):
     pd0['vsini'] = float(d['start'][i, 4])
     cfg = dict(CONFIG)
     cfg.setdefault('max_vsini', 500)
-    r = orc.process(sds, pd0, None, OPTIONS, cfg, libs)
+    try:
+        r = orc.process(sds, pd0, None, OPTIONS, cfg, libs)
+    except RuntimeError:
+        # the reference raises on a non finite likelihood (spec_fit.py:963-974: an
+        # MLP far outside its training box overflows); the batch path records a
+        # status bit for such a spectrum instead
+        return [np.nan] * 14
     return [r['vel'], r['vel_err'], r['chisq'], r['vsini']] + \
         [r['param'][k] for k in names] + [r['param_err'][k] for k in names] + \
         [sum(r['nm_nit']), sum(r['nm_nfev'])]
@@ -568,7 +642,8 @@ def main():
     nfft = int(dicts[arm_name(ARMS[0])]['ccf_npoints'])
     tp = truth_params(S, seed=3 + 1000 * (args.seed_rank if args.seed_rank >= 0
                                           else rank))
-    arms = make_spectra_device(tp, dev)
+    arms = make_spectra_device(tp, dev) if EVALUATOR == 'polylinear' else \
+        make_spectra_from_library(tp, dev, CONFIG)
     if args.workload == 'sdss':
         # every spectrum keeps its own piece of the lattice: its pixels move to the
         # front of its row, the rest is padding (engine.ArmData, grid sets)
@@ -1131,8 +1206,9 @@ def run_process_addon(batch, rec, arms, args, dev):
                                  'on the C port of get_chisq)' % m)
         with np.errstate(all='ignore'):
             out['parity'] = dict(
-                n=m, max_abs_dvel=float(np.abs(gv - o[:, 0]).max()),
-                max_abs_dchisq=float(np.abs(gc - o[:, 2]).max()),
+                n=m, cpu_raised=int(np.isnan(o[:, 0]).sum()),
+                max_abs_dvel=float(np.nanmax(np.abs(gv - o[:, 0]))),
+                max_abs_dchisq=float(np.nanmax(np.abs(gc - o[:, 2]))),
                 max_dparam_over_sigma=float(np.nanmax(
                     np.abs(gp - o[:, 4:8]) / np.where(perr > 0, perr, np.nan))))
     return out

@@ -292,14 +292,15 @@ def library_as_npz_dict(lib, ccf=None):
 
 
 def make_ccf_templates(lib, lam0, lam1, step, every=64, vsinis=(0., 300.),
-                       convolve=None):
+                       convolve=None, cont=None):
     """CCF template set for a synthetic library in the reference's artefact
     layout (make_ccf.py:417-493): continuum-normalised, optionally rotationally
     broadened models rebinned on exp(linspace(log lam0, log lam1, 2^k)), their
     rfft and the rfft of their squares.  The continuum of the synthetic model is
     known analytically, so no robust fit is needed here (offline prep, not part
     of the hot path).  `convolve(lam, templ[J, n], vsini[J])` is the vsini
-    broadening routine (the HIP kernel in the bench)."""
+    broadening routine (the HIP kernel in the bench).  `cont`: the models'
+    continuum where it is not the synthetic family's (a float or [n_sel, ntp])."""
     npoints = to_power_two(int((lam1 - lam0) / step))
     logl = np.linspace(np.log(lam0), np.log(lam1), npoints)
     sel = np.arange(0, lib['dats'].shape[0], every)
@@ -309,7 +310,10 @@ def make_ccf_templates(lib, lam0, lam1, step, every=64, vsinis=(0., 300.),
     if not isinstance(rows, np.ndarray):     # device tensor (bench, big grids)
         rows = rows.cpu().numpy()
     flux = np.exp(rows.astype(np.float64))
-    cont = continuum(lib['lam'][None, :], phys[0][:, None])
+    if cont is None:
+        cont = continuum(lib['lam'][None, :], phys[0][:, None])
+    else:
+        cont = np.broadcast_to(np.asarray(cont, dtype=np.float64), flux.shape)
     for vs in vsinis:
         m = flux
         if vs and vs > 0:

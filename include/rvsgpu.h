@@ -82,7 +82,8 @@ extern "C" {
  *      changed);
  *      rvs_nm_run uses counts[5] (rows of a round that evaluates all candidates)
  *  12: rvs_bfgs_run / rvs_bfgs_run_bytes (the second minimiser's rounds on the
- *      device; additions: no signature changed) */
+ *      device), rvs_chisq_grid_resol_g (resolution matrices on grid sets);
+ *      additions: no signature changed */
 #define RVS_ABI_VERSION 12
 int rvs_abi_version(void);
 
@@ -309,6 +310,23 @@ int rvs_chisq_grid_resol(const double *lam, const double *polysT,
                          int64_t vel_stride, int Nv, const double *penalty,
                          double badchi, double beta, double *out,
                          int32_t *status, void *stream);
+/* ... for spectra of an arm on G wavelength grids of their own (grid sets, above:
+ * lam [G, npix], work from rvs_chisq_prepare_g, polysT of grid g at polysT + g *
+ * polys_stride), each with its own resolution matrix (spec_fit.py:922-929 accepts
+ * any SpecData.resolution; tests/test_sdss.py): taps [S, npix, nd] with npix the
+ * longest grid -- the rows behind a spectrum's own pixels, and every tap that
+ * refers to a pixel behind them, are zero.  pen_scale as in rvs_chisq_grid_g.
+ * G = 1 (grid_id NULL) is rvs_chisq_grid_resol. */
+int rvs_chisq_grid_resol_g(const double *lam, const double *polysT,
+                           const double *work, int npix, int npoly, int S,
+                           const int32_t *grid_id, int G, int64_t polys_stride,
+                           const double *knots, const double *coef, int ntp,
+                           int Tn, int log_step, const double *taps, int nd,
+                           int64_t taps_stride, const int32_t *job_spec,
+                           const int32_t *job_templ, int J, const double *vels,
+                           int64_t vel_stride, int Nv, const double *penalty,
+                           double badchi, double beta, const double *pen_scale,
+                           double *out, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------
  * get_chisq(full_output=True) for one velocity per job and one arm

@@ -41,6 +41,8 @@ SIGNATURES = {
                            D, D, I, P, P, P]),
     'rvs_chisq_grid_resol': (I, [P, P, P, I, I, I, P, P, I, I, I, P, I, L, P, P,
                                  I, P, L, I, P, D, D, P, P, P]),
+    'rvs_chisq_grid_resol_g': (I, [P, P, P, I, I, I, P, I, L, P, P, I, I, I, P, I, L,
+                                   P, P, I, P, L, I, P, D, D, P, P, P, P]),
     'rvs_chisq_full': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, P, P, I,
                            P, D, I, P, I, L, P, P, P, P, P, P, P, P]),
     'rvs_chisq_full_g': (I, [P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, P, P, I,

@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
                             int Nv, const double *__restrict__ penalty,
                             double badchi, double beta_out,
                             double *__restrict__ out,
-                            int32_t *__restrict__ status) {
+                            int32_t *__restrict__ status, GridSet GS) {
   extern __shared__ double ring[];  // [nd][256]
   const int j = blockIdx.y;
   const int wave_v0 = blockIdx.x * 256 + (threadIdx.x & ~63);
@@ -675,6 +675,7 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
   const int t = job_templ ? job_templ[j] : j;
   double *outp = out + (int64_t)j * Nv;
   const double pen = penalty ? penalty[j] : 0.0;
+  if (GS.pen_scale) badchi *= GS.pen_scale[s];
   if (!(pen == pen) || isinf(pen)) {
     if (active) {
       const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
@@ -682,10 +683,14 @@ __global__ void __launch_bounds__(256, (P <= 10 ? 2 : 1))
     }
     return;
   }
-  const double *pixa = work;
-  const double2 *W = reinterpret_cast<const double2 *>(work + npix) +
+  // the spectrum's own wavelength grid (grid sets: rvs_chisq_prepare_g's layout)
+  const int64_t gi = GS.gid ? GS.gid[s] : 0;
+  lam += gi * npix;
+  polysT += gi * GS.polys_stride;
+  const double *pixa = work + gi * npix;
+  const double2 *W = reinterpret_cast<const double2 *>(work + (int64_t)GS.G * npix) +
                      (int64_t)s * npix;
-  const double *scal = work + npix + 2ll * S * npix + 2 * s;
+  const double *scal = work + (int64_t)GS.G * npix + 2ll * S * npix + 2 * s;
   const double4 *cf = coef + (int64_t)t * ntp;
   const double *tp = taps + (int64_t)s * taps_stride;
   const int m = (nd - 1) / 2;
@@ -814,7 +819,8 @@ __global__ void __launch_bounds__(64)
                             int Nv, const double *__restrict__ penalty,
                             double badchi, double beta_out,
                             double *__restrict__ out,
-                            int32_t *__restrict__ status, int J, int nw) {
+                            int32_t *__restrict__ status, int J, int nw,
+                            GridSet GS) {
   // Blocks are dealt round-robin over the 8 XCDs: the nw waves of a job are 8
   // blocks apart (as in chisq_grid_kernel), so that the job's taps (npix x 11
   // doubles, 242 KB per DESI arm, read by every one of its waves through the
@@ -833,6 +839,7 @@ __global__ void __launch_bounds__(64)
   const int t = job_templ ? job_templ[j] : j;
   double *outp = out + (int64_t)j * Nv;
   const double pen = penalty ? penalty[j] : 0.0;
+  if (GS.pen_scale) badchi *= GS.pen_scale[s];
   if (!(pen == pen) || isinf(pen)) {
     if (active) {
       const double base = (beta_out != 0.0) ? beta_out * outp[iv] : 0.0;
@@ -840,10 +847,14 @@ __global__ void __launch_bounds__(64)
     }
     return;
   }
-  const double *pixa = work;
-  const double2 *W = reinterpret_cast<const double2 *>(work + npix) +
+  // the spectrum's own wavelength grid (grid sets: rvs_chisq_prepare_g's layout)
+  const int64_t gi = GS.gid ? GS.gid[s] : 0;
+  lam += gi * npix;
+  polysT += gi * GS.polys_stride;
+  const double *pixa = work + gi * npix;
+  const double2 *W = reinterpret_cast<const double2 *>(work + (int64_t)GS.G * npix) +
                      (int64_t)s * npix;
-  const double *scal = work + npix + 2ll * S * npix + 2 * s;
+  const double *scal = work + (int64_t)GS.G * npix + 2ll * S * npix + 2 * s;
   const double4 *cf = coef + (int64_t)t * ntp;
   const double *tp = taps + (int64_t)s * taps_stride;
   const double vel = vels[(int64_t)j * vel_stride + iv];
@@ -1205,16 +1216,19 @@ extern "C" int rvs_chisq_grid(const double *lam, const double *polysT,
                           nullptr, out, status, stream);
 }
 
-extern "C" int rvs_chisq_grid_resol(
+extern "C" int rvs_chisq_grid_resol_g(
     const double *lam, const double *polysT, const double *work, int npix,
-    int npoly, int S, const double *knots, const double *coef, int ntp, int Tn,
+    int npoly, int S, const int32_t *grid_id, int G, int64_t polys_stride,
+    const double *knots, const double *coef, int ntp, int Tn,
     int log_step, const double *taps, int nd, int64_t taps_stride,
     const int32_t *job_spec, const int32_t *job_templ, int J, const double *vels,
     int64_t vel_stride, int Nv, const double *penalty, double badchi,
-    double beta, double *out, int32_t *status, void *stream) {
+    double beta, const double *pen_scale, double *out, int32_t *status,
+    void *stream) {
   if (npix < 1 || J < 1 || Nv < 1 || ntp < 3 || Tn < 1 || !taps || nd < 1 ||
-      nd > RES_MAXND || (nd & 1) == 0 || J > 65535)
+      nd > RES_MAXND || (nd & 1) == 0 || J > 65535 || G < 1 || (G > 1 && !grid_id))
     return RVS_E_ARG;
+  const GridSet GS = {G > 1 ? grid_id : nullptr, polys_stride, G, pen_scale};
   hipStream_t st = rvs_stream(stream);
   dim3 grid((Nv + 255) / 256, J);
   const size_t shm = (size_t)nd * 256 * sizeof(double);
@@ -1236,14 +1250,14 @@ extern "C" int rvs_chisq_grid_resol(
                          reinterpret_cast<const double4 *>(coef), ntp,         \
                          log_step, taps, taps_stride, job_spec, job_templ,     \
                          vels, vel_stride, Nv, penalty, badchi, beta, out,     \
-                         status, J, (Nv + 63) / 64);                           \
+                         status, J, (Nv + 63) / 64, GS);                       \
     else                                                                       \
       hipLaunchKernelGGL(chisq_grid_resol_kernel<PP>, grid, dim3(256), shm,    \
                          st, lam, polysT, work, npix, S, knots,                \
                          reinterpret_cast<const double4 *>(coef), ntp,         \
                          log_step, taps, nd, taps_stride, job_spec, job_templ, \
                          vels, vel_stride, Nv, penalty, badchi, beta, out,     \
-                         status);                                              \
+                         status, GS);                                          \
   } break;
   switch (npoly) {
     RVS_CASE(1) RVS_CASE(2) RVS_CASE(3) RVS_CASE(4) RVS_CASE(5) RVS_CASE(6)
@@ -1255,6 +1269,19 @@ extern "C" int rvs_chisq_grid_resol(
 #undef RVS_CASE
   RVS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int rvs_chisq_grid_resol(
+    const double *lam, const double *polysT, const double *work, int npix,
+    int npoly, int S, const double *knots, const double *coef, int ntp, int Tn,
+    int log_step, const double *taps, int nd, int64_t taps_stride,
+    const int32_t *job_spec, const int32_t *job_templ, int J, const double *vels,
+    int64_t vel_stride, int Nv, const double *penalty, double badchi,
+    double beta, double *out, int32_t *status, void *stream) {
+  return rvs_chisq_grid_resol_g(lam, polysT, work, npix, npoly, S, nullptr, 1, 0, knots,
+                                coef, ntp, Tn, log_step, taps, nd, taps_stride,
+                                job_spec, job_templ, J, vels, vel_stride, Nv, penalty,
+                                badchi, beta, nullptr, out, status, stream);
 }
 
 // ---------------------------------------------------------------------------

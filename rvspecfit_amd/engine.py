@@ -85,27 +85,30 @@ def resol_taps(mats, npix):
     """A9: banded resolution matrices (scipy.sparse, e.g. the dia matrices of
     construct_resol_mat / desi_fit.construct_resolution_sparse_matrix) as row
     taps for the kernels: taps[s, k, d] = R_s[k, k - m + d], m = (nd-1)/2.
+    A matrix may be SMALLER than npix (a spectrum on a shorter grid of a grid
+    set): its rows fill the first pixels, everything behind them is zero.
     Returns (taps float64 [len(mats), npix, nd], nd)."""
     import scipy.sparse
     m = 0
     dias = []
     for M in mats:
         D = scipy.sparse.dia_matrix(M)
-        assert D.shape == (npix, npix)
+        assert D.shape[0] == D.shape[1] and D.shape[0] <= npix
         offs = [int(o) for o, row in zip(D.offsets, D.data) if np.any(row != 0)]
         if offs:
             m = max(m, max(abs(o) for o in offs))
         dias.append(D)
     nd = 2 * m + 1
     taps = np.zeros((len(mats), npix, nd))
-    k = np.arange(npix)
     for i, D in enumerate(dias):
+        n = D.shape[0]
+        k = np.arange(n)
         for o, row in zip(D.offsets, D.data):
             o = int(o)
             if abs(o) > m:
                 continue
             # dia storage: data[d, j] = R[j - o, j]  ->  R[k, k + o] = row[k + o]
-            ok = (k + o >= 0) & (k + o < npix)
+            ok = (k + o >= 0) & (k + o < n)
             taps[i, k[ok], m + o] += row[k[ok] + o]
     return taps, nd
 
@@ -163,8 +166,6 @@ class ArmData:
         assert self.spec.shape == self.espec.shape == self.badmask.shape
         assert self.spec.shape[1] == self.npix
         if self.G > 1:
-            assert resolution is None, \
-                'resolution matrices need one wavelength grid per arm'
             assert len(self.grid_id_host) == self.S
             # the padding: no weight (espec = +inf is the kernels' marker), masked
             n_s = torch.as_tensor(self.npix_g).to(device)[self.grid_id.long()]
@@ -185,6 +186,10 @@ class ArmData:
 
     def set_resolution(self, mats):
         assert len(mats) in (1, self.S)
+        if self.G > 1:   # (one matrix per spectrum, of its own grid's size)
+            assert len(mats) == self.S and all(
+                m.shape[0] == self.npix_g[g]
+                for m, g in zip(mats, self.grid_id_host))
         taps, nd = resol_taps(mats, self.npix)
         self.resol = make_resol(taps, nd, self.S, self.device)
 
@@ -197,13 +202,20 @@ class ArmData:
                                   return_inverse=True)
             npx = int(self.npix_g[used].max())
             if len(used) == 1:
-                return ArmData(self.name, self.grids[int(used[0])],
-                               self.spec[idx][:, :npx], self.espec[idx][:, :npx],
-                               self.badmask[idx][:, :npx], device=self.device)
-            return ArmData(self.name, [self.grids[int(k)] for k in used],
-                           self.spec[idx][:, :npx], self.espec[idx][:, :npx],
-                           self.badmask[idx][:, :npx], device=self.device,
-                           grid_id=gid.astype(np.int32))
+                a = ArmData(self.name, self.grids[int(used[0])],
+                            self.spec[idx][:, :npx], self.espec[idx][:, :npx],
+                            self.badmask[idx][:, :npx], device=self.device)
+            else:
+                a = ArmData(self.name, [self.grids[int(k)] for k in used],
+                            self.spec[idx][:, :npx], self.espec[idx][:, :npx],
+                            self.badmask[idx][:, :npx], device=self.device,
+                            grid_id=gid.astype(np.int32))
+            if self.resol is not None:   # (per spectrum: taps [S, npix, nd])
+                r = self.resol
+                a.resol = dict(taps=r['taps'][idx][:, :npx].contiguous(),
+                               nd=r['nd'], stride=npx * r['nd'],
+                               unit=r['unit'][idx][:, :npx].contiguous())
+            return a
         a = ArmData(self.name, self.lam_host, self.spec[idx], self.espec[idx],
                     self.badmask[idx], device=self.device)
         if self.resol is not None:
@@ -564,9 +576,6 @@ class SpecBatch:
                             resolution=None if res[0] is None else
                             [r.mat for r in res]))
                 continue
-            if res[0] is not None:
-                raise ValueError('spectra with resolution matrices must share the '
-                                 'wavelength grid of their arm to be batched')
             npix = max(len(g) for g in grids)
 
             def padded(attr, fill, dtype):
@@ -578,7 +587,11 @@ class SpecBatch:
             arms.append(ArmData(sd0.name, grids, padded('spec', 0.0, np.float64),
                                 padded('espec', np.inf, np.float64),
                                 padded('badmask', 1, np.uint8), device=device,
-                                grid_id=np.array(gid, dtype=np.int32)))
+                                grid_id=np.array(gid, dtype=np.int32),
+                                # (spec_fit.py:922-929: any SpecData.resolution --
+                                # one matrix per spectrum, of its own grid's size)
+                                resolution=None if res[0] is None else
+                                [r.mat for r in res]))
         return cls(arms)
 
     def badchi_jobs(self, job_spec=None):
@@ -781,16 +794,17 @@ def chisq_grid(batch, libs, coefs, outsides, vels, npoly=5, rbf=True,
             jt = _lib.ptr(job_templ[a:b]) if job_templ is not None else \
                 (_lib.ptr(_arange32(a, b, dev)) if a > 0 else None)
             if rs is not None:   # A9: banded resolution matrix
-                assert arm.G == 1
-                rc = L.rvs_chisq_grid_resol(
+                gid, G = arm.grid_args()
+                rc = L.rvs_chisq_grid_resol_g(
                     _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(work),
-                    arm.npix, npoly, arm.S, _lib.ptr(lib.knots), _lib.ptr(coef),
+                    arm.npix, npoly, arm.S, gid, G, arm.basis_stride(npoly),
+                    _lib.ptr(lib.knots), _lib.ptr(coef),
                     lib.ntp, coef.shape[0], int(lib.log_step),
                     _lib.ptr(rs['taps']), rs['nd'], rs['stride'], js, jt, b - a,
                     _lib.ptr(vels if shared else vels[a:b]), vstride, Nv,
                     _lib.ptr(pen[a:b]), float(batch.badchi),
-                    0.0 if ia == 0 else 1.0, _lib.ptr(out[a:b]),
-                    _lib.ptr(status[a:b]), _lib.stream())
+                    0.0 if ia == 0 else 1.0, _lib.ptr(batch.pen_scale),
+                    _lib.ptr(out[a:b]), _lib.ptr(status[a:b]), _lib.stream())
                 _lib.check(rc, 'rvs_chisq_grid_resol')
                 continue
             gid, G = arm.grid_args()
@@ -1129,7 +1143,6 @@ def chisq_full(batch, libs, coefs, vel, npoly=5, rbf=True, job_spec=None,
         coef = None if unit_template else coefs[ia]
         rs = _arm_resol(arm, ia, resols)
         gid, G = arm.grid_args()
-        assert rs is None or G == 1
         rc = L.rvs_chisq_full_g(
             _lib.ptr(arm.lam), _lib.ptr(polysT), _lib.ptr(arm.spec),
             _lib.ptr(arm.espec), _lib.ptr(arm.badmask), arm.npix, npoly, arm.S,

@@ -293,6 +293,11 @@ def _resols(batch, resol_params):
         if arm.resol is not None:
             raise ValueError('You are not allowed to set resol_param together '
                              'with the resolution of each SpecData')
+        if arm.G > 1:
+            # (the reference applies resol_params[setup] to every spectrum of the
+            # setup: one matrix cannot fit wavelength grids of different length)
+            raise ValueError('resol_params needs one wavelength grid per setup; '
+                             'give each SpecData its own resolution')
         key = (hash(R), arm.S, str(batch.device))
         def make(R=R, arm=arm):
             taps, nd = engine.resol_taps([R.mat], arm.npix)

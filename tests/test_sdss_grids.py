@@ -195,3 +195,109 @@ def test_process_two_halves_on_grid_set(gcases, gbatch, monkeypatch):
     for i in range(S):
         n = len(sds[i][0].lam)
         assert not ya[i, n:].any()
+
+
+# --------------------------------------------------------------------------
+# ... each with its own resolution matrix (spec_fit.py:922-929)
+# --------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def rcases():
+    return dict(np.load(os.path.join(GOLD, 'sdss_grid_resol_cases.npz')))
+
+
+def _resol_batch(gcases, rcases, sname):
+    from rvspecfit_amd import spec_fit
+    from rvspecfit_amd.engine import SpecBatch
+    sds = []
+    for i, rr in enumerate(rcases[sname + '/resol']):
+        lam = gcases['s%d/lam' % i]
+        sds.append([spec_fit.SpecData(
+            'sdss1', lam, gcases['s%d/spec' % i], gcases['s%d/espec' % i],
+            badmask=gcases['s%d/badmask' % i],
+            resolution=spec_fit.construct_resol_mat(lam, float(rr)))])
+    return sds, SpecBatch.from_specdata(sds)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sname', ['A', 'B'])
+def test_resolution_matrices_on_a_grid_set(gcases, rcases, gbatch, sname):
+    """SpecData.resolution on spectra that each come on their own wavelength grid
+    (the reference's own tests/test_sdss.py fits an SDSS spectrum through a resolution
+    matrix; as a batch these raised ValueError until round 6).  Set A: ten spectra,
+    bands of 9 / 11 diagonals (the software-pipelined velocity-grid kernel of nd =
+    11, rvs_chisq_grid_resol_g); set B: four spectra, 17-21 diagonals (the LDS-ring
+    kernel).  The batch equals the spectra one by one, bit for bit, and the
+    reference's get_chisq, find_best (whole chi^2 grid) and get_chisq_continuum of
+    every spectrum (sdss_grid_resol_cases.npz)."""
+    import torch
+    from rvspecfit_amd import spec_fit
+    sds, batch = _resol_batch(gcases, rcases, sname)
+    S = len(sds)
+    arm = batch.arms[0]
+    assert arm.G > 1 and arm.resol is not None
+    nds = [int(rcases['%s/s%d/ndiag' % (sname, i)]) for i in range(S)]
+    assert arm.resol['nd'] == max(nds) and (max(nds) == 11) == (sname == 'A')
+    for q, (v, par, vs) in enumerate(POINTS):
+        rot = None if vs is None else torch.full((S, ), vs, dtype=torch.float64,
+                                                 device=batch.device)
+        out = spec_fit.get_chisq(batch, np.full(S, v), par, rot_params=rot,
+                                 config=CFG, options=OPT, full_output=True)
+        chi = out['chisq'].cpu().numpy()
+        for i in range(S):
+            one = spec_fit.get_chisq(sds[i], v, par,
+                                     rot_params=None if vs is None else (vs, ),
+                                     config=CFG, options=OPT, full_output=True)
+            assert chi[i] == one['chisq'], (q, i)
+            n = len(sds[i][0].lam)
+            mod = out['models'][0][i].cpu().numpy()
+            assert np.array_equal(mod[:n], one['models'][0])
+            t = '%s/s%d/pt%d/' % (sname, i, q)
+            ref = float(rcases[t + 'chisq'])
+            assert abs(chi[i] - ref) <= 1e-7 * abs(ref), (q, i, chi[i], ref)
+            rm = rcases[t + 'model']
+            assert np.abs(mod[:n] - rm).max() <= 1e-6 * np.abs(rm).max()
+    vel_grid = rcases['vel_grid']
+    plist = [list(POINTS[0][1]), list(POINTS[1][1])]
+    fb = spec_fit.find_best(batch, vel_grid, plist, rot_params=None,
+                            options=OPT, config=CFG)
+    par = torch.as_tensor(np.array(plist))[None].expand(S, 2, 4).contiguous().to('cuda')
+    grid, st, _ = spec_fit.chisq_grid_jobs(batch, torch.as_tensor(vel_grid).to('cuda'),
+                                           par, None, OPT, CFG)
+    grid = grid.cpu().numpy()     # [S, Np, Nv]
+    cc = spec_fit.get_chisq_continuum(batch, options=OPT)['chisq_array'].cpu().numpy()
+    for i in range(S):
+        t = '%s/s%d/find_best/' % (sname, i)
+        assert abs(float(fb['best_vel'][i]) - rcases[t + 'best_vel']) < 1e-3
+        assert np.isclose(float(fb['best_chi'][i]), rcases[t + 'best_chi'], rtol=1e-7)
+        assert np.isclose(float(fb['vel_err'][i]), rcases[t + 'vel_err'], rtol=1e-4)
+        assert list(fb['best_param'][i].cpu().numpy()) == list(rcases[t + 'best_param'])
+        ref = rcases[t + 'chisq0']
+        assert np.abs(grid[i, 0] / ref - 1).max() < 1e-7
+        one = spec_fit.find_best(sds[i], vel_grid, plist, rot_params=None,
+                                 options=OPT, config=CFG)
+        assert float(fb['best_chi'][i]) == one['best_chi']
+        assert float(fb['best_vel'][i]) == one['best_vel']
+        assert np.isclose(cc[i, 0], rcases['%s/s%d/continuum' % (sname, i)][0],
+                          rtol=1e-8)
+        assert cc[i, 0] == spec_fit.get_chisq_continuum(
+            sds[i], options=OPT)['chisq_array'][0]
+    assert int(st.sum().item()) == 0
+
+
+@pytest.mark.gpu
+def test_process_with_resolution_on_a_grid_set(gcases, rcases, gbatch):
+    """vel_fit.process of such a batch (the optimiser's chain objective: the point
+    kernel takes the spectrum's own grid and its own taps) equals the spectra fitted
+    one by one"""
+    from rvspecfit_amd import vel_fit
+    sds, batch = _resol_batch(gcases, rcases, 'B')
+    cfg = dict(CFG, second_minimizer=False)
+    pd0 = dict(teff=np.array([5200., 5600., 4800., 5000.]),
+               logg=np.array([3., 4., 2.5, 3.5]), feh=np.full(4, -1.),
+               alpha=np.full(4, 0.2))
+    rb = vel_fit.process(batch, pd0, options=OPT, config=cfg)
+    for i in (0, 2):
+        r1 = vel_fit.process(sds[i], {k: float(v[i]) for k, v in pd0.items()},
+                             options=OPT, config=cfg)
+        assert float(rb['vel'][i]) == r1['vel']
+        assert float(rb['chisq'][i]) == r1['chisq']

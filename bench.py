@@ -169,6 +169,22 @@ def build_library_dicts(ccf_every, convolve, device=None):
             for k in ('dats', 'idgrid', 'vec', 'uvec0', 'uvec1', 'uvec2', 'uvec3'):
                 d.pop(k)
             d.update(w)
+        if EVALUATOR == 'tri':
+            # interpolation_type 'triangulation' (make_nd without --regulargrid,
+            # spec_inter.py:11-59): scipy's Delaunay of the mapped grid nodes, its
+            # arrays as the artefact converter exports them
+            import scipy.spatial
+            d = out[arm_name(a)]
+            dl = scipy.spatial.Delaunay(lib['vec'].T)
+            for k in ('idgrid', 'uvec0', 'uvec1', 'uvec2', 'uvec3'):
+                d.pop(k)
+            rows = lib['dats']
+            if not isinstance(rows, np.ndarray):
+                rows = rows.cpu().numpy()
+            d.update(dats=rows.astype(np.float64),
+                     simplices=dl.simplices.astype(np.int32),
+                     transform=dl.transform, extraflags=np.zeros(rows.shape[0]),
+                     interpolation_type=np.array('triangulation'))
     return out
 
 
@@ -544,9 +560,12 @@ def main():
     ap.add_argument('--workload', choices=['desi', 'cfg2', 'sdss'], default='desi',
                     help='desi: BASELINE configs[2] (3 arms); cfg2: configs[1] '
                          '(1 arm, 2001 px, N_fft 4096)')
-    ap.add_argument('--evaluator', choices=['polylinear', 'nn'],
+    ap.add_argument('--evaluator', choices=['polylinear', 'nn', 'tri'],
                     default='polylinear',
-                    help='nn: BASELINE configs[3], MLP template evaluator on MFMA')
+                    help='nn: BASELINE configs[3], MLP template evaluator on MFMA; '
+                         'tri: the same grid nodes as a Delaunay library '
+                         '(spec_inter.TriInterp: 31 104 simplices for the 7^4 grid), '
+                         'find_simplex through the bucket grid')
     ap.add_argument('--grid', type=str, default='',
                     help='template grid nodes per dimension "nteff,nlogg,nfeh,'
                          'nalpha" (default 7,7,7,7 = 60 MB/arm, Infinity-Cache '
@@ -642,7 +661,7 @@ def main():
     nfft = int(dicts[arm_name(ARMS[0])]['ccf_npoints'])
     tp = truth_params(S, seed=3 + 1000 * (args.seed_rank if args.seed_rank >= 0
                                           else rank))
-    arms = make_spectra_device(tp, dev) if EVALUATOR == 'polylinear' else \
+    arms = make_spectra_device(tp, dev) if EVALUATOR != 'nn' else \
         make_spectra_from_library(tp, dev, CONFIG)
     if args.workload == 'sdss':
         # every spectrum keeps its own piece of the lattice: its pixels move to the
@@ -737,7 +756,10 @@ def main():
     # stage and a first-guess grid evaluate them anywhere in the grid, i.e.
     # 16 rows per job scattered over the whole library
     gather = None
-    if EVALUATOR == 'polylinear' and rank == 0:
+    if EVALUATOR in ('polylinear', 'tri') and rank == 0:
+        # (rows blended per template: the 2^4 float32 vertex rows of a grid cell, or
+        # the 5 float64 rows of a Delaunay simplex behind find_simplex)
+        rows_b = 16 * 4 if EVALUATOR == 'polylinear' else 5 * 8
         ptrue = torch.as_tensor(np.stack(
             [tp[k] for k in ('teff', 'logg', 'feh', 'alpha')], axis=1)).to(dev)
         gb, gms = 0.0, 0.0
@@ -753,19 +775,25 @@ def main():
             torch.cuda.synchronize()
             gms += e0.elapsed_time(e1) / 3
             # algorithmic bytes: 16 float32 rows in, one float64 template out
-            gb += S * lib.ntp * (16 * 4 + 8)
+            gb += S * lib.ntp * (rows_b + 8)
         gather = dict(ms_per_batch=round(gms, 3),
                       alg_GBps=round(gb / (gms * 1e-3) / 1e9, 1),
                       frac_of_hbm_peak=round(gb / (gms * 1e-3) / 1e9
                                              / HBM_PEAK_GBS, 4),
                       library_MB_per_arm=[round(
                           dicts[arm_name(a)]['dats'].shape[0]
-                          * len(dicts[arm_name(a)]['lam']) * 4 / 1e6, 1)
+                          * len(dicts[arm_name(a)]['lam'])
+                          * (4 if EVALUATOR == 'polylinear' else 8) / 1e6, 1)
                           for a in ARMS],
-                      note='rvs_template_polylinear at the %d spectra\'s own '
-                           '(random in-grid) parameters, all arms; bytes = 16 '
-                           'float32 rows read + one float64 template written '
-                           'per job' % S)
+                      note=('rvs_template_polylinear at the %d spectra\'s own '
+                            '(random in-grid) parameters, all arms; bytes = 16 '
+                            'float32 rows read + one float64 template written '
+                            'per job' % S) if EVALUATOR == 'polylinear' else
+                      ('rvs_template_tri_buckets (find_simplex through the bucket '
+                       'grid + blend) at the %d spectra\'s own parameters, all arms; '
+                       'bytes = 5 float64 rows read + one template written per job; '
+                       '%d simplices' % (S, dicts[arm_name(ARMS[0])][
+                           'simplices'].shape[0])))
 
     if rank != 0:
         if world > 1:
@@ -904,7 +932,8 @@ def main():
                            fp64_TFLOPs=round(grid_tflops, 2)),
     }
     if gather is not None:
-        kernels['template_polylinear'] = gather
+        kernels['template_polylinear' if EVALUATOR == 'polylinear'
+                else 'template_tri'] = gather
     if 'ccf_preprocess' in kt:
         kernels['ccf_preprocess'] = dict(
             ms_per_step=round(kt['ccf_preprocess'][1] / args.steps, 2))
@@ -973,7 +1002,8 @@ def main():
 
     # SURVEY 8(d) D3 end-to-end byte model: B_alg = spectrum terms + polylinear
     # gather + CCF template block + outputs, per spectrum
-    b_alg = npix_tot * 16 + (16 * 4 * ntp_tot if EVALUATOR == 'polylinear' else 0) \
+    b_alg = npix_tot * 16 + (16 * 4 * ntp_tot if EVALUATOR == 'polylinear' else
+                             (5 * 8 * ntp_tot if EVALUATOR == 'tri' else 0)) \
         + b_ccf_unit + 4096
     line = dict(
         metric='spectra/sec (CCF+chi2 grid) DESI 3-arm' if args.workload == 'desi'

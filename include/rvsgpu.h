@@ -82,7 +82,8 @@ extern "C" {
  *      changed);
  *      rvs_nm_run uses counts[5] (rows of a round that evaluates all candidates)
  *  12: rvs_bfgs_run / rvs_bfgs_run_bytes (the second minimiser's rounds on the
- *      device), rvs_chisq_grid_resol_g (resolution matrices on grid sets);
+ *      device), rvs_chisq_grid_resol_g (resolution matrices on grid sets),
+ *      rvs_template_tri_buckets (find_simplex through a bucket grid);
  *      additions: no signature changed */
 #define RVS_ABI_VERSION 12
 int rvs_abi_version(void);
@@ -174,6 +175,27 @@ int rvs_template_tri(const double *dats, int ntp, const int32_t *simplices,
                      int nsimplex, int ndim, uint32_t log_mask, int exp_flag,
                      const double *params, int B, double *templ, double *outside,
                      int32_t *simplex, double *weights, void *stream);
+
+/* ... with find_simplex through a bucket grid instead of the exhaustive search (the
+ * same answer: the lowest simplex id that passes scipy's inside test,
+ * spec_inter.py:11-59 / Delaunay.find_simplex): cell c of a uniform grid over the
+ * mapped parameter space lists, ascending, every simplex whose bounding box (grown by
+ * 1e-9 of the grid's extent) overlaps it.  The cell of a mapped coordinate x in
+ * dimension d is clamp(floor((x - lo[d]) * inv_w[d]), 0, n[d] - 1), cells in C order
+ * over the dimensions.  The struct is read on the host; cell_start [ncell + 1] and
+ * cell_list [cell_start[ncell]] are device arrays. */
+typedef struct rvs_tri_buckets {
+  const int32_t *cell_start, *cell_list;
+  double lo[6], inv_w[6];
+  int32_t n[6];
+} rvs_tri_buckets;
+int rvs_template_tri_buckets(const double *dats, int ntp, const int32_t *simplices,
+                             const double *transform, const double *extraflags,
+                             int nsimplex, int ndim, uint32_t log_mask,
+                             int exp_flag, const rvs_tri_buckets *buckets,
+                             const double *params, int B, double *templ,
+                             double *outside, int32_t *simplex, double *weights,
+                             void *stream);
 
 /* ------------------------------------------------------------------------
  * A6  rotational broadening; replaces spec_fit.convolve_vsini /

@@ -26,6 +26,8 @@ SIGNATURES = {
     'rvs_template_polylinear': (I, [P, L, I, P, P, P, I, P, P, U, I, P, I, P, P,
                                     P, P, P]),
     'rvs_template_tri': (I, [P, I, P, P, P, I, I, U, I, P, I, P, P, P, P, P]),
+    'rvs_template_tri_buckets': (I, [P, I, P, P, P, I, I, U, I, P, P, I, P, P, P,
+                                     P, P]),
     'rvs_vsini_convolve': (I, [P, P, P, D, D, I, I, P, P]),
     'rvs_spline_factors': (I, [P, I, P, P]),
     'rvs_spline_factors_len': (ctypes.c_int64, [I]),
@@ -190,6 +192,13 @@ class BfgsState(ctypes.Structure):
                     (k, ctypes.c_double) for k in
                     ('gtol', 'c1', 'c2', 'xrtol')] + [
                     (k, ctypes.c_int32) for k in ('S', 'n', 'cap', 'maxiter')]
+
+
+class TriBuckets(ctypes.Structure):
+    """rvs_tri_buckets of include/rvsgpu.h"""
+    _fields_ = [('cell_start', ctypes.c_void_p), ('cell_list', ctypes.c_void_p),
+                ('lo', ctypes.c_double * 6), ('inv_w', ctypes.c_double * 6),
+                ('n', ctypes.c_int32 * 6)]
 
 
 class PointArm(ctypes.Structure):

@@ -255,6 +255,79 @@ __global__ void __launch_bounds__(256)
   if (weights && tid <= nd) weights[(int64_t)b * (nd + 1) + tid] = sh_b[tid];
 }
 
+// find_simplex through a uniform bucket grid over the (mapped) parameter space: a
+// cell lists, in ascending order, every simplex whose bounding box (grown by 1e-9 of
+// the grid's extent: far more than the inside test's 100 eps) overlaps it, so the
+// simplices that can contain a point are all in the point's cell and the first one
+// that passes scipy's inside test is the LOWEST matching id -- what the exhaustive
+// search returns -- after a few dozen tests instead of all 10^4 - 10^6 of a
+// PHOENIX-size triangulation.  One lane per query; the lists are built once per
+// library on the host (library.tri_buckets).
+__global__ void __launch_bounds__(64)
+    tri_locate_bucket_kernel(const double *__restrict__ transform, int nd,
+                             uint32_t log_mask, const double *__restrict__ params,
+                             int B, rvs_tri_buckets K,
+                             int32_t *__restrict__ simplex) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  double p[TRI_MAXDIM];
+  bool finite = true;
+  int64_t cell = 0;
+  for (int d = 0; d < nd; d++) {
+    p[d] = tri_map(params[(int64_t)b * nd + d], d, log_mask);
+    if (!(fabs(p[d]) <= 1.79e308)) finite = false;
+    double c = floor((p[d] - K.lo[d]) * K.inv_w[d]);
+    c = fmin(fmax(c, 0.0), (double)(K.n[d] - 1));
+    cell = cell * K.n[d] + (finite ? (int64_t)c : 0);
+  }
+  int found = 0x7fffffff;
+  if (finite) {
+    const double eps = 100.0 * 2.220446049250313e-16;
+    const int e0 = K.cell_start[cell], e1 = K.cell_start[cell + 1];
+    for (int e = e0; e < e1; e++) {
+      const int s = K.cell_list[e];
+      const double *T = transform + (int64_t)s * (nd + 1) * nd;
+      const double *r = T + nd * nd;
+      bool in = true;
+      double sum = 0;
+      for (int i = 0; i < nd; i++) {
+        double c = 0;
+        for (int jj = 0; jj < nd; jj++) c += T[i * nd + jj] * (p[jj] - r[jj]);
+        sum += c;
+        if (!(c >= -eps && c <= 1 + eps)) in = false;
+      }
+      const double cl = 1.0 - sum;
+      if (!(cl >= -eps && cl <= 1 + eps)) in = false;
+      if (in) {
+        found = s;
+        break;
+      }
+    }
+  }
+  simplex[b] = found;
+}
+
+extern "C" int rvs_template_tri_buckets(
+    const double *dats, int ntp, const int32_t *simplices, const double *transform,
+    const double *extraflags, int nsimplex, int ndim, uint32_t log_mask,
+    int exp_flag, const rvs_tri_buckets *buckets, const double *params, int B,
+    double *templ, double *outside, int32_t *simplex, double *weights,
+    void *stream) {
+  if (ndim < 1 || ndim > TRI_MAXDIM || B < 1 || ntp < 1 || nsimplex < 1 ||
+      !simplex || !buckets || !buckets->cell_start || !buckets->cell_list)
+    return RVS_E_ARG;
+  for (int d = 0; d < ndim; d++)
+    if (buckets->n[d] < 1) return RVS_E_ARG;
+  hipStream_t st = rvs_stream(stream);
+  hipLaunchKernelGGL(tri_locate_bucket_kernel, dim3((B + 63) / 64), dim3(64), 0, st,
+                     transform, ndim, log_mask, params, B, *buckets, simplex);
+  hipLaunchKernelGGL(tri_eval_kernel, dim3(B), dim3(256), 0, st, dats, ntp,
+                     simplices, transform, extraflags, ndim, log_mask, exp_flag,
+                     params, simplex, templ, outside, weights);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int rvs_template_tri(const double *dats, int ntp,
                                 const int32_t *simplices,
                                 const double *transform,

@@ -27,6 +27,78 @@ def _dev(a, dtype, device):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
 
 
+# find_simplex of Delaunay libraries: bucket grid from this many simplices up
+TRI_BUCKET_MIN = 256
+TRI_BUCKETS = True
+
+
+def tri_buckets(transform, ndim, per_cell=8, max_n=48, max_entries=1 << 26):
+    """The bucket grid of rvs_template_tri_buckets for a Delaunay triangulation given
+    as scipy's `transform` [nsimplex, ndim + 1, ndim] (spec_inter.py:11-59 keeps the
+    Delaunay object; the artefact reader exports its arrays): vertices from the
+    transform (the last one is r, the others r + the columns of the inverse), bounding
+    boxes grown by 1e-9 of the extent, a uniform grid of n^ndim cells with about
+    `per_cell` simplices per cell, every simplex entered in each cell its box
+    overlaps, the lists ascending.  Degenerate simplices (non-finite transform: they
+    never pass the inside test) are in no list.  Returns dict(cell_start int32
+    [ncell + 1], cell_list int32 [entries], lo, inv_w float64 [ndim], n int32 [ndim])."""
+    tr = np.asarray(transform, dtype=np.float64)
+    ns = tr.shape[0]
+    good = np.isfinite(tr).all(axis=(1, 2))
+    if good.any():
+        with np.errstate(all='ignore'):
+            det = np.linalg.det(tr[good][:, :ndim, :])
+        g2 = np.zeros(ns, dtype=bool)
+        g2[np.nonzero(good)[0][np.isfinite(det) & (det != 0)]] = True
+        good = g2
+    ids = np.nonzero(good)[0]
+    if len(ids) == 0:
+        return dict(cell_start=np.zeros(2, dtype=np.int32),
+                    cell_list=np.zeros(1, dtype=np.int32), lo=np.zeros(ndim),
+                    inv_w=np.zeros(ndim), n=np.ones(ndim, dtype=np.int32))
+    r = tr[ids, ndim, :]
+    cols = np.linalg.inv(tr[ids, :ndim, :])          # column j = vertex j - r
+    verts = np.concatenate([r[:, None, :] + np.swapaxes(cols, 1, 2),
+                            r[:, None, :]], axis=1)   # [n, ndim + 1, ndim]
+    blo, bhi = verts.min(axis=1), verts.max(axis=1)
+    lo, hi = blo.min(axis=0), bhi.max(axis=0)
+    ext = np.where(hi > lo, hi - lo, 1.0)
+    m = 1e-9 * ext
+    n1 = int(np.clip(round((len(ids) / float(per_cell))**(1.0 / ndim)), 1, max_n))
+    while True:
+        n = np.full(ndim, n1, dtype=np.int64)
+        inv_w = n / ext
+        i0 = np.clip(np.floor((blo - m - lo) * inv_w), 0, n - 1).astype(np.int64)
+        i1 = np.clip(np.floor((bhi + m - lo) * inv_w), 0, n - 1).astype(np.int64)
+        span = i1 - i0 + 1
+        total = int(span.prod(axis=1).sum())
+        if total <= max_entries or n1 == 1:
+            break
+        n1 = max(1, n1 // 2)
+    cells, sims = [], []
+    smax = span.max(axis=0)
+    for off in np.ndindex(*[int(_) for _ in smax]):
+        o = np.array(off)
+        ok = (o[None, :] < span).all(axis=1)
+        if not ok.any():
+            continue
+        c = np.zeros(int(ok.sum()), dtype=np.int64)
+        for d in range(ndim):
+            c = c * n[d] + (i0[ok, d] + o[d])
+        cells.append(c)
+        sims.append(ids[ok])
+    cells = np.concatenate(cells)
+    sims = np.concatenate(sims)
+    order = np.lexsort((sims, cells))        # by cell, ascending simplex inside
+    cells, sims = cells[order], sims[order]
+    ncell = int(n.prod())
+    start = np.zeros(ncell + 1, dtype=np.int64)
+    np.add.at(start, cells + 1, 1)
+    start = np.cumsum(start)
+    return dict(cell_start=start.astype(np.int32), cell_list=sims.astype(np.int32),
+                lo=lo, inv_w=inv_w, n=n.astype(np.int32))
+
+
 class TemplateLibrary:
 
     def __init__(self, name, d, device='cuda'):
@@ -71,6 +143,21 @@ class TemplateLibrary:
             self.tri_extraflags = _dev(np.asarray(d['extraflags']).reshape(-1),
                                        torch.float64, device)
             self.tri_nsimplex = int(np.asarray(d['simplices']).shape[0])
+            # find_simplex through a bucket grid (rvs_template_tri_buckets) from a
+            # few hundred simplices up; TRI_BUCKETS = False keeps the exhaustive
+            # search (tests hold one against the other)
+            self._tri_bk = self._tri_keep = None
+            if self.tri_nsimplex >= TRI_BUCKET_MIN and str(device) != 'cpu':
+                bk = tri_buckets(np.asarray(d['transform']), self.ndim)
+                self._tri_keep = (_dev(bk['cell_start'], torch.int32, device),
+                                  _dev(bk['cell_list'], torch.int32, device))
+                t = _lib.TriBuckets()
+                t.cell_start = self._tri_keep[0].data_ptr()
+                t.cell_list = self._tri_keep[1].data_ptr()
+                for k in range(self.ndim):
+                    t.lo[k], t.inv_w[k] = float(bk['lo'][k]), float(bk['inv_w'][k])
+                    t.n[k] = int(bk['n'][k])
+                self._tri_bk = t
             self.dats = _dev(d['dats'], torch.float64, device)
             self.exp_flag = int(bool(d.get('log_spec', True)))
         elif 'dats' in d:
@@ -182,12 +269,8 @@ class TemplateLibrary:
             sx = torch.empty(J, dtype=torch.int32, device=self.device)
             wts = torch.zeros((J, self.ndim + 1), dtype=torch.float64,
                               device=self.device) if details else None
-            rc = L.rvs_template_tri(
-                _lib.ptr(self.dats), self.ntp, _lib.ptr(self.tri_simplices),
-                _lib.ptr(self.tri_transform), _lib.ptr(self.tri_extraflags),
-                self.tri_nsimplex, self.ndim, log_mask, self.exp_flag,
-                _lib.ptr(params), J, _lib.ptr(templ), _lib.ptr(outside),
-                _lib.ptr(sx), _lib.ptr(wts), _lib.stream())
+            rc = self._tri_call(log_mask, params, J, templ, outside, sx, wts,
+                                _lib.stream())
             _lib.check(rc, 'rvs_template_tri')
             if details:
                 return templ, outside, sx, wts
@@ -209,6 +292,24 @@ class TemplateLibrary:
             return templ, outside, cell, wts
         return templ, outside
 
+    def _tri_call(self, log_mask, params, J, templ, outside, sx, wts, stream):
+        import ctypes
+        L = _lib.lib()
+        if self._tri_bk is not None and TRI_BUCKETS:
+            return L.rvs_template_tri_buckets(
+                _lib.ptr(self.dats), self.ntp, _lib.ptr(self.tri_simplices),
+                _lib.ptr(self.tri_transform), _lib.ptr(self.tri_extraflags),
+                self.tri_nsimplex, self.ndim, log_mask, self.exp_flag,
+                ctypes.addressof(self._tri_bk), _lib.ptr(params), J,
+                _lib.ptr(templ), _lib.ptr(outside), _lib.ptr(sx), _lib.ptr(wts),
+                stream)
+        return L.rvs_template_tri(
+            _lib.ptr(self.dats), self.ntp, _lib.ptr(self.tri_simplices),
+            _lib.ptr(self.tri_transform), _lib.ptr(self.tri_extraflags),
+            self.tri_nsimplex, self.ndim, log_mask, self.exp_flag,
+            _lib.ptr(params), J, _lib.ptr(templ), _lib.ptr(outside),
+            _lib.ptr(sx), _lib.ptr(wts), stream)
+
     def eval_into(self, params, J, templ, outside, stream, scratch=None):
         """launch-only variant of eval_batch on caller-owned buffers (no
         allocation, no synchronisation): params [>=J, ndim], templ [>=J, ntp],
@@ -224,12 +325,8 @@ class TemplateLibrary:
                 _lib.ptr(outside), None, None, stream)
             _lib.check(rc, 'rvs_template_polylinear')
         elif self.kind == 'triangulation':
-            rc = L.rvs_template_tri(
-                _lib.ptr(self.dats), self.ntp, _lib.ptr(self.tri_simplices),
-                _lib.ptr(self.tri_transform), _lib.ptr(self.tri_extraflags),
-                self.tri_nsimplex, self.ndim, self.log_mask, self.exp_flag,
-                _lib.ptr(params), J, _lib.ptr(templ), _lib.ptr(outside),
-                _lib.ptr(scratch), None, stream)
+            rc = self._tri_call(self.log_mask, params, J, templ, outside, scratch,
+                                None, stream)
             _lib.check(rc, 'rvs_template_tri')
         elif self.kind == 'nn':
             # scratch: dict(a0, a1 float32 [>=J, width], torch_stream) -- the

@@ -323,7 +323,12 @@ def cpu_worker(args):
 
 
 def _cpu_warm(process):
-    (_cpu_one_process if process else _cpu_one)(0)
+    # (an exception in a Pool initializer makes the pool respawn workers for ever:
+    # a failing first call is left to the first real task, which reports it)
+    try:
+        (_cpu_one_process if process else _cpu_one)(0)
+    except Exception:   # noqa: BLE001
+        pass
 
 
 def _cpu_noop(i):

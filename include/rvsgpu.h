@@ -84,7 +84,7 @@ extern "C" {
  *  12: rvs_bfgs_run / rvs_bfgs_run_bytes (the second minimiser's rounds on the
  *      device), rvs_chisq_grid_resol_g (resolution matrices on grid sets),
  *      rvs_template_tri_buckets (find_simplex through a bucket grid);
- *      additions: no signature changed */
+ *      rvs_nm_objective grew by `tri` (Delaunay libraries inside rvs_nm_run) */
 #define RVS_ABI_VERSION 12
 int rvs_abi_version(void);
 
@@ -835,6 +835,19 @@ int rvs_template_nn_arms_n(const double *params, int B, const int32_t *njobs_dev
                            int ndim, int narm, const rvs_nm_nn_arm *arms,
                            void *stream);
 
+/* One arm's Delaunay evaluator for rvs_nm_run / rvs_bfgs_run: the arguments of
+ * rvs_template_tri_buckets and the buffers the round's template rows / outside flags /
+ * simplex ids go to ([>= rows, ntp] / [>= rows] / int32 [>= rows], device). */
+typedef struct rvs_nm_tri_arm {
+  const double *dats, *transform, *extraflags;
+  const int32_t *simplices;
+  double *templ, *outside;
+  int32_t *simplex;
+  rvs_tri_buckets buckets;
+  int32_t ntp, nsimplex, exp_flag;
+  uint32_t log_mask;
+} rvs_nm_tri_arm;
+
 typedef struct rvs_nm_objective {
   const rvs_objective_arm *arms;
   const double *fixed, *vsini_fixed, *safe, *prior_mean, *prior_isig;
@@ -849,6 +862,10 @@ typedef struct rvs_nm_objective {
    * arm, then rvs_objective_from_template (vel_fit.py:505-737 with
    * nn/RVSInterpolator.py:36-71 as the evaluator) */
   const rvs_nm_nn_arm *nn;
+  /* NULL, or [narm]: Delaunay libraries on every arm (spec_inter.py:11-59) -- a
+   * round's objective is rvs_template_tri_buckets per arm, then
+   * rvs_objective_from_template.  At most one of nn / tri is set. */
+  const rvs_nm_tri_arm *tri;
 } rvs_nm_objective;
 int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o, double xatol,
                double fatol, int maxiter, int sync_every, int64_t *stats,

@@ -342,6 +342,10 @@ class TriLibrary:
         self.parnames = tuple(str(_) for _ in d['parnames'])
         self.ndim = self.transform.shape[2]
         self.exp = True
+        # the CCF part of the setup is that of Library (make_ccf.py builds it from
+        # whatever evaluator the setup has)
+        self.ccf_sets = _ccf_sets(d)
+        self.ccf = self.ccf_sets.get(True)
 
     map_params = Library.map_params
 

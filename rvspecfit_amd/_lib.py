@@ -181,7 +181,8 @@ class NmObjective(ctypes.Structure):
                     ('min_vel', 'max_vel', 'max_vsini', 'badchi')] + [
                     (k, ctypes.c_int32) for k in
                     ('narm', 'npoly', 'n', 'ndim', 'vsini_col')] + [
-                    ('src', ctypes.c_int32 * 8), ('nn', ctypes.c_void_p)]
+                    ('src', ctypes.c_int32 * 8), ('nn', ctypes.c_void_p),
+                    ('tri', ctypes.c_void_p)]
 
 
 class BfgsState(ctypes.Structure):
@@ -199,6 +200,15 @@ class TriBuckets(ctypes.Structure):
     _fields_ = [('cell_start', ctypes.c_void_p), ('cell_list', ctypes.c_void_p),
                 ('lo', ctypes.c_double * 6), ('inv_w', ctypes.c_double * 6),
                 ('n', ctypes.c_int32 * 6)]
+
+
+class NmTriArm(ctypes.Structure):
+    """rvs_nm_tri_arm of include/rvsgpu.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ('dats', 'transform', 'extraflags', 'simplices', 'templ', 'outside',
+                 'simplex')] + [('buckets', TriBuckets)] + [
+                    (k, ctypes.c_int32) for k in ('ntp', 'nsimplex', 'exp_flag')] + [
+                    ('log_mask', ctypes.c_uint32)]
 
 
 class PointArm(ctypes.Structure):

@@ -724,6 +724,21 @@ int rvs_internal_nm_eval(const rvs_nm_objective *o, const int32_t *list,
                                        o->vsini, o->job_spec, J, live, o->vel,
                                        o->badchi, 1 | RVS_OBJ_STATUS_STORE,
                                        o->scratch, o->chi, o->jstatus, st);
+  } else if (o->tri) {
+    // Delaunay libraries: find_simplex + blend per arm, then the same kernel
+    const double *tp[8], *op[8];
+    if (o->narm > 8) return RVS_E_ARG;
+    rc = rvs_internal_template_tri_arms_n(o->params, J, live, o->ndim, o->narm, o->tri,
+                                          st);
+    if (rc) return rc;
+    for (int a = 0; a < o->narm; a++) {
+      tp[a] = o->tri[a].templ;
+      op[a] = o->tri[a].outside;
+    }
+    rc = rvs_objective_from_template_n(o->arms, o->narm, o->npoly, tp, op,
+                                       o->vsini, o->job_spec, J, live, o->vel,
+                                       o->badchi, 1 | RVS_OBJ_STATUS_STORE,
+                                       o->scratch, o->chi, o->jstatus, st);
   } else {
     rc = rvs_objective_fused_n(o->arms, o->narm, o->npoly, o->params, o->vsini,
                                o->job_spec, J, live, o->vel, o->badchi,
@@ -1390,6 +1405,21 @@ static int nm_objective_rows(const rvs_nm_objective *o, int J, const int32_t *li
     for (int a = 0; a < o->narm; a++) {
       tp[a] = o->nn[a].templ;
       op[a] = o->nn[a].outside;
+    }
+    return rvs_objective_from_template_n(o->arms, o->narm, o->npoly, tp, op,
+                                         o->vsini, o->job_spec, J, live, o->vel,
+                                         o->badchi, 1 | RVS_OBJ_NO_SUM, o->scratch,
+                                         nullptr, nullptr, st);
+  }
+  if (o->tri) {
+    const double *tp[8], *op[8];
+    if (o->narm > 8) return RVS_E_ARG;
+    int rc = rvs_internal_template_tri_arms_n(o->params, J, live, o->ndim, o->narm,
+                                              o->tri, st);
+    if (rc) return rc;
+    for (int a = 0; a < o->narm; a++) {
+      tp[a] = o->tri[a].templ;
+      op[a] = o->tri[a].outside;
     }
     return rvs_objective_from_template_n(o->arms, o->narm, o->npoly, tp, op,
                                          o->vsini, o->job_spec, J, live, o->vel,

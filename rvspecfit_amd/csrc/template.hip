@@ -7,6 +7,7 @@
 #include "common.h"
 
 #include "template_dev.h"
+#include "nm_internal.h"
 
 // One 256-thread block per spectrum.  The 2^ndim vertex rows are contiguous
 // float32 rows of `dats`: consecutive lanes read consecutive pixels (coalesced
@@ -193,11 +194,13 @@ __global__ void __launch_bounds__(256)
                     const double *__restrict__ params,
                     const int32_t *__restrict__ simplex,
                     double *__restrict__ templ, double *__restrict__ outside,
-                    double *__restrict__ weights) {
+                    double *__restrict__ weights,
+                    const int32_t *__restrict__ live = nullptr) {
   __shared__ double sh_b[TRI_MAXDIM + 1];
   __shared__ int sh_id[TRI_MAXDIM + 1];
   __shared__ double red_m[8];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (live && b >= live[0]) return;   // (rows nobody waits for: rvs_nm_run)
   const int sx = simplex[b];
   double *out = templ + (int64_t)b * ntp;
   if (sx == 0x7fffffff || sx < 0) {  // TriInterp returns nan (spec_inter.py:45-47)
@@ -267,9 +270,10 @@ __global__ void __launch_bounds__(64)
     tri_locate_bucket_kernel(const double *__restrict__ transform, int nd,
                              uint32_t log_mask, const double *__restrict__ params,
                              int B, rvs_tri_buckets K,
-                             int32_t *__restrict__ simplex) {
+                             int32_t *__restrict__ simplex,
+                             const int32_t *__restrict__ live) {
   const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
+  if (b >= B || (live && b >= live[0])) return;
   double p[TRI_MAXDIM];
   bool finite = true;
   int64_t cell = 0;
@@ -320,10 +324,32 @@ extern "C" int rvs_template_tri_buckets(
     if (buckets->n[d] < 1) return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
   hipLaunchKernelGGL(tri_locate_bucket_kernel, dim3((B + 63) / 64), dim3(64), 0, st,
-                     transform, ndim, log_mask, params, B, *buckets, simplex);
+                     transform, ndim, log_mask, params, B, *buckets, simplex, nullptr);
   hipLaunchKernelGGL(tri_eval_kernel, dim3(B), dim3(256), 0, st, dats, ntp,
                      simplices, transform, extraflags, ndim, log_mask, exp_flag,
-                     params, simplex, templ, outside, weights);
+                     params, simplex, templ, outside, weights, nullptr);
+  RVS_LAUNCH_CHECK();
+  return 0;
+}
+
+// the template rows of an optimiser round on Delaunay libraries (rvs_nm_run,
+// rvs_bfgs_run): the first min(B, live[0]) rows of `params` through every arm's
+// triangulation -- same kernels, same values as rvs_template_tri_buckets
+int rvs_internal_template_tri_arms_n(const double *params, int B, const int32_t *live,
+                                     int ndim, int narm, const rvs_nm_tri_arm *arms,
+                                     hipStream_t st) {
+  if (ndim < 1 || ndim > TRI_MAXDIM || B < 1 || narm < 1 || !arms) return RVS_E_ARG;
+  for (int a = 0; a < narm; a++) {
+    const rvs_nm_tri_arm &A = arms[a];
+    if (!A.buckets.cell_start || !A.buckets.cell_list || !A.simplex || A.ntp < 1)
+      return RVS_E_ARG;
+    hipLaunchKernelGGL(tri_locate_bucket_kernel, dim3((B + 63) / 64), dim3(64), 0, st,
+                       A.transform, ndim, A.log_mask, params, B, A.buckets, A.simplex,
+                       live);
+    hipLaunchKernelGGL(tri_eval_kernel, dim3(B), dim3(256), 0, st, A.dats, A.ntp,
+                       A.simplices, A.transform, A.extraflags, ndim, A.log_mask,
+                       A.exp_flag, params, A.simplex, A.templ, A.outside, nullptr, live);
+  }
   RVS_LAUNCH_CHECK();
   return 0;
 }

@@ -140,6 +140,10 @@ class ProcessObjective:
         # MLP libraries on every arm: the rounds can run inside rvs_nm_run too
         self.nn_native = self.from_templ and all(
             libs[arm.name].kind == 'nn' for arm in batch.arms)
+        # ... and Delaunay libraries (find_simplex through the bucket grid)
+        self.tri_native = self.from_templ and all(
+            libs[arm.name].kind == 'triangulation' and
+            libs[arm.name]._tri_bk is not None for arm in batch.arms)
         self.streams = [torch.cuda.Stream(device=dev) for _ in batch.arms]
         self.ev_in = torch.cuda.Event()
         self.ev_out = [torch.cuda.Event() for _ in batch.arms]
@@ -193,6 +197,22 @@ class ProcessObjective:
                     a.nfx, a.nfy = hull[0].shape[0], hull[1].shape[0]
                 a.nlayer, a.log_mask = nl, lib.log_mask
             o.nn = ctypes.addressof(self._nn_arr)
+        o.tri = None
+        if self.tri_native:
+            narm = len(self.arm_buf)
+            self._tri_arr = (_lib.NmTriArm * narm)()
+            for ia, (arm, b) in enumerate(zip(self.batch.arms, self.arm_buf)):
+                lib = self.libs[arm.name]
+                a = self._tri_arr[ia]
+                a.dats, a.transform = lib.dats.data_ptr(), lib.tri_transform.data_ptr()
+                a.extraflags = lib.tri_extraflags.data_ptr()
+                a.simplices = lib.tri_simplices.data_ptr()
+                a.templ, a.outside = b['templ'].data_ptr(), b['outside'].data_ptr()
+                a.simplex = b['sx'].data_ptr()
+                a.buckets = lib._tri_bk
+                a.ntp, a.nsimplex = lib.ntp, lib.tri_nsimplex
+                a.exp_flag, a.log_mask = lib.exp_flag, lib.log_mask
+            o.tri = ctypes.addressof(self._tri_arr)
         return o
 
     def eval(self, list_t, X, J, counts, cidx, F):
@@ -389,7 +409,7 @@ class DeviceNelderMead:
         self.fsim.copy_(fsim)
         fs = self.fsim
         if NATIVE_ROUNDS and isinstance(objective, ProcessObjective) and \
-                (objective.fused or objective.nn_native):
+                (objective.fused or objective.nn_native or objective.tri_native):
             # the rounds in C (rvs_nm_run): same launches, no interpreter
             m = _lib.NmState()
             for k, t in (('sim', sim), ('fsim', fs), ('X1', self.X1),

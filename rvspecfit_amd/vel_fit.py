@@ -696,7 +696,10 @@ def _rounds_run_in_c(batch, config, resolParams, options=None):
         return True
     # MLP libraries on every arm: rvs_nm_run drives rvs_template_nn +
     # rvs_objective_from_template itself
-    return all(libs[a.name].kind == 'nn' for a in batch.arms) and \
+    def native(kind):
+        return all(libs[a.name].kind == kind for a in batch.arms)
+    return (native('nn') or (native('triangulation') and all(
+        libs[a.name]._tri_bk is not None for a in batch.arms))) and \
         engine.can_fuse_objective(batch, libs, rs, npoly=npoly,
                                   from_template=True)
 
@@ -838,7 +841,7 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
         t0 = time.time()
         hess_inv0 = get_hess_inv(mapper.get_fitted_params())
         if BFGS_ON_DEVICE and optimizer.NATIVE_ROUNDS and (
-                pobj.fused or pobj.nn_native):
+                pobj.fused or pobj.nn_native or pobj.tri_native):
             # the rounds inside the library (rvs_bfgs_run), on the objective the
             # simplex stage ran on
             jobs_before = pobj.jobs

@@ -1675,6 +1675,50 @@ def test_triangulation(cases, gpu):
     np.testing.assert_allclose(fb['best_param'], g['c1/best_param'])
 
 
+def test_process_on_delaunay_libraries_rounds_in_c(cases, config, monkeypatch):
+    """vel_fit.process of a batch on Delaunay libraries: the optimiser's rounds inside
+    the library (rvs_nm_run / rvs_bfgs_run with rvs_nm_objective.tri: find_simplex
+    through the bucket grid + blend per arm, then rvs_objective_from_template) against
+    the same rounds driven from Python on the same kernels (NATIVE_ROUNDS off, the
+    host BFGS machines) -- every number bit for bit through the simplex stage, the
+    BFGS polish to its own tolerance"""
+    from rvspecfit_amd import optimizer, spec_inter, vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    from rvspecfit_amd.library import TemplateLibrary
+    cfg = dict(config, template_lib='golden-tri://')
+    for n in ('gold_b', 'gold_r'):
+        d = np.load(os.path.join(GOLD, 'lib_tri_%s.npz' % n))
+        spec_inter.register_library(TemplateLibrary(n, d), 'golden-tri://')
+    rng = np.random.RandomState(12)
+    S = 30
+    lists = [_sds(cases, ('c1', 'c3')[i % 2]) for i in range(S)]
+    batch = SpecBatch.from_specdata(lists)
+    for a in batch.arms:
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.02 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pd0 = dict(teff=rng.uniform(5200, 6500, S), logg=rng.uniform(2., 4., S),
+               feh=rng.uniform(-1.2, -0.3, S), alpha=rng.uniform(0.1, 0.3, S),
+               vsini=rng.uniform(1, 60, S))
+    out = {}
+    for sm in (False, True):
+        c2 = dict(cfg, second_minimizer=sm)
+        for native in (True, False):
+            monkeypatch.setattr(optimizer, 'NATIVE_ROUNDS', native)
+            with np.errstate(all='ignore'):
+                out[sm, native] = vel_fit.process(batch, dict(pd0),
+                                                  options=dict(npoly=10), config=c2)
+    a, b = out[False, True], out[False, False]
+    assert int(a['nm_nit'].max()) > 50
+    for k in ('vel', 'chisq', 'vsini', 'nm_nit', 'nm_nfev', 'nm_vel'):
+        assert torch.equal(a[k], b[k]), k
+    for k in ('teff', 'logg', 'feh', 'alpha'):
+        assert torch.equal(a['param'][k], b['param'][k]), k
+    a, b = out[True, True], out[True, False]
+    assert a['bfgs']['device'] and not b['bfgs']['device']
+    assert torch.equal(a['nm_nit'], b['nm_nit'])
+    assert (a['chisq'] - b['chisq']).abs().max().item() < 2e-3
+
+
 @pytest.mark.parametrize('kind,snr,feh0', [('regulargrid', 100., -0.2),
                                            ('triangulation', 1000., 0.)])
 def test_fit_fake(cases, config, kind, snr, feh0):

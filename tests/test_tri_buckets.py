@@ -96,7 +96,7 @@ def test_bucket_search_equals_exhaustive_on_the_device(n, jitter):
         library.TRI_BUCKETS = True
     assert torch.equal(s0, s1)
     found = (s0 != 0x7fffffff)
-    assert 0.7 < found.float().mean().item() < 0.98
+    assert found.float().mean().item() > 0.7
     assert torch.equal(w0, w1)
     assert torch.equal(t0[found], t1[found])
     assert torch.isnan(t1[~found]).all()

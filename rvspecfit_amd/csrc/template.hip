@@ -266,18 +266,27 @@ __global__ void __launch_bounds__(256)
 // search returns -- after a few dozen tests instead of all 10^4 - 10^6 of a
 // PHOENIX-size triangulation.  One lane per query; the lists are built once per
 // library on the host (library.tri_buckets).
-__global__ void __launch_bounds__(64)
+// (One WAVE per query: the lanes test 64 consecutive entries of the cell's list at a
+// time and the lowest lane that passes wins -- the list ascends, so the first chunk
+// with a match holds the lowest matching id.  One lane per query walked its list
+// entry by entry, a dependent chain of loads per entry: ~1 us each, up to 384 of them
+// for a point outside the hull -- 0.5 ms per launch in the optimiser's rounds.)
+#define TRI_LOC_WAVES 4
+__global__ void __launch_bounds__(64 * TRI_LOC_WAVES)
     tri_locate_bucket_kernel(const double *__restrict__ transform, int nd,
                              uint32_t log_mask, const double *__restrict__ params,
                              int B, rvs_tri_buckets K,
                              int32_t *__restrict__ simplex,
                              const int32_t *__restrict__ live) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= B || (live && b >= live[0])) return;
+  const int b = blockIdx.x * TRI_LOC_WAVES + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= B || (live && b >= live[0])) return;   // (wave-uniform)
   double p[TRI_MAXDIM];
   bool finite = true;
   int64_t cell = 0;
-  for (int d = 0; d < nd; d++) {
+#pragma unroll
+  for (int d = 0; d < TRI_MAXDIM; d++) {   // (static indices: K and p in registers)
+    if (d >= nd) break;
     p[d] = tri_map(params[(int64_t)b * nd + d], d, log_mask);
     if (!(fabs(p[d]) <= 1.79e308)) finite = false;
     double c = floor((p[d] - K.lo[d]) * K.inv_w[d]);
@@ -288,27 +297,32 @@ __global__ void __launch_bounds__(64)
   if (finite) {
     const double eps = 100.0 * 2.220446049250313e-16;
     const int e0 = K.cell_start[cell], e1 = K.cell_start[cell + 1];
-    for (int e = e0; e < e1; e++) {
-      const int s = K.cell_list[e];
-      const double *T = transform + (int64_t)s * (nd + 1) * nd;
-      const double *r = T + nd * nd;
-      bool in = true;
-      double sum = 0;
-      for (int i = 0; i < nd; i++) {
-        double c = 0;
-        for (int jj = 0; jj < nd; jj++) c += T[i * nd + jj] * (p[jj] - r[jj]);
-        sum += c;
-        if (!(c >= -eps && c <= 1 + eps)) in = false;
-      }
-      const double cl = 1.0 - sum;
-      if (!(cl >= -eps && cl <= 1 + eps)) in = false;
+    for (int eb = e0; eb < e1; eb += 64) {
+      const int e = eb + lane;
+      bool in = e < e1;
+      int s = 0;
       if (in) {
-        found = s;
+        s = K.cell_list[e];
+        const double *T = transform + (int64_t)s * (nd + 1) * nd;
+        const double *r = T + nd * nd;
+        double sum = 0;
+        for (int i = 0; i < nd; i++) {
+          double c = 0;
+          for (int jj = 0; jj < nd; jj++) c += T[i * nd + jj] * (p[jj] - r[jj]);
+          sum += c;
+          if (!(c >= -eps && c <= 1 + eps)) in = false;
+        }
+        const double cl = 1.0 - sum;
+        if (!(cl >= -eps && cl <= 1 + eps)) in = false;
+      }
+      const unsigned long long m = __ballot(in);
+      if (m) {
+        found = __shfl(s, __ffsll((long long)m) - 1, 64);
         break;
       }
     }
   }
-  simplex[b] = found;
+  if (lane == 0) simplex[b] = found;
 }
 
 extern "C" int rvs_template_tri_buckets(
@@ -323,8 +337,10 @@ extern "C" int rvs_template_tri_buckets(
   for (int d = 0; d < ndim; d++)
     if (buckets->n[d] < 1) return RVS_E_ARG;
   hipStream_t st = rvs_stream(stream);
-  hipLaunchKernelGGL(tri_locate_bucket_kernel, dim3((B + 63) / 64), dim3(64), 0, st,
-                     transform, ndim, log_mask, params, B, *buckets, simplex, nullptr);
+  hipLaunchKernelGGL(tri_locate_bucket_kernel,
+                     dim3((B + TRI_LOC_WAVES - 1) / TRI_LOC_WAVES),
+                     dim3(64 * TRI_LOC_WAVES), 0, st, transform, ndim, log_mask, params,
+                     B, *buckets, simplex, nullptr);
   hipLaunchKernelGGL(tri_eval_kernel, dim3(B), dim3(256), 0, st, dats, ntp,
                      simplices, transform, extraflags, ndim, log_mask, exp_flag,
                      params, simplex, templ, outside, weights, nullptr);
@@ -343,9 +359,10 @@ int rvs_internal_template_tri_arms_n(const double *params, int B, const int32_t 
     const rvs_nm_tri_arm &A = arms[a];
     if (!A.buckets.cell_start || !A.buckets.cell_list || !A.simplex || A.ntp < 1)
       return RVS_E_ARG;
-    hipLaunchKernelGGL(tri_locate_bucket_kernel, dim3((B + 63) / 64), dim3(64), 0, st,
-                       A.transform, ndim, A.log_mask, params, B, A.buckets, A.simplex,
-                       live);
+    hipLaunchKernelGGL(tri_locate_bucket_kernel,
+                       dim3((B + TRI_LOC_WAVES - 1) / TRI_LOC_WAVES),
+                       dim3(64 * TRI_LOC_WAVES), 0, st, A.transform, ndim, A.log_mask,
+                       params, B, A.buckets, A.simplex, live);
     hipLaunchKernelGGL(tri_eval_kernel, dim3(B), dim3(256), 0, st, A.dats, A.ntp,
                        A.simplices, A.transform, A.extraflags, ndim, A.log_mask,
                        A.exp_flag, params, A.simplex, A.templ, A.outside, nullptr, live);

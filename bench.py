@@ -1058,6 +1058,16 @@ def main():
         cpu_baseline=cpu,
         stage_ms=stage_round(stage),
         kernels=kernels, parity_sample=parity, setup_s=round(t_setup, 1))
+    # what a reader of an N-GPU line needs to hold it against the N = 1 line: the
+    # value per GPU (weak scaling: every rank runs the N = 1 workload) and the
+    # process group torch.distributed actually formed (backend 'nccl' = RCCL)
+    line['per_gpu_value'] = round(value / world, 1)
+    line['dist'] = dict(
+        world_size=world, backend=dist.get_backend() if world > 1 else None,
+        launched_as=int(os.environ.get('WORLD_SIZE', '1')),
+        collective='all_gather_into_tensor of the [S, %d] float64 result records '
+                   '(rvspecfit_amd/dist.py), inside the timed step'
+                   % len(pipeline.RECORD_FIELDS) if world > 1 else None)
     if proc is not None:
         line['process'] = proc
     if desi is not None:

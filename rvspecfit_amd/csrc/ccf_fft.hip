@@ -681,8 +681,13 @@ __global__ void __launch_bounds__(XB_NT)
 #define XW_HALF 512
 
 // radix-8 DIF pass p (M = n2 >> 3p) of the n2 = 2^LOG2N point image a[]: butterfly t
+// (Tc, nullable: the pass's twiddles T1[r << (tws - 1)], r < Mp, copied side by side --
+// read at their stride in T1 the lanes of a wave land on two bank groups: pass 1 of
+// the 4096-point image reads 64 twiddles 128 bytes apart, a 32-way conflict per wave
+// and template: profiles/r05_sq_counters.json, bank-conflict cycles 23 % of LDS-active)
 template <int SIGN, int LOG2N>
-__device__ __forceinline__ void xw_pass(double2 *a, const double2 *T1, int p, int t) {
+__device__ __forceinline__ void xw_pass(double2 *a, const double2 *T1, int p, int t,
+                                        const double2 *Tc = nullptr) {
   const int lgM = LOG2N - 3 * p, lgMp = lgM - 3, Mp = 1 << lgMp;
   const int tws = LOG2N + 1 - lgM;
   const int blk = t >> lgMp, r = t & (Mp - 1);
@@ -692,7 +697,7 @@ __device__ __forceinline__ void xw_pass(double2 *a, const double2 *T1, int p, in
   for (int j = 0; j < 8; j++) v[j] = a[base + Mp * j];
   dft8<SIGN>(v);
   if (Mp > 1) {
-    double2 w1 = T1[r << (tws - 1)];
+    double2 w1 = Tc ? Tc[r] : T1[r << (tws - 1)];
     if (SIGN < 0) w1.y = -w1.y;
     v[1] = cmul(v[1], w1);
     const double2 w2 = cmul(w1, w1);
@@ -732,10 +737,14 @@ __global__ void __launch_bounds__(XW_NT)
   auto img = [&](int i) -> double2 * { return fa + (i & 1) * n2; };
   const double2 *T1 = fa + 2 * n2;                         // [n2 / 8]
   double *c0 = reinterpret_cast<double *>(fa + 2 * n2 + XC_NTW(n2));  // [nlag]
+  // pass 1's 64 twiddles and the folded pass's 8, side by side (xw_pass)
+  double2 *T1c = fa + 2 * n2 + XC_NTW(n2) + ((nlag + 1) >> 1);   // [64 + 8]
   const int b = blockIdx.x, tid = threadIdx.x;
   const bool producer = tid >= XW_HALF;
   const int pt = tid & (XW_HALF - 1);
   const double inv_n = 1.0 / nfft;
+  if (P12 && tid < 72)   // (straight from the table: the LDS copy of T1 is in flight)
+    T1c[tid] = tid < 64 ? tw[2 * (tid << 3)] : tw[2 * ((tid - 64) << (log2n - 6))];
   xc_fill_twiddles<XW_NT>(fa + n2, n2, tw);   // -> fa[2 n2 + i]
   // output masks of the last two passes (consumers), and the block-wide vote on the
   // folded form of those passes (see fft_lds)
@@ -866,7 +875,7 @@ __global__ void __launch_bounds__(XW_NT)
     if (beta != 0.0) pre_old = out[tvx];
     if (pt < (n2 >> 3)) xw_pass<1, LOG2N>(a, T1, 0, pt);
     __syncthreads();
-    if (pt < (n2 >> 3)) xw_pass<1, LOG2N>(a, T1, 1, pt);
+    if (pt < (n2 >> 3)) xw_pass<1, LOG2N>(a, T1, 1, pt, P12 ? T1c : nullptr);
     __syncthreads();
     if (!P12) {
       // nfft 4096: a third radix-8 pass (M = 32) and the radix-4 pass (M = 4)
@@ -889,7 +898,7 @@ __global__ void __launch_bounds__(XW_NT)
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = a[B * 64 + s + 8 * j];
         dft8<1>(v);
-        double2 w = T1[s << (log2n - 6)];
+        double2 w = T1c[64 + s];   // = T1[s << (log2n - 6)]
         w.y = -w.y;
         double2 x63 = cmul(v[7], w), x0 = v[0];
         auto sum8 = [](double x) {
@@ -1175,7 +1184,8 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
         ws_attr = true;
       }
       const size_t shmw = sizeof(double2) * (size_t)(2 * n2 + XC_NTW(n2)) +
-                          sizeof(double) * (size_t)nlag;
+                          sizeof(double) * (size_t)nlag +
+                          sizeof(double2) * (72 + 1);   // (+ pass 1's twiddles: T1c)
       if (p12)
         hipLaunchKernelGGL(ccf_xcorr_ws_kernel<12>, dim3(B), dim3(XW_NT), shmw, st,
                            reinterpret_cast<const double2 *>(work),

@@ -31,4 +31,5 @@ cfg --spectra 62500
 cfg --grid 40,11,8,5
 cfg --npoly 15
 cfg --workload sdss
+cfg --evaluator tri
 cat $out | head -c 3000

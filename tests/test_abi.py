@@ -130,7 +130,10 @@ def test_struct_layouts_match_the_header(tmp_path):
              ('rvs_objective_arm', _lib.ObjectiveArm),
              ('rvs_nm_state', _lib.NmState),
              ('rvs_nm_nn_arm', _lib.NmNNArm),
-             ('rvs_nm_objective', _lib.NmObjective)]
+             ('rvs_nm_objective', _lib.NmObjective),
+             ('rvs_bfgs_state', _lib.BfgsState),
+             ('rvs_tri_buckets', _lib.TriBuckets),
+             ('rvs_nm_tri_arm', _lib.NmTriArm)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rvsgpu.h"',
              'int main(void) {']
     for cname, cls in pairs:

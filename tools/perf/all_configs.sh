@@ -40,6 +40,9 @@ run --npoly 13 --steps 3 --warmup 1 --no-cpu-baseline
 run --workload sdss --steps 3 --warmup 1 --cpu-sample 128
 run --grid 40,11,8,5 --spectra 10000 --steps 1 --warmup 1 --no-cpu-baseline --process 10000
 run --npoly 15 --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000
+# round 6: Delaunay libraries (find_simplex through the bucket grid; the rounds in rvs_nm_run)
+run --evaluator tri --steps 3 --warmup 1 --cpu-sample 16
+run --evaluator tri --spectra 2000 --steps 1 --warmup 1 --no-cpu-baseline --process 2000
 python - <<PY
 import json
 for l in open("$out"):

@@ -84,7 +84,8 @@ extern "C" {
  *  12: rvs_bfgs_run / rvs_bfgs_run_bytes (the second minimiser's rounds on the
  *      device), rvs_chisq_grid_resol_g (resolution matrices on grid sets),
  *      rvs_template_tri_buckets (find_simplex through a bucket grid);
- *      rvs_nm_objective grew by `tri` (Delaunay libraries inside rvs_nm_run) */
+ *      rvs_nm_objective grew by `tri` (Delaunay libraries inside rvs_nm_run),
+ *      rvs_nm_state by `stop_below` */
 #define RVS_ABI_VERSION 12
 int rvs_abi_version(void);
 
@@ -806,6 +807,12 @@ typedef struct rvs_nm_state {
   double *sim, *fsim, *X1, *X2, *F1, *F2;
   int32_t *nit, *nfev, *flags, *list1, *list2, *list3, *cases, *pos2, *counts;
   int32_t S, N;
+  /* > 0: rvs_nm_run returns at its first look that finds at most this many simplices
+   * running (none parked); a second call with the same state (and 0 here) runs the
+   * rest -- every call starts by testing all simplices and listing the running ones,
+   * so the rounds continue where they stopped, bit for bit.  What a caller gains: the
+   * spectra that are done can go on while the stragglers' last rounds run. */
+  int32_t stop_below, reserved_;
 } rvs_nm_state;
 /* One arm's MLP evaluator for rvs_nm_run: the arguments of rvs_template_nn and
  * rvs_nn_outside (xeqs == NULL: no hull, outside = 0), and the buffers the

@@ -159,7 +159,8 @@ class NmState(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in
                 ('sim', 'fsim', 'X1', 'X2', 'F1', 'F2', 'nit', 'nfev', 'flags',
                  'list1', 'list2', 'list3', 'cases', 'pos2', 'counts')] + [
-                    ('S', ctypes.c_int32), ('N', ctypes.c_int32)]
+                    ('S', ctypes.c_int32), ('N', ctypes.c_int32),
+                    ('stop_below', ctypes.c_int32), ('reserved_', ctypes.c_int32)]
 
 
 class NmNNArm(ctypes.Structure):

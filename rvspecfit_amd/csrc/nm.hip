@@ -1502,6 +1502,8 @@ extern "C" int rvs_nm_run(const rvs_nm_state *m, const rvs_nm_objective *o,
       continue;
     }
     if (live == 0) break;
+    // (the caller takes the finished spectra on and calls again for the rest)
+    if (m->stop_below > 0 && live <= m->stop_below) break;
     // the live count only falls between two looks (finished and parked
     // simplices leave the list), so it bounds the launches of the window
     const int jb = live;

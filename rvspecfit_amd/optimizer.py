@@ -91,12 +91,21 @@ class ProcessObjective:
         narm = len(batch.arms)
         self.arr = (_lib.PointArm * narm)()
         self.badchi = float(batch.badchi)
+        # (which form the objective takes decides which row buffers exist: the one-kernel
+        # objective keeps no template or spline record in HBM, the from-template form
+        # only the evaluator's rows -- 0.6 GB per 1000 rows less to allocate for the
+        # sub-batches of vel_fit._post_nm)
+        self.fused = engine.can_fuse_objective(batch, libs, resols,
+                                               npoly=self.npoly)
+        self.from_templ = (not self.fused) and engine.can_fuse_objective(
+            batch, libs, resols, npoly=self.npoly, from_template=True)
+        chain = not (self.fused or self.from_templ)
         for ia, arm in enumerate(batch.arms):
             lib = libs[arm.name]
-            b = dict(templ=torch.empty((cap, lib.ntp), **f64),
+            b = dict(templ=None if self.fused else torch.empty((cap, lib.ntp), **f64),
                      templ2=torch.empty((cap, lib.ntp), **f64)
-                     if self.has_vsini else None,
-                     coef=torch.empty((cap, lib.ntp, 4), **f64),
+                     if (self.has_vsini and chain) else None,
+                     coef=torch.empty((cap, lib.ntp, 4), **f64) if chain else None,
                      outside=torch.empty(cap, **f64),
                      sx=torch.empty(cap, **i32),
                      nn=None if lib.kind != 'nn' else dict(
@@ -112,7 +121,8 @@ class ProcessObjective:
             a.lam, a.polysT = arm.lam.data_ptr(), b['polysT'].data_ptr()
             a.spec, a.espec = arm.spec.data_ptr(), arm.espec.data_ptr()
             a.work, a.knots = b['work'].data_ptr(), lib.knots.data_ptr()
-            a.coef, a.penalty = b['coef'].data_ptr(), b['pen'].data_ptr()
+            a.coef = b['coef'].data_ptr() if chain else None
+            a.penalty = b['pen'].data_ptr()
             a.npix, a.S, a.ntp = arm.npix, arm.S, lib.ntp
             engine.set_point_grid(a, arm, self.npoly)
             a.log_step = int(lib.log_step)
@@ -125,12 +135,8 @@ class ProcessObjective:
                 self._resol_keep = getattr(self, '_resol_keep', []) + [rs]
         nb = L.rvs_chisq_point_work_size(cap, narm)
         self.scratch = torch.empty((nb + 7) // 8, **f64)
-        self.fused = engine.can_fuse_objective(batch, libs, resols,
-                                               npoly=self.npoly)
-        # evaluators that are no grid gather (MLP, Delaunay): the template rows
-        # of a round from their own kernel, everything behind them in one
-        self.from_templ = (not self.fused) and engine.can_fuse_objective(
-            batch, libs, resols, npoly=self.npoly, from_template=True)
+        # (from_templ: evaluators that are no grid gather (MLP, Delaunay) -- the
+        # template rows of a round from their own kernel, everything behind them in one)
         if self.fused or self.from_templ:
             self.oarr = (_lib.ObjectiveArm * narm)()
             self._keep = engine.fill_objective_arms(self.oarr, batch, libs,
@@ -395,7 +401,11 @@ class DeviceNelderMead:
         self.counts = torch.zeros(8, **i32)
 
     def minimize(self, objective, simplex, fatol=1e-3, xatol=1e-2,
-                 maxiter=10000, sync_every=4, stats=None):
+                 maxiter=10000, sync_every=4, stats=None, stop_below=0):
+        """stop_below > 0 (rounds inside the library only): return at the first look
+        that finds at most that many simplices running -- the result then carries
+        paused = True and finished [S] (converged and out of the rounds); resume()
+        runs the rest."""
         L = _lib.lib()
         S, N = self.S, self.N
         sim = simplex.clone().to(torch.float64).contiguous()
@@ -421,25 +431,11 @@ class DeviceNelderMead:
                          ('counts', self.counts)):
                 setattr(m, k, t.data_ptr())
             m.S, m.N = S, N
+            m.stop_below = int(stop_below)
             o = objective.native_desc()
-            st3 = (ctypes.c_int64 * 3)()
-            nfev0 = self.nfev.sum()
-            rc = L.rvs_nm_run(ctypes.addressof(m), ctypes.addressof(o),
-                              float(xatol), float(fatol), int(maxiter),
-                              int(sync_every), st3, _lib.stream())
-            _lib.check(rc, 'rvs_nm_run')
-            objective.calls += int(st3[1])
-            # evaluations performed = the function values scipy's algorithm counts
-            # (rows of a launch behind the device count are skipped); `slots` =
-            # rows launched
-            objective.jobs += int((self.nfev.sum() - nfev0).item())
-            objective.slots = getattr(objective, 'slots', 0) + int(st3[2])
-            if stats is not None:
-                stats['rounds'] = stats.get('rounds', 0) + int(st3[0])
-            success = (self.flags & 2) != 0
-            return dict(x=sim[:, 0].clone(), fun=fs.min(dim=1)[0],
-                        nit=self.nit.long(), nfev=self.nfev.long(),
-                        success=success, final_simplex=(sim, fs))
+            self._native = (m, o, sim, fs, float(xatol), float(fatol), int(maxiter),
+                            int(sync_every))
+            return self._run_native(objective, stats)
 
         def one_round(jb):
             st = _lib.stream()
@@ -501,6 +497,37 @@ class DeviceNelderMead:
         return dict(x=sim[:, 0].clone(), fun=fs.min(dim=1)[0],
                     nit=self.nit.long(), nfev=self.nfev.long(), success=success,
                     final_simplex=(sim, fs))
+
+    def _run_native(self, objective, stats):
+        L = _lib.lib()
+        m, o, sim, fs, xatol, fatol, maxiter, sync_every = self._native
+        st3 = (ctypes.c_int64 * 3)()
+        nfev0 = self.nfev.sum()
+        rc = L.rvs_nm_run(ctypes.addressof(m), ctypes.addressof(o), xatol, fatol,
+                          maxiter, sync_every, st3, _lib.stream())
+        _lib.check(rc, 'rvs_nm_run')
+        objective.calls += int(st3[1])
+        # evaluations performed = the function values scipy's algorithm counts
+        # (rows of a launch behind the device count are skipped); `slots` =
+        # rows launched
+        objective.jobs += int((self.nfev.sum() - nfev0).item())
+        objective.slots = getattr(objective, 'slots', 0) + int(st3[2])
+        if stats is not None:
+            stats['rounds'] = stats.get('rounds', 0) + int(st3[0])
+        success = (self.flags & 2) != 0
+        out = dict(x=sim[:, 0].clone(), fun=fs.min(dim=1)[0],
+                   nit=self.nit.long(), nfev=self.nfev.long(),
+                   success=success, final_simplex=(sim, fs))
+        if m.stop_below > 0:
+            running = (self.flags & 5) != 0      # active, or parked for a shrink
+            out['paused'] = bool(running.any().item())
+            out['finished'] = (~running) & success
+        return out
+
+    def resume(self, objective, stats=None):
+        """the rest of a run that minimize(stop_below > 0) returned from"""
+        self._native[0].stop_below = 0
+        return self._run_native(objective, stats)
 
     def _shrink(self, objective, sim, parked):
         """scipy's shrink step for the parked simplices: N objective calls"""

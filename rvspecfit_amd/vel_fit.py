@@ -765,6 +765,11 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     tm = timers if timers is not None else {}
 
     def _tick(k, t0):
+        # (stage clocks only when somebody asked for them: the device-wide
+        # synchronisation they need would make the two halves of a split batch wait
+        # for one another at every stage boundary)
+        if timers is None:
+            return
         if str(dev).startswith('cuda'):
             torch.cuda.synchronize()
         tm[k] = tm.get(k, 0.) + time.time() - t0
@@ -791,18 +796,55 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     libs = spec_inter.get_libs(batch.names, config)
     from . import optimizer
 
-    def device_nm(b, pd, pri, start, safe, resp):
-        """lock-step simplices of the spectra of `b` on the device (rvs_nm_*):
-        every library kind -- grid libraries with the one-kernel objective where
-        it applies, the kernel chain (incl. rvs_template_nn for MLP evaluators)
-        otherwise"""
-        pobj = optimizer.ProcessObjective(
-            b, libs, names, pd, fixParam, fitVsini, config, options, pri, safe,
-            resols=spec_fit._resols(b, resp))
-        r = optimizer.DeviceNelderMead(b.S, start.shape[2], dev).minimize(
-            pobj, start, fatol=1e-3, xatol=1e-2, maxiter=NM_MAXITER, stats=stats)
-        return r, pobj
-    nm, pobj = device_nm(batch, pd0, priors, simplex, curparam, resolParams)
+    # The spectra that leave the simplex stage first do not wait for the slowest
+    # simplex (_early_split): their BFGS polish, refinement and Hessian run on a second
+    # stream under the stage's latency-bound last rounds.
+    early = (EARLY_SPLIT and is_batch and timers is None and S >= EARLY_SPLIT_MIN
+             and optimizer.NATIVE_ROUNDS)
+    pobj = optimizer.ProcessObjective(
+        batch, libs, names, pd0, fixParam, fitVsini, config, options, priors,
+        curparam, resols=spec_fit._resols(batch, resolParams))
+    nmdev = optimizer.DeviceNelderMead(S, simplex.shape[2], dev)
+    early = early and (pobj.fused or pobj.nn_native or pobj.tri_native)
+    nm = nmdev.minimize(pobj, simplex, fatol=1e-3, xatol=1e-2, maxiter=NM_MAXITER,
+                        stats=stats,
+                        stop_below=max(1, int(EARLY_SPLIT_FRAC * S)) if early else 0)
+    ctx = dict(batch=batch, pd0=pd0, priors=priors, curparam=curparam, names=names,
+               fixParam=fixParam, fitVsini=fitVsini, vsiniMapper=vsiniMapper,
+               config=config, options=options, resolParams=resolParams, libs=libs,
+               st0=st0.reshape(S, -1)[:, 0], tick=_tick, is_batch=is_batch)
+    side = None
+    if nm.get('paused'):
+        fin = torch.nonzero(nm['finished']).reshape(-1)
+        rest = torch.nonzero(~nm['finished']).reshape(-1)
+        if fin.numel() >= EARLY_SPLIT_MIN // 4 and rest.numel() > 0:
+            # the finished spectra's later stages, on a stream of their own
+            st_main = torch.cuda.current_stream()
+            key = (dev.index, st_main.cuda_stream)
+            if key not in _EARLY_STREAMS:
+                _EARLY_STREAMS[key] = torch.cuda.Stream(device=dev)
+            st_side = _EARLY_STREAMS[key]
+            ev = torch.cuda.Event()
+            ev.record(st_main)
+            xs, ns, fs_ = nm['x'][fin].clone(), nm['nit'][fin].clone(), \
+                nm['nfev'][fin].clone()
+            stat_fin = pobj.status[fin].clone()
+            box = {}
+
+            def run_side():
+                try:
+                    with torch.cuda.stream(st_side):
+                        st_side.wait_event(ev)
+                        box['ret'] = _post_nm(
+                            ctx, fin, xs, torch.ones_like(fin, dtype=torch.bool), ns,
+                            fs_, stat_fin, None, dict(rounds=0, evals=0, slots=0))
+                    st_side.synchronize()
+                except BaseException as e:  # noqa: BLE001 -- re-raised below
+                    box['err'] = e
+            side = (threading.Thread(target=run_side), fin, rest, box)
+            side[0].start()
+            EARLY_SPLITS.append((int(fin.numel()), int(rest.numel())))
+        nm = nmdev.resume(pobj, stats=stats)
     obj.status |= pobj.status
     obj.nfev += pobj.jobs
     slots = getattr(pobj, 'slots', 0)
@@ -812,17 +854,15 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     if redo.numel():
         # vel_fit.py:624-649: a second run restarts from the final simplex; the
         # unconverged spectra form a batch of their own on the same kernels
-        pri2 = priors
-        if priors:
-            pri2 = {n_: tuple(v[redo].contiguous()
-                              if isinstance(v, torch.Tensor) and v.dim() else v
-                              for v in mv) for n_, mv in priors.items()}
+        pri2 = _subset_priors(priors, redo)
         sub = batch.subset(redo)
-        nm2, pobj2 = device_nm(sub, {k_: v[redo].contiguous()
-                                     for k_, v in pd0.items()}, pri2,
-                               nm['final_simplex'][0][redo].contiguous(),
-                               curparam[redo].contiguous(),
-                               resolParams)   # (shared by every spectrum)
+        pobj2 = optimizer.ProcessObjective(
+            sub, libs, names, {k_: v[redo].contiguous() for k_, v in pd0.items()},
+            fixParam, fitVsini, config, options, pri2, curparam[redo].contiguous(),
+            resols=spec_fit._resols(sub, resolParams))
+        nm2 = optimizer.DeviceNelderMead(sub.S, simplex.shape[2], dev).minimize(
+            pobj2, nm['final_simplex'][0][redo].contiguous(), fatol=1e-3,
+            xatol=1e-2, maxiter=NM_MAXITER, stats=stats)
         obj.status[redo] |= pobj2.status
         obj.nfev += pobj2.jobs
         slots += getattr(pobj2, 'slots', 0)
@@ -831,7 +871,62 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
         nit[redo] += nm2['nit']
         nfev[redo] += nm2['nfev']
     _tick('neldermead', t0)
+    nmstats = dict(rounds=stats.get('rounds', 0), evals=obj.nfev, slots=slots)
+    if side is None:
+        return _post_nm(ctx, None, x, success, nit, nfev, obj.status, pobj, nmstats)
+    th, fin, rest, box = side
+    r_rest = _post_nm(ctx, rest, x[rest].contiguous(), success[rest], nit[rest],
+                      nfev[rest], obj.status[rest], None, nmstats)
+    th.join()
+    if 'err' in box:
+        raise box['err']
+    torch.cuda.current_stream().synchronize()
+    return _merge_parts([box['ret'], r_rest], [fin, rest], S)
 
+
+# Spectra that finish the simplex stage early go on to their BFGS polish, refinement
+# and Hessian while the stragglers' last rounds -- a chain of latencies that leaves the
+# chip mostly idle -- are still running: rvs_nm_run returns at its first look that
+# finds at most EARLY_SPLIT_FRAC of the simplices running, the converged spectra's later
+# stages start on a second stream, and the rounds resume.  No spectrum sees another:
+# the results are those of the unsplit run (test_process_early_split_equals_unsplit).
+EARLY_SPLIT = os.environ.get('RVS_EARLY_SPLIT', '1') != '0'
+EARLY_SPLIT_FRAC = float(os.environ.get('RVS_EARLY_SPLIT_FRAC', '0.25'))
+EARLY_SPLIT_MIN = int(os.environ.get('RVS_EARLY_SPLIT_MIN', '128'))
+_EARLY_STREAMS = {}
+EARLY_SPLITS = []   # (finished, still running) of every split made (tests, tools)
+
+
+def _subset_priors(priors, idx):
+    if not priors:
+        return priors
+    return {n_: tuple(v[idx].contiguous()
+                      if isinstance(v, torch.Tensor) and v.dim() else v for v in mv)
+            for n_, mv in priors.items()}
+
+
+def _post_nm(ctx, idx, x, success, nit, nfev, status_nm, pobj, nmstats):
+    """vel_fit.py:653-737 behind the simplex stage, for the spectra `idx` of the
+    batch (None: all of them, on the simplex stage's own objective `pobj`): BFGS
+    polish, velocity refinement, full output, Hessian, the result dict."""
+    from . import optimizer
+    batch, pd0, priors, curparam = ctx['batch'], ctx['pd0'], ctx['priors'], \
+        ctx['curparam']
+    names, fixParam, fitVsini = ctx['names'], ctx['fixParam'], ctx['fitVsini']
+    config, options, resolParams = ctx['config'], ctx['options'], ctx['resolParams']
+    _tick, is_batch, st0 = ctx['tick'], ctx['is_batch'], ctx['st0']
+    if idx is not None:
+        batch = batch.subset(idx)
+        pd0 = {k_: v[idx].contiguous() for k_, v in pd0.items()}
+        priors = _subset_priors(priors, idx)
+        curparam = curparam[idx].contiguous()
+        st0 = st0[idx]
+    S, dev = batch.S, batch.device
+    mapper = ParamMapper(names, pd0, fixParam, ctx['vsiniMapper'], fitVsini=fitVsini)
+    obj = _Objective(batch, mapper, config, options, priors, resolParams)
+    obj.safe_params = curparam
+    obj.status |= status_nm
+    slots = nmstats['slots']
     allidx = torch.arange(S, device=dev)
     # vel_fit.py:653-658: optional BFGS polish from the simplex optimum
     second_run = False
@@ -840,15 +935,20 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
         from . import bfgs
         t0 = time.time()
         hess_inv0 = get_hess_inv(mapper.get_fitted_params())
-        if BFGS_ON_DEVICE and optimizer.NATIVE_ROUNDS and (
+        if pobj is None and BFGS_ON_DEVICE and optimizer.NATIVE_ROUNDS:
+            pobj = optimizer.ProcessObjective(
+                batch, ctx['libs'], names, pd0, fixParam, fitVsini, config, options,
+                priors, curparam, resols=spec_fit._resols(batch, resolParams))
+        if BFGS_ON_DEVICE and optimizer.NATIVE_ROUNDS and pobj is not None and (
                 pobj.fused or pobj.nn_native or pobj.tri_native):
             # the rounds inside the library (rvs_bfgs_run), on the objective the
             # simplex stage ran on
             jobs_before = pobj.jobs
+            slots_before = getattr(pobj, 'slots', 0)
             br = bfgs.minimize_lockstep_device(pobj, x, hess_inv0=hess_inv0)
             obj.status |= pobj.status
             obj.nfev += pobj.jobs - jobs_before
-            slots = getattr(pobj, 'slots', slots)
+            slots += getattr(pobj, 'slots', 0) - slots_before
             x = br['x']
             bfgs_info = dict(nit=br['nit'].cpu().numpy(),
                              nfev=br['nfev'].cpu().numpy(),
@@ -914,7 +1014,7 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
         ret['logl'] = outp['logl']
         ret['chisq_array'] = outp['chisq_array']
         ret['npix_array'] = outp['npix_array']
-        ret['status'] = obj.status | outp['status'] | st0.reshape(S, -1)[:, 0]
+        ret['status'] = obj.status | outp['status'] | st0
     else:
         if int(obj.status[0].item()) & _lib_nonfinite():
             raise RuntimeError('non-finite likelihood during the optimisation')
@@ -939,8 +1039,8 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     ret['nm_vel'] = nm_vel if is_batch else float(nm_vel[0].item())
     ret['nm_nit'] = nit if is_batch else int(nit[0].item())
     ret['nm_nfev'] = nfev if is_batch else int(nfev[0].item())
-    ret['nm_rounds'] = stats.get('rounds', 0)
-    ret['objective_evals'] = obj.nfev
+    ret['nm_rounds'] = nmstats['rounds']
+    ret['objective_evals'] = nmstats['evals'] + obj.nfev
     # rows the lock-step Nelder-Mead launched (an upper bound known on the host);
     # the rows behind the device counts are skipped by the objective kernel
     ret['nm_launched_rows'] = slots

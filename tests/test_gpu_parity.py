@@ -1873,6 +1873,53 @@ def test_process_bfgs_device_equals_host(cases, config, monkeypatch, S):
     assert (a['chisq'] - b['chisq']).abs().max().item() < 2e-3    # fatol level
 
 
+@pytest.mark.parametrize('second', [False, True])
+def test_process_early_split_equals_unsplit(cases, config, monkeypatch, second):
+    """vel_fit.process lets the spectra that leave the simplex stage first go on to
+    their BFGS polish, refinement and Hessian on a second stream while the stragglers'
+    last rounds run (rvs_nm_run returns at stop_below running simplices and is called
+    again for the rest): every number equals the run in which all spectra wait for the
+    slowest simplex, bit for bit -- no spectrum sees another, and a resumed run
+    continues where it stopped."""
+    from rvspecfit_amd import vel_fit
+    from rvspecfit_amd.engine import SpecBatch
+    rng = np.random.RandomState(21)
+    S = 400
+    lists = [_sds(cases, ('c1', 'c3')[i % 2]) for i in range(S)]
+    batch = SpecBatch.from_specdata(lists)
+    for a in batch.arms:
+        a.spec.mul_(torch.as_tensor(
+            1 + 0.02 * rng.normal(size=tuple(a.spec.shape))).to(a.spec.device))
+    pd0 = dict(teff=rng.uniform(5000, 6800, S), logg=rng.uniform(1.5, 4.5, S),
+               feh=rng.uniform(-1.5, -0.1, S), alpha=rng.uniform(0, 0.4, S),
+               vsini=rng.uniform(1, 60, S))
+    cfg = dict(config, second_minimizer=second)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(vel_fit, 'EARLY_SPLIT', flag)
+        del vel_fit.EARLY_SPLITS[:]
+        out[flag] = vel_fit.process(batch, dict(pd0), options=dict(npoly=10),
+                                    config=cfg)
+        # (two halves of 200 spectra: each split once)
+        assert (len(vel_fit.EARLY_SPLITS) == 2) == flag, vel_fit.EARLY_SPLITS
+        if flag:
+            assert all(f >= 32 and r >= 1 for f, r in vel_fit.EARLY_SPLITS)
+    a, b = out[True], out[False]
+    for k in ('vel', 'chisq', 'vsini', 'nm_nit', 'nm_nfev', 'nm_vel', 'vel_err',
+              'minimize_success', 'status'):
+        assert torch.equal(torch.as_tensor(a[k]), torch.as_tensor(b[k])), k
+    for k in ('teff', 'logg', 'feh', 'alpha'):
+        assert torch.equal(a['param'][k], b['param'][k]), k
+        np.testing.assert_array_equal(a['param_err'][k], b['param_err'][k])
+    np.testing.assert_array_equal(a['bad_hessian'], b['bad_hessian'])
+    for m1, m2 in zip(a['yfit'], b['yfit']):
+        assert torch.equal(m1, m2)
+    assert a['objective_evals'] == b['objective_evals']
+    if second:
+        for k in ('nit', 'nfev', 'status'):
+            np.testing.assert_array_equal(a['bfgs'][k], b['bfgs'][k])
+
+
 @pytest.mark.parametrize('S', [40, 1300])
 def test_nm_round_kernels_equal_chain(cases, config, S):
     """rvs_nm_run's rounds -- three bookkeeping kernels that also sum the arms and

@@ -806,9 +806,9 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
         curparam, resols=spec_fit._resols(batch, resolParams))
     nmdev = optimizer.DeviceNelderMead(S, simplex.shape[2], dev)
     early = early and (pobj.fused or pobj.nn_native or pobj.tri_native)
+    kw_nm = dict(stop_below=max(1, int(EARLY_SPLIT_FRAC * S))) if early else {}
     nm = nmdev.minimize(pobj, simplex, fatol=1e-3, xatol=1e-2, maxiter=NM_MAXITER,
-                        stats=stats,
-                        stop_below=max(1, int(EARLY_SPLIT_FRAC * S)) if early else 0)
+                        stats=stats, **kw_nm)
     ctx = dict(batch=batch, pd0=pd0, priors=priors, curparam=curparam, names=names,
                fixParam=fixParam, fitVsini=fitVsini, vsiniMapper=vsiniMapper,
                config=config, options=options, resolParams=resolParams, libs=libs,
@@ -884,13 +884,18 @@ def _process_one(specdata, paramDict0, fixParam=None, options=None, config=None,
     return _merge_parts([box['ret'], r_rest], [fin, rest], S)
 
 
-# Spectra that finish the simplex stage early go on to their BFGS polish, refinement
-# and Hessian while the stragglers' last rounds -- a chain of latencies that leaves the
-# chip mostly idle -- are still running: rvs_nm_run returns at its first look that
-# finds at most EARLY_SPLIT_FRAC of the simplices running, the converged spectra's later
-# stages start on a second stream, and the rounds resume.  No spectrum sees another:
-# the results are those of the unsplit run (test_process_early_split_equals_unsplit).
-EARLY_SPLIT = os.environ.get('RVS_EARLY_SPLIT', '1') != '0'
+# An option, OFF by default (measured slower, below): spectra that finish the simplex
+# stage early go on to their BFGS polish, refinement and Hessian while the stragglers'
+# last rounds -- a chain of latencies that leaves the chip mostly idle -- are still
+# running: rvs_nm_run returns at its first look that finds at most EARLY_SPLIT_FRAC of
+# the simplices running, the converged spectra's later stages start on a second stream,
+# and the rounds resume.  No spectrum sees another: the results are those of the
+# unsplit run bit for bit (test_process_early_split_equals_unsplit).  What it costs is
+# a second latency-bound BFGS tail (the stragglers' own ~200 rounds, behind
+# everything) and the sub-batches' set-up: --process 2000 2060-2110 against 2190-2200
+# spectra/s for fractions of 0.02-0.25, 500: 1340-1410 against 1480-1505, 10 000 equal
+# (tools/perf/proc_ab.sh, one job, alternating).
+EARLY_SPLIT = os.environ.get('RVS_EARLY_SPLIT', '0') != '0'
 EARLY_SPLIT_FRAC = float(os.environ.get('RVS_EARLY_SPLIT_FRAC', '0.25'))
 EARLY_SPLIT_MIN = int(os.environ.get('RVS_EARLY_SPLIT_MIN', '128'))
 _EARLY_STREAMS = {}

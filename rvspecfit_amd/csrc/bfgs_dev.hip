@@ -23,7 +23,13 @@
 
 using rvs_bfgs::Run;
 
-#define BF_NT 64        // advance: one wave per block (the runs spread over the CUs)
+#ifndef BF_NT
+// advance: FOUR runs per block -- a run's state is 7.7 KB of its own, so every load of
+// a wave touches as many cache lines as it has live lanes; few lanes per wave and many
+// waves over the CUs: BFGS of 500 / 2000 spectra 0.088 / 0.227 -> 0.083 / 0.221 s
+// against 64 runs per block (16: 0.085 / 0.224; tools/perf/ab_libs3.sh)
+#define BF_NT 4
+#endif
 #define BF_SCAN_NT 1024
 #define BF_NCHUNK 24    // counts[0 .. 24): rows of chunk c; [24] rows; [25] live runs
 

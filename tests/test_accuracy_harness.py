@@ -42,7 +42,7 @@ def test_batch_of_the_harness_equals_the_oracle_one_by_one():
     from conftest import GOLD, gold_lib_dict
     from oracle import rvs_oracle as orc
     n = 48
-    out = accuracy_suite.run(sn=100., n=n)
+    out = accuracy_suite.run(sn=100., n=n, config=dict(second_minimizer=False))
     lam = np.load(os.path.join(GOLD, 'cases.npz'))['c0/gold_b/lam']
     v0, truth, spec, espec = accuracy_suite.make_spectra(lam, n, 100.)
     assert np.array_equal(v0, out['v0'])
@@ -67,7 +67,8 @@ def test_batch_of_the_harness_equals_the_reference_one_by_one():
     from conftest import GOLD
     g = np.load(os.path.join(GOLD, 'accuracy_cases.npz'))
     n = int(g['n'])
-    out = accuracy_suite.run(sn=float(g['sn']), n=n)
+    out = accuracy_suite.run(sn=float(g['sn']), n=n,
+                             config=dict(second_minimizer=False))
     idx = [int(_) for _ in g['idx']]
     assert np.array_equal(out['v0'][idx], g['v0'])
     res = out['res']
@@ -100,7 +101,34 @@ def test_harness_statistics_equal_the_reference():
     from conftest import GOLD
     g = np.load(os.path.join(GOLD, 'accuracy_cases.npz'))
     n = int(g['all/n'])
+    out = accuracy_suite.run(sn=float(g['sn']), n=n,
+                             config=dict(second_minimizer=False))
+    dv = np.abs(out['vel'] - g['all/vel'])
+    assert dv.max() < 0.01, (int(np.argmax(dv)), dv.max())
+    np.testing.assert_allclose(out['vel_err'], g['all/vel_err'], rtol=2e-2)
+    chisq = out['res']['chisq'].cpu().numpy()
+    assert np.all(np.abs(chisq - g['all/chisq']) <
+                  np.maximum(2e-3, 1e-6 * np.abs(g['all/chisq'])))
+    dx, dxr = out['vel'] - out['v0'], g['all/vel'] - out['v0']
+    assert abs(np.median(dx) - np.median(dxr)) < 2e-3
+    assert abs(np.std(dx) / np.std(dxr) - 1) < 1e-3
+    assert abs(np.std(dx / out['vel_err']) / np.std(dxr / g['all/vel_err']) - 1) < 5e-3
+
+
+def test_harness_at_the_reference_default_equals_the_reference():
+    """the same 200 spectra at the reference's DEFAULT optimiser configuration
+    (second_minimizer = True, utils.py:26: what tests/accuracy.py itself runs): the
+    reference's vel_fit.process one by one with scipy's BFGS behind Nelder-Mead
+    (accuracy_bfgs_cases.npz, make_golden_accuracy_bfgs.py) against ONE GPU batch with
+    both minimisers' rounds on the device (rvs_nm_run, rvs_bfgs_run) -- every velocity
+    within the contract's 0.01 km/s, chi^2 at the optimiser's own tolerance, the
+    harness's summary statistics to three digits"""
+    import accuracy_suite
+    from conftest import GOLD
+    g = np.load(os.path.join(GOLD, 'accuracy_bfgs_cases.npz'))
+    n = int(g['all/n'])
     out = accuracy_suite.run(sn=float(g['sn']), n=n)
+    assert out['res']['second_minimizer_run'] and out['res']['bfgs']['device']
     dv = np.abs(out['vel'] - g['all/vel'])
     assert dv.max() < 0.01, (int(np.argmax(dv)), dv.max())
     np.testing.assert_allclose(out['vel_err'], g['all/vel_err'], rtol=2e-2)

@@ -6,7 +6,7 @@ scale 10**U(-3, 3), Gaussian noise at a given S/N -- each through vel_fit.proces
 the same starting point, then the median and scatter of v - v0 and the width of the
 pull (v - v0) / vel_err) -- as ONE batch on the GPU instead of a 24-process pool.
 
-    python tools/accuracy_suite.py [S/N = 300] [n = 1000] [library npz = golden 7^4 grid]
+    python tools/accuracy_suite.py [S/N = 300] [n = 1000] [library npz = golden 7^4 grid | -] [nobfgs]
 
 prints the reference's two summary lines:
     median(dx) median(err) std(dx) std(dx / err)
@@ -63,7 +63,10 @@ def run(sn=300.0, n=1000, lib_npz=None, setup='gold_b', lam=None, seed=1, npoly=
     if lam is None:
         lam = np.load(os.path.join(gold, 'cases.npz'))['c0/%s/lam' % setup]
     cfg = dict(min_vel=-1500, max_vel=1500, min_vel_step=0.2, vel_step0=5,
-               min_vsini=0.1, max_vsini=500, second_minimizer=False)
+               min_vsini=0.1, max_vsini=500, second_minimizer=True)
+    # (second_minimizer = True: utils.read_config's default, utils.py:26 -- what the
+    # reference's tests/accuracy.py runs; config=dict(second_minimizer=False) for the
+    # Nelder-Mead-only run)
     cfg.update(config or {})
     cfg['template_lib'] = root
     v0, truth, spec, espec = make_spectra(lam, n, sn, seed)
@@ -89,7 +92,8 @@ if __name__ == '__main__':
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     import time
     t0 = time.time()
-    out = run(sn, n, sys.argv[3] if len(sys.argv) > 3 else None)
+    out = run(sn, n, sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != '-' else None,
+              config=dict(second_minimizer=False) if 'nobfgs' in sys.argv[3:] else None)
     s = out['summary']
     # (the two lines runall_accuracy.py prints)
     print(s['median_dx'], s['median_err'], s['std_dx'], s['std_pull'])

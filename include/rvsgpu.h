@@ -114,7 +114,7 @@ int rvs_abi_version(void);
  *   "nm_tail_window" 16 rvs_nm_run: rounds between two looks of the host (counter
  *                       copy + stream synchronisation) once <= 256 rows are live,
  *                       if larger than sync_every
- *   "obj_inblk_max" 256 objective launches of <= this many blocks search their grid
+ *   "obj_inblk_max" 768 objective launches of <= this many blocks search their grid
  *                       cell inside the block (0 = never)
  *   "obj_sort"       1  objective jobs evaluated in grid-cell order
  *   "nn_pipe"        1  rvs_template_nn(_arms): the wide last layer through the kernel

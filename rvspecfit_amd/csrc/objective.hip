@@ -1419,7 +1419,9 @@ static int objective_launch(const rvs_objective_arm *arms, int narm, int npoly,
     bool pre = true;
     for (int i = 0; i < narm; i++)
       if ((1 << arms[i].ndim) > OBJ_LOC_NV) pre = false;
-    // a launch that fits the chip in one go (<= 256 blocks): the cell search inside
+    // a launch of up to three passes over the CUs (<= 768 blocks; 256 until round 6:
+    // --process 500 1498 -> 1548 spectra/s, 2000 equal, 3072 slower -- the launches
+    // lose their cell order): the cell search inside
     // the block -- the same device function, so the same values -- and one launch
     // less per evaluation in the optimiser's latency-bound last rounds (+1 % at 2000
     // spectra; option obj_inblk_max overrides the bound, 0 = never)

@@ -28,7 +28,7 @@ const OptDef kDefs[RVS_OPT_COUNT] = {
     {"xc_ws1", "RVS_XC_WS1", 0, true},
     {"nm_glue", "RVS_NM_GLUE", 1, false},
     {"nm_bucket", "RVS_NM_BUCKET", 0, true},
-    {"obj_inblk_max", "RVS_OBJ_INBLK_MAX", 256, false},
+    {"obj_inblk_max", "RVS_OBJ_INBLK_MAX", 768, false},
     {"obj_sort", "RVS_OBJ_SORT", 1, false},
     {"nn_pipe", "RVS_NN_PIPE", 1, false},
     {"nm_split_min", "RVS_NM_SPLIT_MIN", 1024, false},

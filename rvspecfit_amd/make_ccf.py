@@ -5,6 +5,10 @@ fitter_ccf.fit calls per spectrum and arm), on the MI355X kernels.
 The template side of make_ccf (preprocess_model, ccf_executor, main: building a
 library's CCF template set once, offline) is not rebuilt; artefacts made by the
 reference are read as they are (library.py, tools/convert_artefacts.py).
+get_continuum / fit_resid (the robust continuum of a spectrum, make_ccf.py:105-164)
+exist only inside preprocess_data's kernel (rvs_ccf_preprocess: the Levenberg-
+Marquardt fit on the device; engine.ccf_preprocess(details=True) returns the
+continuum and the node values).
 """
 import types
 
@@ -46,6 +50,40 @@ def get_ccf_config(logl0=None, logl1=None, npoints=None, splinestep=1000,
         widest = 3e5 * (np.exp((logl1 - logl0) / maxcontpts) - 1)
         conf['splinestep'] = max(splinestep, widest)
     return conf
+
+
+def to_power_two(i):
+    """make_ccf.to_power_two (make_ccf.py:496-497): the next power of two >= i"""
+    return 2**(int(np.ceil(np.log(i) / np.log(2))))
+
+
+def interp_masker(lam, spec, badmask):
+    """make_ccf.interp_masker (make_ccf.py:288-327): the spectrum with its masked
+    pixels filled -- linearly in wavelength between the nearest good neighbours, with
+    the nearest good value beyond the first / last good pixel; everything masked: the
+    spectrum itself with non-finite values set to 1.  Host arithmetic on one spectrum
+    (index work; preprocess_data does the same inside its kernel for a batch)."""
+    lam = np.asarray(lam)
+    spec = np.asarray(spec)
+    bad = np.asarray(badmask, dtype=bool)
+    out = spec * 1
+    good_ix = np.flatnonzero(~bad)
+    if good_ix.size == 0:
+        import logging
+        logging.warning('All the pixels are masked for the ccf determination')
+        out[~np.isfinite(out)] = 1
+        return out
+    bad_ix = np.flatnonzero(bad)
+    nxt = np.searchsorted(good_ix, bad_ix)      # first good pixel behind each bad one
+    left, right = nxt == 0, nxt == good_ix.size
+    inner = ~(left | right)
+    out[bad_ix[left]] = spec[good_ix[0]]
+    out[bad_ix[right]] = spec[good_ix[-1]]
+    a, b = good_ix[nxt[inner] - 1], good_ix[nxt[inner]]
+    l0 = lam[bad_ix[inner]]
+    out[bad_ix[inner]] = (-(lam[a] - l0) * spec[b] + (lam[b] - l0) * spec[a]) / \
+        (lam[b] - lam[a])
+    return out
 
 
 class _ConfLib:

@@ -242,9 +242,16 @@ class VSiniMapper:
         self.max_vsini = max_vsini
 
     def to_internal(self, vsini):
+        if not isinstance(vsini, torch.Tensor):   # (one spectrum: the reference's form)
+            return np.clip(vsini, 0, self.max_vsini)
         return torch.clamp(vsini, 0, self.max_vsini)
 
     def to_vsini(self, x):
+        if not isinstance(x, torch.Tensor):
+            vsini = np.clip(x, 0, self.max_vsini)
+            penalty = int(x < 0) * (vsini - x)**2 + int(x > self.max_vsini) * \
+                (vsini - x)**2
+            return vsini, penalty
         vsini = torch.clamp(x, 0, self.max_vsini)
         out = (x < 0) | (x > self.max_vsini)
         penalty = torch.where(out, (vsini - x)**2, torch.zeros_like(x))
@@ -265,7 +272,9 @@ class ParamMapper:
         self.vsiniMapper = vsiniMapper
         self.fitVsini = fitVsini
 
-    def forward(self, p0, idx):
+    def forward(self, p0, idx=None):
+        if idx is None and not isinstance(p0, torch.Tensor):
+            return self._forward_one(p0)
         ret = {}
         k = 0
         ret['vel'] = p0[:, k]
@@ -292,6 +301,33 @@ class ParamMapper:
         ret['penalty'] = penalty
         return ret
 
+    def _forward_one(self, p0):
+        """the reference's own form (vel_fit.py:156-202): ONE parameter vector ->
+        dict(vel, vsini, rot_params, params [list], penalty) of plain numbers;
+        paramDict0 holds numbers"""
+        ret = {}
+        p0rev = list(p0)[::-1]
+        penalty = 0
+        ret['vel'] = p0rev.pop()
+        if self.fitVsini:
+            vsini, penalty_vsini = self.vsiniMapper.to_vsini(p0rev.pop())
+            penalty += penalty_vsini
+            ret['vsini'] = vsini
+        elif 'vsini' in self.fixParam:
+            ret['vsini'] = self.paramDict0['vsini']
+        else:
+            ret['vsini'] = None
+        ret['rot_params'] = None if ret['vsini'] is None else (ret['vsini'], )
+        ret['params'] = []
+        for x in self.specParams:
+            if x in self.fixParam:
+                ret['params'].append(self.paramDict0[x])
+            else:
+                ret['params'].append(p0rev.pop())
+        assert len(p0rev) == 0
+        ret['penalty'] = penalty
+        return ret
+
     def get_fitted_params(self):
         ret = ['vel']
         if self.fitVsini:
@@ -300,6 +336,44 @@ class ParamMapper:
             if x not in self.fixParam:
                 ret.append(x)
         return ret
+
+
+def chisq_func0(pdict, args, outside_penalty=True):
+    """vel_fit.chisq_func0 (vel_fit.py:210-230): chi-square + priors of ONE spectrum
+    at the parameter dictionary `pdict` (ParamMapper.forward of one vector); `args` as
+    the reference builds it in process (specdata, paramMapper, resolParams, options,
+    config, priors).  For user code that drives its own sampler over the objective of
+    `process`; process itself evaluates S such objectives per kernel launch."""
+    chisq = 0
+    if args.get('priors') is not None:
+        priors = args['priors']
+        for i, k in enumerate(args['paramMapper'].specParams):
+            if k in priors:
+                chisq += ((priors[k][0] - pdict['params'][i]) / priors[k][1])**2
+    chisq += spec_fit.get_chisq(args['specdata'], pdict['vel'],
+                                tuple(pdict['params']), pdict['rot_params'],
+                                args.get('resolParams'), options=args['options'],
+                                config=args['config'],
+                                outside_penalty=outside_penalty)
+    return chisq
+
+
+def chisq_func(p, args):
+    """vel_fit.chisq_func (vel_fit.py:233-257): the function process minimises --
+    1e30 outside [min_vel, max_vel] or at a non-finite parameter, else chisq_func0 +
+    the vsini penalty"""
+    pdict = args['paramMapper'].forward(p)
+    if (pdict['vel'] > args['max_vel'] or pdict['vel'] < args['min_vel']
+            or (~np.isfinite(np.asarray(pdict['params'], dtype=float))).any()):
+        return 1e30
+    return chisq_func0(pdict, args) + pdict['penalty']
+
+
+def hess_func(p, pdict, args):
+    """vel_fit.hess_func (vel_fit.py:260-269): 0.5 chi-square in the stellar parameters
+    `p` at the rest of `pdict`"""
+    pdict['params'][:] = p[:]
+    return 0.5 * chisq_func0(pdict, args)
 
 
 def get_hess_inv(param_names):

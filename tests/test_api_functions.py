@@ -114,9 +114,10 @@ def test_public_names_of_the_path_exist():
                      'getSpecParams'],
         fitter_ccf: ['CCFCache', 'get_ccf_info', 'fit'],
         make_ccf: ['get_continuum_prefix', 'get_ccf_info_name', 'get_ccf_dat_name',
-                   'get_ccf_mod_name', 'get_ccf_config', 'preprocess_data'],
+                   'get_ccf_mod_name', 'get_ccf_config', 'preprocess_data',
+                   'interp_masker', 'to_power_two'],
         vel_fit: ['firstguess', 'process', 'VSiniMapper', 'ParamMapper',
-                  'get_hess_inv'],
+                  'get_hess_inv', 'chisq_func0', 'chisq_func', 'hess_func'],
     }
     for mod, names in want.items():
         for n in names:
@@ -329,3 +330,77 @@ def test_get_ccf_info():
         np.testing.assert_array_equal(mod, d['ccf_mod'])
     assert 'gold_b' in fitter_ccf.CCFCache.ccfs
     assert fitter_ccf.get_ccf_info('gold_b', cfg)[0] is fft   # cached
+
+
+# --------------------------------------------------------------------------
+# round 6: the objective functions of vel_fit.process and make_ccf's gap filler by
+# name (api2_cases.npz, make_golden_api2.py)
+# --------------------------------------------------------------------------
+def test_interp_masker_and_to_power_two():
+    """make_ccf.interp_masker (make_ccf.py:288-327) against the reference's outputs:
+    interior gaps, both edges, everything masked, nothing masked"""
+    from rvspecfit_amd import make_ccf
+    g = np.load(os.path.join(GOLD, 'api2_cases.npz'))
+    for m, want in zip(g['im/masks'], g['im/out']):
+        got = make_ccf.interp_masker(g['im/lam'], g['im/spec'], m)
+        np.testing.assert_allclose(got, want, rtol=1e-14, atol=0)
+    assert [make_ccf.to_power_two(_) for _ in (1, 2, 3, 1000, 4096, 4097)] == \
+        [1, 2, 4, 1024, 4096, 8192]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('t', ['f0', 'f1'])
+def test_chisq_func_by_name(t):
+    """vel_fit.chisq_func0 / chisq_func / hess_func (vel_fit.py:210-269) with the
+    reference's own `args` dictionary and its one-vector ParamMapper.forward: priors, a
+    fixed parameter, vsini inside and outside its range (the penalty), a velocity
+    outside [min_vel, max_vel] and a non-finite parameter (1e30 without evaluating)"""
+    from rvspecfit_amd import spec_fit, spec_inter, vel_fit
+    from rvspecfit_amd.library import TemplateLibrary
+    from conftest import GOLD_CONFIG
+    g = np.load(os.path.join(GOLD, 'api2_cases.npz'))
+    cases = np.load(os.path.join(GOLD, 'cases.npz'))
+    cfg = dict(GOLD_CONFIG)
+    for n in ('gold_b', 'gold_r'):
+        spec_inter.register_library(
+            TemplateLibrary(n, np.load(os.path.join(GOLD, 'lib_%s.npz' % n))),
+            cfg['template_lib'])
+    case = str(g[t + '/case'])
+    names = [str(_) for _ in cases[case + '/names']]
+    sds = [spec_fit.SpecData(n, cases['%s/%s/lam' % (case, n)],
+                             cases['%s/%s/spec' % (case, n)],
+                             cases['%s/%s/espec' % (case, n)],
+                             badmask=cases['%s/%s/badmask' % (case, n)]) for n in names]
+    pd0 = dict(zip([str(_) for _ in g[t + '/pd0_keys']],
+                   [float(_) for _ in g[t + '/pd0_vals']]))
+    fix = [str(_) for _ in g[t + '/fix']]
+    pri = None
+    if t + '/prior_keys' in g:
+        pri = {str(k): tuple(v) for k, v in zip(g[t + '/prior_keys'],
+                                                g[t + '/prior_vals'])}
+    fit_vsini = 'vsini' in pd0 and 'vsini' not in fix
+    vm = vel_fit.VSiniMapper(cfg['max_vsini']) if fit_vsini else None
+    pm = vel_fit.ParamMapper(['teff', 'logg', 'feh', 'alpha'], pd0, fix, vm,
+                             fitVsini=fit_vsini)
+    args = dict(specdata=sds, paramMapper=pm, resolParams=None, options=dict(npoly=10),
+                config=cfg, priors=pri, min_vel=cfg['min_vel'],
+                max_vel=cfg['max_vel'])
+    npix = sum(len(_.lam) for _ in sds)
+
+    def close(a, b):
+        return abs(a - b) <= 1e-6 * max(abs(b), npix)
+    for i, p in enumerate(g[t + '/ps']):
+        want = float(g[t + '/chisq_func'][i])
+        with np.errstate(all='ignore'):
+            got = vel_fit.chisq_func(np.array(p), args)
+        assert got == want if want == 1e30 else close(got, want), (i, got, want)
+        if want == 1e30:
+            continue
+        pd = pm.forward(np.array(p))
+        assert isinstance(pd['params'], list) and pd['penalty'] >= 0
+        w0 = g[t + '/chisq_func0'][i]
+        assert close(vel_fit.chisq_func0(pd, args), w0[0])
+        assert close(vel_fit.chisq_func0(pd, args, outside_penalty=False), w0[1])
+        pd['params'] = np.array(pd['params'], dtype=float)
+        h = vel_fit.hess_func(pd['params'] * np.array([1.001, 1.0, 1.0, 1.0]), pd, args)
+        assert close(2 * h, 2 * float(g[t + '/hess_func'][i]))

@@ -360,11 +360,10 @@ def test_chisq_func_by_name(t):
     from conftest import GOLD_CONFIG
     g = np.load(os.path.join(GOLD, 'api2_cases.npz'))
     cases = np.load(os.path.join(GOLD, 'cases.npz'))
-    cfg = dict(GOLD_CONFIG)
+    cfg = dict(GOLD_CONFIG, template_lib='golden-api2://')
     for n in ('gold_b', 'gold_r'):
-        spec_inter.register_library(
-            TemplateLibrary(n, np.load(os.path.join(GOLD, 'lib_%s.npz' % n))),
-            cfg['template_lib'])
+        spec_inter.register_library(TemplateLibrary(n, gold_lib_dict(n)),
+                                    cfg['template_lib'])
     case = str(g[t + '/case'])
     names = [str(_) for _ in cases[case + '/names']]
     sds = [spec_fit.SpecData(n, cases['%s/%s/lam' % (case, n)],

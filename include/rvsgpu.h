@@ -183,8 +183,10 @@ int rvs_template_tri(const double *dats, int ntp, const int32_t *simplices,
  * mapped parameter space lists, ascending, every simplex whose bounding box (grown by
  * 1e-9 of the grid's extent) overlaps it.  The cell of a mapped coordinate x in
  * dimension d is clamp(floor((x - lo[d]) * inv_w[d]), 0, n[d] - 1), cells in C order
- * over the dimensions.  The struct is read on the host; cell_start [ncell + 1] and
- * cell_list [cell_start[ncell]] are device arrays. */
+ * over the dimensions.  List number ncell (behind the last cell) holds the simplices
+ * whose boxes overlap too many cells to be entered in each: every query tests it as
+ * well, the lower id of the two finds wins.  The struct is read on the host;
+ * cell_start [ncell + 2] and cell_list [cell_start[ncell + 1]] are device arrays. */
 typedef struct rvs_tri_buckets {
   const int32_t *cell_start, *cell_list;
   double lo[6], inv_w[6];

@@ -296,7 +296,15 @@ __global__ void __launch_bounds__(64 * TRI_LOC_WAVES)
   int found = 0x7fffffff;
   if (finite) {
     const double eps = 100.0 * 2.220446049250313e-16;
-    const int e0 = K.cell_start[cell], e1 = K.cell_start[cell + 1];
+    int64_t ncell = 1;
+#pragma unroll
+    for (int d = 0; d < TRI_MAXDIM; d++)
+      if (d < nd) ncell *= K.n[d];
+    // the point's own cell, then the list of the simplices too wide for the grid
+    // (list number ncell, library.tri_buckets); the lower id of the two finds
+    for (int pass = 0; pass < 2; pass++) {
+    const int64_t li = pass ? ncell : cell;
+    const int e0 = K.cell_start[li], e1 = K.cell_start[li + 1];
     for (int eb = e0; eb < e1; eb += 64) {
       const int e = eb + lane;
       bool in = e < e1;
@@ -317,9 +325,10 @@ __global__ void __launch_bounds__(64 * TRI_LOC_WAVES)
       }
       const unsigned long long m = __ballot(in);
       if (m) {
-        found = __shfl(s, __ffsll((long long)m) - 1, 64);
+        found = min(found, __shfl(s, __ffsll((long long)m) - 1, 64));
         break;
       }
+    }
     }
   }
   if (lane == 0) simplex[b] = found;

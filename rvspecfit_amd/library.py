@@ -30,18 +30,23 @@ def _dev(a, dtype, device):
 # find_simplex of Delaunay libraries: bucket grid from this many simplices up
 TRI_BUCKET_MIN = 256
 TRI_BUCKETS = True
+TRI_WIDE_CELLS = 4096   # a simplex whose box overlaps more cells goes to the wide list
 
 
-def tri_buckets(transform, ndim, per_cell=8, max_n=48, max_entries=1 << 26):
+def tri_buckets(transform, ndim, per_cell=8, max_n=48, max_entries=1 << 25,
+                wide_cells=4096):
     """The bucket grid of rvs_template_tri_buckets for a Delaunay triangulation given
     as scipy's `transform` [nsimplex, ndim + 1, ndim] (spec_inter.py:11-59 keeps the
     Delaunay object; the artefact reader exports its arrays): vertices from the
     transform (the last one is r, the others r + the columns of the inverse), bounding
     boxes grown by 1e-9 of the extent, a uniform grid of n^ndim cells with about
     `per_cell` simplices per cell, every simplex entered in each cell its box
-    overlaps, the lists ascending.  Degenerate simplices (non-finite transform: they
-    never pass the inside test) are in no list.  Returns dict(cell_start int32
-    [ncell + 1], cell_list int32 [entries], lo, inv_w float64 [ndim], n int32 [ndim])."""
+    overlaps, the lists ascending.  A simplex whose box overlaps more than
+    `wide_cells` cells (the long slivers Qhull leaves on a hull) is entered ONCE, in a
+    list of its own behind the last cell -- list number ncell --, which every query
+    tests as well.  Degenerate simplices (non-finite transform: they never pass the
+    inside test) are in no list.  Returns dict(cell_start int32 [ncell + 2],
+    cell_list int32 [entries], lo, inv_w float64 [ndim], n int32 [ndim])."""
     tr = np.asarray(transform, dtype=np.float64)
     ns = tr.shape[0]
     good = np.isfinite(tr).all(axis=(1, 2))
@@ -53,7 +58,7 @@ def tri_buckets(transform, ndim, per_cell=8, max_n=48, max_entries=1 << 26):
         good = g2
     ids = np.nonzero(good)[0]
     if len(ids) == 0:
-        return dict(cell_start=np.zeros(2, dtype=np.int32),
+        return dict(cell_start=np.zeros(3, dtype=np.int32),
                     cell_list=np.zeros(1, dtype=np.int32), lo=np.zeros(ndim),
                     inv_w=np.zeros(ndim), n=np.ones(ndim, dtype=np.int32))
     r = tr[ids, ndim, :]
@@ -71,31 +76,40 @@ def tri_buckets(transform, ndim, per_cell=8, max_n=48, max_entries=1 << 26):
         i0 = np.clip(np.floor((blo - m - lo) * inv_w), 0, n - 1).astype(np.int64)
         i1 = np.clip(np.floor((bhi + m - lo) * inv_w), 0, n - 1).astype(np.int64)
         span = i1 - i0 + 1
-        total = int(span.prod(axis=1).sum())
+        cnt = span.prod(axis=1)
+        wide = cnt > wide_cells
+        total = int(cnt[~wide].sum())
         if total <= max_entries or n1 == 1:
             break
         n1 = max(1, n1 // 2)
-    cells, sims = [], []
-    smax = span.max(axis=0)
-    for off in np.ndindex(*[int(_) for _ in smax]):
-        o = np.array(off)
-        ok = (o[None, :] < span).all(axis=1)
-        if not ok.any():
-            continue
-        c = np.zeros(int(ok.sum()), dtype=np.int64)
-        for d in range(ndim):
-            c = c * n[d] + (i0[ok, d] + o[d])
-        cells.append(c)
-        sims.append(ids[ok])
-    cells = np.concatenate(cells)
-    sims = np.concatenate(sims)
+    # every (simplex, cell) pair of the narrow simplices, without a Python loop: entry e
+    # belongs to simplex owner[e] and is cell number local[e] of its box, decoded digit
+    # by digit in the box's own mixed radix
+    nar = np.nonzero(~wide)[0]
+    c_n = cnt[nar]
+    owner = np.repeat(nar, c_n)
+    local = np.arange(int(c_n.sum()), dtype=np.int64) - np.repeat(
+        np.cumsum(c_n) - c_n, c_n)
+    digits = []
+    for d in range(ndim - 1, -1, -1):
+        sp = span[owner, d]
+        digits.append(i0[owner, d] + local % sp)
+        local = local // sp
+    cells = np.zeros(len(owner), dtype=np.int64)
+    for d, dg in zip(range(ndim), digits[::-1]):
+        cells = cells * n[d] + dg
+    sims = ids[owner]
     order = np.lexsort((sims, cells))        # by cell, ascending simplex inside
     cells, sims = cells[order], sims[order]
     ncell = int(n.prod())
-    start = np.zeros(ncell + 1, dtype=np.int64)
+    start = np.zeros(ncell + 2, dtype=np.int64)
     np.add.at(start, cells + 1, 1)
+    start[ncell + 1] = int(wide.sum())
     start = np.cumsum(start)
-    return dict(cell_start=start.astype(np.int32), cell_list=sims.astype(np.int32),
+    lst = np.concatenate([sims, np.sort(ids[wide])])
+    if len(lst) == 0:
+        lst = np.zeros(1, dtype=np.int64)
+    return dict(cell_start=start.astype(np.int32), cell_list=lst.astype(np.int32),
                 lo=lo, inv_w=inv_w, n=n.astype(np.int32))
 
 
@@ -148,7 +162,9 @@ class TemplateLibrary:
             # search (tests hold one against the other)
             self._tri_bk = self._tri_keep = None
             if self.tri_nsimplex >= TRI_BUCKET_MIN and str(device) != 'cpu':
-                bk = tri_buckets(np.asarray(d['transform']), self.ndim)
+                bk = tri_buckets(np.asarray(d['transform']), self.ndim,
+                                 wide_cells=TRI_WIDE_CELLS)
+                self.tri_nwide = int(bk['cell_start'][-1] - bk['cell_start'][-2])
                 self._tri_keep = (_dev(bk['cell_start'], torch.int32, device),
                                   _dev(bk['cell_list'], torch.int32, device))
                 t = _lib.TriBuckets()

@@ -28,20 +28,25 @@ def _grid_delaunay(n, jitter, seed):
     return pts, scipy.spatial.Delaunay(pts)
 
 
-@pytest.mark.parametrize('jitter', [0.0, 0.2])
-def test_bucket_lists_hold_every_candidate(jitter):
+@pytest.mark.parametrize('jitter,wide', [(0.0, 10**9), (0.2, 10**9), (0.2, 20)])
+def test_bucket_lists_hold_every_candidate(jitter, wide):
     """host side: for random points (inside, on the hull, outside) the lowest
     matching simplex of the point's cell list is the lowest matching simplex of the
     whole triangulation; lists ascending; a regular grid (Qhull's triangulated
-    cospherical facets, what a PHOENIX grid gives) and a jittered one"""
+    cospherical facets, what a PHOENIX grid gives) and a jittered one; wide = 20: the
+    simplices whose boxes overlap more than 20 cells in the list of their own that
+    every query tests as well"""
     from rvspecfit_amd.library import tri_buckets
     pts, D = _grid_delaunay(5, jitter, 3)
     nd = 4
-    bk = tri_buckets(D.transform, nd)
+    bk = tri_buckets(D.transform, nd, wide_cells=wide)
     st, ls = bk['cell_start'], bk['cell_list']
-    assert st[-1] == len(ls) and np.all(np.diff(st) >= 0)
+    ncell = int(np.prod(bk['n']))
+    assert len(st) == ncell + 2 and st[-1] == len(ls) and np.all(np.diff(st) >= 0)
     for c in range(len(st) - 1):
         assert np.all(np.diff(ls[st[c]:st[c + 1]]) > 0)
+    wide_list = ls[st[ncell]:st[ncell + 1]]
+    assert (len(wide_list) > 0) == (wide < 10**6)
     rng = np.random.RandomState(5)
     q = np.concatenate([rng.uniform(-0.05, 1.05, (600, 4)), pts[::7],
                         0.5 * (pts[10:200:3] + pts[11:201:3])])
@@ -52,10 +57,13 @@ def test_bucket_lists_hold_every_candidate(jitter):
         cell = 0
         for d in range(nd):
             cell = cell * bk['n'][d] + c[d]
-        lst = ls[st[cell]:st[cell + 1]]
-        mm = lst[_inside(D.transform[lst], p, nd)] if len(lst) else []
-        assert (mm[0] if len(mm) else -1) == want
-    assert np.diff(st).mean() < 0.25 * len(D.simplices)
+        got = []
+        for lst in (ls[st[cell]:st[cell + 1]], wide_list):
+            mm = lst[_inside(D.transform[lst], p, nd)] if len(lst) else []
+            if len(mm):
+                got.append(mm[0])
+        assert (min(got) if got else -1) == want
+    assert np.diff(st)[:ncell].mean() < 0.25 * len(D.simplices)
 
 
 def _tri_library(pts, D, ntp=40, seed=2):
@@ -72,16 +80,20 @@ def _tri_library(pts, D, ntp=40, seed=2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,jitter', [(7, 0.0), (7, 0.25)])
-def test_bucket_search_equals_exhaustive_on_the_device(n, jitter):
+@pytest.mark.parametrize('n,jitter,wide', [(7, 0.0, 4096), (7, 0.25, 4096),
+                                           (7, 0.25, 24)])
+def test_bucket_search_equals_exhaustive_on_the_device(n, jitter, wide, monkeypatch):
     """10^5 random points (a tenth outside the hull), 31 000 simplices: the ids of
-    rvs_template_tri_buckets are those of rvs_template_tri, the templates too"""
+    rvs_template_tri_buckets are those of rvs_template_tri, the templates too; wide =
+    24: thousands of simplices in the list every query tests beside its cell's"""
     import torch
     from rvspecfit_amd import library
+    monkeypatch.setattr(library, 'TRI_WIDE_CELLS', wide)
     pts, D = _grid_delaunay(n, jitter, 11)
     assert len(D.simplices) > 20000
     lib = _tri_library(pts, D)
     assert lib._tri_bk is not None
+    assert (lib.tri_nwide > 100) == (wide < 100), lib.tri_nwide
     rng = np.random.RandomState(9)
     q = rng.uniform(-0.03, 1.03, (100000, 4))
     q[:2000] = pts[rng.randint(0, len(pts), 2000)]          # vertices

@@ -116,6 +116,9 @@ def nn_node_rows(w, physical_vec, chunk=4096):
     return out
 
 
+_TRI_CACHE = {}
+
+
 def node_templates(T, S):
     """pipeline.fit_batch's rule for sharing one template per CCF node"""
     ntp = max(len(synth.template_lam_grid(*arm_def(a)['templ'])) for a in ARMS)
@@ -175,7 +178,11 @@ def build_library_dicts(ccf_every, convolve, device=None):
             # arrays as the artefact converter exports them
             import scipy.spatial
             d = out[arm_name(a)]
-            dl = scipy.spatial.Delaunay(lib['vec'].T)
+            # (the arms share the parameter grid: one triangulation for all of them)
+            key = lib['vec'].tobytes()
+            if _TRI_CACHE.get('key') != key:
+                _TRI_CACHE.update(key=key, dl=scipy.spatial.Delaunay(lib['vec'].T))
+            dl = _TRI_CACHE['dl']
             for k in ('idgrid', 'uvec0', 'uvec1', 'uvec2', 'uvec3'):
                 d.pop(k)
             rows = lib['dats']

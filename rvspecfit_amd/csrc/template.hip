@@ -185,17 +185,17 @@ __global__ void __launch_bounds__(64)
   if (active && finite && found != 0x7fffffff) atomicMin(&simplex[b], found);
 }
 
-__global__ void __launch_bounds__(256)
-    tri_eval_kernel(const double *__restrict__ dats, int ntp,
-                    const int32_t *__restrict__ simplices,
-                    const double *__restrict__ transform,
-                    const double *__restrict__ extraflags, int nd,
-                    uint32_t log_mask, int exp_flag,
-                    const double *__restrict__ params,
-                    const int32_t *__restrict__ simplex,
-                    double *__restrict__ templ, double *__restrict__ outside,
-                    double *__restrict__ weights,
-                    const int32_t *__restrict__ live = nullptr) {
+__device__ __forceinline__ void
+    tri_eval_body(const double *__restrict__ dats, int ntp,
+                  const int32_t *__restrict__ simplices,
+                  const double *__restrict__ transform,
+                  const double *__restrict__ extraflags, int nd,
+                  uint32_t log_mask, int exp_flag,
+                  const double *__restrict__ params,
+                  const int32_t *__restrict__ simplex,
+                  double *__restrict__ templ, double *__restrict__ outside,
+                  double *__restrict__ weights,
+                  const int32_t *__restrict__ live) {
   __shared__ double sh_b[TRI_MAXDIM + 1];
   __shared__ int sh_id[TRI_MAXDIM + 1];
   __shared__ double red_m[8];
@@ -257,6 +257,20 @@ __global__ void __launch_bounds__(256)
   }
   if (weights && tid <= nd) weights[(int64_t)b * (nd + 1) + tid] = sh_b[tid];
 }
+__global__ void __launch_bounds__(256)
+    tri_eval_kernel(const double *__restrict__ dats, int ntp,
+                    const int32_t *__restrict__ simplices,
+                    const double *__restrict__ transform,
+                    const double *__restrict__ extraflags, int nd,
+                    uint32_t log_mask, int exp_flag,
+                    const double *__restrict__ params,
+                    const int32_t *__restrict__ simplex,
+                    double *__restrict__ templ, double *__restrict__ outside,
+                    double *__restrict__ weights,
+                    const int32_t *__restrict__ live = nullptr) {
+  tri_eval_body(dats, ntp, simplices, transform, extraflags, nd, log_mask, exp_flag,
+                params, simplex, templ, outside, weights, live);
+}
 
 // find_simplex through a uniform bucket grid over the (mapped) parameter space: a
 // cell lists, in ascending order, every simplex whose bounding box (grown by 1e-9 of
@@ -272,12 +286,12 @@ __global__ void __launch_bounds__(256)
 // entry by entry, a dependent chain of loads per entry: ~1 us each, up to 384 of them
 // for a point outside the hull -- 0.5 ms per launch in the optimiser's rounds.)
 #define TRI_LOC_WAVES 4
-__global__ void __launch_bounds__(64 * TRI_LOC_WAVES)
-    tri_locate_bucket_kernel(const double *__restrict__ transform, int nd,
-                             uint32_t log_mask, const double *__restrict__ params,
-                             int B, rvs_tri_buckets K,
-                             int32_t *__restrict__ simplex,
-                             const int32_t *__restrict__ live) {
+__device__ __forceinline__ void
+    tri_locate_bucket_body(const double *__restrict__ transform, int nd,
+                           uint32_t log_mask, const double *__restrict__ params,
+                           int B, const rvs_tri_buckets &K,
+                           int32_t *__restrict__ simplex,
+                           const int32_t *__restrict__ live) {
   const int b = blockIdx.x * TRI_LOC_WAVES + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= B || (live && b >= live[0])) return;   // (wave-uniform)
@@ -333,6 +347,14 @@ __global__ void __launch_bounds__(64 * TRI_LOC_WAVES)
   }
   if (lane == 0) simplex[b] = found;
 }
+__global__ void __launch_bounds__(64 * TRI_LOC_WAVES)
+    tri_locate_bucket_kernel(const double *__restrict__ transform, int nd,
+                             uint32_t log_mask, const double *__restrict__ params,
+                             int B, rvs_tri_buckets K,
+                             int32_t *__restrict__ simplex,
+                             const int32_t *__restrict__ live) {
+  tri_locate_bucket_body(transform, nd, log_mask, params, B, K, simplex, live);
+}
 
 extern "C" int rvs_template_tri_buckets(
     const double *dats, int ntp, const int32_t *simplices, const double *transform,
@@ -359,23 +381,59 @@ extern "C" int rvs_template_tri_buckets(
 
 // the template rows of an optimiser round on Delaunay libraries (rvs_nm_run,
 // rvs_bfgs_run): the first min(B, live[0]) rows of `params` through every arm's
-// triangulation -- same kernels, same values as rvs_template_tri_buckets
+// triangulation -- the kernels above with the arm as grid.y (two launches per
+// evaluation instead of two per arm: in the optimiser's rounds a launch costs as much
+// as its work), same values as rvs_template_tri_buckets
+struct TriArms {
+  rvs_nm_tri_arm a[RVS_MAX_ARMS];
+};
+__global__ void __launch_bounds__(64 * TRI_LOC_WAVES)
+    tri_locate_arms_kernel(TriArms A, int nd, const double *__restrict__ params, int B,
+                           const int32_t *__restrict__ live) {
+  const rvs_nm_tri_arm &T = A.a[blockIdx.y];
+  tri_locate_bucket_body(T.transform, nd, T.log_mask, params, B, T.buckets, T.simplex,
+                         live);
+}
+__global__ void __launch_bounds__(256)
+    tri_eval_arms_kernel(TriArms A, int nd, const double *__restrict__ params,
+                         const int32_t *__restrict__ live) {
+  const rvs_nm_tri_arm &T = A.a[blockIdx.y];
+  tri_eval_body(T.dats, T.ntp, T.simplices, T.transform, T.extraflags, nd, T.log_mask,
+                T.exp_flag, params, T.simplex, T.templ, T.outside, nullptr, live);
+}
+
 int rvs_internal_template_tri_arms_n(const double *params, int B, const int32_t *live,
                                      int ndim, int narm, const rvs_nm_tri_arm *arms,
                                      hipStream_t st) {
-  if (ndim < 1 || ndim > TRI_MAXDIM || B < 1 || narm < 1 || !arms) return RVS_E_ARG;
-  for (int a = 0; a < narm; a++) {
-    const rvs_nm_tri_arm &A = arms[a];
-    if (!A.buckets.cell_start || !A.buckets.cell_list || !A.simplex || A.ntp < 1)
+  if (ndim < 1 || ndim > TRI_MAXDIM || B < 1 || narm < 1 || narm > RVS_MAX_ARMS || !arms)
+    return RVS_E_ARG;
+  TriArms A;
+  for (int a = 0; a < RVS_MAX_ARMS; a++) {
+    A.a[a] = arms[a < narm ? a : 0];
+    const rvs_nm_tri_arm &T = A.a[a];
+    if (!T.buckets.cell_start || !T.buckets.cell_list || !T.simplex || T.ntp < 1)
       return RVS_E_ARG;
-    hipLaunchKernelGGL(tri_locate_bucket_kernel,
-                       dim3((B + TRI_LOC_WAVES - 1) / TRI_LOC_WAVES),
-                       dim3(64 * TRI_LOC_WAVES), 0, st, A.transform, ndim, A.log_mask,
-                       params, B, A.buckets, A.simplex, live);
-    hipLaunchKernelGGL(tri_eval_kernel, dim3(B), dim3(256), 0, st, A.dats, A.ntp,
-                       A.simplices, A.transform, A.extraflags, ndim, A.log_mask,
-                       A.exp_flag, params, A.simplex, A.templ, A.outside, nullptr, live);
   }
+  // find_simplex once per TRIANGULATION: arms whose libraries share one (the arms of a
+  // setup are computed on one parameter grid; library.py keeps one device copy per
+  // distinct triangulation) also share the simplex ids -- the caller hands such arms the
+  // same `simplex` buffer
+  TriArms L;
+  int nloc = 0;
+  for (int a = 0; a < narm; a++) {
+    bool seen = false;
+    for (int q = 0; q < nloc; q++)
+      if (L.a[q].transform == arms[a].transform && L.a[q].simplex == arms[a].simplex &&
+          L.a[q].log_mask == arms[a].log_mask)
+        seen = true;
+    if (!seen) L.a[nloc++] = arms[a];
+  }
+  for (int a = nloc; a < RVS_MAX_ARMS; a++) L.a[a] = L.a[0];
+  hipLaunchKernelGGL(tri_locate_arms_kernel,
+                     dim3((B + TRI_LOC_WAVES - 1) / TRI_LOC_WAVES, nloc),
+                     dim3(64 * TRI_LOC_WAVES), 0, st, L, ndim, params, B, live);
+  hipLaunchKernelGGL(tri_eval_arms_kernel, dim3(B, narm), dim3(256), 0, st, A, ndim,
+                     params, live);
   RVS_LAUNCH_CHECK();
   return 0;
 }

@@ -31,6 +31,7 @@ def _dev(a, dtype, device):
 TRI_BUCKET_MIN = 256
 TRI_BUCKETS = True
 TRI_WIDE_CELLS = 4096   # a simplex whose box overlaps more cells goes to the wide list
+_TRI_SHARED = {}        # device arrays of the (few) distinct triangulations in use
 
 
 def tri_buckets(transform, ndim, per_cell=8, max_n=48, max_entries=1 << 25,
@@ -152,8 +153,23 @@ class TemplateLibrary:
             # interpolation_type 'triangulation' (make_nd without --regulargrid):
             # the reference's Delaunay object, exported as arrays
             self.kind = 'triangulation'
-            self.tri_simplices = _dev(d['simplices'], torch.int32, device)
-            self.tri_transform = _dev(d['transform'], torch.float64, device)
+            # one device copy per distinct triangulation: the arms of a setup are
+            # computed on one parameter grid, and find_simplex is then done once for
+            # all of them (rvs_nm_run: arms with the same arrays share the ids)
+            import hashlib
+            tkey = (str(device), hashlib.sha1(
+                np.ascontiguousarray(d['transform']).tobytes()).hexdigest(),
+                hashlib.sha1(np.ascontiguousarray(d['simplices']).tobytes()).hexdigest())
+            shared = _TRI_SHARED.get(tkey)
+            if shared is None:
+                shared = _TRI_SHARED[tkey] = dict(
+                    simplices=_dev(d['simplices'], torch.int32, device),
+                    transform=_dev(d['transform'], torch.float64, device))
+                while len(_TRI_SHARED) > 8:
+                    _TRI_SHARED.pop(next(iter(_TRI_SHARED)))
+            self._tri_shared = shared
+            self.tri_simplices = shared['simplices']
+            self.tri_transform = shared['transform']
             self.tri_extraflags = _dev(np.asarray(d['extraflags']).reshape(-1),
                                        torch.float64, device)
             self.tri_nsimplex = int(np.asarray(d['simplices']).shape[0])
@@ -162,11 +178,15 @@ class TemplateLibrary:
             # search (tests hold one against the other)
             self._tri_bk = self._tri_keep = None
             if self.tri_nsimplex >= TRI_BUCKET_MIN and str(device) != 'cpu':
-                bk = tri_buckets(np.asarray(d['transform']), self.ndim,
-                                 wide_cells=TRI_WIDE_CELLS)
+                bkey = ('buckets', TRI_WIDE_CELLS)
+                if bkey not in shared:
+                    bk = tri_buckets(np.asarray(d['transform']), self.ndim,
+                                     wide_cells=TRI_WIDE_CELLS)
+                    shared[bkey] = (bk, _dev(bk['cell_start'], torch.int32, device),
+                                    _dev(bk['cell_list'], torch.int32, device))
+                bk = shared[bkey][0]
                 self.tri_nwide = int(bk['cell_start'][-1] - bk['cell_start'][-2])
-                self._tri_keep = (_dev(bk['cell_start'], torch.int32, device),
-                                  _dev(bk['cell_list'], torch.int32, device))
+                self._tri_keep = shared[bkey][1:]
                 t = _lib.TriBuckets()
                 t.cell_start = self._tri_keep[0].data_ptr()
                 t.cell_list = self._tri_keep[1].data_ptr()

@@ -214,7 +214,13 @@ class ProcessObjective:
                 a.extraflags = lib.tri_extraflags.data_ptr()
                 a.simplices = lib.tri_simplices.data_ptr()
                 a.templ, a.outside = b['templ'].data_ptr(), b['outside'].data_ptr()
-                a.simplex = b['sx'].data_ptr()
+                # (arms on ONE triangulation share the simplex ids: rvs_nm_run searches
+                # once for all of them)
+                first = [k for k in range(ia + 1) if self.libs[
+                    self.batch.arms[k].name].tri_transform.data_ptr() ==
+                    lib.tri_transform.data_ptr() and self.libs[
+                    self.batch.arms[k].name].log_mask == lib.log_mask][0]
+                a.simplex = self.arm_buf[first]['sx'].data_ptr()
                 a.buckets = lib._tri_bk
                 a.ntp, a.nsimplex = lib.ntp, lib.tri_nsimplex
                 a.exp_flag, a.log_mask = lib.exp_flag, lib.log_mask

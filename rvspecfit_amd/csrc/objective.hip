@@ -80,8 +80,18 @@ extern "C" int rvs_dbg_read(unsigned long long *out) {
              ? 0
              : -1;
 }
+// (no barrier: thread 0's own clock inside a phase that one wave runs)
+#define OBJ_TW(i)                                                        \
+  do {                                                                   \
+    if (threadIdx.x == 0) {                                              \
+      const unsigned long long t_ = wall_clock64();                      \
+      atomicAdd(&obj_dbg[i], t_ - t_prev);                               \
+      t_prev = t_;                                                       \
+    }                                                                    \
+  } while (0)
 #else
 #define OBJ_T(i)
+#define OBJ_TW(i)
 #endif
 
 // (Two waves: the cell search itself needs 20 threads, but a point outside the grid --
@@ -272,13 +282,16 @@ __global__ void __launch_bounds__(OBJ_NT)
   __shared__ double red_static[RED_DYN ? 1 : OBJ_NW * (NV + 1)];
   __shared__ double edge_s[2][OBJ_NW][6];   // chunk coefficients across wave boundaries
   __shared__ double coefs[P + 2];
-  __shared__ double Lm[P][P + 1];
+  __shared__ double Lm[P + 1][P + 1];   // (row P: y of L y = v)
   __shared__ double ldv[P];
+  __shared__ double dgv[P];    // the diagonal of L on its way to the wave that takes its log
+  __shared__ int dg_flag;     // 1: dgv[] is there
   __shared__ double red8[2 * OBJ_NW];
   __shared__ double jobsc[3];   // the job's Doppler scalars (obj_job_scalars)
   __shared__ int rot_s[2];      // {kmax, refused} of its rotational kernel (the record's)
   const rvs_objective_arm &T = A.a[blockIdx.y];
   const int tid = threadIdx.x;
+  if (tid == 0) dg_flag = 0;   // (many barriers ahead of its use)
   // Job of this block.  With `perm` (the jobs of the launch in the order of their
   // grid cell, objective_order_kernel) block x takes position
   //   p = f (J / 8) + min(f, J % 8) + (x >> 3),   f = x & 7:
@@ -1138,19 +1151,46 @@ __global__ void __launch_bounds__(OBJ_NT)
   // (wave 0 requests its rows behind the factorisation: 8 waves x 30 16-byte loads
   // take the CU's address pipe ~1.5 us to accept, and the chain everybody waits for
   // would start behind them)
+  // The logarithms of L's diagonal (the determinant term) are off that chain too: wave 0
+  // hands the diagonal over behind the factorisation and goes on with the back
+  // substitution, the LAST wave -- idle at the barrier below, and the one with the fewest
+  // pixels -- takes the logarithm of each element and sums them in the same order:
+  // ~0.5 us of one wave's dependent fp64 instructions that every other wave waited for.
+  // (An LDS flag, not a barrier: gfx950 has one barrier per block.  Wave 0 never waits
+  // for the last wave before it raises the flag.)
+  constexpr bool LOG_AWAY = OBJ_NW > 1;
   if (w != 0) load_qp();
+  if (LOG_AWAY && w == OBJ_NW - 1) {
+    while (__atomic_load_n(&dg_flag, __ATOMIC_RELAXED) == 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < P) ldv[lane] = log(dgv[lane]);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      double ldet = 0;
+#pragma unroll
+      for (int q = 0; q < P; q++) ldet += ldv[q];
+      coefs[P] = ldet;
+    }
+  }
   if (w == 0) {
     // Cholesky + the two triangular solves with ROW i on lane i (i < P):
     // left-looking, sums over q ascending as in the in-lane version of the
     // other chi^2 kernels, but the rows advance side by side: the serial chain
     // is P columns instead of P(P+1)/2 entries.  L is mirrored in LDS so that a
     // lane can read another row (same wave: LDS operations complete in order).
-    const int i = lane < P ? lane : P - 1;
+    // Lane P carries the right-hand side v as one more row of the matrix: what the
+    // trailing updates leave there is y of L y = v -- v_k - sum_q L_kq y_q with q
+    // ascending, times 1 / L_kk: the operations of the forward substitution that
+    // followed the factorisation until round 6, now inside it.
+    const int i = lane < P ? lane : P;
     double row[P];
 #pragma unroll
-    for (int jj = 0; jj < P; jj++) row[jj] = (jj <= i) ? red[0][TRI(i, jj)] : 0.0;
-    const double vi = red[0][NT + i];
+    for (int jj = 0; jj < P; jj++) {
+      const double m = red[0][i < P ? TRI(i, jj <= i ? jj : 0) : NT + jj];
+      row[jj] = (jj <= i) ? m : 0.0;
+    }
     bool ok = true;
+    OBJ_TW(18);   // (debug) the rows out of LDS
     // dg / rdg: this lane's diagonal element of L and its reciprocal (the
     // off-diagonal elements and both triangular solves multiply by it: one
     // division per column on the serial chain).  A value of another row is a
@@ -1192,42 +1232,47 @@ __global__ void __launch_bounds__(OBJ_NT)
       }
       const double rdj = bcast(rd, jj);
       row[jj] = (lane == jj) ? d : sum * rdj;
-      Lm[i][jj] = row[jj];  // mirror for the back-substitution (column reads)
+      Lm[i][jj] = row[jj];  // mirror for the back-substitution (column reads); row P: y
 #pragma unroll
       for (int k = jj + 1; k < P; k++) row[k] -= row[jj] * bcast(row[jj], k);  // L[k][jj]
     }
+    OBJ_TW(19);   // (debug) factorisation
     load_qp();
+    OBJ_TW(20);   // (debug) wave 0's row requests
     // log of the diagonal: all rows at once (not one per column of the loop)
-    if (lane < P) ldv[lane] = log(dg);
-    // L y = v, column by column: y_q from lane q, the rows below take their share
-    double si = vi;
-#pragma unroll
-    for (int q = 0; q < P; q++) {
-      const double yq = bcast(si * rdg, q);
-      if (i > q) si -= row[q] * yq;
-      if (lane == q) si = yq;  // keep y_q: this lane's right-hand side below
+    if (LOG_AWAY) {
+      if (lane < P) dgv[lane] = dg;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __atomic_store_n(&dg_flag, 1, __ATOMIC_RELAXED);
+    } else if (lane < P) {
+      ldv[lane] = log(dg);
     }
+    OBJ_TW(21);   // (debug) log of the diagonal
     // L^T a = y from the last row up: a_ii from lane ii, the rows above subtract
-    // L[ii][i] a_ii (column i of L out of the mirror, fetched ahead of the chain)
+    // L[ii][i] a_ii (column i of L and y_i out of the mirror, fetched ahead of the chain)
     __builtin_amdgcn_wave_barrier();
+    const int ic = lane < P ? lane : P - 1;
     double col[P];
 #pragma unroll
-    for (int ii = 0; ii < P; ii++) col[ii] = Lm[ii][i];
-    double ti = si;
+    for (int ii = 0; ii < P; ii++) col[ii] = Lm[ii][ic];
+    double ti = Lm[P][ic];
 #pragma unroll
     for (int ii = P - 1; ii >= 0; ii--) {
       const double aii = bcast(ti * rdg, ii);
       if (lane == 0) coefs[ii] = aii;
-      if (i < ii) ti -= col[ii] * aii;
+      if (ic < ii) ti -= col[ii] * aii;
     }
     const unsigned long long okm = __ballot(ok || lane >= P);
     if (lane == 0) {
-      double ldet = 0;
+      if (!LOG_AWAY) {
+        double ldet = 0;
 #pragma unroll
-      for (int q = 0; q < P; q++) ldet += ldv[q];
-      coefs[P] = ldet;
+        for (int q = 0; q < P; q++) ldet += ldv[q];
+        coefs[P] = ldet;
+      }
       coefs[P + 1] = (okm == ~0ull) ? 1.0 : 0.0;
     }
+    OBJ_TW(23);   // (debug) backward solve, determinant
   }
   __syncthreads();
   OBJ_T(5);

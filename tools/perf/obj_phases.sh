@@ -16,6 +16,13 @@ L.rvs_dbg_read.argtypes = [ctypes.c_void_p]
 L.rvs_dbg_read(ctypes.addressof(buf))
 t = np.array(buf[:10], dtype=float)
 names = ['locate', 'gather+exp', 'vsini', 'spline', 'tv+normal', 'cholesky+solve', 'resid', 'model pass', 'wave reduce', 'fold']
-print({n: round(float(v / t.sum()), 3) for n, v in zip(names, t)}, 'total ticks', t.sum())
+# (indices 18..23: wave 0 inside 'cholesky+solve', clocked without barriers)
+sub = np.array(buf[18:24], dtype=float)
+tot = t.sum() + sub.sum()
+print({n: round(float(v / tot), 3) for n, v in zip(names, t)}, 'total ticks', tot)
+print('all 24 clocks / total:', [round(float(v) / float(sum(buf[:24])), 3) for v in buf[:24]])
+print({n: round(float(v / tot), 3) for n, v in zip(
+    ['chol: rows from LDS', 'chol: factor', 'chol: row requests', 'chol: log',
+     'chol: forward', 'chol: backward+det'], sub)})
 PY
 cp /tmp/librvsgpu_orig.so rvspecfit_amd/librvsgpu.so

@@ -557,7 +557,7 @@ def main():
                     help='with --desi-file: this many copies of the file are '
                          'processed as one group (desi_fit.proc_desi_group, what '
                          'proc_many does with files_per_batch)')
-    ap.add_argument('--desi-files-per-batch', type=int, default=4,
+    ap.add_argument('--desi-files-per-batch', type=int, default=8,
                     help='with --desi-nfiles: files fitted together in one GPU '
                          'batch (proc_many files_per_batch)')
     ap.add_argument('--desi-workers', type=int, default=1,
@@ -1313,6 +1313,7 @@ def run_desi_addon(arms, args, dev, dicts):
     D.proc_desi(fname, tabf, modf, None, cfg, doplot=False, minsn=-1e9,
                 npoly=OPTIONS['npoly'], device=dev)      # warm-up
     tm = {}
+    D.FIT_TIMES.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nfiles = max(1, args.desi_nfiles)
@@ -1366,6 +1367,7 @@ def run_desi_addon(arms, args, dev, dicts):
                output_MB=round((os.path.getsize(tabf)
                                 + os.path.getsize(modf)) / 1e6, 1),
                success_frac=round(float((warn == 0).mean()), 4),
+               fit_stage_s={k: round(v, 3) for k, v in D.FIT_TIMES.items()} or None,
                second_minimizer=(not args.process_no_bfgs),
                note='add-on, not part of `value`: desi_fit.proc_desi on one '
                     'synthetic coadd file, FITS in -> RVTAB/RVMOD out')

@@ -722,6 +722,11 @@ NAME_MAPPINGS = (('logg', 'LOGG'), ('teff', 'TEFF'), ('feh', 'FEH'),
                  ('alpha', 'ALPHAFE'))
 
 
+# RVS_DESI_STAGE_TIMES=1: wall seconds of fit_batch's stages (device synchronised at
+# each boundary -- a measuring aid, tools/perf/desi_fpb.sh)
+FIT_TIMES = {}
+
+
 def fit_batch(batch, config, options, ccf_init=True):
     """The body of proc_onespec (desi_fit.py:283-354) for a SpecBatch: the
     starting point (CCF or brute-force grid), vel_fit.process, the continuum
@@ -730,6 +735,15 @@ def fit_batch(batch, config, options, ccf_init=True):
     import torch
     from .. import fitter_ccf, vel_fit, _lib
     S = batch.S
+    timed = bool(os.environ.get('RVS_DESI_STAGE_TIMES'))
+    t_last = [time.time()]
+
+    def tick(k):
+        if timed:
+            torch.cuda.synchronize()
+            now = time.time()
+            FIT_TIMES[k] = FIT_TIMES.get(k, 0.) + now - t_last[0]
+            t_last[0] = now
     names = spec_inter.getSpecParams(batch.names[0], config)
     if ccf_init:
         res = fitter_ccf.fit(batch, config)
@@ -745,6 +759,7 @@ def fit_batch(batch, config, options, ccf_init=True):
         pd0 = {k: g[k].contiguous() for k in names}
         vs0 = g['vsini']
         vrad_ccf = None
+    tick('start_point')
     has_vs = torch.isfinite(vs0)
     groups = []
     if bool(has_vs.all().item()):
@@ -772,6 +787,7 @@ def fit_batch(batch, config, options, ccf_init=True):
             p0['vsini'] = (vs0 if idx is None else vs0[idx]).contiguous()
         r = vel_fit.process(sub, p0, fixParam=[], config=config,
                             options=options)
+        tick('process')
         for k in ('vel', 'vel_err', 'vel_skewness', 'vel_kurtosis'):
             out[k][sel] = r[k].cpu().numpy()
         if 'vsini' in r and r['vsini'] is not None:
@@ -784,8 +800,10 @@ def fit_batch(batch, config, options, ccf_init=True):
             out['param_err'][k][sel] = np.asarray(r['param_err'][k])
         for ia in range(len(batch.arms)):
             yfit[ia][sel] = r['yfit'][ia].cpu().numpy()
+        tick('to_host')
     cont = spec_fit.get_chisq_continuum(batch, options=options)['chisq_array']
     out['chisq_c_array'] = cont.cpu().numpy()
+    tick('continuum')
     out['vrad_ccf'] = vrad_ccf
     out['yfit'] = yfit
     return out
@@ -1264,7 +1282,7 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
               ccf_init=True, subdirs=True, ccf_continuum_normalize=True,
               process_status_file=None, use_resolution_matrix=None, npoly=None,
               throw_exceptions=None, log_level=None, log_filename=None,
-              shard=None, files_per_batch=4):
+              shard=None, files_per_batch=8):
     """desi_fit.py:1392-1551: loop over files.  `nthreads` > 1 starts that many
     worker PROCESSES on this rank's GPU, each with its own stride of the rank's
     files (the reference's process pool, desi_fit.py:1475-1479): while one
@@ -1276,7 +1294,9 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
     the lock-step optimiser latency-bound); should the group fail, its files
     are retried one by one so that the failure lands on the file that caused
     it.  The first group is half a batch (from 4 files per batch up): its
-    preparation is the one stretch of host work that no fit runs beside.  `shard=(rank, world)` -- or the RANK/WORLD_SIZE environment of
+    preparation is the one stretch of host work that no fit runs beside.  (Eight
+    files -- 4000 fibres -- per batch since round 6: 16 files 1877 -> 1940 fibres/s
+    against four, sixteen 1812; tools/perf/desi_fpb.sh.)  `shard=(rank, world)` -- or the RANK/WORLD_SIZE environment of
     torch.distributed.run -- gives every GPU process its own stride of the file
     list; files are independent, there is no collective."""
     override = dict(ccf_continuum_normalize=ccf_continuum_normalize)

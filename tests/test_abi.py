@@ -70,7 +70,7 @@ def test_option_table(lib):
     from rvspecfit_amd import _lib
     v = ctypes.c_int(-1)
     assert lib.rvs_option_get(b'obj_inblk_max', ctypes.byref(v)) == 0
-    assert v.value == int(os.environ.get('RVS_OBJ_INBLK_MAX', 256))
+    assert v.value == int(os.environ.get('RVS_OBJ_INBLK_MAX', 768))
     for name in ('xc_ws', 'xc_ws1', 'nm_glue', 'nm_bucket', 'obj_sort', 'nn_pipe',
                  'nm_split_min', 'nm_spec_max', 'nm_tail_window'):
         assert lib.rvs_option_get(name.encode(), ctypes.byref(v)) == 0

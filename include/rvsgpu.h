@@ -685,11 +685,12 @@ int rvs_ccf_preprocess_g(const double *lam, const double *spec, const double *es
  *         pass that feed a needed 8-group).  Values are bit-identical to the
  *         unpruned transform.
  * work  complex128 [B, 2, nfft/2+1] scratch for conj rfft of spec*ivar, ivar
- * Kernels behind the call (same interface, results equal to a few ulp): in
- * continuum mode at nfft 8192 (with `prune`) and 4096, nlag and nvel <= 512, T >= 2,
- * one persistent wave-specialised block per spectrum walks the T templates
- * (ccf_xcorr_ws_kernel / _ws2_kernel, csrc/ccf_fft.hip); otherwise one block per
- * (spectrum, template).  rvs_option_set("xc_ws", 0) forces the latter.
+ * Kernels behind the call (same interface, results equal to a few ulp): at nfft
+ * 8192 (with `prune`) and 4096, nlag and nvel <= 512, T >= 2, one persistent
+ * wave-specialised block per spectrum walks the T templates (ccf_xcorr_ws_kernel /
+ * _ws2_kernel, csrc/ccf_fft.hip; without continuum normalisation it takes one of the
+ * two correlations per iteration); otherwise one block per (spectrum, template).
+ * rvs_option_set("xc_ws", 0) forces the latter.
  * ---------------------------------------------------------------------- */
 int rvs_ccf_fft_pos(int nfft, int f);  /* host helper, see lag_pos */
 int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar, int nfft,

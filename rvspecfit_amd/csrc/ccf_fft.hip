@@ -717,7 +717,14 @@ __device__ __forceinline__ void xw_pass(double2 *a, const double2 *T1, int p, in
 
 // LOG2N = 12 (nfft 8192: passes 8,8,8,8, the last two pruned / folded) or 11 (nfft
 // 4096: passes 8,8,8,4, nothing pruned).  NBAR barriers per template: 4 (12, folded) or 5.
-template <int LOG2N>
+// RATIO: the mode without continuum normalisation, -c0^2 / c1 at the lags
+// (fitter_ccf.py:204-207), is not linear in the two correlations: an iteration takes ONE
+// of them -- image 2t is F_t S*, image 2t + 1 is F2_t V* (a producer forms one product
+// per bin pair and requests half the operands), the read-back of image 2t parks c0 at
+// the lags, the read-back of 2t + 1 forms -c0^2 / c1 there (the lane that parked c0[l]
+// is the one that reads it) and only then the interpolation runs.  2 T iterations, the
+// same passes, barriers and formulas per bin as ccf_xcorr_kernel's two passes.
+template <int LOG2N, bool RATIO>
 __global__ void __launch_bounds__(XW_NT)
     ccf_xcorr_ws_kernel(const double2 *__restrict__ work,
                         const double2 *__restrict__ tfft,
@@ -739,6 +746,8 @@ __global__ void __launch_bounds__(XW_NT)
   double *c0 = reinterpret_cast<double *>(fa + 2 * n2 + XC_NTW(n2));  // [nlag]
   // pass 1's 64 twiddles and the folded pass's 8, side by side (xw_pass)
   double2 *T1c = fa + 2 * n2 + XC_NTW(n2) + ((nlag + 1) >> 1);   // [64 + 8]
+  double *cA = reinterpret_cast<double *>(T1c + 73);   // RATIO: c0 at the lags [nlag]
+  const int TI = RATIO ? 2 * T : T;   // image iterations
   const int b = blockIdx.x, tid = threadIdx.x;
   const bool producer = tid >= XW_HALF;
   const int pt = tid & (XW_HALF - 1);
@@ -777,29 +786,43 @@ __global__ void __launch_bounds__(XW_NT)
         (void *)tw, 0, (npair + 1) * 16, 0x00020000);
     double2 op[2][5];   // the batch in flight / the batch being consumed
     auto issue = [&](int t, int u, double2 *o) {
+      const int tt = RATIO ? (t >> 1) : t;
       const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)(tfft + (int64_t)t * (n2 + 1)), 0, nbytes, 0x00020000);
+          (void *)(((RATIO && (t & 1)) ? tfft2 : tfft) + (int64_t)tt * (n2 + 1)), 0,
+          nbytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t rF2 = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)(tfft2 + (int64_t)t * (n2 + 1)), 0, nbytes, 0x00020000);
+          (void *)(tfft2 + (int64_t)tt * (n2 + 1)), 0, nbytes, 0x00020000);
       // (the lane's bin offsets are re-derived at every use: kept live across the
       // template loop they are the registers that spill)
       int ptv = pt;
       asm volatile("" : "+v"(ptv));
       const int k = 1 + ptv + u * XW_HALF;
       const int ok = k * 16, om = (n2 - k) * 16;
-      o[0] = ld(rF, ok), o[1] = ld(rF2, ok);
-      o[2] = ld(rF, om), o[3] = ld(rF2, om);
+      if (RATIO) {   // (one of the two products: F or F2 through rF)
+        o[0] = ld(rF, ok);
+        o[2] = ld(rF, om);
+      } else {
+        o[0] = ld(rF, ok), o[1] = ld(rF2, ok);
+        o[2] = ld(rF, om), o[3] = ld(rF2, om);
+      }
       o[4] = ld(rT, ok);
     };
     double2 dc[4];   // F[0], F2[0], F[n2], F2[n2] of the template being formed (scalar)
-    auto form = [&](double2 *dst, int u, const double2 *o) {
+    auto form = [&](double2 *dst, int u, const double2 *o, int tcur) {
       int ptv = pt;
       asm volatile("" : "+v"(ptv));
       const int k = 1 + ptv + u * XW_HALF, m = n2 - k;
-      const double2 p1 = cmul(o[0], Sk[u]), p2 = cmul(o[1], Vk[u]);
-      const double2 Xk = make_double2(p2.x - 2 * p1.x, p2.y - 2 * p1.y);
-      const double2 q1 = cmul(o[2], Sm[u]), q2 = cmul(o[3], Vm[u]);
-      const double2 Xm = make_double2(q2.x - 2 * q1.x, q2.y - 2 * q1.y);
+      double2 Xk, Xm;
+      if (RATIO) {
+        const bool second = (tcur & 1) != 0;
+        Xk = cmul(o[0], second ? Vk[u] : Sk[u]);
+        Xm = cmul(o[2], second ? Vm[u] : Sm[u]);
+      } else {
+        const double2 p1 = cmul(o[0], Sk[u]), p2 = cmul(o[1], Vk[u]);
+        Xk = make_double2(p2.x - 2 * p1.x, p2.y - 2 * p1.y);
+        const double2 q1 = cmul(o[2], Sm[u]), q2 = cmul(o[3], Vm[u]);
+        Xm = make_double2(q2.x - 2 * q1.x, q2.y - 2 * q1.y);
+      }
       const double2 e = make_double2(Xk.x + Xm.x, Xk.y - Xm.y);
       const double2 d = make_double2(Xk.x - Xm.x, Xk.y + Xm.y);
       const double2 q = cmul(o[4], d);
@@ -808,9 +831,16 @@ __global__ void __launch_bounds__(XW_NT)
       if (u == NPP - 1 && ptv == 0) {
         // the DC / Nyquist pair: wave-uniform addresses (scalar loads, requested in the
         // template's first interval), formed with its last batch by one lane
-        const double2 a1 = cmul(dc[0], Sc[0]), a2 = cmul(dc[1], Vc[0]);
-        const double2 b1 = cmul(dc[2], Sc[n2]), b2 = cmul(dc[3], Vc[n2]);
-        const double xk = a2.x - 2 * a1.x, xm = b2.x - 2 * b1.x;
+        double xk, xm;
+        if (RATIO) {
+          const bool second = (tcur & 1) != 0;
+          xk = cmul(second ? dc[1] : dc[0], second ? Vc[0] : Sc[0]).x;
+          xm = cmul(second ? dc[3] : dc[2], second ? Vc[n2] : Sc[n2]).x;
+        } else {
+          const double2 a1 = cmul(dc[0], Sc[0]), a2 = cmul(dc[1], Vc[0]);
+          const double2 b1 = cmul(dc[2], Sc[n2]), b2 = cmul(dc[3], Vc[n2]);
+          xk = a2.x - 2 * a1.x, xm = b2.x - 2 * b1.x;
+        }
         // numpy irfft ignores the imaginary parts of the DC and Nyquist bins
         dst[0] = make_double2(xk + xm, xk - xm);
       }
@@ -818,13 +848,14 @@ __global__ void __launch_bounds__(XW_NT)
     const int nbar = (P12 && fold) ? 4 : 5;
     issue(0, 0, op[0]);
     if (NPP == 2) issue(0, 1, op[1]);
-    for (int it = -1; it < T; it++) {
-      const int tn = it + 1;   // the template this iteration forms
-      if (tn < T) {
+    for (int it = -1; it < TI; it++) {
+      const int tn = it + 1;   // the image this iteration forms
+      if (tn < TI) {
         double2 *dst = img(tn);
         {
-          const double2 *Fp = tfft + (int64_t)tn * (n2 + 1);
-          const double2 *F2p = tfft2 + (int64_t)tn * (n2 + 1);
+          const int tt = RATIO ? (tn >> 1) : tn;
+          const double2 *Fp = tfft + (int64_t)tt * (n2 + 1);
+          const double2 *F2p = tfft2 + (int64_t)tt * (n2 + 1);
           dc[0] = Fp[0], dc[1] = F2p[0], dc[2] = Fp[n2], dc[3] = F2p[n2];
         }
         if (NPP == 2) {
@@ -833,8 +864,8 @@ __global__ void __launch_bounds__(XW_NT)
           // (five intervals) ahead
 #pragma unroll
           for (int u = 0; u < 2; u++) {
-            form(dst, u, op[u]);
-            if (tn + 1 < T) issue(tn + 1, u, op[u]);
+            form(dst, u, op[u], tn);
+            if (tn + 1 < TI) issue(tn + 1, u, op[u]);
             __syncthreads();
           }
         } else {
@@ -844,9 +875,9 @@ __global__ void __launch_bounds__(XW_NT)
           for (int u = 0; u < NPP; u++) {
             if (u + 1 < NPP)
               issue(tn, u + 1, op[(u + 1) & 1]);
-            else if (tn + 1 < T)
+            else if (tn + 1 < TI)
               issue(tn + 1, 0, op[(u + 1) & 1]);
-            form(dst, u, op[u & 1]);
+            form(dst, u, op[u & 1], tn);
             __syncthreads();
           }
         }
@@ -863,14 +894,14 @@ __global__ void __launch_bounds__(XW_NT)
   const int pre_lo = ilo[tvx];
   const double pre_xg = vgrid[tvx];
   const double pre_x0 = lag_vel[pre_lo], pre_x1 = lag_vel[pre_lo + 1];
-  for (int it = -1; it < T; it++) {
+  for (int it = -1; it < TI; it++) {
     if (it < 0) {
       const int nbar = (P12 && fold) ? 4 : 5;
       for (int q = 0; q < nbar; q++) __syncthreads();
       continue;
     }
     double2 *a = img(it);
-    double *out = chisq + ((int64_t)b * T + it) * nvel;
+    double *out = chisq + ((int64_t)b * T + (RATIO ? (it >> 1) : it)) * nvel;
     double pre_old = 0;
     if (beta != 0.0) pre_old = out[tvx];
     if (pt < (n2 >> 3)) xw_pass<1, LOG2N>(a, T1, 0, pt);
@@ -959,9 +990,19 @@ __global__ void __launch_bounds__(XW_NT)
       }
       __syncthreads();
     }
-    if (pt < nlag) c0[pt] = reinterpret_cast<const double *>(a)[pre_pos] * inv_n;
+    if (RATIO) {
+      if (pt < nlag) {
+        const double c = reinterpret_cast<const double *>(a)[pre_pos] * inv_n;
+        if (it & 1)
+          c0[pt] = -cA[pt] * cA[pt] / c;
+        else
+          cA[pt] = c;
+      }
+    } else if (pt < nlag) {
+      c0[pt] = reinterpret_cast<const double *>(a)[pre_pos] * inv_n;
+    }
     __syncthreads();
-    if (pt < nvel) {
+    if ((!RATIO || (it & 1)) && pt < nvel) {
       const double sl = (c0[pre_lo + 1] - c0[pre_lo]) / (pre_x1 - pre_x0);
       const double val = sl * (pre_xg - pre_x0) + c0[pre_lo];
       out[pt] = (beta != 0.0) ? beta * pre_old + val : val;
@@ -1167,14 +1208,19 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
     // the wave-specialised persistent form (one block per spectrum), where it applies
     const bool ws_on = rvs_opt(RVS_OPT_XC_WS) != 0;   // xc_ws = 0: the per-pair kernel
     const bool p12 = (nfft == 8192 && prune), p11 = (nfft == 4096);
-    if (ws_on && continuum && (p12 || p11) &&
-        nlag <= XW_HALF && nvel <= XW_HALF && T >= 2) {
+    if (ws_on && (p12 || p11) && nlag <= XW_HALF && nvel <= XW_HALF && T >= 2) {
       static bool ws_attr = false;
       if (!ws_attr) {
-        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel<12>,
+        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel<12, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   159 * 1024);
-        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel<11>,
+        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel<11, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  159 * 1024);
+        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel<12, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  159 * 1024);
+        (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws_kernel<11, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   159 * 1024);
         (void)hipFuncSetAttribute((const void *)ccf_xcorr_ws2_kernel,
@@ -1185,16 +1231,33 @@ extern "C" int rvs_ccf_xcorr(const double *proc_spec, const double *proc_ivar,
       }
       const size_t shmw = sizeof(double2) * (size_t)(2 * n2 + XC_NTW(n2)) +
                           sizeof(double) * (size_t)nlag +
-                          sizeof(double2) * (72 + 1);   // (+ pass 1's twiddles: T1c)
+                          sizeof(double2) * (72 + 1) +   // (+ pass 1's twiddles: T1c)
+                          (continuum ? 0 : sizeof(double) * (size_t)nlag);   // (cA)
+#define RVS_XW_ARGS                                                                 \
+  reinterpret_cast<const double2 *>(work), reinterpret_cast<const double2 *>(tfft),  \
+      reinterpret_cast<const double2 *>(tfft2), T, tw, lag_pos, lag_vel, nlag, ilo,  \
+      vgrid, nvel, beta, prune, chisq
+      if (!continuum) {
+        // -c0^2 / c1: one correlation per iteration (the two-templates-per-iteration
+        // form of nfft 4096 pairs TEMPLATES, so 4096 takes the one-image form here)
+        if (p12)
+          hipLaunchKernelGGL((ccf_xcorr_ws_kernel<12, true>), dim3(B), dim3(XW_NT), shmw,
+                             st, RVS_XW_ARGS);
+        else
+          hipLaunchKernelGGL((ccf_xcorr_ws_kernel<11, true>), dim3(B), dim3(XW_NT), shmw,
+                             st, RVS_XW_ARGS);
+        RVS_LAUNCH_CHECK();
+        return 0;
+      }
       if (p12)
-        hipLaunchKernelGGL(ccf_xcorr_ws_kernel<12>, dim3(B), dim3(XW_NT), shmw, st,
+        hipLaunchKernelGGL((ccf_xcorr_ws_kernel<12, false>), dim3(B), dim3(XW_NT), shmw, st,
                            reinterpret_cast<const double2 *>(work),
                            reinterpret_cast<const double2 *>(tfft),
                            reinterpret_cast<const double2 *>(tfft2), T, tw, lag_pos,
                            lag_vel, nlag, ilo, vgrid, nvel, beta, prune, chisq);
       else if (rvs_opt(RVS_OPT_XC_WS1))   // (one template per iteration: measured 1.10
                                           // ms per 1000 spectra against 0.84; per pair 1.34)
-        hipLaunchKernelGGL(ccf_xcorr_ws_kernel<11>, dim3(B), dim3(XW_NT), shmw, st,
+        hipLaunchKernelGGL((ccf_xcorr_ws_kernel<11, false>), dim3(B), dim3(XW_NT), shmw, st,
                            reinterpret_cast<const double2 *>(work),
                            reinterpret_cast<const double2 *>(tfft),
                            reinterpret_cast<const double2 *>(tfft2), T, tw, lag_pos,

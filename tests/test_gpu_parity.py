@@ -2524,10 +2524,11 @@ def test_xcorr_large_template_set_job_map(gpu):
         _xcorr_vs_numpy(8192, 1, 5, 140)
 
 
+@pytest.mark.parametrize('continuum', [1, 0])
 @pytest.mark.parametrize('nfft,B,T', [(8192, 3, 5), (8192, 5, 140), (8192, 2, 2),
                                       (8192, 1, 77), (4096, 2, 2), (4096, 3, 76),
                                       (4096, 1, 3), (4096, 2, 141)])
-def test_xcorr_wave_specialised_equals_per_pair(gpu, nfft, B, T):
+def test_xcorr_wave_specialised_equals_per_pair(gpu, nfft, B, T, continuum):
     """ccf_xcorr_ws_kernel (one persistent block per spectrum: producer waves
     keep S*, V* in registers and stream the templates into one LDS image while
     consumer waves transform the other) against ccf_xcorr_kernel (one block per
@@ -2536,10 +2537,13 @@ def test_xcorr_wave_specialised_equals_per_pair(gpu, nfft, B, T):
     takes two templates per iteration.  Same formulas bin by bin and butterfly
     by butterfly; the two kernels are compiled separately, so which product of a
     complex multiplication the compiler fuses into an fma may differ: equal to a
-    few ulp of the largest term, not bit for bit."""
-    got_ws = _xcorr_vs_numpy(nfft, 1, B, T)
+    few ulp of the largest term, not bit for bit.  continuum = 0: the mode without
+    continuum normalisation, -c0^2 / c1 at the lags (fitter_ccf.py:204-207) -- one
+    correlation per iteration of the persistent block (round 6; the per-pair kernel's
+    two passes before)."""
+    got_ws = _xcorr_vs_numpy(nfft, continuum, B, T)
     with _lib.option('xc_ws', 0):
-        got_pp = _xcorr_vs_numpy(nfft, 1, B, T)
+        got_pp = _xcorr_vs_numpy(nfft, continuum, B, T)
     np.testing.assert_allclose(got_ws, got_pp, rtol=1e-12,
                                atol=1e-12 * np.abs(got_pp).max())
 

@@ -17,9 +17,11 @@ What is restated here (reference lines in each docstring):
   get_column_desc, get_prim_header,
   proc_onespec, proc_desi, proc_desi_wrapper, proc_many
                                     the RVTAB / RVMOD schema and files
+  main                              the command line, with the reference's option names
 
 File I/O goes through fits_min (astropy is not part of the image).  Outside
-the path and not built: the argparse front end (`main`), plots (`make_plot`;
+the path and not built: the file queues behind --mpi / --queue_file (one process
+drives one GPU; ranks of torch.distributed.run shard the file list), plots (`make_plot`;
 doplot is accepted and ignored with a warning), the desitarget object-type
 filter (the reference ignores `objtypes` itself when desitarget is missing,
 desi_fit.py:584-587, 617-623 -- so does this module, always).
@@ -1573,3 +1575,179 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
                 fpool.shutdown()
             wpool.shutdown()
     logging.info('Successfully finished processing')
+
+
+# ---------------------------------------------------------------------------
+# Command line (desi_fit.py:1554-1901, `rvs_desi_fit`): the reference's option names
+# with their meaning, so that a survey's job scripts run unchanged --
+#   python -m rvspecfit_amd.desi.desi_fit --config config.yaml --output_dir out coadd-*.fits
+# What differs, by design: one process drives one GPU (start one process per GPU with
+# torch.distributed.run: every rank takes its own stride of the file list, proc_many's
+# `shard`), so --mpi and --queue_file -- the reference's two ways of dealing files to
+# CPU workers -- are refused with that pointer; --doplot is accepted and ignored.
+# ---------------------------------------------------------------------------
+_CLI_OPTIONS = (
+    # (flags, keyword arguments of add_argument)
+    (('input_files', ), dict(nargs='*', default=None, type=str,
+                             help='spectra / coadd files to fit')),
+    (('--input_file_from', ), dict(type=str, default=None,
+                                   help='text file with one input file per line')),
+    (('--queue_file', ), dict(action='store_true', default=False,
+                              help='not supported here (see --mpi)')),
+    (('--mpi', ), dict(action='store_true', default=False,
+                       help='not supported: start one process per GPU with '
+                            'torch.distributed.run instead')),
+    (('--nthreads', ), dict(type=int, default=1,
+                            help='worker processes sharing this GPU')),
+    (('--config', ), dict(type=str, default=None, help='configuration yaml')),
+    (('--output_dir', ), dict(type=str, default='./', help='where the products go')),
+    (('--output_tab_prefix', ), dict(type=str, default='rvtab',
+                                     help='file name prefix of the tables')),
+    (('--output_mod_prefix', ), dict(type=str, default='rvmod',
+                                     help='file name prefix of the model spectra')),
+    (('--targetid', ), dict(type=int, default=None, help='fit this TARGETID only')),
+    (('--targetid_file_from', ), dict(type=str, default=None,
+                                      help='text file of TARGETIDs to fit')),
+    (('--minsn', ), dict(type=float, default=-1e9,
+                         help='lowest median S/N (any arm) of a fibre to fit')),
+    (('--minexpid', ), dict(type=int, default=None, help='lowest EXPID to fit')),
+    (('--maxexpid', ), dict(type=int, default=None, help='highest EXPID to fit')),
+    (('--npoly', ), dict(type=int, default=None,
+                         help='continuum terms per arm (default 10)')),
+    (('--fitarm', ), dict(type=str, default=None,
+                          help='arms to fit, comma separated out of b,r,z')),
+    (('--figure_dir', ), dict(type=str, default='./', help='(plots are not produced)')),
+    (('--figure_prefix', ), dict(type=str, default='fig',
+                                 help='(plots are not produced)')),
+    (('--log', ), dict(type=str, default=None, help='log file')),
+    (('--log_level', ), dict(type=str, default='WARNING',
+                             help='DEBUG / INFO / WARNING / ERROR')),
+    (('--param_init', ), dict(type=str, default='CCF',
+                              help='starting point: CCF or bruteforce')),
+    (('--process_status_file', ), dict(type=str, default=None,
+                                       help='one status line per processed file')),
+    (('--resolution_matrix', ), dict(dest='resolution_matrix', action='store_true',
+                                     default=False,
+                                     help='fit through the DESI resolution matrices')),
+    (('--no-resolution_matrix', ), dict(dest='resolution_matrix',
+                                        action='store_false',
+                                        help='Gaussian line-spread function of the '
+                                             'templates (default)')),
+    (('--overwrite', ), dict(default=None, help='(has no meaning any more)')),
+    (('--version', ), dict(action='store_true', default=False,
+                           help='print the version and leave')),
+    (('--skipexisting', ), dict(action='store_true', default=False,
+                                help='skip files whose products exist')),
+    (('--zbest_select', ), dict(action='store_true', default=False,
+                                help='select the fibres to fit by their redrock classification')),
+    (('--zbest_include', ), dict(action='store_true', default=False,
+                                 help='copy the redrock columns into the table')),
+    (('--doplot', ), dict(action='store_true', default=False,
+                          help='accepted, ignored: this build makes no plots')),
+    (('--no_ccf_continuum_normalize', ), dict(dest='ccf_continuum_normalize',
+                                              action='store_false', default=True,
+                                              help='cross-correlate without '
+                                                   'continuum normalisation')),
+    (('--no_subdirs', ), dict(dest='subdirs', action='store_false', default=True,
+                              help='no sub-directories below --output_dir')),
+    (('--throw_exceptions', ), dict(action='store_true', default=False,
+                                    help='let a failing file stop the run')),
+    (('--objtypes', ), dict(type=str, default=None,
+                            help='comma separated target classes (needs desitarget; '
+                                 'ignored without it, as in the reference)')),
+    # (not in the reference)
+    (('--files_per_batch', ), dict(type=int, default=8,
+                                   help='files fitted together in one GPU batch')),
+)
+
+
+def _cli_parser():
+    import argparse
+    parser = argparse.ArgumentParser(
+        prog='rvs_desi_fit',
+        description='Radial velocities and stellar parameters of DESI spectra, '
+                    'one GPU batch per group of files')
+    for flags, kw in _CLI_OPTIONS:
+        parser.add_argument(*flags, **kw)
+    return parser
+
+
+def _cli_logging(level, fname):
+    lev = getattr(logging, str(level).upper(), None)
+    if not isinstance(lev, int):
+        raise ValueError('unknown log level %s' % level)
+    kw = dict(level=lev, format='%(asctime)s - %(levelname)s - %(message)s',
+              force=True)
+    if fname is not None:
+        kw['filename'] = fname
+    logging.basicConfig(**kw)
+
+
+def main(args=None):
+    """desi_fit.main (desi_fit.py:1554-1901): parse the reference's options and run
+    proc_many.  Returns nothing; argument errors raise what the reference raises
+    (RuntimeError for contradictory inputs, ValueError for unknown arm names or
+    --param_init values)."""
+    argv = sys.argv[1:] if args is None else list(args)
+    cmdline = ' '.join(argv)
+    parser = _cli_parser()
+    a = parser.parse_args(argv)
+    if a.version:
+        from .. import __version__ as ver
+        print(ver)
+        sys.exit(0)
+    if a.mpi or a.queue_file:
+        raise RuntimeError(
+            '--mpi / --queue_file deal files to CPU workers; here one process drives '
+            'one GPU: start one per GPU with `python -m torch.distributed.run '
+            '--nproc-per-node N -m rvspecfit_amd.desi.desi_fit ...` (every rank fits '
+            'its own stride of the file list)')
+    _cli_logging(a.log_level, a.log)
+    fitarm = None
+    if a.fitarm is not None:
+        fitarm = [x.lower() for x in a.fitarm.split(',')]
+        if any(x not in ('b', 'r', 'z') for x in fitarm):
+            raise ValueError('only allowed arm names are brz')
+    if a.param_init not in ('CCF', 'bruteforce'):
+        raise ValueError('Unknown param_init value; only known ones are CCF and '
+                         'bruteforce')
+    if a.targetid_file_from is not None and a.targetid is not None:
+        raise RuntimeError('You can only specify targetid or targetid_file_from '
+                           'options')
+    fit_targetid = None
+    if a.targetid_file_from is not None:
+        with open(a.targetid_file_from) as fp:
+            fit_targetid = np.unique([int(line) for line in fp if line.strip()])
+    elif a.targetid is not None:
+        fit_targetid = np.unique([a.targetid])
+    files = list(a.input_files or [])
+    if files and a.input_file_from is not None:
+        raise RuntimeError('You can only specify --input_files OR --input_file_from '
+                           'options but not both of them simultaneously')
+    if not files and a.input_file_from is None:
+        parser.print_help()
+        raise RuntimeError('You need to specify the spectra you want to fit')
+    if not files:
+        with open(a.input_file_from) as fp:
+            files = [line.rstrip() for line in fp if line.strip()]
+    if a.overwrite is not None:
+        logging.warning('overwrite keyword is meaningless now')
+    proc_many(files, a.output_dir, a.output_tab_prefix, a.output_mod_prefix,
+              figure_dir=a.figure_dir if a.doplot else None,
+              figure_prefix=a.figure_prefix, nthreads=a.nthreads,
+              config_fname=a.config, fit_targetid=fit_targetid,
+              objtypes=None if a.objtypes is None else a.objtypes.split(','),
+              doplot=a.doplot, subdirs=a.subdirs, minsn=a.minsn,
+              process_status_file=a.process_status_file,
+              expid_range=(a.minexpid, a.maxexpid), skipexisting=a.skipexisting,
+              fitarm=fitarm, cmdline=cmdline, zbest_select=a.zbest_select,
+              zbest_include=a.zbest_include,
+              ccf_continuum_normalize=a.ccf_continuum_normalize,
+              use_resolution_matrix=a.resolution_matrix,
+              ccf_init=(a.param_init == 'CCF'), npoly=a.npoly,
+              throw_exceptions=a.throw_exceptions, log_level=a.log_level,
+              log_filename=a.log, files_per_batch=max(1, a.files_per_batch))
+
+
+if __name__ == '__main__':
+    main()

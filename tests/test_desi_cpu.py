@@ -475,3 +475,39 @@ def test_select_expid_range_and_id_matched_redshifts(coadd, tmp_path):
     assert np.array_equal(np.nonzero(sub)[0], [0, 1, 8, 9, 12])
     assert np.isnan(rz[2]) and rs[2] == '' and rz[9] == rr0['Z'][9]
     assert rs[3] == 'GALAXY' and rsub[0] == 'K'
+
+
+def test_command_line_arguments():
+    """desi_fit.main's front end (desi_fit.py:1554-1901): the reference's option
+    names, defaults and argument errors; nothing is fitted (no GPU)"""
+    from rvspecfit_amd.desi import desi_fit as D
+    a = D._cli_parser().parse_args(['x.fits', 'y.fits'])
+    assert a.input_files == ['x.fits', 'y.fits'] and a.input_file_from is None
+    assert (a.nthreads, a.output_dir, a.output_tab_prefix, a.output_mod_prefix) == \
+        (1, './', 'rvtab', 'rvmod')
+    assert a.minsn == -1e9 and a.npoly is None and a.fitarm is None
+    assert a.param_init == 'CCF' and a.resolution_matrix is False
+    assert a.ccf_continuum_normalize is True and a.subdirs is True
+    assert not (a.skipexisting or a.zbest_select or a.zbest_include or a.doplot
+                or a.throw_exceptions or a.mpi or a.queue_file)
+    b = D._cli_parser().parse_args(['x.fits', '--resolution_matrix',
+                                    '--no_ccf_continuum_normalize', '--no_subdirs',
+                                    '--minexpid', '3', '--maxexpid', '9'])
+    assert b.resolution_matrix and not b.ccf_continuum_normalize and not b.subdirs
+    assert (b.minexpid, b.maxexpid) == (3, 9)
+    assert not D._cli_parser().parse_args(
+        ['x.fits', '--resolution_matrix', '--no-resolution_matrix']).resolution_matrix
+    with pytest.raises(RuntimeError, match='specify the spectra'):
+        D.main([])
+    with pytest.raises(RuntimeError, match='not both'):
+        D.main(['x.fits', '--input_file_from', 'list.txt'])
+    with pytest.raises(RuntimeError, match='targetid or targetid_file_from'):
+        D.main(['x.fits', '--targetid', '5', '--targetid_file_from', 'ids.txt'])
+    with pytest.raises(ValueError, match='arm names'):
+        D.main(['x.fits', '--fitarm', 'b,q'])
+    with pytest.raises(ValueError, match='param_init'):
+        D.main(['x.fits', '--param_init', 'guess'])
+    with pytest.raises(RuntimeError, match='torch.distributed.run'):
+        D.main(['x.fits', '--mpi'])
+    with pytest.raises(SystemExit):
+        D.main(['--version'])

@@ -300,6 +300,52 @@ def test_grouped_files_equal_single(dcases, desi_libs, tmp_path):
     assert np.array_equal(tm['VRAD'], ts['VRAD'])
 
 
+def test_command_line_runs_the_file_loop(dcases, desi_libs, tmp_path):
+    """desi_fit.main (desi_fit.py:1554-1901) with the reference's option names: two
+    files from --input_file_from, the products of proc_desi on the file alone, the
+    command line in the headers' RVS_CMD, the status file"""
+    import yaml
+    from rvspecfit_amd import fits_min as F
+    from rvspecfit_amd.desi import desi_fit as D
+    single = (str(tmp_path / 's_tab.fits'), str(tmp_path / 's_mod.fits'))
+    n1 = D.proc_desi(COADD, single[0], single[1], None, CFG, doplot=False, minsn=2,
+                     zbest_include=True, fitarm=['b', 'r'], npoly=8)
+    ts = F.open(single[0])['RVTAB'].data
+    cfgf = str(tmp_path / 'c.yaml')
+    with open(cfgf, 'w') as fp:
+        yaml.safe_dump({k: v for k, v in CFG.items()
+                        if k != 'config_file_path'}, fp)
+    links = []
+    for i in range(2):
+        links.append(str(tmp_path / ('coadd-m%d.fits' % i)))
+        os.symlink(COADD, links[-1])
+        os.symlink(os.path.join(GOLD, 'redrock-golden.fits'),
+                   str(tmp_path / ('redrock-m%d.fits' % i)))
+    lst = str(tmp_path / 'files.txt')
+    with open(lst, 'w') as fp:
+        fp.write('\n'.join(links) + '\n')
+    st = str(tmp_path / 'status')
+    argv = ['--config', cfgf, '--input_file_from', lst, '--output_dir',
+            str(tmp_path / 'out'), '--minsn', '2', '--zbest_include', '--no_subdirs',
+            '--fitarm', 'B,R', '--npoly', '8', '--process_status_file', st,
+            '--output_tab_prefix', 'tab', '--output_mod_prefix', 'mod',
+            '--log_level', 'ERROR', '--files_per_batch', '2']
+    D.main(argv)
+    rows = [l.split() for l in open(st).read().strip().split('\n')]
+    assert sorted(r[0] for r in rows) == sorted(links)
+    assert all(r[1] == 'SUCCESS' and int(r[2]) == n1 for r in rows), rows
+    for i in range(2):
+        hd = F.open(str(tmp_path / 'out' / ('tab_coadd-m%d.fits' % i)))
+        tg = hd['RVTAB'].data
+        assert tg.columns.names == ts.columns.names
+        for c in ts.columns.names:
+            a, b = ts[c], tg[c]
+            assert np.array_equal(a, b) if a.dtype.kind in 'SUb' else \
+                np.array_equal(a, b, equal_nan=True), c
+        assert hd[0].header['RVS_CMD'] == ' '.join(argv)
+        assert os.path.exists(str(tmp_path / 'out' / ('mod_coadd-m%d.fits' % i)))
+
+
 def test_proc_many_two_fit_threads(dcases, desi_libs, tmp_path, monkeypatch):
     """RVS_DESI_FIT_THREADS=2: two groups of files fitted side by side by two threads
     -- every product is the one of the file processed alone, bit for bit, and every

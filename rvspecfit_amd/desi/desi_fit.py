@@ -20,8 +20,8 @@ What is restated here (reference lines in each docstring):
   main                              the command line, with the reference's option names
 
 File I/O goes through fits_min (astropy is not part of the image).  Outside
-the path and not built: the file queues behind --mpi / --queue_file (one process
-drives one GPU; ranks of torch.distributed.run shard the file list), plots (`make_plot`;
+the path and not built: the MPI file server behind --mpi (one process drives one
+GPU; ranks of torch.distributed.run stride the file list or share a queue file), plots (`make_plot`;
 doplot is accepted and ignored with a warning), the desitarget object-type
 filter (the reference ignores `objtypes` itself when desitarget is missing,
 desi_fit.py:584-587, 617-623 -- so does this module, always).
@@ -1322,12 +1322,14 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
                                    start=True)
     if workers:
         import multiprocessing
-        mine = list(files)[rank::world]
+        shared = getattr(files, 'shared', False)
+        mine = None if shared else list(files)[rank::world]
         ctx = multiprocessing.get_context('spawn')
         procs = []
         for w in range(nthreads):
-            sub = mine[w::nthreads]
-            if not sub:
+            # (a shared queue file: every worker takes its files from it)
+            sub = files if shared else mine[w::nthreads]
+            if not shared and not sub:
                 continue
             kwa = dict(
                 figure_dir=figure_dir, figure_prefix=figure_prefix,
@@ -1532,7 +1534,9 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
                      for pre in (output_tab_prefix, output_mod_prefix))
 
     try:
-        for f in list(files)[rank::world]:
+        # (a shared queue file deals the files itself: utils.FileQueue)
+        shared = getattr(files, 'shared', False)
+        for f in (files if shared else list(files)[rank::world]):
             names = product_names(f)
             if names is None:
                 logging.warning('Invalid file %s: with subdirs it has to be '
@@ -1583,8 +1587,9 @@ def proc_many(files, output_dir, output_tab_prefix, output_mod_prefix,
 #   python -m rvspecfit_amd.desi.desi_fit --config config.yaml --output_dir out coadd-*.fits
 # What differs, by design: one process drives one GPU (start one process per GPU with
 # torch.distributed.run: every rank takes its own stride of the file list, proc_many's
-# `shard`), so --mpi and --queue_file -- the reference's two ways of dealing files to
-# CPU workers -- are refused with that pointer; --doplot is accepted and ignored.
+# `shard`, or -- with --queue_file -- its files from the head of the shared queue file,
+# utils.FileQueue), so --mpi, the reference's server thread that deals files to CPU
+# ranks, is refused with that pointer; --doplot is accepted and ignored.
 # ---------------------------------------------------------------------------
 _CLI_OPTIONS = (
     # (flags, keyword arguments of add_argument)
@@ -1593,7 +1598,8 @@ _CLI_OPTIONS = (
     (('--input_file_from', ), dict(type=str, default=None,
                                    help='text file with one input file per line')),
     (('--queue_file', ), dict(action='store_true', default=False,
-                              help='not supported here (see --mpi)')),
+                              help='--input_file_from is a queue shared by several '
+                                   'processes: each takes its files from its head')),
     (('--mpi', ), dict(action='store_true', default=False,
                        help='not supported: start one process per GPU with '
                             'torch.distributed.run instead')),
@@ -1696,12 +1702,15 @@ def main(args=None):
         from .. import __version__ as ver
         print(ver)
         sys.exit(0)
-    if a.mpi or a.queue_file:
+    if a.mpi:
         raise RuntimeError(
-            '--mpi / --queue_file deal files to CPU workers; here one process drives '
-            'one GPU: start one per GPU with `python -m torch.distributed.run '
-            '--nproc-per-node N -m rvspecfit_amd.desi.desi_fit ...` (every rank fits '
-            'its own stride of the file list)')
+            '--mpi deals files to CPU ranks through a server thread; here one process '
+            'drives one GPU: start one per GPU with `python -m torch.distributed.run '
+            '--nproc-per-node N -m rvspecfit_amd.desi.desi_fit ...` -- every rank fits '
+            'its own stride of the file list, or, with --queue_file --input_file_from, '
+            'takes its files from the shared queue file')
+    if a.queue_file and a.input_file_from is None:
+        raise RuntimeError('--queue_file needs --input_file_from (the queue)')
     _cli_logging(a.log_level, a.log)
     fitarm = None
     if a.fitarm is not None:
@@ -1728,8 +1737,7 @@ def main(args=None):
         parser.print_help()
         raise RuntimeError('You need to specify the spectra you want to fit')
     if not files:
-        with open(a.input_file_from) as fp:
-            files = [line.rstrip() for line in fp if line.strip()]
+        files = utils.FileQueue(file_from=a.input_file_from, queue=a.queue_file)
     if a.overwrite is not None:
         logging.warning('overwrite keyword is meaningless now')
     proc_many(files, a.output_dir, a.output_tab_prefix, a.output_mod_prefix,

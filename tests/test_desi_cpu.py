@@ -509,5 +509,42 @@ def test_command_line_arguments():
         D.main(['x.fits', '--param_init', 'guess'])
     with pytest.raises(RuntimeError, match='torch.distributed.run'):
         D.main(['x.fits', '--mpi'])
+    with pytest.raises(RuntimeError, match='needs --input_file_from'):
+        D.main(['x.fits', '--queue_file'])
     with pytest.raises(SystemExit):
         D.main(['--version'])
+
+
+def _take_all(path, out):
+    from rvspecfit_amd import utils
+    out.put(list(utils.FileQueue(file_from=path, queue=True, wait=(0.001, 0.003))))
+
+
+def test_file_queue_shared_by_processes(tmp_path):
+    """utils.FileQueue (utils.py:113-177): a list, a text file read once, and the text
+    file as a queue that three processes empty together -- every line goes to exactly
+    one of them, the file is left empty (the rename-lock protocol of the reference, so
+    its CPU workers and this build's GPU processes can share one queue file)"""
+    import multiprocessing as mp
+    from rvspecfit_amd import utils
+    names = ['coadd-%03d.fits' % i for i in range(60)]
+    q = str(tmp_path / 'queue.txt')
+    with open(q, 'w') as fp:
+        fp.write(''.join(n + '\n' for n in names))
+    assert list(utils.FileQueue(file_list=names[:3])) == names[:3]
+    once = utils.FileQueue(file_from=q)
+    assert not once.shared and list(once) == names
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_take_all, args=(q, out)) for _ in range(3)]
+    for p_ in procs:
+        p_.start()
+    got = [out.get(timeout=120) for _ in procs]
+    for p_ in procs:
+        p_.join()
+    assert sorted(sum(got, [])) == names
+    assert open(q).read() == ''
+    fq = utils.FileQueue(file_from=q, queue=True)
+    assert fq.shared and list(fq) == []
+    with pytest.raises(ValueError):
+        utils.FileQueue()

@@ -344,6 +344,20 @@ def test_command_line_runs_the_file_loop(dcases, desi_libs, tmp_path):
                 np.array_equal(a, b, equal_nan=True), c
         assert hd[0].header['RVS_CMD'] == ' '.join(argv)
         assert os.path.exists(str(tmp_path / 'out' / ('mod_coadd-m%d.fits' % i)))
+    # the same list as a shared queue file (--queue_file): emptied, same products
+    with open(lst, 'w') as fp:
+        fp.write('\n'.join(links) + '\n')
+    st2 = str(tmp_path / 'status2')
+    D.main(['--config', cfgf, '--input_file_from', lst, '--queue_file', '--output_dir',
+            str(tmp_path / 'outq'), '--minsn', '2', '--zbest_include', '--no_subdirs',
+            '--fitarm', 'B,R', '--npoly', '8', '--process_status_file', st2,
+            '--log_level', 'ERROR', '--files_per_batch', '2'])
+    assert open(lst).read() == ''
+    rows = [l.split() for l in open(st2).read().strip().split('\n')]
+    assert sorted(r[0] for r in rows) == sorted(links)
+    assert all(r[1] == 'SUCCESS' and int(r[2]) == n1 for r in rows), rows
+    tq = F.open(str(tmp_path / 'outq' / 'rvtab_coadd-m1.fits'))['RVTAB'].data
+    assert np.array_equal(tq['VRAD'], ts['VRAD'], equal_nan=True)
 
 
 def test_proc_many_two_fit_threads(dcases, desi_libs, tmp_path, monkeypatch):

@@ -1,6 +1,6 @@
 """Configuration helpers with the reference's keys and defaults
-(py/rvspecfit/utils.py:9-110).  Only what the hot path reads is kept: yaml ->
-defaults merge -> hashable frozen dict."""
+(py/rvspecfit/utils.py:9-110): yaml -> defaults merge -> hashable frozen dict; and the
+driver's file source, FileQueue (utils.py:113-177)."""
 import logging
 import os
 

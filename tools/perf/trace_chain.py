@@ -20,19 +20,25 @@ def main():
         rq = sorted((r for r in rows if r['Queue_Id'] == q and t0 <= r['s'] <= t1),
                     key=lambda r: r['s'])
         agg = defaultdict(lambda: [0, 0, 0])
+        durs = defaultdict(list)
         for a, b in zip(rq, rq[1:]):
             name = b['Kernel_Name'].split('(')[0].replace('void ', '')[:48]
             g = agg[name]
             g[0] += 1
             g[1] += b['e'] - b['s']
             g[2] += max(0, b['s'] - a['e'])
+            durs[name].append(b['e'] - b['s'])
         tot_d = sum(v[1] for v in agg.values())
         tot_g = sum(v[2] for v in agg.values())
         print('queue %s: %d kernels, busy %.3f s, idle in front of kernels %.3f s'
               % (q, len(rq), tot_d / 1e9, tot_g / 1e9))
         for name, (n, d, g) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:16]:
-            print('  %-48s %6d x  run %8.1f ms (%.1f us)  idle before %7.1f ms (%.1f us)'
-                  % (name, n, d / 1e6, d / n / 1e3, g / 1e6, g / n / 1e3))
+            v = sorted(durs[name])
+            print('  %-48s %6d x  run %8.1f ms (%.1f us; p10 %.1f p50 %.1f p90 %.1f)  '
+                  'idle before %7.1f ms (%.1f us)'
+                  % (name, n, d / 1e6, d / n / 1e3, v[len(v) // 10] / 1e3,
+                     v[len(v) // 2] / 1e3, v[(9 * len(v)) // 10] / 1e3, g / 1e6,
+                     g / n / 1e3))
 
 
 if __name__ == '__main__':
